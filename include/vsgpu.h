@@ -1,0 +1,218 @@
+/*
+ * vsgpu.h — C ABI of libvsgpu.so: the MI355X (gfx950) implementation of pgvectorscale's StreamingDiskANN
+ * *search* hot path (SBQ Hamming candidate scoring inside the greedy graph search + f32 rerank), i.e. the work
+ * done between `amrescan` and `amgettuple` of the `diskann` access method.
+ *
+ * Citations are relative to /root/reference/pgvectorscale/src/access_method/ ("AM/").
+ *
+ * The reference has NO FFI seam on this path (storages / distance functions are statically dispatched Rust,
+ * AM/storage.rs:41-142, AM/distance/mod.rs:8); its only C-ABI surface is the IndexAmRoutine filled in by
+ * `amhandler` (AM/mod.rs:27-92).  This header therefore declares what a PGRX shim would bind from inside those
+ * callbacks (the Rust `extern "C"` block is shown in INTEGRATION.md):
+ *
+ *   ambeginscan (AM/scan.rs:308-333) -> vs_beginscan        amrescan  (AM/scan.rs:335-367) -> vs_rescan
+ *   amgettuple  (AM/scan.rs:369-436) -> vs_gettuple         amendscan (AM/scan.rs:438-456) -> vs_endscan
+ *
+ * plus the batched entry points (many backends' queries at once; what a GPU broker process would call) and the
+ * individual kernels K1..K5 of SURVEY.md §2.
+ *
+ * Rules: plain C types only; every call returns 0 (VS_OK) or a negative vs_status and never throws / longjmps;
+ * vs_last_error() gives a thread-local message (the Rust side turns it into pgrx::error!); the caller owns every
+ * host buffer; the library owns device memory and pinned staging buffers; calls are synchronous unless their name
+ * ends in _async; one thread per vs_ctx at a time.  There is NO CPU fallback: without a HIP device every compute
+ * entry point fails with VS_ERR_HIP.
+ */
+#ifndef VSGPU_H
+#define VSGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VS_INVALID_NODE 0xFFFFFFFFu /* InvalidBlockNumber sentinel ending a neighbor list, AM/sbq/node.rs:260-285 */
+
+enum vs_distance_type { VS_COSINE = 0, VS_L2 = 1, VS_IP = 2 }; /* AM/distance/mod.rs:11-15 */
+
+enum vs_status {
+    VS_OK = 0,
+    VS_ERR_INVALID = -1,  /* bad argument / malformed index (e.g. duplicate ids inside one neighbor list) */
+    VS_ERR_HIP = -2,      /* HIP runtime error or no device */
+    VS_ERR_OOM = -3,      /* device or pinned-host allocation failed */
+    VS_ERR_CAPACITY = -4, /* a per-query search structure overflowed even after the automatic retries */
+    VS_ERR_STATE = -5     /* call sequence error (e.g. vs_gettuple before vs_rescan) */
+};
+
+typedef struct vs_ctx vs_ctx;     /* one HIP device + streams + staging buffers */
+typedef struct vs_index vs_index; /* one diskann index resident in HBM */
+typedef struct vs_scan vs_scan;   /* one IndexScanDesc's opaque state (TSVScanState, AM/scan.rs:40-89) */
+
+/* Index geometry = the MetaPage fields that parameterise the search (AM/meta_page.rs:179-210). */
+typedef struct vs_index_desc {
+    uint32_t n;             /* index nodes; node id = dense position (stands in for the ItemPointer)            */
+    uint32_t dim_full;      /* num_dimensions                                                                 */
+    uint32_t dim_index;     /* num_dimensions_to_index (<= dim_full)                                          */
+    uint32_t bits;          /* num_bits_per_dimension; default 2 if dim_index < 900 else 1 (:312-323)         */
+    uint32_t words;         /* W = ceil(dim_index*bits/64) u64 words per SBQ code (AM/sbq/quantize.rs:37-45) */
+    uint32_t num_neighbors; /* R (default 50, :284-294)                                                       */
+    uint32_t distance_type; /* vs_distance_type                                                               */
+    uint32_t has_labels;    /* MetaPage.has_labels                                                            */
+    uint32_t default_start; /* StartNodes.default_node or VS_INVALID_NODE for an empty graph                  */
+    uint32_t n_label_starts;/* entries of StartNodes.labeled_nodes (AM/graph/start_nodes.rs:17-22)            */
+} vs_index_desc;
+
+/* Host-side flat arrays an exporter produces from the index relation's pages (SbqNode items, AM/sbq/node.rs:26-42;
+ * SbqMeans chain, AM/sbq/mod.rs:62-121) and from the heap's vector column. */
+typedef struct vs_index_host {
+    const uint64_t* codes;     /* [n][words]            ArchivedSbqNode.bq_vector                             */
+    const uint32_t* nbrs;      /* [n][nbr_stride]       neighbor_index_pointers, list ends at VS_INVALID_NODE */
+    uint32_t nbr_stride;       /* row stride of `nbrs` in elements (>= num_neighbors)                         */
+    const uint64_t* heap_tids; /* [n] (block<<16)|offset; offset==0 (InvalidOffsetNumber) => deleted tuple    */
+    const float* vecs;         /* [n][dim_full] heap vectors (raw); NULL => no rerank possible (rescore must be 0) */
+    const float* mean;         /* [dim_index]           SbqMeans.means                                        */
+    const float* m2;           /* [dim_index]           SbqMeans.m2 (bits>1; may be NULL when bits==1)        */
+    uint64_t count;            /* SbqMeans.count                                                              */
+    const uint32_t* label_off; /* [n+1] CSR offsets into label_val (has_labels)                               */
+    const int16_t* label_val;  /* per-node sorted, de-duplicated label sets (AM/labels/mod.rs:15-37)          */
+    const int16_t* label_start_labels; /* [n_label_starts] sorted keys of StartNodes.labeled_nodes            */
+    const uint32_t* label_start_nodes; /* [n_label_starts] their start nodes                                  */
+} vs_index_host;
+
+/* GreedySearchStats + TSVResponseIterator counters (AM/stats.rs:68-125, AM/scan.rs:461-472), summed over the call */
+typedef struct vs_stats {
+    uint64_t queries;
+    uint64_t visited_nodes;                  /* "visits"       */
+    uint64_t candidate_nodes;                /* "candidate"    */
+    uint64_t quantized_distance_comparisons; /* "d_quantized"  */
+    uint64_t full_distance_comparisons;      /* "d_full"       */
+    uint64_t node_reads;                     /* "reads_index"  */
+    uint64_t node_heap_reads;                /* "reads_heap"   */
+    uint64_t next_calls;                     /* "next"         */
+    uint64_t retries;                        /* capacity-overflow relaunches (ours; 0 in steady state) */
+} vs_stats;
+
+const char* vs_last_error(void);
+const char* vs_version(void);
+
+/* ---- context ------------------------------------------------------------------------------------------------- */
+int vs_ctx_create(int device, vs_ctx** out);
+void vs_ctx_destroy(vs_ctx* ctx);
+int vs_ctx_sync(vs_ctx* ctx);          /* wait for the compute stream */
+void* vs_ctx_stream(vs_ctx* ctx);      /* the hipStream_t all kernels of this ctx are launched on */
+int vs_ctx_device_name(vs_ctx* ctx, char* buf, size_t len);
+int vs_ctx_mem_info(vs_ctx* ctx, uint64_t* free_bytes, uint64_t* total_bytes);
+
+/* raw device buffers (so callers can keep inputs resident in HBM across calls) */
+int vs_dev_alloc(vs_ctx* ctx, size_t bytes, void** out);
+int vs_dev_free(vs_ctx* ctx, void* p);
+int vs_dev_upload(vs_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);   /* pinned staging + hipMemcpyAsync */
+int vs_dev_download(vs_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+
+/* ---- index ---------------------------------------------------------------------------------------------------- */
+/* Stage host arrays chunk-wise through pinned buffers to HBM (hipMemcpyAsync, double-buffered) and validate them. */
+int vs_index_upload(vs_ctx* ctx, const vs_index_desc* desc, const vs_index_host* host, vs_index** out);
+/* Allocate an index whose arrays are produced on the device (vs_datagen_*, vs_sbq_train, vs_sbq_quantize_corpus,
+ * vs_build_graph); contents are undefined until filled. */
+int vs_index_alloc(vs_ctx* ctx, const vs_index_desc* desc, int with_vecs, vs_index** out);
+void vs_index_free(vs_index* idx);
+int vs_index_get_desc(const vs_index* idx, vs_index_desc* out);
+enum vs_array { VS_ARR_CODES = 0, VS_ARR_NBRS = 1, VS_ARR_TIDS = 2, VS_ARR_VECS = 3, VS_ARR_MEAN = 4, VS_ARR_M2 = 5,
+                VS_ARR_VNORM = 6, VS_ARR_LABEL_OFF = 7, VS_ARR_LABEL_VAL = 8 };
+/* device pointer + row stride (in elements) of one of the index arrays */
+int vs_index_array(const vs_index* idx, int which, void** dev_ptr, uint32_t* row_stride);
+int vs_index_set_quantizer(vs_index* idx, const float* mean, const float* m2, uint64_t count);
+int vs_index_set_start_nodes(vs_index* idx, uint32_t default_start, const int16_t* labels, const uint32_t* nodes, uint32_t n);
+int vs_index_set_labels(vs_index* idx, const uint32_t* label_off, const int16_t* label_val);
+int vs_index_get_quantizer(const vs_index* idx, float* mean, float* m2, uint64_t* count);
+/* copy index arrays back to host (tests / cpu_baseline leg); any pointer may be NULL */
+int vs_index_download(const vs_index* idx, uint64_t* codes, uint32_t* nbrs /*[n][num_neighbors]*/, uint64_t* heap_tids,
+                      float* vecs, uint32_t row_begin, uint32_t row_count);
+/* (re)compute the per-node cosine divisor cache from the vector column (exact preprocess_cosine semantics,
+ * AM/distance/mod.rs:225-253); called by upload automatically */
+int vs_index_refresh_norms(vs_index* idx);
+/* mark heap tuples deleted (what ambulkdelete does to heap_item_pointer, AM/vacuum.rs:24-78) */
+int vs_index_mark_deleted(vs_index* idx, const uint32_t* nodes, uint32_t n);
+
+/* ---- K4: SBQ quantisation of queries (SbqQuantizer::quantize, AM/sbq/quantize.rs:52-102) --------------------- */
+/* q: host [nq][dim_index], already cosine-normalised by the caller if applicable; out: host [nq][words] */
+int vs_quantize(vs_index* idx, const float* q, uint32_t nq, uint64_t* out_codes);
+
+/* ---- K1: XOR+popcount of query codes against gathered node codes (distance_xor_optimized, AM/distance/mod.rs:266-323)
+ * ids/off: CSR — query i is scored against ids[off[i] .. off[i+1]).  out: one u32 per id. */
+int vs_hamming_gather(vs_index* idx, const uint64_t* qcodes, const uint32_t* ids, const uint32_t* off, uint32_t nq,
+                      uint32_t* out);
+
+/* ---- K2: full-precision rerank distances (get_full_distance_for_resort, AM/sbq/storage.rs:304-328 with
+ * distance_l2 / distance_cosine / distance_inner_product in the reference's AVX2 accumulation order,
+ * AM/distance/mod.rs:325-435).  q_full: host [nq][dim_full] RAW queries (cosine-normalised inside, as
+ * PgVector::from_datum does, AM/pg_vector.rs:153-155). */
+int vs_rerank(vs_index* idx, const float* q_full, const uint32_t* ids, const uint32_t* off, uint32_t nq, float* out);
+
+/* ---- K5: flat scan — top-k of Hamming distance over ALL codes, order (hamming asc, node id asc) ------------- */
+int vs_scan_topk(vs_index* idx, const uint64_t* qcodes, uint32_t nq, uint32_t k, uint32_t* out_ids, uint32_t* out_ham);
+
+/* ---- K3 (+K2 + resort window): batched scans ------------------------------------------------------------------
+ * For each query: exactly the rows the reference returns from the first k amgettuple calls after amrescan
+ * (TSVResponseIterator::next_with_resort, AM/scan.rs:244-305) with GUCs diskann.query_search_list_size =
+ * search_list_size and diskann.query_rescore = rescore (AM/guc.rs:3-4).
+ *   queries   host [nq][dim_full] raw f32
+ *   qlabels / qlabel_off: CSR of the smallint[] scan keys, qlabel_off == NULL => no scan key on any query
+ *   out_ids   [nq][k] node ids (VS_INVALID_NODE past the end of a scan), out_tids [nq][k] heap TIDs (may be NULL),
+ *   out_dist  [nq][k] reranked f32 distance (NaN when rescore == 0) (may be NULL)                               */
+int vs_search_batch(vs_index* idx, const float* queries, const int16_t* qlabels, const uint32_t* qlabel_off, uint32_t nq,
+                    uint32_t search_list_size, uint32_t rescore, uint32_t k, uint32_t* out_ids, uint64_t* out_tids,
+                    float* out_dist, vs_stats* stats);
+/* the raw SBQ-ordered stream: first m results of TSVResponseIterator::next (AM/scan.rs:210-242) */
+int vs_stream_batch(vs_index* idx, const float* queries, const int16_t* qlabels, const uint32_t* qlabel_off, uint32_t nq,
+                    uint32_t search_list_size, uint32_t m, uint32_t* out_ids, uint32_t* out_ham, vs_stats* stats);
+/* device-resident variant: d_queries [nq][dim_full] and the outputs are device pointers (vs_dev_alloc); label keys
+ * must already be sorted + de-duplicated per query.  Enqueues on the ctx stream and returns; vs_ctx_sync() (or
+ * vs_search_batch_dev_finish for the stats / error check) completes it. */
+int vs_search_batch_dev(vs_index* idx, const float* d_queries, const int16_t* d_qlabels, const uint32_t* d_qlabel_off,
+                        uint32_t nq, uint32_t search_list_size, uint32_t rescore, uint32_t k, uint32_t* d_out_ids,
+                        uint64_t* d_out_tids, float* d_out_dist);
+int vs_search_batch_dev_finish(vs_index* idx, vs_stats* stats);
+
+/* ---- the amrescan / amgettuple mirror (one row at a time) ---------------------------------------------------- */
+int vs_beginscan(vs_index* idx, vs_scan** out);                                  /* ambeginscan */
+/* query == NULL is the SQL-NULL query (zero vector, labels ignored; AM/labels/mod.rs:214-216).
+ * has_label_key: nkeys == 1 (sets xs_recheck, AM/scan.rs:350-352); labels may be unsorted / contain duplicates. */
+int vs_rescan(vs_scan* scan, const float* query, const int16_t* labels, uint32_t n_labels, int has_label_key,
+              uint32_t search_list_size, uint32_t rescore);                       /* amrescan */
+/* returns 1 and fills the outputs for the next row, 0 at end of scan, <0 on error */
+int vs_gettuple(vs_scan* scan, uint64_t* heap_tid, uint32_t* node, float* dist); /* amgettuple */
+int vs_scan_xs_recheck(const vs_scan* scan);
+int vs_scan_get_stats(const vs_scan* scan, vs_stats* out);
+void vs_endscan(vs_scan* scan);                                                   /* amendscan */
+
+/* ---- build-side helpers (SURVEY.md §8f "next" rows; needed to manufacture device-resident indexes) ---------- */
+/* Welford pass over rows [0,n) in heap order, bit-exact to SbqQuantizer::add_sample (AM/sbq/quantize.rs:115-148):
+ * one lane per dimension, sequential over rows.  Uses the (cosine-normalised) first dim_index dims of the vectors. */
+int vs_sbq_train(vs_index* idx);
+/* codes[i] = quantize(normalised index slice of vecs[i]) for all nodes */
+int vs_sbq_quantize_corpus(vs_index* idx);
+/* Batched Vamana build over the SBQ codes (greedy search + robust prune with alpha ladder, Hamming distances),
+ * the GPU counterpart of Graph::insert / prune_neighbors (AM/graph/mod.rs:392-488,637-717). */
+int vs_build_graph(vs_index* idx, uint32_t search_list_size, double max_alpha, uint32_t batch_max, uint64_t seed);
+
+/* ---- synthetic corpora generated in HBM (bench / tests; bit-reproducible on the CPU, see pgvectorscale_amd/datagen.py) */
+typedef struct vs_datagen_params {
+    uint64_t seed;
+    uint32_t dim;          /* vector dimensionality                                   */
+    uint32_t latent_dim;   /* intrinsic dimensionality of the mixture                 */
+    uint32_t n_clusters;   /* mixture components                                      */
+    uint32_t intra_pct;    /* within-cluster latent spread, percent of between-cluster spread */
+    uint32_t noise_pct;    /* isotropic ambient noise, percent of signal scale        */
+    uint32_t normalize;    /* 1 => unit L2 norm                                       */
+} vs_datagen_params;
+/* fills d_out[row_begin .. row_begin+rows) (row stride = dim floats) with rows `first_row + i` of the stream */
+int vs_datagen_fill(vs_ctx* ctx, const vs_datagen_params* p, uint64_t first_row, uint64_t rows, float* d_out);
+/* exact brute-force f32 top-k on the device (ground truth for recall): d_queries [nq][dim_full] raw */
+int vs_bruteforce_topk(vs_index* idx, const float* d_queries, uint32_t nq, uint32_t k, uint32_t* out_ids, float* out_dist);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VSGPU_H */

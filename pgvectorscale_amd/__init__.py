@@ -1,0 +1,8 @@
+"""pgvectorscale_amd — MI355X (gfx950) implementation of pgvectorscale's StreamingDiskANN search hot path.
+
+The compute lives in libvsgpu.so (hand-written HIP kernels behind the C ABI of include/vsgpu.h); this package is
+the thin host-side mirror of the reference's scan interface (index.py) plus the synthetic corpus generator used by
+tests and bench (datagen.py).
+"""
+from ._lib import VS_COSINE, VS_INVALID_NODE, VS_IP, VS_L2, VsError, load  # noqa: F401
+from .index import Context, DiskAnnIndex, IndexScan  # noqa: F401

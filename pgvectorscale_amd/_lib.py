@@ -1,0 +1,122 @@
+"""ctypes binding of libvsgpu.so (include/vsgpu.h).  Product path: there is no CPU fallback — if the shared library
+is missing or no HIP device is present, calls raise VsError."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvsgpu.so")
+
+VS_INVALID_NODE = 0xFFFFFFFF
+VS_COSINE, VS_L2, VS_IP = 0, 1, 2
+ARR_CODES, ARR_NBRS, ARR_TIDS, ARR_VECS, ARR_MEAN, ARR_M2, ARR_VNORM, ARR_LABEL_OFF, ARR_LABEL_VAL = range(9)
+
+
+class VsError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libvsgpu error {code}: {msg}")
+        self.code = code
+
+
+class IndexDesc(C.Structure):
+    _fields_ = [(k, C.c_uint32) for k in ("n", "dim_full", "dim_index", "bits", "words", "num_neighbors",
+                                          "distance_type", "has_labels", "default_start", "n_label_starts")]
+
+
+class IndexHost(C.Structure):
+    _fields_ = [("codes", C.c_void_p), ("nbrs", C.c_void_p), ("nbr_stride", C.c_uint32), ("heap_tids", C.c_void_p),
+                ("vecs", C.c_void_p), ("mean", C.c_void_p), ("m2", C.c_void_p), ("count", C.c_uint64),
+                ("label_off", C.c_void_p), ("label_val", C.c_void_p), ("label_start_labels", C.c_void_p),
+                ("label_start_nodes", C.c_void_p)]
+
+
+class Stats(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in ("queries", "visited_nodes", "candidate_nodes",
+                                          "quantized_distance_comparisons", "full_distance_comparisons",
+                                          "node_reads", "node_heap_reads", "next_calls", "retries")]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+class DatagenParams(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("dim", C.c_uint32), ("latent_dim", C.c_uint32), ("n_clusters", C.c_uint32),
+                ("intra_pct", C.c_uint32), ("noise_pct", C.c_uint32), ("normalize", C.c_uint32)]
+
+
+# every symbol include/vsgpu.h declares: name -> (restype, argtypes)
+_vp, _u32, _u64, _i, _sz = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int, C.c_size_t
+SYMBOLS = {
+    "vs_last_error": (C.c_char_p, []),
+    "vs_version": (C.c_char_p, []),
+    "vs_ctx_create": (_i, [_i, C.POINTER(_vp)]),
+    "vs_ctx_destroy": (None, [_vp]),
+    "vs_ctx_sync": (_i, [_vp]),
+    "vs_ctx_stream": (_vp, [_vp]),
+    "vs_ctx_device_name": (_i, [_vp, C.c_char_p, _sz]),
+    "vs_ctx_mem_info": (_i, [_vp, C.POINTER(_u64), C.POINTER(_u64)]),
+    "vs_dev_alloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
+    "vs_dev_free": (_i, [_vp, _vp]),
+    "vs_dev_upload": (_i, [_vp, _vp, _vp, _sz]),
+    "vs_dev_download": (_i, [_vp, _vp, _vp, _sz]),
+    "vs_index_upload": (_i, [_vp, C.POINTER(IndexDesc), C.POINTER(IndexHost), C.POINTER(_vp)]),
+    "vs_index_alloc": (_i, [_vp, C.POINTER(IndexDesc), _i, C.POINTER(_vp)]),
+    "vs_index_free": (None, [_vp]),
+    "vs_index_get_desc": (_i, [_vp, C.POINTER(IndexDesc)]),
+    "vs_index_array": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_u32)]),
+    "vs_index_set_quantizer": (_i, [_vp, _vp, _vp, _u64]),
+    "vs_index_set_start_nodes": (_i, [_vp, _u32, _vp, _vp, _u32]),
+    "vs_index_set_labels": (_i, [_vp, _vp, _vp]),
+    "vs_index_get_quantizer": (_i, [_vp, _vp, _vp, C.POINTER(_u64)]),
+    "vs_index_download": (_i, [_vp, _vp, _vp, _vp, _vp, _u32, _u32]),
+    "vs_index_refresh_norms": (_i, [_vp]),
+    "vs_index_mark_deleted": (_i, [_vp, _vp, _u32]),
+    "vs_quantize": (_i, [_vp, _vp, _u32, _vp]),
+    "vs_hamming_gather": (_i, [_vp, _vp, _vp, _vp, _u32, _vp]),
+    "vs_rerank": (_i, [_vp, _vp, _vp, _vp, _u32, _vp]),
+    "vs_scan_topk": (_i, [_vp, _vp, _u32, _u32, _vp, _vp]),
+    "vs_search_batch": (_i, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp, C.POINTER(Stats)]),
+    "vs_stream_batch": (_i, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, C.POINTER(Stats)]),
+    "vs_search_batch_dev": (_i, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp]),
+    "vs_search_batch_dev_finish": (_i, [_vp, C.POINTER(Stats)]),
+    "vs_beginscan": (_i, [_vp, C.POINTER(_vp)]),
+    "vs_rescan": (_i, [_vp, _vp, _vp, _u32, _i, _u32, _u32]),
+    "vs_gettuple": (_i, [_vp, C.POINTER(_u64), C.POINTER(_u32), C.POINTER(C.c_float)]),
+    "vs_scan_xs_recheck": (_i, [_vp]),
+    "vs_scan_get_stats": (_i, [_vp, C.POINTER(Stats)]),
+    "vs_endscan": (None, [_vp]),
+    "vs_sbq_train": (_i, [_vp]),
+    "vs_sbq_quantize_corpus": (_i, [_vp]),
+    "vs_build_graph": (_i, [_vp, _u32, C.c_double, _u32, _u64]),
+    "vs_datagen_fill": (_i, [_vp, C.POINTER(DatagenParams), _u64, _u64, _vp]),
+    "vs_bruteforce_topk": (_i, [_vp, _vp, _u32, _u32, _vp, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libvsgpu.so. torch (if it is going to be used in this process) must be imported BEFORE this so both share
+    one HIP runtime (torch bundles its own libamdhip64 with the same SONAME)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VsError(-2, f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    try:
+        import torch  # noqa: F401  (pins the HIP runtime copy when torch is installed)
+    except Exception:  # pragma: no cover
+        pass
+    L = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        f = getattr(L, name)  # AttributeError if the ABI lost a symbol
+        f.restype = res
+        f.argtypes = args
+    _lib = L
+    return L
+
+
+def check(code):
+    if code < 0:
+        raise VsError(code, load().vs_last_error().decode("utf-8", "replace"))
+    return code

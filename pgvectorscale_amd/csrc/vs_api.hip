@@ -1,0 +1,911 @@
+// vs_api.hip — host side of libvsgpu.so: the C ABI declared in include/vsgpu.h.
+// Context / staging / index residency / batched search pipeline.  No CPU compute fallback anywhere: every compute
+// entry point needs a HIP device and fails with VS_ERR_HIP otherwise.
+#include <cstdarg>
+#include <cmath>
+#include <algorithm>
+
+#include "vs_internal.h"
+
+static thread_local char g_err[1024] = "";
+
+void vs_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* vs_last_error(void) { return g_err; }
+extern "C" const char* vs_version(void) { return "vsgpu 0.1 (gfx950)"; }
+
+int devbuf_reserve(vs_ctx* ctx, DevBuf& b, size_t bytes) {
+    (void)ctx;
+    if (bytes <= b.bytes) return VS_OK;
+    if (b.p) {
+        VS_HIP(hipFree(b.p));
+        b.p = nullptr;
+        b.bytes = 0;
+    }
+    size_t want = bytes + bytes / 8 + 256;
+    VS_HIP(hipMalloc(&b.p, want));
+    b.bytes = want;
+    return VS_OK;
+}
+void devbuf_free(DevBuf& b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.bytes = 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------------------------------
+static const size_t kPinnedBytes = 32u << 20;  // 2 x 32 MiB staging ring
+
+extern "C" int vs_ctx_create(int device, vs_ctx** out) {
+    VS_REQUIRE(out != nullptr, "vs_ctx_create: out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) {
+        vs_set_error("no HIP device available (%s); libvsgpu has no CPU fallback", hipGetErrorString(e));
+        return VS_ERR_HIP;
+    }
+    VS_REQUIRE(device >= 0 && device < ndev, "vs_ctx_create: device %d out of range [0,%d)", device, ndev);
+    VS_HIP(hipSetDevice(device));
+    vs_ctx* c = new vs_ctx();
+    c->device = device;
+    VS_HIP(hipGetDeviceProperties(&c->prop, device));
+    VS_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    VS_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    c->pinned_bytes = kPinnedBytes;
+    for (int i = 0; i < 2; ++i) {
+        VS_HIP(hipHostMalloc(&c->pinned[i], c->pinned_bytes, hipHostMallocDefault));
+        VS_HIP(hipEventCreateWithFlags(&c->pinned_ev[i], hipEventDisableTiming));
+    }
+    *out = c;
+    return VS_OK;
+}
+
+extern "C" void vs_ctx_destroy(vs_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipStreamSynchronize(c->copy_stream);
+    for (int i = 0; i < 2; ++i) {
+        if (c->pinned[i]) (void)hipHostFree(c->pinned[i]);
+        if (c->pinned_ev[i]) (void)hipEventDestroy(c->pinned_ev[i]);
+    }
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    delete c;
+}
+
+extern "C" int vs_ctx_sync(vs_ctx* c) {
+    VS_REQUIRE(c, "vs_ctx_sync: ctx is NULL");
+    VS_HIP(hipStreamSynchronize(c->stream));
+    return VS_OK;
+}
+extern "C" void* vs_ctx_stream(vs_ctx* c) { return c ? (void*)c->stream : nullptr; }
+extern "C" int vs_ctx_device_name(vs_ctx* c, char* buf, size_t len) {
+    VS_REQUIRE(c && buf && len, "vs_ctx_device_name: bad args");
+    snprintf(buf, len, "%s (%s, %d CUs)", c->prop.name, c->prop.gcnArchName, c->prop.multiProcessorCount);
+    return VS_OK;
+}
+extern "C" int vs_ctx_mem_info(vs_ctx* c, uint64_t* free_b, uint64_t* total_b) {
+    VS_REQUIRE(c, "vs_ctx_mem_info: ctx is NULL");
+    size_t f = 0, t = 0;
+    VS_HIP(hipMemGetInfo(&f, &t));
+    if (free_b) *free_b = f;
+    if (total_b) *total_b = t;
+    return VS_OK;
+}
+
+extern "C" int vs_dev_alloc(vs_ctx* c, size_t bytes, void** out) {
+    VS_REQUIRE(c && out, "vs_dev_alloc: bad args");
+    VS_HIP(hipSetDevice(c->device));
+    VS_HIP(hipMalloc(out, bytes ? bytes : 16));
+    return VS_OK;
+}
+extern "C" int vs_dev_free(vs_ctx* c, void* p) {
+    VS_REQUIRE(c, "vs_dev_free: ctx is NULL");
+    if (p) VS_HIP(hipFree(p));
+    return VS_OK;
+}
+
+// Host -> HBM through the pinned ring: memcpy into pinned buffer i while buffer 1-i is in flight (hipMemcpyAsync on
+// the copy stream).  The final event is waited on by the compute stream so kernels see the data.
+extern "C" int vs_dev_upload(vs_ctx* c, void* dst, const void* src, size_t bytes) {
+    VS_REQUIRE(c && (bytes == 0 || (dst && src)), "vs_dev_upload: bad args");
+    const char* s = static_cast<const char*>(src);
+    char* d = static_cast<char*>(dst);
+    int slot = 0;
+    size_t off = 0;
+    while (off < bytes) {
+        size_t n = std::min(c->pinned_bytes, bytes - off);
+        VS_HIP(hipEventSynchronize(c->pinned_ev[slot]));  // buffer free again?
+        memcpy(c->pinned[slot], s + off, n);
+        VS_HIP(hipMemcpyAsync(d + off, c->pinned[slot], n, hipMemcpyHostToDevice, c->copy_stream));
+        VS_HIP(hipEventRecord(c->pinned_ev[slot], c->copy_stream));
+        off += n;
+        slot ^= 1;
+    }
+    VS_HIP(hipStreamSynchronize(c->copy_stream));
+    return VS_OK;
+}
+
+extern "C" int vs_dev_download(vs_ctx* c, void* dst, const void* src, size_t bytes) {
+    VS_REQUIRE(c && (bytes == 0 || (dst && src)), "vs_dev_download: bad args");
+    VS_HIP(hipStreamSynchronize(c->stream));
+    char* d = static_cast<char*>(dst);
+    const char* s = static_cast<const char*>(src);
+    size_t off = 0;
+    int slot = 0;
+    size_t pend_off[2] = {0, 0}, pend_n[2] = {0, 0};
+    while (off < bytes || pend_n[0] || pend_n[1]) {
+        if (pend_n[slot]) {  // drain the older transfer in this slot
+            VS_HIP(hipEventSynchronize(c->pinned_ev[slot]));
+            memcpy(d + pend_off[slot], c->pinned[slot], pend_n[slot]);
+            pend_n[slot] = 0;
+        }
+        if (off < bytes) {
+            size_t n = std::min(c->pinned_bytes, bytes - off);
+            VS_HIP(hipMemcpyAsync(c->pinned[slot], s + off, n, hipMemcpyDeviceToHost, c->copy_stream));
+            VS_HIP(hipEventRecord(c->pinned_ev[slot], c->copy_stream));
+            pend_off[slot] = off;
+            pend_n[slot] = n;
+            off += n;
+        }
+        slot ^= 1;
+    }
+    return VS_OK;
+}
+
+// strided upload: host rows of `row_bytes` into device rows of `dev_row_bytes` (zero padded)
+static int upload_rows(vs_ctx* c, void* dst, size_t dev_row_bytes, const void* src, size_t host_row_bytes,
+                       size_t copy_bytes, size_t rows) {
+    if (rows == 0) return VS_OK;
+    if (dev_row_bytes == host_row_bytes && copy_bytes == host_row_bytes)
+        return vs_dev_upload(c, dst, src, rows * host_row_bytes);
+    const size_t rows_per_chunk = std::max<size_t>(1, c->pinned_bytes / dev_row_bytes);
+    int slot = 0;
+    for (size_t r0 = 0; r0 < rows; r0 += rows_per_chunk) {
+        size_t nr = std::min(rows_per_chunk, rows - r0);
+        VS_HIP(hipEventSynchronize(c->pinned_ev[slot]));
+        char* p = static_cast<char*>(c->pinned[slot]);
+        memset(p, 0, nr * dev_row_bytes);
+        for (size_t r = 0; r < nr; ++r)
+            memcpy(p + r * dev_row_bytes, static_cast<const char*>(src) + (r0 + r) * host_row_bytes, copy_bytes);
+        VS_HIP(hipMemcpyAsync(static_cast<char*>(dst) + r0 * dev_row_bytes, p, nr * dev_row_bytes,
+                              hipMemcpyHostToDevice, c->copy_stream));
+        VS_HIP(hipEventRecord(c->pinned_ev[slot], c->copy_stream));
+        slot ^= 1;
+    }
+    VS_HIP(hipStreamSynchronize(c->copy_stream));
+    return VS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// index
+// ---------------------------------------------------------------------------------------------------------------
+static int check_desc(const vs_index_desc* d) {
+    VS_REQUIRE(d, "index desc is NULL");
+    VS_REQUIRE(d->dim_full >= 1 && d->dim_index >= 1 && d->dim_index <= d->dim_full, "bad dimensions %u/%u",
+               d->dim_index, d->dim_full);
+    VS_REQUIRE(d->bits >= 1 && d->bits <= 8, "num_bits_per_dimension %u unsupported", d->bits);
+    uint64_t nbits = (uint64_t)d->dim_index * d->bits;
+    VS_REQUIRE(d->words == (nbits + 63) / 64, "words=%u does not match ceil(dim_index*bits/64)=%llu", d->words,
+               (unsigned long long)((nbits + 63) / 64));
+    VS_REQUIRE(nbits <= 65535, "dim_index*bits = %llu exceeds the 16-bit Hamming field of the candidate heap",
+               (unsigned long long)nbits);
+    VS_REQUIRE(d->num_neighbors >= 1 && d->num_neighbors <= 1024, "num_neighbors %u unsupported", d->num_neighbors);
+    VS_REQUIRE(d->distance_type <= VS_IP, "unknown distance type %u", d->distance_type);
+    VS_REQUIRE(d->default_start == VS_INVALID_NODE || d->default_start < d->n, "default_start out of range");
+    return VS_OK;
+}
+
+static int index_alloc_common(vs_ctx* c, const vs_index_desc* desc, bool with_vecs, vs_index** out) {
+    VS_REQUIRE(c && out, "index alloc: bad args");
+    VS_TRY(check_desc(desc));
+    VS_HIP(hipSetDevice(c->device));
+    vs_index* ix = new vs_index();
+    ix->ctx = c;
+    ix->d = *desc;
+    ix->code_stride = round_up_u32(desc->words, 2);
+    ix->nbr_stride = round_up_u32(desc->num_neighbors, 16);
+    ix->vec_stride = round_up_u32(desc->dim_full, 4);
+    const size_t n = std::max<uint32_t>(desc->n, 1);
+    VS_HIP(hipMalloc(&ix->codes, n * ix->code_stride * sizeof(uint64_t)));
+    VS_HIP(hipMalloc(&ix->nbrs, n * ix->nbr_stride * sizeof(uint32_t)));
+    VS_HIP(hipMalloc(&ix->tids, n * sizeof(uint64_t)));
+    VS_HIP(hipMalloc(&ix->mean, desc->dim_index * sizeof(float)));
+    VS_HIP(hipMalloc(&ix->m2, desc->dim_index * sizeof(float)));
+    VS_HIP(hipMemsetAsync(ix->m2, 0, desc->dim_index * sizeof(float), c->stream));
+    VS_HIP(hipMemsetAsync(ix->mean, 0, desc->dim_index * sizeof(float), c->stream));
+    if (with_vecs) {
+        VS_HIP(hipMalloc(&ix->vecs, n * ix->vec_stride * sizeof(float)));
+        VS_HIP(hipMalloc(&ix->vnorm, n * sizeof(float)));
+        VS_HIP(hipMemsetAsync(ix->vnorm, 0, n * sizeof(float), c->stream));
+    }
+    *out = ix;
+    return VS_OK;
+}
+
+extern "C" void vs_index_free(vs_index* ix) {
+    if (!ix) return;
+    (void)hipSetDevice(ix->ctx->device);
+    (void)hipStreamSynchronize(ix->ctx->stream);
+    void* ptrs[] = {ix->codes, ix->nbrs, ix->tids, ix->vecs, ix->vnorm, ix->mean, ix->m2,
+                    ix->label_off, ix->label_val, ix->ls_labels, ix->ls_nodes};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    SearchWorkspace& w = ix->ws;
+    DevBuf* bufs[] = {&w.q_full, &w.qcodes, &w.qlabels, &w.qlabel_off, &w.hash, &w.cand_ids, &w.stream_ids,
+                      &w.stream_ham, &w.stream_cnt, &w.stats, &w.status, &w.rr_dist, &w.out_ids, &w.out_tids,
+                      &w.out_dist, &w.resort_heap, &w.raw_q, &w.misc};
+    for (DevBuf* b : bufs) devbuf_free(*b);
+    delete ix;
+}
+
+extern "C" int vs_index_alloc(vs_ctx* c, const vs_index_desc* desc, int with_vecs, vs_index** out) {
+    VS_TRY(index_alloc_common(c, desc, with_vecs != 0, out));
+    vs_index* ix = *out;
+    // empty graph, live tuples with tid = (node<<16)|1 until told otherwise
+    VS_HIP(hipMemsetAsync(ix->nbrs, 0xFF, (size_t)std::max<uint32_t>(desc->n, 1) * ix->nbr_stride * 4, c->stream));
+    VS_HIP(hipMemsetAsync(ix->codes, 0, (size_t)std::max<uint32_t>(desc->n, 1) * ix->code_stride * 8, c->stream));
+    std::vector<uint64_t> t(desc->n);
+    for (uint32_t i = 0; i < desc->n; ++i) t[i] = ((uint64_t)i << 16) | 1u;
+    VS_TRY(vs_dev_upload(c, ix->tids, t.data(), t.size() * 8));
+    VS_HIP(hipStreamSynchronize(c->stream));
+    return VS_OK;
+}
+
+extern "C" int vs_index_set_quantizer(vs_index* ix, const float* mean, const float* m2, uint64_t count) {
+    VS_REQUIRE(ix && mean, "vs_index_set_quantizer: bad args");
+    VS_REQUIRE(ix->d.bits == 1 || m2 != nullptr, "m2 is required when num_bits_per_dimension > 1");
+    VS_TRY(vs_dev_upload(ix->ctx, ix->mean, mean, ix->d.dim_index * sizeof(float)));
+    if (m2) VS_TRY(vs_dev_upload(ix->ctx, ix->m2, m2, ix->d.dim_index * sizeof(float)));
+    ix->count = count;
+    return VS_OK;
+}
+
+extern "C" int vs_index_get_quantizer(const vs_index* ix, float* mean, float* m2, uint64_t* count) {
+    VS_REQUIRE(ix, "vs_index_get_quantizer: index is NULL");
+    if (mean) VS_TRY(vs_dev_download(ix->ctx, mean, ix->mean, ix->d.dim_index * sizeof(float)));
+    if (m2) VS_TRY(vs_dev_download(ix->ctx, m2, ix->m2, ix->d.dim_index * sizeof(float)));
+    if (count) *count = ix->count;
+    return VS_OK;
+}
+
+extern "C" int vs_index_set_start_nodes(vs_index* ix, uint32_t default_start, const int16_t* labels,
+                                        const uint32_t* nodes, uint32_t n) {
+    VS_REQUIRE(ix, "vs_index_set_start_nodes: index is NULL");
+    VS_REQUIRE(default_start == VS_INVALID_NODE || default_start < ix->d.n, "default_start out of range");
+    for (uint32_t i = 0; i < n; ++i) {
+        VS_REQUIRE(nodes[i] < ix->d.n, "label start node out of range");
+        VS_REQUIRE(i == 0 || labels[i - 1] < labels[i], "label start map must be sorted by label, unique");
+    }
+    ix->d.default_start = default_start;
+    if (ix->ls_labels) VS_HIP(hipFree(ix->ls_labels));
+    if (ix->ls_nodes) VS_HIP(hipFree(ix->ls_nodes));
+    ix->ls_labels = nullptr;
+    ix->ls_nodes = nullptr;
+    ix->d.n_label_starts = n;
+    if (n) {
+        VS_HIP(hipMalloc(&ix->ls_labels, n * sizeof(int16_t)));
+        VS_HIP(hipMalloc(&ix->ls_nodes, n * sizeof(uint32_t)));
+        VS_TRY(vs_dev_upload(ix->ctx, ix->ls_labels, labels, n * sizeof(int16_t)));
+        VS_TRY(vs_dev_upload(ix->ctx, ix->ls_nodes, nodes, n * sizeof(uint32_t)));
+    }
+    return VS_OK;
+}
+
+extern "C" int vs_index_set_labels(vs_index* ix, const uint32_t* label_off, const int16_t* label_val) {
+    VS_REQUIRE(ix && label_off, "vs_index_set_labels: bad args");
+    const uint32_t n = ix->d.n;
+    VS_REQUIRE(label_off[0] == 0, "label_off[0] must be 0");
+    for (uint32_t i = 0; i < n; ++i) {
+        VS_REQUIRE(label_off[i] <= label_off[i + 1], "label_off must be non-decreasing");
+        for (uint32_t j = label_off[i] + 1; j < label_off[i + 1]; ++j)
+            VS_REQUIRE(label_val[j - 1] < label_val[j], "node %u: label set must be sorted and de-duplicated", i);
+    }
+    if (ix->label_off) VS_HIP(hipFree(ix->label_off));
+    if (ix->label_val) VS_HIP(hipFree(ix->label_val));
+    ix->n_label_vals = label_off[n];
+    VS_HIP(hipMalloc(&ix->label_off, ((size_t)n + 1) * 4));
+    VS_HIP(hipMalloc(&ix->label_val, std::max<uint64_t>(ix->n_label_vals, 1) * 2));
+    VS_TRY(vs_dev_upload(ix->ctx, ix->label_off, label_off, ((size_t)n + 1) * 4));
+    if (ix->n_label_vals) VS_TRY(vs_dev_upload(ix->ctx, ix->label_val, label_val, ix->n_label_vals * 2));
+    ix->d.has_labels = 1;
+    return VS_OK;
+}
+
+extern "C" int vs_index_refresh_norms(vs_index* ix) {
+    VS_REQUIRE(ix, "vs_index_refresh_norms: index is NULL");
+    VS_TRY(launch_row_norms(ix));
+    VS_HIP(hipStreamSynchronize(ix->ctx->stream));
+    return VS_OK;
+}
+
+static int validate_graph(vs_index* ix) {
+    uint32_t* d_flag = nullptr;
+    VS_HIP(hipMalloc(&d_flag, 4));
+    VS_HIP(hipMemsetAsync(d_flag, 0, 4, ix->ctx->stream));
+    int r = launch_validate_nbrs(ix, d_flag);
+    uint32_t flag = 0;
+    if (r == VS_OK) {
+        hipError_t e = hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, ix->ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ix->ctx->stream);
+        if (e != hipSuccess) {
+            vs_set_error("validate_graph: %s", hipGetErrorString(e));
+            r = VS_ERR_HIP;
+        }
+    }
+    (void)hipFree(d_flag);
+    VS_TRY(r);
+    VS_REQUIRE(!(flag & 2u), "neighbor list refers to a node id >= n");
+    VS_REQUIRE(!(flag & 1u), "a neighbor list contains the same node twice");
+    return VS_OK;
+}
+
+extern "C" int vs_index_upload(vs_ctx* c, const vs_index_desc* desc, const vs_index_host* h, vs_index** out) {
+    VS_REQUIRE(h && out, "vs_index_upload: bad args");
+    VS_REQUIRE(h->codes && h->nbrs && h->heap_tids && h->mean, "vs_index_upload: codes/nbrs/heap_tids/mean required");
+    VS_REQUIRE(h->nbr_stride >= desc->num_neighbors, "nbr_stride < num_neighbors");
+    VS_REQUIRE(!desc->has_labels || (h->label_off && h->label_val), "has_labels set but no label arrays");
+    vs_index* ix = nullptr;
+    VS_TRY(index_alloc_common(c, desc, h->vecs != nullptr, &ix));
+    int r = VS_OK;
+    const size_t n = desc->n;
+    do {
+        if ((r = upload_rows(c, ix->codes, ix->code_stride * 8ull, h->codes, desc->words * 8ull, desc->words * 8ull, n))) break;
+        // neighbor rows: copy R ids, pad the device row with the end-of-list sentinel
+        {
+            std::vector<uint32_t> row_buf;
+            const size_t rows_per_chunk = std::max<size_t>(1, (8u << 20) / (ix->nbr_stride * 4));
+            row_buf.resize(rows_per_chunk * ix->nbr_stride);
+            for (size_t r0 = 0; r0 < n && r == VS_OK; r0 += rows_per_chunk) {
+                size_t nr = std::min(rows_per_chunk, n - r0);
+                std::fill(row_buf.begin(), row_buf.begin() + nr * ix->nbr_stride, VS_INVALID_NODE);
+                for (size_t i = 0; i < nr; ++i)
+                    memcpy(&row_buf[i * ix->nbr_stride], h->nbrs + (r0 + i) * h->nbr_stride, desc->num_neighbors * 4ull);
+                r = vs_dev_upload(c, ix->nbrs + r0 * ix->nbr_stride, row_buf.data(), nr * ix->nbr_stride * 4ull);
+            }
+            if (r) break;
+        }
+        if ((r = vs_dev_upload(c, ix->tids, h->heap_tids, n * 8))) break;
+        if (h->vecs)
+            if ((r = upload_rows(c, ix->vecs, ix->vec_stride * 4ull, h->vecs, desc->dim_full * 4ull, desc->dim_full * 4ull, n))) break;
+        if ((r = vs_index_set_quantizer(ix, h->mean, h->m2, h->count))) break;
+        if (desc->has_labels)
+            if ((r = vs_index_set_labels(ix, h->label_off, h->label_val))) break;
+        if ((r = vs_index_set_start_nodes(ix, desc->default_start, h->label_start_labels, h->label_start_nodes,
+                                          desc->n_label_starts))) break;
+        if ((r = validate_graph(ix))) break;
+        if ((r = vs_index_refresh_norms(ix))) break;
+    } while (0);
+    if (r != VS_OK) {
+        vs_index_free(ix);
+        return r;
+    }
+    *out = ix;
+    return VS_OK;
+}
+
+extern "C" int vs_index_get_desc(const vs_index* ix, vs_index_desc* out) {
+    VS_REQUIRE(ix && out, "vs_index_get_desc: bad args");
+    *out = ix->d;
+    return VS_OK;
+}
+
+extern "C" int vs_index_array(const vs_index* ix, int which, void** p, uint32_t* stride) {
+    VS_REQUIRE(ix && p, "vs_index_array: bad args");
+    uint32_t s = 1;
+    switch (which) {
+        case VS_ARR_CODES: *p = ix->codes; s = ix->code_stride; break;
+        case VS_ARR_NBRS: *p = ix->nbrs; s = ix->nbr_stride; break;
+        case VS_ARR_TIDS: *p = ix->tids; break;
+        case VS_ARR_VECS: *p = ix->vecs; s = ix->vec_stride; break;
+        case VS_ARR_MEAN: *p = ix->mean; break;
+        case VS_ARR_M2: *p = ix->m2; break;
+        case VS_ARR_VNORM: *p = ix->vnorm; break;
+        case VS_ARR_LABEL_OFF: *p = ix->label_off; break;
+        case VS_ARR_LABEL_VAL: *p = ix->label_val; break;
+        default: vs_set_error("vs_index_array: unknown array %d", which); return VS_ERR_INVALID;
+    }
+    if (stride) *stride = s;
+    return VS_OK;
+}
+
+extern "C" int vs_index_download(const vs_index* ix, uint64_t* codes, uint32_t* nbrs, uint64_t* heap_tids, float* vecs,
+                                 uint32_t row_begin, uint32_t row_count) {
+    VS_REQUIRE(ix, "vs_index_download: index is NULL");
+    VS_REQUIRE((uint64_t)row_begin + row_count <= ix->d.n, "vs_index_download: row range out of bounds");
+    vs_ctx* c = ix->ctx;
+    VS_HIP(hipStreamSynchronize(c->stream));
+    const size_t nr = row_count;
+    if (codes)
+        VS_HIP(hipMemcpy2D(codes, ix->d.words * 8ull, ix->codes + (size_t)row_begin * ix->code_stride,
+                           ix->code_stride * 8ull, ix->d.words * 8ull, nr, hipMemcpyDeviceToHost));
+    if (nbrs)
+        VS_HIP(hipMemcpy2D(nbrs, ix->d.num_neighbors * 4ull, ix->nbrs + (size_t)row_begin * ix->nbr_stride,
+                           ix->nbr_stride * 4ull, ix->d.num_neighbors * 4ull, nr, hipMemcpyDeviceToHost));
+    if (heap_tids) VS_HIP(hipMemcpy(heap_tids, ix->tids + row_begin, nr * 8, hipMemcpyDeviceToHost));
+    if (vecs) {
+        VS_REQUIRE(ix->vecs, "index has no vector column");
+        VS_HIP(hipMemcpy2D(vecs, ix->d.dim_full * 4ull, ix->vecs + (size_t)row_begin * ix->vec_stride,
+                           ix->vec_stride * 4ull, ix->d.dim_full * 4ull, nr, hipMemcpyDeviceToHost));
+    }
+    return VS_OK;
+}
+
+extern "C" int vs_index_mark_deleted(vs_index* ix, const uint32_t* nodes, uint32_t n) {
+    VS_REQUIRE(ix && (n == 0 || nodes), "vs_index_mark_deleted: bad args");
+    VS_HIP(hipStreamSynchronize(ix->ctx->stream));
+    for (uint32_t i = 0; i < n; ++i) {
+        VS_REQUIRE(nodes[i] < ix->d.n, "node id out of range");
+        uint64_t t = 0;
+        VS_HIP(hipMemcpy(&t, ix->tids + nodes[i], 8, hipMemcpyDeviceToHost));
+        t &= ~0xFFFFull;  // heap_item_pointer.offset = InvalidOffsetNumber
+        VS_HIP(hipMemcpy(ix->tids + nodes[i], &t, 8, hipMemcpyHostToDevice));
+    }
+    return VS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// single-kernel entry points (host pointers in/out)
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" int vs_quantize(vs_index* ix, const float* q, uint32_t nq, uint64_t* out_codes) {
+    VS_REQUIRE(ix && (nq == 0 || (q && out_codes)), "vs_quantize: bad args");
+    if (nq == 0) return VS_OK;
+    vs_ctx* c = ix->ctx;
+    SearchWorkspace& w = ix->ws;
+    const uint32_t di = ix->d.dim_index;
+    VS_TRY(devbuf_reserve(c, w.raw_q, (size_t)nq * di * 4));
+    VS_TRY(devbuf_reserve(c, w.qcodes, (size_t)nq * ix->code_stride * 8));
+    VS_TRY(vs_dev_upload(c, w.raw_q.p, q, (size_t)nq * di * 4));
+    VS_TRY(launch_quantize_rows(ix, (const float*)w.raw_q.p, di, nq, (uint64_t*)w.qcodes.p, ix->code_stride));
+    VS_HIP(hipStreamSynchronize(c->stream));
+    VS_HIP(hipMemcpy2D(out_codes, ix->d.words * 8ull, w.qcodes.p, ix->code_stride * 8ull, ix->d.words * 8ull, nq,
+                       hipMemcpyDeviceToHost));
+    return VS_OK;
+}
+
+static int upload_qcodes(vs_index* ix, const uint64_t* qcodes, uint32_t nq) {
+    SearchWorkspace& w = ix->ws;
+    VS_TRY(devbuf_reserve(ix->ctx, w.qcodes, (size_t)nq * ix->code_stride * 8));
+    return upload_rows(ix->ctx, w.qcodes.p, ix->code_stride * 8ull, qcodes, ix->d.words * 8ull, ix->d.words * 8ull, nq);
+}
+
+extern "C" int vs_hamming_gather(vs_index* ix, const uint64_t* qcodes, const uint32_t* ids, const uint32_t* off,
+                                 uint32_t nq, uint32_t* out) {
+    VS_REQUIRE(ix && (nq == 0 || (qcodes && off)), "vs_hamming_gather: bad args");
+    if (nq == 0) return VS_OK;
+    VS_REQUIRE(off[0] == 0, "off[0] must be 0");
+    const uint32_t total = off[nq];
+    for (uint32_t i = 0; i < nq; ++i) VS_REQUIRE(off[i] <= off[i + 1], "off must be non-decreasing");
+    for (uint32_t i = 0; i < total; ++i) VS_REQUIRE(ids[i] < ix->d.n, "node id %u out of range", ids[i]);
+    vs_ctx* c = ix->ctx;
+    SearchWorkspace& w = ix->ws;
+    VS_TRY(upload_qcodes(ix, qcodes, nq));
+    VS_TRY(devbuf_reserve(c, w.stream_ids, std::max<size_t>(total, 1) * 4));
+    VS_TRY(devbuf_reserve(c, w.stream_ham, std::max<size_t>(total, 1) * 4));
+    VS_TRY(devbuf_reserve(c, w.qlabel_off, ((size_t)nq + 1) * 4));
+    VS_TRY(vs_dev_upload(c, w.stream_ids.p, ids, (size_t)total * 4));
+    VS_TRY(vs_dev_upload(c, w.qlabel_off.p, off, ((size_t)nq + 1) * 4));
+    VS_TRY(launch_hamming_gather(ix, (const uint64_t*)w.qcodes.p, (const uint32_t*)w.stream_ids.p,
+                                 (const uint32_t*)w.qlabel_off.p, nq, (uint32_t*)w.stream_ham.p));
+    VS_TRY(vs_dev_download(c, out, w.stream_ham.p, (size_t)total * 4));
+    return VS_OK;
+}
+
+extern "C" int vs_rerank(vs_index* ix, const float* q_full, const uint32_t* ids, const uint32_t* off, uint32_t nq,
+                         float* out) {
+    VS_REQUIRE(ix && (nq == 0 || (q_full && off)), "vs_rerank: bad args");
+    if (nq == 0) return VS_OK;
+    VS_REQUIRE(ix->vecs, "index has no vector column: rerank impossible");
+    VS_REQUIRE(off[0] == 0, "off[0] must be 0");
+    const uint32_t total = off[nq];
+    for (uint32_t i = 0; i < nq; ++i) VS_REQUIRE(off[i] <= off[i + 1], "off must be non-decreasing");
+    for (uint32_t i = 0; i < total; ++i) VS_REQUIRE(ids[i] < ix->d.n, "node id %u out of range", ids[i]);
+    vs_ctx* c = ix->ctx;
+    SearchWorkspace& w = ix->ws;
+    VS_TRY(devbuf_reserve(c, w.raw_q, (size_t)nq * ix->d.dim_full * 4));
+    VS_TRY(devbuf_reserve(c, w.q_full, (size_t)nq * ix->vec_stride * 4));
+    VS_TRY(devbuf_reserve(c, w.qcodes, (size_t)nq * ix->code_stride * 8));
+    VS_TRY(devbuf_reserve(c, w.stream_ids, std::max<size_t>(total, 1) * 4));
+    VS_TRY(devbuf_reserve(c, w.rr_dist, std::max<size_t>(total, 1) * 4));
+    VS_TRY(devbuf_reserve(c, w.qlabel_off, ((size_t)nq + 1) * 4));
+    VS_TRY(vs_dev_upload(c, w.raw_q.p, q_full, (size_t)nq * ix->d.dim_full * 4));
+    VS_TRY(vs_dev_upload(c, w.stream_ids.p, ids, (size_t)total * 4));
+    VS_TRY(vs_dev_upload(c, w.qlabel_off.p, off, ((size_t)nq + 1) * 4));
+    VS_TRY(launch_prepare_queries(ix, (const float*)w.raw_q.p, nq, (float*)w.q_full.p, (uint64_t*)w.qcodes.p));
+    VS_TRY(launch_rerank(ix, (const float*)w.q_full.p, (const uint32_t*)w.stream_ids.p, (const uint32_t*)w.qlabel_off.p,
+                         nullptr, 0, nq, (float*)w.rr_dist.p));
+    VS_TRY(vs_dev_download(c, out, w.rr_dist.p, (size_t)total * 4));
+    return VS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// batched scans
+// ---------------------------------------------------------------------------------------------------------------
+struct Caps {
+    uint32_t hcap, vcap, hashcap, idcap;
+};
+
+static Caps initial_caps(const vs_index* ix, uint32_t L, uint32_t M) {
+    // visits ~ 1.3-2 L before the first row + one per further row; each visit pushes <= R candidates, in practice
+    // about half of them are new.  Anything that overflows is retried with doubled capacities.
+    uint64_t visits = 2ull * L + M + 32;
+    uint64_t pushes = visits * ix->d.num_neighbors;
+    uint64_t h = std::max<uint64_t>(1024, pushes * 6 / 10);
+    Caps c;
+    c.idcap = (uint32_t)std::min<uint64_t>(65536, round_up_u32((uint32_t)std::min<uint64_t>(h, 65536), 64));
+    c.hcap = c.idcap;
+    c.vcap = (uint32_t)std::min<uint64_t>(3ull * L + M + 64, 1u << 20);
+    c.hashcap = next_pow2_u32(2ull * c.idcap);
+    return c;
+}
+
+static bool grow_caps(Caps& c, uint32_t ovf) {
+    bool grew = false;
+    if (ovf & (OVF_HEAP | OVF_IDS)) {
+        if (c.idcap < 65536) {
+            c.idcap = std::min<uint32_t>(65536, c.idcap * 2);
+            c.hcap = c.idcap;
+            grew = true;
+        }
+    }
+    if (ovf & OVF_VISITED) {
+        c.vcap *= 2;
+        grew = true;
+    }
+    if (ovf & OVF_HASH) {
+        if (c.hashcap < (1u << 24)) {
+            c.hashcap *= 2;
+            grew = true;
+        }
+    }
+    if (c.hashcap < 2 * c.idcap) c.hashcap = next_pow2_u32(2ull * c.idcap);
+    return grew;
+}
+
+// runs prepare -> search (-> rerank -> resort) for nq queries already on the device.  Outputs land in the workspace
+// (or the caller's device buffers).  Synchronous w.r.t. overflow retries when `allow_sync` is set.
+struct BatchPlan {
+    uint32_t nq, L, rescore, k, M;
+    bool stream_only;  // vs_stream_batch: no rerank
+};
+
+static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_raw_q, const int16_t* d_qlabels,
+                            const uint32_t* d_qlabel_off, uint32_t* d_out_ids, uint64_t* d_out_tids, float* d_out_dist,
+                            Caps& caps, bool check_now, vs_stats* st) {
+    vs_ctx* c = ix->ctx;
+    SearchWorkspace& w = ix->ws;
+    const uint32_t nq = bp.nq, M = bp.M;
+    VS_TRY(devbuf_reserve(c, w.q_full, (size_t)nq * ix->vec_stride * 4));
+    VS_TRY(devbuf_reserve(c, w.qcodes, (size_t)nq * ix->code_stride * 8));
+    VS_TRY(devbuf_reserve(c, w.stream_ids, (size_t)nq * M * 4));
+    VS_TRY(devbuf_reserve(c, w.stream_ham, (size_t)nq * M * 4));
+    VS_TRY(devbuf_reserve(c, w.stream_cnt, (size_t)nq * 4));
+    VS_TRY(devbuf_reserve(c, w.stats, (size_t)nq * ST_N * 4));
+    VS_TRY(devbuf_reserve(c, w.status, (size_t)nq * 4));
+    VS_TRY(launch_prepare_queries(ix, d_raw_q, nq, (float*)w.q_full.p, (uint64_t*)w.qcodes.p));
+    for (int attempt = 0;; ++attempt) {
+        VS_TRY(devbuf_reserve(c, w.hash, (size_t)nq * caps.hashcap * 4));
+        VS_TRY(devbuf_reserve(c, w.cand_ids, (size_t)nq * caps.idcap * 4));
+        VS_HIP(hipMemsetAsync(w.hash.p, 0xFF, (size_t)nq * caps.hashcap * 4, c->stream));
+        SearchLaunch s;
+        s.nq = nq;
+        s.L = bp.L;
+        s.M = M;
+        s.hcap = caps.hcap;
+        s.vcap = caps.vcap;
+        s.hashcap = caps.hashcap;
+        s.idcap = caps.idcap;
+        s.qcodes = (const uint64_t*)w.qcodes.p;
+        s.qlabels = d_qlabels;
+        s.qlabel_off = d_qlabel_off;
+        s.hash = (uint32_t*)w.hash.p;
+        s.cand_ids = (uint32_t*)w.cand_ids.p;
+        s.out_ids = (uint32_t*)w.stream_ids.p;
+        s.out_ham = (uint32_t*)w.stream_ham.p;
+        s.out_cnt = (uint32_t*)w.stream_cnt.p;
+        s.stats = (uint32_t*)w.stats.p;
+        s.status = (uint32_t*)w.status.p;
+        VS_TRY(launch_search(ix, s));
+        if (!check_now) break;
+        std::vector<uint32_t> status(nq);
+        VS_HIP(hipMemcpyAsync(status.data(), w.status.p, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
+        VS_HIP(hipStreamSynchronize(c->stream));
+        uint32_t ovf = 0;
+        for (uint32_t v : status) ovf |= v;
+        if (!ovf) break;
+        if (st) st->retries++;
+        if (attempt >= 6 || !grow_caps(caps, ovf)) {
+            vs_set_error("search structures overflowed (flags 0x%x) at hcap=%u vcap=%u hashcap=%u idcap=%u", ovf,
+                         caps.hcap, caps.vcap, caps.hashcap, caps.idcap);
+            return VS_ERR_CAPACITY;
+        }
+    }
+    if (bp.stream_only) return VS_OK;
+    if (bp.rescore > 0) {
+        VS_REQUIRE(ix->vecs, "diskann.query_rescore > 0 needs the heap vector column on the device");
+        VS_TRY(devbuf_reserve(c, w.rr_dist, (size_t)nq * M * 4));
+        VS_TRY(devbuf_reserve(c, w.resort_heap, (size_t)nq * bp.rescore * 8));
+        VS_TRY(launch_rerank(ix, (const float*)w.q_full.p, (const uint32_t*)w.stream_ids.p, nullptr,
+                             (const uint32_t*)w.stream_cnt.p, M, nq, (float*)w.rr_dist.p));
+    }
+    VS_TRY(launch_resort(ix, nq, M, bp.rescore, bp.k, (const uint32_t*)w.stream_ids.p, (const uint32_t*)w.stream_cnt.p,
+                         bp.rescore ? (const float*)w.rr_dist.p : nullptr, (uint64_t*)w.resort_heap.p, d_out_ids,
+                         d_out_tids, d_out_dist));
+    return VS_OK;
+}
+
+static int collect_stats(vs_index* ix, uint32_t nq, uint32_t M, uint32_t rescore, bool stream_only, vs_stats* st) {
+    if (!st) return VS_OK;
+    SearchWorkspace& w = ix->ws;
+    std::vector<uint32_t> hs((size_t)nq * ST_N), cnt(nq);
+    VS_HIP(hipMemcpyAsync(hs.data(), w.stats.p, hs.size() * 4, hipMemcpyDeviceToHost, ix->ctx->stream));
+    VS_HIP(hipMemcpyAsync(cnt.data(), w.stream_cnt.p, cnt.size() * 4, hipMemcpyDeviceToHost, ix->ctx->stream));
+    VS_HIP(hipStreamSynchronize(ix->ctx->stream));
+    for (uint32_t q = 0; q < nq; ++q) {
+        st->queries++;
+        st->visited_nodes += hs[(size_t)q * ST_N + ST_VISITS];
+        st->candidate_nodes += hs[(size_t)q * ST_N + ST_CAND];
+        st->quantized_distance_comparisons += hs[(size_t)q * ST_N + ST_DQ];
+        st->node_reads += hs[(size_t)q * ST_N + ST_READS];
+        st->next_calls += hs[(size_t)q * ST_N + ST_NEXT];
+        if (!stream_only && rescore > 0) {
+            uint32_t nr = std::min(cnt[q], M);
+            st->full_distance_comparisons += nr;
+            st->node_heap_reads += nr;
+        }
+    }
+    return VS_OK;
+}
+
+static uint32_t stream_len(uint32_t rescore, uint32_t k) { return rescore > 0 ? rescore + k - 1 : k; }
+
+// how many queries fit one launch given the workspace budget
+static uint32_t chunk_queries(const vs_index* ix, const Caps& c, uint32_t M, uint32_t nq) {
+    size_t per_q = (size_t)c.hashcap * 4 + (size_t)c.idcap * 4 + (size_t)M * 12 + ix->vec_stride * 4ull +
+                   ix->code_stride * 8ull + 256;
+    size_t budget = 6ull << 30;
+    uint32_t m = (uint32_t)std::max<size_t>(1, std::min<size_t>(budget / per_q, 1u << 20));
+    return std::min(m, nq);
+}
+
+static int upload_label_keys(vs_index* ix, const int16_t* qlabels, const uint32_t* qlabel_off, uint32_t nq,
+                             const int16_t** d_labels, const uint32_t** d_off) {
+    *d_labels = nullptr;
+    *d_off = nullptr;
+    if (!qlabel_off) return VS_OK;
+    VS_REQUIRE(ix->d.has_labels && ix->label_off, "label scan keys on an index without labels");
+    // LabelSet::from(Vec<Label>): sort_unstable + dedup (AM/labels/mod.rs:30-37)
+    std::vector<int16_t> vals;
+    std::vector<uint32_t> off(nq + 1, 0);
+    for (uint32_t q = 0; q < nq; ++q) {
+        VS_REQUIRE(qlabel_off[q] <= qlabel_off[q + 1], "qlabel_off must be non-decreasing");
+        std::vector<int16_t> l(qlabels + qlabel_off[q], qlabels + qlabel_off[q + 1]);
+        std::sort(l.begin(), l.end());
+        l.erase(std::unique(l.begin(), l.end()), l.end());
+        VS_REQUIRE(l.size() <= 64, "more than 64 distinct labels in one scan key");
+        vals.insert(vals.end(), l.begin(), l.end());
+        off[q + 1] = (uint32_t)vals.size();
+    }
+    SearchWorkspace& w = ix->ws;
+    VS_TRY(devbuf_reserve(ix->ctx, w.qlabels, std::max<size_t>(vals.size(), 1) * 2));
+    VS_TRY(devbuf_reserve(ix->ctx, w.qlabel_off, off.size() * 4));
+    if (!vals.empty()) VS_TRY(vs_dev_upload(ix->ctx, w.qlabels.p, vals.data(), vals.size() * 2));
+    VS_TRY(vs_dev_upload(ix->ctx, w.qlabel_off.p, off.data(), off.size() * 4));
+    *d_labels = (const int16_t*)w.qlabels.p;
+    *d_off = (const uint32_t*)w.qlabel_off.p;
+    return VS_OK;
+}
+
+static int search_host(vs_index* ix, const float* queries, const int16_t* qlabels, const uint32_t* qlabel_off,
+                       uint32_t nq, uint32_t L, uint32_t rescore, uint32_t k, bool stream_only, uint32_t* out_ids,
+                       uint64_t* out_tids, float* out_dist, uint32_t* out_ham, vs_stats* stats) {
+    VS_REQUIRE(ix && (nq == 0 || queries), "search: bad args");
+    VS_REQUIRE(L >= 1 && L <= 10000, "diskann.query_search_list_size %u outside [1,10000]", L);  // AM/guc.rs:11-26
+    VS_REQUIRE(rescore <= 1000, "diskann.query_rescore %u outside [0,1000]", rescore);           // AM/guc.rs:28-43
+    VS_REQUIRE(k >= 1, "k must be >= 1");
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (nq == 0) return VS_OK;
+    vs_ctx* c = ix->ctx;
+    VS_HIP(hipSetDevice(c->device));
+    SearchWorkspace& w = ix->ws;
+    const uint32_t M = stream_only ? k : stream_len(rescore, k);
+    Caps caps = initial_caps(ix, L, M);
+    const int16_t* d_labels_all = nullptr;
+    const uint32_t* d_off_all = nullptr;
+    VS_TRY(upload_label_keys(ix, qlabels, qlabel_off, nq, &d_labels_all, &d_off_all));
+    const uint32_t chunk = chunk_queries(ix, caps, M, nq);
+    for (uint32_t q0 = 0; q0 < nq; q0 += chunk) {
+        const uint32_t cq = std::min(chunk, nq - q0);
+        VS_TRY(devbuf_reserve(c, w.raw_q, (size_t)cq * ix->d.dim_full * 4));
+        VS_TRY(vs_dev_upload(c, w.raw_q.p, queries + (size_t)q0 * ix->d.dim_full, (size_t)cq * ix->d.dim_full * 4));
+        VS_TRY(devbuf_reserve(c, w.out_ids, (size_t)cq * k * 4));
+        VS_TRY(devbuf_reserve(c, w.out_tids, (size_t)cq * k * 8));
+        VS_TRY(devbuf_reserve(c, w.out_dist, (size_t)cq * k * 4));
+        BatchPlan bp{cq, L, rescore, k, M, stream_only};
+        // label CSR offsets are absolute into d_labels_all, so a chunk just offsets the off pointer
+        VS_TRY(run_search_chunk(ix, bp, (const float*)w.raw_q.p, d_labels_all, d_off_all ? d_off_all + q0 : nullptr,
+                                (uint32_t*)w.out_ids.p, (uint64_t*)w.out_tids.p, (float*)w.out_dist.p, caps, true, stats));
+        VS_TRY(collect_stats(ix, cq, M, rescore, stream_only, stats));
+        if (stream_only) {
+            VS_TRY(vs_dev_download(c, out_ids + (size_t)q0 * k, w.stream_ids.p, (size_t)cq * k * 4));
+            if (out_ham) VS_TRY(vs_dev_download(c, out_ham + (size_t)q0 * k, w.stream_ham.p, (size_t)cq * k * 4));
+        } else {
+            VS_TRY(vs_dev_download(c, out_ids + (size_t)q0 * k, w.out_ids.p, (size_t)cq * k * 4));
+            if (out_tids) VS_TRY(vs_dev_download(c, out_tids + (size_t)q0 * k, w.out_tids.p, (size_t)cq * k * 8));
+            if (out_dist) VS_TRY(vs_dev_download(c, out_dist + (size_t)q0 * k, w.out_dist.p, (size_t)cq * k * 4));
+        }
+    }
+    if (stats) ix->last_stats = *stats;
+    return VS_OK;
+}
+
+extern "C" int vs_search_batch(vs_index* ix, const float* queries, const int16_t* qlabels, const uint32_t* qlabel_off,
+                               uint32_t nq, uint32_t L, uint32_t rescore, uint32_t k, uint32_t* out_ids,
+                               uint64_t* out_tids, float* out_dist, vs_stats* stats) {
+    VS_REQUIRE(nq == 0 || out_ids, "vs_search_batch: out_ids is NULL");
+    return search_host(ix, queries, qlabels, qlabel_off, nq, L, rescore, k, false, out_ids, out_tids, out_dist, nullptr,
+                       stats);
+}
+
+extern "C" int vs_stream_batch(vs_index* ix, const float* queries, const int16_t* qlabels, const uint32_t* qlabel_off,
+                               uint32_t nq, uint32_t L, uint32_t m, uint32_t* out_ids, uint32_t* out_ham, vs_stats* stats) {
+    VS_REQUIRE(nq == 0 || out_ids, "vs_stream_batch: out_ids is NULL");
+    return search_host(ix, queries, qlabels, qlabel_off, nq, L, 0, m, true, out_ids, nullptr, nullptr, out_ham, stats);
+}
+
+extern "C" int vs_search_batch_dev(vs_index* ix, const float* d_queries, const int16_t* d_qlabels,
+                                   const uint32_t* d_qlabel_off, uint32_t nq, uint32_t L, uint32_t rescore, uint32_t k,
+                                   uint32_t* d_out_ids, uint64_t* d_out_tids, float* d_out_dist) {
+    VS_REQUIRE(ix && (nq == 0 || (d_queries && d_out_ids)), "vs_search_batch_dev: bad args");
+    VS_REQUIRE(L >= 1 && L <= 10000 && rescore <= 1000 && k >= 1, "vs_search_batch_dev: GUC out of range");
+    SearchWorkspace& w = ix->ws;
+    w.pending = false;
+    if (nq == 0) return VS_OK;
+    VS_HIP(hipSetDevice(ix->ctx->device));
+    const uint32_t M = stream_len(rescore, k);
+    Caps caps = initial_caps(ix, L, M);
+    VS_REQUIRE(chunk_queries(ix, caps, M, nq) == nq, "vs_search_batch_dev: batch of %u queries exceeds the workspace budget", nq);
+    BatchPlan bp{nq, L, rescore, k, M, false};
+    VS_TRY(run_search_chunk(ix, bp, d_queries, d_qlabels, d_qlabel_off, d_out_ids, d_out_tids, d_out_dist, caps, false,
+                            nullptr));
+    w.pending = true;
+    w.pend_nq = nq;
+    w.pend_m = M;
+    ix->last_stats = vs_stats{};
+    ix->last_stats.retries = rescore;  // stash (rescore) for finish(); overwritten there
+    return VS_OK;
+}
+
+extern "C" int vs_search_batch_dev_finish(vs_index* ix, vs_stats* stats) {
+    VS_REQUIRE(ix, "vs_search_batch_dev_finish: index is NULL");
+    SearchWorkspace& w = ix->ws;
+    if (!w.pending) {
+        vs_set_error("vs_search_batch_dev_finish: no batch in flight");
+        return VS_ERR_STATE;
+    }
+    w.pending = false;
+    const uint32_t nq = w.pend_nq, M = w.pend_m;
+    const uint32_t rescore = (uint32_t)ix->last_stats.retries;
+    std::vector<uint32_t> status(nq);
+    VS_HIP(hipMemcpyAsync(status.data(), w.status.p, (size_t)nq * 4, hipMemcpyDeviceToHost, ix->ctx->stream));
+    VS_HIP(hipStreamSynchronize(ix->ctx->stream));
+    uint32_t ovf = 0;
+    for (uint32_t v : status) ovf |= v;
+    if (ovf) {
+        vs_set_error("vs_search_batch_dev: per-query structures overflowed (flags 0x%x); use vs_search_batch, which "
+                     "retries with larger capacities", ovf);
+        return VS_ERR_CAPACITY;
+    }
+    vs_stats st{};
+    VS_TRY(collect_stats(ix, nq, M, rescore, false, &st));
+    ix->last_stats = st;
+    if (stats) *stats = st;
+    return VS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// amrescan / amgettuple mirror.  A scan prefetches `rescore + window` rows with one batched launch and hands them
+// out one at a time; asking past the prefetched rows re-runs the (deterministic) scan with a doubled window — the
+// stream is a pure function of (index, query, GUCs), so the already returned prefix is reproduced exactly.
+// ---------------------------------------------------------------------------------------------------------------
+struct vs_scan {
+    vs_index* ix = nullptr;
+    bool active = false;
+    bool null_query = false;
+    std::vector<float> query;
+    std::vector<int16_t> labels;
+    bool has_label_key = false;
+    uint32_t L = 100, rescore = 50;
+    uint32_t window = 0;                 // rows fetched so far
+    uint32_t cursor = 0;                 // rows handed out
+    bool exhausted = false;              // the fetched window reached the end of the scan
+    std::vector<uint32_t> ids;
+    std::vector<uint64_t> tids;
+    std::vector<float> dist;
+    vs_stats stats{};
+};
+
+extern "C" int vs_beginscan(vs_index* ix, vs_scan** out) {
+    VS_REQUIRE(ix && out, "vs_beginscan: bad args");
+    vs_scan* s = new vs_scan();
+    s->ix = ix;
+    *out = s;
+    return VS_OK;
+}
+
+static int scan_fetch(vs_scan* s, uint32_t window) {
+    vs_index* ix = s->ix;
+    s->ids.assign(window, VS_INVALID_NODE);
+    s->tids.assign(window, 0);
+    s->dist.assign(window, 0.f);
+    uint32_t off[2] = {0, (uint32_t)s->labels.size()};
+    const bool keys = s->has_label_key && !s->null_query;
+    VS_TRY(vs_search_batch(ix, s->query.data(), keys ? s->labels.data() : nullptr, keys ? off : nullptr, 1, s->L,
+                           s->rescore, window, s->ids.data(), s->tids.data(), s->dist.data(), &s->stats));
+    s->window = window;
+    s->exhausted = false;
+    for (uint32_t i = 0; i < window; ++i)
+        if (s->ids[i] == VS_INVALID_NODE) {
+            s->exhausted = true;
+            s->window = i;
+            break;
+        }
+    return VS_OK;
+}
+
+extern "C" int vs_rescan(vs_scan* s, const float* query, const int16_t* labels, uint32_t n_labels, int has_label_key,
+                         uint32_t L, uint32_t rescore) {
+    VS_REQUIRE(s, "vs_rescan: scan is NULL");
+    VS_REQUIRE(L >= 1 && L <= 10000, "diskann.query_search_list_size %u outside [1,10000]", L);
+    VS_REQUIRE(rescore <= 1000, "diskann.query_rescore %u outside [0,1000]", rescore);
+    vs_index* ix = s->ix;
+    s->null_query = query == nullptr;
+    if (query) s->query.assign(query, query + ix->d.dim_full);
+    else s->query.assign(ix->d.dim_full, 0.0f);  // PgVector::zeros (AM/labels/mod.rs:214-216)
+    s->labels.assign(labels ? labels : nullptr, labels ? labels + n_labels : nullptr);
+    s->has_label_key = has_label_key != 0;
+    s->L = L;
+    s->rescore = rescore;
+    s->cursor = 0;
+    s->window = 0;
+    s->exhausted = false;
+    s->active = true;
+    return VS_OK;
+}
+
+extern "C" int vs_gettuple(vs_scan* s, uint64_t* heap_tid, uint32_t* node, float* dist) {
+    if (!s || !s->active) {
+        vs_set_error("vs_gettuple before vs_rescan");
+        return VS_ERR_STATE;
+    }
+    if (s->cursor >= s->window && !s->exhausted) {
+        uint32_t want = s->window == 0 ? 16u : s->window * 2;
+        int r = scan_fetch(s, want);
+        if (r != VS_OK) return r;
+    }
+    if (s->cursor >= s->window) return 0;
+    if (heap_tid) *heap_tid = s->tids[s->cursor];
+    if (node) *node = s->ids[s->cursor];
+    if (dist) *dist = s->dist[s->cursor];
+    s->cursor++;
+    return 1;
+}
+
+extern "C" int vs_scan_xs_recheck(const vs_scan* s) { return (s && s->has_label_key) ? 1 : 0; }  // AM/scan.rs:350-352
+
+extern "C" int vs_scan_get_stats(const vs_scan* s, vs_stats* out) {
+    VS_REQUIRE(s && out, "vs_scan_get_stats: bad args");
+    *out = s->stats;
+    return VS_OK;
+}
+
+extern "C" void vs_endscan(vs_scan* s) { delete s; }

@@ -1,0 +1,130 @@
+// vs_internal.h — shared declarations of libvsgpu.so (HIP / gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/vsgpu.h"
+
+#define VS_EMPTY 0xFFFFFFFFu
+
+void vs_set_error(const char* fmt, ...);
+
+#define VS_HIP(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess) {                                                                        \
+            vs_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__);   \
+            return (_e == hipErrorOutOfMemory) ? VS_ERR_OOM : VS_ERR_HIP;                              \
+        }                                                                                              \
+    } while (0)
+
+#define VS_REQUIRE(cond, ...)         \
+    do {                              \
+        if (!(cond)) {                \
+            vs_set_error(__VA_ARGS__);\
+            return VS_ERR_INVALID;    \
+        }                             \
+    } while (0)
+
+#define VS_TRY(expr)            \
+    do {                        \
+        int _r = (expr);        \
+        if (_r != VS_OK) return _r; \
+    } while (0)
+
+__host__ __device__ static inline uint32_t round_up_u32(uint32_t x, uint32_t m) { return (x + m - 1) / m * m; }
+static inline uint32_t next_pow2_u32(uint64_t x) {
+    uint64_t p = 1;
+    while (p < x) p <<= 1;
+    return (uint32_t)p;
+}
+
+struct vs_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;       // compute
+    hipStream_t copy_stream = nullptr;  // H2D/D2H staging
+    void* pinned[2] = {nullptr, nullptr};
+    size_t pinned_bytes = 0;
+    hipEvent_t pinned_ev[2] = {nullptr, nullptr};
+    hipDeviceProp_t prop;
+};
+
+// growable device scratch buffer
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+struct SearchWorkspace {
+    DevBuf q_full, qcodes, qlabels, qlabel_off, hash, cand_ids, stream_ids, stream_ham, stream_cnt, stats, status,
+        rr_dist, out_ids, out_tids, out_dist, resort_heap, raw_q, misc;
+    // pending async call (vs_search_batch_dev)
+    bool pending = false;
+    uint32_t pend_nq = 0;
+    uint32_t pend_m = 0;
+};
+
+struct vs_index {
+    vs_ctx* ctx = nullptr;
+    vs_index_desc d{};
+    uint32_t code_stride = 0;  // u64 words per code row (W rounded up to even, zero padded)
+    uint32_t nbr_stride = 0;   // u32 per neighbor row (R rounded up to 16)
+    uint32_t vec_stride = 0;   // floats per vector row (dim_full rounded up to 4)
+    uint64_t* codes = nullptr;
+    uint32_t* nbrs = nullptr;
+    uint64_t* tids = nullptr;
+    float* vecs = nullptr;
+    float* vnorm = nullptr;  // per node: 0 => leave vector alone, else divisor sqrt(norm) (preprocess_cosine)
+    float* mean = nullptr;
+    float* m2 = nullptr;
+    uint64_t count = 0;
+    uint32_t* label_off = nullptr;
+    int16_t* label_val = nullptr;
+    uint64_t n_label_vals = 0;
+    int16_t* ls_labels = nullptr;
+    uint32_t* ls_nodes = nullptr;
+    SearchWorkspace ws;
+    vs_stats last_stats{};
+};
+
+int devbuf_reserve(vs_ctx* ctx, DevBuf& b, size_t bytes);
+void devbuf_free(DevBuf& b);
+
+// ---- kernel launch wrappers (defined in the .hip files) -------------------------------------------------------
+struct SearchLaunch {
+    uint32_t nq, L, M;
+    uint32_t hcap, vcap, hashcap, idcap;
+    const uint64_t* qcodes;        // [nq][code_stride]
+    const int16_t* qlabels;        // may be null
+    const uint32_t* qlabel_off;    // may be null => no label keys
+    uint32_t* hash;                // [nq][hashcap], pre-filled with 0xFF
+    uint32_t* cand_ids;            // [nq][idcap]
+    uint32_t* out_ids;             // [nq][M]
+    uint32_t* out_ham;             // [nq][M]
+    uint32_t* out_cnt;             // [nq]
+    uint32_t* stats;               // [nq][8]
+    uint32_t* status;              // [nq]
+};
+enum { ST_VISITS = 0, ST_CAND = 1, ST_DQ = 2, ST_READS = 3, ST_NEXT = 4, ST_N = 8 };
+enum { OVF_HEAP = 1, OVF_VISITED = 2, OVF_HASH = 4, OVF_IDS = 8 };
+
+int launch_prepare_queries(vs_index* idx, const float* d_raw, uint32_t nq, float* d_q_full, uint64_t* d_qcodes);
+int launch_quantize_rows(vs_index* idx, const float* d_rows, uint32_t row_stride, uint32_t nrows, uint64_t* d_codes,
+                         uint32_t code_stride);
+int launch_hamming_gather(vs_index* idx, const uint64_t* d_qcodes, const uint32_t* d_ids, const uint32_t* d_off,
+                          uint32_t nq, uint32_t* d_out);
+int launch_rerank(vs_index* idx, const float* d_q_full, const uint32_t* d_ids, const uint32_t* d_off,
+                  const uint32_t* d_cnt, uint32_t fixed_m, uint32_t nq, float* d_out);
+int launch_search(vs_index* idx, const SearchLaunch& s);
+int launch_resort(vs_index* idx, uint32_t nq, uint32_t M, uint32_t rescore, uint32_t k, const uint32_t* d_stream_ids,
+                  const uint32_t* d_cnt, const float* d_dist, uint64_t* d_heap_ws, uint32_t* d_out_ids,
+                  uint64_t* d_out_tids, float* d_out_dist);
+int launch_row_norms(vs_index* idx);
+int launch_validate_nbrs(vs_index* idx, uint32_t* d_flag);
+int launch_scan_topk(vs_index* idx, const uint64_t* d_qcodes, uint32_t nq, uint32_t k, uint32_t* d_out_ids,
+                     uint32_t* d_out_ham);

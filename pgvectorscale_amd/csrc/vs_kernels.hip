@@ -1,0 +1,871 @@
+// vs_kernels.hip — hand-written gfx950 (CDNA4, wave64) kernels of the StreamingDiskANN search path.
+//
+//   K4 k_prepare_queries / k_quantize_rows : SbqQuantizer::quantize            (AM/sbq/quantize.rs:52-102)
+//   K1 k_hamming_gather                    : distance_xor_optimized on gathers (AM/distance/mod.rs:266-323)
+//   K2 k_rerank                            : distance_l2/cosine/inner_product in the reference's AVX2 accumulation
+//                                            order (AM/distance/mod.rs:325-435, AM/sbq/storage.rs:304-328)
+//   K3 k_search                            : ListSearchResult + greedy_search_iterate + visit_lsn_internal +
+//                                            TSVResponseIterator::next (AM/graph/mod.rs:74-185,357-385,
+//                                            AM/sbq/storage.rs:135-190, AM/scan.rs:210-242)
+//      k_resort                            : the rescore window of next_with_resort (AM/scan.rs:244-305)
+//
+// All of this is HBM-latency / bandwidth bound integer + f32 dot work: no MFMA.  One wave64 owns one query in
+// K3 (the search is a serial chain of dependent expansions), lanes cooperate on the R gathered neighbor codes
+// (4 lanes x 16 B per code row), the candidate heap / visited list live in LDS, the dedup hash set in L2.
+// Compiled with -ffp-contract=off: the reference's L2 kernel uses separate mul+add, its dot kernel FMA.
+#include "vs_internal.h"
+
+#define WAVE 64
+
+// ---------------------------------------------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+// add the value held by the lane with index (lane ^ 1) / (lane ^ 2) via DPP quad_perm (no LDS traffic)
+__device__ __forceinline__ uint32_t quad_sum(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1 /*quad_perm [1,0,3,2]*/, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E /*quad_perm [2,3,0,1]*/, 0xF, 0xF, true);
+    return v;
+}
+
+__device__ __forceinline__ uint32_t hash_u32(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x7feb352dU;
+    x ^= x >> 15;
+    x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
+}
+
+// Hamming distance of one code row against the query code held in LDS, computed by a group of 4 lanes
+// (lane l4 covers words 2*l4 + 8t, 2*l4+1 + 8t: 16 B per lane per step, 64 B contiguous per group per step).
+// Rows are code_stride (even) words, zero padded, so the padded tail contributes popcount(0^0)=0.
+__device__ __forceinline__ uint32_t ham_row4(const uint64_t* __restrict__ row, const uint64_t* qc, int l4,
+                                             uint32_t code_stride, bool active) {
+    uint32_t acc = 0;
+    if (active) {
+        for (uint32_t w = 2u * (uint32_t)l4; w < code_stride; w += 8) {
+            const ulonglong2 r = *reinterpret_cast<const ulonglong2*>(row + w);
+            const ulonglong2 qq = *reinterpret_cast<const ulonglong2*>(qc + w);
+            acc += (uint32_t)__popcll(r.x ^ qq.x) + (uint32_t)__popcll(r.y ^ qq.y);
+        }
+    }
+    return quad_sum(acc);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// preprocess_cosine on a vector held in LDS (AM/distance/mod.rs:225-253): sequential f32 sum of squares (lane 0),
+// then every lane divides.  Returns nothing; buf is normalised in place.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ void lds_preprocess_cosine(float* buf, uint32_t n, int lane, float* bcast /* LDS scratch [1] */) {
+    __syncthreads();
+    if (lane == 0) {
+        float norm = 0.0f;
+        for (uint32_t i = 0; i < n; ++i) {
+            float p = buf[i] * buf[i];
+            norm = norm + p;
+        }
+        const float eps = 1.1920929e-07f;  // f32::EPSILON
+        float adj = eps * (float)n;
+        float s = 0.0f;  // 0 => leave alone
+        if (!(norm < eps) && !(norm >= 1.0f - adj && norm <= 1.0f + adj)) s = sqrtf(norm);
+        *bcast = s;
+    }
+    __syncthreads();
+    float s = *bcast;
+    if (s != 0.0f) {
+        for (uint32_t i = lane; i < n; i += blockDim.x) buf[i] = buf[i] / s;
+    }
+    __syncthreads();
+}
+
+// SbqQuantizer::quantize of a vector in LDS, one wave: lane = bit position inside the output word (ballot packs).
+__device__ void wave_quantize(const float* v, uint32_t dims, uint32_t bits, const float* __restrict__ mean,
+                              const float* __restrict__ m2, float count_f, uint64_t* out, uint32_t words,
+                              uint32_t out_stride, int lane) {
+    for (uint32_t w = 0; w < out_stride; ++w) {
+        uint64_t word = 0;
+        if (w < words) {
+            uint32_t g = w * 64u + (uint32_t)lane;  // global bit index
+            uint32_t dim = g / bits;
+            uint32_t j = g - dim * bits;
+            bool bit = false;
+            if (dim < dims) {
+                float x = v[dim];
+                float mu = mean[dim];
+                if (bits == 1) {
+                    bit = x > mu;
+                } else {
+                    float variance = m2[dim] / count_f;
+                    float std_dev = sqrtf(variance);
+                    float ranges = (float)(bits + 1);
+                    float z = (x - mu) / std_dev;
+                    float index = (z + 2.0f) / (4.0f / ranges);
+                    uint32_t ones = 0;
+                    if (!(index < 1.0f)) {  // NaN falls through like Rust's `if index < 1.0 {} else {..}`
+                        float fl = floorf(index);
+                        // `fl as usize` saturating, NaN -> 0; then min(bits)
+                        if (fl != fl) ones = 0;
+                        else if (fl >= (float)bits) ones = bits;
+                        else if (fl <= 0.0f) ones = 0;
+                        else ones = (uint32_t)fl;
+                    }
+                    bit = j < ones;
+                }
+            }
+            word = __ballot(bit);
+        }
+        if (lane == 0) out[w] = word;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K4a: query preparation = PgVector::from_datum(index=true, full=true) (AM/pg_vector.rs:162-199) +
+//      SbqSearchDistanceMeasure::new (AM/sbq/mod.rs:145-148).  One wave per query.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WAVE) void k_prepare_queries(const float* __restrict__ raw, uint32_t nq,
+                                                          uint32_t dim_full, uint32_t dim_index, uint32_t vec_stride,
+                                                          uint32_t distance_type, uint32_t bits,
+                                                          const float* __restrict__ mean, const float* __restrict__ m2,
+                                                          float count_f, uint32_t words, uint32_t code_stride,
+                                                          float* __restrict__ q_full, uint64_t* __restrict__ qcodes) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* full = reinterpret_cast<float*>(smem);
+    float* idxv = full + round_up_u32(dim_full, 4);
+    float* bc = idxv + round_up_u32(dim_index, 4);
+    const int lane = threadIdx.x;
+    const uint32_t q = blockIdx.x;
+    if (q >= nq) return;
+    const float* src = raw + (size_t)q * dim_full;
+    for (uint32_t i = lane; i < dim_full; i += WAVE) full[i] = src[i];
+    const bool same = dim_full == dim_index;
+    if (!same)
+        for (uint32_t i = lane; i < dim_index; i += WAVE) idxv[i] = src[i];
+    __syncthreads();
+    if (distance_type == VS_COSINE) {
+        lds_preprocess_cosine(full, dim_full, lane, bc);
+        if (!same) lds_preprocess_cosine(idxv, dim_index, lane, bc);
+    }
+    float* qf = q_full + (size_t)q * vec_stride;
+    for (uint32_t i = lane; i < vec_stride; i += WAVE) qf[i] = i < dim_full ? full[i] : 0.0f;
+    wave_quantize(same ? full : idxv, dim_index, bits, mean, m2, count_f, qcodes + (size_t)q * code_stride, words,
+                  code_stride, lane);
+}
+
+// K4b: quantize rows that are already prepared (normalised if cosine): one wave per row.
+__global__ __launch_bounds__(WAVE) void k_quantize_rows(const float* __restrict__ rows, uint32_t row_stride,
+                                                        uint32_t nrows, uint32_t dims, uint32_t bits,
+                                                        const float* __restrict__ mean, const float* __restrict__ m2,
+                                                        float count_f, uint32_t words, uint32_t code_stride,
+                                                        uint64_t* __restrict__ codes) {
+    const int lane = threadIdx.x;
+    for (uint32_t r = blockIdx.x; r < nrows; r += gridDim.x)
+        wave_quantize(rows + (size_t)r * row_stride, dims, bits, mean, m2, count_f, codes + (size_t)r * code_stride,
+                      words, code_stride, lane);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K1: Hamming distances of gathered code rows.  One wave per query; 16 rows per pass.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WAVE) void k_hamming_gather(const uint64_t* __restrict__ codes, uint32_t code_stride,
+                                                         const uint64_t* __restrict__ qcodes,
+                                                         const uint32_t* __restrict__ ids,
+                                                         const uint32_t* __restrict__ off, uint32_t nq,
+                                                         uint32_t* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* qc = reinterpret_cast<uint64_t*>(smem);
+    const int lane = threadIdx.x;
+    const uint32_t q = blockIdx.x;
+    if (q >= nq) return;
+    for (uint32_t w = lane; w < code_stride; w += WAVE) qc[w] = qcodes[(size_t)q * code_stride + w];
+    __syncthreads();
+    const uint32_t b = off[q], e = off[q + 1];
+    for (uint32_t base = b; base < e; base += 16) {
+        uint32_t j = base + (uint32_t)(lane >> 2);
+        bool valid = j < e;
+        uint32_t id = valid ? ids[j] : 0;
+        uint32_t d = ham_row4(codes + (size_t)id * code_stride, qc, lane & 3, code_stride, valid);
+        if (valid && (lane & 3) == 0) out[j] = d;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K2: rerank.  One workgroup (4 waves) per query, query vector staged in LDS; 8 lanes per candidate row, float4
+// loads: lane l8 owns elements 32t+4*l8..+3 of every 32-float step, i.e. exactly 4 of the 32 "virtual AVX2 lanes"
+// (4 accumulators x 8 lanes) of distance_l2_simd_body!/inner_product_simd_body! (AM/distance/mod.rs:325-435).
+// Final reduction replays horizontal_add_ps per accumulator and the left-to-right sum of the 4 accumulators, so the
+// result is the same f32 the AVX2 reference produces (bit-for-bit, given the same hadd lane order).
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float shfl_f(float v, int src) { return __shfl(v, src, WAVE); }
+
+__global__ __launch_bounds__(256) void k_rerank(const float* __restrict__ vecs, uint32_t vec_stride, uint32_t dim_full,
+                                                const float* __restrict__ vnorm, uint32_t distance_type,
+                                                const float* __restrict__ q_full, const uint32_t* __restrict__ ids,
+                                                const uint32_t* __restrict__ off, const uint32_t* __restrict__ cnt,
+                                                uint32_t fixed_m, uint32_t nq, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* qv = reinterpret_cast<float*>(smem);
+    const uint32_t q = blockIdx.x;
+    if (q >= nq) return;
+    for (uint32_t i = threadIdx.x; i < vec_stride; i += blockDim.x) qv[i] = q_full[(size_t)q * vec_stride + i];
+    __syncthreads();
+    uint32_t b, e;
+    if (off) {
+        b = off[q];
+        e = off[q + 1];
+    } else {
+        b = q * fixed_m;
+        e = b + (cnt ? min(cnt[q], fixed_m) : fixed_m);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l8 = lane & 7, grp = lane >> 3;
+    const uint32_t steps = dim_full / 32;
+    for (uint32_t base = b; base < e; base += 32) {
+        uint32_t j = base + (uint32_t)(wave * 8 + grp);
+        bool valid = j < e;
+        uint32_t id = valid ? ids[j] : VS_INVALID_NODE;
+        if (id == VS_INVALID_NODE) valid = false;
+        const float* row = vecs + (size_t)(valid ? id : 0) * vec_stride;
+        float s = 0.0f;
+        if (valid && distance_type == VS_COSINE) s = vnorm[id];
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        if (valid) {
+            if (distance_type == VS_L2) {
+                for (uint32_t t = 0; t < steps; ++t) {
+                    float4 x = *reinterpret_cast<const float4*>(row + 32 * t + 4 * l8);
+                    float4 y = *reinterpret_cast<const float4*>(qv + 32 * t + 4 * l8);
+                    float d0 = x.x - y.x, d1 = x.y - y.y, d2 = x.z - y.z, d3 = x.w - y.w;
+                    float p0 = d0 * d0, p1 = d1 * d1, p2 = d2 * d2, p3 = d3 * d3;
+                    a0 = a0 + p0;
+                    a1 = a1 + p1;
+                    a2 = a2 + p2;
+                    a3 = a3 + p3;
+                }
+            } else {
+                for (uint32_t t = 0; t < steps; ++t) {
+                    float4 x = *reinterpret_cast<const float4*>(row + 32 * t + 4 * l8);
+                    float4 y = *reinterpret_cast<const float4*>(qv + 32 * t + 4 * l8);
+                    if (s != 0.0f) {
+                        x.x = x.x / s;
+                        x.y = x.y / s;
+                        x.z = x.z / s;
+                        x.w = x.w / s;
+                    }
+                    a0 = __builtin_fmaf(x.x, y.x, a0);
+                    a1 = __builtin_fmaf(x.y, y.y, a1);
+                    a2 = __builtin_fmaf(x.z, y.z, a2);
+                    a3 = __builtin_fmaf(x.w, y.w, a3);
+                }
+            }
+        }
+        // horizontal_add_ps of accumulator j lives on lanes (2j, 2j+1) of the 8-lane group:
+        // s_c = a_c + a_{c+4}; h = (s0+s1)+(s2+s3)
+        float s0 = a0 + shfl_f(a0, lane ^ 1);
+        float s1 = a1 + shfl_f(a1, lane ^ 1);
+        float s2 = a2 + shfl_f(a2, lane ^ 1);
+        float s3 = a3 + shfl_f(a3, lane ^ 1);
+        float t0 = s0 + s1;
+        float t1 = s2 + s3;
+        float h = t0 + t1;
+        const int g0 = lane & ~7;
+        float h0 = shfl_f(h, g0 + 0), h1 = shfl_f(h, g0 + 2), h2 = shfl_f(h, g0 + 4), h3 = shfl_f(h, g0 + 6);
+        float dist = h0 + h1;
+        dist = dist + h2;
+        dist = dist + h3;
+        if (valid && l8 == 0) {
+            for (uint32_t i = steps * 32; i < dim_full; ++i) {  // scalar tail, in element order
+                float x = row[i];
+                if (distance_type == VS_L2) {
+                    float diff = x - qv[i];
+                    float p = diff * diff;
+                    dist = dist + p;
+                } else {
+                    if (s != 0.0f) x = x / s;
+                    float p = x * qv[i];
+                    dist = dist + p;
+                }
+            }
+            float r;
+            if (distance_type == VS_L2) r = dist;
+            else if (distance_type == VS_IP) r = -dist;
+            else r = fmaxf(1.0f - dist, 0.0f);
+            out[j] = r;
+        }
+    }
+}
+
+// per-node cosine divisor cache: exact preprocess_cosine_get_norm (sequential f32 sum).  A wave owns 64 rows;
+// a [64 rows][64 dims] tile is staged through LDS so global reads stay coalesced while each lane walks one row
+// in element order.
+__global__ __launch_bounds__(WAVE) void k_row_norms(const float* __restrict__ vecs, uint32_t vec_stride, uint32_t dim,
+                                                    uint32_t n, float* __restrict__ vnorm) {
+    __shared__ float tile[64][65];
+    const int lane = threadIdx.x;
+    for (uint32_t row0 = blockIdx.x * 64u; row0 < n; row0 += gridDim.x * 64u) {
+        float norm = 0.0f;
+        for (uint32_t d0 = 0; d0 < dim; d0 += 64) {
+            for (int r = 0; r < 64; ++r) {
+                uint32_t row = row0 + r;
+                uint32_t d = d0 + lane;
+                tile[r][lane] = (row < n && d < dim) ? vecs[(size_t)row * vec_stride + d] : 0.0f;
+            }
+            __syncthreads();
+            uint32_t lim = min(64u, dim - d0);
+            for (uint32_t c = 0; c < lim; ++c) {
+                float v = tile[lane][c];
+                float p = v * v;
+                norm = norm + p;
+            }
+            __syncthreads();
+        }
+        uint32_t row = row0 + lane;
+        if (row < n) {
+            const float eps = 1.1920929e-07f;
+            float adj = eps * (float)dim;
+            float s = 0.0f;
+            if (!(norm < eps) && !(norm >= 1.0f - adj && norm <= 1.0f + adj)) s = sqrtf(norm);
+            vnorm[row] = s;
+        }
+    }
+}
+
+// duplicate ids inside one neighbor list would make the wave-parallel dedup order-dependent: reject them at upload.
+__global__ void k_validate_nbrs(const uint32_t* __restrict__ nbrs, uint32_t nbr_stride, uint32_t R, uint32_t n,
+                                uint32_t* flag) {
+    uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n) return;
+    const uint32_t* r = nbrs + (size_t)row * nbr_stride;
+    uint32_t deg = 0;
+    while (deg < R && r[deg] != VS_INVALID_NODE) {
+        if (r[deg] >= n) atomicOr(flag, 2u);
+        ++deg;
+    }
+    for (uint32_t i = 1; i < deg; ++i)
+        for (uint32_t j = 0; j < i; ++j)
+            if (r[i] == r[j]) atomicOr(flag, 1u);
+}
+
+// ===============================================================================================================
+// K3: the streaming beam search.  One wave = one scan.
+// ===============================================================================================================
+struct SearchArgs {
+    const uint64_t* codes;
+    const uint32_t* nbrs;
+    const uint64_t* tids;
+    const uint32_t* label_off;
+    const int16_t* label_val;
+    const int16_t* ls_labels;
+    const uint32_t* ls_nodes;
+    uint32_t code_stride, nbr_stride, R, n, n_ls, default_start;
+    SearchLaunch s;
+};
+
+#define MAX_QLABELS 64
+
+// candidates: BinaryHeap<Reverse<ListSearchNeighbor>> (AM/graph/mod.rs:75).  Entry = (hamming << 16) | seq where seq
+// indexes this query's cand_ids[] (push order).  Ordering uses the distance only (DistanceWithTieBreak with the
+// constant tie-break 0 of with_query, AM/graph/neighbor_with_distance.rs:31-43,74-83).  Heap index i lives at
+// heap[i + 1] so sibling pairs are 8-byte aligned.  Mechanics are Rust std BinaryHeap's (push = sift_up; pop = swap
+// last into the root, sift_down_to_bottom, then sift_up), because the order of equal distances depends on them.
+struct WaveHeap {
+    uint32_t* h;  // LDS
+    uint32_t len;
+    __device__ __forceinline__ uint32_t key(uint32_t e) const { return e >> 16; }
+    // sift_up(0, pos): while pos>0 { parent=(pos-1)/2; if elem <= parent break }  with Reverse => parent.d <= elem.d
+    __device__ __forceinline__ void sift_up(uint32_t pos, uint32_t elem, int lane) {
+        const uint32_t ek = key(elem);
+        while (pos > 0) {
+            uint32_t parent = (pos - 1) >> 1;
+            uint32_t pe = rfl(h[parent + 1]);
+            if (key(pe) <= ek) break;
+            if (lane == 0) h[pos + 1] = pe;
+            pos = parent;
+        }
+        if (lane == 0) h[pos + 1] = elem;
+    }
+    __device__ __forceinline__ void push(uint32_t elem, int lane) {
+        uint32_t pos = len;
+        len = pos + 1;
+        sift_up(pos, elem, lane);
+    }
+    __device__ __forceinline__ uint32_t peek() const { return rfl(h[1]); }
+    // pop(): Vec::pop; swap with data[0]; sift_down_to_bottom(0)
+    __device__ __forceinline__ uint32_t pop(int lane) {
+        uint32_t item = rfl(h[len]);  // data[len-1]
+        len -= 1;
+        if (len == 0) return item;
+        uint32_t top = rfl(h[1]);
+        const uint32_t end = len;
+        uint32_t pos = 0, child = 1;
+        const uint32_t lim = end >= 2 ? end - 2 : 0;
+        while (child <= lim) {
+            // child += (data[child] <= data[child+1]) ; Reverse => right.d <= left.d picks the right child
+            uint2 pr = *reinterpret_cast<const uint2*>(h + child + 1);
+            uint32_t le = rfl(pr.x), ri = rfl(pr.y);
+            uint32_t pick = (key(ri) <= key(le)) ? 1u : 0u;
+            child += pick;
+            if (lane == 0) h[pos + 1] = pick ? ri : le;
+            pos = child;
+            child = 2 * pos + 1;
+        }
+        if (child == end - 1) {
+            uint32_t ce = rfl(h[child + 1]);
+            if (lane == 0) h[pos + 1] = ce;
+            pos = child;
+        }
+        sift_up(pos, item, lane);
+        return top;
+    }
+};
+
+__global__ __launch_bounds__(WAVE) void k_search(SearchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x;
+    const uint32_t q = blockIdx.x;
+    const SearchLaunch& s = a.s;
+    if (q >= s.nq) return;
+
+    // ---- LDS carve (all offsets multiples of 16 B) ----
+    uint32_t* heap_mem = reinterpret_cast<uint32_t*>(smem);                  // hcap + 2 (index i at [i+1])
+    uint32_t* vdist = heap_mem + round_up_u32(s.hcap + 2, 4);               // sorted visited list: distances
+    uint32_t* vid = vdist + round_up_u32(s.vcap, 4);                        //                      node ids
+    uint32_t* surv_id = vid + round_up_u32(s.vcap, 4);                      // survivors of one neighbor chunk
+    uint32_t* surv_d = surv_id + 64;
+    uint64_t* qc = reinterpret_cast<uint64_t*>(surv_d + 64);                // query code
+    int16_t* ql = reinterpret_cast<int16_t*>(qc + a.code_stride);           // query labels (sorted, dedup)
+
+    for (uint32_t w = lane; w < a.code_stride; w += WAVE) qc[w] = s.qcodes[(size_t)q * a.code_stride + w];
+    // LabeledVector.labels: Some iff a scan key exists (AM/labels/mod.rs:222-236)
+    const bool labels_some = s.qlabel_off != nullptr;
+    uint32_t nql = 0;
+    if (labels_some) {
+        uint32_t lb = s.qlabel_off[q], le = s.qlabel_off[q + 1];
+        nql = min(le - lb, (uint32_t)MAX_QLABELS);
+        for (uint32_t i = lane; i < nql; i += WAVE) ql[i] = s.qlabels[lb + i];
+    }
+    const bool has_label_filter = labels_some && nql > 0;  // AM/scan.rs:189 ; no_filter = !has_label_filter
+    __syncthreads();
+
+    uint32_t* hash = s.hash + (size_t)q * s.hashcap;
+    const uint32_t hmask = s.hashcap - 1;
+    uint32_t* cand_ids = s.cand_ids + (size_t)q * s.idcap;
+
+    WaveHeap heap{heap_mem, 0};
+    uint32_t vlen = 0, npush = 0, ninserted = 0, emitted = 0, status = 0;
+    uint32_t st_visits = 0, st_cand = 0, st_dq = 0, st_reads = 0, st_next = 0;
+
+    // ---- ListSearchResult::new: start nodes (AM/graph/mod.rs:97-124, AM/graph/start_nodes.rs:39-48) ----
+    {
+        uint32_t nstarts = labels_some ? nql : 1u;
+        if (a.default_start == VS_INVALID_NODE || a.n == 0) nstarts = 0;  // ListSearchResult::empty()
+        for (uint32_t si = 0; si < nstarts; ++si) {
+            uint32_t sn = VS_INVALID_NODE;
+            if (!labels_some) {
+                sn = a.default_start;
+            } else {
+                int16_t lab = ql[si];
+                int lo = 0, hi = (int)a.n_ls;  // binary search in the sorted label->start map
+                while (lo < hi) {
+                    int mid = (lo + hi) >> 1;
+                    if (a.ls_labels[mid] < lab) lo = mid + 1;
+                    else hi = mid;
+                }
+                if (lo < (int)a.n_ls && a.ls_labels[lo] == lab) sn = a.ls_nodes[lo];
+            }
+            sn = rfl(sn);
+            if (sn == VS_INVALID_NODE) continue;
+            // create_lsn_for_start_node (AM/sbq/storage.rs:365-391): prepare_insert, read node, distance, push
+            uint32_t fresh = 0;
+            if (lane == 0) {
+                uint32_t hslot = hash_u32(sn) & hmask;
+                while (true) {
+                    uint32_t old = atomicCAS(&hash[hslot], VS_EMPTY, sn);
+                    if (old == VS_EMPTY) { fresh = 1; break; }
+                    if (old == sn) break;
+                    hslot = (hslot + 1) & hmask;
+                }
+            }
+            fresh = rfl(fresh);
+            if (!fresh) continue;
+            ninserted++;
+            st_reads++;
+            uint32_t d = ham_row4(a.codes + (size_t)sn * a.code_stride, qc, lane & 3, a.code_stride, lane < 4);
+            d = rfl(d);
+            st_dq++;
+            st_cand++;
+            if (lane == 0) cand_ids[npush] = sn;
+            heap.push((d << 16) | npush, lane);
+            npush++;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+
+    // ---- TSVResponseIterator::next, repeated until M rows are emitted (AM/scan.rs:210-242) ----
+    while (emitted < s.M && status == 0) {
+        st_next++;
+        bool got = false;
+        while (true) {  // "Iterate until we find a non-deleted tuple"
+            // ---- greedy_search_iterate (AM/graph/mod.rs:357-385) ----
+            while (true) {
+                // visit_closest(L) (AM/graph/mod.rs:153-170)
+                if (heap.len == 0) break;
+                if (vlen > s.L) {
+                    uint32_t node_at_pos = rfl(vdist[s.L - 1]);
+                    if ((heap.peek() >> 16) >= node_at_pos) break;
+                }
+                uint32_t head = heap.pop(lane);
+                const uint32_t hd = head >> 16;
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                const uint32_t node = rfl(cand_ids[head & 0xFFFFu]);
+                // visited.insert(partition_point(|x| *x < head), head): before the first element >= head
+                if (vlen + 1 > s.vcap) { status |= OVF_VISITED; break; }
+                {
+                    uint32_t cntlt = 0;
+                    for (uint32_t base = 0; base < vlen; base += WAVE) {
+                        uint32_t i = base + lane;
+                        bool lt = i < vlen && vdist[i] < hd;
+                        cntlt += (uint32_t)__popcll(__ballot(lt));
+                    }
+                    const uint32_t idx = cntlt;
+                    uint32_t hi = vlen;
+                    while (hi > idx) {  // shift [idx, vlen) right by one, top chunk first
+                        uint32_t lo = (hi - idx > WAVE) ? hi - WAVE : idx;
+                        uint32_t i = lo + lane;
+                        uint32_t td = 0, ti = 0;
+                        if (i < hi) { td = vdist[i]; ti = vid[i]; }
+                        __syncthreads();
+                        if (i < hi) { vdist[i + 1] = td; vid[i + 1] = ti; }
+                        __syncthreads();
+                        hi = lo;
+                    }
+                    if (lane == 0) { vdist[idx] = hd; vid[idx] = node; }
+                    vlen++;
+                    __syncthreads();
+                }
+                st_visits++;
+                // ---- visit_lsn_internal, Disk arm (AM/sbq/storage.rs:135-190) ----
+                st_reads++;  // SbqNode::read(visiting)
+                const uint32_t* nrow = a.nbrs + (size_t)node * a.nbr_stride;
+                bool list_ended = false;
+                for (uint32_t c0 = 0; c0 < a.R && !list_ended && status == 0; c0 += WAVE) {
+                    uint32_t slot = c0 + lane;
+                    uint32_t nid = (slot < a.R) ? nrow[slot] : VS_INVALID_NODE;
+                    // list ends at the first InvalidBlockNumber (AM/sbq/node.rs:260-285)
+                    uint64_t inval = __ballot(nid == VS_INVALID_NODE);
+                    uint32_t nvalid = inval ? (uint32_t)__builtin_ctzll(inval) : WAVE;
+                    if (nvalid < WAVE) list_ended = true;
+                    bool act = (uint32_t)lane < nvalid;
+                    // prepare_insert: HashSet::insert (marks BEFORE the label check, AM/sbq/storage.rs:148-172)
+                    bool fresh = false;
+                    if (act) {
+                        uint32_t hslot = hash_u32(nid) & hmask;
+                        for (uint32_t probe = 0; probe <= hmask; ++probe) {
+                            uint32_t old = atomicCAS(&hash[hslot], VS_EMPTY, nid);
+                            if (old == VS_EMPTY) { fresh = true; break; }
+                            if (old == nid) break;
+                            hslot = (hslot + 1) & hmask;
+                        }
+                    }
+                    uint64_t fm = __ballot(fresh);
+                    uint32_t nfresh = (uint32_t)__popcll(fm);
+                    ninserted += nfresh;
+                    st_reads += nfresh;  // SbqNode::read(neighbor)
+                    if (ninserted * 4u > s.hashcap * 3u) { status |= OVF_HASH; break; }
+                    // label filter: query.labels.overlaps(node.labels) (AM/labels/mod.rs:124-142)
+                    bool pass = fresh;
+                    if (fresh && has_label_filter) {
+                        uint32_t lb = a.label_off[nid], le = a.label_off[nid + 1];
+                        uint32_t i = 0, j = lb;
+                        bool ov = false;
+                        while (i < nql && j < le) {
+                            int16_t x = ql[i], y = a.label_val[j];
+                            if (x == y) { ov = true; break; }
+                            if (x < y) ++i;
+                            else ++j;
+                        }
+                        pass = ov;
+                    }
+                    uint64_t pm = __ballot(pass);
+                    uint32_t c = (uint32_t)__popcll(pm);
+                    if (c == 0) continue;
+                    // compact survivors in neighbor-list order
+                    if (pass) surv_id[__popcll(pm & ((1ull << lane) - 1ull))] = nid;
+                    __syncthreads();
+                    // distances: 4 lanes per code row, 16 rows per pass, all loads of the chunk issued up front
+#pragma unroll
+                    for (int pass_i = 0; pass_i < 4; ++pass_i) {
+                        uint32_t j = (uint32_t)pass_i * 16u + (uint32_t)(lane >> 2);
+                        bool valid = j < c;
+                        uint32_t id = valid ? surv_id[j] : 0;
+                        uint32_t d = ham_row4(a.codes + (size_t)id * a.code_stride, qc, lane & 3, a.code_stride, valid);
+                        if (valid && (lane & 3) == 0) surv_d[j] = d;
+                    }
+                    st_dq += c;
+                    st_cand += c;
+                    if (npush + c > s.idcap) { status |= OVF_IDS; break; }
+                    if (heap.len + c > s.hcap) { status |= OVF_HEAP; break; }
+                    if ((uint32_t)lane < c) cand_ids[npush + lane] = surv_id[lane];
+                    __syncthreads();
+                    // insert_neighbor in list order (AM/graph/mod.rs:144-147)
+                    for (uint32_t j = 0; j < c; ++j) {
+                        uint32_t d = rfl(surv_d[j]);
+                        heap.push((d << 16) | (npush + j), lane);
+                    }
+                    npush += c;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                }
+                if (status) break;
+            }
+            if (status) break;
+            // ---- consume (AM/graph/mod.rs:174-184) + return_lsn (AM/sbq/storage.rs:404-414) ----
+            if (vlen == 0) break;  // None
+            __syncthreads();
+            const uint32_t fd = rfl(vdist[0]);
+            const uint32_t fnode = rfl(vid[0]);
+            {   // visited.remove(0)
+                uint32_t lo = 1;
+                while (lo < vlen) {
+                    uint32_t i = lo + lane;
+                    uint32_t hi = min(lo + WAVE, vlen);
+                    uint32_t td = 0, ti = 0;
+                    if (i < hi) { td = vdist[i]; ti = vid[i]; }
+                    __syncthreads();
+                    if (i < hi) { vdist[i - 1] = td; vid[i - 1] = ti; }
+                    __syncthreads();
+                    lo = hi;
+                }
+                vlen--;
+            }
+            st_reads++;
+            const uint64_t tid = a.tids[fnode];
+            if ((tid & 0xFFFFull) == 0) continue;  // InvalidOffsetNumber: deleted tuple (AM/scan.rs:231-234)
+            if (lane == 0) {
+                s.out_ids[(size_t)q * s.M + emitted] = fnode;
+                s.out_ham[(size_t)q * s.M + emitted] = fd;
+            }
+            emitted++;
+            got = true;
+            break;
+        }
+        if (!got) break;
+    }
+    for (uint32_t i = emitted + lane; i < s.M; i += WAVE) {
+        s.out_ids[(size_t)q * s.M + i] = VS_INVALID_NODE;
+        s.out_ham[(size_t)q * s.M + i] = 0xFFFFFFFFu;
+    }
+    if (lane == 0) {
+        s.out_cnt[q] = emitted;
+        s.status[q] = status;
+        uint32_t* st = s.stats + (size_t)q * ST_N;
+        st[ST_VISITS] = st_visits;
+        st[ST_CAND] = st_cand;
+        st[ST_DQ] = st_dq;
+        st[ST_READS] = st_reads;
+        st[ST_NEXT] = st_next;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Rescore window of next_with_resort (AM/scan.rs:244-305): BinaryHeap<ResortData> with
+// cmp(self, other) = other.distance.total_cmp(self.distance)  (AM/scan.rs:111-117).  One thread per query.
+// heap entries: (total_cmp key as i32 in the high word, stream position in the low word).
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int32_t total_key(float f) {
+    int32_t b = __float_as_int(f);
+    b ^= (int32_t)(((uint32_t)(b >> 31)) >> 1);
+    return b;
+}
+
+__global__ void k_resort(uint32_t nq, uint32_t M, uint32_t rescore, uint32_t k, const uint32_t* __restrict__ stream,
+                         const uint32_t* __restrict__ cnt, const float* __restrict__ dist, const uint64_t* __restrict__ tids,
+                         uint64_t* __restrict__ heap_ws, uint32_t* __restrict__ out_ids, uint64_t* __restrict__ out_tids,
+                         float* __restrict__ out_dist) {
+    uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    const uint32_t n = min(cnt[q], M);
+    const uint32_t* sid = stream + (size_t)q * M;
+    const float* sd = dist ? dist + (size_t)q * M : nullptr;
+    uint32_t produced = 0;
+    if (rescore == 0) {  // resort_buffer.capacity() == 0 -> plain next()
+        for (; produced < k && produced < n; ++produced) {
+            uint32_t id = sid[produced];
+            out_ids[(size_t)q * k + produced] = id;
+            if (out_tids) out_tids[(size_t)q * k + produced] = tids[id];
+            if (out_dist) out_dist[(size_t)q * k + produced] = __int_as_float(0x7fc00000);
+        }
+    } else {
+        uint64_t* h = heap_ws + (size_t)q * rescore;
+        uint32_t len = 0, pos = 0;
+        // le(a,b) (Rust a <= b for ResortData) == key(b) <= key(a)
+        auto kof = [](uint64_t e) { return (int32_t)(uint32_t)(e >> 32); };
+        auto sift_up = [&](uint32_t p, uint64_t elem) {
+            while (p > 0) {
+                uint32_t parent = (p - 1) >> 1;
+                uint64_t pe = h[parent];
+                if (kof(pe) <= kof(elem)) break;  // elem <= parent
+                h[p] = pe;
+                p = parent;
+            }
+            h[p] = elem;
+        };
+        while (produced < k) {
+            while (len < rescore && pos < n) {
+                uint64_t e = ((uint64_t)(uint32_t)total_key(sd[pos]) << 32) | pos;
+                uint32_t p = len++;
+                sift_up(p, e);
+                ++pos;
+            }
+            if (len == 0) break;
+            uint64_t item = h[--len];
+            uint64_t top = item;
+            if (len > 0) {
+                top = h[0];
+                uint32_t end = len, p = 0, child = 1;
+                uint32_t lim = end >= 2 ? end - 2 : 0;
+                while (child <= lim) {
+                    uint64_t le = h[child], ri = h[child + 1];
+                    uint32_t pick = (kof(ri) <= kof(le)) ? 1u : 0u;  // data[child] <= data[child+1]
+                    child += pick;
+                    h[p] = pick ? ri : le;
+                    p = child;
+                    child = 2 * p + 1;
+                }
+                if (child == end - 1) {
+                    h[p] = h[child];
+                    p = child;
+                }
+                sift_up(p, item);
+            }
+            uint32_t sp = (uint32_t)top;
+            uint32_t id = sid[sp];
+            out_ids[(size_t)q * k + produced] = id;
+            if (out_tids) out_tids[(size_t)q * k + produced] = tids[id];
+            if (out_dist) out_dist[(size_t)q * k + produced] = sd[sp];
+            ++produced;
+        }
+    }
+    for (; produced < k; ++produced) {
+        out_ids[(size_t)q * k + produced] = VS_INVALID_NODE;
+        if (out_tids) out_tids[(size_t)q * k + produced] = 0;
+        if (out_dist) out_dist[(size_t)q * k + produced] = __int_as_float(0x7fc00000);
+    }
+}
+
+// ===============================================================================================================
+// launch wrappers
+// ===============================================================================================================
+static float count_as_f32(uint64_t c) { return (float)c; }
+
+int launch_prepare_queries(vs_index* idx, const float* d_raw, uint32_t nq, float* d_q_full, uint64_t* d_qcodes) {
+    if (nq == 0) return VS_OK;
+    const vs_index_desc& d = idx->d;
+    size_t lds = (round_up_u32(d.dim_full, 4) + round_up_u32(d.dim_index, 4) + 4) * sizeof(float);
+    VS_REQUIRE(lds <= 160 * 1024, "query too large for LDS staging (%u dims)", d.dim_full);
+    hipLaunchKernelGGL(k_prepare_queries, dim3(nq), dim3(WAVE), lds, idx->ctx->stream, d_raw, nq, d.dim_full,
+                       d.dim_index, idx->vec_stride, d.distance_type, d.bits, idx->mean, idx->m2,
+                       count_as_f32(idx->count), d.words, idx->code_stride, d_q_full, d_qcodes);
+    VS_HIP(hipGetLastError());
+    return VS_OK;
+}
+
+int launch_quantize_rows(vs_index* idx, const float* d_rows, uint32_t row_stride, uint32_t nrows, uint64_t* d_codes,
+                         uint32_t code_stride) {
+    if (nrows == 0) return VS_OK;
+    const vs_index_desc& d = idx->d;
+    uint32_t grid = nrows < 65536u * 16 ? nrows : 65536u * 16;
+    hipLaunchKernelGGL(k_quantize_rows, dim3(grid), dim3(WAVE), 0, idx->ctx->stream, d_rows, row_stride, nrows,
+                       d.dim_index, d.bits, idx->mean, idx->m2, count_as_f32(idx->count), d.words, code_stride, d_codes);
+    VS_HIP(hipGetLastError());
+    return VS_OK;
+}
+
+int launch_hamming_gather(vs_index* idx, const uint64_t* d_qcodes, const uint32_t* d_ids, const uint32_t* d_off,
+                          uint32_t nq, uint32_t* d_out) {
+    if (nq == 0) return VS_OK;
+    size_t lds = (size_t)idx->code_stride * 8;
+    hipLaunchKernelGGL(k_hamming_gather, dim3(nq), dim3(WAVE), lds, idx->ctx->stream, idx->codes, idx->code_stride,
+                       d_qcodes, d_ids, d_off, nq, d_out);
+    VS_HIP(hipGetLastError());
+    return VS_OK;
+}
+
+int launch_rerank(vs_index* idx, const float* d_q_full, const uint32_t* d_ids, const uint32_t* d_off,
+                  const uint32_t* d_cnt, uint32_t fixed_m, uint32_t nq, float* d_out) {
+    if (nq == 0) return VS_OK;
+    VS_REQUIRE(idx->vecs != nullptr, "index has no vector column: rerank impossible");
+    size_t lds = (size_t)idx->vec_stride * 4;
+    hipLaunchKernelGGL(k_rerank, dim3(nq), dim3(256), lds, idx->ctx->stream, idx->vecs, idx->vec_stride,
+                       idx->d.dim_full, idx->vnorm, idx->d.distance_type, d_q_full, d_ids, d_off, d_cnt, fixed_m, nq,
+                       d_out);
+    VS_HIP(hipGetLastError());
+    return VS_OK;
+}
+
+static size_t search_lds_bytes(const vs_index* idx, const SearchLaunch& s) {
+    size_t words32 = round_up_u32(s.hcap + 2, 4) + 2 * (size_t)round_up_u32(s.vcap, 4) + 128;
+    return words32 * 4 + (size_t)idx->code_stride * 8 + MAX_QLABELS * 2 + 16;
+}
+
+int launch_search(vs_index* idx, const SearchLaunch& s) {
+    if (s.nq == 0) return VS_OK;
+    SearchArgs a;
+    a.codes = idx->codes;
+    a.nbrs = idx->nbrs;
+    a.tids = idx->tids;
+    a.label_off = idx->label_off;
+    a.label_val = idx->label_val;
+    a.ls_labels = idx->ls_labels;
+    a.ls_nodes = idx->ls_nodes;
+    a.code_stride = idx->code_stride;
+    a.nbr_stride = idx->nbr_stride;
+    a.R = idx->d.num_neighbors;
+    a.n = idx->d.n;
+    a.n_ls = idx->d.n_label_starts;
+    a.default_start = idx->d.default_start;
+    a.s = s;
+    size_t lds = search_lds_bytes(idx, s);
+    if (lds > 160 * 1024) {
+        vs_set_error("search_list_size too large for the LDS-resident candidate heap (%zu B needed)", lds);
+        return VS_ERR_CAPACITY;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        VS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_search), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_search, dim3(s.nq), dim3(WAVE), lds, idx->ctx->stream, a);
+    VS_HIP(hipGetLastError());
+    return VS_OK;
+}
+
+size_t vs_search_lds_bytes(const vs_index* idx, const SearchLaunch& s) { return search_lds_bytes(idx, s); }
+
+int launch_resort(vs_index* idx, uint32_t nq, uint32_t M, uint32_t rescore, uint32_t k, const uint32_t* d_stream_ids,
+                  const uint32_t* d_cnt, const float* d_dist, uint64_t* d_heap_ws, uint32_t* d_out_ids,
+                  uint64_t* d_out_tids, float* d_out_dist) {
+    if (nq == 0) return VS_OK;
+    hipLaunchKernelGGL(k_resort, dim3((nq + 63) / 64), dim3(64), 0, idx->ctx->stream, nq, M, rescore, k, d_stream_ids,
+                       d_cnt, d_dist, idx->tids, d_heap_ws, d_out_ids, d_out_tids, d_out_dist);
+    VS_HIP(hipGetLastError());
+    return VS_OK;
+}
+
+int launch_row_norms(vs_index* idx) {
+    if (!idx->vecs || idx->d.n == 0) return VS_OK;
+    uint32_t blocks = (idx->d.n + 63) / 64;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_row_norms, dim3(blocks), dim3(WAVE), 0, idx->ctx->stream, idx->vecs, idx->vec_stride,
+                       idx->d.dim_full, idx->d.n, idx->vnorm);
+    VS_HIP(hipGetLastError());
+    return VS_OK;
+}
+
+int launch_validate_nbrs(vs_index* idx, uint32_t* d_flag) {
+    if (idx->d.n == 0) return VS_OK;
+    hipLaunchKernelGGL(k_validate_nbrs, dim3((idx->d.n + 255) / 256), dim3(256), 0, idx->ctx->stream, idx->nbrs,
+                       idx->nbr_stride, idx->d.num_neighbors, idx->d.n, d_flag);
+    VS_HIP(hipGetLastError());
+    return VS_OK;
+}

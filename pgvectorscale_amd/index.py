@@ -1,0 +1,342 @@
+"""Host-side mirror of the reference's scan interface for the `diskann` access method.
+
+Names follow the reference: `DiskAnnIndex` stands for the index relation (MetaPage + SbqNode pages + SbqMeans,
+AM/meta_page.rs, AM/sbq/node.rs), `IndexScan` for the IndexScanDesc whose lifecycle is
+ambeginscan -> amrescan -> amgettuple* -> amendscan (AM/scan.rs:308-456).  Everything is computed by libvsgpu.so on
+the MI355X; this module only marshals numpy arrays into the C ABI.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import VS_COSINE, VS_INVALID_NODE, VS_IP, VS_L2, IndexDesc, IndexHost, Stats, check  # noqa: F401
+
+# GUC defaults (AM/guc.rs:3-4) and index defaults (AM/meta_page.rs:284-323)
+DEFAULT_QUERY_SEARCH_LIST_SIZE = 100
+DEFAULT_QUERY_RESCORE = 50
+DEFAULT_NUM_NEIGHBORS = 50
+
+
+def default_bits(dims_to_index):
+    return 2 if dims_to_index < 900 else 1
+
+
+def quantized_size(dims, bits):
+    return (dims * bits + 63) // 64
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """One MI355X + its streams and pinned staging buffers."""
+
+    def __init__(self, device=0):
+        self._L = _lib.load()
+        h = C.c_void_p()
+        check(self._L.vs_ctx_create(device, C.byref(h)))
+        self.h = h
+        self.device = device
+
+    def device_name(self):
+        buf = C.create_string_buffer(256)
+        check(self._L.vs_ctx_device_name(self.h, buf, 256))
+        return buf.value.decode()
+
+    def mem_info(self):
+        f, t = C.c_uint64(), C.c_uint64()
+        check(self._L.vs_ctx_mem_info(self.h, C.byref(f), C.byref(t)))
+        return int(f.value), int(t.value)
+
+    def sync(self):
+        check(self._L.vs_ctx_sync(self.h))
+
+    def alloc(self, nbytes):
+        p = C.c_void_p()
+        check(self._L.vs_dev_alloc(self.h, nbytes, C.byref(p)))
+        return p
+
+    def free(self, p):
+        check(self._L.vs_dev_free(self.h, p))
+
+    def upload(self, dev_ptr, arr):
+        arr = np.ascontiguousarray(arr)
+        check(self._L.vs_dev_upload(self.h, dev_ptr, _p(arr), arr.nbytes))
+
+    def download(self, dev_ptr, arr):
+        assert arr.flags["C_CONTIGUOUS"]
+        check(self._L.vs_dev_download(self.h, _p(arr), dev_ptr, arr.nbytes))
+        return arr
+
+    def close(self):
+        if self.h:
+            self._L.vs_ctx_destroy(self.h)
+            self.h = None
+
+
+class DiskAnnIndex:
+    """A `diskann` index resident in HBM."""
+
+    def __init__(self, ctx, handle):
+        self.ctx = ctx
+        self._L = ctx._L
+        self.h = handle
+        d = IndexDesc()
+        check(self._L.vs_index_get_desc(self.h, C.byref(d)))
+        self.desc = d
+
+    # -- construction ---------------------------------------------------------------------------------------------
+    @classmethod
+    def upload(cls, ctx, *, codes, nbrs, heap_tids, vecs, mean, m2, count, bits, dim_index, num_neighbors,
+               distance_type, default_start, label_off=None, label_val=None, label_starts=None):
+        codes = np.ascontiguousarray(codes, np.uint64)
+        nbrs = np.ascontiguousarray(nbrs, np.uint32)
+        heap_tids = np.ascontiguousarray(heap_tids, np.uint64)
+        vecs = None if vecs is None else np.ascontiguousarray(vecs, np.float32)
+        mean = np.ascontiguousarray(mean, np.float32)
+        m2 = None if m2 is None else np.ascontiguousarray(m2, np.float32)
+        n, w = codes.shape
+        d = IndexDesc()
+        d.n, d.dim_index, d.bits, d.words = n, dim_index, bits, w
+        d.dim_full = dim_index if vecs is None else vecs.shape[1]
+        d.num_neighbors, d.distance_type = num_neighbors, distance_type
+        d.has_labels = int(label_off is not None)
+        d.default_start = default_start
+        ls = sorted((label_starts or {}).items())
+        d.n_label_starts = len(ls)
+        lsl = np.array([k for k, _ in ls], np.int16)
+        lsn = np.array([v for _, v in ls], np.uint32)
+        lo = None if label_off is None else np.ascontiguousarray(label_off, np.uint32)
+        lv = None if label_val is None else np.ascontiguousarray(label_val, np.int16)
+        h = IndexHost()
+        h.codes, h.nbrs, h.nbr_stride = _p(codes).value, _p(nbrs).value, nbrs.shape[1]
+        h.heap_tids = _p(heap_tids).value
+        h.vecs = None if vecs is None else _p(vecs).value
+        h.mean = _p(mean).value
+        h.m2 = None if m2 is None else _p(m2).value
+        h.count = count
+        h.label_off = None if lo is None else _p(lo).value
+        h.label_val = None if lv is None else _p(lv).value
+        h.label_start_labels = _p(lsl).value if len(ls) else None
+        h.label_start_nodes = _p(lsn).value if len(ls) else None
+        out = C.c_void_p()
+        check(ctx._L.vs_index_upload(ctx.h, C.byref(d), C.byref(h), C.byref(out)))
+        return cls(ctx, out)
+
+    @classmethod
+    def alloc(cls, ctx, *, n, dim_full, dim_index=None, bits=None, num_neighbors=DEFAULT_NUM_NEIGHBORS,
+              distance_type=VS_L2, with_vecs=True):
+        dim_index = dim_index or dim_full
+        bits = bits or default_bits(dim_index)
+        d = IndexDesc()
+        d.n, d.dim_full, d.dim_index, d.bits = n, dim_full, dim_index, bits
+        d.words = quantized_size(dim_index, bits)
+        d.num_neighbors, d.distance_type, d.has_labels = num_neighbors, distance_type, 0
+        d.default_start, d.n_label_starts = VS_INVALID_NODE, 0
+        out = C.c_void_p()
+        check(ctx._L.vs_index_alloc(ctx.h, C.byref(d), int(with_vecs), C.byref(out)))
+        return cls(ctx, out)
+
+    def _refresh(self):
+        check(self._L.vs_index_get_desc(self.h, C.byref(self.desc)))
+
+    def array(self, which):
+        p, s = C.c_void_p(), C.c_uint32()
+        check(self._L.vs_index_array(self.h, which, C.byref(p), C.byref(s)))
+        return p, int(s.value)
+
+    def set_quantizer(self, mean, m2, count):
+        mean = np.ascontiguousarray(mean, np.float32)
+        m2 = None if m2 is None else np.ascontiguousarray(m2, np.float32)
+        check(self._L.vs_index_set_quantizer(self.h, _p(mean), _p(m2), count))
+
+    def get_quantizer(self):
+        mean = np.empty(self.desc.dim_index, np.float32)
+        m2 = np.empty(self.desc.dim_index, np.float32)
+        cnt = C.c_uint64()
+        check(self._L.vs_index_get_quantizer(self.h, _p(mean), _p(m2), C.byref(cnt)))
+        return mean, m2, int(cnt.value)
+
+    def set_start_nodes(self, default_start, label_starts=None):
+        ls = sorted((label_starts or {}).items())
+        lsl = np.array([k for k, _ in ls], np.int16)
+        lsn = np.array([v for _, v in ls], np.uint32)
+        check(self._L.vs_index_set_start_nodes(self.h, default_start, _p(lsl), _p(lsn), len(ls)))
+        self._refresh()
+
+    def set_labels(self, label_off, label_val):
+        lo = np.ascontiguousarray(label_off, np.uint32)
+        lv = np.ascontiguousarray(label_val, np.int16)
+        check(self._L.vs_index_set_labels(self.h, _p(lo), _p(lv)))
+        self._refresh()
+
+    def download(self, codes=True, nbrs=True, tids=True, vecs=False, row_begin=0, row_count=None):
+        n = self.desc.n if row_count is None else row_count
+        out = {}
+        c = np.empty((n, self.desc.words), np.uint64) if codes else None
+        nb = np.empty((n, self.desc.num_neighbors), np.uint32) if nbrs else None
+        t = np.empty(n, np.uint64) if tids else None
+        v = np.empty((n, self.desc.dim_full), np.float32) if vecs else None
+        check(self._L.vs_index_download(self.h, _p(c), _p(nb), _p(t), _p(v), row_begin, n))
+        out.update(codes=c, nbrs=nb, heap_tids=t, vecs=v)
+        return out
+
+    def mark_deleted(self, nodes):
+        a = np.ascontiguousarray(nodes, np.uint32)
+        check(self._L.vs_index_mark_deleted(self.h, _p(a), a.size))
+
+    def refresh_norms(self):
+        check(self._L.vs_index_refresh_norms(self.h))
+
+    # -- build-side helpers -----------------------------------------------------------------------------------------
+    def sbq_train(self):
+        check(self._L.vs_sbq_train(self.h))
+
+    def sbq_quantize_corpus(self):
+        check(self._L.vs_sbq_quantize_corpus(self.h))
+
+    def build_graph(self, search_list_size=100, max_alpha=1.2, batch_max=0, seed=0):
+        check(self._L.vs_build_graph(self.h, search_list_size, max_alpha, batch_max, seed))
+        self._refresh()
+
+    # -- single kernels ------------------------------------------------------------------------------------------------
+    def quantize(self, q):
+        q = np.ascontiguousarray(q, np.float32).reshape(-1, self.desc.dim_index)
+        out = np.empty((q.shape[0], self.desc.words), np.uint64)
+        check(self._L.vs_quantize(self.h, _p(q), q.shape[0], _p(out)))
+        return out
+
+    @staticmethod
+    def _csr(lists):
+        off = np.zeros(len(lists) + 1, np.uint32)
+        for i, l in enumerate(lists):
+            off[i + 1] = off[i] + len(l)
+        flat = np.concatenate([np.asarray(l, np.uint32) for l in lists]) if len(lists) and off[-1] else np.zeros(0, np.uint32)
+        return np.ascontiguousarray(flat, np.uint32), off
+
+    def hamming_gather(self, qcodes, id_lists):
+        qcodes = np.ascontiguousarray(qcodes, np.uint64).reshape(-1, self.desc.words)
+        ids, off = self._csr(id_lists)
+        out = np.empty(ids.size, np.uint32)
+        check(self._L.vs_hamming_gather(self.h, _p(qcodes), _p(ids), _p(off), qcodes.shape[0], _p(out)))
+        return [out[off[i]:off[i + 1]] for i in range(len(id_lists))]
+
+    def rerank(self, queries, id_lists):
+        q = np.ascontiguousarray(queries, np.float32).reshape(-1, self.desc.dim_full)
+        ids, off = self._csr(id_lists)
+        out = np.empty(ids.size, np.float32)
+        check(self._L.vs_rerank(self.h, _p(q), _p(ids), _p(off), q.shape[0], _p(out)))
+        return [out[off[i]:off[i + 1]] for i in range(len(id_lists))]
+
+    def scan_topk(self, qcodes, k):
+        qcodes = np.ascontiguousarray(qcodes, np.uint64).reshape(-1, self.desc.words)
+        nq = qcodes.shape[0]
+        ids = np.empty((nq, k), np.uint32)
+        ham = np.empty((nq, k), np.uint32)
+        check(self._L.vs_scan_topk(self.h, _p(qcodes), nq, k, _p(ids), _p(ham)))
+        return ids, ham
+
+    # -- batched scans ---------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _label_keys(qlabels, nq):
+        if qlabels is None:
+            return None, None
+        assert len(qlabels) == nq
+        off = np.zeros(nq + 1, np.uint32)
+        vals = []
+        for i, l in enumerate(qlabels):
+            vals.extend(int(x) for x in l)
+            off[i + 1] = len(vals)
+        return np.array(vals, np.int16), off
+
+    def search_batch(self, queries, search_list_size=DEFAULT_QUERY_SEARCH_LIST_SIZE, rescore=DEFAULT_QUERY_RESCORE,
+                     k=10, qlabels=None):
+        """For each query: the rows of the first k amgettuple calls (node ids, heap TIDs, reranked distances)."""
+        q = np.ascontiguousarray(queries, np.float32).reshape(-1, self.desc.dim_full)
+        nq = q.shape[0]
+        lv, lo = self._label_keys(qlabels, nq)
+        ids = np.empty((nq, k), np.uint32)
+        tids = np.empty((nq, k), np.uint64)
+        dist = np.empty((nq, k), np.float32)
+        st = Stats()
+        check(self._L.vs_search_batch(self.h, _p(q), _p(lv), _p(lo), nq, search_list_size, rescore, k, _p(ids), _p(tids),
+                                      _p(dist), C.byref(st)))
+        return ids, tids, dist, st.as_dict()
+
+    def stream_batch(self, queries, search_list_size=DEFAULT_QUERY_SEARCH_LIST_SIZE, m=59, qlabels=None):
+        q = np.ascontiguousarray(queries, np.float32).reshape(-1, self.desc.dim_full)
+        nq = q.shape[0]
+        lv, lo = self._label_keys(qlabels, nq)
+        ids = np.empty((nq, m), np.uint32)
+        ham = np.empty((nq, m), np.uint32)
+        st = Stats()
+        check(self._L.vs_stream_batch(self.h, _p(q), _p(lv), _p(lo), nq, search_list_size, m, _p(ids), _p(ham),
+                                      C.byref(st)))
+        return ids, ham, st.as_dict()
+
+    def search_batch_dev(self, d_queries, nq, search_list_size, rescore, k, d_out_ids, d_out_tids=None, d_out_dist=None):
+        check(self._L.vs_search_batch_dev(self.h, d_queries, None, None, nq, search_list_size, rescore, k, d_out_ids,
+                                          d_out_tids, d_out_dist))
+
+    def search_batch_dev_finish(self):
+        st = Stats()
+        check(self._L.vs_search_batch_dev_finish(self.h, C.byref(st)))
+        return st.as_dict()
+
+    def bruteforce_topk(self, d_queries, nq, k):
+        ids = np.empty((nq, k), np.uint32)
+        dist = np.empty((nq, k), np.float32)
+        check(self._L.vs_bruteforce_topk(self.h, d_queries, nq, k, _p(ids), _p(dist)))
+        return ids, dist
+
+    # -- the access-method surface ------------------------------------------------------------------------------------------
+    def beginscan(self):
+        """ambeginscan (AM/scan.rs:308-333)"""
+        return IndexScan(self)
+
+    def close(self):
+        if self.h:
+            self._L.vs_index_free(self.h)
+            self.h = None
+
+
+class IndexScan:
+    """IndexScanDesc + TSVScanState: rescan() = amrescan, gettuple() = amgettuple, endscan() = amendscan."""
+
+    def __init__(self, index):
+        self.index = index
+        self._L = index._L
+        h = C.c_void_p()
+        check(self._L.vs_beginscan(index.h, C.byref(h)))
+        self.h = h
+
+    def rescan(self, query, labels=None, search_list_size=DEFAULT_QUERY_SEARCH_LIST_SIZE, rescore=DEFAULT_QUERY_RESCORE):
+        """query=None is the SQL NULL query; labels=None means no scan key (nkeys == 0)."""
+        q = None if query is None else np.ascontiguousarray(query, np.float32)
+        lv = None if labels is None else np.array(labels, np.int16)
+        check(self._L.vs_rescan(self.h, _p(q), _p(lv), 0 if lv is None else lv.size, int(labels is not None),
+                                search_list_size, rescore))
+
+    def gettuple(self):
+        """Returns (heap_tid, node, distance) or None at end of scan."""
+        tid, node, d = C.c_uint64(), C.c_uint32(), C.c_float()
+        r = check(self._L.vs_gettuple(self.h, C.byref(tid), C.byref(node), C.byref(d)))
+        if r == 0:
+            return None
+        return int(tid.value), int(node.value), np.float32(d.value)
+
+    @property
+    def xs_recheck(self):
+        return bool(self._L.vs_scan_xs_recheck(self.h))
+
+    def stats(self):
+        st = Stats()
+        check(self._L.vs_scan_get_stats(self.h, C.byref(st)))
+        return st.as_dict()
+
+    def endscan(self):
+        if self.h:
+            self._L.vs_endscan(self.h)
+            self.h = None

@@ -1,0 +1,154 @@
+"""Oracle vs every known-answer test / golden vector the reference holds for this path.
+CPU only."""
+import numpy as np
+import pytest
+
+
+def _seq_norm(v):
+    s = np.float32(0)
+    for x in v:
+        s = np.float32(s + np.float32(x * x))
+    return np.float32(np.sqrt(s))
+
+
+def test_distances_equal_kat(oracle):
+    """AM/distance/distance_x86.rs:41-62 `distances_equal`: |simd - scalar| < 1e-6 on 2000-d normalised ramps."""
+    O = oracle
+    r = np.arange(2000, dtype=np.float32) + 1
+    l = np.arange(2000, dtype=np.float32) + 2
+    r = (r / _seq_norm(r)).astype(np.float32)
+    l = (l / _seq_norm(l)).astype(np.float32)
+    assert abs(float(O.distance_cosine(r, l)) - float(O.distance_cosine_unoptimized(r, l))) < 1e-6
+    assert abs(float(O.distance_l2(r, l)) - float(O.distance_l2_unoptimized(r, l))) < 1e-6
+
+
+def test_simd_lane_emulation_matches_real_avx2(oracle):
+    """The scalar restatement of the 4x8-lane AVX2 accumulation must be bit-identical to real AVX2/FMA intrinsics."""
+    O = oracle
+    if not O.have_avx2():
+        pytest.skip("host without AVX2+FMA")
+    rng = np.random.default_rng(5)
+    for n in (1, 7, 31, 32, 33, 64, 100, 128, 768, 1536, 2000):
+        a = rng.standard_normal(n).astype(np.float32)
+        b = rng.standard_normal(n).astype(np.float32)
+        assert O.distance_l2(a, b).tobytes() == O.distance_l2_avx2(a, b).tobytes()
+        assert O.inner_product(a, b).tobytes() == O.inner_product_avx2(a, b).tobytes()
+
+
+def test_bench_inputs_with_derivable_answers(oracle):
+    """benches/distance.rs:299-305: 1536-bit patterns i%2==0 vs i%3==0 -> Hamming = 768+512-2*256 = 768."""
+    O = oracle
+    a = np.array([i % 2 == 0 for i in range(1536)])
+    b = np.array([i % 3 == 0 for i in range(1536)])
+    pack = lambda x: np.packbits(x, bitorder="little").view(np.uint64)
+    assert pack(a).size == 24
+    assert O.distance_xor(pack(a), pack(b)) == 768
+    # benches/distance.rs:145-146 ramps: exact L2^2 = 2000 * 1000.1^2 in real arithmetic; f32 result within 1e-3 rel
+    r = (np.arange(2000, dtype=np.float32) + np.float32(1000.1)).astype(np.float32)
+    l = (np.arange(2000, dtype=np.float32) + np.float32(2000.2)).astype(np.float32)
+    exact = float(np.sum((r.astype(np.float64) - l.astype(np.float64)) ** 2))
+    assert abs(float(O.distance_l2(r, l)) - exact) / exact < 1e-5
+
+
+@pytest.mark.parametrize("a,b,expect", [
+    ([], [1, 2, 3], False),                        # test_overlaps_empty           AM/labels/mod.rs:253-259
+    ([1, 2], [2, 3], True),                        # test_overlaps_non_empty       :261-267
+    ([1, 2], [3, 4], False),                       # test_overlaps_no_overlap      :269-275
+    ([1, 2, 3, 4, 5], [1, 2, 3, 4], True),         # test_overlaps_longer          :277-283
+    ([1, 2, 3, 4, 5], [6, 7, 8, 9, 10], False),    # test_overlaps_non_empty_no_overlap :285-291
+    ([1, 2, 3, 4, 5], [2, 3, 4, 5, 6], True),      # test_overlaps_non_empty_overlap    :293-299
+    ([1, 3, 5, 10, 11], [2, 4, 6, 8, 11], True),   # test_overlaps_interleavings   :301-307
+])
+def test_label_overlaps_kat(oracle, a, b, expect):
+    assert oracle.labels_overlap(a, b) is expect
+    assert oracle.labels_overlap(b, a) is expect
+
+
+def test_contains_intersection_kat(oracle):
+    """AM/labels/mod.rs:309-330 (first three contains_intersection tests)."""
+    O = oracle
+    a, b = [1, 3, 5, 10, 11], [2, 4, 6, 8, 11]
+    c = list(range(1, 12))
+    assert O.labels_contains_intersection(c, a, b) and O.labels_contains_intersection(c, b, a)
+    assert O.labels_contains_intersection([1, 2, 3], [], [1, 2, 3])
+    assert O.labels_contains_intersection([1, 2, 3], [1, 2, 3], [])
+    assert O.labels_contains_intersection([7], [1, 2, 3], [4, 5, 6])  # empty intersection is contained in anything
+
+
+@pytest.mark.parametrize("l,r,expect", [
+    ([None, None, None], [None, None, None], False),   # test_empty_overlap   AM/mod.rs:324-334
+    ([3, 1, 2], [6, 2, 4], True),                      # test_simple_overlap  :336-346
+    ([3, 1, 2], [8, 4, 6], False),                     # test_no_overlap      :348-358
+    ([2, 1, 3, 2], [6, 4, 2], True),                   # test_repeated_overlap :360-370
+    ([19, 3, 2, 15, 7, 1, 14, 10, 11, 8, 13, 12, 9, 16, 17, 18, 2], [8, 6, 2, 4, 7], True),   # :372-383
+    ([33, 2, 30, 5, 10, 20, 23, 24, 25, 26, 27, 28, 29, 1, 31, 32, 3], [9, 4, 8, 6], False),  # :385-396
+])
+def test_smallint_array_overlap_kat(oracle, l, r, expect):
+    assert oracle.smallint_array_overlap(l, r) is expect
+
+
+def test_labelset_from_sorts_and_dedups(oracle):
+    assert list(oracle.labelset([3, 1, 2, 3, 1])) == [1, 2, 3]  # AM/labels/mod.rs:30-37
+
+
+def test_quantized_size_and_default_bits(oracle):
+    O = oracle
+    assert O.quantized_size(128, 2) == 4 and O.quantized_size(768, 2) == 24 and O.quantized_size(1536, 1) == 24
+    assert O.quantized_size(65, 1) == 2 and O.quantized_size(16000, 1) == 250
+    assert O.default_bits(768) == 2 and O.default_bits(899) == 2 and O.default_bits(900) == 1 and O.default_bits(1536) == 1
+
+
+def test_quantize_semantics(oracle):
+    """No KAT exists in the reference for SbqQuantizer::quantize; pin the restated rules on hand-computable cases
+    (AM/sbq/quantize.rs:52-102)."""
+    O = oracle
+    # 1 bit: strictly greater than the mean, LSB-first
+    mean = np.zeros(70, np.float32)
+    v = np.zeros(70, np.float32)
+    v[0] = 1
+    v[63] = 1
+    v[64] = 2
+    v[69] = -1
+    c = O.quantize(mean, None, 10, 1, v)
+    assert c[0] == (1 | (1 << 63)) and c[1] == 1
+    # 2 bits: std=1 (m2/count = 1), thresholds at z=-2+4/3 and z=-2+8/3
+    mean = np.zeros(4, np.float32)
+    m2 = np.full(4, 10, np.float32)
+    v = np.array([-1.0, -0.6, 0.7, 5.0], np.float32)   # index = (z+2)/(4/3): 0.75, 1.05, 2.025, 5.25
+    c = O.quantize(mean, m2, 10, 2, v)
+    assert c[0] == 0b11_11_01_00
+    # std = 0 and v == mean -> NaN index -> `NaN < 1.0` false -> `NaN as usize` = 0 ones; v > mean -> +inf -> all ones
+    m2 = np.zeros(2, np.float32)
+    c = O.quantize(np.zeros(2, np.float32), m2, 10, 2, np.array([0.0, 1.0], np.float32))
+    assert c[0] == 0b11_00
+
+
+def test_welford_training(oracle):
+    """add_sample (AM/sbq/quantize.rs:115-148) restated in f32: compare with a straight numpy transcription."""
+    O = oracle
+    rng = np.random.default_rng(3)
+    X = rng.random((200, 5), dtype=np.float32)
+    mean, m2, cnt = O.train(X, 2)
+    m = np.zeros(5, np.float32)
+    s2 = np.zeros(5, np.float32)
+    for i, s in enumerate(X):
+        c = np.float32(i + 1)
+        delta = (s - m).astype(np.float32)
+        m = (m + ((s - m).astype(np.float32) / c).astype(np.float32)).astype(np.float32)
+        delta2 = (s - m).astype(np.float32)
+        s2 = (s2 + (delta * delta2).astype(np.float32)).astype(np.float32)
+    assert cnt == 200 and mean.tobytes() == m.tobytes() and m2.tobytes() == s2.tobytes()
+
+
+def test_preprocess_cosine(oracle):
+    O = oracle
+    z = np.zeros(16, np.float32)
+    out, ch = O.preprocess_cosine(z)
+    assert not ch and not out.any()                      # zero vector left alone (AM/distance/mod.rs:231-233)
+    u = np.zeros(16, np.float32)
+    u[3] = 1
+    assert not O.preprocess_cosine(u)[1]                 # already unit (:235-237)
+    v = np.arange(1, 17, dtype=np.float32)
+    out, ch = O.preprocess_cosine(v)
+    assert ch and abs(float(np.dot(out, out)) - 1) < 1e-5
+    assert not O.preprocess_cosine(out)[1]               # idempotent (debug_assert :246-249)

@@ -1,0 +1,383 @@
+// vs_build.hip — batched Vamana construction over SBQ codes on the GPU (a "next" row: index build is
+// NOT the reference's search path, but a device-resident index of 1M..50M nodes cannot be manufactured any other way
+// inside a benchmark run).  It is the batch-parallel counterpart of
+//   Graph::insert / insert_internal        AM/graph/mod.rs:637-717
+//   greedy_search_for_build                AM/graph/mod.rs:285-327   (k_search<BUILD=true>)
+//   add_neighbors + prune_neighbors        AM/graph/mod.rs:212-266,392-488 (alpha ladder 1.0, 1.2 .. max_alpha)
+//   update_back_pointer                    AM/graph/mod.rs:719-735
+// with SBQ Hamming distances between nodes exactly like SbqNodeDistanceMeasure (AM/sbq/mod.rs:161-190).
+// Nodes are inserted in heap order; node 0 is the default start node (first inserted node, as in the reference).
+// Batches: sizes double until `batch_max`; every node of a batch searches the graph of all previous batches, its
+// out-edges are pruned, then back-edges are grouped per target (radix sort) and each target's list is re-pruned once.
+// The result is deterministic for a given (codes, parameters); it is not claimed to be edge-identical to the
+// reference's sequential build (which is itself HashSet-order dependent, AM/graph/mod.rs:317-326).
+#include <hipcub/hipcub.hpp>
+
+#include "vs_internal.h"
+
+#define WAVE 64
+
+__device__ __forceinline__ uint32_t ham_words(const uint64_t* a, const uint64_t* b, uint32_t stride) {
+    uint32_t acc = 0;
+    for (uint32_t w = 0; w < stride; w += 2) {
+        const ulonglong2 x = *reinterpret_cast<const ulonglong2*>(a + w);
+        const ulonglong2 y = *reinterpret_cast<const ulonglong2*>(b + w);
+        acc += (uint32_t)__popcll(x.x ^ y.x) + (uint32_t)__popcll(x.y ^ y.y);
+    }
+    return acc;
+}
+
+// prune_neighbors for one node by one wave.  cand_id/cand_d: C candidates sorted ascending by (distance, id)
+// (LDS).  ccode: optional LDS copy of the candidate codes [C][stride] (nullptr => read codes from global).
+// Writes up to R selected candidate *positions* into sel[] (LDS) and returns their number.
+__device__ uint32_t wave_prune(const uint32_t* cand_id, const uint32_t* cand_d, uint32_t C, const uint64_t* ccode,
+                               const uint64_t* __restrict__ codes, uint32_t stride, uint32_t R, float max_alpha,
+                               float* maxf /*LDS [C]*/, uint32_t* sel /*LDS [R]*/, int lane) {
+    for (uint32_t j = lane; j < C; j += WAVE) maxf[j] = 0.0f;
+    __syncthreads();
+    uint32_t nres = 0;
+    float alpha = 1.0f;
+    const float FMAX = 3.0e38f;
+    while (alpha <= max_alpha && nres < R) {
+        for (uint32_t i = 0; i < C && nres < R; ++i) {
+            float mf = maxf[i];
+            if (mf > alpha) continue;
+            __syncthreads();
+            if (lane == 0) {
+                maxf[i] = FMAX;
+                sel[nres] = i;
+            }
+            nres++;
+            const uint64_t* ci = ccode ? ccode + (size_t)i * stride : codes + (size_t)cand_id[i] * stride;
+            for (uint32_t j = i + 1 + lane; j < C; j += WAVE) {
+                float mj = maxf[j];
+                if (mj > max_alpha) continue;
+                const uint64_t* cj = ccode ? ccode + (size_t)j * stride : codes + (size_t)cand_id[j] * stride;
+                uint32_t dij = ham_words(cj, ci, stride);
+                float factor;
+                if (dij == 0) factor = cand_d[j] == 0 ? 1.0f : FMAX;
+                else factor = (float)cand_d[j] / (float)dij;
+                maxf[j] = fmaxf(mj, factor);
+            }
+            __syncthreads();
+        }
+        alpha *= 1.2f;
+    }
+    __syncthreads();
+    return nres;
+}
+
+// ---- out-edges of the new nodes of one batch ------------------------------------------------------------------
+// one wave per new node p = b0 + blockIdx.x.  Input: its visited list (sorted) from k_search<BUILD>.
+__global__ __launch_bounds__(WAVE) void k_build_prune_new(const uint64_t* __restrict__ codes, uint32_t stride,
+                                                          uint32_t* __restrict__ nbrs, uint32_t nbr_stride, uint32_t R,
+                                                          float max_alpha, uint32_t b0, uint32_t bn,
+                                                          const uint32_t* __restrict__ vis_ids,
+                                                          const uint32_t* __restrict__ vis_d,
+                                                          const uint32_t* __restrict__ vis_cnt, uint32_t vmax,
+                                                          uint32_t use_lds_codes, uint32_t* __restrict__ edge_q,
+                                                          uint64_t* __restrict__ edge_pd) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x;
+    const uint32_t b = blockIdx.x;
+    if (b >= bn) return;
+    const uint32_t p = b0 + b;
+    uint32_t C = min(vis_cnt[b], vmax);
+    uint32_t* cid = reinterpret_cast<uint32_t*>(smem);
+    uint32_t* cd = cid + vmax;
+    float* maxf = reinterpret_cast<float*>(cd + vmax);
+    uint32_t* sel = reinterpret_cast<uint32_t*>(maxf + vmax);
+    uint64_t* ccode = reinterpret_cast<uint64_t*>(sel + round_up_u32(R, 4));
+    for (uint32_t j = lane; j < C; j += WAVE) {
+        cid[j] = vis_ids[(size_t)b * vmax + j];
+        cd[j] = vis_d[(size_t)b * vmax + j];
+    }
+    __syncthreads();
+    if (use_lds_codes) {
+        // coalesced copy: 2 u64 per lane per step
+        for (uint32_t j = 0; j < C; ++j) {
+            const uint64_t* src = codes + (size_t)cid[j] * stride;
+            for (uint32_t w = 2 * lane; w < stride; w += 2 * WAVE)
+                *reinterpret_cast<ulonglong2*>(ccode + (size_t)j * stride + w) = *reinterpret_cast<const ulonglong2*>(src + w);
+        }
+        __syncthreads();
+    }
+    uint32_t nres = wave_prune(cid, cd, C, use_lds_codes ? ccode : nullptr, codes, stride, R, max_alpha, maxf, sel, lane);
+    uint32_t* row = nbrs + (size_t)p * nbr_stride;
+    for (uint32_t t = lane; t < nbr_stride; t += WAVE) row[t] = t < nres ? cid[sel[t]] : VS_INVALID_NODE;
+    // back-edge requests (q <- p, d)
+    for (uint32_t t = lane; t < R; t += WAVE) {
+        size_t e = (size_t)b * R + t;
+        if (t < nres) {
+            edge_q[e] = cid[sel[t]];
+            edge_pd[e] = ((uint64_t)cd[sel[t]] << 32) | p;
+        } else {
+            edge_q[e] = VS_INVALID_NODE;
+            edge_pd[e] = 0;
+        }
+    }
+}
+
+// segment heads of the sorted back-edge list
+__global__ void k_seg_heads(const uint32_t* __restrict__ q_sorted, uint32_t ne, uint32_t* __restrict__ seg_start,
+                            uint32_t* __restrict__ nseg) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ne) return;
+    uint32_t q = q_sorted[i];
+    if (q == VS_INVALID_NODE) return;
+    if (i == 0 || q_sorted[i - 1] != q) seg_start[atomicAdd(nseg, 1u)] = i;
+}
+
+// in-LDS bitonic sort of u64 keys (n padded to pow2 with ~0)
+__device__ void wave_bitonic_sort(uint64_t* keys, uint32_t npow2, int lane) {
+    for (uint32_t k = 2; k <= npow2; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = lane; i < npow2; i += WAVE) {
+                uint32_t ixj = i ^ j;
+                if (ixj > i) {
+                    uint64_t a = keys[i], b = keys[ixj];
+                    bool up = (i & k) == 0;
+                    if ((a > b) == up) {
+                        keys[i] = b;
+                        keys[ixj] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ---- back-edges: one wave per target node q ---------------------------------------------------------------------
+__global__ __launch_bounds__(WAVE) void k_build_backedges(const uint64_t* __restrict__ codes, uint32_t stride,
+                                                          uint32_t* __restrict__ nbrs, uint32_t nbr_stride, uint32_t R,
+                                                          float max_alpha, const uint32_t* __restrict__ q_sorted,
+                                                          const uint64_t* __restrict__ pd_sorted, uint32_t ne,
+                                                          const uint32_t* __restrict__ seg_start,
+                                                          const uint32_t* __restrict__ nseg_p, uint32_t cmax,
+                                                          uint32_t use_lds_codes) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x;
+    const uint32_t nseg = *nseg_p;
+    uint64_t* keys = reinterpret_cast<uint64_t*>(smem);  // [cmax] (pow2)
+    uint32_t* cid = reinterpret_cast<uint32_t*>(keys + cmax);
+    uint32_t* cd = cid + cmax;
+    float* maxf = reinterpret_cast<float*>(cd + cmax);
+    uint32_t* sel = reinterpret_cast<uint32_t*>(maxf + cmax);
+    uint64_t* ccode = reinterpret_cast<uint64_t*>(sel + round_up_u32(R, 4));
+    for (uint32_t sidx = blockIdx.x; sidx < nseg; sidx += gridDim.x) {
+        const uint32_t e0 = seg_start[sidx];
+        const uint32_t q = q_sorted[e0];
+        uint32_t* row = nbrs + (size_t)q * nbr_stride;
+        // existing degree
+        uint32_t deg = 0;
+        for (uint32_t c0 = 0; c0 < R; c0 += WAVE) {
+            uint32_t t = c0 + lane;
+            uint32_t v = t < R ? row[t] : VS_INVALID_NODE;
+            uint64_t inval = __ballot(v == VS_INVALID_NODE);
+            if (inval) {
+                deg = c0 + (uint32_t)__builtin_ctzll(inval);
+                break;
+            }
+            deg = c0 + WAVE;
+        }
+        deg = min(deg, R);
+        // segment length
+        uint32_t m = 0;
+        while (e0 + m < ne && q_sorted[e0 + m] == q) ++m;  // uniform scalar loop (short)
+        if (deg + m <= R) {  // room: append in (sorted) order
+            for (uint32_t t = lane; t < m; t += WAVE) row[deg + t] = (uint32_t)pd_sorted[e0 + t];
+            continue;
+        }
+        // candidates = existing neighbors (distance computed) + new sources; keep the closest cmax
+        const uint32_t take_new = min(m, cmax - deg);
+        const uint32_t T = deg + take_new;
+        uint32_t np2 = 1;
+        while (np2 < T) np2 <<= 1;
+        const uint64_t* cq = codes + (size_t)q * stride;
+        for (uint32_t t = lane; t < np2; t += WAVE) {
+            uint64_t key = ~0ull;
+            if (t < deg) {
+                uint32_t id = row[t];
+                key = ((uint64_t)ham_words(codes + (size_t)id * stride, cq, stride) << 32) | id;
+            } else if (t < T) {
+                uint64_t pd = pd_sorted[e0 + (t - deg)];
+                key = pd;  // (dist << 32) | p
+            }
+            keys[t] = key;
+        }
+        __syncthreads();
+        wave_bitonic_sort(keys, np2, lane);
+        for (uint32_t t = lane; t < T; t += WAVE) {
+            cid[t] = (uint32_t)keys[t];
+            cd[t] = (uint32_t)(keys[t] >> 32);
+        }
+        __syncthreads();
+        if (use_lds_codes) {
+            for (uint32_t j = 0; j < T; ++j) {
+                const uint64_t* src = codes + (size_t)cid[j] * stride;
+                for (uint32_t w = 2 * lane; w < stride; w += 2 * WAVE)
+                    *reinterpret_cast<ulonglong2*>(ccode + (size_t)j * stride + w) =
+                        *reinterpret_cast<const ulonglong2*>(src + w);
+            }
+            __syncthreads();
+        }
+        uint32_t nres = wave_prune(cid, cd, T, use_lds_codes ? ccode : nullptr, codes, stride, R, max_alpha, maxf, sel, lane);
+        for (uint32_t t = lane; t < nbr_stride; t += WAVE) row[t] = t < nres ? cid[sel[t]] : VS_INVALID_NODE;
+        __syncthreads();
+    }
+}
+
+struct BuildBufs {
+    uint32_t *vis_ids = nullptr, *vis_d = nullptr, *vis_cnt = nullptr, *stats = nullptr, *status = nullptr;
+    uint32_t *hash = nullptr, *cand_ids = nullptr;
+    uint32_t *edge_q = nullptr, *edge_q_sorted = nullptr, *seg_start = nullptr, *nseg = nullptr;
+    uint64_t *edge_pd = nullptr, *edge_pd_sorted = nullptr;
+    void* cub_tmp = nullptr;
+    size_t cub_bytes = 0;
+    void free_all() {
+        void* ps[] = {vis_ids, vis_d, vis_cnt, stats, status, hash, cand_ids, edge_q, edge_q_sorted, seg_start, nseg,
+                      edge_pd, edge_pd_sorted, cub_tmp};
+        for (void* p : ps)
+            if (p) (void)hipFree(p);
+    }
+};
+
+static int build_graph_impl(vs_index* ix, uint32_t L, double max_alpha_d, uint32_t batch_max, BuildBufs& B) {
+    vs_ctx* c = ix->ctx;
+    hipStream_t st = c->stream;
+    const uint32_t n = ix->d.n, R = ix->d.num_neighbors, stride = ix->code_stride;
+    const float max_alpha = (float)max_alpha_d;
+    VS_HIP(hipMemsetAsync(ix->nbrs, 0xFF, (size_t)std::max(n, 1u) * ix->nbr_stride * 4, st));
+    if (n == 0) {
+        ix->d.default_start = VS_INVALID_NODE;
+        return VS_OK;
+    }
+    ix->d.default_start = 0;
+    if (batch_max == 0) batch_max = std::min<uint32_t>(65536, std::max<uint32_t>(1024, n / 64));
+    // capacities of the build-mode search
+    uint32_t vmax = std::max<uint32_t>(round_up_u32(3 * L + 64, 64), 128);      // visited list cap (candidates of prune)
+    uint32_t idcap = std::min<uint32_t>(65536, round_up_u32((2 * L + 64) * R * 6 / 10 + 1024, 64));
+    uint32_t hashcap = next_pow2_u32(2ull * idcap);
+    uint32_t cmax = 1;
+    while (cmax < R + 128) cmax <<= 1;  // back-edge candidate cap (pow2, >= R + new sources kept)
+    const size_t code_bytes = (size_t)stride * 8;
+    const uint32_t use_lds_new = (vmax * code_bytes + vmax * 12 + R * 4 + 64 <= 150 * 1024) ? 1 : 0;
+    const uint32_t use_lds_back = (cmax * code_bytes + cmax * 20 + R * 4 + 64 <= 150 * 1024) ? 1 : 0;
+    const size_t lds_new = (size_t)vmax * 12 + round_up_u32(R, 4) * 4 + (use_lds_new ? vmax * code_bytes : 0) + 64;
+    const size_t lds_back = (size_t)cmax * 20 + round_up_u32(R, 4) * 4 + (use_lds_back ? cmax * code_bytes : 0) + 64;
+    VS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_build_prune_new),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    VS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_build_backedges),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+
+    const size_t bm = batch_max;
+    VS_HIP(hipMalloc(&B.vis_ids, bm * vmax * 4));
+    VS_HIP(hipMalloc(&B.vis_d, bm * vmax * 4));
+    VS_HIP(hipMalloc(&B.vis_cnt, bm * 4));
+    VS_HIP(hipMalloc(&B.stats, bm * ST_N * 4));
+    VS_HIP(hipMalloc(&B.status, bm * 4));
+    VS_HIP(hipMalloc(&B.edge_q, bm * R * 4));
+    VS_HIP(hipMalloc(&B.edge_q_sorted, bm * R * 4));
+    VS_HIP(hipMalloc(&B.edge_pd, bm * R * 8));
+    VS_HIP(hipMalloc(&B.edge_pd_sorted, bm * R * 8));
+    VS_HIP(hipMalloc(&B.seg_start, bm * R * 4));
+    VS_HIP(hipMalloc(&B.nseg, 4));
+    VS_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, B.cub_bytes, B.edge_q, B.edge_q_sorted, B.edge_pd,
+                                              B.edge_pd_sorted, (int)(bm * R), 0, 32, st));
+    VS_HIP(hipMalloc(&B.cub_tmp, B.cub_bytes + 16));
+    size_t hash_alloc = 0, ids_alloc = 0;
+
+    uint32_t b0 = 1;  // node 0 is the start node and has no one to link to yet
+    uint32_t bsz = 1;
+    while (b0 < n) {
+        const uint32_t bn = std::min<uint32_t>(std::min<uint32_t>(bsz, batch_max), n - b0);
+        for (int attempt = 0;; ++attempt) {
+            if ((size_t)bn * hashcap * 4 > hash_alloc || !B.hash) {
+                if (B.hash) VS_HIP(hipFree(B.hash));
+                B.hash = nullptr;
+                hash_alloc = (size_t)batch_max * hashcap * 4;
+                VS_HIP(hipMalloc(&B.hash, hash_alloc));
+            }
+            if ((size_t)bn * idcap * 4 > ids_alloc || !B.cand_ids) {
+                if (B.cand_ids) VS_HIP(hipFree(B.cand_ids));
+                B.cand_ids = nullptr;
+                ids_alloc = (size_t)batch_max * idcap * 4;
+                VS_HIP(hipMalloc(&B.cand_ids, ids_alloc));
+            }
+            VS_HIP(hipMemsetAsync(B.hash, 0xFF, (size_t)bn * hashcap * 4, st));
+            SearchLaunch s;
+            s.nq = bn;
+            s.L = L;
+            s.M = vmax;
+            s.hcap = idcap;
+            s.vcap = vmax + 64;
+            s.hashcap = hashcap;
+            s.idcap = idcap;
+            s.qcodes = ix->codes + (size_t)b0 * stride;
+            s.qlabels = nullptr;
+            s.qlabel_off = nullptr;
+            s.hash = B.hash;
+            s.cand_ids = B.cand_ids;
+            s.out_ids = B.vis_ids;
+            s.out_ham = B.vis_d;
+            s.out_cnt = B.vis_cnt;
+            s.stats = B.stats;
+            s.status = B.status;
+            VS_TRY(launch_search(ix, s, true));
+            std::vector<uint32_t> status(bn);
+            VS_HIP(hipMemcpyAsync(status.data(), B.status, (size_t)bn * 4, hipMemcpyDeviceToHost, st));
+            VS_HIP(hipStreamSynchronize(st));
+            uint32_t ovf = 0;
+            for (uint32_t v : status) ovf |= v;
+            if (!ovf) break;
+            if (attempt >= 5) {
+                vs_set_error("vs_build_graph: search structures overflowed (flags 0x%x)", ovf);
+                return VS_ERR_CAPACITY;
+            }
+            if (ovf & OVF_VISITED) {
+                // the visited list outgrew the prune candidate cap: keep the closest vmax (list is sorted) — retry
+                // with a larger in-LDS list only
+                vs_set_error("vs_build_graph: visited list overflow (search_list_size too large for LDS)");
+                return VS_ERR_CAPACITY;
+            }
+            if (ovf & (OVF_HEAP | OVF_IDS)) idcap = std::min<uint32_t>(65536, idcap * 2);
+            if (ovf & OVF_HASH) hashcap *= 2;
+            if (hashcap < 2 * idcap) hashcap = next_pow2_u32(2ull * idcap);
+        }
+        // out-edges of the new nodes + back-edge requests
+        hipLaunchKernelGGL(k_build_prune_new, dim3(bn), dim3(WAVE), lds_new, st, ix->codes, stride, ix->nbrs,
+                           ix->nbr_stride, R, max_alpha, b0, bn, B.vis_ids, B.vis_d, B.vis_cnt, vmax, use_lds_new,
+                           B.edge_q, B.edge_pd);
+        VS_HIP(hipGetLastError());
+        const uint32_t ne = bn * R;
+        size_t tmp_bytes = B.cub_bytes;
+        VS_HIP(hipcub::DeviceRadixSort::SortPairs(B.cub_tmp, tmp_bytes, B.edge_q, B.edge_q_sorted, B.edge_pd,
+                                                  B.edge_pd_sorted, (int)ne, 0, 32, st));
+        VS_HIP(hipMemsetAsync(B.nseg, 0, 4, st));
+        hipLaunchKernelGGL(k_seg_heads, dim3((ne + 255) / 256), dim3(256), 0, st, B.edge_q_sorted, ne, B.seg_start, B.nseg);
+        VS_HIP(hipGetLastError());
+        uint32_t grid = std::min<uint32_t>(ne, 16384);
+        hipLaunchKernelGGL(k_build_backedges, dim3(grid), dim3(WAVE), lds_back, st, ix->codes, stride, ix->nbrs,
+                           ix->nbr_stride, R, max_alpha, B.edge_q_sorted, B.edge_pd_sorted, ne, B.seg_start, B.nseg, cmax,
+                           use_lds_back);
+        VS_HIP(hipGetLastError());
+        b0 += bn;
+        if (bsz < batch_max) bsz = std::min<uint32_t>(batch_max, bsz * 2);
+    }
+    VS_HIP(hipStreamSynchronize(st));
+    return VS_OK;
+}
+
+extern "C" int vs_build_graph(vs_index* ix, uint32_t search_list_size, double max_alpha, uint32_t batch_max, uint64_t seed) {
+    (void)seed;
+    VS_REQUIRE(ix, "vs_build_graph: index is NULL");
+    VS_REQUIRE(search_list_size >= 1 && search_list_size <= 1000, "vs_build_graph: search_list_size outside [1,1000]");
+    VS_REQUIRE(max_alpha >= 1.0 && max_alpha <= 5.0, "vs_build_graph: max_alpha outside [1,5]");
+    VS_HIP(hipSetDevice(ix->ctx->device));
+    BuildBufs B;
+    int r = build_graph_impl(ix, search_list_size, max_alpha, batch_max, B);
+    (void)hipStreamSynchronize(ix->ctx->stream);
+    B.free_all();
+    return r;
+}

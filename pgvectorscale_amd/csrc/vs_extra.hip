@@ -1,15 +1,330 @@
-// vs_extra.hip — K5 flat scan, build-side kernels and the synthetic corpus generator (filled in incrementally).
+// vs_extra.hip — build-side kernels that manufacture device-resident indexes (SURVEY.md §8f "next" rows) and the
+// synthetic corpus generator.  None of this is on the reference's *search* path; it exists so that corpora far
+// larger than host RAM (50M x 768 f32 = 153.6 GB) can be generated, trained, quantised and indexed in HBM.
 #include "vs_internal.h"
 
-#define NOT_YET(name)                                      \
-    do {                                                   \
+#define WAVE 64
+
+// ===============================================================================================================
+// Synthetic corpus: clustered mixture with low intrinsic dimensionality, embedded by a fixed random projection.
+// All arithmetic is integer (64-bit) until the final scaling, which uses IEEE f64 sqrt/div: the stream is
+// bit-reproducible on the CPU (pgvectorscale_amd/datagen.py holds the numpy twin).
+//   h(seed, a, b)     = splitmix64-style mix
+//   G(h)              = (sum of the 8 bytes of h) - 1020          ~ N(0, 209^2), integer in [-1020, 1020]
+//   cluster(r)        = h(seed, r, 0) mod n_clusters
+//   z[r][j]           = 100 * G(h(seed^K1, cluster, j)) + intra_pct * G(h(seed, r, 1 + j))
+//   x[r][i]           = sum_j z[r][j] * G(h(seed^K2, j, i)) + noise_pct * isqrt(latent) * 209 * G(h(seed^K3, r, i))
+//   xs                = x >> 10 (arithmetic)        ss = sum_i xs^2 (exact int64)
+//   out[r][i]         = normalize ? (float)((double)xs / sqrt((double)ss)) : (float)((double)xs * 2^-14)
+// ===============================================================================================================
+#define DG_K1 0x9E3779B97F4A7C15ull
+#define DG_K2 0xC2B2AE3D27D4EB4Full
+#define DG_K3 0x165667B19E3779F9ull
+
+__host__ __device__ static inline uint64_t dg_hash(uint64_t seed, uint64_t a, uint64_t b) {
+    uint64_t x = seed + a * 0x9E3779B97F4A7C15ull + b * 0xBF58476D1CE4E5B9ull + 0x94D049BB133111EBull;
+    x ^= x >> 30;
+    x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 27;
+    x *= 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    return x;
+}
+__host__ __device__ static inline int32_t dg_gauss(uint64_t h) {
+    // byte sum via SWAR
+    uint64_t s = (h & 0x00FF00FF00FF00FFull) + ((h >> 8) & 0x00FF00FF00FF00FFull);
+    s = (s & 0x0000FFFF0000FFFFull) + ((s >> 16) & 0x0000FFFF0000FFFFull);
+    s = (s & 0xFFFFFFFFull) + (s >> 32);
+    return (int32_t)s - 1020;
+}
+static uint32_t isqrt_u32(uint32_t v) {
+    uint32_t r = 0;
+    while ((r + 1) * (r + 1) <= v) ++r;
+    return r;
+}
+
+__global__ void k_dg_tables(uint64_t seed, uint32_t dim, uint32_t latent, uint32_t n_clusters,
+                            int16_t* __restrict__ proj /*[latent][dim]*/, int16_t* __restrict__ centers /*[nc][latent]*/) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < latent * dim) {
+        uint32_t j = t / dim, i = t - j * dim;
+        proj[t] = (int16_t)dg_gauss(dg_hash(seed ^ DG_K2, j, i));
+    }
+    if (t < n_clusters * latent) {
+        uint32_t c = t / latent, j = t - c * latent;
+        centers[t] = (int16_t)dg_gauss(dg_hash(seed ^ DG_K1, c, j));
+    }
+}
+
+// one workgroup (256 threads) per row
+__global__ __launch_bounds__(256) void k_dg_fill(uint64_t seed, uint32_t dim, uint32_t latent, uint32_t n_clusters,
+                                                 uint32_t intra_pct, int64_t noise_mult, uint32_t normalize,
+                                                 const int16_t* __restrict__ proj, const int16_t* __restrict__ centers,
+                                                 uint64_t first_row, uint64_t rows, float* __restrict__ out,
+                                                 uint32_t out_stride) {
+    __shared__ int32_t z[256];
+    __shared__ long long red[256];
+    for (uint64_t rr = blockIdx.x; rr < rows; rr += gridDim.x) {
+        const uint64_t r = first_row + rr;
+        const uint32_t c = (uint32_t)(dg_hash(seed, r, 0) % n_clusters);
+        if (threadIdx.x < latent)
+            z[threadIdx.x] = 100 * (int32_t)centers[c * latent + threadIdx.x] +
+                             (int32_t)intra_pct * dg_gauss(dg_hash(seed, r, 1 + threadIdx.x));
+        __syncthreads();
+        long long ss = 0;
+        // each thread owns dims i = tid, tid+256, ... ; keep xs in registers (dim <= 16 * 256)
+        long long xs_loc[16];
+        int cnt = 0;
+        for (uint32_t i = threadIdx.x; i < dim; i += 256, ++cnt) {
+            long long acc = 0;
+            for (uint32_t j = 0; j < latent; ++j) acc += (long long)z[j] * (long long)proj[j * dim + i];
+            acc += noise_mult * (long long)dg_gauss(dg_hash(seed ^ DG_K3, r, i));
+            long long xs = acc >> 10;
+            xs_loc[cnt] = xs;
+            ss += xs * xs;
+        }
+        red[threadIdx.x] = ss;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+            __syncthreads();
+        }
+        const long long tot = red[0];
+        const double denom = sqrt((double)tot);
+        cnt = 0;
+        for (uint32_t i = threadIdx.x; i < dim; i += 256, ++cnt) {
+            double v = normalize ? ((double)xs_loc[cnt] / denom) : ((double)xs_loc[cnt] * (1.0 / 16384.0));
+            out[rr * out_stride + i] = (float)v;
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int vs_datagen_fill(vs_ctx* c, const vs_datagen_params* p, uint64_t first_row, uint64_t rows, float* d_out) {
+    VS_REQUIRE(c && p && (rows == 0 || d_out), "vs_datagen_fill: bad args");
+    VS_REQUIRE(p->dim >= 1 && p->dim <= 4096, "vs_datagen_fill: dim %u outside [1,4096]", p->dim);
+    VS_REQUIRE(p->latent_dim >= 1 && p->latent_dim <= 64, "vs_datagen_fill: latent_dim %u outside [1,64]", p->latent_dim);
+    VS_REQUIRE(p->n_clusters >= 1 && p->intra_pct <= 100 && p->noise_pct <= 100, "vs_datagen_fill: bad mixture params");
+    if (rows == 0) return VS_OK;
+    VS_HIP(hipSetDevice(c->device));
+    int16_t *proj = nullptr, *centers = nullptr;
+    VS_HIP(hipMalloc(&proj, (size_t)p->latent_dim * p->dim * 2));
+    VS_HIP(hipMalloc(&centers, (size_t)p->n_clusters * p->latent_dim * 2));
+    uint32_t tmax = std::max(p->latent_dim * p->dim, p->n_clusters * p->latent_dim);
+    hipLaunchKernelGGL(k_dg_tables, dim3((tmax + 255) / 256), dim3(256), 0, c->stream, p->seed, p->dim, p->latent_dim,
+                       p->n_clusters, proj, centers);
+    int64_t noise_mult = (int64_t)p->noise_pct * isqrt_u32(p->latent_dim) * 209;
+    uint32_t grid = (uint32_t)std::min<uint64_t>(rows, 1u << 20);
+    hipLaunchKernelGGL(k_dg_fill, dim3(grid), dim3(256), 0, c->stream, p->seed, p->dim, p->latent_dim, p->n_clusters,
+                       p->intra_pct, noise_mult, p->normalize, proj, centers, first_row, rows, d_out, p->dim);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(proj);
+    (void)hipFree(centers);
+    VS_HIP(e);
+    return VS_OK;
+}
+
+// ===============================================================================================================
+// SBQ training: SbqQuantizer::add_sample (AM/sbq/quantize.rs:115-148) over all rows in heap order.  The Welford
+// recurrence is sequential in f32 per dimension, so parallelism is across dimensions only: lane = dimension,
+// 64 dims per wave, rows prefetched 32 at a time (double-buffered registers) to keep the HBM latency off the
+// dependent chain.  Bit-exact with the reference by construction.
+// ===============================================================================================================
+__global__ __launch_bounds__(WAVE) void k_sbq_train(const float* __restrict__ vecs, uint32_t vec_stride, uint32_t n,
+                                                    uint32_t dim_index, uint32_t bits, const float* __restrict__ rnorm,
+                                                    float* __restrict__ mean, float* __restrict__ m2) {
+    const uint32_t d = blockIdx.x * WAVE + threadIdx.x;
+    const bool act = d < dim_index;
+    const uint32_t dd = act ? d : 0;
+    float mu = 0.0f, s2 = 0.0f;
+    constexpr int T = 32;
+    float cur[T], nxt[T];
+    auto load_tile = [&](uint32_t r0, float* buf) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            uint32_t r = r0 + t;
+            float v = 0.0f;
+            if (r < n) {
+                v = vecs[(size_t)r * vec_stride + dd];
+                if (rnorm) {
+                    float s = rnorm[r];
+                    if (s != 0.0f) v = v / s;
+                }
+            }
+            buf[t] = v;
+        }
+    };
+    load_tile(0, cur);
+    for (uint32_t r0 = 0; r0 < n; r0 += T) {
+        load_tile(r0 + T, nxt);
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            uint32_t r = r0 + t;
+            if (r < n) {
+                float c = (float)(uint64_t)(r + 1);  // count as f32
+                float s = cur[t];
+                float delta = s - mu;
+                mu = mu + (s - mu) / c;
+                if (bits > 1) {
+                    float delta2 = s - mu;
+                    float p = delta * delta2;
+                    s2 = s2 + p;
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < T; ++t) cur[t] = nxt[t];
+    }
+    if (act) {
+        mean[d] = mu;
+        m2[d] = s2;
+    }
+}
+
+// row divisor for the index slice when dim_index != dim_full (same rule as k_row_norms in vs_kernels.hip)
+__global__ __launch_bounds__(WAVE) void k_slice_norms(const float* __restrict__ vecs, uint32_t vec_stride, uint32_t dim,
+                                                      uint32_t n, float* __restrict__ out) {
+    __shared__ float tile[64][65];
+    const int lane = threadIdx.x;
+    for (uint32_t row0 = blockIdx.x * 64u; row0 < n; row0 += gridDim.x * 64u) {
+        float norm = 0.0f;
+        for (uint32_t d0 = 0; d0 < dim; d0 += 64) {
+            for (int r = 0; r < 64; ++r) {
+                uint32_t row = row0 + r, d = d0 + lane;
+                tile[r][lane] = (row < n && d < dim) ? vecs[(size_t)row * vec_stride + d] : 0.0f;
+            }
+            __syncthreads();
+            uint32_t lim = min(64u, dim - d0);
+            for (uint32_t c = 0; c < lim; ++c) {
+                float v = tile[lane][c];
+                float p = v * v;
+                norm = norm + p;
+            }
+            __syncthreads();
+        }
+        uint32_t row = row0 + lane;
+        if (row < n) {
+            const float eps = 1.1920929e-07f;
+            float adj = eps * (float)dim;
+            float s = 0.0f;
+            if (!(norm < eps) && !(norm >= 1.0f - adj && norm <= 1.0f + adj)) s = sqrtf(norm);
+            out[row] = s;
+        }
+    }
+}
+
+// the divisor array to use for the *index slice* of each heap vector, or nullptr when no normalisation applies
+static int index_slice_norms(vs_index* ix, float** out, bool* owned) {
+    *out = nullptr;
+    *owned = false;
+    if (ix->d.distance_type != VS_COSINE) return VS_OK;
+    if (ix->d.dim_index == ix->d.dim_full) {
+        VS_TRY(launch_row_norms(ix));
+        *out = ix->vnorm;
+        return VS_OK;
+    }
+    float* tmp = nullptr;
+    VS_HIP(hipMalloc(&tmp, (size_t)std::max<uint32_t>(ix->d.n, 1) * 4));
+    uint32_t blocks = std::min<uint32_t>((ix->d.n + 63) / 64, 8192);
+    hipLaunchKernelGGL(k_slice_norms, dim3(blocks), dim3(WAVE), 0, ix->ctx->stream, ix->vecs, ix->vec_stride,
+                       ix->d.dim_index, ix->d.n, tmp);
+    *out = tmp;
+    *owned = true;
+    return VS_OK;
+}
+
+extern "C" int vs_sbq_train(vs_index* ix) {
+    VS_REQUIRE(ix && ix->vecs, "vs_sbq_train: needs the vector column on the device");
+    VS_HIP(hipSetDevice(ix->ctx->device));
+    float* rn = nullptr;
+    bool owned = false;
+    VS_TRY(index_slice_norms(ix, &rn, &owned));
+    hipLaunchKernelGGL(k_sbq_train, dim3((ix->d.dim_index + WAVE - 1) / WAVE), dim3(WAVE), 0, ix->ctx->stream, ix->vecs,
+                       ix->vec_stride, ix->d.n, ix->d.dim_index, ix->d.bits, rn, ix->mean, ix->m2);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ix->ctx->stream);
+    if (owned) (void)hipFree(rn);
+    VS_HIP(e);
+    ix->count = ix->d.n;
+    return VS_OK;
+}
+
+// ===============================================================================================================
+// Corpus quantisation: codes[i] = SbqQuantizer::quantize(normalised index slice of vecs[i]).  One wave per row,
+// lane = output bit (ballot packs 64 bits per word).
+// ===============================================================================================================
+__global__ __launch_bounds__(WAVE) void k_quantize_corpus(const float* __restrict__ vecs, uint32_t vec_stride, uint32_t n,
+                                                          uint32_t dims, uint32_t bits, const float* __restrict__ rnorm,
+                                                          const float* __restrict__ mean, const float* __restrict__ m2,
+                                                          float count_f, uint32_t words, uint32_t code_stride,
+                                                          uint64_t* __restrict__ codes) {
+    const int lane = threadIdx.x;
+    for (uint32_t r = blockIdx.x; r < n; r += gridDim.x) {
+        const float* v = vecs + (size_t)r * vec_stride;
+        const float s = rnorm ? rnorm[r] : 0.0f;
+        uint64_t* out = codes + (size_t)r * code_stride;
+        for (uint32_t w = 0; w < code_stride; ++w) {
+            uint64_t word = 0;
+            if (w < words) {
+                uint32_t g = w * 64u + (uint32_t)lane;
+                uint32_t dim = g / bits;
+                uint32_t j = g - dim * bits;
+                bool bit = false;
+                if (dim < dims) {
+                    float x = v[dim];
+                    if (s != 0.0f) x = x / s;
+                    float mu = mean[dim];
+                    if (bits == 1) {
+                        bit = x > mu;
+                    } else {
+                        float variance = m2[dim] / count_f;
+                        float std_dev = sqrtf(variance);
+                        float ranges = (float)(bits + 1);
+                        float z = (x - mu) / std_dev;
+                        float index = (z + 2.0f) / (4.0f / ranges);
+                        uint32_t ones = 0;
+                        if (!(index < 1.0f)) {
+                            float fl = floorf(index);
+                            if (fl != fl) ones = 0;
+                            else if (fl >= (float)bits) ones = bits;
+                            else if (fl <= 0.0f) ones = 0;
+                            else ones = (uint32_t)fl;
+                        }
+                        bit = j < ones;
+                    }
+                }
+                word = __ballot(bit);
+            }
+            if (lane == 0) out[w] = word;
+        }
+    }
+}
+
+extern "C" int vs_sbq_quantize_corpus(vs_index* ix) {
+    VS_REQUIRE(ix && ix->vecs, "vs_sbq_quantize_corpus: needs the vector column on the device");
+    VS_REQUIRE(ix->count > 0, "vs_sbq_quantize_corpus: quantizer not trained");
+    VS_HIP(hipSetDevice(ix->ctx->device));
+    float* rn = nullptr;
+    bool owned = false;
+    VS_TRY(index_slice_norms(ix, &rn, &owned));
+    uint32_t grid = std::min<uint32_t>(ix->d.n, 1u << 20);
+    if (grid)
+        hipLaunchKernelGGL(k_quantize_corpus, dim3(grid), dim3(WAVE), 0, ix->ctx->stream, ix->vecs, ix->vec_stride, ix->d.n,
+                           ix->d.dim_index, ix->d.bits, rn, ix->mean, ix->m2, (float)ix->count, ix->d.words,
+                           ix->code_stride, ix->codes);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ix->ctx->stream);
+    if (owned) (void)hipFree(rn);
+    VS_HIP(e);
+    return VS_OK;
+}
+
+#define NOT_YET(name)                                         \
+    do {                                                      \
         vs_set_error(name ": not implemented in this build"); \
-        return VS_ERR_STATE;                               \
+        return VS_ERR_STATE;                                  \
     } while (0)
 
 extern "C" int vs_scan_topk(vs_index*, const uint64_t*, uint32_t, uint32_t, uint32_t*, uint32_t*) { NOT_YET("vs_scan_topk"); }
-extern "C" int vs_sbq_train(vs_index*) { NOT_YET("vs_sbq_train"); }
-extern "C" int vs_sbq_quantize_corpus(vs_index*) { NOT_YET("vs_sbq_quantize_corpus"); }
-extern "C" int vs_build_graph(vs_index*, uint32_t, double, uint32_t, uint64_t) { NOT_YET("vs_build_graph"); }
-extern "C" int vs_datagen_fill(vs_ctx*, const vs_datagen_params*, uint64_t, uint64_t, float*) { NOT_YET("vs_datagen_fill"); }
 extern "C" int vs_bruteforce_topk(vs_index*, const float*, uint32_t, uint32_t, uint32_t*, float*) { NOT_YET("vs_bruteforce_topk"); }

@@ -120,7 +120,7 @@ int launch_hamming_gather(vs_index* idx, const uint64_t* d_qcodes, const uint32_
                           uint32_t nq, uint32_t* d_out);
 int launch_rerank(vs_index* idx, const float* d_q_full, const uint32_t* d_ids, const uint32_t* d_off,
                   const uint32_t* d_cnt, uint32_t fixed_m, uint32_t nq, float* d_out);
-int launch_search(vs_index* idx, const SearchLaunch& s);
+int launch_search(vs_index* idx, const SearchLaunch& s, bool build_mode = false);
 int launch_resort(vs_index* idx, uint32_t nq, uint32_t M, uint32_t rescore, uint32_t k, const uint32_t* d_stream_ids,
                   const uint32_t* d_cnt, const float* d_dist, uint64_t* d_heap_ws, uint32_t* d_out_ids,
                   uint64_t* d_out_tids, float* d_out_dist);

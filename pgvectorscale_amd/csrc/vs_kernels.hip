@@ -419,6 +419,9 @@ struct WaveHeap {
     }
 };
 
+// BUILD = true: greedy_search_for_build (AM/graph/mod.rs:285-327): one greedy_search_iterate, then the whole visited
+// list (sorted by distance) is the output; used by the graph builder with the new node's own code as the query.
+template <bool BUILD>
 __global__ __launch_bounds__(WAVE) void k_search(SearchArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
@@ -519,7 +522,10 @@ __global__ __launch_bounds__(WAVE) void k_search(SearchArgs a) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 const uint32_t node = rfl(cand_ids[head & 0xFFFFu]);
                 // visited.insert(partition_point(|x| *x < head), head): before the first element >= head
-                if (vlen + 1 > s.vcap) { status |= OVF_VISITED; break; }
+                if (vlen + 1 > s.vcap) {
+                    if (BUILD) vlen = s.vcap - 1;  // build mode keeps the closest vcap visited nodes as prune candidates
+                    else { status |= OVF_VISITED; break; }
+                }
                 {
                     uint32_t cntlt = 0;
                     for (uint32_t base = 0; base < vlen; base += WAVE) {
@@ -618,6 +624,7 @@ __global__ __launch_bounds__(WAVE) void k_search(SearchArgs a) {
                 if (status) break;
             }
             if (status) break;
+            if (BUILD) break;
             // ---- consume (AM/graph/mod.rs:174-184) + return_lsn (AM/sbq/storage.rs:404-414) ----
             if (vlen == 0) break;  // None
             __syncthreads();
@@ -649,6 +656,14 @@ __global__ __launch_bounds__(WAVE) void k_search(SearchArgs a) {
             break;
         }
         if (!got) break;
+    }
+    if (BUILD) {
+        __syncthreads();
+        emitted = min(vlen, s.M);
+        for (uint32_t i = lane; i < emitted; i += WAVE) {
+            s.out_ids[(size_t)q * s.M + i] = vid[i];
+            s.out_ham[(size_t)q * s.M + i] = vdist[i];
+        }
     }
     for (uint32_t i = emitted + lane; i < s.M; i += WAVE) {
         s.out_ids[(size_t)q * s.M + i] = VS_INVALID_NODE;
@@ -807,7 +822,7 @@ static size_t search_lds_bytes(const vs_index* idx, const SearchLaunch& s) {
     return words32 * 4 + (size_t)idx->code_stride * 8 + MAX_QLABELS * 2 + 16;
 }
 
-int launch_search(vs_index* idx, const SearchLaunch& s) {
+int launch_search(vs_index* idx, const SearchLaunch& s, bool build_mode) {
     if (s.nq == 0) return VS_OK;
     SearchArgs a;
     a.codes = idx->codes;
@@ -831,11 +846,14 @@ int launch_search(vs_index* idx, const SearchLaunch& s) {
     }
     static bool attr_set = false;
     if (!attr_set) {
-        VS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_search), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   160 * 1024));
+        VS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_search<false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        VS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_search<true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_search, dim3(s.nq), dim3(WAVE), lds, idx->ctx->stream, a);
+    if (build_mode) hipLaunchKernelGGL(k_search<true>, dim3(s.nq), dim3(WAVE), lds, idx->ctx->stream, a);
+    else hipLaunchKernelGGL(k_search<false>, dim3(s.nq), dim3(WAVE), lds, idx->ctx->stream, a);
     VS_HIP(hipGetLastError());
     return VS_OK;
 }

@@ -104,6 +104,15 @@ void* vs_ctx_stream(vs_ctx* ctx);      /* the hipStream_t all kernels of this ct
 int vs_ctx_device_name(vs_ctx* ctx, char* buf, size_t len);
 int vs_ctx_mem_info(vs_ctx* ctx, uint64_t* free_bytes, uint64_t* total_bytes);
 
+/* per-kernel timing with HIP events recorded on the ctx stream around every launch of the batched-scan pipeline
+ * (what bench.py's roofline figure is computed from).  kind: 0 prepare_queries, 1 search, 2 rerank, 3 resort. */
+typedef struct vs_profile {
+    double ms[8];        /* accumulated kernel time per kind */
+    uint64_t launches[8];
+} vs_profile;
+int vs_profile_enable(vs_ctx* ctx, int on);
+int vs_profile_read(vs_ctx* ctx, vs_profile* out, int reset); /* synchronises the stream */
+
 /* raw device buffers (so callers can keep inputs resident in HBM across calls) */
 int vs_dev_alloc(vs_ctx* ctx, size_t bytes, void** out);
 int vs_dev_free(vs_ctx* ctx, void* p);

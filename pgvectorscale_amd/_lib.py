@@ -38,6 +38,10 @@ class Stats(C.Structure):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
 
 
+class Profile(C.Structure):
+    _fields_ = [("ms", C.c_double * 8), ("launches", C.c_uint64 * 8)]
+
+
 class DatagenParams(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("dim", C.c_uint32), ("latent_dim", C.c_uint32), ("n_clusters", C.c_uint32),
                 ("intra_pct", C.c_uint32), ("noise_pct", C.c_uint32), ("normalize", C.c_uint32)]
@@ -54,6 +58,8 @@ SYMBOLS = {
     "vs_ctx_stream": (_vp, [_vp]),
     "vs_ctx_device_name": (_i, [_vp, C.c_char_p, _sz]),
     "vs_ctx_mem_info": (_i, [_vp, C.POINTER(_u64), C.POINTER(_u64)]),
+    "vs_profile_enable": (_i, [_vp, _i]),
+    "vs_profile_read": (_i, [_vp, C.POINTER(Profile), _i]),
     "vs_dev_alloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
     "vs_dev_free": (_i, [_vp, _vp]),
     "vs_dev_upload": (_i, [_vp, _vp, _vp, _sz]),

@@ -73,6 +73,11 @@ extern "C" void vs_ctx_destroy(vs_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     (void)hipStreamSynchronize(c->copy_stream);
+    for (auto& sp : c->spans) {
+        (void)hipEventDestroy(sp.a);
+        (void)hipEventDestroy(sp.b);
+    }
+    for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     for (int i = 0; i < 2; ++i) {
         if (c->pinned[i]) (void)hipHostFree(c->pinned[i]);
         if (c->pinned_ev[i]) (void)hipEventDestroy(c->pinned_ev[i]);
@@ -99,6 +104,56 @@ extern "C" int vs_ctx_mem_info(vs_ctx* c, uint64_t* free_b, uint64_t* total_b) {
     VS_HIP(hipMemGetInfo(&f, &t));
     if (free_b) *free_b = f;
     if (total_b) *total_b = t;
+    return VS_OK;
+}
+
+static hipEvent_t pool_event(vs_ctx* c) {
+    if (!c->event_pool.empty()) {
+        hipEvent_t e = c->event_pool.back();
+        c->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+hipEvent_t prof_begin(vs_ctx* c) {
+    if (!c->profiling) return nullptr;
+    hipEvent_t a = pool_event(c);
+    (void)hipEventRecord(a, c->stream);
+    return a;
+}
+void prof_end(vs_ctx* c, int kind, hipEvent_t a) {
+    if (!c->profiling || !a) return;
+    hipEvent_t b = pool_event(c);
+    (void)hipEventRecord(b, c->stream);
+    c->spans.push_back({kind, a, b});
+}
+extern "C" int vs_profile_enable(vs_ctx* c, int on) {
+    VS_REQUIRE(c, "vs_profile_enable: ctx is NULL");
+    c->profiling = on != 0;
+    return VS_OK;
+}
+extern "C" int vs_profile_read(vs_ctx* c, vs_profile* out, int reset) {
+    VS_REQUIRE(c && out, "vs_profile_read: bad args");
+    VS_HIP(hipStreamSynchronize(c->stream));
+    for (auto& sp : c->spans) {
+        float ms = 0.f;
+        VS_HIP(hipEventElapsedTime(&ms, sp.a, sp.b));
+        c->prof_ms[sp.kind] += ms;
+        c->prof_launches[sp.kind] += 1;
+        c->event_pool.push_back(sp.a);
+        c->event_pool.push_back(sp.b);
+    }
+    c->spans.clear();
+    for (int i = 0; i < 8; ++i) {
+        out->ms[i] = c->prof_ms[i];
+        out->launches[i] = c->prof_launches[i];
+        if (reset) {
+            c->prof_ms[i] = 0;
+            c->prof_launches[i] = 0;
+        }
+    }
     return VS_OK;
 }
 
@@ -591,7 +646,11 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
     VS_TRY(devbuf_reserve(c, w.stream_cnt, (size_t)nq * 4));
     VS_TRY(devbuf_reserve(c, w.stats, (size_t)nq * ST_N * 4));
     VS_TRY(devbuf_reserve(c, w.status, (size_t)nq * 4));
-    VS_TRY(launch_prepare_queries(ix, d_raw_q, nq, (float*)w.q_full.p, (uint64_t*)w.qcodes.p));
+    {
+        hipEvent_t ev = prof_begin(c);
+        VS_TRY(launch_prepare_queries(ix, d_raw_q, nq, (float*)w.q_full.p, (uint64_t*)w.qcodes.p));
+        prof_end(c, PK_PREPARE, ev);
+    }
     for (int attempt = 0;; ++attempt) {
         VS_TRY(devbuf_reserve(c, w.hash, (size_t)nq * caps.hashcap * 4));
         VS_TRY(devbuf_reserve(c, w.cand_ids, (size_t)nq * caps.idcap * 4));
@@ -614,7 +673,11 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
         s.out_cnt = (uint32_t*)w.stream_cnt.p;
         s.stats = (uint32_t*)w.stats.p;
         s.status = (uint32_t*)w.status.p;
-        VS_TRY(launch_search(ix, s));
+        {
+            hipEvent_t ev = prof_begin(c);
+            VS_TRY(launch_search(ix, s));
+            prof_end(c, PK_SEARCH, ev);
+        }
         if (!check_now) break;
         std::vector<uint32_t> status(nq);
         VS_HIP(hipMemcpyAsync(status.data(), w.status.p, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
@@ -634,12 +697,16 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
         VS_REQUIRE(ix->vecs, "diskann.query_rescore > 0 needs the heap vector column on the device");
         VS_TRY(devbuf_reserve(c, w.rr_dist, (size_t)nq * M * 4));
         VS_TRY(devbuf_reserve(c, w.resort_heap, (size_t)nq * bp.rescore * 8));
+        hipEvent_t ev = prof_begin(c);
         VS_TRY(launch_rerank(ix, (const float*)w.q_full.p, (const uint32_t*)w.stream_ids.p, nullptr,
                              (const uint32_t*)w.stream_cnt.p, M, nq, (float*)w.rr_dist.p));
+        prof_end(c, PK_RERANK, ev);
     }
+    hipEvent_t ev = prof_begin(c);
     VS_TRY(launch_resort(ix, nq, M, bp.rescore, bp.k, (const uint32_t*)w.stream_ids.p, (const uint32_t*)w.stream_cnt.p,
                          bp.rescore ? (const float*)w.rr_dist.p : nullptr, (uint64_t*)w.resort_heap.p, d_out_ids,
                          d_out_tids, d_out_dist));
+    prof_end(c, PK_RESORT, ev);
     return VS_OK;
 }
 
@@ -672,7 +739,7 @@ static uint32_t stream_len(uint32_t rescore, uint32_t k) { return rescore > 0 ? 
 static uint32_t chunk_queries(const vs_index* ix, const Caps& c, uint32_t M, uint32_t nq) {
     size_t per_q = (size_t)c.hashcap * 4 + (size_t)c.idcap * 4 + (size_t)M * 12 + ix->vec_stride * 4ull +
                    ix->code_stride * 8ull + 256;
-    size_t budget = 6ull << 30;
+    size_t budget = 24ull << 30;
     uint32_t m = (uint32_t)std::max<size_t>(1, std::min<size_t>(budget / per_q, 1u << 20));
     return std::min(m, nq);
 }

@@ -52,7 +52,17 @@ struct vs_ctx {
     size_t pinned_bytes = 0;
     hipEvent_t pinned_ev[2] = {nullptr, nullptr};
     hipDeviceProp_t prop;
+    // optional per-kernel event timing (vs_profile_*)
+    bool profiling = false;
+    struct ProfSpan { int kind; hipEvent_t a, b; };
+    std::vector<ProfSpan> spans;
+    std::vector<hipEvent_t> event_pool;
+    double prof_ms[8] = {0};
+    uint64_t prof_launches[8] = {0};
 };
+enum { PK_PREPARE = 0, PK_SEARCH = 1, PK_RERANK = 2, PK_RESORT = 3 };
+hipEvent_t prof_begin(vs_ctx* c);
+void prof_end(vs_ctx* c, int kind, hipEvent_t a);
 
 // growable device scratch buffer
 struct DevBuf {

@@ -53,6 +53,16 @@ class Context:
     def sync(self):
         check(self._L.vs_ctx_sync(self.h))
 
+    def profile_enable(self, on=True):
+        check(self._L.vs_profile_enable(self.h, int(on)))
+
+    def profile_read(self, reset=True):
+        """{kernel: (total_ms, launches)} from HIP events recorded on the ctx stream."""
+        p = _lib.Profile()
+        check(self._L.vs_profile_read(self.h, C.byref(p), int(reset)))
+        names = ["prepare_queries", "search", "rerank", "resort"]
+        return {n: (float(p.ms[k]), int(p.launches[k])) for k, n in enumerate(names)}
+
     def alloc(self, nbytes):
         p = C.c_void_p()
         check(self._L.vs_dev_alloc(self.h, nbytes, C.byref(p)))

@@ -182,17 +182,13 @@ def main():
         ctx.sync()
         torch.cuda.synchronize()
 
-    gathered = None
-    if world > 1:
-        gathered = [torch.empty_like(out_ids) for _ in range(world)], [torch.empty_like(out_dist) for _ in range(world)]
+    from pgvectorscale_amd.sharding import gather_topk
 
     def step(b):
         ix.search_batch_dev(qbuf[b], nq, L, S, k, C.c_void_p(out_ids.data_ptr()), None, C.c_void_p(out_dist.data_ptr()))
         st = ix.search_batch_dev_finish()  # waits for the kernels, checks overflow flags, sums the work counters
-        if world > 1:  # final top-k gather over RCCL/xGMI
-            import torch.distributed as dist
-            dist.all_gather(gathered[0], out_ids)
-            dist.all_gather(gathered[1], out_dist)
+        if world > 1:  # final top-k gather over RCCL/xGMI (the only collective on this path)
+            gather_topk(out_ids, out_dist)
         return st
 
     for b in range(args.warmup):

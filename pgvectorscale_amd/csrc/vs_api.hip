@@ -4,6 +4,7 @@
 #include <cstdarg>
 #include <cmath>
 #include <algorithm>
+#include <cstdlib>
 
 #include "vs_internal.h"
 
@@ -252,7 +253,7 @@ static int check_desc(const vs_index_desc* d) {
     uint64_t nbits = (uint64_t)d->dim_index * d->bits;
     VS_REQUIRE(d->words == (nbits + 63) / 64, "words=%u does not match ceil(dim_index*bits/64)=%llu", d->words,
                (unsigned long long)((nbits + 63) / 64));
-    VS_REQUIRE(nbits <= 65535, "dim_index*bits = %llu exceeds the 16-bit Hamming field of the candidate heap",
+    VS_REQUIRE(nbits <= (1u << 24), "dim_index*bits = %llu: Hamming distances must stay exactly representable in f32",
                (unsigned long long)nbits);
     VS_REQUIRE(d->num_neighbors >= 1 && d->num_neighbors <= 1024, "num_neighbors %u unsupported", d->num_neighbors);
     VS_REQUIRE(d->distance_type <= VS_IP, "unknown distance type %u", d->distance_type);
@@ -296,7 +297,7 @@ extern "C" void vs_index_free(vs_index* ix) {
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     SearchWorkspace& w = ix->ws;
-    DevBuf* bufs[] = {&w.q_full, &w.qcodes, &w.qlabels, &w.qlabel_off, &w.hash, &w.cand_ids, &w.stream_ids,
+    DevBuf* bufs[] = {&w.q_full, &w.qcodes, &w.qlabels, &w.qlabel_off, &w.hash, &w.heap_g, &w.stream_ids,
                       &w.stream_ham, &w.stream_cnt, &w.stats, &w.status, &w.rr_dist, &w.out_ids, &w.out_tids,
                       &w.out_dist, &w.resort_heap, &w.raw_q, &w.misc};
     for (DevBuf* b : bufs) devbuf_free(*b);
@@ -586,43 +587,44 @@ extern "C" int vs_rerank(vs_index* ix, const float* q_full, const uint32_t* ids,
 // batched scans
 // ---------------------------------------------------------------------------------------------------------------
 struct Caps {
-    uint32_t hcap, vcap, hashcap, idcap;
+    uint32_t hl, hcap, vcap, lh, hashcap, g0;
 };
 
+static uint32_t env_u32(const char* name, uint32_t dflt) {
+    const char* v = getenv(name);
+    return v && *v ? (uint32_t)strtoul(v, nullptr, 10) : dflt;
+}
+
 static Caps initial_caps(const vs_index* ix, uint32_t L, uint32_t M) {
-    // visits ~ 1.3-2 L before the first row + one per further row; each visit pushes <= R candidates, in practice
-    // about half of them are new.  Anything that overflows is retried with doubled capacities.
+    // visits ~ 1.3-2 L before the first row + one per further row; each visit pushes <= R candidates.
+    // LDS holds the hot part (top `hl` heap positions, an exact dedup table of `lh` slots, the visited list); colder
+    // state spills to per-scan global arrays that cost address space only.  Overflows are retried with doubled caps.
     uint64_t visits = 2ull * L + M + 32;
     uint64_t pushes = visits * ix->d.num_neighbors;
-    uint64_t h = std::max<uint64_t>(1024, pushes * 6 / 10);
     Caps c;
-    c.idcap = (uint32_t)std::min<uint64_t>(65536, round_up_u32((uint32_t)std::min<uint64_t>(h, 65536), 64));
-    c.hcap = c.idcap;
+    c.hl = env_u32("VS_HL", 1024);
+    c.lh = env_u32("VS_LH", 0);
+    c.g0 = env_u32("VS_G0", 4096);
+    c.hcap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(pushes, c.hl), 1u << 22);
     c.vcap = (uint32_t)std::min<uint64_t>(3ull * L + M + 64, 1u << 20);
-    c.hashcap = next_pow2_u32(2ull * c.idcap);
+    c.hashcap = std::max<uint32_t>(next_pow2_u32(std::min<uint64_t>(2ull * pushes, 1u << 23)), c.g0);
     return c;
 }
 
 static bool grow_caps(Caps& c, uint32_t ovf) {
     bool grew = false;
-    if (ovf & (OVF_HEAP | OVF_IDS)) {
-        if (c.idcap < 65536) {
-            c.idcap = std::min<uint32_t>(65536, c.idcap * 2);
-            c.hcap = c.idcap;
-            grew = true;
-        }
+    if ((ovf & OVF_HEAP) && c.hcap < (1u << 24)) {
+        c.hcap *= 2;
+        grew = true;
     }
     if (ovf & OVF_VISITED) {
         c.vcap *= 2;
         grew = true;
     }
-    if (ovf & OVF_HASH) {
-        if (c.hashcap < (1u << 24)) {
-            c.hashcap *= 2;
-            grew = true;
-        }
+    if ((ovf & OVF_HASH) && c.hashcap < (1u << 26)) {
+        c.hashcap *= 2;
+        grew = true;
     }
-    if (c.hashcap < 2 * c.idcap) c.hashcap = next_pow2_u32(2ull * c.idcap);
     return grew;
 }
 
@@ -652,22 +654,24 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
         prof_end(c, PK_PREPARE, ev);
     }
     for (int attempt = 0;; ++attempt) {
+        const size_t hg = caps.hcap > caps.hl ? caps.hcap - caps.hl : 0;
         VS_TRY(devbuf_reserve(c, w.hash, (size_t)nq * caps.hashcap * 4));
-        VS_TRY(devbuf_reserve(c, w.cand_ids, (size_t)nq * caps.idcap * 4));
-        VS_HIP(hipMemsetAsync(w.hash.p, 0xFF, (size_t)nq * caps.hashcap * 4, c->stream));
+        VS_TRY(devbuf_reserve(c, w.heap_g, std::max<size_t>((size_t)nq * hg * 8, 16)));
         SearchLaunch s;
         s.nq = nq;
         s.L = bp.L;
         s.M = M;
+        s.hl = caps.hl;
         s.hcap = caps.hcap;
         s.vcap = caps.vcap;
+        s.lh = caps.lh;
         s.hashcap = caps.hashcap;
-        s.idcap = caps.idcap;
+        s.g0 = caps.g0;
         s.qcodes = (const uint64_t*)w.qcodes.p;
         s.qlabels = d_qlabels;
         s.qlabel_off = d_qlabel_off;
+        s.heap_g = (uint64_t*)w.heap_g.p;
         s.hash = (uint32_t*)w.hash.p;
-        s.cand_ids = (uint32_t*)w.cand_ids.p;
         s.out_ids = (uint32_t*)w.stream_ids.p;
         s.out_ham = (uint32_t*)w.stream_ham.p;
         s.out_cnt = (uint32_t*)w.stream_cnt.p;
@@ -687,8 +691,8 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
         if (!ovf) break;
         if (st) st->retries++;
         if (attempt >= 6 || !grow_caps(caps, ovf)) {
-            vs_set_error("search structures overflowed (flags 0x%x) at hcap=%u vcap=%u hashcap=%u idcap=%u", ovf,
-                         caps.hcap, caps.vcap, caps.hashcap, caps.idcap);
+            vs_set_error("search structures overflowed (flags 0x%x) at hcap=%u vcap=%u hashcap=%u", ovf, caps.hcap,
+                         caps.vcap, caps.hashcap);
             return VS_ERR_CAPACITY;
         }
     }
@@ -737,7 +741,7 @@ static uint32_t stream_len(uint32_t rescore, uint32_t k) { return rescore > 0 ? 
 
 // how many queries fit one launch given the workspace budget
 static uint32_t chunk_queries(const vs_index* ix, const Caps& c, uint32_t M, uint32_t nq) {
-    size_t per_q = (size_t)c.hashcap * 4 + (size_t)c.idcap * 4 + (size_t)M * 12 + ix->vec_stride * 4ull +
+    size_t per_q = (size_t)c.hashcap * 4 + (size_t)(c.hcap > c.hl ? c.hcap - c.hl : 0) * 8 + (size_t)M * 12 + ix->vec_stride * 4ull +
                    ix->code_stride * 8ull + 256;
     size_t budget = 24ull << 30;
     uint32_t m = (uint32_t)std::max<size_t>(1, std::min<size_t>(budget / per_q, 1u << 20));

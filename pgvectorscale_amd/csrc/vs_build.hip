@@ -230,13 +230,14 @@ __global__ __launch_bounds__(WAVE) void k_build_backedges(const uint64_t* __rest
 
 struct BuildBufs {
     uint32_t *vis_ids = nullptr, *vis_d = nullptr, *vis_cnt = nullptr, *stats = nullptr, *status = nullptr;
-    uint32_t *hash = nullptr, *cand_ids = nullptr;
+    uint32_t* hash = nullptr;
+    uint64_t* heap_g = nullptr;
     uint32_t *edge_q = nullptr, *edge_q_sorted = nullptr, *seg_start = nullptr, *nseg = nullptr;
     uint64_t *edge_pd = nullptr, *edge_pd_sorted = nullptr;
     void* cub_tmp = nullptr;
     size_t cub_bytes = 0;
     void free_all() {
-        void* ps[] = {vis_ids, vis_d, vis_cnt, stats, status, hash, cand_ids, edge_q, edge_q_sorted, seg_start, nseg,
+        void* ps[] = {vis_ids, vis_d, vis_cnt, stats, status, hash, heap_g, edge_q, edge_q_sorted, seg_start, nseg,
                       edge_pd, edge_pd_sorted, cub_tmp};
         for (void* p : ps)
             if (p) (void)hipFree(p);
@@ -257,8 +258,9 @@ static int build_graph_impl(vs_index* ix, uint32_t L, double max_alpha_d, uint32
     if (batch_max == 0) batch_max = std::min<uint32_t>(65536, std::max<uint32_t>(1024, n / 64));
     // capacities of the build-mode search
     uint32_t vmax = std::max<uint32_t>(round_up_u32(3 * L + 64, 64), 128);      // visited list cap (candidates of prune)
-    uint32_t idcap = std::min<uint32_t>(65536, round_up_u32((2 * L + 64) * R * 6 / 10 + 1024, 64));
-    uint32_t hashcap = next_pow2_u32(2ull * idcap);
+    uint32_t hl = 512, lh = 0;                                       // LDS-resident parts of the search state
+    uint32_t hcap = (2 * L + 64) * R;                                // heap capacity (global spill beyond hl)
+    uint32_t hashcap = next_pow2_u32(2ull * hcap);
     uint32_t cmax = 1;
     while (cmax < R + 128) cmax <<= 1;  // back-edge candidate cap (pow2, >= R + new sources kept)
     const size_t code_bytes = (size_t)stride * 8;
@@ -299,26 +301,28 @@ static int build_graph_impl(vs_index* ix, uint32_t L, double max_alpha_d, uint32
                 hash_alloc = (size_t)batch_max * hashcap * 4;
                 VS_HIP(hipMalloc(&B.hash, hash_alloc));
             }
-            if ((size_t)bn * idcap * 4 > ids_alloc || !B.cand_ids) {
-                if (B.cand_ids) VS_HIP(hipFree(B.cand_ids));
-                B.cand_ids = nullptr;
-                ids_alloc = (size_t)batch_max * idcap * 4;
-                VS_HIP(hipMalloc(&B.cand_ids, ids_alloc));
+            const size_t hg = hcap > hl ? hcap - hl : 0;
+            if ((size_t)bn * hg * 8 > ids_alloc || !B.heap_g) {
+                if (B.heap_g) VS_HIP(hipFree(B.heap_g));
+                B.heap_g = nullptr;
+                ids_alloc = std::max<size_t>((size_t)batch_max * hg * 8, 16);
+                VS_HIP(hipMalloc(&B.heap_g, ids_alloc));
             }
-            VS_HIP(hipMemsetAsync(B.hash, 0xFF, (size_t)bn * hashcap * 4, st));
             SearchLaunch s;
             s.nq = bn;
             s.L = L;
             s.M = vmax;
-            s.hcap = idcap;
+            s.hl = hl;
+            s.hcap = hcap;
             s.vcap = vmax + 64;
+            s.lh = lh;
             s.hashcap = hashcap;
-            s.idcap = idcap;
+            s.g0 = 4096;
             s.qcodes = ix->codes + (size_t)b0 * stride;
             s.qlabels = nullptr;
             s.qlabel_off = nullptr;
+            s.heap_g = B.heap_g;
             s.hash = B.hash;
-            s.cand_ids = B.cand_ids;
             s.out_ids = B.vis_ids;
             s.out_ham = B.vis_d;
             s.out_cnt = B.vis_cnt;
@@ -341,9 +345,8 @@ static int build_graph_impl(vs_index* ix, uint32_t L, double max_alpha_d, uint32
                 vs_set_error("vs_build_graph: visited list overflow (search_list_size too large for LDS)");
                 return VS_ERR_CAPACITY;
             }
-            if (ovf & (OVF_HEAP | OVF_IDS)) idcap = std::min<uint32_t>(65536, idcap * 2);
+            if (ovf & OVF_HEAP) hcap *= 2;
             if (ovf & OVF_HASH) hashcap *= 2;
-            if (hashcap < 2 * idcap) hashcap = next_pow2_u32(2ull * idcap);
         }
         // out-edges of the new nodes + back-edge requests
         hipLaunchKernelGGL(k_build_prune_new, dim3(bn), dim3(WAVE), lds_new, st, ix->codes, stride, ix->nbrs,

@@ -1,0 +1,43 @@
+// vs_device.h — device helpers shared by the gfx950 kernels (wave64).
+#pragma once
+#include "vs_internal.h"
+
+#define WAVE 64
+
+// ---------------------------------------------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+// add the value held by the lane with index (lane ^ 1) / (lane ^ 2) via DPP quad_perm (no LDS traffic)
+__device__ __forceinline__ uint32_t quad_sum(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1 /*quad_perm [1,0,3,2]*/, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E /*quad_perm [2,3,0,1]*/, 0xF, 0xF, true);
+    return v;
+}
+
+__device__ __forceinline__ uint32_t hash_u32(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x7feb352dU;
+    x ^= x >> 15;
+    x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
+}
+
+// Hamming distance of one code row against the query code held in LDS, computed by a group of 4 lanes
+// (lane l4 covers words 2*l4 + 8t, 2*l4+1 + 8t: 16 B per lane per step, 64 B contiguous per group per step).
+// Rows are code_stride (even) words, zero padded, so the padded tail contributes popcount(0^0)=0.
+__device__ __forceinline__ uint32_t ham_row4(const uint64_t* __restrict__ row, const uint64_t* qc, int l4,
+                                             uint32_t code_stride, bool active) {
+    uint32_t acc = 0;
+    if (active) {
+        for (uint32_t w = 2u * (uint32_t)l4; w < code_stride; w += 8) {
+            const ulonglong2 r = *reinterpret_cast<const ulonglong2*>(row + w);
+            const ulonglong2 qq = *reinterpret_cast<const ulonglong2*>(qc + w);
+            acc += (uint32_t)__popcll(r.x ^ qq.x) + (uint32_t)__popcll(r.y ^ qq.y);
+        }
+    }
+    return quad_sum(acc);
+}
+

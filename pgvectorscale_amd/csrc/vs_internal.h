@@ -71,7 +71,7 @@ struct DevBuf {
 };
 
 struct SearchWorkspace {
-    DevBuf q_full, qcodes, qlabels, qlabel_off, hash, cand_ids, stream_ids, stream_ham, stream_cnt, stats, status,
+    DevBuf q_full, qcodes, qlabels, qlabel_off, hash, heap_g, stream_ids, stream_ham, stream_cnt, stats, status,
         rr_dist, out_ids, out_tids, out_dist, resort_heap, raw_q, misc;
     // pending async call (vs_search_batch_dev)
     bool pending = false;
@@ -108,20 +108,26 @@ void devbuf_free(DevBuf& b);
 // ---- kernel launch wrappers (defined in the .hip files) -------------------------------------------------------
 struct SearchLaunch {
     uint32_t nq, L, M;
-    uint32_t hcap, vcap, hashcap, idcap;
+    uint32_t hl;       // candidate-heap entries resident in LDS (heap positions [0, hl))
+    uint32_t hcap;     // total candidate-heap capacity; positions [hl, hcap) live in heap_g
+    uint32_t vcap;     // visited-list capacity (LDS)
+    uint32_t lh;       // slots of the LDS-resident exact dedup table (power of two, 0 = none)
+    uint32_t hashcap;  // slots reserved per scan for the global overflow dedup ladder
+    uint32_t g0;       // slots of the ladder's first level (power of two); level j has g0 << j slots
     const uint64_t* qcodes;        // [nq][code_stride]
     const int16_t* qlabels;        // may be null
     const uint32_t* qlabel_off;    // may be null => no label keys
-    uint32_t* hash;                // [nq][hashcap], pre-filled with 0xFF
-    uint32_t* cand_ids;            // [nq][idcap]
+    uint64_t* heap_g;              // [nq][hcap - hl]  (untouched unless a heap outgrows LDS)
+    uint32_t* hash;                // [nq][hashcap]    (lazily cleared by the kernel when first needed)
     uint32_t* out_ids;             // [nq][M]
     uint32_t* out_ham;             // [nq][M]
     uint32_t* out_cnt;             // [nq]
     uint32_t* stats;               // [nq][8]
     uint32_t* status;              // [nq]
 };
-enum { ST_VISITS = 0, ST_CAND = 1, ST_DQ = 2, ST_READS = 3, ST_NEXT = 4, ST_N = 8 };
-enum { OVF_HEAP = 1, OVF_VISITED = 2, OVF_HASH = 4, OVF_IDS = 8 };
+enum { ST_VISITS = 0, ST_CAND = 1, ST_DQ = 2, ST_READS = 3, ST_NEXT = 4, ST_GSPILL = 5, ST_PFHIT = 6, ST_N = 8 };
+enum { OVF_HEAP = 1, OVF_VISITED = 2, OVF_HASH = 4 };
+size_t search_lds_bytes(const vs_index* idx, const SearchLaunch& s);
 
 int launch_prepare_queries(vs_index* idx, const float* d_raw, uint32_t nq, float* d_q_full, uint64_t* d_qcodes);
 int launch_quantize_rows(vs_index* idx, const float* d_rows, uint32_t row_stride, uint32_t nrows, uint64_t* d_codes,

@@ -4,7 +4,7 @@
 //   K1 k_hamming_gather                    : distance_xor_optimized on gathers (AM/distance/mod.rs:266-323)
 //   K2 k_rerank                            : distance_l2/cosine/inner_product in the reference's AVX2 accumulation
 //                                            order (AM/distance/mod.rs:325-435, AM/sbq/storage.rs:304-328)
-//   K3 k_search                            : ListSearchResult + greedy_search_iterate + visit_lsn_internal +
+//   K3 k_search (vs_search.hip)            : ListSearchResult + greedy_search_iterate + visit_lsn_internal +
 //                                            TSVResponseIterator::next (AM/graph/mod.rs:74-185,357-385,
 //                                            AM/sbq/storage.rs:135-190, AM/scan.rs:210-242)
 //      k_resort                            : the rescore window of next_with_resort (AM/scan.rs:244-305)
@@ -14,45 +14,7 @@
 // (4 lanes x 16 B per code row), the candidate heap / visited list live in LDS, the dedup hash set in L2.
 // Compiled with -ffp-contract=off: the reference's L2 kernel uses separate mul+add, its dot kernel FMA.
 #include "vs_internal.h"
-
-#define WAVE 64
-
-// ---------------------------------------------------------------------------------------------------------------
-// small device helpers
-// ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
-
-// add the value held by the lane with index (lane ^ 1) / (lane ^ 2) via DPP quad_perm (no LDS traffic)
-__device__ __forceinline__ uint32_t quad_sum(uint32_t v) {
-    v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1 /*quad_perm [1,0,3,2]*/, 0xF, 0xF, true);
-    v += (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E /*quad_perm [2,3,0,1]*/, 0xF, 0xF, true);
-    return v;
-}
-
-__device__ __forceinline__ uint32_t hash_u32(uint32_t x) {
-    x ^= x >> 16;
-    x *= 0x7feb352dU;
-    x ^= x >> 15;
-    x *= 0x846ca68bU;
-    x ^= x >> 16;
-    return x;
-}
-
-// Hamming distance of one code row against the query code held in LDS, computed by a group of 4 lanes
-// (lane l4 covers words 2*l4 + 8t, 2*l4+1 + 8t: 16 B per lane per step, 64 B contiguous per group per step).
-// Rows are code_stride (even) words, zero padded, so the padded tail contributes popcount(0^0)=0.
-__device__ __forceinline__ uint32_t ham_row4(const uint64_t* __restrict__ row, const uint64_t* qc, int l4,
-                                             uint32_t code_stride, bool active) {
-    uint32_t acc = 0;
-    if (active) {
-        for (uint32_t w = 2u * (uint32_t)l4; w < code_stride; w += 8) {
-            const ulonglong2 r = *reinterpret_cast<const ulonglong2*>(row + w);
-            const ulonglong2 qq = *reinterpret_cast<const ulonglong2*>(qc + w);
-            acc += (uint32_t)__popcll(r.x ^ qq.x) + (uint32_t)__popcll(r.y ^ qq.y);
-        }
-    }
-    return quad_sum(acc);
-}
+#include "vs_device.h"
 
 // ---------------------------------------------------------------------------------------------------------------
 // preprocess_cosine on a vector held in LDS (AM/distance/mod.rs:225-253): sequential f32 sum of squares (lane 0),
@@ -346,341 +308,6 @@ __global__ void k_validate_nbrs(const uint32_t* __restrict__ nbrs, uint32_t nbr_
             if (r[i] == r[j]) atomicOr(flag, 1u);
 }
 
-// ===============================================================================================================
-// K3: the streaming beam search.  One wave = one scan.
-// ===============================================================================================================
-struct SearchArgs {
-    const uint64_t* codes;
-    const uint32_t* nbrs;
-    const uint64_t* tids;
-    const uint32_t* label_off;
-    const int16_t* label_val;
-    const int16_t* ls_labels;
-    const uint32_t* ls_nodes;
-    uint32_t code_stride, nbr_stride, R, n, n_ls, default_start;
-    SearchLaunch s;
-};
-
-#define MAX_QLABELS 64
-
-// candidates: BinaryHeap<Reverse<ListSearchNeighbor>> (AM/graph/mod.rs:75).  Entry = (hamming << 16) | seq where seq
-// indexes this query's cand_ids[] (push order).  Ordering uses the distance only (DistanceWithTieBreak with the
-// constant tie-break 0 of with_query, AM/graph/neighbor_with_distance.rs:31-43,74-83).  Heap index i lives at
-// heap[i + 1] so sibling pairs are 8-byte aligned.  Mechanics are Rust std BinaryHeap's (push = sift_up; pop = swap
-// last into the root, sift_down_to_bottom, then sift_up), because the order of equal distances depends on them.
-struct WaveHeap {
-    uint32_t* h;  // LDS
-    uint32_t len;
-    __device__ __forceinline__ uint32_t key(uint32_t e) const { return e >> 16; }
-    // sift_up(0, pos): while pos>0 { parent=(pos-1)/2; if elem <= parent break }  with Reverse => parent.d <= elem.d
-    __device__ __forceinline__ void sift_up(uint32_t pos, uint32_t elem, int lane) {
-        const uint32_t ek = key(elem);
-        while (pos > 0) {
-            uint32_t parent = (pos - 1) >> 1;
-            uint32_t pe = rfl(h[parent + 1]);
-            if (key(pe) <= ek) break;
-            if (lane == 0) h[pos + 1] = pe;
-            pos = parent;
-        }
-        if (lane == 0) h[pos + 1] = elem;
-    }
-    __device__ __forceinline__ void push(uint32_t elem, int lane) {
-        uint32_t pos = len;
-        len = pos + 1;
-        sift_up(pos, elem, lane);
-    }
-    __device__ __forceinline__ uint32_t peek() const { return rfl(h[1]); }
-    // pop(): Vec::pop; swap with data[0]; sift_down_to_bottom(0)
-    __device__ __forceinline__ uint32_t pop(int lane) {
-        uint32_t item = rfl(h[len]);  // data[len-1]
-        len -= 1;
-        if (len == 0) return item;
-        uint32_t top = rfl(h[1]);
-        const uint32_t end = len;
-        uint32_t pos = 0, child = 1;
-        const uint32_t lim = end >= 2 ? end - 2 : 0;
-        while (child <= lim) {
-            // child += (data[child] <= data[child+1]) ; Reverse => right.d <= left.d picks the right child
-            uint2 pr = *reinterpret_cast<const uint2*>(h + child + 1);
-            uint32_t le = rfl(pr.x), ri = rfl(pr.y);
-            uint32_t pick = (key(ri) <= key(le)) ? 1u : 0u;
-            child += pick;
-            if (lane == 0) h[pos + 1] = pick ? ri : le;
-            pos = child;
-            child = 2 * pos + 1;
-        }
-        if (child == end - 1) {
-            uint32_t ce = rfl(h[child + 1]);
-            if (lane == 0) h[pos + 1] = ce;
-            pos = child;
-        }
-        sift_up(pos, item, lane);
-        return top;
-    }
-};
-
-// BUILD = true: greedy_search_for_build (AM/graph/mod.rs:285-327): one greedy_search_iterate, then the whole visited
-// list (sorted by distance) is the output; used by the graph builder with the new node's own code as the query.
-template <bool BUILD>
-__global__ __launch_bounds__(WAVE) void k_search(SearchArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lane = threadIdx.x;
-    const uint32_t q = blockIdx.x;
-    const SearchLaunch& s = a.s;
-    if (q >= s.nq) return;
-
-    // ---- LDS carve (all offsets multiples of 16 B) ----
-    uint32_t* heap_mem = reinterpret_cast<uint32_t*>(smem);                  // hcap + 2 (index i at [i+1])
-    uint32_t* vdist = heap_mem + round_up_u32(s.hcap + 2, 4);               // sorted visited list: distances
-    uint32_t* vid = vdist + round_up_u32(s.vcap, 4);                        //                      node ids
-    uint32_t* surv_id = vid + round_up_u32(s.vcap, 4);                      // survivors of one neighbor chunk
-    uint32_t* surv_d = surv_id + 64;
-    uint64_t* qc = reinterpret_cast<uint64_t*>(surv_d + 64);                // query code
-    int16_t* ql = reinterpret_cast<int16_t*>(qc + a.code_stride);           // query labels (sorted, dedup)
-
-    for (uint32_t w = lane; w < a.code_stride; w += WAVE) qc[w] = s.qcodes[(size_t)q * a.code_stride + w];
-    // LabeledVector.labels: Some iff a scan key exists (AM/labels/mod.rs:222-236)
-    const bool labels_some = s.qlabel_off != nullptr;
-    uint32_t nql = 0;
-    if (labels_some) {
-        uint32_t lb = s.qlabel_off[q], le = s.qlabel_off[q + 1];
-        nql = min(le - lb, (uint32_t)MAX_QLABELS);
-        for (uint32_t i = lane; i < nql; i += WAVE) ql[i] = s.qlabels[lb + i];
-    }
-    const bool has_label_filter = labels_some && nql > 0;  // AM/scan.rs:189 ; no_filter = !has_label_filter
-    __syncthreads();
-
-    uint32_t* hash = s.hash + (size_t)q * s.hashcap;
-    const uint32_t hmask = s.hashcap - 1;
-    uint32_t* cand_ids = s.cand_ids + (size_t)q * s.idcap;
-
-    WaveHeap heap{heap_mem, 0};
-    uint32_t vlen = 0, npush = 0, ninserted = 0, emitted = 0, status = 0;
-    uint32_t st_visits = 0, st_cand = 0, st_dq = 0, st_reads = 0, st_next = 0;
-
-    // ---- ListSearchResult::new: start nodes (AM/graph/mod.rs:97-124, AM/graph/start_nodes.rs:39-48) ----
-    {
-        uint32_t nstarts = labels_some ? nql : 1u;
-        if (a.default_start == VS_INVALID_NODE || a.n == 0) nstarts = 0;  // ListSearchResult::empty()
-        for (uint32_t si = 0; si < nstarts; ++si) {
-            uint32_t sn = VS_INVALID_NODE;
-            if (!labels_some) {
-                sn = a.default_start;
-            } else {
-                int16_t lab = ql[si];
-                int lo = 0, hi = (int)a.n_ls;  // binary search in the sorted label->start map
-                while (lo < hi) {
-                    int mid = (lo + hi) >> 1;
-                    if (a.ls_labels[mid] < lab) lo = mid + 1;
-                    else hi = mid;
-                }
-                if (lo < (int)a.n_ls && a.ls_labels[lo] == lab) sn = a.ls_nodes[lo];
-            }
-            sn = rfl(sn);
-            if (sn == VS_INVALID_NODE) continue;
-            // create_lsn_for_start_node (AM/sbq/storage.rs:365-391): prepare_insert, read node, distance, push
-            uint32_t fresh = 0;
-            if (lane == 0) {
-                uint32_t hslot = hash_u32(sn) & hmask;
-                while (true) {
-                    uint32_t old = atomicCAS(&hash[hslot], VS_EMPTY, sn);
-                    if (old == VS_EMPTY) { fresh = 1; break; }
-                    if (old == sn) break;
-                    hslot = (hslot + 1) & hmask;
-                }
-            }
-            fresh = rfl(fresh);
-            if (!fresh) continue;
-            ninserted++;
-            st_reads++;
-            uint32_t d = ham_row4(a.codes + (size_t)sn * a.code_stride, qc, lane & 3, a.code_stride, lane < 4);
-            d = rfl(d);
-            st_dq++;
-            st_cand++;
-            if (lane == 0) cand_ids[npush] = sn;
-            heap.push((d << 16) | npush, lane);
-            npush++;
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-
-    // ---- TSVResponseIterator::next, repeated until M rows are emitted (AM/scan.rs:210-242) ----
-    while (emitted < s.M && status == 0) {
-        st_next++;
-        bool got = false;
-        while (true) {  // "Iterate until we find a non-deleted tuple"
-            // ---- greedy_search_iterate (AM/graph/mod.rs:357-385) ----
-            while (true) {
-                // visit_closest(L) (AM/graph/mod.rs:153-170)
-                if (heap.len == 0) break;
-                if (vlen > s.L) {
-                    uint32_t node_at_pos = rfl(vdist[s.L - 1]);
-                    if ((heap.peek() >> 16) >= node_at_pos) break;
-                }
-                uint32_t head = heap.pop(lane);
-                const uint32_t hd = head >> 16;
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                const uint32_t node = rfl(cand_ids[head & 0xFFFFu]);
-                // visited.insert(partition_point(|x| *x < head), head): before the first element >= head
-                if (vlen + 1 > s.vcap) {
-                    if (BUILD) vlen = s.vcap - 1;  // build mode keeps the closest vcap visited nodes as prune candidates
-                    else { status |= OVF_VISITED; break; }
-                }
-                {
-                    uint32_t cntlt = 0;
-                    for (uint32_t base = 0; base < vlen; base += WAVE) {
-                        uint32_t i = base + lane;
-                        bool lt = i < vlen && vdist[i] < hd;
-                        cntlt += (uint32_t)__popcll(__ballot(lt));
-                    }
-                    const uint32_t idx = cntlt;
-                    uint32_t hi = vlen;
-                    while (hi > idx) {  // shift [idx, vlen) right by one, top chunk first
-                        uint32_t lo = (hi - idx > WAVE) ? hi - WAVE : idx;
-                        uint32_t i = lo + lane;
-                        uint32_t td = 0, ti = 0;
-                        if (i < hi) { td = vdist[i]; ti = vid[i]; }
-                        __syncthreads();
-                        if (i < hi) { vdist[i + 1] = td; vid[i + 1] = ti; }
-                        __syncthreads();
-                        hi = lo;
-                    }
-                    if (lane == 0) { vdist[idx] = hd; vid[idx] = node; }
-                    vlen++;
-                    __syncthreads();
-                }
-                st_visits++;
-                // ---- visit_lsn_internal, Disk arm (AM/sbq/storage.rs:135-190) ----
-                st_reads++;  // SbqNode::read(visiting)
-                const uint32_t* nrow = a.nbrs + (size_t)node * a.nbr_stride;
-                bool list_ended = false;
-                for (uint32_t c0 = 0; c0 < a.R && !list_ended && status == 0; c0 += WAVE) {
-                    uint32_t slot = c0 + lane;
-                    uint32_t nid = (slot < a.R) ? nrow[slot] : VS_INVALID_NODE;
-                    // list ends at the first InvalidBlockNumber (AM/sbq/node.rs:260-285)
-                    uint64_t inval = __ballot(nid == VS_INVALID_NODE);
-                    uint32_t nvalid = inval ? (uint32_t)__builtin_ctzll(inval) : WAVE;
-                    if (nvalid < WAVE) list_ended = true;
-                    bool act = (uint32_t)lane < nvalid;
-                    // prepare_insert: HashSet::insert (marks BEFORE the label check, AM/sbq/storage.rs:148-172)
-                    bool fresh = false;
-                    if (act) {
-                        uint32_t hslot = hash_u32(nid) & hmask;
-                        for (uint32_t probe = 0; probe <= hmask; ++probe) {
-                            uint32_t old = atomicCAS(&hash[hslot], VS_EMPTY, nid);
-                            if (old == VS_EMPTY) { fresh = true; break; }
-                            if (old == nid) break;
-                            hslot = (hslot + 1) & hmask;
-                        }
-                    }
-                    uint64_t fm = __ballot(fresh);
-                    uint32_t nfresh = (uint32_t)__popcll(fm);
-                    ninserted += nfresh;
-                    st_reads += nfresh;  // SbqNode::read(neighbor)
-                    if (ninserted * 4u > s.hashcap * 3u) { status |= OVF_HASH; break; }
-                    // label filter: query.labels.overlaps(node.labels) (AM/labels/mod.rs:124-142)
-                    bool pass = fresh;
-                    if (fresh && has_label_filter) {
-                        uint32_t lb = a.label_off[nid], le = a.label_off[nid + 1];
-                        uint32_t i = 0, j = lb;
-                        bool ov = false;
-                        while (i < nql && j < le) {
-                            int16_t x = ql[i], y = a.label_val[j];
-                            if (x == y) { ov = true; break; }
-                            if (x < y) ++i;
-                            else ++j;
-                        }
-                        pass = ov;
-                    }
-                    uint64_t pm = __ballot(pass);
-                    uint32_t c = (uint32_t)__popcll(pm);
-                    if (c == 0) continue;
-                    // compact survivors in neighbor-list order
-                    if (pass) surv_id[__popcll(pm & ((1ull << lane) - 1ull))] = nid;
-                    __syncthreads();
-                    // distances: 4 lanes per code row, 16 rows per pass, all loads of the chunk issued up front
-#pragma unroll
-                    for (int pass_i = 0; pass_i < 4; ++pass_i) {
-                        uint32_t j = (uint32_t)pass_i * 16u + (uint32_t)(lane >> 2);
-                        bool valid = j < c;
-                        uint32_t id = valid ? surv_id[j] : 0;
-                        uint32_t d = ham_row4(a.codes + (size_t)id * a.code_stride, qc, lane & 3, a.code_stride, valid);
-                        if (valid && (lane & 3) == 0) surv_d[j] = d;
-                    }
-                    st_dq += c;
-                    st_cand += c;
-                    if (npush + c > s.idcap) { status |= OVF_IDS; break; }
-                    if (heap.len + c > s.hcap) { status |= OVF_HEAP; break; }
-                    if ((uint32_t)lane < c) cand_ids[npush + lane] = surv_id[lane];
-                    __syncthreads();
-                    // insert_neighbor in list order (AM/graph/mod.rs:144-147)
-                    for (uint32_t j = 0; j < c; ++j) {
-                        uint32_t d = rfl(surv_d[j]);
-                        heap.push((d << 16) | (npush + j), lane);
-                    }
-                    npush += c;
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                }
-                if (status) break;
-            }
-            if (status) break;
-            if (BUILD) break;
-            // ---- consume (AM/graph/mod.rs:174-184) + return_lsn (AM/sbq/storage.rs:404-414) ----
-            if (vlen == 0) break;  // None
-            __syncthreads();
-            const uint32_t fd = rfl(vdist[0]);
-            const uint32_t fnode = rfl(vid[0]);
-            {   // visited.remove(0)
-                uint32_t lo = 1;
-                while (lo < vlen) {
-                    uint32_t i = lo + lane;
-                    uint32_t hi = min(lo + WAVE, vlen);
-                    uint32_t td = 0, ti = 0;
-                    if (i < hi) { td = vdist[i]; ti = vid[i]; }
-                    __syncthreads();
-                    if (i < hi) { vdist[i - 1] = td; vid[i - 1] = ti; }
-                    __syncthreads();
-                    lo = hi;
-                }
-                vlen--;
-            }
-            st_reads++;
-            const uint64_t tid = a.tids[fnode];
-            if ((tid & 0xFFFFull) == 0) continue;  // InvalidOffsetNumber: deleted tuple (AM/scan.rs:231-234)
-            if (lane == 0) {
-                s.out_ids[(size_t)q * s.M + emitted] = fnode;
-                s.out_ham[(size_t)q * s.M + emitted] = fd;
-            }
-            emitted++;
-            got = true;
-            break;
-        }
-        if (!got) break;
-    }
-    if (BUILD) {
-        __syncthreads();
-        emitted = min(vlen, s.M);
-        for (uint32_t i = lane; i < emitted; i += WAVE) {
-            s.out_ids[(size_t)q * s.M + i] = vid[i];
-            s.out_ham[(size_t)q * s.M + i] = vdist[i];
-        }
-    }
-    for (uint32_t i = emitted + lane; i < s.M; i += WAVE) {
-        s.out_ids[(size_t)q * s.M + i] = VS_INVALID_NODE;
-        s.out_ham[(size_t)q * s.M + i] = 0xFFFFFFFFu;
-    }
-    if (lane == 0) {
-        s.out_cnt[q] = emitted;
-        s.status[q] = status;
-        uint32_t* st = s.stats + (size_t)q * ST_N;
-        st[ST_VISITS] = st_visits;
-        st[ST_CAND] = st_cand;
-        st[ST_DQ] = st_dq;
-        st[ST_READS] = st_reads;
-        st[ST_NEXT] = st_next;
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------------
 // Rescore window of next_with_resort (AM/scan.rs:244-305): BinaryHeap<ResortData> with
 // cmp(self, other) = other.distance.total_cmp(self.distance)  (AM/scan.rs:111-117).  One thread per query.
@@ -816,49 +443,6 @@ int launch_rerank(vs_index* idx, const float* d_q_full, const uint32_t* d_ids, c
     VS_HIP(hipGetLastError());
     return VS_OK;
 }
-
-static size_t search_lds_bytes(const vs_index* idx, const SearchLaunch& s) {
-    size_t words32 = round_up_u32(s.hcap + 2, 4) + 2 * (size_t)round_up_u32(s.vcap, 4) + 128;
-    return words32 * 4 + (size_t)idx->code_stride * 8 + MAX_QLABELS * 2 + 16;
-}
-
-int launch_search(vs_index* idx, const SearchLaunch& s, bool build_mode) {
-    if (s.nq == 0) return VS_OK;
-    SearchArgs a;
-    a.codes = idx->codes;
-    a.nbrs = idx->nbrs;
-    a.tids = idx->tids;
-    a.label_off = idx->label_off;
-    a.label_val = idx->label_val;
-    a.ls_labels = idx->ls_labels;
-    a.ls_nodes = idx->ls_nodes;
-    a.code_stride = idx->code_stride;
-    a.nbr_stride = idx->nbr_stride;
-    a.R = idx->d.num_neighbors;
-    a.n = idx->d.n;
-    a.n_ls = idx->d.n_label_starts;
-    a.default_start = idx->d.default_start;
-    a.s = s;
-    size_t lds = search_lds_bytes(idx, s);
-    if (lds > 160 * 1024) {
-        vs_set_error("search_list_size too large for the LDS-resident candidate heap (%zu B needed)", lds);
-        return VS_ERR_CAPACITY;
-    }
-    static bool attr_set = false;
-    if (!attr_set) {
-        VS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_search<false>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        VS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_search<true>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
-    if (build_mode) hipLaunchKernelGGL(k_search<true>, dim3(s.nq), dim3(WAVE), lds, idx->ctx->stream, a);
-    else hipLaunchKernelGGL(k_search<false>, dim3(s.nq), dim3(WAVE), lds, idx->ctx->stream, a);
-    VS_HIP(hipGetLastError());
-    return VS_OK;
-}
-
-size_t vs_search_lds_bytes(const vs_index* idx, const SearchLaunch& s) { return search_lds_bytes(idx, s); }
 
 int launch_resort(vs_index* idx, uint32_t nq, uint32_t M, uint32_t rescore, uint32_t k, const uint32_t* d_stream_ids,
                   const uint32_t* d_cnt, const float* d_dist, uint64_t* d_heap_ws, uint32_t* d_out_ids,

@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Kernel-level A/B harness for the search path: builds one device-resident index, then times the batched scan pipeline
+under different on-chip state splits (VS_HL = heap entries in LDS, VS_LH = LDS dedup slots) in ONE process.
+
+  python scripts/perf_search.py --n 1000000 --nq 16384 --configs 1024:4096,512:2048,4096:4096
+"""
+import argparse
+import ctypes as C
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=1_000_000)
+    ap.add_argument("--dim", type=int, default=768)
+    ap.add_argument("--nq", type=int, default=16384)
+    ap.add_argument("--L", type=int, default=100)
+    ap.add_argument("--rescore", type=int, default=50)
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--reps", type=int, default=4)
+    ap.add_argument("--configs", default="1024:4096")
+    ap.add_argument("--kind", default="clustered", choices=["clustered", "hard"])
+    args = ap.parse_args()
+    import numpy as np
+    import torch  # noqa: F401
+    import pgvectorscale_amd as P
+    from pgvectorscale_amd import _lib
+    from pgvectorscale_amd.datagen import DatagenParams, fill_device
+
+    ctx = P.Context(0)
+    ix = P.DiskAnnIndex.alloc(ctx, n=args.n, dim_full=args.dim, num_neighbors=50, distance_type=P.VS_L2)
+    gp = DatagenParams(seed=3, dim=args.dim) if args.kind == "clustered" else \
+        DatagenParams(seed=3, dim=args.dim, latent_dim=64, n_clusters=16, intra_pct=100, noise_pct=40)
+    vp, _ = ix.array(_lib.ARR_VECS)
+    t0 = time.time()
+    fill_device(ctx, gp, 0, args.n, vp)
+    ix.refresh_norms()
+    ix.sbq_train()
+    ix.sbq_quantize_corpus()
+    ix.build_graph(search_list_size=100, max_alpha=1.2)
+    print(f"index ready in {time.time() - t0:.2f}s", flush=True)
+    nq, k = args.nq, args.k
+    q = ctx.alloc(nq * args.dim * 4)
+    fill_device(ctx, gp, 1 << 40, nq, q)
+    out = ctx.alloc(nq * k * 4)
+    W, R = ix.desc.words, ix.desc.num_neighbors
+    ref_ids = None
+    for cfg in args.configs.split(","):
+        parts = cfg.split(":")
+        hl, lh = parts[0], parts[1]
+        os.environ["VS_HL"], os.environ["VS_LH"] = hl, lh
+        os.environ["VS_G0"] = parts[2] if len(parts) > 2 else "4096"
+        ctx.profile_enable(True)
+        ix.search_batch_dev(q, nq, args.L, args.rescore, k, out)
+        ix.search_batch_dev_finish()
+        ctx.profile_read(reset=True)
+        t0 = time.perf_counter()
+        for _ in range(args.reps):
+            ix.search_batch_dev(q, nq, args.L, args.rescore, k, out)
+            st = ix.search_batch_dev_finish()
+        wall = (time.perf_counter() - t0) / args.reps
+        prof = ctx.profile_read(reset=True)
+        ids = ctx.download(out, np.empty((nq, k), np.uint32))
+        same = "ref" if ref_ids is None else str(bool((ids == ref_ids).all()))
+        if ref_ids is None:
+            ref_ids = ids
+        ms = prof["search"][0] / prof["search"][1]
+        bytes_ = st["visited_nodes"] * 4 * R + st["quantized_distance_comparisons"] * 8 * W
+        print(f"HL={hl:>5} LH={lh:>5} G0={os.environ['VS_G0']:>5}: search {ms:8.3f} ms  rerank {prof['rerank'][0] / prof['rerank'][1]:.3f} ms  wall {wall * 1e3:8.3f} ms "
+              f"-> {nq / wall:10.0f} QPS  {bytes_ / ms / 1e6:7.1f} GB/s alg  visits/q {st['visited_nodes'] / nq:.1f} "
+              f"dq/q {st['quantized_distance_comparisons'] / nq:.1f}  same_ids={same}", flush=True)
+    ix.close()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

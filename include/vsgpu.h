@@ -91,6 +91,9 @@ typedef struct vs_stats {
     uint64_t node_heap_reads;                /* "reads_heap"   */
     uint64_t next_calls;                     /* "next"         */
     uint64_t retries;                        /* capacity-overflow relaunches (ours; 0 in steady state) */
+    uint64_t fallback_scans;                 /* scans the LDS-resident fast kernel handed to the general kernel (ours) */
+    uint64_t fallback_visited_nodes;         /* their share of visited_nodes */
+    uint64_t fallback_quantized_distance_comparisons; /* their share of quantized_distance_comparisons */
 } vs_stats;
 
 const char* vs_last_error(void);
@@ -105,7 +108,9 @@ int vs_ctx_device_name(vs_ctx* ctx, char* buf, size_t len);
 int vs_ctx_mem_info(vs_ctx* ctx, uint64_t* free_bytes, uint64_t* total_bytes);
 
 /* per-kernel timing with HIP events recorded on the ctx stream around every launch of the batched-scan pipeline
- * (what bench.py's roofline figure is computed from).  kind: 0 prepare_queries, 1 search, 2 rerank, 3 resort. */
+ * (what bench.py's roofline figure is computed from).  kind: 0 prepare_queries, 1 search (the LDS-resident fast
+ * kernel; the general kernel when the fast path is off), 2 rerank, 3 resort, 4 search fallback (general kernel re-running
+ * the scans the fast kernel handed over). */
 typedef struct vs_profile {
     double ms[8];        /* accumulated kernel time per kind */
     uint64_t launches[8];

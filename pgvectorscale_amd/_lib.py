@@ -32,7 +32,9 @@ class IndexHost(C.Structure):
 class Stats(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in ("queries", "visited_nodes", "candidate_nodes",
                                           "quantized_distance_comparisons", "full_distance_comparisons",
-                                          "node_reads", "node_heap_reads", "next_calls", "retries")]
+                                          "node_reads", "node_heap_reads", "next_calls", "retries",
+                                          "fallback_scans", "fallback_visited_nodes",
+                                          "fallback_quantized_distance_comparisons")]
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}

@@ -297,7 +297,7 @@ extern "C" void vs_index_free(vs_index* ix) {
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     SearchWorkspace& w = ix->ws;
-    DevBuf* bufs[] = {&w.q_full, &w.qcodes, &w.qlabels, &w.qlabel_off, &w.hash, &w.heap_g, &w.stream_ids,
+    DevBuf* bufs[] = {&w.q_full, &w.qcodes, &w.qlabels, &w.qlabel_off, &w.hash, &w.heap_g, &w.heap_g4, &w.ghash4, &w.fb_flag, &w.phase, &w.stream_ids,
                       &w.stream_ham, &w.stream_cnt, &w.stats, &w.status, &w.rr_dist, &w.out_ids, &w.out_tids,
                       &w.out_dist, &w.resort_heap, &w.raw_q, &w.misc};
     for (DevBuf* b : bufs) devbuf_free(*b);
@@ -587,7 +587,9 @@ extern "C" int vs_rerank(vs_index* ix, const float* q_full, const uint32_t* ids,
 // batched scans
 // ---------------------------------------------------------------------------------------------------------------
 struct Caps {
-    uint32_t hl, hcap, vcap, lh, hashcap, g0;
+    uint32_t hl, hcap, vcap, lh, hashcap, g0;  // general kernel (vs_search.hip)
+    // fast kernel (vs_search_fast.hip); f_lh == 0 disables it
+    uint32_t f_hl, f_hcap, f_gstride, f_lh, f_gcap, f_sb, f_vr, f_vcap;
 };
 
 static uint32_t env_u32(const char* name, uint32_t dflt) {
@@ -596,18 +598,45 @@ static uint32_t env_u32(const char* name, uint32_t dflt) {
 }
 
 static Caps initial_caps(const vs_index* ix, uint32_t L, uint32_t M) {
-    // visits ~ 1.3-2 L before the first row + one per further row; each visit pushes <= R candidates.
-    // LDS holds the hot part (top `hl` heap positions, an exact dedup table of `lh` slots, the visited list); colder
-    // state spills to per-scan global arrays that cost address space only.  Overflows are retried with doubled caps.
+    // visits ~ 1.1-2 L before the first row + one per further row; each visit pushes <= R candidates.
     uint64_t visits = 2ull * L + M + 32;
     uint64_t pushes = visits * ix->d.num_neighbors;
     Caps c;
+    // general kernel: LDS holds the top `hl` heap positions and the visited list, the rest spills to per-scan global
+    // arrays that cost address space only.  Overflows are retried with doubled caps.
     c.hl = env_u32("VS_HL", 1024);
     c.lh = env_u32("VS_LH", 0);
     c.g0 = env_u32("VS_G0", 4096);
     c.hcap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(pushes, c.hl), 1u << 22);
     c.vcap = (uint32_t)std::min<uint64_t>(3ull * L + M + 64, 1u << 20);
     c.hashcap = std::max<uint32_t>(next_pow2_u32(std::min<uint64_t>(2ull * pushes, 1u << 23)), c.g0);
+    // fast kernel: everything in LDS, sized for the typical scan (about 8-10 new candidates per visit, 1.1 L + M
+    // visits); the rare scan that outgrows it is re-run by the general kernel.
+    const uint64_t typ_visits = (uint64_t)L + L / 4 + M + 16;
+    const uint64_t typ_ins = typ_visits * std::min<uint64_t>(ix->d.num_neighbors, 12);
+    c.f_lh = env_u32("VS_F_LH", (uint32_t)std::min<uint64_t>(round_up_u32((uint32_t)std::min<uint64_t>(typ_ins, 1u << 20), 64), 1u << 15));
+    c.f_hl = env_u32("VS_F_HL", 1023);
+    const uint32_t want_v = (uint32_t)std::min<uint64_t>((uint64_t)L + L / 2 + 32, 1u << 20);
+    c.f_vr = env_u32("VS_F_VR", want_v <= 256 ? 4 : 0);
+    c.f_vcap = c.f_vr ? 256 : std::max<uint32_t>(next_pow2_u32(env_u32("VS_F_VCAP", want_v)), 64);
+    if (!env_u32("VS_FAST", 1)) c.f_lh = 0;
+    if (c.f_lh) {
+        c.f_lh = round_up_u32(std::max<uint32_t>(c.f_lh, 256), 4);
+        c.f_hl = std::max<uint32_t>(next_pow2_u32(c.f_hl + 1), 64) - 1;
+        // overflow table: room for every candidate the worst scan could insert beyond the LDS table
+        c.f_gcap = next_pow2_u32(std::min<uint64_t>(std::max<uint64_t>(pushes, 1024), 1u << 22));
+        c.f_sb = 0;
+        while ((1ull << c.f_sb) < (uint64_t)c.f_lh + c.f_gcap) c.f_sb++;
+        c.f_hcap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(pushes, c.f_hl), 1u << 22);
+        c.f_gstride = round_up_u32(c.f_hcap - c.f_hl + 2, 2);
+        const uint64_t nbits = (uint64_t)ix->d.dim_index * ix->d.bits;
+        FastLaunch probe{};
+        probe.hl = c.f_hl;
+        probe.lh = c.f_lh;
+        probe.vr = c.f_vr;
+        probe.vcap = c.f_vcap;
+        if (nbits >= (1ull << (32 - c.f_sb)) || fast_lds_bytes(ix, probe) > 64 * 1024) c.f_lh = 0;
+    }
     return c;
 }
 
@@ -653,6 +682,45 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
         VS_TRY(launch_prepare_queries(ix, d_raw_q, nq, (float*)w.q_full.p, (uint64_t*)w.qcodes.p));
         prof_end(c, PK_PREPARE, ev);
     }
+    bool fast_done = false;
+    if (caps.f_lh) {
+        VS_TRY(devbuf_reserve(c, w.heap_g4, std::max<size_t>((size_t)nq * caps.f_gstride * 4, 16)));
+        VS_TRY(devbuf_reserve(c, w.ghash4, (size_t)nq * caps.f_gcap * 4));
+        VS_TRY(devbuf_reserve(c, w.fb_flag, (size_t)nq * 4));
+        VS_HIP(hipMemsetAsync(w.fb_flag.p, 0, (size_t)nq * 4, c->stream));
+        FastLaunch f;
+        f.nq = nq;
+        f.L = bp.L;
+        f.M = M;
+        f.hl = caps.f_hl;
+        f.hcap = caps.f_hcap;
+        f.gstride = caps.f_gstride;
+        f.vr = caps.f_vr;
+        f.heap_g = (uint32_t*)w.heap_g4.p;
+        f.gcap = caps.f_gcap;
+        f.ghash = (uint32_t*)w.ghash4.p;
+        f.lh = caps.f_lh;
+        f.sb = caps.f_sb;
+        f.vcap = caps.f_vcap;
+        f.qcodes = (const uint64_t*)w.qcodes.p;
+        f.qlabels = d_qlabels;
+        f.qlabel_off = d_qlabel_off;
+        f.out_ids = (uint32_t*)w.stream_ids.p;
+        f.out_ham = (uint32_t*)w.stream_ham.p;
+        f.out_cnt = (uint32_t*)w.stream_cnt.p;
+        f.stats = (uint32_t*)w.stats.p;
+        f.status = (uint32_t*)w.status.p;
+        if (env_u32("VS_PHASE", 0)) {
+            VS_TRY(devbuf_reserve(c, w.phase, (size_t)nq * 64));
+            VS_HIP(hipMemsetAsync(w.phase.p, 0, (size_t)nq * 64, c->stream));
+            f.phase = (uint64_t*)w.phase.p;
+        }
+        hipEvent_t ev = prof_begin(c);
+        VS_TRY(launch_search_fast(ix, f));
+        prof_end(c, PK_SEARCH, ev);
+        fast_done = true;
+    }
+    w.fb_valid = fast_done;
     for (int attempt = 0;; ++attempt) {
         const size_t hg = caps.hcap > caps.hl ? caps.hcap - caps.hl : 0;
         VS_TRY(devbuf_reserve(c, w.hash, (size_t)nq * caps.hashcap * 4));
@@ -677,10 +745,13 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
         s.out_cnt = (uint32_t*)w.stream_cnt.p;
         s.stats = (uint32_t*)w.stats.p;
         s.status = (uint32_t*)w.status.p;
+        // after the fast kernel (or a failed attempt) only the scans whose status is non-zero are (re)run
+        s.only_failed = (fast_done || attempt > 0) ? 1u : 0u;
+        s.fb_flag = fast_done ? (uint32_t*)w.fb_flag.p : nullptr;
         {
             hipEvent_t ev = prof_begin(c);
             VS_TRY(launch_search(ix, s));
-            prof_end(c, PK_SEARCH, ev);
+            prof_end(c, fast_done ? PK_SEARCH_FB : PK_SEARCH, ev);
         }
         if (!check_now) break;
         std::vector<uint32_t> status(nq);
@@ -717,10 +788,25 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
 static int collect_stats(vs_index* ix, uint32_t nq, uint32_t M, uint32_t rescore, bool stream_only, vs_stats* st) {
     if (!st) return VS_OK;
     SearchWorkspace& w = ix->ws;
-    std::vector<uint32_t> hs((size_t)nq * ST_N), cnt(nq);
+    std::vector<uint32_t> hs((size_t)nq * ST_N), cnt(nq), fb(nq, 0);
     VS_HIP(hipMemcpyAsync(hs.data(), w.stats.p, hs.size() * 4, hipMemcpyDeviceToHost, ix->ctx->stream));
+    if (w.fb_valid) VS_HIP(hipMemcpyAsync(fb.data(), w.fb_flag.p, fb.size() * 4, hipMemcpyDeviceToHost, ix->ctx->stream));
     VS_HIP(hipMemcpyAsync(cnt.data(), w.stream_cnt.p, cnt.size() * 4, hipMemcpyDeviceToHost, ix->ctx->stream));
     VS_HIP(hipStreamSynchronize(ix->ctx->stream));
+    if (env_u32("VS_PHASE", 0) && w.phase.p && w.fb_valid) {
+        std::vector<uint64_t> ph((size_t)nq * 8);
+        VS_HIP(hipMemcpy(ph.data(), w.phase.p, ph.size() * 8, hipMemcpyDeviceToHost));
+        double sum[8] = {0};
+        uint64_t visits = 0;
+        for (uint32_t q = 0; q < nq; ++q) {
+            for (int k = 0; k < 8; ++k) sum[k] += (double)ph[(size_t)q * 8 + k];
+            visits += hs[(size_t)q * ST_N + ST_VISITS];
+        }
+        const char* names[8] = {"pop", "row_wait", "visited", "dedup", "gather", "push", "other", "-"};
+        fprintf(stderr, "[VS_PHASE] shader clocks per visit:");
+        for (int k = 0; k < 7; ++k) fprintf(stderr, " %s=%.0f", names[k], sum[k] / (double)std::max<uint64_t>(visits, 1));
+        fprintf(stderr, "\n");
+    }
     for (uint32_t q = 0; q < nq; ++q) {
         st->queries++;
         st->visited_nodes += hs[(size_t)q * ST_N + ST_VISITS];
@@ -728,6 +814,11 @@ static int collect_stats(vs_index* ix, uint32_t nq, uint32_t M, uint32_t rescore
         st->quantized_distance_comparisons += hs[(size_t)q * ST_N + ST_DQ];
         st->node_reads += hs[(size_t)q * ST_N + ST_READS];
         st->next_calls += hs[(size_t)q * ST_N + ST_NEXT];
+        if (fb[q]) {
+            st->fallback_scans++;
+            st->fallback_visited_nodes += hs[(size_t)q * ST_N + ST_VISITS];
+            st->fallback_quantized_distance_comparisons += hs[(size_t)q * ST_N + ST_DQ];
+        }
         if (!stream_only && rescore > 0) {
             uint32_t nr = std::min(cnt[q], M);
             st->full_distance_comparisons += nr;
@@ -743,6 +834,7 @@ static uint32_t stream_len(uint32_t rescore, uint32_t k) { return rescore > 0 ? 
 static uint32_t chunk_queries(const vs_index* ix, const Caps& c, uint32_t M, uint32_t nq) {
     size_t per_q = (size_t)c.hashcap * 4 + (size_t)(c.hcap > c.hl ? c.hcap - c.hl : 0) * 8 + (size_t)M * 12 + ix->vec_stride * 4ull +
                    ix->code_stride * 8ull + 256;
+    if (c.f_lh) per_q += (size_t)c.f_gcap * 4 + (size_t)c.f_gstride * 4 + 64;
     size_t budget = 24ull << 30;
     uint32_t m = (uint32_t)std::max<size_t>(1, std::min<size_t>(budget / per_q, 1u << 20));
     return std::min(m, nq);

@@ -60,7 +60,7 @@ struct vs_ctx {
     double prof_ms[8] = {0};
     uint64_t prof_launches[8] = {0};
 };
-enum { PK_PREPARE = 0, PK_SEARCH = 1, PK_RERANK = 2, PK_RESORT = 3 };
+enum { PK_PREPARE = 0, PK_SEARCH = 1, PK_RERANK = 2, PK_RESORT = 3, PK_SEARCH_FB = 4 };
 hipEvent_t prof_begin(vs_ctx* c);
 void prof_end(vs_ctx* c, int kind, hipEvent_t a);
 
@@ -71,9 +71,10 @@ struct DevBuf {
 };
 
 struct SearchWorkspace {
-    DevBuf q_full, qcodes, qlabels, qlabel_off, hash, heap_g, stream_ids, stream_ham, stream_cnt, stats, status,
+    DevBuf q_full, qcodes, qlabels, qlabel_off, hash, heap_g, heap_g4, ghash4, fb_flag, phase, stream_ids, stream_ham, stream_cnt, stats, status,
         rr_dist, out_ids, out_tids, out_dist, resort_heap, raw_q, misc;
     // pending async call (vs_search_batch_dev)
+    bool fb_valid = false;  // fb_flag holds the fallback marks of the last chunk
     bool pending = false;
     uint32_t pend_nq = 0;
     uint32_t pend_m = 0;
@@ -124,7 +125,34 @@ struct SearchLaunch {
     uint32_t* out_cnt;             // [nq]
     uint32_t* stats;               // [nq][8]
     uint32_t* status;              // [nq]
+    uint32_t only_failed = 0;      // 1: run only the scans whose status[q] != 0 (left over by the fast kernel)
+    uint32_t* fb_flag = nullptr;   // [nq] set to 1 for every scan this launch ran in only_failed mode
 };
+// fast path (vs_search_fast.hip): all hot state in LDS
+struct FastLaunch {
+    uint32_t nq, L, M;
+    uint32_t hl;       // heap positions resident in LDS, 2^k - 1
+    uint32_t hcap;     // total heap capacity; positions [hl, hcap) live in heap_g
+    uint32_t gstride;  // u32 per scan in heap_g (even, >= hcap - hl + 2)
+    uint32_t lh;       // slots of the LDS dedup table (multiple of 4)
+    uint32_t gcap;     // slots of the per-scan global overflow dedup table (power of two), handles lh .. lh + gcap - 1
+    uint32_t sb;       // bits of a slot handle inside a heap entry (lh + gcap <= 1 << sb)
+    uint32_t vr;       // visited list: 4 = four register pairs (256 entries), 0 = LDS ring of vcap entries
+    uint32_t vcap;     // visited ring capacity (power of two; vr == 0)
+    const uint64_t* qcodes;
+    const int16_t* qlabels;
+    const uint32_t* qlabel_off;
+    uint32_t* heap_g;
+    uint32_t* ghash;   // [nq][gcap] (cleared by the kernel on first use)
+    uint32_t* out_ids;
+    uint32_t* out_ham;
+    uint32_t* out_cnt;
+    uint32_t* stats;
+    uint32_t* status;
+    uint64_t* phase = nullptr;  // optional [nq][8] per-phase shader-clock sums (VS_PHASE=1, diagnostics only)
+};
+size_t fast_lds_bytes(const vs_index* idx, const FastLaunch& s);
+int launch_search_fast(vs_index* idx, const FastLaunch& s);
 enum { ST_VISITS = 0, ST_CAND = 1, ST_DQ = 2, ST_READS = 3, ST_NEXT = 4, ST_GSPILL = 5, ST_PFHIT = 6, ST_N = 8 };
 enum { OVF_HEAP = 1, OVF_VISITED = 2, OVF_HASH = 4 };
 size_t search_lds_bytes(const vs_index* idx, const SearchLaunch& s);

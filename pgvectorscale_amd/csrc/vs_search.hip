@@ -125,6 +125,10 @@ __global__ __launch_bounds__(WAVE) void k_search(SearchArgs a) {
     const uint32_t q = blockIdx.x;
     const SearchLaunch& s = a.s;
     if (q >= s.nq) return;
+    if (s.only_failed) {  // follow-up of the fast kernel: only the scans it handed over
+        if (s.status[q] == 0) return;
+        if (threadIdx.x == 0 && s.fb_flag) s.fb_flag[q] = 1;
+    }
 
     // ---- LDS carve (every offset a multiple of 16 B) ----
     uint64_t* heap_l = reinterpret_cast<uint64_t*>(smem);                        // hl + 2 entries

@@ -1,0 +1,785 @@
+// vs_search_fast.hip — K3 fast path: the streaming beam search with all hot per-scan state on chip, one wave64 per scan.
+//
+// Same semantics and citations as vs_search.hip (the general kernel).  What limits this kernel is not bandwidth but
+// the serial chain of one scan (pop -> neighbor row -> dedup -> code gather -> pushes -> pop ...) times the number of
+// scans a CU can hold at once, which is set by LDS bytes per scan.  So the data structures are restated to keep the
+// dependent chain short and the LDS footprint small:
+//
+//   * candidate heap  BinaryHeap<Reverse<ListSearchNeighbor>> (AM/graph/mod.rs:75): 4-byte entries
+//     (hamming << sb | dedup slot) in LDS; the node id is looked up in the dedup table when the entry is popped.
+//       - pop  = sift_down_to_bottom: "which child moves up" is local to a node, so the wave evaluates it for a whole
+//         6-level subtree at once (one ds_read_b64 of both children per lane); a lane is on the root-to-leaf path iff
+//         the choices of its ancestors lead to it — one AND + compare against per-lane constants — and all moves are
+//         one masked LDS store.  Two such rounds cover 4095 entries.
+//       - push = sift_up: lane r compares the new element with its r-th ancestor (one LDS read for the whole chain),
+//         the climb is one ballot + ctz and the shift down the path one LDS store.  (Batching several pushes per
+//         round was tried: ~70 % of the candidates climb and siblings then conflict, so it did not pay.)
+//     Both replay Rust std's exact array mechanics (tie order of equal Hamming distances depends on them).
+//   * dedup set ("inserted", HashSet<ItemPointer>): exact open-addressing table in LDS (ds_cmpst), never rehashed, so
+//     a slot index is a stable handle for the node id.  When it reaches 87.5 % load it is frozen (read-only) and new
+//     ids go to a per-scan global table (handles >= lh) that the wave clears lazily — the long tail of scans pays L2
+//     latency for its last inserts instead of forcing every scan to reserve LDS for the worst case.
+//   * visited list (sorted Vec<ListSearchNeighbor>): sorted array in REGISTERS (entry i = lane i % 64 of register
+//     i / 64); insert / remove(0) are DPP wave shifts, no LDS traffic.  (LDS ring buffer when it does not fit.)
+//   * the query code lives in registers (4 lanes x 16 B per code row, NCH steps).
+//   * neighbor rows are requested ahead of the pop that needs them (see the main loop).
+//
+// A scan whose state outgrows the LDS budget sets a status flag and is re-run by the general kernel
+// (vs_search.hip, unbounded global spill) in a follow-up launch that skips every scan that completed here.
+#include "vs_device.h"
+
+#define MAX_QLABELS 64
+
+struct FastArgs {
+    const uint64_t* codes;
+    const uint32_t* nbrs;
+    const uint64_t* tids;
+    const uint32_t* label_off;
+    const int16_t* label_val;
+    const int16_t* ls_labels;
+    const uint32_t* ls_nodes;
+    uint32_t code_stride, nbr_stride, R, n, n_ls, default_start;
+    FastLaunch s;
+};
+
+__device__ __forceinline__ void wave_sync() {
+    // single-wave workgroup: LDS operations of one wave execute in order, so cross-lane LDS communication only needs
+    // the COMPILER not to cache / reorder across this point (no instructions are emitted)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ uint32_t gload32(const uint32_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void gstore32(uint32_t* p, uint32_t v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint64_t gload64u(const uint64_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint32_t readlane_u32(uint32_t v, uint32_t l) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l);
+}
+// lane i <- lane i-1, lane 0 <- carry   /   lane i <- lane i+1, lane 63 <- carry   (DPP wave shifts, gfx9 family)
+__device__ __forceinline__ uint32_t wave_shr1(uint32_t v, uint32_t carry) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)carry, (int)v, 0x138, 0xF, 0xF, false);
+}
+__device__ __forceinline__ uint32_t wave_shl1(uint32_t v, uint32_t carry) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)carry, (int)v, 0x130, 0xF, 0xF, false);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Heap position i lives at l[i + 1] while i < hl (hl = 2^k - 1, so a sibling pair (2a+1, 2a+2) is one aligned 8-byte
+// word both in LDS and in the spill array g[i - hl]); l[0] is a sentinel with key 0 ("ancestor of the root").
+// ---------------------------------------------------------------------------------------------------------------
+struct FastHeap {
+    uint32_t* l;
+    uint32_t* g;
+    uint32_t hl, sb, len;
+    int lane;
+    uint32_t lvl, offm1;   // this lane's level / (offset - 1) inside a 6-level subtree (lane 63: never a node)
+    uint32_t amask, dpat;  // lane j is on the sift-down path iff (pick_bits & amask) == dpat (ancestor choices)
+
+    __device__ __forceinline__ void init(int lane_) {
+        lane = lane_;
+        len = 0;
+        const uint32_t j1 = (uint32_t)lane + 1u;
+        lvl = 31u - (uint32_t)__builtin_clz(j1);
+        offm1 = lane < 63 ? j1 - (1u << lvl) - 1u : 0x40000000u;
+        amask = 0;
+        dpat = 0;
+        for (uint32_t k = 1; k <= lvl; ++k) {
+            const uint32_t anc = (j1 >> k) - 1u, dir = (j1 >> (k - 1)) & 1u;
+            amask |= 1u << anc;
+            dpat |= dir << anc;
+        }
+        if (lane >= 63) { amask = 0; dpat = 1; }  // never matches
+    }
+    __device__ __forceinline__ uint32_t root() const { return rfl(l[1]); }
+
+    __device__ __forceinline__ uint32_t get(uint32_t i) const { return i < hl ? l[i + 1] : gload32(g + (i - hl)); }
+    __device__ __forceinline__ void set(uint32_t i, uint32_t v) const {
+        if (i < hl) l[i + 1] = v;
+        else gstore32(g + (i - hl), v);
+    }
+    // ---- sift_up(0, pos) of `elem` (not yet stored): while elem < parent (Reverse => smaller distance) move parent down
+    __device__ __forceinline__ void sift_up_lds(uint32_t pos, uint32_t elem) const {
+        const uint32_t p1 = pos + 1;
+        // lane r looks at the r-th ancestor, stored at l[p1 >> r] (l[0] = sentinel once the root is passed); lanes >= 32
+        // alias lanes r - 32 (shift amounts are mod 32) and are ignored
+        const uint32_t e = l[p1 >> (lane & 31)];
+        const bool cmp = (elem >> sb) < (e >> sb);
+        const uint32_t bal = (uint32_t)__ballot(cmp) >> 1;  // bit r-1 <-> ancestor r; bit 31 is always clear
+        const uint32_t t = (uint32_t)__builtin_ctz(~bal);   // leading run of ancestors that move down
+        if ((uint32_t)lane <= t) {
+            const uint32_t dst = lane == 0 ? (p1 >> t) : (p1 >> (lane - 1));
+            l[dst] = lane == 0 ? elem : e;
+        }
+        wave_sync();
+    }
+    __device__ __forceinline__ void sift_up_gen(uint32_t pos, uint32_t elem) const {
+        const uint32_t p1 = pos + 1;
+        const uint32_t r = (uint32_t)lane;
+        const uint32_t ar1 = r < 32 ? (p1 >> r) : 0u;  // (r-th ancestor) + 1
+        const bool valid = r >= 1 && ar1 >= 1;
+        uint32_t e = 0;
+        if (valid) e = get(ar1 - 1);
+        const bool cmp = valid && (elem >> sb) < (e >> sb);
+        const uint64_t bal = __ballot(cmp) >> 1;
+        const uint32_t t = (uint32_t)__builtin_ctzll(~bal);
+        if (r >= 1 && r <= t) set((p1 >> (r - 1)) - 1, e);
+        if (lane == 0) set((p1 >> t) - 1, elem);
+        wave_sync();
+    }
+    __device__ __forceinline__ void push(uint32_t elem) {
+        if (len < hl) sift_up_lds(len, elem);
+        else sift_up_gen(len, elem);
+        len += 1;
+    }
+
+    // ---- BinaryHeap::pop: Vec::pop, swap with data[0], sift_down_to_bottom(0), sift_up.  (len > 0; the caller has
+    // already read data[0])
+    __device__ __forceinline__ void pop() {
+        const uint32_t last = len - 1;
+        const bool all_lds = last < hl;
+        const uint32_t item = rfl(all_lds ? l[last + 1] : get(last));
+        len = last;
+        if (len == 0) return;
+        const uint32_t end = len;
+        const uint32_t ikey = item >> sb;
+        uint32_t root = 0, pos = 0;
+        uint32_t pkey = 0;  // key of the value now stored in the parent of `root` (0 for the heap root: never moves)
+        for (;;) {
+            // one 6-level subtree per iteration: lane j < 63 is the node with relative heap index j
+            const uint32_t aidx = ((root + 1) << lvl) + offm1;
+            const uint32_t c = 2 * aidx + 1;
+            const bool exists = aidx < end, have1 = c < end, have2 = c + 1 < end;
+            uint32_t le = 0, ri = 0;
+            if (have1) {
+                if (all_lds || c < hl) {
+                    const uint2 p = *reinterpret_cast<const uint2*>(l + c + 1);
+                    le = p.x;
+                    ri = p.y;
+                } else {
+                    const uint64_t p = gload64u(reinterpret_cast<const uint64_t*>(g + (c - hl)));
+                    le = (uint32_t)p;
+                    ri = (uint32_t)(p >> 32);
+                }
+            }
+            // child += (data[child] <= data[child+1]); Reverse => right.d <= left.d picks the right child
+            const bool pick = have2 && (ri >> sb) <= (le >> sb);
+            const uint32_t cv = pick ? ri : le;
+            const uint64_t B = __ballot(pick);
+            // a node is on the path iff every ancestor inside this subtree chose the child leading to it
+            const bool onpath = exists && (((uint32_t)B & amask) == dpat);
+            const uint64_t pm = __ballot(onpath);
+            if (onpath && have1) {
+                if (all_lds) l[aidx + 1] = cv;
+                else set(aidx, cv);
+            }
+            wave_sync();
+            const uint32_t jd = 63u - (uint32_t)__builtin_clzll(pm);  // deepest path node (pm != 0: the root exists)
+            const uint32_t ad = readlane_u32(aidx, jd);
+            const uint64_t h1 = __ballot(have1);
+            if (!((h1 >> jd) & 1ull)) {  // a leaf: the hole ends here
+                pos = ad;
+                if (jd > 0) pkey = readlane_u32(cv, (jd - 1) >> 1) >> sb;  // what its parent just received
+                break;
+            }
+            pkey = readlane_u32(cv, jd) >> sb;
+            root = 2 * ad + 1 + (uint32_t)((B >> jd) & 1ull);  // jd is on the subtree's last level: descend
+        }
+        // sift_up(0, pos) of the former last element: it only moves when it is smaller than the new parent value
+        if (ikey < pkey) {
+            if (all_lds) sift_up_lds(pos, item);
+            else sift_up_gen(pos, item);
+        } else {
+            if (lane == 0) {
+                if (all_lds) l[pos + 1] = item;
+                else set(pos, item);
+            }
+            wave_sync();
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// visited: Vec<ListSearchNeighbor> kept sorted (AM/graph/mod.rs:76,167-168,181).  VR > 0: in registers, entry i is
+// lane i % 64 of (h[i / 64], n[i / 64]).  VR == 0: ring buffer of (hamming << 32 | node) in LDS.
+// ---------------------------------------------------------------------------------------------------------------
+template <int VR>
+struct Visited {
+    static constexpr int NR = VR > 0 ? VR : 1;
+    uint32_t h[NR], n[NR];
+    uint64_t* ring;
+    uint32_t vmask, head, len;
+    int lane;
+
+    __device__ __forceinline__ void init(int lane_, uint64_t* ring_, uint32_t vcap) {
+        lane = lane_;
+        ring = ring_;
+        vmask = vcap - 1;
+        head = 0;
+        len = 0;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) { h[r] = 0; n[r] = 0; }
+    }
+    __device__ __forceinline__ uint32_t capacity() const { return VR > 0 ? 64u * VR : vmask + 1; }
+    // hamming of entry i (i < len, uniform)
+    __device__ __forceinline__ uint32_t ham_at(uint32_t i) const {
+        if (VR > 0) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int r = 0; r < NR; ++r)
+                if ((i >> 6) == (uint32_t)r) v = readlane_u32(h[r], i & 63u);
+            return v;
+        }
+        return rfl((uint32_t)(ring[(head + i) & vmask] >> 32));
+    }
+    // visited.insert(partition_point(|x| *x < new), new): before the first element >= new  (caller checked capacity)
+    __device__ __forceinline__ void insert(uint32_t hd, uint32_t node) {
+        if (VR > 0) {
+            uint32_t idx = 0;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                if ((uint32_t)r * 64u < len) {
+                    const uint32_t gi = (uint32_t)r * 64u + (uint32_t)lane;
+                    idx += (uint32_t)__popcll(__ballot(gi < len && h[r] < hd));
+                }
+            }
+#pragma unroll
+            for (int r = NR - 1; r >= 0; --r) {
+                if ((uint32_t)r * 64u <= len && (uint32_t)r * 64u + 63u >= idx) {  // register holds a moved / new entry
+                    const uint32_t ch = r > 0 ? readlane_u32(h[r > 0 ? r - 1 : 0], 63) : 0u;
+                    const uint32_t cn = r > 0 ? readlane_u32(n[r > 0 ? r - 1 : 0], 63) : 0u;
+                    const uint32_t sh = wave_shr1(h[r], ch), sn = wave_shr1(n[r], cn);
+                    const uint32_t gi = (uint32_t)r * 64u + (uint32_t)lane;
+                    h[r] = gi > idx ? sh : (gi == idx ? hd : h[r]);
+                    n[r] = gi > idx ? sn : (gi == idx ? node : n[r]);
+                }
+            }
+            len++;
+            return;
+        }
+        uint32_t idx = 0;
+        for (uint32_t base = 0; base < len; base += WAVE) {
+            const uint32_t i = base + lane;
+            const bool lt = i < len && (uint32_t)(ring[(head + i) & vmask] >> 32) < hd;
+            idx += (uint32_t)__popcll(__ballot(lt));
+        }
+        if (2 * idx < len) {  // move [0, idx) one slot towards the front, lowest chunk first
+            for (uint32_t base = 0; base < idx; base += WAVE) {
+                const uint32_t i = base + lane;
+                uint64_t e = 0;
+                if (i < idx) e = ring[(head + i) & vmask];
+                wave_sync();
+                if (i < idx) ring[(head + i - 1) & vmask] = e;
+                wave_sync();
+            }
+            head = (head - 1) & vmask;
+        } else {  // move [idx, len) one slot towards the back, highest chunk first
+            uint32_t hi = len;
+            while (hi > idx) {
+                const uint32_t lo = (hi - idx > WAVE) ? hi - WAVE : idx;
+                const uint32_t i = lo + lane;
+                uint64_t e = 0;
+                if (i < hi) e = ring[(head + i) & vmask];
+                wave_sync();
+                if (i < hi) ring[(head + i + 1) & vmask] = e;
+                wave_sync();
+                hi = lo;
+            }
+        }
+        if (lane == 0) ring[(head + idx) & vmask] = ((uint64_t)hd << 32) | node;
+        len++;
+        wave_sync();
+    }
+    // visited.remove(0) (len > 0)
+    __device__ __forceinline__ void pop_front(uint32_t& hd, uint32_t& node) {
+        if (VR > 0) {
+            hd = readlane_u32(h[0], 0);
+            node = readlane_u32(n[0], 0);
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                if ((uint32_t)r * 64u < len) {
+                    const uint32_t ch = r + 1 < NR ? readlane_u32(h[r + 1 < NR ? r + 1 : 0], 0) : 0u;
+                    const uint32_t cn = r + 1 < NR ? readlane_u32(n[r + 1 < NR ? r + 1 : 0], 0) : 0u;
+                    h[r] = wave_shl1(h[r], ch);
+                    n[r] = wave_shl1(n[r], cn);
+                }
+            }
+            len--;
+            return;
+        }
+        const uint64_t front = ring[head];
+        hd = rfl((uint32_t)(front >> 32));
+        node = rfl((uint32_t)front);
+        head = (head + 1) & vmask;
+        len--;
+    }
+};
+
+template <int NCH>
+__device__ __forceinline__ uint32_t ham_row_reg(const uint64_t* __restrict__ row, const ulonglong2 (&qv)[NCH > 0 ? NCH : 1],
+                                                const uint64_t* qc_l, int l4, uint32_t code_stride, bool active) {
+    uint32_t acc = 0;
+    if (NCH > 0) {
+        if (active) {
+            ulonglong2 r[NCH > 0 ? NCH : 1];
+#pragma unroll
+            for (int t = 0; t < NCH; ++t) {
+                const uint32_t w = 2u * (uint32_t)l4 + 8u * (uint32_t)t;
+                r[t] = w < code_stride ? *reinterpret_cast<const ulonglong2*>(row + w) : make_ulonglong2(0, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < NCH; ++t)
+                acc += (uint32_t)__popcll(r[t].x ^ qv[t].x) + (uint32_t)__popcll(r[t].y ^ qv[t].y);
+        }
+        return quad_sum(acc);
+    }
+    return ham_row4(row, qc_l, l4, code_stride, active);
+}
+
+// minimum over the wave (DPP row reduction + 4 readlanes; no LDS)
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x111 /*row_shr:1*/, 0xF, 0xF, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x112 /*row_shr:2*/, 0xF, 0xF, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x114 /*row_shr:4*/, 0xF, 0xF, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x118 /*row_shr:8*/, 0xF, 0xF, false));
+    return min(min(readlane_u32(v, 15), readlane_u32(v, 31)), min(readlane_u32(v, 47), readlane_u32(v, 63)));
+}
+
+template <int NCH, int VR, bool TIMING>
+__global__ __launch_bounds__(WAVE) void k_search_fast(FastArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x;
+    const uint32_t q = blockIdx.x;
+    const FastLaunch& s = a.s;
+    if (q >= s.nq) return;
+
+    // ---- LDS carve ----
+    uint32_t* hp = reinterpret_cast<uint32_t*>(smem);                 // hl + 1 (hl + 1 is a power of two >= 64)
+    uint32_t* lhash = hp + (s.hl + 1);                                // lh (multiple of 4)
+    uint32_t* surv_id = lhash + s.lh;                                 // 64
+    uint32_t* surv_slot = surv_id + 64;                               // 64
+    uint32_t* surv_d = surv_slot + 64;                                // 64
+    uint64_t* ring = reinterpret_cast<uint64_t*>(surv_d + 64);        // vcap entries (VR == 0 only)
+    int16_t* ql = reinterpret_cast<int16_t*>(ring + (VR > 0 ? 0 : s.vcap));  // MAX_QLABELS
+    uint64_t* qc_l = reinterpret_cast<uint64_t*>(ql + MAX_QLABELS);   // code_stride words (NCH == 0 only)
+
+    const int l4 = lane & 3;
+    ulonglong2 qv[NCH > 0 ? NCH : 1];
+    if (NCH > 0) {
+#pragma unroll
+        for (int t = 0; t < NCH; ++t) {
+            const uint32_t w = 2u * (uint32_t)l4 + 8u * (uint32_t)t;
+            qv[t] = w < a.code_stride
+                        ? *reinterpret_cast<const ulonglong2*>(s.qcodes + (size_t)q * a.code_stride + w)
+                        : make_ulonglong2(0, 0);
+        }
+    } else {
+        for (uint32_t w = lane; w < a.code_stride; w += WAVE) qc_l[w] = s.qcodes[(size_t)q * a.code_stride + w];
+    }
+    for (uint32_t i = 4u * lane; i < s.lh; i += 4u * WAVE)
+        *reinterpret_cast<uint4*>(lhash + i) = make_uint4(VS_EMPTY, VS_EMPTY, VS_EMPTY, VS_EMPTY);
+    if (lane == 0) hp[0] = 0;  // heap sentinel
+    const bool labels_some = s.qlabel_off != nullptr;  // LabeledVector.labels is Some (AM/labels/mod.rs:222-236)
+    uint32_t nql = 0;
+    if (labels_some) {
+        const uint32_t lb = s.qlabel_off[q], le = s.qlabel_off[q + 1];
+        nql = min(le - lb, (uint32_t)MAX_QLABELS);
+        for (uint32_t i = lane; i < nql; i += WAVE) ql[i] = s.qlabels[lb + i];
+    }
+    const bool has_label_filter = labels_some && nql > 0;  // AM/scan.rs:189
+    wave_sync();
+
+    FastHeap heap;
+    heap.l = hp;
+    heap.g = s.heap_g + (size_t)q * s.gstride;
+    heap.hl = s.hl;
+    heap.sb = s.sb;
+    heap.init(lane);
+    Visited<VR> vis;
+    vis.init(lane, ring, VR > 0 ? 64u * VR : s.vcap);
+
+    const uint32_t slot_limit = s.lh - s.lh / 8;  // stop at 87.5 % load: the scan is handed to the general kernel
+    const uint32_t smask = (1u << s.sb) - 1u;
+    uint32_t emitted = 0, status = 0, nins = 0, hmax = 0;
+    uint32_t st_visits = 0, st_cand = 0, st_dq = 0, st_reads = 0, st_pfhit = 0;
+    // optional phase clock (s_memtime): 0 pop, 1 row wait, 2 visited, 3 dedup, 4 gather, 5 push, 6 other
+    uint64_t ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t tmark = TIMING ? __builtin_readcyclecounter() : 0;
+    auto lap = [&](int k) {
+        if (TIMING) {
+            const uint64_t now = __builtin_readcyclecounter();
+            ph[k] += now - tmark;
+            tmark = now;
+        }
+    };
+
+    // ---- HashSet::insert.  Normal mode: the first CAS is ISSUED by the caller so independent work can overlap its
+    // latency, finish_insert completes the probe sequence.  Frozen mode (LDS table at its load limit): read-only
+    // probe of the LDS table, then insert into the per-scan global overflow table.
+    uint32_t* ghash = s.ghash + (size_t)q * s.gcap;
+    const uint32_t gmask = s.gcap - 1;
+    uint32_t nins_g = 0;
+    bool g_open = false;
+    auto hash_home = [&](uint32_t nid) -> uint32_t { return (uint32_t)(((uint64_t)hash_u32(nid) * s.lh) >> 32); };
+    auto node_of = [&](uint32_t handle) -> uint32_t {  // uniform handle -> node id
+        if (handle < s.lh) return rfl(lhash[handle]);
+        return rfl(gload32(ghash + (handle - s.lh)));
+    };
+    // true where the id was not present before; slot_out = its handle
+    auto finish_insert = [&](uint32_t nid, bool act, uint32_t slot, uint32_t old, uint32_t& slot_out) -> bool {
+        bool fresh = false;
+        if (act) {
+            for (;;) {
+                if (old == VS_EMPTY) { fresh = true; break; }
+                if (old == nid) break;
+                slot = slot + 1 == s.lh ? 0 : slot + 1;
+                old = atomicCAS(&lhash[slot], VS_EMPTY, nid);  // ds_cmpst_rtn_b32
+            }
+            slot_out = slot;
+        }
+        nins += (uint32_t)__popcll(__ballot(fresh));
+        return fresh;
+    };
+    auto frozen_insert = [&](uint32_t nid, bool act, uint32_t& slot_out) -> bool {
+        bool need_g = act, fresh = false;
+        if (act) {
+            uint32_t slot = hash_home(nid);
+            for (;;) {
+                const uint32_t v = lhash[slot];
+                if (v == nid) { need_g = false; break; }
+                if (v == VS_EMPTY) break;
+                slot = slot + 1 == s.lh ? 0 : slot + 1;
+            }
+        }
+        if (__ballot(need_g)) {
+            if (!g_open) {  // first use: this wave clears its own table
+                g_open = true;
+                for (uint32_t i = 4u * lane; i < s.gcap; i += 4u * WAVE)
+                    *reinterpret_cast<uint4*>(ghash + i) = make_uint4(VS_EMPTY, VS_EMPTY, VS_EMPTY, VS_EMPTY);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            }
+            if ((nins_g + WAVE) * 4u > s.gcap * 3u) {
+                status |= OVF_HASH;
+                return false;
+            }
+            if (need_g) {
+                uint32_t gs = hash_u32(nid ^ 0x5bd1e995u) & gmask;
+                for (;;) {
+                    const uint32_t o = atomicCAS(&ghash[gs], VS_EMPTY, nid);  // L2 atomic
+                    if (o == VS_EMPTY) { fresh = true; break; }
+                    if (o == nid) break;
+                    gs = (gs + 1) & gmask;
+                }
+                slot_out = s.lh + gs;
+            }
+            nins_g += (uint32_t)__popcll(__ballot(fresh));
+        }
+        return fresh;
+    };
+
+    // ---- ListSearchResult::new: start nodes (AM/graph/mod.rs:97-124, AM/graph/start_nodes.rs:39-48) ----
+    {
+        uint32_t nstarts = labels_some ? nql : 1u;
+        if (a.default_start == VS_INVALID_NODE || a.n == 0) nstarts = 0;  // ListSearchResult::empty()
+        for (uint32_t si = 0; si < nstarts; ++si) {
+            uint32_t sn = VS_INVALID_NODE;
+            if (!labels_some) {
+                sn = a.default_start;
+            } else {
+                const int16_t lab = ql[si];
+                int lo = 0, hi = (int)a.n_ls;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (a.ls_labels[mid] < lab) lo = mid + 1;
+                    else hi = mid;
+                }
+                if (lo < (int)a.n_ls && a.ls_labels[lo] == lab) sn = a.ls_nodes[lo];
+            }
+            sn = rfl(sn);
+            if (sn == VS_INVALID_NODE) continue;
+            // create_lsn_for_start_node (AM/sbq/storage.rs:365-391)
+            uint32_t slot = hash_home(sn), old = VS_EMPTY;
+            bool fr;
+            if (nins + WAVE > slot_limit) {
+                fr = frozen_insert(sn, lane == 0, slot);
+                if (status) break;
+            } else {
+                if (lane == 0) old = atomicCAS(&lhash[slot], VS_EMPTY, sn);
+                fr = finish_insert(sn, lane == 0, slot, old, slot);
+            }
+            if (!rfl(fr ? 1u : 0u)) continue;
+            slot = rfl(slot);
+            st_reads++;
+            const uint32_t d =
+                rfl(ham_row_reg<NCH>(a.codes + (size_t)sn * a.code_stride, qv, qc_l, l4, a.code_stride, lane < 4));
+            st_dq++;
+            st_cand++;
+            if (heap.len + 1 > s.hcap) { status |= OVF_HEAP; break; }
+            heap.push((d << s.sb) | slot);
+        }
+    }
+
+    // Neighbor rows are requested ahead of the pop that needs them: slot A = the heap root left by the last pop (asked
+    // for together with the code gather, so both latencies overlap), slot B = the best new candidate when it beats that
+    // root (asked for as soon as its distance is known; the pushes / pop / visited insert cover the latency).
+    uint32_t pfa_node = VS_INVALID_NODE, pfa_val = VS_INVALID_NODE;
+    uint32_t pfb_node = VS_INVALID_NODE, pfb_val = VS_INVALID_NODE;
+
+    // ---- TSVResponseIterator::next until M rows are emitted (AM/scan.rs:210-242), flattened: every iteration is
+    // either one visit_closest() expansion (greedy_search_iterate, AM/graph/mod.rs:357-385) or one consume() ----
+    while (status == 0) {
+        uint32_t top = 0;
+        bool can_visit = heap.len > 0;
+        if (can_visit) {
+            top = heap.root();
+            if (vis.len > s.L)  // visit_closest(L) stop rule (AM/graph/mod.rs:153-170)
+                can_visit = (top >> s.sb) < vis.ham_at(s.L - 1);
+        }
+        if (!can_visit) {
+            // ---- consume (AM/graph/mod.rs:174-184) + return_lsn (AM/sbq/storage.rs:404-414) ----
+            if (vis.len == 0) break;  // None: the stream has ended
+            uint32_t fd, fnode;
+            vis.pop_front(fd, fnode);
+            st_reads++;
+            const uint64_t tid = a.tids[fnode];
+            if ((tid & 0xFFFFull) == 0) continue;  // InvalidOffsetNumber: deleted tuple (AM/scan.rs:231-234)
+            if (lane == 0) {
+                s.out_ids[(size_t)q * s.M + emitted] = fnode;
+                s.out_ham[(size_t)q * s.M + emitted] = fd;
+            }
+            emitted++;
+            lap(6);
+            if (emitted == s.M) break;
+            continue;
+        }
+        hmax = max(hmax, heap.len);
+        lap(6);
+        const uint32_t hd = top >> s.sb;
+        const uint32_t node = node_of(top & smask);
+        heap.pop();
+        const uint32_t* nrow = a.nbrs + (size_t)node * a.nbr_stride;
+        uint32_t row0;
+        if (node == pfa_node) {
+            row0 = pfa_val;
+            st_pfhit++;
+        } else if (node == pfb_node) {
+            row0 = pfb_val;
+            st_pfhit++;
+        } else {
+            row0 = ((uint32_t)lane < a.R) ? nrow[lane] : VS_INVALID_NODE;
+        }
+        lap(0);
+        if (vis.len + 1 > vis.capacity()) { status |= OVF_VISITED; break; }
+        st_visits++;
+        // ---- visit_lsn_internal, Disk arm (AM/sbq/storage.rs:135-190) ----
+        st_reads++;  // SbqNode::read(visiting)
+        const uint32_t root_after = heap.len > 0 ? heap.root() : 0xFFFFFFFFu;
+        uint32_t best = 0xFFFFFFFFu;  // smallest (hamming << sb | slot) among this visit's new candidates
+        bool pfa_issued = false, pfb_issued = false, vis_done = false;
+        bool list_ended = false;
+        for (uint32_t c0 = 0; c0 < a.R && !list_ended; c0 += WAVE) {
+            const uint32_t slotidx = c0 + lane;
+            const uint32_t nid = c0 == 0 ? row0 : ((slotidx < a.R) ? nrow[slotidx] : VS_INVALID_NODE);
+            // list ends at the first InvalidBlockNumber (AM/sbq/node.rs:260-285)
+            const uint64_t inval = __ballot(nid == VS_INVALID_NODE);
+            const uint32_t nvalid = inval ? (uint32_t)__builtin_ctzll(inval) : WAVE;
+            if (nvalid < WAVE) list_ended = true;
+            const bool act = (uint32_t)lane < nvalid;
+            lap(1);
+            // prepare_insert (marks BEFORE the label check, AM/sbq/storage.rs:148-172): first probe issued, ...
+            const bool frozen = nins + WAVE > slot_limit;
+            uint32_t hslot = hash_home(nid), old = VS_EMPTY;
+            if (!frozen && act) old = atomicCAS(&lhash[hslot], VS_EMPTY, nid);
+            // ... visited.insert(partition_point(|x| *x < head), head) runs in registers meanwhile ...
+            if (!vis_done) {
+                vis_done = true;
+                vis.insert(hd, node);
+                lap(2);
+            }
+            // ... then the probe sequence is finished
+            bool fresh;
+            if (frozen) {
+                fresh = frozen_insert(nid, act, hslot);
+                if (status) break;
+            } else {
+                fresh = finish_insert(nid, act, hslot, old, hslot);
+            }
+            st_reads += (uint32_t)__popcll(__ballot(fresh));  // SbqNode::read(neighbor)
+            // label filter: query.labels.overlaps(node.labels) (AM/labels/mod.rs:124-142)
+            bool pass = fresh;
+            if (has_label_filter && fresh) {
+                const uint32_t lb = a.label_off[nid], le = a.label_off[nid + 1];
+                uint32_t i = 0, j = lb;
+                bool ov = false;
+                while (i < nql && j < le) {
+                    const int16_t x = ql[i], y = a.label_val[j];
+                    if (x == y) { ov = true; break; }
+                    if (x < y) ++i;
+                    else ++j;
+                }
+                pass = ov;
+            }
+            const uint64_t pm = __ballot(pass);
+            const uint32_t c = (uint32_t)__popcll(pm);
+            lap(3);
+            if (c == 0) continue;
+            if (heap.len + c > s.hcap) { status |= OVF_HEAP; break; }
+            // compact survivors in neighbor-list order
+            if (pass) {
+                const uint32_t rank = (uint32_t)__popcll(pm & ((1ull << lane) - 1ull));
+                surv_id[rank] = nid;
+                surv_slot[rank] = hslot;
+            }
+            wave_sync();
+            // distances: 4 lanes per code row, 16 rows per pass; the row of the current heap root rides along
+            const uint32_t npass = (c + 15u) >> 4;
+            for (uint32_t pass_i = 0; pass_i < npass; ++pass_i) {
+                const uint32_t j = pass_i * 16u + (uint32_t)(lane >> 2);
+                const bool valid = j < c;
+                const uint32_t id = valid ? surv_id[j] : 0;
+                const uint64_t* crow = a.codes + (size_t)id * a.code_stride;
+                if (pass_i == 0 && !pfa_issued) {
+                    pfa_issued = true;
+                    pfa_node = VS_INVALID_NODE;
+                    if (root_after != 0xFFFFFFFFu) {
+                        pfa_node = node_of(root_after & smask);
+                        pfa_val = ((uint32_t)lane < a.R) ? a.nbrs[(size_t)pfa_node * a.nbr_stride + lane] : VS_INVALID_NODE;
+                    }
+                }
+                const uint32_t d = ham_row_reg<NCH>(crow, qv, qc_l, l4, a.code_stride, valid);
+                if (valid && l4 == 0) surv_d[j] = d;
+            }
+            st_dq += c;
+            st_cand += c;
+            wave_sync();
+            uint32_t entry = 0xFFFFFFFFu;
+            if ((uint32_t)lane < c) entry = (surv_d[lane] << s.sb) | surv_slot[lane];
+            if (TIMING) {
+                if (__ballot(entry == 0xFFFFFFFEu) == ~0ull) status |= 0x100;
+                lap(4);
+            }
+            // a new candidate with a strictly smaller key than the root's is the next pop for sure
+            best = min(best, wave_min_u32(entry));
+            if ((list_ended || c0 + WAVE >= a.R) && !pfb_issued) {
+                pfb_issued = true;
+                pfb_node = VS_INVALID_NODE;
+                if (best != 0xFFFFFFFFu && (best >> s.sb) < (root_after >> s.sb)) {
+                    pfb_node = node_of(best & smask);
+                    pfb_val = ((uint32_t)lane < a.R) ? a.nbrs[(size_t)pfb_node * a.nbr_stride + lane] : VS_INVALID_NODE;
+                }
+            }
+            // insert_neighbor in list order (AM/graph/mod.rs:144-147)
+            for (uint32_t j = 0; j < c; ++j) heap.push(readlane_u32(entry, j));
+            lap(5);
+        }
+        if (status) break;
+        if (!vis_done) vis.insert(hd, node);  // (an empty neighbor list)
+        if (!pfa_issued) {  // nothing new to score: the old root is the next expansion
+            pfa_node = VS_INVALID_NODE;
+            if (root_after != 0xFFFFFFFFu) {
+                pfa_node = node_of(root_after & smask);
+                pfa_val = ((uint32_t)lane < a.R) ? a.nbrs[(size_t)pfa_node * a.nbr_stride + lane] : VS_INVALID_NODE;
+            }
+        }
+        if (!pfb_issued) pfb_node = VS_INVALID_NODE;
+    }
+    // one `next` call per emitted row, plus the call that found the stream exhausted
+    const uint32_t st_next = emitted + ((emitted < s.M && status == 0) ? 1u : 0u);
+    if (status == 0) {
+        for (uint32_t i = emitted + lane; i < s.M; i += WAVE) {
+            s.out_ids[(size_t)q * s.M + i] = VS_INVALID_NODE;
+            s.out_ham[(size_t)q * s.M + i] = 0xFFFFFFFFu;
+        }
+    }
+    if (lane == 0) {
+        s.status[q] = status;
+        if (status == 0) {
+            s.out_cnt[q] = emitted;
+            uint32_t* st = s.stats + (size_t)q * ST_N;
+            st[ST_VISITS] = st_visits;
+            st[ST_CAND] = st_cand;
+            st[ST_DQ] = st_dq;
+            st[ST_READS] = st_reads;
+            st[ST_NEXT] = st_next;
+            st[ST_GSPILL] = hmax;
+            st[ST_PFHIT] = st_pfhit;
+            st[7] = nins + nins_g;
+        }
+        if (TIMING && s.phase) {
+            lap(6);
+            for (int k = 0; k < 8; ++k) s.phase[(size_t)q * 8 + k] = ph[k];
+        }
+    }
+}
+
+size_t fast_lds_bytes(const vs_index* idx, const FastLaunch& s) {
+    size_t b = (size_t)(s.hl + 1) * 4 + (size_t)s.lh * 4 + 3 * 64 * 4 + (s.vr ? 0 : (size_t)s.vcap * 8) + MAX_QLABELS * 2 +
+               (size_t)idx->code_stride * 8 + 16;
+    return (b + 15) / 16 * 16;
+}
+
+template <int NCH, int VR, bool TIMING>
+static int launch_fast_tt(vs_index* idx, const FastArgs& a, size_t lds) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        VS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_search_fast<NCH, VR, TIMING>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_search_fast<NCH, VR, TIMING>), dim3(a.s.nq), dim3(WAVE), lds, idx->ctx->stream, a);
+    VS_HIP(hipGetLastError());
+    return VS_OK;
+}
+
+template <int NCH>
+static int launch_fast_t(vs_index* idx, const FastArgs& a, size_t lds) {
+    if (a.s.phase) {
+        VS_REQUIRE(NCH == 3 && a.s.vr == 4, "VS_PHASE diagnostics are built for 17..24-word codes / register visited list only");
+        return launch_fast_tt<3, 4, true>(idx, a, lds);
+    }
+    if (a.s.vr == 4) return launch_fast_tt<NCH, 4, false>(idx, a, lds);
+    return launch_fast_tt<NCH, 0, false>(idx, a, lds);
+}
+
+int launch_search_fast(vs_index* idx, const FastLaunch& s) {
+    if (s.nq == 0) return VS_OK;
+    FastArgs a;
+    a.codes = idx->codes;
+    a.nbrs = idx->nbrs;
+    a.tids = idx->tids;
+    a.label_off = idx->label_off;
+    a.label_val = idx->label_val;
+    a.ls_labels = idx->ls_labels;
+    a.ls_nodes = idx->ls_nodes;
+    a.code_stride = idx->code_stride;
+    a.nbr_stride = idx->nbr_stride;
+    a.R = idx->d.num_neighbors;
+    a.n = idx->d.n;
+    a.n_ls = idx->d.n_label_starts;
+    a.default_start = idx->d.default_start;
+    a.s = s;
+    const size_t lds = fast_lds_bytes(idx, s);
+    VS_REQUIRE(lds <= 160 * 1024, "fast search state does not fit LDS (%zu B)", lds);
+    VS_REQUIRE(((s.hl + 1) & s.hl) == 0 && s.hl >= 63, "fast search: hl must be 2^k - 1 >= 63");
+    VS_REQUIRE(s.vr == 4 || (s.vr == 0 && (s.vcap & (s.vcap - 1)) == 0 && s.vcap >= 64),
+               "fast search: visited list must be 4 registers or a power-of-two ring");
+    VS_REQUIRE(s.lh % 4 == 0 && s.lh >= 256 && (s.gcap & (s.gcap - 1)) == 0 && s.gcap >= 256 &&
+                   (uint64_t)s.lh + s.gcap <= (1ull << s.sb) && s.hcap >= s.hl && s.gstride % 2 == 0 &&
+                   s.gstride >= s.hcap - s.hl + 2,
+               "fast search: bad dedup table / spill geometry");
+    const uint32_t nch = (idx->code_stride + 7) / 8;
+    switch (nch) {
+        case 1: return launch_fast_t<1>(idx, a, lds);
+        case 2: return launch_fast_t<2>(idx, a, lds);
+        case 3: return launch_fast_t<3>(idx, a, lds);
+        case 4: return launch_fast_t<4>(idx, a, lds);
+        case 5:
+        case 6: return launch_fast_t<6>(idx, a, lds);
+        default: return launch_fast_t<0>(idx, a, lds);
+    }
+}

@@ -2,7 +2,7 @@
 """Kernel-level A/B harness for the search path: builds one device-resident index, then times the batched scan pipeline
 under different on-chip state splits (VS_HL = heap entries in LDS, VS_LH = LDS dedup slots) in ONE process.
 
-  python scripts/perf_search.py --n 1000000 --nq 16384 --configs 1024:4096,512:2048,4096:4096
+  python scripts/perf_search.py --n 1000000 --nq 16384 --configs VS_FAST=0,VS_FAST=1:VS_F_LH=2048
 """
 import argparse
 import ctypes as C
@@ -23,7 +23,7 @@ def main():
     ap.add_argument("--rescore", type=int, default=50)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--reps", type=int, default=4)
-    ap.add_argument("--configs", default="1024:4096")
+    ap.add_argument("--configs", default="VS_FAST=1")
     ap.add_argument("--kind", default="clustered", choices=["clustered", "hard"])
     args = ap.parse_args()
     import numpy as np
@@ -51,10 +51,12 @@ def main():
     W, R = ix.desc.words, ix.desc.num_neighbors
     ref_ids = None
     for cfg in args.configs.split(","):
-        parts = cfg.split(":")
-        hl, lh = parts[0], parts[1]
-        os.environ["VS_HL"], os.environ["VS_LH"] = hl, lh
-        os.environ["VS_G0"] = parts[2] if len(parts) > 2 else "4096"
+        # a config is a ':'-separated list of NAME=VALUE environment overrides read by libvsgpu (VS_FAST, VS_F_LH, VS_F_HL,
+        # VS_F_VCAP for the fast kernel; VS_HL, VS_LH, VS_G0 for the general one)
+        for kv in cfg.split(":"):
+            if kv:
+                k_, v_ = kv.split("=")
+                os.environ[k_] = v_
         ctx.profile_enable(True)
         ix.search_batch_dev(q, nq, args.L, args.rescore, k, out)
         ix.search_batch_dev_finish()
@@ -69,10 +71,12 @@ def main():
         same = "ref" if ref_ids is None else str(bool((ids == ref_ids).all()))
         if ref_ids is None:
             ref_ids = ids
-        ms = prof["search"][0] / prof["search"][1]
+        ms = prof["search"][0] / max(prof["search"][1], 1)
+        fb = prof["search_fallback"][0] / max(prof["search_fallback"][1], 1)
         bytes_ = st["visited_nodes"] * 4 * R + st["quantized_distance_comparisons"] * 8 * W
-        print(f"HL={hl:>5} LH={lh:>5} G0={os.environ['VS_G0']:>5}: search {ms:8.3f} ms  rerank {prof['rerank'][0] / prof['rerank'][1]:.3f} ms  wall {wall * 1e3:8.3f} ms "
-              f"-> {nq / wall:10.0f} QPS  {bytes_ / ms / 1e6:7.1f} GB/s alg  visits/q {st['visited_nodes'] / nq:.1f} "
+        print(f"{cfg:40s}: search {ms:8.3f} ms (+fallback {fb:6.3f} ms, {st['fallback_scans']} scans)  rerank "
+              f"{prof['rerank'][0] / prof['rerank'][1]:.3f} ms  wall {wall * 1e3:8.3f} ms "
+              f"-> {nq / wall:10.0f} QPS  {bytes_ / (ms + fb) / 1e6:7.1f} GB/s alg  visits/q {st['visited_nodes'] / nq:.1f} "
               f"dq/q {st['quantized_distance_comparisons'] / nq:.1f}  same_ids={same}", flush=True)
     ix.close()
     ctx.close()

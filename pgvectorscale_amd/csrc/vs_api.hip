@@ -297,7 +297,7 @@ extern "C" void vs_index_free(vs_index* ix) {
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     SearchWorkspace& w = ix->ws;
-    DevBuf* bufs[] = {&w.q_full, &w.qcodes, &w.qlabels, &w.qlabel_off, &w.hash, &w.heap_g, &w.heap_g4, &w.ghash4, &w.fb_flag, &w.phase, &w.stream_ids,
+    DevBuf* bufs[] = {&w.q_full, &w.qcodes, &w.qlabels, &w.qlabel_off, &w.hash, &w.heap_g, &w.heap_g4, &w.ghash4, &w.pool_ctr, &w.fb_flag, &w.phase, &w.stream_ids,
                       &w.stream_ham, &w.stream_cnt, &w.stats, &w.status, &w.rr_dist, &w.out_ids, &w.out_tids,
                       &w.out_dist, &w.resort_heap, &w.raw_q, &w.misc};
     for (DevBuf* b : bufs) devbuf_free(*b);
@@ -613,7 +613,7 @@ static Caps initial_caps(const vs_index* ix, uint32_t L, uint32_t M) {
     // fast kernel: everything in LDS, sized for the typical scan (about 8-10 new candidates per visit, 1.1 L + M
     // visits); the rare scan that outgrows it is re-run by the general kernel.
     const uint64_t typ_visits = (uint64_t)L + L / 4 + M + 16;
-    const uint64_t typ_ins = typ_visits * std::min<uint64_t>(ix->d.num_neighbors, 12);
+    const uint64_t typ_ins = typ_visits * std::min<uint64_t>(ix->d.num_neighbors, 11);
     c.f_lh = env_u32("VS_F_LH", (uint32_t)std::min<uint64_t>(round_up_u32((uint32_t)std::min<uint64_t>(typ_ins, 1u << 20), 64), 1u << 15));
     c.f_hl = env_u32("VS_F_HL", 1023);
     const uint32_t want_v = (uint32_t)std::min<uint64_t>((uint64_t)L + L / 2 + 32, 1u << 20);
@@ -640,8 +640,11 @@ static Caps initial_caps(const vs_index* ix, uint32_t L, uint32_t M) {
     return c;
 }
 
+static uint32_t fast_pool_slots(uint32_t nq) { return std::max<uint32_t>(256, nq / 4); }
+static uint32_t general_pool_slots(uint32_t nq) { return std::max<uint32_t>(64, nq / 64); }
+
 static bool grow_caps(Caps& c, uint32_t ovf) {
-    bool grew = false;
+    bool grew = (ovf & OVF_POOL) != 0;  // pool exhausted: the relaunch hands out the regions again
     if ((ovf & OVF_HEAP) && c.hcap < (1u << 24)) {
         c.hcap *= 2;
         grew = true;
@@ -684,8 +687,11 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
     }
     bool fast_done = false;
     if (caps.f_lh) {
+        const uint32_t fslots = fast_pool_slots(nq);
         VS_TRY(devbuf_reserve(c, w.heap_g4, std::max<size_t>((size_t)nq * caps.f_gstride * 4, 16)));
-        VS_TRY(devbuf_reserve(c, w.ghash4, (size_t)nq * caps.f_gcap * 4));
+        VS_TRY(devbuf_reserve(c, w.ghash4, (size_t)fslots * caps.f_gcap * 4));
+        VS_TRY(devbuf_reserve(c, w.pool_ctr, 64));
+        VS_HIP(hipMemsetAsync(w.pool_ctr.p, 0, 64, c->stream));
         VS_TRY(devbuf_reserve(c, w.fb_flag, (size_t)nq * 4));
         VS_HIP(hipMemsetAsync(w.fb_flag.p, 0, (size_t)nq * 4, c->stream));
         FastLaunch f;
@@ -699,6 +705,8 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
         f.heap_g = (uint32_t*)w.heap_g4.p;
         f.gcap = caps.f_gcap;
         f.ghash = (uint32_t*)w.ghash4.p;
+        f.pool_counter = (uint32_t*)w.pool_ctr.p;
+        f.pool_slots = fslots;
         f.lh = caps.f_lh;
         f.sb = caps.f_sb;
         f.vcap = caps.f_vcap;
@@ -719,12 +727,29 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
         VS_TRY(launch_search_fast(ix, f));
         prof_end(c, PK_SEARCH, ev);
         fast_done = true;
+        if (env_u32("VS_DEBUG_STATUS", 0)) {  // diagnostics: which flags did the fast kernel leave behind?
+            std::vector<uint32_t> stv(nq);
+            VS_HIP(hipMemcpyAsync(stv.data(), w.status.p, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
+            uint32_t ctr[2] = {0, 0};
+            VS_HIP(hipMemcpyAsync(ctr, w.pool_ctr.p, 4, hipMemcpyDeviceToHost, c->stream));
+            VS_HIP(hipStreamSynchronize(c->stream));
+            uint32_t hist[16] = {0};
+            for (uint32_t v : stv) hist[v & 15]++;
+            fprintf(stderr, "[VS_DEBUG_STATUS] fast kernel: pool claims=%u of %u;", ctr[0], fast_pool_slots(nq));
+            for (int i = 0; i < 16; ++i)
+                if (hist[i]) fprintf(stderr, " status[%d]=%u", i, hist[i]);
+            fprintf(stderr, "\n");
+        }
     }
     w.fb_valid = fast_done;
     for (int attempt = 0;; ++attempt) {
         const size_t hg = caps.hcap > caps.hl ? caps.hcap - caps.hl : 0;
-        VS_TRY(devbuf_reserve(c, w.hash, (size_t)nq * caps.hashcap * 4));
-        VS_TRY(devbuf_reserve(c, w.heap_g, std::max<size_t>((size_t)nq * hg * 8, 16)));
+        // after the fast kernel only a few scans are left: they claim their regions from a small pool
+        const uint32_t gslots = fast_done ? general_pool_slots(nq) : nq;
+        VS_TRY(devbuf_reserve(c, w.hash, (size_t)gslots * caps.hashcap * 4));
+        VS_TRY(devbuf_reserve(c, w.heap_g, std::max<size_t>((size_t)gslots * hg * 8, 16)));
+        VS_TRY(devbuf_reserve(c, w.pool_ctr, 64));
+        if (fast_done) VS_HIP(hipMemsetAsync((char*)w.pool_ctr.p + 32, 0, 4, c->stream));
         SearchLaunch s;
         s.nq = nq;
         s.L = bp.L;
@@ -748,6 +773,8 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
         // after the fast kernel (or a failed attempt) only the scans whose status is non-zero are (re)run
         s.only_failed = (fast_done || attempt > 0) ? 1u : 0u;
         s.fb_flag = fast_done ? (uint32_t*)w.fb_flag.p : nullptr;
+        s.pool_counter = fast_done ? (uint32_t*)((char*)w.pool_ctr.p + 32) : nullptr;
+        s.pool_slots = gslots;
         {
             hipEvent_t ev = prof_begin(c);
             VS_TRY(launch_search(ix, s));
@@ -832,9 +859,10 @@ static uint32_t stream_len(uint32_t rescore, uint32_t k) { return rescore > 0 ? 
 
 // how many queries fit one launch given the workspace budget
 static uint32_t chunk_queries(const vs_index* ix, const Caps& c, uint32_t M, uint32_t nq) {
-    size_t per_q = (size_t)c.hashcap * 4 + (size_t)(c.hcap > c.hl ? c.hcap - c.hl : 0) * 8 + (size_t)M * 12 + ix->vec_stride * 4ull +
-                   ix->code_stride * 8ull + 256;
-    if (c.f_lh) per_q += (size_t)c.f_gcap * 4 + (size_t)c.f_gstride * 4 + 64;
+    const size_t general = (size_t)c.hashcap * 4 + (size_t)(c.hcap > c.hl ? c.hcap - c.hl : 0) * 8;
+    size_t per_q = (size_t)M * 12 + ix->vec_stride * 4ull + ix->code_stride * 8ull + 256;
+    if (c.f_lh) per_q += (size_t)c.f_gcap * 4 / 8 + (size_t)c.f_gstride * 4 + general / 64 + 64;
+    else per_q += general;
     size_t budget = 24ull << 30;
     uint32_t m = (uint32_t)std::max<size_t>(1, std::min<size_t>(budget / per_q, 1u << 20));
     return std::min(m, nq);
@@ -961,11 +989,17 @@ extern "C" int vs_search_batch_dev_finish(vs_index* ix, vs_stats* stats) {
     std::vector<uint32_t> status(nq);
     VS_HIP(hipMemcpyAsync(status.data(), w.status.p, (size_t)nq * 4, hipMemcpyDeviceToHost, ix->ctx->stream));
     VS_HIP(hipStreamSynchronize(ix->ctx->stream));
-    uint32_t ovf = 0;
-    for (uint32_t v : status) ovf |= v;
+    uint32_t ovf = 0, nbad = 0;
+    for (uint32_t v : status) {
+        ovf |= v;
+        nbad += v != 0;
+    }
     if (ovf) {
-        vs_set_error("vs_search_batch_dev: per-query structures overflowed (flags 0x%x); use vs_search_batch, which "
-                     "retries with larger capacities", ovf);
+        uint32_t ctr[16] = {0};
+        if (w.pool_ctr.p) (void)hipMemcpy(ctr, w.pool_ctr.p, 64, hipMemcpyDeviceToHost);
+        vs_set_error("vs_search_batch_dev: per-query structures overflowed in %u of %u scans (flags 0x%x; dedup-overflow "
+                     "tables claimed %u, fallback regions claimed %u); use vs_search_batch, which retries with larger "
+                     "capacities", nbad, nq, ovf, ctr[0], ctr[8]);
         return VS_ERR_CAPACITY;
     }
     vs_stats st{};

@@ -71,7 +71,7 @@ struct DevBuf {
 };
 
 struct SearchWorkspace {
-    DevBuf q_full, qcodes, qlabels, qlabel_off, hash, heap_g, heap_g4, ghash4, fb_flag, phase, stream_ids, stream_ham, stream_cnt, stats, status,
+    DevBuf q_full, qcodes, qlabels, qlabel_off, hash, heap_g, heap_g4, ghash4, pool_ctr, fb_flag, phase, stream_ids, stream_ham, stream_cnt, stats, status,
         rr_dist, out_ids, out_tids, out_dist, resort_heap, raw_q, misc;
     // pending async call (vs_search_batch_dev)
     bool fb_valid = false;  // fb_flag holds the fallback marks of the last chunk
@@ -126,6 +126,8 @@ struct SearchLaunch {
     uint32_t* stats;               // [nq][8]
     uint32_t* status;              // [nq]
     uint32_t only_failed = 0;      // 1: run only the scans whose status[q] != 0 (left over by the fast kernel)
+    uint32_t* pool_counter = nullptr;  // non-null: heap_g / hash hold pool_slots regions claimed with an atomic counter
+    uint32_t pool_slots = 0;
     uint32_t* fb_flag = nullptr;   // [nq] set to 1 for every scan this launch ran in only_failed mode
 };
 // fast path (vs_search_fast.hip): all hot state in LDS
@@ -142,8 +144,11 @@ struct FastLaunch {
     const uint64_t* qcodes;
     const int16_t* qlabels;
     const uint32_t* qlabel_off;
-    uint32_t* heap_g;
-    uint32_t* ghash;   // [nq][gcap] (cleared by the kernel on first use)
+    uint32_t* heap_g;  // [nq][gstride] heap positions >= hl
+    // the global dedup overflow table is claimed on first need from a pool of pool_slots tables
+    uint32_t* ghash;   // [pool_slots][gcap] (cleared by the claiming wave)
+    uint32_t* pool_counter;
+    uint32_t pool_slots;
     uint32_t* out_ids;
     uint32_t* out_ham;
     uint32_t* out_cnt;
@@ -154,7 +159,7 @@ struct FastLaunch {
 size_t fast_lds_bytes(const vs_index* idx, const FastLaunch& s);
 int launch_search_fast(vs_index* idx, const FastLaunch& s);
 enum { ST_VISITS = 0, ST_CAND = 1, ST_DQ = 2, ST_READS = 3, ST_NEXT = 4, ST_GSPILL = 5, ST_PFHIT = 6, ST_N = 8 };
-enum { OVF_HEAP = 1, OVF_VISITED = 2, OVF_HASH = 4 };
+enum { OVF_HEAP = 1, OVF_VISITED = 2, OVF_HASH = 4, OVF_POOL = 8 };
 size_t search_lds_bytes(const vs_index* idx, const SearchLaunch& s);
 
 int launch_prepare_queries(vs_index* idx, const float* d_raw, uint32_t nq, float* d_q_full, uint64_t* d_qcodes);

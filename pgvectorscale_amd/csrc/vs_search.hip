@@ -129,6 +129,15 @@ __global__ __launch_bounds__(WAVE) void k_search(SearchArgs a) {
         if (s.status[q] == 0) return;
         if (threadIdx.x == 0 && s.fb_flag) s.fb_flag[q] = 1;
     }
+    uint32_t wslot = q;  // which region of heap_g / hash this scan uses
+    if (s.pool_counter) {
+        if (threadIdx.x == 0) wslot = atomicAdd(s.pool_counter, 1u);
+        wslot = rfl(wslot);
+        if (wslot >= s.pool_slots) {  // pool exhausted: the host re-launches the scans that are still marked
+            if (threadIdx.x == 0) s.status[q] = OVF_POOL;
+            return;
+        }
+    }
 
     // ---- LDS carve (every offset a multiple of 16 B) ----
     uint64_t* heap_l = reinterpret_cast<uint64_t*>(smem);                        // hl + 2 entries
@@ -155,14 +164,14 @@ __global__ __launch_bounds__(WAVE) void k_search(SearchArgs a) {
     // global dedup overflow: a ladder of tables (level j has g0 << j slots at offset (g0 << j) - g0); a new level is
     // opened (and cleared by this wave) when the current one is half full, so small scans stay cache-resident and
     // nothing is ever re-hashed.  Membership = present in ANY level; inserts go to the top level.
-    uint32_t* ghash = s.hash + (size_t)q * s.hashcap;
+    uint32_t* ghash = s.hash + (size_t)wslot * s.hashcap;
     const uint32_t g0 = s.g0;
     const uint32_t lmask = s.lh ? s.lh - 1 : 0;
     const uint32_t l_full_at = s.lh ? (s.lh / 4) * 3 : 0;  // stop inserting into the LDS table at 75 % load
     int glev = -1;                                            // top level in use (-1: global ladder untouched)
     uint32_t nins_l = 0, nins_g = 0, nins_top = 0;
 
-    WaveHeap heap{heap_l, s.heap_g + (size_t)q * (s.hcap > s.hl ? s.hcap - s.hl : 0), s.hl, 0, 0};
+    WaveHeap heap{heap_l, s.heap_g + (size_t)wslot * (s.hcap > s.hl ? s.hcap - s.hl : 0), s.hl, 0, 0};
     uint32_t vlen = 0, emitted = 0, status = 0;
     uint32_t st_visits = 0, st_cand = 0, st_dq = 0, st_reads = 0, st_next = 0, st_pfhit = 0;
 

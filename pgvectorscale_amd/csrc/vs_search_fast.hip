@@ -138,6 +138,51 @@ struct FastHeap {
         len += 1;
     }
 
+    // ---- insert_neighbor x c (AM/graph/mod.rs:144-147): elements 0..c-1 (lanes 0..c-1 of `entry`, neighbor-list order)
+    // are pushed one after another, but only the first one waits for LDS: consecutive leaves P, P+1 on the same level
+    // share their ancestors from rank sh = bitlen((P+1) xor (P+2)) upwards, and what push j did to that chain is known
+    // in registers (ranks r < t_j now hold the old rank r+1 value, rank t_j holds element j), so the chain of push j+1
+    // is patched from registers for r >= sh and taken from an LDS read issued one push earlier for r < sh (positions
+    // push j never touches).
+    __device__ __forceinline__ void push_run(uint32_t entry, uint32_t c) {
+        if (c == 0) return;
+        if (len + c > hl || len < 2) {  // spill region involved / tiny heap: one at a time
+            for (uint32_t j = 0; j < c; ++j) push(readlane_u32(entry, j));
+            return;
+        }
+        const uint32_t r = (uint32_t)lane & 31u;
+        uint32_t p1 = len + 1;
+        uint32_t chain = l[p1 >> r];
+        for (uint32_t j = 0; j < c; ++j) {
+            const uint32_t elem = readlane_u32(entry, j);
+            const uint32_t p1n = p1 + 1;
+            const bool more = j + 1 < c;
+            uint32_t nxt = 0;
+            if (more) nxt = l[p1n >> r];  // valid for the ranks push j cannot touch (r < sh)
+            const bool cmp = (elem >> sb) < (chain >> sb);
+            const uint32_t bal = (uint32_t)__ballot(cmp) >> 1;  // bit r-1 <-> ancestor r; bit 31 is always clear
+            const uint32_t t = (uint32_t)__builtin_ctz(~bal);   // leading run of ancestors that move down
+            if ((uint32_t)lane <= t) {
+                const uint32_t dst = lane == 0 ? (p1 >> t) : (p1 >> (lane - 1));
+                l[dst] = lane == 0 ? elem : chain;
+            }
+            if (more) {
+                if ((p1n & (p1n - 1)) == 0) {  // the next leaf opens a new level: ranks do not line up, re-read
+                    wave_sync();
+                    chain = l[p1n >> r];
+                } else {
+                    const uint32_t sh = 32u - (uint32_t)__builtin_clz(p1 ^ p1n);
+                    const uint32_t up = wave_shl1(chain, 0);  // rank r+1 value
+                    const uint32_t patched = r < t ? up : (r == t ? elem : chain);
+                    chain = r >= sh ? patched : nxt;
+                }
+            }
+            p1 = p1n;
+        }
+        wave_sync();
+        len += c;
+    }
+
     // ---- BinaryHeap::pop: Vec::pop, swap with data[0], sift_down_to_bottom(0), sift_up.  (len > 0; the caller has
     // already read data[0])
     __device__ __forceinline__ void pop() {
@@ -421,10 +466,24 @@ __global__ __launch_bounds__(WAVE) void k_search_fast(FastArgs a) {
     // ---- HashSet::insert.  Normal mode: the first CAS is ISSUED by the caller so independent work can overlap its
     // latency, finish_insert completes the probe sequence.  Frozen mode (LDS table at its load limit): read-only
     // probe of the LDS table, then insert into the per-scan global overflow table.
-    uint32_t* ghash = s.ghash + (size_t)q * s.gcap;
+    uint32_t* ghash = s.ghash;
     const uint32_t gmask = s.gcap - 1;
     uint32_t nins_g = 0;
-    bool g_open = false;
+    bool g_open = false, region = false;
+    // global dedup overflow table: claimed from the pool on first need
+    auto claim_region = [&]() -> bool {
+        if (region) return true;
+        uint32_t slot = 0;
+        if (lane == 0) slot = atomicAdd(s.pool_counter, 1u);
+        slot = rfl(slot);
+        if (slot >= s.pool_slots) {
+            status |= OVF_POOL;
+            return false;
+        }
+        region = true;
+        ghash = s.ghash + (size_t)slot * s.gcap;
+        return true;
+    };
     auto hash_home = [&](uint32_t nid) -> uint32_t { return (uint32_t)(((uint64_t)hash_u32(nid) * s.lh) >> 32); };
     auto node_of = [&](uint32_t handle) -> uint32_t {  // uniform handle -> node id
         if (handle < s.lh) return rfl(lhash[handle]);
@@ -457,7 +516,8 @@ __global__ __launch_bounds__(WAVE) void k_search_fast(FastArgs a) {
             }
         }
         if (__ballot(need_g)) {
-            if (!g_open) {  // first use: this wave clears its own table
+            if (!g_open) {  // first use: this wave claims and clears its own table
+                if (!claim_region()) return false;
                 g_open = true;
                 for (uint32_t i = 4u * lane; i < s.gcap; i += 4u * WAVE)
                     *reinterpret_cast<uint4*>(ghash + i) = make_uint4(VS_EMPTY, VS_EMPTY, VS_EMPTY, VS_EMPTY);
@@ -532,7 +592,16 @@ __global__ __launch_bounds__(WAVE) void k_search_fast(FastArgs a) {
 
     // ---- TSVResponseIterator::next until M rows are emitted (AM/scan.rs:210-242), flattened: every iteration is
     // either one visit_closest() expansion (greedy_search_iterate, AM/graph/mod.rs:357-385) or one consume() ----
+    uint32_t ft_node = VS_INVALID_NODE;  // heap tid of the visited list's front entry, requested ahead of consume()
+    uint64_t ft_val = 0;
     while (status == 0) {
+        if (VR > 0 && vis.len > 0) {
+            const uint32_t fn = readlane_u32(vis.n[0], 0);
+            if (fn != ft_node) {
+                ft_node = fn;
+                ft_val = a.tids[fn];
+            }
+        }
         uint32_t top = 0;
         bool can_visit = heap.len > 0;
         if (can_visit) {
@@ -546,7 +615,7 @@ __global__ __launch_bounds__(WAVE) void k_search_fast(FastArgs a) {
             uint32_t fd, fnode;
             vis.pop_front(fd, fnode);
             st_reads++;
-            const uint64_t tid = a.tids[fnode];
+            const uint64_t tid = (VR > 0 && fnode == ft_node) ? ft_val : a.tids[fnode];
             if ((tid & 0xFFFFull) == 0) continue;  // InvalidOffsetNumber: deleted tuple (AM/scan.rs:231-234)
             if (lane == 0) {
                 s.out_ids[(size_t)q * s.M + emitted] = fnode;
@@ -674,7 +743,7 @@ __global__ __launch_bounds__(WAVE) void k_search_fast(FastArgs a) {
                 }
             }
             // insert_neighbor in list order (AM/graph/mod.rs:144-147)
-            for (uint32_t j = 0; j < c; ++j) heap.push(readlane_u32(entry, j));
+            heap.push_run(entry, c);
             lap(5);
         }
         if (status) break;

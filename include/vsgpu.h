@@ -110,7 +110,7 @@ int vs_ctx_mem_info(vs_ctx* ctx, uint64_t* free_bytes, uint64_t* total_bytes);
 /* per-kernel timing with HIP events recorded on the ctx stream around every launch of the batched-scan pipeline
  * (what bench.py's roofline figure is computed from).  kind: 0 prepare_queries, 1 search (the LDS-resident fast
  * kernel; the general kernel when the fast path is off), 2 rerank, 3 resort, 4 search fallback (general kernel re-running
- * the scans the fast kernel handed over). */
+ * the scans the fast kernel handed over), 5 flat SBQ scan (vs_scan_topk). */
 typedef struct vs_profile {
     double ms[8];        /* accumulated kernel time per kind */
     uint64_t launches[8];

@@ -1,6 +1,9 @@
 // vs_extra.hip — build-side kernels that manufacture device-resident indexes (SURVEY.md §8f "next" rows) and the
 // synthetic corpus generator.  None of this is on the reference's *search* path; it exists so that corpora far
 // larger than host RAM (50M x 768 f32 = 153.6 GB) can be generated, trained, quantised and indexed in HBM.
+#include <algorithm>
+#include <cmath>
+
 #include "vs_internal.h"
 
 #define WAVE 64
@@ -320,11 +323,115 @@ extern "C" int vs_sbq_quantize_corpus(vs_index* ix) {
     return VS_OK;
 }
 
-#define NOT_YET(name)                                         \
-    do {                                                      \
-        vs_set_error(name ": not implemented in this build"); \
-        return VS_ERR_STATE;                                  \
-    } while (0)
+// ===============================================================================================================
+// K5 host entry: flat SBQ scan (kernels in vs_scan.hip)
+// ===============================================================================================================
+extern "C" int vs_scan_topk(vs_index* ix, const uint64_t* qcodes, uint32_t nq, uint32_t k, uint32_t* out_ids, uint32_t* out_ham) {
+    VS_REQUIRE(ix && (nq == 0 || (qcodes && out_ids)), "vs_scan_topk: bad args");
+    if (nq == 0) return VS_OK;
+    vs_ctx* c = ix->ctx;
+    VS_HIP(hipSetDevice(c->device));
+    SearchWorkspace& w = ix->ws;
+    const uint32_t W = ix->d.words, cs = ix->code_stride;
+    // repack [nq][W] -> [nq][code_stride] (zero padded) through the pinned staging path
+    std::vector<uint64_t> padded((size_t)nq * cs, 0);
+    for (uint32_t q = 0; q < nq; ++q) memcpy(&padded[(size_t)q * cs], qcodes + (size_t)q * W, (size_t)W * 8);
+    VS_TRY(devbuf_reserve(c, w.qcodes, padded.size() * 8));
+    VS_TRY(devbuf_reserve(c, w.out_ids, (size_t)nq * k * 4));
+    VS_TRY(devbuf_reserve(c, w.stream_ham, (size_t)nq * k * 4));
+    VS_TRY(vs_dev_upload(c, w.qcodes.p, padded.data(), padded.size() * 8));
+    VS_TRY(launch_scan_topk(ix, (const uint64_t*)w.qcodes.p, nq, k, (uint32_t*)w.out_ids.p, (uint32_t*)w.stream_ham.p));
+    VS_TRY(vs_dev_download(c, out_ids, w.out_ids.p, (size_t)nq * k * 4));
+    if (out_ham) VS_TRY(vs_dev_download(c, out_ham, w.stream_ham.p, (size_t)nq * k * 4));
+    return VS_OK;
+}
 
-extern "C" int vs_scan_topk(vs_index*, const uint64_t*, uint32_t, uint32_t, uint32_t*, uint32_t*) { NOT_YET("vs_scan_topk"); }
-extern "C" int vs_bruteforce_topk(vs_index*, const float*, uint32_t, uint32_t, uint32_t*, float*) { NOT_YET("vs_bruteforce_topk"); }
+// ===============================================================================================================
+// Exact brute force (ground truth for recall): the f32 distance of every row in the reference's accumulation order
+// (k_rerank on contiguous row chunks) folded into a running top-k per query, order (distance total_cmp, node id).
+// One wave per query; its list lives in global memory between chunks.
+// ===============================================================================================================
+__device__ __forceinline__ uint32_t bf_total_key(float f) {  // monotone u32 image of f32::total_cmp
+    uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+__global__ __launch_bounds__(WAVE) void k_bf_fold(const float* __restrict__ dist, const uint64_t* __restrict__ tids, uint32_t chunk,
+                                                  uint32_t row_base, uint32_t nq, uint32_t k,
+                                                  uint64_t* __restrict__ lists /*[nq][k] ascending*/) {
+    __shared__ uint64_t lst[64];
+    const uint32_t q = blockIdx.x;
+    if (q >= nq) return;
+    const int lane = threadIdx.x;
+    if ((uint32_t)lane < k) lst[lane] = lists[(size_t)q * k + lane];
+    __syncthreads();
+    uint64_t th = lst[k - 1];
+    const float* d = dist + (size_t)q * chunk;
+    for (uint32_t i0 = 0; i0 < chunk; i0 += WAVE) {
+        const uint32_t i = i0 + lane;
+        uint64_t key = ~0ull;
+        // deleted tuples (InvalidOffsetNumber) are never returned by a scan: not part of the ground truth either
+        if (i < chunk && (tids[row_base + i] & 0xFFFFull) != 0) key = ((uint64_t)bf_total_key(d[i]) << 32) | (row_base + i);
+        uint64_t hit = __ballot(key < th);
+        while (hit) {
+            const int src = __builtin_ctzll(hit);
+            hit &= hit - 1;
+            const uint64_t kk = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key >> 32), src) << 32) |
+                                (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, src);
+            if (kk < th) {
+                uint64_t b = ~0ull;
+                if ((uint32_t)lane < k) b = lst[lane];
+                const uint32_t pos = (uint32_t)__popcll(__ballot((uint32_t)lane < k && b < kk));
+                __syncthreads();
+                if ((uint32_t)lane >= pos && (uint32_t)lane + 1 < k) lst[lane + 1] = b;
+                if ((uint32_t)lane == pos) lst[pos] = kk;
+                __syncthreads();
+                th = lst[k - 1];
+            }
+        }
+    }
+    if ((uint32_t)lane < k) lists[(size_t)q * k + lane] = lst[lane];
+}
+
+extern "C" int vs_bruteforce_topk(vs_index* ix, const float* d_queries, uint32_t nq, uint32_t k, uint32_t* out_ids, float* out_dist) {
+    VS_REQUIRE(ix && (nq == 0 || (d_queries && out_ids)), "vs_bruteforce_topk: bad args");
+    VS_REQUIRE(ix->vecs, "vs_bruteforce_topk: needs the vector column on the device");
+    VS_REQUIRE(k >= 1 && k <= 64, "vs_bruteforce_topk: k must be in [1, 64]");
+    if (nq == 0) return VS_OK;
+    vs_ctx* c = ix->ctx;
+    VS_HIP(hipSetDevice(c->device));
+    SearchWorkspace& w = ix->ws;
+    const uint32_t n = ix->d.n;
+    // query preparation exactly as for a scan (cosine normalisation of the full slice)
+    VS_TRY(devbuf_reserve(c, w.q_full, (size_t)nq * ix->vec_stride * 4));
+    VS_TRY(devbuf_reserve(c, w.qcodes, (size_t)nq * ix->code_stride * 8));
+    VS_TRY(launch_prepare_queries(ix, d_queries, nq, (float*)w.q_full.p, (uint64_t*)w.qcodes.p));
+    const uint32_t chunk = (uint32_t)std::min<uint64_t>(std::max<uint32_t>(n, 1), std::max<uint64_t>(4096, (256ull << 20) / nq));
+    VS_TRY(devbuf_reserve(c, w.rr_dist, (size_t)nq * chunk * 4));
+    VS_TRY(devbuf_reserve(c, w.resort_heap, (size_t)nq * k * 8));
+    VS_HIP(hipMemsetAsync(w.resort_heap.p, 0xFF, (size_t)nq * k * 8, c->stream));
+    for (uint64_t r0 = 0; r0 < n; r0 += chunk) {
+        const uint32_t m = (uint32_t)std::min<uint64_t>(chunk, n - r0);
+        VS_TRY(launch_rerank(ix, (const float*)w.q_full.p, nullptr, nullptr, nullptr, m, nq, (float*)w.rr_dist.p, (uint32_t)r0));
+        hipLaunchKernelGGL(k_bf_fold, dim3(nq), dim3(WAVE), 0, c->stream, (const float*)w.rr_dist.p, ix->tids, m, (uint32_t)r0, nq, k,
+                           (uint64_t*)w.resort_heap.p);
+        VS_HIP(hipGetLastError());
+    }
+    std::vector<uint64_t> lists((size_t)nq * k);
+    VS_TRY(vs_dev_download(c, lists.data(), w.resort_heap.p, lists.size() * 8));
+    for (size_t i = 0; i < lists.size(); ++i) {
+        const uint64_t e = lists[i];
+        if (e == ~0ull) {
+            out_ids[i] = VS_INVALID_NODE;
+            if (out_dist) out_dist[i] = NAN;
+        } else {
+            out_ids[i] = (uint32_t)e;
+            uint32_t kb = (uint32_t)(e >> 32);
+            kb = (kb & 0x80000000u) ? (kb & 0x7FFFFFFFu) : ~kb;
+            float f;
+            memcpy(&f, &kb, 4);
+            if (out_dist) out_dist[i] = f;
+        }
+    }
+    return VS_OK;
+}

@@ -60,7 +60,7 @@ struct vs_ctx {
     double prof_ms[8] = {0};
     uint64_t prof_launches[8] = {0};
 };
-enum { PK_PREPARE = 0, PK_SEARCH = 1, PK_RERANK = 2, PK_RESORT = 3, PK_SEARCH_FB = 4 };
+enum { PK_PREPARE = 0, PK_SEARCH = 1, PK_RERANK = 2, PK_RESORT = 3, PK_SEARCH_FB = 4, PK_SCAN = 5 };
 hipEvent_t prof_begin(vs_ctx* c);
 void prof_end(vs_ctx* c, int kind, hipEvent_t a);
 
@@ -168,7 +168,7 @@ int launch_quantize_rows(vs_index* idx, const float* d_rows, uint32_t row_stride
 int launch_hamming_gather(vs_index* idx, const uint64_t* d_qcodes, const uint32_t* d_ids, const uint32_t* d_off,
                           uint32_t nq, uint32_t* d_out);
 int launch_rerank(vs_index* idx, const float* d_q_full, const uint32_t* d_ids, const uint32_t* d_off,
-                  const uint32_t* d_cnt, uint32_t fixed_m, uint32_t nq, float* d_out);
+                  const uint32_t* d_cnt, uint32_t fixed_m, uint32_t nq, float* d_out, uint32_t row_base = 0);
 int launch_search(vs_index* idx, const SearchLaunch& s, bool build_mode = false);
 int launch_resort(vs_index* idx, uint32_t nq, uint32_t M, uint32_t rescore, uint32_t k, const uint32_t* d_stream_ids,
                   const uint32_t* d_cnt, const float* d_dist, uint64_t* d_heap_ws, uint32_t* d_out_ids,

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void k_rerank(const float* __restrict__ vecs, 
                                                 const float* __restrict__ vnorm, uint32_t distance_type,
                                                 const float* __restrict__ q_full, const uint32_t* __restrict__ ids,
                                                 const uint32_t* __restrict__ off, const uint32_t* __restrict__ cnt,
-                                                uint32_t fixed_m, uint32_t nq, float* __restrict__ out) {
+                                                uint32_t fixed_m, uint32_t nq, float* __restrict__ out, uint32_t row_base) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* qv = reinterpret_cast<float*>(smem);
     const uint32_t q = blockIdx.x;
@@ -186,7 +186,8 @@ __global__ __launch_bounds__(256) void k_rerank(const float* __restrict__ vecs, 
     for (uint32_t base = b; base < e; base += 32) {
         uint32_t j = base + (uint32_t)(wave * 8 + grp);
         bool valid = j < e;
-        uint32_t id = valid ? ids[j] : VS_INVALID_NODE;
+        // ids == nullptr: the contiguous rows row_base .. row_base + fixed_m - 1 (exact brute force, vs_bruteforce_topk)
+        uint32_t id = valid ? (ids ? ids[j] : row_base + (j - b)) : VS_INVALID_NODE;
         if (id == VS_INVALID_NODE) valid = false;
         const float* row = vecs + (size_t)(valid ? id : 0) * vec_stride;
         float s = 0.0f;
@@ -433,13 +434,13 @@ int launch_hamming_gather(vs_index* idx, const uint64_t* d_qcodes, const uint32_
 }
 
 int launch_rerank(vs_index* idx, const float* d_q_full, const uint32_t* d_ids, const uint32_t* d_off,
-                  const uint32_t* d_cnt, uint32_t fixed_m, uint32_t nq, float* d_out) {
+                  const uint32_t* d_cnt, uint32_t fixed_m, uint32_t nq, float* d_out, uint32_t row_base) {
     if (nq == 0) return VS_OK;
     VS_REQUIRE(idx->vecs != nullptr, "index has no vector column: rerank impossible");
     size_t lds = (size_t)idx->vec_stride * 4;
     hipLaunchKernelGGL(k_rerank, dim3(nq), dim3(256), lds, idx->ctx->stream, idx->vecs, idx->vec_stride,
                        idx->d.dim_full, idx->vnorm, idx->d.distance_type, d_q_full, d_ids, d_off, d_cnt, fixed_m, nq,
-                       d_out);
+                       d_out, row_base);
     VS_HIP(hipGetLastError());
     return VS_OK;
 }

@@ -60,7 +60,7 @@ class Context:
         """{kernel: (total_ms, launches)} from HIP events recorded on the ctx stream."""
         p = _lib.Profile()
         check(self._L.vs_profile_read(self.h, C.byref(p), int(reset)))
-        names = ["prepare_queries", "search", "rerank", "resort", "search_fallback"]
+        names = ["prepare_queries", "search", "rerank", "resort", "search_fallback", "scan"]
         return {n: (float(p.ms[k]), int(p.launches[k])) for k, n in enumerate(names)}
 
     def alloc(self, nbytes):

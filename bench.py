@@ -38,11 +38,13 @@ class _DevArr:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--n", type=int, default=1_000_000, help="corpus size (BASELINE configs: 1M / 10M / 50M)")
     ap.add_argument("--dim", type=int, default=768)
-    ap.add_argument("--nq", type=int, default=16384, help="queries per step per GPU")
+    ap.add_argument("--nq", type=int, default=131072, help="queries per step per GPU (scans of one launch; the kernel has a serial "
+                    "tail of a few ms per launch, so large batches amortise it)")
+    ap.add_argument("--scan-nq", type=int, default=64, help="queries of the flat SBQ scan (K5) roofline measurement, 0 = skip")
     ap.add_argument("--distance", default="l2", choices=["l2", "cosine", "ip"])
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--recall-target", type=float, default=0.99)
@@ -214,10 +216,13 @@ def main():
     K = args.steps
     qps = world * nq * K / elapsed
 
-    # ---- roofline of the dominant kernel (k_search): algorithmic bytes = visits*4R + d_quantized*8W ---------------
+    # ---- roofline of the dominant kernel (k_search_fast): algorithmic bytes = visits*4R + d_quantized*8W of the scans
+    # it completed (the few scans handed to the general kernel are accounted to "search_fallback") -------------------
     s_ms, s_n = prof["search"]
+    f_ms, f_n = prof["search_fallback"]
     r_ms, r_n = prof["rerank"]
-    alg_bytes_search = tot["visited_nodes"] * 4 * R + tot["quantized_distance_comparisons"] * 8 * W
+    fb_bytes = tot.get("fallback_visited_nodes", 0) * 4 * R + tot.get("fallback_quantized_distance_comparisons", 0) * 8 * W
+    alg_bytes_search = tot["visited_nodes"] * 4 * R + tot["quantized_distance_comparisons"] * 8 * W - fb_bytes
     alg_bytes_rerank = tot["full_distance_comparisons"] * 4 * dim
     per_launch = alg_bytes_search / max(s_n, 1)
     avg_ms = s_ms / max(s_n, 1)
@@ -231,12 +236,45 @@ def main():
                 traffic = pj.get("hbm_bytes_per_launch")
         except Exception:
             pass
-    roofline = {"bound": "hbm", "kernel": "k_search", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
+    roofline = {"bound": "hbm", "kernel": "k_search_fast", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(achieved / 8000.0, 5), "traffic": traffic,
-                "alg_bytes_per_launch": int(per_launch), "avg_kernel_ms": round(avg_ms, 4), "launches": s_n}
-    kernels = {name: {"ms_total": round(ms, 3), "launches": cnt} for name, (ms, cnt) in prof.items()}
+                "alg_bytes_per_launch": int(per_launch), "avg_kernel_ms": round(avg_ms, 4), "launches": s_n,
+                "alg_bytes_per_query": round(alg_bytes_search / max(tot.get("queries", 1) - tot.get("fallback_scans", 0), 1), 1)}
+    kernels = {name: {"ms_total": round(ms, 3), "launches": cnt} for name, (ms, cnt) in prof.items() if cnt}
     if r_ms > 0:
         kernels["rerank"]["achieved_GBps"] = round(alg_bytes_rerank / (r_ms * 1e-3) / 1e9, 2)
+    if f_n and f_ms > 0:
+        kernels["search_fallback"]["scans"] = tot.get("fallback_scans", 0)
+
+    # ---- K5: the flat SBQ scan (same codes, streamed instead of gathered): the bandwidth-bound form of the candidate scan
+    scan_roofline = None
+    if args.scan_nq > 0 and rank == 0:
+        try:
+            os.environ.setdefault("VS_SCAN_Q", "4")
+            qt = int(os.environ["VS_SCAN_Q"])
+            qh_s = ctx.download(qbuf[0], np.empty((nq, dim), np.float32))[:args.scan_nq]
+            if dt == P.VS_COSINE:
+                qh_s = qh_s / np.linalg.norm(qh_s, axis=1, keepdims=True)
+            qcodes = ix.quantize(qh_s)
+            ix.scan_topk(qcodes, k)  # warm-up
+            ctx.profile_enable(True)
+            ctx.profile_read(reset=True)
+            for _ in range(5):
+                ix.scan_topk(qcodes, k)
+            sp = ctx.profile_read(reset=True)
+            ctx.profile_enable(False)
+            sc_ms = sp["scan"][0] / max(sp["scan"][1], 1)
+            tiles = (args.scan_nq + qt - 1) // qt
+            cs = W + (W & 1)
+            sc_bytes = tiles * n * 8 * cs
+            sc_gbps = sc_bytes / (sc_ms * 1e-3) / 1e9
+            scan_roofline = {"bound": "hbm", "kernel": "k_scan_topk", "achieved": round(sc_gbps, 1), "peak": 8000.0,
+                             "unit": "GB/s", "frac": round(sc_gbps / 8000.0, 4), "traffic": None,
+                             "alg_bytes_per_launch": int(sc_bytes), "avg_kernel_ms": round(sc_ms, 4),
+                             "queries": args.scan_nq, "queries_per_tile": qt, "tiles": tiles,
+                             "note": "codes streamed once per tile of queries; exact (hamming, id) top-k"}
+        except Exception as e:
+            scan_roofline = {"error": repr(e)}
 
     result = {
         "metric": f"QPS at recall@{k}>={args.recall_target:g}",
@@ -259,6 +297,7 @@ def main():
         "recall_target_met": bool(recall >= args.recall_target),
         "recall_sweep": sweep_log,
         "roofline": roofline,
+        "sbq_scan_roofline": scan_roofline,
         "kernels": kernels,
         "work_per_query": {kk: round(vv / max(tot.get("queries", 1), 1), 2) for kk, vv in tot.items() if kk != "queries"},
         "setup_s": setup,

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--reps", type=int, default=4)
     ap.add_argument("--configs", default="VS_FAST=1")
     ap.add_argument("--kind", default="clustered", choices=["clustered", "hard"])
+    ap.add_argument("--scan", type=int, default=0, help="also run the flat SBQ scan (K5) with this many queries (PMC calibration)")
     args = ap.parse_args()
     import numpy as np
     import torch  # noqa: F401
@@ -78,6 +79,16 @@ def main():
               f"{prof['rerank'][0] / prof['rerank'][1]:.3f} ms  wall {wall * 1e3:8.3f} ms "
               f"-> {nq / wall:10.0f} QPS  {bytes_ / (ms + fb) / 1e6:7.1f} GB/s alg  visits/q {st['visited_nodes'] / nq:.1f} "
               f"dq/q {st['quantized_distance_comparisons'] / nq:.1f}  same_ids={same}", flush=True)
+    if args.scan:
+        os.environ.setdefault("VS_SCAN_Q", "4")
+        rng = np.random.default_rng(1)
+        qs = rng.standard_normal((args.scan, args.dim)).astype(np.float32)
+        qs /= np.linalg.norm(qs, axis=1, keepdims=True)
+        qcodes = ix.quantize(qs)
+        for _ in range(3):
+            ix.scan_topk(qcodes, k)
+        qt = int(os.environ["VS_SCAN_Q"])
+        print(f"scan: nq={args.scan} tiles={(args.scan + qt - 1) // qt} bytes_per_launch={(args.scan + qt - 1) // qt * args.n * 8 * (W + (W & 1))}", flush=True)
     ix.close()
     ctx.close()
 

@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Turns the two rocprofv3 --pmc passes of scripts/pmc_traffic.sh into HBM bytes per launch for k_search_fast (written to
+profiles/pmc_search_traffic.json, which bench.py reports as roofline.traffic when the configuration matches).
+
+FETCH_SIZE / WRITE_SIZE are in KiB.  On gfx950 FETCH_SIZE under-reports wide coalesced reads (MI355X_MICROARCH.md, HBM
+section), so the read side is calibrated on k_scan_topk of the same process, whose traffic is known exactly
+(tiles * n * 8 * code_stride bytes; 16-B-per-lane loads like the search kernel's code gathers)."""
+import argparse
+import csv
+import json
+import os
+import re
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def per_kernel(path, counter):
+    acc = defaultdict(list)
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if r["Counter_Name"] != counter:
+                continue
+            name = re.sub(r"^void\s+", "", r["Kernel_Name"])
+            m = re.match(r"([A-Za-z0-9_]+)", name)
+            acc[m.group(1) if m else name].append(float(r["Counter_Value"]))
+    return acc
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, required=True)
+    ap.add_argument("--nq", type=int, required=True)
+    ap.add_argument("--L", type=int, required=True)
+    ap.add_argument("--rescore", type=int, required=True)
+    ap.add_argument("--dir", default=os.path.join(ROOT, "gpurun_out"))
+    args = ap.parse_args()
+    fetch = per_kernel(os.path.join(args.dir, "pmc_fetch", "p_counter_collection.csv"), "FETCH_SIZE")
+    write = per_kernel(os.path.join(args.dir, "pmc_write", "p_counter_collection.csv"), "WRITE_SIZE")
+    log = open(os.path.join(args.dir, "pmc_fetch.log")).read()
+    m = re.search(r"scan: nq=(\d+) tiles=(\d+) bytes_per_launch=(\d+)", log)
+    scan_bytes = int(m.group(3))
+    scan_fetch = sum(fetch["k_scan_topk"][-3:]) / len(fetch["k_scan_topk"][-3:]) * 1024
+    cal = scan_bytes / scan_fetch
+    out = {"n": args.n, "nq": args.nq, "L": args.L, "rescore": args.rescore,
+           "fetch_calibration": {"kernel": "k_scan_topk", "known_bytes": scan_bytes, "FETCH_SIZE_bytes": round(scan_fetch),
+                                 "factor": round(cal, 4)}}
+    for kern in ("k_search_fast", "k_rerank"):
+        if kern not in fetch:
+            continue
+        f = fetch[kern][-2:]
+        w = write.get(kern, [0.0])[-2:]
+        fb = sum(f) / len(f) * 1024
+        wb = sum(w) / len(w) * 1024
+        out[kern] = {"FETCH_SIZE_bytes": round(fb), "WRITE_SIZE_bytes": round(wb), "read_bytes_calibrated": round(fb * cal),
+                     "hbm_bytes_per_launch": round(fb * cal + wb)}
+    out["hbm_bytes_per_launch"] = out.get("k_search_fast", {}).get("hbm_bytes_per_launch")
+    os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+    dst = os.path.join(args.dir, "pmc_search_traffic.json")
+    json.dump(out, open(dst, "w"), indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()

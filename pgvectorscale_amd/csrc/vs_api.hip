@@ -590,6 +590,7 @@ struct Caps {
     uint32_t hl, hcap, vcap, lh, hashcap, g0;  // general kernel (vs_search.hip)
     // fast kernel (vs_search_fast.hip); f_lh == 0 disables it
     uint32_t f_hl, f_hcap, f_gstride, f_lh, f_gcap, f_sb, f_vr, f_vcap;
+    double f_pool_frac;  // share of the scans expected to need a global dedup-overflow table
 };
 
 static uint32_t env_u32(const char* name, uint32_t dflt) {
@@ -612,9 +613,13 @@ static Caps initial_caps(const vs_index* ix, uint32_t L, uint32_t M) {
     c.hashcap = std::max<uint32_t>(next_pow2_u32(std::min<uint64_t>(2ull * pushes, 1u << 23)), c.g0);
     // fast kernel: everything in LDS, sized for the typical scan (about 8-10 new candidates per visit, 1.1 L + M
     // visits); the rare scan that outgrows it is re-run by the general kernel.
+    // (about 8-10 new candidates per visit at 1M nodes, 1.1 L + M visits); bigger graphs overlap less, so the table is
+    // sized from what the previous batches with the same (L, M) actually inserted once that is known.
     const uint64_t typ_visits = (uint64_t)L + L / 4 + M + 16;
-    const uint64_t typ_ins = typ_visits * std::min<uint64_t>(ix->d.num_neighbors, 11);
-    c.f_lh = env_u32("VS_F_LH", (uint32_t)std::min<uint64_t>(round_up_u32((uint32_t)std::min<uint64_t>(typ_ins, 1u << 20), 64), 1u << 15));
+    uint64_t typ_ins = typ_visits * std::min<uint64_t>(ix->d.num_neighbors, 16);
+    if (ix->obs.valid && ix->obs.L == L && ix->obs.M == M) typ_ins = (uint64_t)(ix->obs.ins_mean * 1.75) + 96;
+    c.f_lh = env_u32("VS_F_LH", (uint32_t)std::min<uint64_t>(round_up_u32((uint32_t)std::min<uint64_t>(typ_ins, 1u << 20), 64), 8192));
+    c.f_pool_frac = (ix->obs.valid && ix->obs.L == L && ix->obs.M == M) ? std::min(1.0, 2.0 * ix->obs.ov_frac + 0.03) : 1.0;
     c.f_hl = env_u32("VS_F_HL", 1023);
     const uint32_t want_v = (uint32_t)std::min<uint64_t>((uint64_t)L + L / 2 + 32, 1u << 20);
     c.f_vr = env_u32("VS_F_VR", want_v <= 256 ? 4 : 0);
@@ -624,7 +629,7 @@ static Caps initial_caps(const vs_index* ix, uint32_t L, uint32_t M) {
         c.f_lh = round_up_u32(std::max<uint32_t>(c.f_lh, 256), 4);
         c.f_hl = std::max<uint32_t>(next_pow2_u32(c.f_hl + 1), 64) - 1;
         // overflow table: room for every candidate the worst scan could insert beyond the LDS table
-        c.f_gcap = next_pow2_u32(std::min<uint64_t>(std::max<uint64_t>(pushes, 1024), 1u << 22));
+        c.f_gcap = next_pow2_u32(std::min<uint64_t>(std::max<uint64_t>(std::min<uint64_t>(pushes, 4 * typ_ins), 1024), 1u << 22));
         c.f_sb = 0;
         while ((1ull << c.f_sb) < (uint64_t)c.f_lh + c.f_gcap) c.f_sb++;
         c.f_hcap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(pushes, c.f_hl), 1u << 22);
@@ -640,7 +645,9 @@ static Caps initial_caps(const vs_index* ix, uint32_t L, uint32_t M) {
     return c;
 }
 
-static uint32_t fast_pool_slots(uint32_t nq) { return std::max<uint32_t>(256, nq / 4); }
+static uint32_t fast_pool_slots(uint32_t nq, double frac) {
+    return (uint32_t)std::min<uint64_t>(nq, std::max<uint64_t>(256, (uint64_t)(frac * nq) + 1));
+}
 static uint32_t general_pool_slots(uint32_t nq) { return std::max<uint32_t>(64, nq / 64); }
 
 static bool grow_caps(Caps& c, uint32_t ovf) {
@@ -687,7 +694,8 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
     }
     bool fast_done = false;
     if (caps.f_lh) {
-        const uint32_t fslots = fast_pool_slots(nq);
+        const uint32_t fslots = fast_pool_slots(nq, caps.f_pool_frac);
+        ix->last_ins_limit = caps.f_lh - caps.f_lh / 8 - 64;
         VS_TRY(devbuf_reserve(c, w.heap_g4, std::max<size_t>((size_t)nq * caps.f_gstride * 4, 16)));
         VS_TRY(devbuf_reserve(c, w.ghash4, (size_t)fslots * caps.f_gcap * 4));
         VS_TRY(devbuf_reserve(c, w.pool_ctr, 64));
@@ -735,7 +743,7 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
             VS_HIP(hipStreamSynchronize(c->stream));
             uint32_t hist[16] = {0};
             for (uint32_t v : stv) hist[v & 15]++;
-            fprintf(stderr, "[VS_DEBUG_STATUS] fast kernel: pool claims=%u of %u;", ctr[0], fast_pool_slots(nq));
+            fprintf(stderr, "[VS_DEBUG_STATUS] fast kernel: pool claims=%u of %u;", ctr[0], fast_pool_slots(nq, caps.f_pool_frac));
             for (int i = 0; i < 16; ++i)
                 if (hist[i]) fprintf(stderr, " status[%d]=%u", i, hist[i]);
             fprintf(stderr, "\n");
@@ -812,7 +820,8 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
     return VS_OK;
 }
 
-static int collect_stats(vs_index* ix, uint32_t nq, uint32_t M, uint32_t rescore, bool stream_only, vs_stats* st) {
+static int collect_stats(vs_index* ix, uint32_t nq, uint32_t M, uint32_t rescore, bool stream_only, vs_stats* st,
+                         uint32_t obs_L = 0) {
     if (!st) return VS_OK;
     SearchWorkspace& w = ix->ws;
     std::vector<uint32_t> hs((size_t)nq * ST_N), cnt(nq), fb(nq, 0);
@@ -833,6 +842,29 @@ static int collect_stats(vs_index* ix, uint32_t nq, uint32_t M, uint32_t rescore
         fprintf(stderr, "[VS_PHASE] shader clocks per visit:");
         for (int k = 0; k < 7; ++k) fprintf(stderr, " %s=%.0f", names[k], sum[k] / (double)std::max<uint64_t>(visits, 1));
         fprintf(stderr, "\n");
+    }
+    if (w.fb_valid && ix->last_ins_limit) {  // what this batch needed: sizes the next launch with the same (L, M)
+        double sum = 0, mx = 0;
+        uint32_t cnt_fast = 0, ov = 0;
+        for (uint32_t q = 0; q < nq; ++q) {
+            if (fb[q]) { ov++; continue; }
+            const double v = hs[(size_t)q * ST_N + 7];
+            sum += v;
+            mx = std::max(mx, v);
+            cnt_fast++;
+            ov += v > ix->last_ins_limit;
+        }
+        if (cnt_fast) {
+            ScanObs& o = ix->obs;
+            const bool same = o.valid && o.L == obs_L && o.M == M;
+            const double a = same ? 0.5 : 1.0;  // exponential average over batches
+            o.ins_mean = (1 - a) * o.ins_mean + a * (sum / cnt_fast);
+            o.ins_max = same ? std::max(o.ins_max, mx) : mx;
+            o.ov_frac = (1 - a) * (same ? o.ov_frac : 0.0) + a * ((double)ov / nq);
+            o.L = obs_L;
+            o.M = M;
+            o.valid = true;
+        }
     }
     for (uint32_t q = 0; q < nq; ++q) {
         st->queries++;
@@ -861,7 +893,7 @@ static uint32_t stream_len(uint32_t rescore, uint32_t k) { return rescore > 0 ? 
 static uint32_t chunk_queries(const vs_index* ix, const Caps& c, uint32_t M, uint32_t nq) {
     const size_t general = (size_t)c.hashcap * 4 + (size_t)(c.hcap > c.hl ? c.hcap - c.hl : 0) * 8;
     size_t per_q = (size_t)M * 12 + ix->vec_stride * 4ull + ix->code_stride * 8ull + 256;
-    if (c.f_lh) per_q += (size_t)c.f_gcap * 4 / 8 + (size_t)c.f_gstride * 4 + general / 64 + 64;
+    if (c.f_lh) per_q += (size_t)((double)c.f_gcap * 4 * c.f_pool_frac) + (size_t)c.f_gstride * 4 + general / 64 + 64;
     else per_q += general;
     size_t budget = 24ull << 30;
     uint32_t m = (uint32_t)std::max<size_t>(1, std::min<size_t>(budget / per_q, 1u << 20));
@@ -925,7 +957,7 @@ static int search_host(vs_index* ix, const float* queries, const int16_t* qlabel
         // label CSR offsets are absolute into d_labels_all, so a chunk just offsets the off pointer
         VS_TRY(run_search_chunk(ix, bp, (const float*)w.raw_q.p, d_labels_all, d_off_all ? d_off_all + q0 : nullptr,
                                 (uint32_t*)w.out_ids.p, (uint64_t*)w.out_tids.p, (float*)w.out_dist.p, caps, true, stats));
-        VS_TRY(collect_stats(ix, cq, M, rescore, stream_only, stats));
+        VS_TRY(collect_stats(ix, cq, M, rescore, stream_only, stats, L));
         if (stream_only) {
             VS_TRY(vs_dev_download(c, out_ids + (size_t)q0 * k, w.stream_ids.p, (size_t)cq * k * 4));
             if (out_ham) VS_TRY(vs_dev_download(c, out_ham + (size_t)q0 * k, w.stream_ham.p, (size_t)cq * k * 4));
@@ -971,6 +1003,7 @@ extern "C" int vs_search_batch_dev(vs_index* ix, const float* d_queries, const i
     w.pending = true;
     w.pend_nq = nq;
     w.pend_m = M;
+    w.pend_L = L;
     ix->last_stats = vs_stats{};
     ix->last_stats.retries = rescore;  // stash (rescore) for finish(); overwritten there
     return VS_OK;
@@ -1003,7 +1036,7 @@ extern "C" int vs_search_batch_dev_finish(vs_index* ix, vs_stats* stats) {
         return VS_ERR_CAPACITY;
     }
     vs_stats st{};
-    VS_TRY(collect_stats(ix, nq, M, rescore, false, &st));
+    VS_TRY(collect_stats(ix, nq, M, rescore, false, &st, w.pend_L));
     ix->last_stats = st;
     if (stats) *stats = st;
     return VS_OK;

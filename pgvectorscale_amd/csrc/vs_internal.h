@@ -78,6 +78,15 @@ struct SearchWorkspace {
     bool pending = false;
     uint32_t pend_nq = 0;
     uint32_t pend_m = 0;
+    uint32_t pend_L = 0;
+};
+
+// what the last batches needed (per search_list_size / stream length): sizes the LDS dedup table of the next launch
+struct ScanObs {
+    bool valid = false;
+    uint32_t L = 0, M = 0;
+    double ins_mean = 0, ins_max = 0;  // inserted ids per scan
+    double ov_frac = 1.0;              // fraction of scans that outgrew the LDS table
 };
 
 struct vs_index {
@@ -100,6 +109,8 @@ struct vs_index {
     int16_t* ls_labels = nullptr;
     uint32_t* ls_nodes = nullptr;
     SearchWorkspace ws;
+    ScanObs obs;
+    uint32_t last_ins_limit = 0;  // LDS-table admission limit of the last fast launch
     vs_stats last_stats{};
 };
 

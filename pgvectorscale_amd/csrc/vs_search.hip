@@ -134,7 +134,10 @@ __global__ __launch_bounds__(WAVE) void k_search(SearchArgs a) {
         if (threadIdx.x == 0) wslot = atomicAdd(s.pool_counter, 1u);
         wslot = rfl(wslot);
         if (wslot >= s.pool_slots) {  // pool exhausted: the host re-launches the scans that are still marked
-            if (threadIdx.x == 0) s.status[q] = OVF_POOL;
+            if (threadIdx.x == 0) {
+                s.status[q] = OVF_POOL;
+                s.out_cnt[q] = 0;  // an empty stream: the rerank / resort kernels behind this launch stay in bounds
+            }
             return;
         }
     }
@@ -450,7 +453,7 @@ __global__ __launch_bounds__(WAVE) void k_search(SearchArgs a) {
         s.out_ham[(size_t)q * s.M + i] = 0xFFFFFFFFu;
     }
     if (lane == 0) {
-        s.out_cnt[q] = emitted;
+        s.out_cnt[q] = status ? 0 : emitted;  // a failed scan publishes an empty stream (it is re-run or reported)
         s.status[q] = status;
         uint32_t* st = s.stats + (size_t)q * ST_N;
         st[ST_VISITS] = st_visits;

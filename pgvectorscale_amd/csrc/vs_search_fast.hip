@@ -767,8 +767,8 @@ __global__ __launch_bounds__(WAVE) void k_search_fast(FastArgs a) {
     }
     if (lane == 0) {
         s.status[q] = status;
+        s.out_cnt[q] = status ? 0 : emitted;  // a failed scan publishes an empty stream until the fallback re-runs it
         if (status == 0) {
-            s.out_cnt[q] = emitted;
             uint32_t* st = s.stats + (size_t)q * ST_N;
             st[ST_VISITS] = st_visits;
             st[ST_CAND] = st_cand;

@@ -301,6 +301,8 @@ extern "C" void vs_index_free(vs_index* ix) {
                       &w.stream_ham, &w.stream_cnt, &w.stats, &w.status, &w.rr_dist, &w.out_ids, &w.out_tids,
                       &w.out_dist, &w.resort_heap, &w.raw_q, &w.misc};
     for (DevBuf* b : bufs) devbuf_free(*b);
+    free(w.pend_blob);
+    w.pend_blob = nullptr;
     delete ix;
 }
 
@@ -620,10 +622,17 @@ static Caps initial_caps(const vs_index* ix, uint32_t L, uint32_t M) {
     if (ix->obs.valid && ix->obs.L == L && ix->obs.M == M) typ_ins = (uint64_t)(ix->obs.ins_mean * 1.75) + 96;
     c.f_lh = env_u32("VS_F_LH", (uint32_t)std::min<uint64_t>(round_up_u32((uint32_t)std::min<uint64_t>(typ_ins, 1u << 20), 64), 8192));
     c.f_pool_frac = (ix->obs.valid && ix->obs.L == L && ix->obs.M == M) ? std::min(1.0, 2.0 * ix->obs.ov_frac + 0.03) : 1.0;
-    c.f_hl = env_u32("VS_F_HL", 1023);
+    // LDS heap levels: spilling the bottom level to global memory costs every pop / push an L2 round trip, so the heap
+    // gets LDS for about 3/4 of the ids a scan inserts (its typical final size) once that is known
+    uint32_t hl_auto = 1023;
+    if (ix->obs.valid && ix->obs.L == L && ix->obs.M == M) {
+        const double want = 0.75 * ix->obs.ins_mean;
+        hl_auto = want > 2047 ? 4095 : (want > 1023 ? 2047 : 1023);
+    }
+    c.f_hl = env_u32("VS_F_HL", hl_auto);
     const uint32_t want_v = (uint32_t)std::min<uint64_t>((uint64_t)L + L / 2 + 32, 1u << 20);
-    c.f_vr = env_u32("VS_F_VR", want_v <= 256 ? 4 : 0);
-    c.f_vcap = c.f_vr ? 256 : std::max<uint32_t>(next_pow2_u32(env_u32("VS_F_VCAP", want_v)), 64);
+    c.f_vr = env_u32("VS_F_VR", want_v <= 512 ? 8 : 0);
+    c.f_vcap = c.f_vr ? 512 : std::max<uint32_t>(next_pow2_u32(env_u32("VS_F_VCAP", want_v)), 64);
     if (!env_u32("VS_FAST", 1)) c.f_lh = 0;
     if (c.f_lh) {
         c.f_lh = round_up_u32(std::max<uint32_t>(c.f_lh, 256), 4);
@@ -673,6 +682,97 @@ struct BatchPlan {
     uint32_t nq, L, rescore, k, M;
     bool stream_only;  // vs_stream_batch: no rerank
 };
+
+// rerank + rescore window over the streams the search kernels left in the workspace
+struct PendingBatch {
+    BatchPlan bp;
+    Caps caps;
+    const int16_t* d_qlabels;
+    const uint32_t* d_qlabel_off;
+    uint32_t* d_out_ids;
+    uint64_t* d_out_tids;
+    float* d_out_dist;
+};
+
+static int run_post_search(vs_index* ix, const BatchPlan& bp, uint32_t* d_out_ids, uint64_t* d_out_tids, float* d_out_dist) {
+    vs_ctx* c = ix->ctx;
+    SearchWorkspace& w = ix->ws;
+    const uint32_t nq = bp.nq, M = bp.M;
+    if (bp.stream_only) return VS_OK;
+    if (bp.rescore > 0) {
+        VS_REQUIRE(ix->vecs, "diskann.query_rescore > 0 needs the heap vector column on the device");
+        VS_TRY(devbuf_reserve(c, w.rr_dist, (size_t)nq * M * 4));
+        VS_TRY(devbuf_reserve(c, w.resort_heap, (size_t)nq * bp.rescore * 8));
+        hipEvent_t ev = prof_begin(c);
+        VS_TRY(launch_rerank(ix, (const float*)w.q_full.p, (const uint32_t*)w.stream_ids.p, nullptr,
+                             (const uint32_t*)w.stream_cnt.p, M, nq, (float*)w.rr_dist.p));
+        prof_end(c, PK_RERANK, ev);
+    }
+    hipEvent_t ev = prof_begin(c);
+    VS_TRY(launch_resort(ix, nq, M, bp.rescore, bp.k, (const uint32_t*)w.stream_ids.p, (const uint32_t*)w.stream_cnt.p,
+                         bp.rescore ? (const float*)w.rr_dist.p : nullptr, (uint64_t*)w.resort_heap.p, d_out_ids,
+                         d_out_tids, d_out_dist));
+    prof_end(c, PK_RESORT, ev);
+    return VS_OK;
+}
+
+// (re)runs the general kernel over the scans whose status is non-zero until none is left; synchronises the stream
+static int retry_failed_scans(vs_index* ix, const BatchPlan& bp, const int16_t* d_qlabels, const uint32_t* d_qlabel_off,
+                              Caps& caps, vs_stats* st) {
+    vs_ctx* c = ix->ctx;
+    SearchWorkspace& w = ix->ws;
+    const uint32_t nq = bp.nq, M = bp.M;
+    std::vector<uint32_t> status(nq);
+    for (int attempt = 0;; ++attempt) {
+        VS_HIP(hipMemcpyAsync(status.data(), w.status.p, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
+        VS_HIP(hipStreamSynchronize(c->stream));
+        uint32_t ovf = 0, nbad = 0;
+        for (uint32_t v : status) {
+            ovf |= v;
+            nbad += v != 0;
+        }
+        if (!ovf) return VS_OK;
+        if (st) st->retries++;
+        if (attempt >= 8 || !grow_caps(caps, ovf)) {
+            vs_set_error("search structures overflowed in %u of %u scans (flags 0x%x) at hcap=%u vcap=%u hashcap=%u", nbad, nq,
+                         ovf, caps.hcap, caps.vcap, caps.hashcap);
+            return VS_ERR_CAPACITY;
+        }
+        const size_t hg = caps.hcap > caps.hl ? caps.hcap - caps.hl : 0;
+        const uint32_t gslots = std::min<uint32_t>(nq, std::max<uint32_t>(general_pool_slots(nq), nbad));
+        VS_TRY(devbuf_reserve(c, w.hash, (size_t)gslots * caps.hashcap * 4));
+        VS_TRY(devbuf_reserve(c, w.heap_g, std::max<size_t>((size_t)gslots * hg * 8, 16)));
+        VS_TRY(devbuf_reserve(c, w.pool_ctr, 64));
+        VS_HIP(hipMemsetAsync((char*)w.pool_ctr.p + 32, 0, 4, c->stream));
+        SearchLaunch s;
+        s.nq = nq;
+        s.L = bp.L;
+        s.M = M;
+        s.hl = caps.hl;
+        s.hcap = caps.hcap;
+        s.vcap = caps.vcap;
+        s.lh = caps.lh;
+        s.hashcap = caps.hashcap;
+        s.g0 = caps.g0;
+        s.qcodes = (const uint64_t*)w.qcodes.p;
+        s.qlabels = d_qlabels;
+        s.qlabel_off = d_qlabel_off;
+        s.heap_g = (uint64_t*)w.heap_g.p;
+        s.hash = (uint32_t*)w.hash.p;
+        s.out_ids = (uint32_t*)w.stream_ids.p;
+        s.out_ham = (uint32_t*)w.stream_ham.p;
+        s.out_cnt = (uint32_t*)w.stream_cnt.p;
+        s.stats = (uint32_t*)w.stats.p;
+        s.status = (uint32_t*)w.status.p;
+        s.only_failed = 1;
+        s.fb_flag = w.fb_valid ? (uint32_t*)w.fb_flag.p : nullptr;
+        s.pool_counter = (uint32_t*)((char*)w.pool_ctr.p + 32);
+        s.pool_slots = gslots;
+        hipEvent_t ev = prof_begin(c);
+        VS_TRY(launch_search(ix, s));
+        prof_end(c, PK_SEARCH_FB, ev);
+    }
+}
 
 static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_raw_q, const int16_t* d_qlabels,
                             const uint32_t* d_qlabel_off, uint32_t* d_out_ids, uint64_t* d_out_tids, float* d_out_dist,
@@ -788,36 +888,10 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
             VS_TRY(launch_search(ix, s));
             prof_end(c, fast_done ? PK_SEARCH_FB : PK_SEARCH, ev);
         }
-        if (!check_now) break;
-        std::vector<uint32_t> status(nq);
-        VS_HIP(hipMemcpyAsync(status.data(), w.status.p, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
-        VS_HIP(hipStreamSynchronize(c->stream));
-        uint32_t ovf = 0;
-        for (uint32_t v : status) ovf |= v;
-        if (!ovf) break;
-        if (st) st->retries++;
-        if (attempt >= 6 || !grow_caps(caps, ovf)) {
-            vs_set_error("search structures overflowed (flags 0x%x) at hcap=%u vcap=%u hashcap=%u", ovf, caps.hcap,
-                         caps.vcap, caps.hashcap);
-            return VS_ERR_CAPACITY;
-        }
+        break;
     }
-    if (bp.stream_only) return VS_OK;
-    if (bp.rescore > 0) {
-        VS_REQUIRE(ix->vecs, "diskann.query_rescore > 0 needs the heap vector column on the device");
-        VS_TRY(devbuf_reserve(c, w.rr_dist, (size_t)nq * M * 4));
-        VS_TRY(devbuf_reserve(c, w.resort_heap, (size_t)nq * bp.rescore * 8));
-        hipEvent_t ev = prof_begin(c);
-        VS_TRY(launch_rerank(ix, (const float*)w.q_full.p, (const uint32_t*)w.stream_ids.p, nullptr,
-                             (const uint32_t*)w.stream_cnt.p, M, nq, (float*)w.rr_dist.p));
-        prof_end(c, PK_RERANK, ev);
-    }
-    hipEvent_t ev = prof_begin(c);
-    VS_TRY(launch_resort(ix, nq, M, bp.rescore, bp.k, (const uint32_t*)w.stream_ids.p, (const uint32_t*)w.stream_cnt.p,
-                         bp.rescore ? (const float*)w.rr_dist.p : nullptr, (uint64_t*)w.resort_heap.p, d_out_ids,
-                         d_out_tids, d_out_dist));
-    prof_end(c, PK_RESORT, ev);
-    return VS_OK;
+    if (check_now) VS_TRY(retry_failed_scans(ix, bp, d_qlabels, d_qlabel_off, caps, st));
+    return run_post_search(ix, bp, d_out_ids, d_out_tids, d_out_dist);
 }
 
 static int collect_stats(vs_index* ix, uint32_t nq, uint32_t M, uint32_t rescore, bool stream_only, vs_stats* st,
@@ -895,7 +969,16 @@ static uint32_t chunk_queries(const vs_index* ix, const Caps& c, uint32_t M, uin
     size_t per_q = (size_t)M * 12 + ix->vec_stride * 4ull + ix->code_stride * 8ull + 256;
     if (c.f_lh) per_q += (size_t)((double)c.f_gcap * 4 * c.f_pool_frac) + (size_t)c.f_gstride * 4 + general / 64 + 64;
     else per_q += general;
+    // workspace budget: half of what is free on the device right now (plus what the workspace already holds), <= 64 GiB
     size_t budget = 24ull << 30;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+        const SearchWorkspace& w = ix->ws;
+        const size_t held = w.hash.bytes + w.heap_g.bytes + w.heap_g4.bytes + w.ghash4.bytes + w.stream_ids.bytes +
+                            w.stream_ham.bytes + w.rr_dist.bytes + w.q_full.bytes + w.qcodes.bytes;
+        budget = std::min<size_t>((free_b + held) / 2, 64ull << 30);
+        budget = std::max<size_t>(budget, 1ull << 30);
+    }
     uint32_t m = (uint32_t)std::max<size_t>(1, std::min<size_t>(budget / per_q, 1u << 20));
     return std::min(m, nq);
 }
@@ -1004,8 +1087,14 @@ extern "C" int vs_search_batch_dev(vs_index* ix, const float* d_queries, const i
     w.pend_nq = nq;
     w.pend_m = M;
     w.pend_L = L;
+    {
+        const PendingBatch pbv{bp, caps, d_qlabels, d_qlabel_off, d_out_ids, d_out_tids, d_out_dist};
+        free(w.pend_blob);  // trivially copyable record
+        w.pend_blob = malloc(sizeof(PendingBatch));
+        VS_REQUIRE(w.pend_blob, "out of host memory");
+        memcpy(w.pend_blob, &pbv, sizeof(pbv));
+    }
     ix->last_stats = vs_stats{};
-    ix->last_stats.retries = rescore;  // stash (rescore) for finish(); overwritten there
     return VS_OK;
 }
 
@@ -1018,25 +1107,23 @@ extern "C" int vs_search_batch_dev_finish(vs_index* ix, vs_stats* stats) {
     }
     w.pending = false;
     const uint32_t nq = w.pend_nq, M = w.pend_m;
-    const uint32_t rescore = (uint32_t)ix->last_stats.retries;
+    VS_REQUIRE(w.pend_blob, "vs_search_batch_dev_finish: no batch descriptor");
+    PendingBatch pb;
+    memcpy(&pb, w.pend_blob, sizeof(pb));
     std::vector<uint32_t> status(nq);
     VS_HIP(hipMemcpyAsync(status.data(), w.status.p, (size_t)nq * 4, hipMemcpyDeviceToHost, ix->ctx->stream));
     VS_HIP(hipStreamSynchronize(ix->ctx->stream));
-    uint32_t ovf = 0, nbad = 0;
-    for (uint32_t v : status) {
-        ovf |= v;
-        nbad += v != 0;
-    }
-    if (ovf) {
-        uint32_t ctr[16] = {0};
-        if (w.pool_ctr.p) (void)hipMemcpy(ctr, w.pool_ctr.p, 64, hipMemcpyDeviceToHost);
-        vs_set_error("vs_search_batch_dev: per-query structures overflowed in %u of %u scans (flags 0x%x; dedup-overflow "
-                     "tables claimed %u, fallback regions claimed %u); use vs_search_batch, which retries with larger "
-                     "capacities", nbad, nq, ovf, ctr[0], ctr[8]);
-        return VS_ERR_CAPACITY;
-    }
+    uint32_t ovf = 0;
+    for (uint32_t v : status) ovf |= v;
     vs_stats st{};
-    VS_TRY(collect_stats(ix, nq, M, rescore, false, &st, w.pend_L));
+    if (ovf) {
+        // some scans outgrew even the fallback pools of the asynchronous launch: re-run exactly those (synchronously,
+        // with growing capacities), then redo the rerank / rescore window so the outputs are complete
+        VS_TRY(retry_failed_scans(ix, pb.bp, pb.d_qlabels, pb.d_qlabel_off, pb.caps, &st));
+        VS_TRY(run_post_search(ix, pb.bp, pb.d_out_ids, pb.d_out_tids, pb.d_out_dist));
+        VS_HIP(hipStreamSynchronize(ix->ctx->stream));
+    }
+    VS_TRY(collect_stats(ix, nq, M, pb.bp.rescore, false, &st, w.pend_L));
     ix->last_stats = st;
     if (stats) *stats = st;
     return VS_OK;

@@ -79,6 +79,7 @@ struct SearchWorkspace {
     uint32_t pend_nq = 0;
     uint32_t pend_m = 0;
     uint32_t pend_L = 0;
+    void* pend_blob = nullptr;  // PendingBatch of vs_api.hip (plan + capacities + output pointers of the batch in flight)
 };
 
 // what the last batches needed (per search_list_size / stream length): sizes the LDS dedup table of the next launch
@@ -150,7 +151,7 @@ struct FastLaunch {
     uint32_t lh;       // slots of the LDS dedup table (multiple of 4)
     uint32_t gcap;     // slots of the per-scan global overflow dedup table (power of two), handles lh .. lh + gcap - 1
     uint32_t sb;       // bits of a slot handle inside a heap entry (lh + gcap <= 1 << sb)
-    uint32_t vr;       // visited list: 4 = four register pairs (256 entries), 0 = LDS ring of vcap entries
+    uint32_t vr;       // visited list: 8 = eight register pairs (512 entries), 0 = LDS ring of vcap entries
     uint32_t vcap;     // visited ring capacity (power of two; vr == 0)
     const uint64_t* qcodes;
     const int16_t* qlabels;

@@ -151,36 +151,42 @@ struct FastHeap {
             return;
         }
         const uint32_t r = (uint32_t)lane & 31u;
-        uint32_t p1 = len + 1;
-        uint32_t chain = l[p1 >> r];
-        for (uint32_t j = 0; j < c; ++j) {
-            const uint32_t elem = readlane_u32(entry, j);
-            const uint32_t p1n = p1 + 1;
-            const bool more = j + 1 < c;
-            uint32_t nxt = 0;
-            if (more) nxt = l[p1n >> r];  // valid for the ranks push j cannot touch (r < sh)
-            const bool cmp = (elem >> sb) < (chain >> sb);
-            const uint32_t bal = (uint32_t)__ballot(cmp) >> 1;  // bit r-1 <-> ancestor r; bit 31 is always clear
-            const uint32_t t = (uint32_t)__builtin_ctz(~bal);   // leading run of ancestors that move down
-            if ((uint32_t)lane <= t) {
-                const uint32_t dst = lane == 0 ? (p1 >> t) : (p1 >> (lane - 1));
-                l[dst] = lane == 0 ? elem : chain;
-            }
-            if (more) {
-                if ((p1n & (p1n - 1)) == 0) {  // the next leaf opens a new level: ranks do not line up, re-read
-                    wave_sync();
-                    chain = l[p1n >> r];
-                } else {
+        uint32_t j = 0;
+        while (j < c) {
+            uint32_t p1 = len + 1;
+            uint32_t chain = l[p1 >> r];
+            asm volatile("" : "+v"(chain));  // the chain is complete before the loop: no LDS wait at the loop head
+            bool boundary = false;
+            for (; j < c; ++j) {
+                const uint32_t elem = readlane_u32(entry, j);
+                const uint32_t p1n = p1 + 1;
+                const bool more = j + 1 < c;
+                uint32_t nxt = 0;
+                if (more) nxt = l[p1n >> r];  // valid for the ranks push j cannot touch (r < sh); in flight during the push
+                const bool cmp = (elem >> sb) < (chain >> sb);
+                const uint32_t bal = (uint32_t)__ballot(cmp) >> 1;  // bit r-1 <-> ancestor r; bit 31 is always clear
+                const uint32_t t = (uint32_t)__builtin_ctz(~bal);   // leading run of ancestors that move down
+                if ((uint32_t)lane <= t) {
+                    const uint32_t dst = lane == 0 ? (p1 >> t) : (p1 >> (lane - 1));
+                    l[dst] = lane == 0 ? elem : chain;
+                }
+                len += 1;
+                if (more) {
+                    if ((p1n & (p1n - 1)) == 0) {  // the next leaf opens a new level: ranks do not line up, restart
+                        boundary = true;
+                        ++j;
+                        break;
+                    }
                     const uint32_t sh = 32u - (uint32_t)__builtin_clz(p1 ^ p1n);
                     const uint32_t up = wave_shl1(chain, 0);  // rank r+1 value
                     const uint32_t patched = r < t ? up : (r == t ? elem : chain);
                     chain = r >= sh ? patched : nxt;
                 }
+                p1 = p1n;
             }
-            p1 = p1n;
+            wave_sync();
+            if (!boundary) break;
         }
-        wave_sync();
-        len += c;
     }
 
     // ---- BinaryHeap::pop: Vec::pop, swap with data[0], sift_down_to_bottom(0), sift_up.  (len > 0; the caller has
@@ -808,10 +814,10 @@ static int launch_fast_tt(vs_index* idx, const FastArgs& a, size_t lds) {
 template <int NCH>
 static int launch_fast_t(vs_index* idx, const FastArgs& a, size_t lds) {
     if (a.s.phase) {
-        VS_REQUIRE(NCH == 3 && a.s.vr == 4, "VS_PHASE diagnostics are built for 17..24-word codes / register visited list only");
-        return launch_fast_tt<3, 4, true>(idx, a, lds);
+        VS_REQUIRE(NCH == 3 && a.s.vr == 8, "VS_PHASE diagnostics are built for 17..24-word codes / register visited list only");
+        return launch_fast_tt<3, 8, true>(idx, a, lds);
     }
-    if (a.s.vr == 4) return launch_fast_tt<NCH, 4, false>(idx, a, lds);
+    if (a.s.vr == 8) return launch_fast_tt<NCH, 8, false>(idx, a, lds);
     return launch_fast_tt<NCH, 0, false>(idx, a, lds);
 }
 
@@ -835,8 +841,8 @@ int launch_search_fast(vs_index* idx, const FastLaunch& s) {
     const size_t lds = fast_lds_bytes(idx, s);
     VS_REQUIRE(lds <= 160 * 1024, "fast search state does not fit LDS (%zu B)", lds);
     VS_REQUIRE(((s.hl + 1) & s.hl) == 0 && s.hl >= 63, "fast search: hl must be 2^k - 1 >= 63");
-    VS_REQUIRE(s.vr == 4 || (s.vr == 0 && (s.vcap & (s.vcap - 1)) == 0 && s.vcap >= 64),
-               "fast search: visited list must be 4 registers or a power-of-two ring");
+    VS_REQUIRE(s.vr == 8 || (s.vr == 0 && (s.vcap & (s.vcap - 1)) == 0 && s.vcap >= 64),
+               "fast search: visited list must be 8 register pairs or a power-of-two ring");
     VS_REQUIRE(s.lh % 4 == 0 && s.lh >= 256 && (s.gcap & (s.gcap - 1)) == 0 && s.gcap >= 256 &&
                    (uint64_t)s.lh + s.gcap <= (1ull << s.sb) && s.hcap >= s.hl && s.gstride % 2 == 0 &&
                    s.gstride >= s.hcap - s.hl + 2,

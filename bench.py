@@ -4,7 +4,8 @@
 One "step" = one pass of the hot path (query preparation + SBQ quantisation, streaming beam search with Hamming
 scoring, f32 rerank, rescore window) over one batch of `--nq` synthetic queries that already sit in HBM.
 
-  python bench.py                       # 1 GPU, default workload (BASELINE.json configs[1]: 1M x 768, L2, SBQ 2 bit)
+  python bench.py                       # 1 GPU, default workload (BASELINE.json configs[2]: 10M x 768, cosine, SBQ 2 bit + rerank)
+  python bench.py --n 1000000 --distance l2      # configs[1];   --n 50000000 --distance l2: configs[3] on one GPU (~7 min)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W   # index replicated per GPU, queries sharded, RCCL all_gather of top-k
 
@@ -40,12 +41,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=1_000_000, help="corpus size (BASELINE configs: 1M / 10M / 50M)")
+    ap.add_argument("--n", type=int, default=10_000_000,
+                    help="corpus size (BASELINE configs: 1M / 10M / 50M); the default is configs[2], the largest configuration "
+                         "BASELINE.json assigns to one MI355X; 50M x 768 (configs[3]) also fits one GPU: --n 50000000")
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--nq", type=int, default=131072, help="queries per step per GPU (scans of one launch; the kernel has a serial "
                     "tail of a few ms per launch, so large batches amortise it)")
     ap.add_argument("--scan-nq", type=int, default=64, help="queries of the flat SBQ scan (K5) roofline measurement, 0 = skip")
-    ap.add_argument("--distance", default="l2", choices=["l2", "cosine", "ip"])
+    ap.add_argument("--distance", default="cosine", choices=["l2", "cosine", "ip"])
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--recall-target", type=float, default=0.99)
     ap.add_argument("--recall-queries", type=int, default=1000)

@@ -590,7 +590,8 @@ extern "C" int vs_rerank(vs_index* ix, const float* q_full, const uint32_t* ids,
 // ---------------------------------------------------------------------------------------------------------------
 struct Caps {
     uint32_t hl, hcap, vcap, lh, hashcap, g0;  // general kernel (vs_search.hip)
-    // fast kernel (vs_search_fast.hip); f_lh == 0 disables it
+    // fast kernel (vs_search_fast.hip); f_lh == 0: no LDS dedup table (every id in the global table)
+    bool f_on;
     uint32_t f_hl, f_hcap, f_gstride, f_lh, f_gcap, f_sb, f_vr, f_vcap;
     double f_pool_frac;  // share of the scans expected to need a global dedup-overflow table
 };
@@ -620,12 +621,19 @@ static Caps initial_caps(const vs_index* ix, uint32_t L, uint32_t M) {
     const uint64_t typ_visits = (uint64_t)L + L / 4 + M + 16;
     uint64_t typ_ins = typ_visits * std::min<uint64_t>(ix->d.num_neighbors, 16);
     if (ix->obs.valid && ix->obs.L == L && ix->obs.M == M) typ_ins = (uint64_t)(ix->obs.ins_mean * 1.75) + 96;
-    c.f_lh = env_u32("VS_F_LH", (uint32_t)std::min<uint64_t>(round_up_u32((uint32_t)std::min<uint64_t>(typ_ins, 1u << 20), 64), 8192));
-    c.f_pool_frac = (ix->obs.valid && ix->obs.L == L && ix->obs.M == M) ? std::min(1.0, 2.0 * ix->obs.ov_frac + 0.03) : 1.0;
+    // Two operating points.  Small scans (typ_ins up to ~3K ids): the whole dedup table lives in LDS (~10 KB / scan).
+    // Large scans: an LDS table for all ids would leave 3-4 scans per CU, and measurements (10M x 768: 148 ms vs 97 ms
+    // per 65536 scans) show that occupancy beats on-chip latency there, so the table shrinks to a 256-slot stub, ids go
+    // to the per-scan global table (L2 atomics) and the CU holds 16+ scans.
+    const bool lds_table = typ_ins <= env_u32("VS_F_LDS_MAX_INS", 3072);
+    c.f_lh = env_u32("VS_F_LH", lds_table ? (uint32_t)round_up_u32((uint32_t)typ_ins, 64) : 0u);
+    c.f_pool_frac = !lds_table ? 1.0
+                    : (ix->obs.valid && ix->obs.L == L && ix->obs.M == M) ? std::min(1.0, 2.0 * ix->obs.ov_frac + 0.03) : 1.0;
+    if (const char* e = getenv("VS_F_POOL")) c.f_pool_frac = std::min(1.0, std::max(0.01, atof(e)));
     // LDS heap levels: spilling the bottom level to global memory costs every pop / push an L2 round trip, so the heap
     // gets LDS for about 3/4 of the ids a scan inserts (its typical final size) once that is known
     uint32_t hl_auto = 1023;
-    if (ix->obs.valid && ix->obs.L == L && ix->obs.M == M) {
+    if (lds_table && ix->obs.valid && ix->obs.L == L && ix->obs.M == M) {
         const double want = 0.75 * ix->obs.ins_mean;
         hl_auto = want > 2047 ? 4095 : (want > 1023 ? 2047 : 1023);
     }
@@ -633,9 +641,9 @@ static Caps initial_caps(const vs_index* ix, uint32_t L, uint32_t M) {
     const uint32_t want_v = (uint32_t)std::min<uint64_t>((uint64_t)L + L / 2 + 32, 1u << 20);
     c.f_vr = env_u32("VS_F_VR", want_v <= 512 ? 8 : 0);
     c.f_vcap = c.f_vr ? 512 : std::max<uint32_t>(next_pow2_u32(env_u32("VS_F_VCAP", want_v)), 64);
-    if (!env_u32("VS_FAST", 1)) c.f_lh = 0;
-    if (c.f_lh) {
-        c.f_lh = round_up_u32(std::max<uint32_t>(c.f_lh, 256), 4);
+    c.f_on = env_u32("VS_FAST", 1) != 0;
+    if (c.f_on) {
+        if (c.f_lh) c.f_lh = round_up_u32(std::max<uint32_t>(c.f_lh, 256), 4);
         c.f_hl = std::max<uint32_t>(next_pow2_u32(c.f_hl + 1), 64) - 1;
         // overflow table: room for every candidate the worst scan could insert beyond the LDS table
         c.f_gcap = next_pow2_u32(std::min<uint64_t>(std::max<uint64_t>(std::min<uint64_t>(pushes, 4 * typ_ins), 1024), 1u << 22));
@@ -649,7 +657,7 @@ static Caps initial_caps(const vs_index* ix, uint32_t L, uint32_t M) {
         probe.lh = c.f_lh;
         probe.vr = c.f_vr;
         probe.vcap = c.f_vcap;
-        if (nbits >= (1ull << (32 - c.f_sb)) || fast_lds_bytes(ix, probe) > 64 * 1024) c.f_lh = 0;
+        if (nbits >= (1ull << (32 - c.f_sb)) || fast_lds_bytes(ix, probe) > 64 * 1024) c.f_on = false;
     }
     return c;
 }
@@ -793,9 +801,9 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
         prof_end(c, PK_PREPARE, ev);
     }
     bool fast_done = false;
-    if (caps.f_lh) {
+    if (caps.f_on) {
         const uint32_t fslots = fast_pool_slots(nq, caps.f_pool_frac);
-        ix->last_ins_limit = caps.f_lh - caps.f_lh / 8 - 64;
+        ix->last_ins_limit = caps.f_lh ? caps.f_lh - caps.f_lh / 8 - 64 : 0xFFFFFFFFu;
         VS_TRY(devbuf_reserve(c, w.heap_g4, std::max<size_t>((size_t)nq * caps.f_gstride * 4, 16)));
         VS_TRY(devbuf_reserve(c, w.ghash4, (size_t)fslots * caps.f_gcap * 4));
         VS_TRY(devbuf_reserve(c, w.pool_ctr, 64));
@@ -816,6 +824,7 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
         f.pool_counter = (uint32_t*)w.pool_ctr.p;
         f.pool_slots = fslots;
         f.lh = caps.f_lh;
+        f.minw = env_u32("VS_F_MINW", caps.f_lh == 0 ? 4 : 1);
         f.sb = caps.f_sb;
         f.vcap = caps.f_vcap;
         f.qcodes = (const uint64_t*)w.qcodes.p;
@@ -967,7 +976,7 @@ static uint32_t stream_len(uint32_t rescore, uint32_t k) { return rescore > 0 ? 
 static uint32_t chunk_queries(const vs_index* ix, const Caps& c, uint32_t M, uint32_t nq) {
     const size_t general = (size_t)c.hashcap * 4 + (size_t)(c.hcap > c.hl ? c.hcap - c.hl : 0) * 8;
     size_t per_q = (size_t)M * 12 + ix->vec_stride * 4ull + ix->code_stride * 8ull + 256;
-    if (c.f_lh) per_q += (size_t)((double)c.f_gcap * 4 * c.f_pool_frac) + (size_t)c.f_gstride * 4 + general / 64 + 64;
+    if (c.f_on) per_q += (size_t)((double)c.f_gcap * 4 * c.f_pool_frac) + (size_t)c.f_gstride * 4 + general / 64 + 64;
     else per_q += general;
     // workspace budget: half of what is free on the device right now (plus what the workspace already holds), <= 64 GiB
     size_t budget = 24ull << 30;

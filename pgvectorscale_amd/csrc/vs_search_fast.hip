@@ -95,6 +95,7 @@ struct FastHeap {
             dpat |= dir << anc;
         }
         if (lane >= 63) { amask = 0; dpat = 1; }  // never matches
+        init_wide();
     }
     __device__ __forceinline__ uint32_t root() const { return rfl(l[1]); }
 
@@ -139,53 +140,83 @@ struct FastHeap {
     }
 
     // ---- insert_neighbor x c (AM/graph/mod.rs:144-147): elements 0..c-1 (lanes 0..c-1 of `entry`, neighbor-list order)
-    // are pushed one after another, but only the first one waits for LDS: consecutive leaves P, P+1 on the same level
-    // share their ancestors from rank sh = bitlen((P+1) xor (P+2)) upwards, and what push j did to that chain is known
-    // in registers (ranks r < t_j now hold the old rank r+1 value, rank t_j holds element j), so the chain of push j+1
-    // is patched from registers for r >= sh and taken from an LDS read issued one push earlier for r < sh (positions
-    // push j never touches).
+    // are pushed one after another, but memory is touched once per RUN of up to 24 leaves on one level:
+    //   * the distinct ancestors of such a run are few (<= 13 parents, 7 grandparents, 4, 3, then <= 2 per rank), so one
+    //     wave-wide load (lane -> fixed (rank, slot) layout below) brings all of them in, from LDS or from the spill array;
+    //   * consecutive leaves P, P+1 share their ancestors from rank sh = bitlen((P+1) xor (P+2)) upwards, and what push j
+    //     did to that shared chain is known in registers (ranks r < t_j now hold the old rank r+1 value, rank t_j holds
+    //     element j); the ranks below sh are positions no earlier push of the run can have touched, so push j+1 takes
+    //     them from the wide load (ds_bpermute) and the rest from the patched chain of push j.
+    // lane layout of the wide load: rank 1 -> lanes 0..15, rank 2 -> 16..23, rank 3 -> 24..28, rank 4 -> 29..31,
+    // rank r >= 5 -> lanes 32 + 2 (r - 5), +1  (ranks up to 20: heaps of up to 2^20 entries)
+    uint32_t wl_rank, wl_slot, wl_base;  // this lane's (rank, slot) as a wide-load lane; first lane of rank `lane`
+    __device__ __forceinline__ void init_wide() {
+        const uint32_t i = (uint32_t)lane;
+        if (i < 16) { wl_rank = 1; wl_slot = i; }
+        else if (i < 24) { wl_rank = 2; wl_slot = i - 16; }
+        else if (i < 29) { wl_rank = 3; wl_slot = i - 24; }
+        else if (i < 32) { wl_rank = 4; wl_slot = i - 29; }
+        else { wl_rank = 5 + ((i - 32) >> 1); wl_slot = (i - 32) & 1u; }
+        const uint32_t r = i;  // as a chain lane: where do rank-r values start
+        wl_base = r <= 1 ? 0u : (r == 2 ? 16u : (r == 3 ? 24u : (r == 4 ? 29u : 32u + 2u * (r - 5u))));
+    }
+    // entry at index idx (= heap position + 1; 0 = sentinel)
+    __device__ __forceinline__ uint32_t get1(uint32_t idx) const { return idx <= hl ? l[idx] : gload32(g + (idx - 1 - hl)); }
+    __device__ __forceinline__ void set1(uint32_t idx, uint32_t v) const {
+        if (idx <= hl) l[idx] = v;
+        else gstore32(g + (idx - 1 - hl), v);
+    }
     __device__ __forceinline__ void push_run(uint32_t entry, uint32_t c) {
-        if (c == 0) return;
-        if (len + c > hl || len < 2) {  // spill region involved / tiny heap: one at a time
-            for (uint32_t j = 0; j < c; ++j) push(readlane_u32(entry, j));
-            return;
-        }
-        const uint32_t r = (uint32_t)lane & 31u;
         uint32_t j = 0;
         while (j < c) {
-            uint32_t p1 = len + 1;
-            uint32_t chain = l[p1 >> r];
-            asm volatile("" : "+v"(chain));  // the chain is complete before the loop: no LDS wait at the loop head
-            bool boundary = false;
-            for (; j < c; ++j) {
+            const uint32_t p1f = len + 1;  // (position of the run's first leaf) + 1
+            // a run stays on one heap level, has at most 24 leaves, and needs a heap of >= 64 entries / depth <= 20
+            const uint32_t room = (2u << (31u - (uint32_t)__builtin_clz(p1f))) - p1f;  // leaves left on this level
+            const uint32_t n = min(min(c - j, 24u), room);
+            if (len < 64 || p1f >= (1u << 20)) {  // tiny or huge heap: one at a time
+                push(readlane_u32(entry, j));
+                ++j;
+                continue;
+            }
+            const uint32_t p1l = p1f + n - 1;
+            const bool spill = p1l > hl;  // some leaf (hence possibly some parent) lives in the spill array
+            // ---- wide load of every distinct ancestor of the run
+            uint32_t anc = 0;
+            {
+                const uint32_t idx = (p1f >> wl_rank) + wl_slot;
+                if (idx <= (p1l >> wl_rank)) anc = spill ? get1(idx) : l[idx];
+            }
+            const uint32_t r = (uint32_t)lane;       // chain lane = ancestor rank (lane 0 and lanes > 20 unused)
+            const bool rank_ok = r >= 1 && r <= 20;
+            auto fresh_of = [&](uint32_t p1) -> uint32_t {  // rank-r ancestor of leaf p1 as loaded at the start of the run
+                const uint32_t src = wl_base + ((p1 >> (r & 31u)) - (p1f >> (r & 31u)));
+                const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((rank_ok ? src : 0u) << 2), (int)anc);
+                return rank_ok ? v : 0u;
+            };
+            uint32_t p1 = p1f;
+            uint32_t chain = fresh_of(p1);
+            asm volatile("" : "+v"(chain));  // the chain is complete before the loop
+            for (uint32_t e = 0; e < n; ++e, ++j) {
                 const uint32_t elem = readlane_u32(entry, j);
                 const uint32_t p1n = p1 + 1;
-                const bool more = j + 1 < c;
-                uint32_t nxt = 0;
-                if (more) nxt = l[p1n >> r];  // valid for the ranks push j cannot touch (r < sh); in flight during the push
+                const uint32_t nxt = fresh_of(p1n);  // in flight during this push (unused after the last leaf)
                 const bool cmp = (elem >> sb) < (chain >> sb);
-                const uint32_t bal = (uint32_t)__ballot(cmp) >> 1;  // bit r-1 <-> ancestor r; bit 31 is always clear
-                const uint32_t t = (uint32_t)__builtin_ctz(~bal);   // leading run of ancestors that move down
-                if ((uint32_t)lane <= t) {
-                    const uint32_t dst = lane == 0 ? (p1 >> t) : (p1 >> (lane - 1));
-                    l[dst] = lane == 0 ? elem : chain;
+                const uint32_t bal = ((uint32_t)__ballot(cmp) & 0x1FFFFEu) >> 1;  // bit r-1 <-> ancestor r (ranks 1..20)
+                const uint32_t t = (uint32_t)__builtin_ctz(~bal);                   // leading run of ancestors that move down
+                if (r <= t) {
+                    const uint32_t dst = r == 0 ? (p1 >> t) : (p1 >> (r - 1));
+                    const uint32_t val = r == 0 ? elem : chain;
+                    if (spill) set1(dst, val);
+                    else l[dst] = val;
                 }
-                len += 1;
-                if (more) {
-                    if ((p1n & (p1n - 1)) == 0) {  // the next leaf opens a new level: ranks do not line up, restart
-                        boundary = true;
-                        ++j;
-                        break;
-                    }
-                    const uint32_t sh = 32u - (uint32_t)__builtin_clz(p1 ^ p1n);
-                    const uint32_t up = wave_shl1(chain, 0);  // rank r+1 value
-                    const uint32_t patched = r < t ? up : (r == t ? elem : chain);
-                    chain = r >= sh ? patched : nxt;
-                }
+                const uint32_t sh = 32u - (uint32_t)__builtin_clz(p1 ^ p1n);
+                const uint32_t up = wave_shl1(chain, 0);  // rank r+1 value
+                const uint32_t patched = r < t ? up : (r == t ? elem : chain);
+                chain = r >= sh ? patched : nxt;
                 p1 = p1n;
             }
+            len += n;
             wave_sync();
-            if (!boundary) break;
         }
     }
 
@@ -194,11 +225,12 @@ struct FastHeap {
     __device__ __forceinline__ void pop() {
         const uint32_t last = len - 1;
         const bool all_lds = last < hl;
-        const uint32_t item = rfl(all_lds ? l[last + 1] : get(last));
+        // the former last element is only needed once the hole has reached a leaf: its load (L2 when the heap spills)
+        // stays in flight during the sift-down rounds
+        const uint32_t item_v = all_lds ? l[last + 1] : get(last);
         len = last;
         if (len == 0) return;
         const uint32_t end = len;
-        const uint32_t ikey = item >> sb;
         uint32_t root = 0, pos = 0;
         uint32_t pkey = 0;  // key of the value now stored in the parent of `root` (0 for the heap root: never moves)
         for (;;) {
@@ -242,6 +274,8 @@ struct FastHeap {
             root = 2 * ad + 1 + (uint32_t)((B >> jd) & 1ull);  // jd is on the subtree's last level: descend
         }
         // sift_up(0, pos) of the former last element: it only moves when it is smaller than the new parent value
+        const uint32_t item = rfl(item_v);
+        const uint32_t ikey = item >> sb;
         if (ikey < pkey) {
             if (all_lds) sift_up_lds(pos, item);
             else sift_up_gen(pos, item);
@@ -401,8 +435,10 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
     return min(min(readlane_u32(v, 15), readlane_u32(v, 31)), min(readlane_u32(v, 47), readlane_u32(v, 63)));
 }
 
-template <int NCH, int VR, bool TIMING>
-__global__ __launch_bounds__(WAVE) void k_search_fast(FastArgs a) {
+// MINW = waves per SIMD the register allocator must leave room for (1 = unconstrained): in the table-less regime the
+// kernel is occupancy bound and LDS no longer limits it, so fewer VGPRs (some cold values in scratch) can pay.
+template <int NCH, int VR, bool TIMING, int MINW>
+__global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
     const uint32_t q = blockIdx.x;
@@ -491,9 +527,11 @@ __global__ __launch_bounds__(WAVE) void k_search_fast(FastArgs a) {
         return true;
     };
     auto hash_home = [&](uint32_t nid) -> uint32_t { return (uint32_t)(((uint64_t)hash_u32(nid) * s.lh) >> 32); };
-    auto node_of = [&](uint32_t handle) -> uint32_t {  // uniform handle -> node id
-        if (handle < s.lh) return rfl(lhash[handle]);
-        return rfl(gload32(ghash + (handle - s.lh)));
+    // handle -> node id.  node_load only ISSUES the read (LDS, or L2 for ids in the overflow table); the value is made
+    // uniform with rfl() where it is needed, so the latency overlaps whatever runs in between.
+    auto node_load = [&](uint32_t handle) -> uint32_t {
+        if (handle < s.lh) return lhash[handle];
+        return gload32(ghash + (handle - s.lh));
     };
     // true where the id was not present before; slot_out = its handle
     auto finish_insert = [&](uint32_t nid, bool act, uint32_t slot, uint32_t old, uint32_t& slot_out) -> bool {
@@ -512,7 +550,7 @@ __global__ __launch_bounds__(WAVE) void k_search_fast(FastArgs a) {
     };
     auto frozen_insert = [&](uint32_t nid, bool act, uint32_t& slot_out) -> bool {
         bool need_g = act, fresh = false;
-        if (act) {
+        if (act && s.lh) {
             uint32_t slot = hash_home(nid);
             for (;;) {
                 const uint32_t v = lhash[slot];
@@ -547,6 +585,32 @@ __global__ __launch_bounds__(WAVE) void k_search_fast(FastArgs a) {
         }
         return fresh;
     };
+
+    // ---- table-less mode (lh == 0): every id lives in the global table; the first CAS is issued by the caller
+    const bool gmode = s.lh == 0;
+    auto ghash_home = [&](uint32_t nid) -> uint32_t { return hash_u32(nid ^ 0x5bd1e995u) & gmask; };
+    auto finish_global = [&](uint32_t nid, bool act, uint32_t gs, uint32_t old, uint32_t& slot_out) -> bool {
+        bool fresh = false;
+        if (act) {
+            for (;;) {
+                if (old == VS_EMPTY) { fresh = true; break; }
+                if (old == nid) break;
+                gs = (gs + 1) & gmask;
+                old = atomicCAS(&ghash[gs], VS_EMPTY, nid);  // L2 atomic
+            }
+            slot_out = gs;  // handle = lh + gs with lh == 0
+        }
+        nins_g += (uint32_t)__popcll(__ballot(fresh));
+        return fresh;
+    };
+    if (gmode) {  // claim and clear this scan's table up front
+        if (claim_region()) {
+            g_open = true;
+            for (uint32_t i = 4u * lane; i < s.gcap; i += 4u * WAVE)
+                *reinterpret_cast<uint4*>(ghash + i) = make_uint4(VS_EMPTY, VS_EMPTY, VS_EMPTY, VS_EMPTY);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        }
+    }
 
     // ---- ListSearchResult::new: start nodes (AM/graph/mod.rs:97-124, AM/graph/start_nodes.rs:39-48) ----
     {
@@ -635,8 +699,9 @@ __global__ __launch_bounds__(WAVE) void k_search_fast(FastArgs a) {
         hmax = max(hmax, heap.len);
         lap(6);
         const uint32_t hd = top >> s.sb;
-        const uint32_t node = node_of(top & smask);
+        const uint32_t node_v = node_load(top & smask);
         heap.pop();
+        const uint32_t node = rfl(node_v);
         const uint32_t* nrow = a.nbrs + (size_t)node * a.nbr_stride;
         uint32_t row0;
         if (node == pfa_node) {
@@ -654,7 +719,10 @@ __global__ __launch_bounds__(WAVE) void k_search_fast(FastArgs a) {
         // ---- visit_lsn_internal, Disk arm (AM/sbq/storage.rs:135-190) ----
         st_reads++;  // SbqNode::read(visiting)
         const uint32_t root_after = heap.len > 0 ? heap.root() : 0xFFFFFFFFu;
+        uint32_t root_node_v = VS_INVALID_NODE;  // id of the new root (slot A of the row prefetch), resolved at gather time
+        if (root_after != 0xFFFFFFFFu) root_node_v = node_load(root_after & smask);
         uint32_t best = 0xFFFFFFFFu;  // smallest (hamming << sb | slot) among this visit's new candidates
+        uint32_t best_node = VS_INVALID_NODE;
         bool pfa_issued = false, pfb_issued = false, vis_done = false;
         bool list_ended = false;
         for (uint32_t c0 = 0; c0 < a.R && !list_ended; c0 += WAVE) {
@@ -668,8 +736,13 @@ __global__ __launch_bounds__(WAVE) void k_search_fast(FastArgs a) {
             lap(1);
             // prepare_insert (marks BEFORE the label check, AM/sbq/storage.rs:148-172): first probe issued, ...
             const bool frozen = nins + WAVE > slot_limit;
-            uint32_t hslot = hash_home(nid), old = VS_EMPTY;
-            if (!frozen && act) old = atomicCAS(&lhash[hslot], VS_EMPTY, nid);
+            uint32_t hslot = gmode ? ghash_home(nid) : hash_home(nid), old = VS_EMPTY;
+            if (gmode) {
+                if ((nins_g + WAVE) * 4u > s.gcap * 3u) { status |= OVF_HASH; break; }
+                if (act) old = atomicCAS(&ghash[hslot], VS_EMPTY, nid);  // L2 atomic, in flight during the visited insert
+            } else if (!frozen && act) {
+                old = atomicCAS(&lhash[hslot], VS_EMPTY, nid);
+            }
             // ... visited.insert(partition_point(|x| *x < head), head) runs in registers meanwhile ...
             if (!vis_done) {
                 vis_done = true;
@@ -678,7 +751,9 @@ __global__ __launch_bounds__(WAVE) void k_search_fast(FastArgs a) {
             }
             // ... then the probe sequence is finished
             bool fresh;
-            if (frozen) {
+            if (gmode) {
+                fresh = finish_global(nid, act, hslot, old, hslot);
+            } else if (frozen) {
                 fresh = frozen_insert(nid, act, hslot);
                 if (status) break;
             } else {
@@ -722,7 +797,7 @@ __global__ __launch_bounds__(WAVE) void k_search_fast(FastArgs a) {
                     pfa_issued = true;
                     pfa_node = VS_INVALID_NODE;
                     if (root_after != 0xFFFFFFFFu) {
-                        pfa_node = node_of(root_after & smask);
+                        pfa_node = rfl(root_node_v);
                         pfa_val = ((uint32_t)lane < a.R) ? a.nbrs[(size_t)pfa_node * a.nbr_stride + lane] : VS_INVALID_NODE;
                     }
                 }
@@ -739,12 +814,18 @@ __global__ __launch_bounds__(WAVE) void k_search_fast(FastArgs a) {
                 lap(4);
             }
             // a new candidate with a strictly smaller key than the root's is the next pop for sure
-            best = min(best, wave_min_u32(entry));
+            {
+                const uint32_t m = wave_min_u32(entry);
+                if (m < best) {
+                    best = m;
+                    best_node = rfl(surv_id[__builtin_ctzll(__ballot(entry == m))]);  // entry lane = survivor rank
+                }
+            }
             if ((list_ended || c0 + WAVE >= a.R) && !pfb_issued) {
                 pfb_issued = true;
                 pfb_node = VS_INVALID_NODE;
                 if (best != 0xFFFFFFFFu && (best >> s.sb) < (root_after >> s.sb)) {
-                    pfb_node = node_of(best & smask);
+                    pfb_node = best_node;  // a candidate of this visit: its id is known without a table lookup
                     pfb_val = ((uint32_t)lane < a.R) ? a.nbrs[(size_t)pfb_node * a.nbr_stride + lane] : VS_INVALID_NODE;
                 }
             }
@@ -757,7 +838,7 @@ __global__ __launch_bounds__(WAVE) void k_search_fast(FastArgs a) {
         if (!pfa_issued) {  // nothing new to score: the old root is the next expansion
             pfa_node = VS_INVALID_NODE;
             if (root_after != 0xFFFFFFFFu) {
-                pfa_node = node_of(root_after & smask);
+                pfa_node = rfl(root_node_v);
                 pfa_val = ((uint32_t)lane < a.R) ? a.nbrs[(size_t)pfa_node * a.nbr_stride + lane] : VS_INVALID_NODE;
             }
         }
@@ -798,15 +879,15 @@ size_t fast_lds_bytes(const vs_index* idx, const FastLaunch& s) {
     return (b + 15) / 16 * 16;
 }
 
-template <int NCH, int VR, bool TIMING>
+template <int NCH, int VR, bool TIMING, int MINW>
 static int launch_fast_tt(vs_index* idx, const FastArgs& a, size_t lds) {
     static bool attr_set = false;
     if (!attr_set) {
-        VS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_search_fast<NCH, VR, TIMING>),
+        VS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_search_fast<NCH, VR, TIMING, MINW>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_search_fast<NCH, VR, TIMING>), dim3(a.s.nq), dim3(WAVE), lds, idx->ctx->stream, a);
+    hipLaunchKernelGGL((k_search_fast<NCH, VR, TIMING, MINW>), dim3(a.s.nq), dim3(WAVE), lds, idx->ctx->stream, a);
     VS_HIP(hipGetLastError());
     return VS_OK;
 }
@@ -815,10 +896,17 @@ template <int NCH>
 static int launch_fast_t(vs_index* idx, const FastArgs& a, size_t lds) {
     if (a.s.phase) {
         VS_REQUIRE(NCH == 3 && a.s.vr == 8, "VS_PHASE diagnostics are built for 17..24-word codes / register visited list only");
-        return launch_fast_tt<3, 8, true>(idx, a, lds);
+        return launch_fast_tt<3, 8, true, 1>(idx, a, lds);
     }
-    if (a.s.vr == 8) return launch_fast_tt<NCH, 8, false>(idx, a, lds);
-    return launch_fast_tt<NCH, 0, false>(idx, a, lds);
+    if (a.s.vr == 8) {
+        if (NCH == 3) {  // the headline geometry (768 x 2 bit, 1536 x 1 bit): register-capped variants for the occupancy-bound regime
+            if (a.s.minw == 4) return launch_fast_tt<3, 8, false, 4>(idx, a, lds);
+            if (a.s.minw == 5) return launch_fast_tt<3, 8, false, 5>(idx, a, lds);
+            if (a.s.minw == 6) return launch_fast_tt<3, 8, false, 6>(idx, a, lds);
+        }
+        return launch_fast_tt<NCH, 8, false, 1>(idx, a, lds);
+    }
+    return launch_fast_tt<NCH, 0, false, 1>(idx, a, lds);
 }
 
 int launch_search_fast(vs_index* idx, const FastLaunch& s) {
@@ -843,7 +931,7 @@ int launch_search_fast(vs_index* idx, const FastLaunch& s) {
     VS_REQUIRE(((s.hl + 1) & s.hl) == 0 && s.hl >= 63, "fast search: hl must be 2^k - 1 >= 63");
     VS_REQUIRE(s.vr == 8 || (s.vr == 0 && (s.vcap & (s.vcap - 1)) == 0 && s.vcap >= 64),
                "fast search: visited list must be 8 register pairs or a power-of-two ring");
-    VS_REQUIRE(s.lh % 4 == 0 && s.lh >= 256 && (s.gcap & (s.gcap - 1)) == 0 && s.gcap >= 256 &&
+    VS_REQUIRE(s.lh % 4 == 0 && (s.lh == 0 || s.lh >= 256) && (s.gcap & (s.gcap - 1)) == 0 && s.gcap >= 256 &&
                    (uint64_t)s.lh + s.gcap <= (1ull << s.sb) && s.hcap >= s.hl && s.gstride % 2 == 0 &&
                    s.gstride >= s.hcap - s.hl + 2,
                "fast search: bad dedup table / spill geometry");

@@ -166,7 +166,23 @@ struct FastHeap {
         if (idx <= hl) l[idx] = v;
         else gstore32(g + (idx - 1 - hl), v);
     }
-    __device__ __forceinline__ void push_run(uint32_t entry, uint32_t c) {
+    // geometry of the first run of c pushes starting at the current length (0 = "one at a time" path)
+    __device__ __forceinline__ uint32_t first_run(uint32_t c) const {
+        const uint32_t p1f = len + 1;
+        if (len < 64 || p1f >= (1u << 20)) return 0;
+        const uint32_t room = (2u << (31u - (uint32_t)__builtin_clz(p1f))) - p1f;
+        return min(min(c, 24u), room);
+    }
+    // the wide ancestor load of a run of n leaves starting at the current length (only ISSUES the reads)
+    __device__ __forceinline__ uint32_t wide_load(uint32_t n) const {
+        const uint32_t p1f = len + 1, p1l = p1f + n - 1;
+        const uint32_t idx = (p1f >> wl_rank) + wl_slot;
+        uint32_t anc = 0;
+        if (idx <= (p1l >> wl_rank)) anc = p1l > hl ? get1(idx) : l[idx];
+        return anc;
+    }
+    // pre_n / pre_anc: a wide load the caller already issued for the first run (pre_n = first_run(c)), or pre_n = 0
+    __device__ __forceinline__ void push_run(uint32_t entry, uint32_t c, uint32_t pre_n, uint32_t pre_anc) {
         uint32_t j = 0;
         while (j < c) {
             const uint32_t p1f = len + 1;  // (position of the run's first leaf) + 1
@@ -180,12 +196,8 @@ struct FastHeap {
             }
             const uint32_t p1l = p1f + n - 1;
             const bool spill = p1l > hl;  // some leaf (hence possibly some parent) lives in the spill array
-            // ---- wide load of every distinct ancestor of the run
-            uint32_t anc = 0;
-            {
-                const uint32_t idx = (p1f >> wl_rank) + wl_slot;
-                if (idx <= (p1l >> wl_rank)) anc = spill ? get1(idx) : l[idx];
-            }
+            // ---- wide load of every distinct ancestor of the run (the first run's may already be in flight)
+            const uint32_t anc = (j == 0 && pre_n == n) ? pre_anc : wide_load(n);
             const uint32_t r = (uint32_t)lane;       // chain lane = ancestor rank (lane 0 and lanes > 20 unused)
             const bool rank_ok = r >= 1 && r <= 20;
             auto fresh_of = [&](uint32_t p1) -> uint32_t {  // rank-r ancestor of leaf p1 as loaded at the start of the run
@@ -786,6 +798,10 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
                 surv_slot[rank] = hslot;
             }
             wave_sync();
+            // the heap positions the new candidates will get are already known: their ancestors' load (L2 when the heap
+            // spills) is issued now and overlaps the code gather
+            const uint32_t pre_n = heap.first_run(c);
+            const uint32_t pre_anc = pre_n ? heap.wide_load(pre_n) : 0u;
             // distances: 4 lanes per code row, 16 rows per pass; the row of the current heap root rides along
             const uint32_t npass = (c + 15u) >> 4;
             for (uint32_t pass_i = 0; pass_i < npass; ++pass_i) {
@@ -830,7 +846,7 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
                 }
             }
             // insert_neighbor in list order (AM/graph/mod.rs:144-147)
-            heap.push_run(entry, c);
+            heap.push_run(entry, c, pre_n, pre_anc);
             lap(5);
         }
         if (status) break;

@@ -27,6 +27,31 @@ __device__ __forceinline__ uint32_t ham_words(const uint64_t* a, const uint64_t*
     return acc;
 }
 
+// copy the codes of C candidates into LDS: all 16-byte chunks of all rows are spread over the wave, 4 loads in flight per
+// lane (a row-at-a-time loop pays one HBM latency per candidate, which dominated the build)
+__device__ __forceinline__ void stage_codes(uint64_t* ccode, const uint64_t* __restrict__ codes, const uint32_t* cid,
+                                            uint32_t C, uint32_t stride, int lane) {
+    const uint32_t cpr = stride >> 1;  // 16-byte chunks per row (stride is even)
+    const uint32_t total = C * cpr;
+    for (uint32_t base = 0; base < total; base += 4 * WAVE) {
+        ulonglong2 v[4];
+        uint32_t dst[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t idx = base + (uint32_t)u * WAVE + (uint32_t)lane;
+            dst[u] = 0xFFFFFFFFu;
+            if (idx < total) {
+                const uint32_t j = idx / cpr, w = 2u * (idx - j * cpr);
+                v[u] = *reinterpret_cast<const ulonglong2*>(codes + (size_t)cid[j] * stride + w);
+                dst[u] = j * stride + w;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (dst[u] != 0xFFFFFFFFu) *reinterpret_cast<ulonglong2*>(ccode + dst[u]) = v[u];
+    }
+}
+
 // prune_neighbors for one node by one wave.  cand_id/cand_d: C candidates sorted ascending by (distance, id)
 // (LDS).  ccode: optional LDS copy of the candidate codes [C][stride] (nullptr => read codes from global).
 // Writes up to R selected candidate *positions* into sel[] (LDS) and returns their number.
@@ -94,12 +119,7 @@ __global__ __launch_bounds__(WAVE) void k_build_prune_new(const uint64_t* __rest
     }
     __syncthreads();
     if (use_lds_codes) {
-        // coalesced copy: 2 u64 per lane per step
-        for (uint32_t j = 0; j < C; ++j) {
-            const uint64_t* src = codes + (size_t)cid[j] * stride;
-            for (uint32_t w = 2 * lane; w < stride; w += 2 * WAVE)
-                *reinterpret_cast<ulonglong2*>(ccode + (size_t)j * stride + w) = *reinterpret_cast<const ulonglong2*>(src + w);
-        }
+        stage_codes(ccode, codes, cid, C, stride, lane);
         __syncthreads();
     }
     uint32_t nres = wave_prune(cid, cd, C, use_lds_codes ? ccode : nullptr, codes, stride, R, max_alpha, maxf, sel, lane);
@@ -214,12 +234,7 @@ __global__ __launch_bounds__(WAVE) void k_build_backedges(const uint64_t* __rest
         }
         __syncthreads();
         if (use_lds_codes) {
-            for (uint32_t j = 0; j < T; ++j) {
-                const uint64_t* src = codes + (size_t)cid[j] * stride;
-                for (uint32_t w = 2 * lane; w < stride; w += 2 * WAVE)
-                    *reinterpret_cast<ulonglong2*>(ccode + (size_t)j * stride + w) =
-                        *reinterpret_cast<const ulonglong2*>(src + w);
-            }
+            stage_codes(ccode, codes, cid, T, stride, lane);
             __syncthreads();
         }
         uint32_t nres = wave_prune(cid, cd, T, use_lds_codes ? ccode : nullptr, codes, stride, R, max_alpha, maxf, sel, lane);

@@ -639,8 +639,10 @@ static Caps initial_caps(const vs_index* ix, uint32_t L, uint32_t M) {
     }
     c.f_hl = env_u32("VS_F_HL", hl_auto);
     const uint32_t want_v = (uint32_t)std::min<uint64_t>((uint64_t)L + L / 2 + 32, 1u << 20);
-    c.f_vr = env_u32("VS_F_VR", want_v <= 512 ? 8 : 0);
-    c.f_vcap = c.f_vr ? 512 : std::max<uint32_t>(next_pow2_u32(env_u32("VS_F_VCAP", want_v)), 64);
+    // visited list: register resident (8 VGPR pairs) while LDS is the limiter; in the table-less regime registers are,
+    // and the LDS ring variant needs 87 VGPRs instead of 141 (5 instead of 3 waves per SIMD)
+    c.f_vr = env_u32("VS_F_VR", (lds_table && want_v <= 512) ? 8 : 0);
+    c.f_vcap = c.f_vr ? 512 : round_up_u32(std::max<uint32_t>(env_u32("VS_F_VCAP", 2 * want_v), 64), 64);
     c.f_on = env_u32("VS_FAST", 1) != 0;
     if (c.f_on) {
         if (c.f_lh) c.f_lh = round_up_u32(std::max<uint32_t>(c.f_lh, 256), 4);
@@ -824,7 +826,7 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
         f.pool_counter = (uint32_t*)w.pool_ctr.p;
         f.pool_slots = fslots;
         f.lh = caps.f_lh;
-        f.minw = env_u32("VS_F_MINW", caps.f_lh == 0 ? 4 : 1);
+        f.minw = env_u32("VS_F_MINW", (caps.f_lh == 0 && caps.f_vr) ? 4 : 1);
         f.sb = caps.f_sb;
         f.vcap = caps.f_vcap;
         f.qcodes = (const uint64_t*)w.qcodes.p;

@@ -152,7 +152,7 @@ struct FastLaunch {
     uint32_t gcap;     // slots of the per-scan global overflow dedup table (power of two), handles lh .. lh + gcap - 1
     uint32_t sb;       // bits of a slot handle inside a heap entry (lh + gcap <= 1 << sb)
     uint32_t vr;       // visited list: 8 = eight register pairs (512 entries), 0 = LDS ring of vcap entries
-    uint32_t vcap;     // visited ring capacity (power of two; vr == 0)
+    uint32_t vcap;     // visited ring capacity (vr == 0)
     uint32_t minw;     // register cap variant: waves per SIMD to leave room for (1 = unconstrained)
     const uint64_t* qcodes;
     const int16_t* qlabels;

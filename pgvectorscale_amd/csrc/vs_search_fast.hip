@@ -310,19 +310,25 @@ struct Visited {
     static constexpr int NR = VR > 0 ? VR : 1;
     uint32_t h[NR], n[NR];
     uint64_t* ring;
-    uint32_t vmask, head, len;
+    uint32_t vcapv, head, len;  // ring capacity (any size), index of entry 0, number of entries
     int lane;
 
     __device__ __forceinline__ void init(int lane_, uint64_t* ring_, uint32_t vcap) {
         lane = lane_;
         ring = ring_;
-        vmask = vcap - 1;
+        vcapv = vcap;
         head = 0;
         len = 0;
 #pragma unroll
         for (int r = 0; r < NR; ++r) { h[r] = 0; n[r] = 0; }
     }
-    __device__ __forceinline__ uint32_t capacity() const { return VR > 0 ? 64u * VR : vmask + 1; }
+    __device__ __forceinline__ uint32_t capacity() const { return VR > 0 ? 64u * VR : vcapv; }
+    // ring slot of entry i (i <= capacity; i == 0xFFFFFFFF means "one before entry 0")
+    __device__ __forceinline__ uint32_t slot(uint32_t i) const {
+        if (i == 0xFFFFFFFFu) return head ? head - 1 : vcapv - 1;
+        const uint32_t x = head + i;
+        return x >= vcapv ? x - vcapv : x;
+    }
     // hamming of entry i (i < len, uniform)
     __device__ __forceinline__ uint32_t ham_at(uint32_t i) const {
         if (VR > 0) {
@@ -332,7 +338,7 @@ struct Visited {
                 if ((i >> 6) == (uint32_t)r) v = readlane_u32(h[r], i & 63u);
             return v;
         }
-        return rfl((uint32_t)(ring[(head + i) & vmask] >> 32));
+        return rfl((uint32_t)(ring[slot(i)] >> 32));
     }
     // visited.insert(partition_point(|x| *x < new), new): before the first element >= new  (caller checked capacity)
     __device__ __forceinline__ void insert(uint32_t hd, uint32_t node) {
@@ -362,33 +368,33 @@ struct Visited {
         uint32_t idx = 0;
         for (uint32_t base = 0; base < len; base += WAVE) {
             const uint32_t i = base + lane;
-            const bool lt = i < len && (uint32_t)(ring[(head + i) & vmask] >> 32) < hd;
+            const bool lt = i < len && (uint32_t)(ring[slot(i)] >> 32) < hd;
             idx += (uint32_t)__popcll(__ballot(lt));
         }
         if (2 * idx < len) {  // move [0, idx) one slot towards the front, lowest chunk first
             for (uint32_t base = 0; base < idx; base += WAVE) {
                 const uint32_t i = base + lane;
                 uint64_t e = 0;
-                if (i < idx) e = ring[(head + i) & vmask];
+                if (i < idx) e = ring[slot(i)];
                 wave_sync();
-                if (i < idx) ring[(head + i - 1) & vmask] = e;
+                if (i < idx) ring[slot(i - 1)] = e;
                 wave_sync();
             }
-            head = (head - 1) & vmask;
+            head = head ? head - 1 : vcapv - 1;
         } else {  // move [idx, len) one slot towards the back, highest chunk first
             uint32_t hi = len;
             while (hi > idx) {
                 const uint32_t lo = (hi - idx > WAVE) ? hi - WAVE : idx;
                 const uint32_t i = lo + lane;
                 uint64_t e = 0;
-                if (i < hi) e = ring[(head + i) & vmask];
+                if (i < hi) e = ring[slot(i)];
                 wave_sync();
-                if (i < hi) ring[(head + i + 1) & vmask] = e;
+                if (i < hi) ring[slot(i + 1)] = e;
                 wave_sync();
                 hi = lo;
             }
         }
-        if (lane == 0) ring[(head + idx) & vmask] = ((uint64_t)hd << 32) | node;
+        if (lane == 0) ring[slot(idx)] = ((uint64_t)hd << 32) | node;
         len++;
         wave_sync();
     }
@@ -412,7 +418,7 @@ struct Visited {
         const uint64_t front = ring[head];
         hd = rfl((uint32_t)(front >> 32));
         node = rfl((uint32_t)front);
-        head = (head + 1) & vmask;
+        head = head + 1 == vcapv ? 0 : head + 1;
         len--;
     }
 };
@@ -890,8 +896,8 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
 }
 
 size_t fast_lds_bytes(const vs_index* idx, const FastLaunch& s) {
-    size_t b = (size_t)(s.hl + 1) * 4 + (size_t)s.lh * 4 + 3 * 64 * 4 + (s.vr ? 0 : (size_t)s.vcap * 8) + MAX_QLABELS * 2 +
-               (size_t)idx->code_stride * 8 + 16;
+    const size_t qcopy = (idx->code_stride + 7) / 8 > 6 ? (size_t)idx->code_stride * 8 : 0;  // NCH == 0 variant only
+    size_t b = (size_t)(s.hl + 1) * 4 + (size_t)s.lh * 4 + 3 * 64 * 4 + (s.vr ? 0 : (size_t)s.vcap * 8) + MAX_QLABELS * 2 + qcopy + 16;
     return (b + 15) / 16 * 16;
 }
 
@@ -922,6 +928,10 @@ static int launch_fast_t(vs_index* idx, const FastArgs& a, size_t lds) {
         }
         return launch_fast_tt<NCH, 8, false, 1>(idx, a, lds);
     }
+    if (NCH == 3) {
+        if (a.s.minw == 6) return launch_fast_tt<3, 0, false, 6>(idx, a, lds);
+        if (a.s.minw == 8) return launch_fast_tt<3, 0, false, 8>(idx, a, lds);
+    }
     return launch_fast_tt<NCH, 0, false, 1>(idx, a, lds);
 }
 
@@ -945,8 +955,8 @@ int launch_search_fast(vs_index* idx, const FastLaunch& s) {
     const size_t lds = fast_lds_bytes(idx, s);
     VS_REQUIRE(lds <= 160 * 1024, "fast search state does not fit LDS (%zu B)", lds);
     VS_REQUIRE(((s.hl + 1) & s.hl) == 0 && s.hl >= 63, "fast search: hl must be 2^k - 1 >= 63");
-    VS_REQUIRE(s.vr == 8 || (s.vr == 0 && (s.vcap & (s.vcap - 1)) == 0 && s.vcap >= 64),
-               "fast search: visited list must be 8 register pairs or a power-of-two ring");
+    VS_REQUIRE(s.vr == 8 || (s.vr == 0 && s.vcap >= 64 && s.vcap % 2 == 0),
+               "fast search: visited list must be 8 register pairs or a ring of >= 64 entries");
     VS_REQUIRE(s.lh % 4 == 0 && (s.lh == 0 || s.lh >= 256) && (s.gcap & (s.gcap - 1)) == 0 && s.gcap >= 256 &&
                    (uint64_t)s.lh + s.gcap <= (1ull << s.sb) && s.hcap >= s.hl && s.gstride % 2 == 0 &&
                    s.gstride >= s.hcap - s.hl + 2,

@@ -212,6 +212,22 @@ class DiskAnnIndex:
         self._refresh()
 
     # -- single kernels ------------------------------------------------------------------------------------------------
+    def save_graph(self, path):
+        """Dump the neighbor array (device layout [n][nbr_stride] u32) to a file (benchmark convenience: the on-device
+        build of a 50M-node index takes minutes and is deterministic)."""
+        ptr, stride = self.array(_lib.ARR_NBRS)
+        arr = np.empty((self.desc.n, stride), np.uint32)
+        self.ctx.download(ptr, arr)
+        arr.tofile(path)
+
+    def load_graph(self, path, default_start=0):
+        ptr, stride = self.array(_lib.ARR_NBRS)
+        arr = np.fromfile(path, np.uint32)
+        if arr.size != self.desc.n * stride:
+            raise ValueError(f"{path}: {arr.size} u32, expected {self.desc.n} x {stride}")
+        self.ctx.upload(ptr, arr.reshape(self.desc.n, stride))
+        self.set_start_nodes(default_start)
+
     def quantize(self, q):
         q = np.ascontiguousarray(q, np.float32).reshape(-1, self.desc.dim_index)
         out = np.empty((q.shape[0], self.desc.words), np.uint64)

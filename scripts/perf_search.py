@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--reps", type=int, default=4)
     ap.add_argument("--configs", default="VS_FAST=1")
     ap.add_argument("--kind", default="clustered", choices=["clustered", "hard"])
+    ap.add_argument("--graph-cache", default=None, help="neighbor-array file (see bench.py --graph-cache)")
     ap.add_argument("--scan", type=int, default=0, help="also run the flat SBQ scan (K5) with this many queries (PMC calibration)")
     args = ap.parse_args()
     import numpy as np
@@ -35,15 +36,22 @@ def main():
 
     ctx = P.Context(0)
     ix = P.DiskAnnIndex.alloc(ctx, n=args.n, dim_full=args.dim, num_neighbors=50, distance_type=P.VS_L2)
-    gp = DatagenParams(seed=3, dim=args.dim) if args.kind == "clustered" else \
-        DatagenParams(seed=3, dim=args.dim, latent_dim=64, n_clusters=16, intra_pct=100, noise_pct=40)
+    seed = {1_000_000: 3, 10_000_000: 5, 50_000_000: 6}.get(args.n, 3)  # same corpora as bench.py
+    gp = DatagenParams(seed=seed, dim=args.dim) if args.kind == "clustered" else \
+        DatagenParams(seed=seed, dim=args.dim, latent_dim=64, n_clusters=16, intra_pct=100, noise_pct=40)
     vp, _ = ix.array(_lib.ARR_VECS)
     t0 = time.time()
     fill_device(ctx, gp, 0, args.n, vp)
     ix.refresh_norms()
     ix.sbq_train()
     ix.sbq_quantize_corpus()
-    ix.build_graph(search_list_size=100, max_alpha=1.2)
+    cache = args.graph_cache and f"{args.graph_cache}.{args.n}x{args.dim}.l2.L100.r0"
+    if cache and os.path.exists(cache) and args.kind == "clustered":
+        ix.load_graph(cache)
+    else:
+        ix.build_graph(search_list_size=100, max_alpha=1.2)
+        if cache and args.kind == "clustered":
+            ix.save_graph(cache)
     print(f"index ready in {time.time() - t0:.2f}s", flush=True)
     nq, k = args.nq, args.k
     q = ctx.alloc(nq * args.dim * 4)

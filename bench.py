@@ -244,8 +244,10 @@ def main():
     avg_ms = s_ms / max(s_n, 1)
     achieved = per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "pmc_search_traffic.json")
-    if os.path.exists(pmc_path):
+    # HBM bytes per launch from the TCC counters (scripts/pmc_traffic.sh; rocprofv3 cannot run inside this process):
+    # taken from the committed measurement whose configuration equals this run's
+    import glob
+    for pmc_path in sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_search_traffic*.json"))):
         try:
             pj = json.load(open(pmc_path))
             if pj.get("n") == n and pj.get("nq") == nq and pj.get("L") == L and pj.get("rescore") == S:

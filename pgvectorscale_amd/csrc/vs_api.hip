@@ -665,7 +665,8 @@ static Caps initial_caps(const vs_index* ix, uint32_t L, uint32_t M) {
 }
 
 static uint32_t fast_pool_slots(uint32_t nq, double frac) {
-    return (uint32_t)std::min<uint64_t>(nq, std::max<uint64_t>(256, (uint64_t)(frac * nq) + 1));
+    const uint64_t floor_slots = getenv("VS_F_POOL") ? 1 : 256;  // (the override exists to exercise pool exhaustion in tests)
+    return (uint32_t)std::min<uint64_t>(nq, std::max<uint64_t>(floor_slots, (uint64_t)(frac * nq) + 1));
 }
 static uint32_t general_pool_slots(uint32_t nq) { return std::max<uint32_t>(64, nq / 64); }
 

@@ -1,0 +1,73 @@
+"""The search kernel has several operating points chosen from the scan statistics (LDS dedup table / frozen table with
+global overflow / table-less, register or LDS-ring visited list, heap top in LDS with spill, general-kernel fallback).
+The small indexes of the other parity tests only ever reach the first one, so every regime is forced here through the
+library's tuning variables and must produce the oracle's stream bit for bit (ids, Hamming distances, work counters)."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import cached_index
+
+pytestmark = pytest.mark.gpu
+
+REGIMES = {
+    "default": {},
+    "tableless": {"VS_F_LDS_MAX_INS": "0"},
+    "tableless_capped_regs": {"VS_F_LDS_MAX_INS": "0", "VS_F_VR": "8", "VS_F_MINW": "4"},
+    "frozen_overflow": {"VS_F_LH": "256"},
+    "lds_ring_small": {"VS_F_VR": "0", "VS_F_VCAP": "64"},
+    "heap_spill": {"VS_F_HL": "63"},
+    "heap_spill_tableless": {"VS_F_HL": "63", "VS_F_LDS_MAX_INS": "0"},
+    "tiny_pool": {"VS_F_LH": "256", "VS_F_POOL": "0.01"},
+    "general_kernel": {"VS_FAST": "0"},
+    "general_kernel_spill": {"VS_FAST": "0", "VS_HL": "64", "VS_G0": "256"},
+}
+INDEXES = {
+    "l2_R50": (dict(n=4000, dim_full=128, bits=2, R=50, distance=1, seed=1, kind="uniform", L_build=100), "uniform", 100, 50),
+    "labels_deleted": (dict(n=3000, dim_full=64, bits=2, R=32, distance=1, seed=11, kind="gauss", L_build=64, n_labels=6,
+                            deleted_frac=0.1), "gauss", 60, 30),
+}
+
+
+@pytest.fixture(scope="module")
+def regime_indexes(gpu_ctx):
+    cache = {}
+    for name, (kw, _, _, _) in INDEXES.items():
+        ti = cached_index(**kw)
+        cache[name] = (ti, ti.upload(gpu_ctx))
+    yield cache
+    for _, ix in cache.values():
+        ix.close()
+
+
+@pytest.mark.parametrize("regime", list(REGIMES))
+@pytest.mark.parametrize("iname", list(INDEXES))
+def test_every_regime_is_exact(regime_indexes, iname, regime):
+    ti, ix = regime_indexes[iname]
+    _, qkind, L, rescore = INDEXES[iname]
+    q = ti.queries(96, seed=77, kind=qkind)
+    qlabels = None
+    if ti.label_off is not None:
+        rng = np.random.default_rng(5)
+        qlabels = [sorted(set(int(v) for v in rng.integers(1, 7, int(rng.integers(1, 3))))) for _ in range(len(q))]
+    m = rescore + 15
+    oi, oh, ost = ti.oracle.stream_batch(q, L=L, m=m, qlabels=qlabels)
+    osi, osd, _ = ti.oracle.search_batch(q, L=L, rescore=rescore, k=10, qlabels=qlabels)
+    saved = {k: os.environ.get(k) for k in REGIMES[regime]}
+    try:
+        os.environ.update(REGIMES[regime])
+        for _ in range(2):  # the second call runs with the statistics the first one left behind
+            gi, gh, gst = ix.stream_batch(q, search_list_size=L, m=m, qlabels=qlabels)
+            assert (gi == oi).all() and (gh == oh).all()
+            for key in ("visited_nodes", "candidate_nodes", "quantized_distance_comparisons", "node_reads", "next_calls"):
+                assert gst[key] == ost[key], (key, gst[key], ost[key])
+            si, _, sd, _ = ix.search_batch(q, search_list_size=L, rescore=rescore, k=10, qlabels=qlabels)
+            assert (si == osi).all()
+            assert (sd.view(np.uint32) == osd.view(np.uint32)).all()
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v

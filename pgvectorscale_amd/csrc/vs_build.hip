@@ -19,6 +19,17 @@
 
 __device__ __forceinline__ uint32_t ham_words(const uint64_t* a, const uint64_t* b, uint32_t stride) {
     uint32_t acc = 0;
+    if (stride == 24) {  // 768 x 2 bit / 1536 x 1 bit: fully unrolled so the 24 loads are in flight together
+        ulonglong2 x[12], y[12];
+#pragma unroll
+        for (int t = 0; t < 12; ++t) {
+            x[t] = *reinterpret_cast<const ulonglong2*>(a + 2 * t);
+            y[t] = *reinterpret_cast<const ulonglong2*>(b + 2 * t);
+        }
+#pragma unroll
+        for (int t = 0; t < 12; ++t) acc += (uint32_t)__popcll(x[t].x ^ y[t].x) + (uint32_t)__popcll(x[t].y ^ y[t].y);
+        return acc;
+    }
     for (uint32_t w = 0; w < stride; w += 2) {
         const ulonglong2 x = *reinterpret_cast<const ulonglong2*>(a + w);
         const ulonglong2 y = *reinterpret_cast<const ulonglong2*>(b + w);

@@ -69,11 +69,50 @@ __device__ __forceinline__ void stage_codes(uint64_t* ccode, const uint64_t* __r
 __device__ uint32_t wave_prune(const uint32_t* cand_id, const uint32_t* cand_d, uint32_t C, const uint64_t* ccode,
                                const uint64_t* __restrict__ codes, uint32_t stride, uint32_t R, float max_alpha,
                                float* maxf /*LDS [C]*/, uint32_t* sel /*LDS [R]*/, int lane) {
+    const float FMAX = 3.0e38f;
+    if (ccode && stride == 24 && C <= WAVE) {
+        // register form of the same loop (768 x 2 bit / 1536 x 1 bit codes, at most one candidate per lane): lane j keeps
+        // candidate j's code, distance and max-factor in registers; only the selected candidate's code is read from LDS
+        // (a broadcast read).  Same arithmetic in the same order as the general loop below.
+        const bool mine_ok = (uint32_t)lane < C;
+        ulonglong2 mine[12];
+#pragma unroll
+        for (int t = 0; t < 12; ++t)
+            mine[t] = mine_ok ? *reinterpret_cast<const ulonglong2*>(ccode + (size_t)lane * 24 + 2 * t) : make_ulonglong2(0, 0);
+        const uint32_t myd = mine_ok ? cand_d[lane] : 0u;
+        float mymax = 0.0f;
+        uint32_t nres = 0;
+        float alpha = 1.0f;
+        while (alpha <= max_alpha && nres < R) {
+            for (uint32_t i = 0; i < C && nres < R; ++i) {
+                const float mf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mymax), (int)i));
+                if (mf > alpha) continue;
+                if ((uint32_t)lane == i) mymax = FMAX;
+                if (lane == 0) sel[nres] = i;
+                nres++;
+                if ((uint32_t)lane > i && mine_ok && !(mymax > max_alpha)) {
+                    const uint64_t* ci = ccode + (size_t)i * 24;
+                    uint32_t dij = 0;
+#pragma unroll
+                    for (int t = 0; t < 12; ++t) {
+                        const ulonglong2 c = *reinterpret_cast<const ulonglong2*>(ci + 2 * t);
+                        dij += (uint32_t)__popcll(mine[t].x ^ c.x) + (uint32_t)__popcll(mine[t].y ^ c.y);
+                    }
+                    float factor;
+                    if (dij == 0) factor = myd == 0 ? 1.0f : FMAX;
+                    else factor = (float)myd / (float)dij;
+                    mymax = fmaxf(mymax, factor);
+                }
+            }
+            alpha *= 1.2f;
+        }
+        __syncthreads();
+        return nres;
+    }
     for (uint32_t j = lane; j < C; j += WAVE) maxf[j] = 0.0f;
     __syncthreads();
     uint32_t nres = 0;
     float alpha = 1.0f;
-    const float FMAX = 3.0e38f;
     while (alpha <= max_alpha && nres < R) {
         for (uint32_t i = 0; i < C && nres < R; ++i) {
             float mf = maxf[i];

@@ -71,3 +71,35 @@ def test_every_regime_is_exact(regime_indexes, iname, regime):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+
+
+# every code-width specialisation of the search kernel (template parameter NCH = 16-byte steps per 4-lane group):
+# W = 12 -> NCH 2, W = 30 -> NCH 4, W = 48 -> NCH 6, W = 60 -> the generic LDS-resident query code (NCH 0)
+WIDTHS = {"w12": (384, 2), "w30": (960, 2), "w48": (1536, 2), "w60": (1900, 2), "w24_one_bit": (1536, 1)}
+
+
+@pytest.mark.parametrize("wname", list(WIDTHS))
+@pytest.mark.parametrize("regime", ["default", "tableless", "heap_spill"])
+def test_code_width_specialisations(gpu_ctx, wname, regime):
+    dims, bits = WIDTHS[wname]
+    ti = cached_index(n=400, dim_full=dims, bits=bits, R=16, distance=1, seed=21, kind="gauss", L_build=40)
+    ix = ti.upload(gpu_ctx)
+    q = ti.queries(24, seed=5, kind="gauss")
+    oi, oh, ost = ti.oracle.stream_batch(q, L=30, m=25)
+    osi, osd, _ = ti.oracle.search_batch(q, L=30, rescore=15, k=8)
+    saved = {k: os.environ.get(k) for k in REGIMES[regime]}
+    try:
+        os.environ.update(REGIMES[regime])
+        gi, gh, gst = ix.stream_batch(q, search_list_size=30, m=25)
+        assert (gi == oi).all() and (gh == oh).all()
+        assert gst["quantized_distance_comparisons"] == ost["quantized_distance_comparisons"]
+        si, _, sd, _ = ix.search_batch(q, search_list_size=30, rescore=15, k=8)
+        assert (si == osi).all()
+        assert (sd.view(np.uint32) == osd.view(np.uint32)).all()
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        ix.close()

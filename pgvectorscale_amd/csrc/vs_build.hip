@@ -11,6 +11,8 @@
 // out-edges are pruned, then back-edges are grouped per target (radix sort) and each target's list is re-pruned once.
 // The result is deterministic for a given (codes, parameters); it is not claimed to be edge-identical to the
 // reference's sequential build (which is itself HashSet-order dependent, AM/graph/mod.rs:317-326).
+#include <cstdlib>
+
 #include <hipcub/hipcub.hpp>
 
 #include "vs_internal.h"
@@ -301,9 +303,10 @@ struct BuildBufs {
     uint64_t *edge_pd = nullptr, *edge_pd_sorted = nullptr;
     void* cub_tmp = nullptr;
     size_t cub_bytes = 0;
+    uint32_t *f_ghash = nullptr, *f_heap = nullptr, *f_pool = nullptr;  // fast-kernel overflow table / heap spill / pool counter
     void free_all() {
         void* ps[] = {vis_ids, vis_d, vis_cnt, stats, status, hash, heap_g, edge_q, edge_q_sorted, seg_start, nseg,
-                      edge_pd, edge_pd_sorted, cub_tmp};
+                      edge_pd, edge_pd_sorted, cub_tmp, f_ghash, f_heap, f_pool};
         for (void* p : ps)
             if (p) (void)hipFree(p);
     }
@@ -355,6 +358,36 @@ static int build_graph_impl(vs_index* ix, uint32_t L, double max_alpha_d, uint32
     VS_HIP(hipMalloc(&B.cub_tmp, B.cub_bytes + 16));
     size_t hash_alloc = 0, ids_alloc = 0;
 
+    // The searches of a batch run on the LDS-resident kernel (vs_search_fast.hip, BUILD variant); the general kernel only
+    // re-runs the scans that outgrow it.  Same operating-point rule as for queries: dedup table in LDS for small graphs,
+    // table-less (global table, high occupancy) once a search inserts more ids than an LDS table should hold.
+    FastLaunch f{};
+    bool use_fast = getenv("VS_BUILD_FAST") ? atoi(getenv("VS_BUILD_FAST")) != 0 : true;
+    {
+        const uint64_t nbits = (uint64_t)ix->d.dim_index * ix->d.bits;
+        const uint32_t typ_ins = (L + L / 4 + 16) * std::min<uint32_t>(R, 16);
+        const bool lds_table = n <= 4000000u && typ_ins <= 3072;
+        f.L = L;
+        f.M = vmax;
+        f.hl = 1023;
+        f.hcap = hcap;
+        f.gstride = round_up_u32(hcap - f.hl + 2, 2);
+        f.lh = lds_table ? round_up_u32(typ_ins, 64) : 0;
+        f.gcap = next_pow2_u32(std::max<uint32_t>(4 * typ_ins, 1024));
+        f.sb = 0;
+        while ((1ull << f.sb) < (uint64_t)f.lh + f.gcap) f.sb++;
+        f.vr = 0;
+        f.vcap = vmax + 64;
+        f.minw = 1;
+        f.build = 1;
+        if (nbits >= (1ull << (32 - f.sb)) || fast_lds_bytes(ix, f) > 64 * 1024) use_fast = false;
+        if (use_fast) {
+            VS_HIP(hipMalloc(&B.f_ghash, bm * f.gcap * 4));
+            VS_HIP(hipMalloc(&B.f_heap, bm * f.gstride * 4));
+            VS_HIP(hipMalloc(&B.f_pool, 64));
+        }
+    }
+
     uint32_t b0 = 1;  // node 0 is the start node and has no one to link to yet
     uint32_t bsz = 1;
     while (b0 < n) {
@@ -393,6 +426,26 @@ static int build_graph_impl(vs_index* ix, uint32_t L, double max_alpha_d, uint32
             s.out_cnt = B.vis_cnt;
             s.stats = B.stats;
             s.status = B.status;
+            if (use_fast && attempt == 0) {
+                f.nq = bn;
+                f.hcap = hcap;
+                f.qcodes = s.qcodes;
+                f.qlabels = nullptr;
+                f.qlabel_off = nullptr;
+                f.heap_g = B.f_heap;
+                f.ghash = B.f_ghash;
+                f.pool_counter = B.f_pool;
+                f.pool_slots = bn;
+                f.out_ids = B.vis_ids;
+                f.out_ham = B.vis_d;
+                f.out_cnt = B.vis_cnt;
+                f.stats = B.stats;
+                f.status = B.status;
+                VS_HIP(hipMemsetAsync(B.f_pool, 0, 64, st));
+                VS_TRY(launch_search_fast(ix, f));
+            }
+            // after the fast kernel (or a failed attempt) only the scans whose status is non-zero are (re)run
+            s.only_failed = (use_fast || attempt > 0) ? 1u : 0u;
             VS_TRY(launch_search(ix, s, true));
             std::vector<uint32_t> status(bn);
             VS_HIP(hipMemcpyAsync(status.data(), B.status, (size_t)bn * 4, hipMemcpyDeviceToHost, st));

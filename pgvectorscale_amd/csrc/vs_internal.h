@@ -154,6 +154,7 @@ struct FastLaunch {
     uint32_t vr;       // visited list: 8 = eight register pairs (512 entries), 0 = LDS ring of vcap entries
     uint32_t vcap;     // visited ring capacity (vr == 0)
     uint32_t minw;     // register cap variant: waves per SIMD to leave room for (1 = unconstrained)
+    uint32_t build = 0; // 1: greedy_search_for_build (the visited list is the output; needs vr == 0)
     const uint64_t* qcodes;
     const int16_t* qlabels;
     const uint32_t* qlabel_off;

@@ -455,7 +455,9 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 
 // MINW = waves per SIMD the register allocator must leave room for (1 = unconstrained): in the table-less regime the
 // kernel is occupancy bound and LDS no longer limits it, so fewer VGPRs (some cold values in scratch) can pay.
-template <int NCH, int VR, bool TIMING, int MINW>
+// BUILD = greedy_search_for_build (AM/graph/mod.rs:285-327): no rows are consumed; the sorted visited list (capped at the
+// ring capacity, farthest entry dropped) is the result.
+template <int NCH, int VR, bool TIMING, int MINW, bool BUILD>
 __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
@@ -698,6 +700,7 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
                 can_visit = (top >> s.sb) < vis.ham_at(s.L - 1);
         }
         if (!can_visit) {
+            if (BUILD) break;  // greedy_search_for_build stops here: the visited list is the candidate set
             // ---- consume (AM/graph/mod.rs:174-184) + return_lsn (AM/sbq/storage.rs:404-414) ----
             if (vis.len == 0) break;  // None: the stream has ended
             uint32_t fd, fnode;
@@ -732,7 +735,10 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
             row0 = ((uint32_t)lane < a.R) ? nrow[lane] : VS_INVALID_NODE;
         }
         lap(0);
-        if (vis.len + 1 > vis.capacity()) { status |= OVF_VISITED; break; }
+        if (vis.len + 1 > vis.capacity()) {
+            if (BUILD) vis.len = vis.capacity() - 1;  // build mode keeps the closest entries as prune candidates
+            else { status |= OVF_VISITED; break; }
+        }
         st_visits++;
         // ---- visit_lsn_internal, Disk arm (AM/sbq/storage.rs:135-190) ----
         st_reads++;  // SbqNode::read(visiting)
@@ -866,6 +872,14 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
         }
         if (!pfb_issued) pfb_node = VS_INVALID_NODE;
     }
+    if (BUILD && VR == 0 && status == 0) {  // the visited list itself is the output (sorted by (hamming, recency))
+        emitted = min(vis.len, s.M);
+        for (uint32_t i = lane; i < emitted; i += WAVE) {
+            const uint64_t e = vis.ring[vis.slot(i)];
+            s.out_ids[(size_t)q * s.M + i] = (uint32_t)e;
+            s.out_ham[(size_t)q * s.M + i] = (uint32_t)(e >> 32);
+        }
+    }
     // one `next` call per emitted row, plus the call that found the stream exhausted
     const uint32_t st_next = emitted + ((emitted < s.M && status == 0) ? 1u : 0u);
     if (status == 0) {
@@ -901,38 +915,42 @@ size_t fast_lds_bytes(const vs_index* idx, const FastLaunch& s) {
     return (b + 15) / 16 * 16;
 }
 
-template <int NCH, int VR, bool TIMING, int MINW>
+template <int NCH, int VR, bool TIMING, int MINW, bool BUILD>
 static int launch_fast_tt(vs_index* idx, const FastArgs& a, size_t lds) {
     static bool attr_set = false;
     if (!attr_set) {
-        VS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_search_fast<NCH, VR, TIMING, MINW>),
+        VS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_search_fast<NCH, VR, TIMING, MINW, BUILD>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_search_fast<NCH, VR, TIMING, MINW>), dim3(a.s.nq), dim3(WAVE), lds, idx->ctx->stream, a);
+    hipLaunchKernelGGL((k_search_fast<NCH, VR, TIMING, MINW, BUILD>), dim3(a.s.nq), dim3(WAVE), lds, idx->ctx->stream, a);
     VS_HIP(hipGetLastError());
     return VS_OK;
 }
 
 template <int NCH>
 static int launch_fast_t(vs_index* idx, const FastArgs& a, size_t lds) {
+    if (a.s.build) {
+        VS_REQUIRE(a.s.vr == 0 && !a.s.phase, "build-mode search uses the LDS-ring visited list");
+        return launch_fast_tt<NCH, 0, false, 1, true>(idx, a, lds);
+    }
     if (a.s.phase) {
         VS_REQUIRE(NCH == 3 && a.s.vr == 8, "VS_PHASE diagnostics are built for 17..24-word codes / register visited list only");
-        return launch_fast_tt<3, 8, true, 1>(idx, a, lds);
+        return launch_fast_tt<3, 8, true, 1, false>(idx, a, lds);
     }
     if (a.s.vr == 8) {
         if (NCH == 3) {  // the headline geometry (768 x 2 bit, 1536 x 1 bit): register-capped variants for the occupancy-bound regime
-            if (a.s.minw == 4) return launch_fast_tt<3, 8, false, 4>(idx, a, lds);
-            if (a.s.minw == 5) return launch_fast_tt<3, 8, false, 5>(idx, a, lds);
-            if (a.s.minw == 6) return launch_fast_tt<3, 8, false, 6>(idx, a, lds);
+            if (a.s.minw == 4) return launch_fast_tt<3, 8, false, 4, false>(idx, a, lds);
+            if (a.s.minw == 5) return launch_fast_tt<3, 8, false, 5, false>(idx, a, lds);
+            if (a.s.minw == 6) return launch_fast_tt<3, 8, false, 6, false>(idx, a, lds);
         }
-        return launch_fast_tt<NCH, 8, false, 1>(idx, a, lds);
+        return launch_fast_tt<NCH, 8, false, 1, false>(idx, a, lds);
     }
     if (NCH == 3) {
-        if (a.s.minw == 6) return launch_fast_tt<3, 0, false, 6>(idx, a, lds);
-        if (a.s.minw == 8) return launch_fast_tt<3, 0, false, 8>(idx, a, lds);
+        if (a.s.minw == 6) return launch_fast_tt<3, 0, false, 6, false>(idx, a, lds);
+        if (a.s.minw == 8) return launch_fast_tt<3, 0, false, 8, false>(idx, a, lds);
     }
-    return launch_fast_tt<NCH, 0, false, 1>(idx, a, lds);
+    return launch_fast_tt<NCH, 0, false, 1, false>(idx, a, lds);
 }
 
 int launch_search_fast(vs_index* idx, const FastLaunch& s) {
@@ -955,7 +973,7 @@ int launch_search_fast(vs_index* idx, const FastLaunch& s) {
     const size_t lds = fast_lds_bytes(idx, s);
     VS_REQUIRE(lds <= 160 * 1024, "fast search state does not fit LDS (%zu B)", lds);
     VS_REQUIRE(((s.hl + 1) & s.hl) == 0 && s.hl >= 63, "fast search: hl must be 2^k - 1 >= 63");
-    VS_REQUIRE(s.vr == 8 || (s.vr == 0 && s.vcap >= 64 && s.vcap % 2 == 0),
+    VS_REQUIRE(s.vr == 8 || (s.vr == 0 && s.vcap >= 64),
                "fast search: visited list must be 8 register pairs or a ring of >= 64 entries");
     VS_REQUIRE(s.lh % 4 == 0 && (s.lh == 0 || s.lh >= 256) && (s.gcap & (s.gcap - 1)) == 0 && s.gcap >= 256 &&
                    (uint64_t)s.lh + s.gcap <= (1ull << s.sb) && s.hcap >= s.hl && s.gstride % 2 == 0 &&

@@ -149,6 +149,69 @@ int vs_index_refresh_norms(vs_index* idx);
 /* mark heap tuples deleted (what ambulkdelete does to heap_item_pointer, AM/vacuum.rs:24-78) */
 int vs_index_mark_deleted(vs_index* idx, const uint32_t* nodes, uint32_t n);
 
+/* ---- index relation pages -> vs_index_host (the exporter the arrays above come from) ------
+ * The reference reaches a node through the buffer manager, one page pin per neighbor (ItemPointer::read_bytes,
+ * util/mod.rs:152-155; ReadablePage::get_item_unchecked, util/page.rs:270-283; rkyv::archived_root,
+ * pgvectorscale_derive/src/lib.rs:35-40).  Here the blocks of the index relation's main fork are handed over in bulk,
+ * in block order (from ReadBufferExtended copies, or straight from the relation's segment files after a CHECKPOINT);
+ * every SbqNode item (AM/sbq/node.rs:26-42) is decoded on the host cores into the flat arrays, neighbor ItemPointers
+ * become dense node ids (node id = SbqNode items on earlier blocks + offset - 1), and vs_index_upload streams the
+ * result to HBM.  Host-only code: these calls work without a device. */
+#define VS_BLCKSZ 8192u
+enum vs_page_type { /* PageType, util/page.rs:28-39 */
+    VS_PAGE_META_V1 = 0, VS_PAGE_NODE = 1, VS_PAGE_PQ_QUANTIZER_DEF = 2, VS_PAGE_PQ_QUANTIZER_VECTOR = 3,
+    VS_PAGE_SBQ_MEANS_V1 = 4, VS_PAGE_SBQ_NODE = 5, VS_PAGE_META_V2 = 6, VS_PAGE_SBQ_MEANS = 7, VS_PAGE_META = 8 };
+
+/* Byte offsets of the fields inside the archived root object of an SbqNode item (the last root_size bytes of the
+ * item).  rkyv 0.7 archives ClassicSbqNode / LabeledSbqNode as repr(Rust) structs of four 8-byte, 4-aligned fields;
+ * vs_node_layout_default() assumes declaration order.  Nothing in the reference pins that order, so a PGRX shim
+ * should pass core::mem::offset_of!(ArchivedLabeledSbqNode, ...) values instead. */
+typedef struct vs_node_layout {
+    uint32_t root_size;                   /* size_of::<ArchivedClassicSbqNode>() = 32                       */
+    uint32_t off_heap_item_pointer;       /* ArchivedItemPointer {u32 block_number, u16 offset} (util/mod.rs:17-23) */
+    uint32_t off_bq_vector;               /* ArchivedVec<u64>  = {i32 relative offset, u32 len}              */
+    uint32_t off_neighbor_index_pointers; /* ArchivedVec<ArchivedItemPointer>                                */
+    uint32_t off_labels;                  /* ArchivedLabelSet = ArchivedVec<i16> (LabeledSbqNode); 0xFFFFFFFF otherwise */
+} vs_node_layout;
+int vs_node_layout_default(int has_labels, vs_node_layout* out);
+
+typedef struct vs_pages_info {
+    uint32_t n_blocks;
+    uint32_t n_nodes;          /* -> vs_index_desc.n                                                          */
+    uint32_t words;            /* bq_vector.len() of every node -> vs_index_desc.words                        */
+    uint32_t num_neighbors;    /* neighbor_index_pointers.len() of every node -> vs_index_desc.num_neighbors  */
+    uint32_t has_labels;
+    uint32_t n_deleted;        /* nodes whose heap_item_pointer.offset == InvalidOffsetNumber                 */
+    uint64_t n_label_vals;
+    uint32_t pages_by_type[9]; /* indexed by vs_page_type                                                     */
+    uint32_t new_pages;        /* all-zero blocks (PageIsNew)                                                 */
+    uint32_t meta_magic;       /* MetaPageHeader (block 0, item 1; AM/meta_page.rs:166-174), 0 if block 0 is no meta page */
+    uint32_t meta_version;
+} vs_pages_info;
+
+typedef struct vs_pages vs_pages; /* reader over the main fork of one diskann index relation */
+/* has_labels = MetaPage.has_labels (selects LabeledSbqNode); layout NULL = vs_node_layout_default; threads 0 = all cores (<= 32) */
+int vs_pages_open(uint32_t page_size, int has_labels, const vs_node_layout* layout, uint32_t threads, vs_pages** out);
+/* append blocks first_block .. first_block+n_blocks-1 (must continue where the previous call stopped; the bytes are
+ * not referenced after the call returns).  A failing call leaves the reader unchanged. */
+int vs_pages_add(vs_pages* p, uint32_t first_block, const void* pages, uint32_t n_blocks);
+/* translate neighbor ItemPointers to node ids, check the MetaPageHeader magic; info may be NULL */
+int vs_pages_finish(vs_pages* p, vs_pages_info* info);
+/* borrowed pointers (valid until vs_pages_close): codes, nbrs, nbr_stride, heap_tids, label_off, label_val; the
+ * caller fills vecs (heap column), mean / m2 / count (vs_pages_sbq_means) and the start-node arrays, then calls
+ * vs_index_upload */
+int vs_pages_host(const vs_pages* p, vs_index_host* host);
+/* IndexPointer <-> node id (start nodes of the MetaPage, AM/graph/start_nodes.rs:17-22) */
+int vs_pages_node_of(const vs_pages* p, uint32_t block, uint32_t offset, uint32_t* node);
+int vs_pages_item_pointer_of(const vs_pages* p, uint32_t node, uint32_t* block, uint32_t* offset);
+/* ChainItemIterator (util/chain.rs:159-185): concatenated payload of the chain that starts at (block, offset);
+ * page_type VS_PAGE_SBQ_MEANS or VS_PAGE_META; buf may be NULL to query *len */
+int vs_pages_read_chain(const vs_pages* p, uint32_t block, uint32_t offset, int page_type, void* buf, size_t cap, size_t* len);
+/* SbqMeans::load (AM/sbq/mod.rs:85-121) at MetaPage.quantizer_metadata: chained SbqMeans or single-item SbqMeansV1 */
+int vs_pages_sbq_means(const vs_pages* p, uint32_t block, uint32_t offset, float* mean, float* m2, uint32_t dim_cap,
+                       uint32_t* dim, uint64_t* count);
+void vs_pages_close(vs_pages* p);
+
 /* ---- K4: SBQ quantisation of queries (SbqQuantizer::quantize, AM/sbq/quantize.rs:52-102) --------------------- */
 /* q: host [nq][dim_index], already cosine-normalised by the caller if applicable; out: host [nq][words] */
 int vs_quantize(vs_index* idx, const float* q, uint32_t nq, uint64_t* out_codes);

@@ -40,6 +40,18 @@ class Stats(C.Structure):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
 
 
+class NodeLayout(C.Structure):
+    _fields_ = [(k, C.c_uint32) for k in ("root_size", "off_heap_item_pointer", "off_bq_vector",
+                                          "off_neighbor_index_pointers", "off_labels")]
+
+
+class PagesInfo(C.Structure):
+    _fields_ = [("n_blocks", C.c_uint32), ("n_nodes", C.c_uint32), ("words", C.c_uint32), ("num_neighbors", C.c_uint32),
+                ("has_labels", C.c_uint32), ("n_deleted", C.c_uint32), ("n_label_vals", C.c_uint64),
+                ("pages_by_type", C.c_uint32 * 9), ("new_pages", C.c_uint32), ("meta_magic", C.c_uint32),
+                ("meta_version", C.c_uint32)]
+
+
 class Profile(C.Structure):
     _fields_ = [("ms", C.c_double * 8), ("launches", C.c_uint64 * 8)]
 
@@ -78,6 +90,16 @@ SYMBOLS = {
     "vs_index_download": (_i, [_vp, _vp, _vp, _vp, _vp, _u32, _u32]),
     "vs_index_refresh_norms": (_i, [_vp]),
     "vs_index_mark_deleted": (_i, [_vp, _vp, _u32]),
+    "vs_node_layout_default": (_i, [_i, C.POINTER(NodeLayout)]),
+    "vs_pages_open": (_i, [_u32, _i, C.POINTER(NodeLayout), _u32, C.POINTER(_vp)]),
+    "vs_pages_add": (_i, [_vp, _u32, _vp, _u32]),
+    "vs_pages_finish": (_i, [_vp, C.POINTER(PagesInfo)]),
+    "vs_pages_host": (_i, [_vp, C.POINTER(IndexHost)]),
+    "vs_pages_node_of": (_i, [_vp, _u32, _u32, C.POINTER(_u32)]),
+    "vs_pages_item_pointer_of": (_i, [_vp, _u32, C.POINTER(_u32), C.POINTER(_u32)]),
+    "vs_pages_read_chain": (_i, [_vp, _u32, _u32, _i, _vp, _sz, C.POINTER(_sz)]),
+    "vs_pages_sbq_means": (_i, [_vp, _u32, _u32, _vp, _vp, _u32, C.POINTER(_u32), C.POINTER(_u64)]),
+    "vs_pages_close": (None, [_vp]),
     "vs_quantize": (_i, [_vp, _vp, _u32, _vp]),
     "vs_hamming_gather": (_i, [_vp, _vp, _vp, _vp, _u32, _vp]),
     "vs_rerank": (_i, [_vp, _vp, _vp, _vp, _u32, _vp]),

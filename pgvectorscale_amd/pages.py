@@ -1,0 +1,162 @@
+"""Index relation pages -> an index resident in HBM (host-side mirror of the vs_pages_* calls of include/vsgpu.h).
+
+`IndexPages` stands for the main fork of a `diskann` index relation (Meta chain on block 0, SbqMeans chain, SbqNode
+pages; UT/page.rs:28-39).  Blocks are appended in block order, decoded by libvsgpu on the host cores into the flat
+arrays of `vs_index_host`, and `upload()` streams them to the device through the pinned staging ring.  What is NOT
+read from the pages is what the reference itself keeps elsewhere or only the Rust side can decode: the heap's vector
+column (`vecs`, needed for rerank) and the MetaPage body (geometry and start nodes are passed as arguments).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import IndexDesc, IndexHost, NodeLayout, PagesInfo, check
+
+BLCKSZ = 8192
+PAGE_SBQ_MEANS, PAGE_META = 7, 8
+
+
+class IndexPages:
+    def __init__(self, has_labels=False, page_size=BLCKSZ, layout=None, threads=0):
+        self._L = _lib.load()
+        h = C.c_void_p()
+        lay = None
+        if layout is not None:
+            lay = NodeLayout(*layout)
+        check(self._L.vs_pages_open(page_size, int(has_labels), None if lay is None else C.byref(lay), threads, C.byref(h)))
+        self.h = h
+        self.page_size = page_size
+        self.has_labels = bool(has_labels)
+        self.n_blocks = 0
+        self.info = None
+
+    @staticmethod
+    def default_layout(has_labels):
+        lay = NodeLayout()
+        check(_lib.load().vs_node_layout_default(int(has_labels), C.byref(lay)))
+        return tuple(int(getattr(lay, k)) for k, _ in NodeLayout._fields_)
+
+    def add(self, pages, first_block=None):
+        """Append whole blocks (bytes-like, a multiple of page_size long)."""
+        buf = np.frombuffer(pages, np.uint8)
+        if buf.size % self.page_size:
+            raise ValueError(f"{buf.size} bytes is not a whole number of {self.page_size}-byte pages")
+        nb = buf.size // self.page_size
+        fb = self.n_blocks if first_block is None else first_block
+        check(self._L.vs_pages_add(self.h, fb, buf.ctypes.data_as(C.c_void_p), nb))
+        self.n_blocks += nb
+
+    def add_file(self, path, chunk_blocks=16384):
+        """Append a relation segment file (base/<db>/<relfilenode>[.N]) chunk by chunk."""
+        with open(path, "rb") as f:
+            while True:
+                b = f.read(chunk_blocks * self.page_size)
+                if not b:
+                    break
+                self.add(b)
+
+    def finish(self):
+        info = PagesInfo()
+        check(self._L.vs_pages_finish(self.h, C.byref(info)))
+        self.info = info
+        return info
+
+    def node_of(self, block, offset):
+        """IndexPointer -> node id (e.g. the MetaPage's start nodes)."""
+        out = C.c_uint32()
+        check(self._L.vs_pages_node_of(self.h, block, offset, C.byref(out)))
+        return int(out.value)
+
+    def item_pointer_of(self, node):
+        b, o = C.c_uint32(), C.c_uint32()
+        check(self._L.vs_pages_item_pointer_of(self.h, node, C.byref(b), C.byref(o)))
+        return int(b.value), int(o.value)
+
+    def read_chain(self, block, offset, page_type):
+        n = C.c_size_t()
+        check(self._L.vs_pages_read_chain(self.h, block, offset, page_type, None, 0, C.byref(n)))
+        buf = np.empty(int(n.value), np.uint8)
+        check(self._L.vs_pages_read_chain(self.h, block, offset, page_type, buf.ctypes.data_as(C.c_void_p), buf.size,
+                                          C.byref(n)))
+        return buf.tobytes()
+
+    def sbq_means(self, block, offset):
+        """SbqMeans::load at MetaPage.quantizer_metadata -> (count, mean, m2)"""
+        dim, cnt = C.c_uint32(), C.c_uint64()
+        check(self._L.vs_pages_sbq_means(self.h, block, offset, None, None, 0, C.byref(dim), C.byref(cnt)))
+        mean = np.empty(dim.value, np.float32)
+        m2 = np.empty(dim.value, np.float32)
+        check(self._L.vs_pages_sbq_means(self.h, block, offset, mean.ctypes.data_as(C.c_void_p),
+                                         m2.ctypes.data_as(C.c_void_p), dim.value, C.byref(dim), C.byref(cnt)))
+        return int(cnt.value), mean, m2
+
+    def _host(self):
+        if self.info is None:
+            self.finish()
+        h = IndexHost()
+        check(self._L.vs_pages_host(self.h, C.byref(h)))
+        return h
+
+    def arrays(self):
+        """Copies of the decoded flat arrays (tests / inspection)."""
+        h = self._host()
+        n, W, R = self.info.n_nodes, self.info.words, self.info.num_neighbors
+
+        def view(ptr, dtype, count):
+            if not ptr or count == 0:
+                return np.zeros(0, dtype)
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(np.ctypeslib.as_ctypes_type(dtype))), (count,)).copy()
+
+        out = {"codes": view(h.codes, np.uint64, n * W).reshape(n, W), "nbrs": view(h.nbrs, np.uint32, n * R).reshape(n, R),
+               "heap_tids": view(h.heap_tids, np.uint64, n)}
+        if self.has_labels:
+            out["label_off"] = view(h.label_off, np.uint32, n + 1)
+            out["label_val"] = view(h.label_val, np.int16, int(self.info.n_label_vals))
+        return out
+
+    def upload(self, ctx, *, dim_index, bits, distance_type, default_start, quantizer_metadata=None, mean=None, m2=None,
+               count=0, vecs=None, label_starts=None):
+        """vs_index_upload of the decoded arrays.  default_start / label_starts values are IndexPointers (block, offset)
+        or node ids; quantizer_metadata is the IndexPointer of the SbqMeans chain (or pass mean / m2 / count)."""
+        from .index import DiskAnnIndex
+        h = self._host()
+        info = self.info
+        if quantizer_metadata is not None:
+            count, mean, m2 = self.sbq_means(*quantizer_metadata)
+        mean = np.ascontiguousarray(mean, np.float32)
+        m2 = None if m2 is None else np.ascontiguousarray(m2, np.float32)
+        vecs = None if vecs is None else np.ascontiguousarray(vecs, np.float32)
+
+        def node(x):
+            return self.node_of(*x) if isinstance(x, tuple) else int(x)
+
+        d = IndexDesc()
+        d.n, d.dim_index, d.bits, d.words = info.n_nodes, dim_index, bits, info.words
+        d.dim_full = dim_index if vecs is None else vecs.shape[1]
+        d.num_neighbors, d.distance_type, d.has_labels = info.num_neighbors, distance_type, int(self.has_labels)
+        d.default_start = _lib.VS_INVALID_NODE if default_start is None else node(default_start)
+        ls = sorted((int(k), node(v)) for k, v in (label_starts or {}).items())
+        d.n_label_starts = len(ls)
+        lsl = np.array([k for k, _ in ls], np.int16)
+        lsn = np.array([v for _, v in ls], np.uint32)
+        h.vecs = None if vecs is None else vecs.ctypes.data
+        h.mean = mean.ctypes.data
+        h.m2 = None if m2 is None else m2.ctypes.data
+        h.count = count
+        h.label_start_labels = lsl.ctypes.data if ls else None
+        h.label_start_nodes = lsn.ctypes.data if ls else None
+        out = C.c_void_p()
+        check(ctx._L.vs_index_upload(ctx.h, C.byref(d), C.byref(h), C.byref(out)))
+        return DiskAnnIndex(ctx, out)
+
+    def close(self):
+        if self.h:
+            self._L.vs_pages_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -45,7 +45,8 @@ def main():
     ix.refresh_norms()
     ix.sbq_train()
     ix.sbq_quantize_corpus()
-    cache = args.graph_cache and f"{args.graph_cache}.{args.n}x{args.dim}.l2.L100.r0"
+    # same file name as bench.py's graph_cache_path() for an explicit prefix
+    cache = args.graph_cache and f"{args.graph_cache}.{args.n}x{args.dim}.l2.b{ix.desc.bits}.R50.L100.s{seed}"
     if cache and os.path.exists(cache) and args.kind == "clustered":
         ix.load_graph(cache)
     else:

@@ -1,0 +1,300 @@
+// TEST INFRASTRUCTURE ONLY — scheduler of the wave64 lockstep interpreter (see fake/hip/hip_runtime.h).
+//
+// One GPU thread = one fiber with its own stack; the fibers of a workgroup are scheduled round-robin on ONE host thread
+// and only switch at cross-lane operations / barriers, so everything between two such points runs lane after lane — the
+// same result as lockstep execution provided lanes do not communicate through memory without a wave barrier in between
+// (the product kernels put wave_sync() there because the compiler needs it too).  Workgroups are independent and are
+// spread over host threads (VS_EMU_THREADS, default: all cores); global atomics are real atomics.
+#include <hip/hip_runtime.h>
+#include <sys/mman.h>
+
+#include <dlfcn.h>
+#include <execinfo.h>
+#include <signal.h>
+#include <ucontext.h>
+
+#include <mutex>
+#include <thread>
+
+namespace emu {
+
+thread_local Fiber* cur = nullptr;
+
+struct Wave {
+    uint64_t vals[2][64];
+    uint64_t snap_active[2];
+    uint64_t arrived = 0, live = 0;
+    uint32_t gen = 0;
+    const char* file = nullptr;
+    int line = 0;
+};
+struct Block {
+    uint32_t live = 0, arrived = 0, gen = 0;
+    const char* file = nullptr;
+    int line = 0;
+};
+
+}  // namespace emu
+
+// the dynamic LDS segment every kernel declares as `extern __shared__ unsigned char smem[]`
+thread_local __attribute__((aligned(64))) unsigned char smem[160 * 1024];
+
+// void emu_switch(void** save_sp, void* load_sp): callee-saved registers + stack pointer (System V x86-64)
+extern "C" void emu_switch(void** save_sp, void* load_sp);
+asm(R"(
+    .text
+    .globl emu_switch
+    .type emu_switch,@function
+emu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+    .size emu_switch,.-emu_switch
+)");
+
+namespace emu {
+
+static constexpr size_t kStackBytes = 512 * 1024;
+static constexpr int kMaxThreadsPerBlock = 1024;
+
+struct Worker {
+    void* sched_sp = nullptr;
+    char* stacks = nullptr;  // kMaxThreadsPerBlock stacks, committed lazily
+    void (*thunk)(void*) = nullptr;
+    void* ctx = nullptr;
+    ~Worker() {
+        if (stacks) munmap(stacks, kStackBytes * kMaxThreadsPerBlock);
+    }
+};
+static thread_local Worker tl_worker;
+
+[[noreturn]] static void die(const char* what, const char* f1, int l1, const char* f2, int l2) {
+    fprintf(stderr, "emu: %s\n  at %s:%d\n  vs %s:%d\n", what, f1 ? f1 : "?", l1, f2 ? f2 : "?", l2);
+    abort();
+}
+
+static void yield_to_scheduler() { emu_switch(&cur->sp, tl_worker.sched_sp); }
+
+static void wave_release(Wave* w) {
+    w->snap_active[w->gen & 1] = w->arrived;
+    w->arrived = 0;
+    w->gen++;
+}
+
+Snap wave_exchange(uint64_t v, const char* file, int line) {
+    Fiber* f = cur;
+    Wave* w = f->wave;
+    const uint32_t g = w->gen;
+    const int buf = g & 1;
+    if (w->arrived == 0) {
+        w->file = file;
+        w->line = line;
+    } else if (w->line != line || w->file != file) {
+        die("lanes of one wave reached different cross-lane operations (divergent control flow around a wave collective)", file, line,
+            w->file, w->line);
+    }
+    w->vals[buf][f->lane] = v;
+    w->arrived |= 1ull << f->lane;
+    if (w->arrived == w->live) {
+        wave_release(w);
+    } else {
+        f->state = 1;
+        f->wait_gen = g;
+        yield_to_scheduler();
+    }
+    return Snap{w->vals[buf], w->snap_active[buf]};
+}
+
+void block_barrier(const char* file, int line) {
+    Fiber* f = cur;
+    Block* b = f->block;
+    const uint32_t g = b->gen;
+    if (b->arrived == 0) {
+        b->file = file;
+        b->line = line;
+    } else if (b->line != line || b->file != file) {
+        die("threads of one workgroup reached different __syncthreads()", file, line, b->file, b->line);
+    }
+    b->arrived++;
+    if (b->arrived == b->live) {
+        b->arrived = 0;
+        b->gen++;
+    } else {
+        f->state = 2;
+        f->wait_gen = g;
+        yield_to_scheduler();
+    }
+}
+
+static void fiber_main() {
+    Fiber* f = cur;
+    tl_worker.thunk(tl_worker.ctx);
+    // the thread has left the kernel: it no longer takes part in collectives / barriers
+    f = cur;
+    Wave* w = f->wave;
+    w->live &= ~(1ull << f->lane);
+    if (w->arrived && w->arrived == w->live) wave_release(w);
+    Block* b = f->block;
+    b->live--;
+    if (b->arrived && b->arrived == b->live) {
+        b->arrived = 0;
+        b->gen++;
+    }
+    f->state = 3;
+    yield_to_scheduler();
+    abort();  // a finished fiber is never resumed
+}
+
+static void run_block(Worker& wk, Idx bid, dim3 block, dim3 grid, std::vector<Fiber>& fibers, std::vector<Wave>& waves) {
+    const uint32_t nthreads = block.x * block.y * block.z;
+    const uint32_t nwaves = (nthreads + 63) / 64;
+    Block blk;
+    blk.live = nthreads;
+    for (uint32_t w = 0; w < nwaves; ++w) {
+        waves[w] = Wave();
+        const uint32_t in_wave = std::min(64u, nthreads - w * 64);
+        waves[w].live = in_wave == 64 ? ~0ull : ((1ull << in_wave) - 1);
+    }
+    for (uint32_t t = 0; t < nthreads; ++t) {
+        Fiber& f = fibers[t];
+        f.tid = Idx{t % block.x, (t / block.x) % block.y, t / (block.x * block.y)};
+        f.bid = bid;
+        f.bdim = Idx{block.x, block.y, block.z};
+        f.gdim = Idx{grid.x, grid.y, grid.z};
+        f.lane = (int)(t & 63);
+        f.wave = &waves[t >> 6];
+        f.block = &blk;
+        f.state = 0;
+        f.stack = wk.stacks + (size_t)t * kStackBytes;
+        // initial frame: six callee-saved registers, the entry point, and a slot that keeps the ABI's stack alignment
+        uint64_t* top = reinterpret_cast<uint64_t*>(f.stack + kStackBytes);
+        top[-1] = 0;
+        top[-2] = reinterpret_cast<uint64_t>(&fiber_main);
+        for (int r = 3; r <= 8; ++r) top[-r] = 0;
+        f.sp = top - 8;
+    }
+    uint32_t done = 0;
+    while (done < nthreads) {
+        bool progress = false;
+        for (uint32_t t = 0; t < nthreads; ++t) {
+            Fiber& f = fibers[t];
+            if (f.state == 3) continue;
+            if (f.state == 1 && f.wave->gen == f.wait_gen) continue;
+            if (f.state == 2 && blk.gen == f.wait_gen) continue;
+            f.state = 0;
+            cur = &f;
+            emu_switch(&wk.sched_sp, f.sp);
+            progress = true;
+            if (f.state == 3) done++;
+        }
+        if (!progress) {
+            // every remaining thread waits for someone who will never arrive
+            for (uint32_t t = 0; t < nthreads; ++t)
+                if (fibers[t].state == 1)
+                    die("deadlock: part of a wave waits at a cross-lane operation the other lanes never reach", fibers[t].wave->file,
+                        fibers[t].wave->line, blk.file, blk.line);
+            die("deadlock at __syncthreads()", blk.file, blk.line, nullptr, 0);
+        }
+    }
+    cur = nullptr;
+}
+
+static void on_segv(int sig, siginfo_t* si, void* uc_) {
+    ucontext_t* uc = static_cast<ucontext_t*>(uc_);
+    Dl_info di{};
+    void* pc = (void*)uc->uc_mcontext.gregs[REG_RIP];
+    dladdr(pc, &di);
+    fprintf(stderr, "emu: fault address %p, pc %p = %s+0x%lx (%s)\n", si->si_addr, pc, di.dli_fname ? di.dli_fname : "?",
+            (unsigned long)((char*)pc - (char*)di.dli_fbase), di.dli_sname ? di.dli_sname : "?");
+    void** sp = (void**)uc->uc_mcontext.gregs[REG_RSP];
+    for (int i = 0; i < 6; ++i) {
+        Dl_info d2{};
+        if (dladdr(sp[i], &d2) && d2.dli_fname)
+            fprintf(stderr, "emu:   stack[%d] = %p = %s+0x%lx (%s)\n", i, sp[i], d2.dli_fname, (unsigned long)((char*)sp[i] - (char*)d2.dli_fbase),
+                    d2.dli_sname ? d2.dli_sname : "?");
+    }
+    void* frames[48];
+    const int n = backtrace(frames, 48);
+    fprintf(stderr, "emu: signal %d in GPU thread (%u,%u,%u) of workgroup (%u,%u,%u)\n", sig, cur ? cur->tid.x : 0, cur ? cur->tid.y : 0,
+            cur ? cur->tid.z : 0, cur ? cur->bid.x : 0, cur ? cur->bid.y : 0, cur ? cur->bid.z : 0);
+    backtrace_symbols_fd(frames, n, 2);
+    _exit(139);
+}
+
+void run_grid(dim3 grid, dim3 block, size_t lds_bytes, void (*thunk)(void*), void* ctx) {
+    static const bool trace = [] {
+        const char* e = getenv("VS_EMU_TRACE");
+        if (e && *e) {
+            static char altstack[1 << 16];
+            stack_t ss{};
+            ss.ss_sp = altstack;
+            ss.ss_size = sizeof altstack;
+            sigaltstack(&ss, nullptr);
+            struct sigaction sa{};
+            sa.sa_sigaction = on_segv;
+            sa.sa_flags = SA_ONSTACK | SA_SIGINFO;
+            sigaction(SIGSEGV, &sa, nullptr);
+            sigaction(SIGBUS, &sa, nullptr);
+            return true;
+        }
+        return false;
+    }();
+    if (trace) fprintf(stderr, "emu: launch grid (%u,%u,%u) block (%u,%u,%u) lds %zu\n", grid.x, grid.y, grid.z, block.x, block.y, block.z, lds_bytes);
+    const uint32_t nthreads = block.x * block.y * block.z;
+    if (nthreads == 0 || nthreads > (uint32_t)kMaxThreadsPerBlock || lds_bytes > sizeof(smem)) {
+        fprintf(stderr, "emu: unsupported launch (%u threads per workgroup, %zu B LDS)\n", nthreads, lds_bytes);
+        abort();
+    }
+    const uint64_t nblocks = (uint64_t)grid.x * grid.y * grid.z;
+    if (nblocks == 0) return;
+    static const uint32_t max_threads = [] {
+        const char* e = getenv("VS_EMU_THREADS");
+        const uint32_t hw = std::max(1u, std::thread::hardware_concurrency());
+        return e && *e ? std::max(1u, (uint32_t)atoi(e)) : hw;
+    }();
+    std::atomic<uint64_t> next{0};
+    auto body = [&]() {
+        Worker& wk = tl_worker;
+        if (!wk.stacks) {
+            void* m = mmap(nullptr, kStackBytes * kMaxThreadsPerBlock, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+            if (m == MAP_FAILED) {
+                perror("emu: mmap of fiber stacks");
+                abort();
+            }
+            wk.stacks = static_cast<char*>(m);
+        }
+        wk.thunk = thunk;
+        wk.ctx = ctx;
+        std::vector<Fiber> fibers(nthreads);
+        std::vector<Wave> waves((nthreads + 63) / 64);
+        for (;;) {
+            const uint64_t b = next.fetch_add(1);
+            if (b >= nblocks) break;
+            memset(smem, 0xCD, std::min(sizeof(smem), lds_bytes + 4096));  // LDS is not zero initialised
+            const Idx bid{(unsigned)(b % grid.x), (unsigned)((b / grid.x) % grid.y), (unsigned)(b / ((uint64_t)grid.x * grid.y))};
+            run_block(wk, bid, block, grid, fibers, waves);
+        }
+    };
+    const uint32_t T = (uint32_t)std::min<uint64_t>(max_threads, nblocks);
+    if (T <= 1) {
+        body();
+        return;
+    }
+    std::vector<std::thread> pool;
+    for (uint32_t t = 0; t < T; ++t) pool.emplace_back(body);
+    for (auto& th : pool) th.join();
+}
+
+}  // namespace emu

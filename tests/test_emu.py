@@ -1,0 +1,43 @@
+"""Kernel SOURCE parity without a GPU: the `-m gpu` parity tests re-run in a child process against
+tests/emu/libvsgpu_emu.so — the unmodified product sources (pgvectorscale_amd/csrc/*.hip) compiled for the host on top
+of a wave64 lockstep interpreter (tests/emu/fake/hip/hip_runtime.h, tests/emu/emu_rt.cpp: one fiber per GPU thread,
+rendezvous at every cross-lane operation).  The interpreter is test infrastructure: it checks what the kernels COMPUTE
+(heap mechanics, dedup, visited list, DPP / ballot logic, accumulation order) against the oracle when no MI355X is at
+hand; it says nothing about speed, registers or memory-model races, and the product never loads it.  The GPU tier
+(`-m gpu`, real hardware through the real libvsgpu.so) remains the parity gate.
+
+Default: a subset that finishes in well under a minute on 8 cores.  VS_EMU_FULL=1: the whole `-m gpu` suite (about 3 minutes on 8 cores).
+"""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU_DIR = os.path.join(ROOT, "tests", "emu")
+
+SUBSET = ("test_hip_path_reproduces_golden or test_index_from_pages_searches_like_the_oracle or "
+          "(test_every_regime_is_exact and labels_deleted) or (test_search_rows_match_oracle and (cosine_768 or tiny_L)) or "
+          "(test_sbq_stream_bit_exact and (three_bits or big_R)) or (test_rerank_matches_reference_order and 100) or "
+          "test_scan_topk or test_train_and_quantize_corpus_bit_exact or test_deleted_label_null_and_exhaustive")
+
+
+@pytest.fixture(scope="module")
+def emu_lib():
+    if os.environ.get("VS_EMU"):
+        pytest.skip("already inside the emulated run")
+    r = subprocess.run(["make", "-C", EMU_DIR, "-j8", "-s"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    return os.path.join(EMU_DIR, "libvsgpu_emu.so")
+
+
+def test_gpu_parity_tests_pass_on_the_wave64_interpreter(emu_lib):
+    env = dict(os.environ, VS_EMU="1")
+    cmd = [sys.executable, "-m", "pytest", os.path.join(ROOT, "tests"), "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider"]
+    if not os.environ.get("VS_EMU_FULL"):
+        cmd += ["-k", SUBSET]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, cwd=ROOT, timeout=3000)
+    tail = (r.stdout + r.stderr)[-3000:]
+    assert r.returncode == 0, tail
+    assert " passed" in r.stdout and "failed" not in r.stdout, tail

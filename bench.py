@@ -67,6 +67,56 @@ def graph_cache_path(args, n, dim, seed, bits, R):
     return path
 
 
+def choose_operating_point(run_sample, k, target, sweep_log, err_type=Exception):
+    """Cheapest (search_list_size, rescore) whose recall on the sample reaches `target`.
+
+    Both knobs are the reference's query-time GUCs (diskann.query_search_list_size, diskann.query_rescore,
+    AM/guc.rs:3-4).  Cost model of one scan: its MEASURED expansions (about 1.1 L before the first row + one per further
+    row of the stream, M = rescore + k - 1 rows) plus one f32 row per stream entry for the rerank (about 0.12 of an
+    expansion at 768 dims, from the kernel times of earlier runs).  Every grid point is tried on the recall sample (one
+    launch of a thousand scans, milliseconds); the cheapest one that reaches the target is taken and its rescore is then
+    bisected towards the next smaller grid value.  run_sample(L, S) -> (recall, stats dict).  Returns (L, S, recall);
+    when nothing reaches the target, the point with the best recall."""
+    tried = {}
+
+    def cost_of(st, S):
+        return st["visited_nodes"] / max(st["queries"], 1) + 0.12 * (S + k - 1 if S else k)
+
+    def try_point(cl, cs):
+        if (cl, cs) not in tried:
+            try:
+                r_, st_ = run_sample(cl, cs)
+                tried[(cl, cs)] = (r_, cost_of(st_, cs))
+                sweep_log.append((cl, cs, round(r_, 4)))
+                log(f"recall sweep L={cl} rescore={cs}: recall@{k}={r_:.4f} cost={tried[(cl, cs)][1]:.1f}")
+            except err_type as e:
+                tried[(cl, cs)] = (0.0, float("inf"))
+                log(f"L={cl} rescore={cs}: {e}")
+        return tried[(cl, cs)]
+
+    s_grid = [25, 50, 100, 200, 400]
+    for cl in (50, 75, 100, 150, 200, 400):
+        for cs in s_grid:
+            r_, _ = try_point(cl, cs)
+            if r_ >= target:
+                break  # a larger rescore at this L only costs more
+    ok = [(c_, p_) for p_, (r_, c_) in tried.items() if r_ >= target]
+    if not ok:
+        (L, S), (rec, _) = max(tried.items(), key=lambda kv: kv[1][0])
+        log(f"WARNING: recall target {target} not reached; using best L={L} rescore={S} ({rec:.4f})")
+        return L, S, rec
+    _, (L, S) = min(ok)
+    lo = max([x for x in s_grid if x < S], default=0)  # the last grid value that failed at this L (or 0)
+    while S - lo > max(4, S // 16):
+        mid = (lo + S) // 2
+        r_, _ = try_point(L, mid)
+        if r_ >= target:
+            S = mid
+        else:
+            lo = mid
+    return L, S, tried[(L, S)][0]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -209,32 +259,14 @@ def main():
         rec = float(np.mean([len(set(got[i].tolist()) & set(gt[i].tolist())) / k for i in range(nr)]))
         return rec, st
 
-    # ---- recall sweep: cheapest (L, rescore) reaching the target ---------------------------------------------------
+    # ---- recall sweep: cheapest (L, rescore) reaching the target (choose_operating_point) --------------------------
     sweep_log = []
     if args.fixed:
         L, S = (int(x) for x in args.fixed.split(","))
         rec, st = run_sample(L, S)
         sweep_log.append((L, S, round(rec, 4)))
     else:
-        L = S = None
-        cand = [(100, 50), (100, 100), (100, 200), (150, 150), (200, 200), (200, 400), (300, 300), (400, 400)]
-        best = None
-        for (cl, cs) in cand:
-            try:
-                rec, st = run_sample(cl, cs)
-            except P.VsError as e:
-                log(f"L={cl} rescore={cs}: {e}")
-                continue
-            sweep_log.append((cl, cs, round(rec, 4)))
-            log(f"recall sweep L={cl} rescore={cs}: recall@{k}={rec:.4f}")
-            if best is None or rec > best[2]:
-                best = (cl, cs, rec)
-            if rec >= args.recall_target:
-                L, S = cl, cs
-                break
-        if L is None:
-            L, S, rec = best
-            log(f"WARNING: recall target {args.recall_target} not reached; using best L={L} rescore={S} ({rec:.4f})")
+        L, S, rec = choose_operating_point(run_sample, k, args.recall_target, sweep_log, P.VsError)
     recall = rec
     log(f"operating point: L={L} rescore={S} recall@{k}={recall:.4f}")
 
@@ -292,15 +324,20 @@ def main():
     # HBM bytes per launch from the TCC counters (scripts/pmc_traffic.sh; rocprofv3 cannot run inside this process):
     # taken from the committed measurement whose configuration equals this run's
     import glob
+    traffic_ref = None  # the committed PMC measurement of the same corpus / launch size at another operating point
     for pmc_path in sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_search_traffic*.json"))):
         try:
             pj = json.load(open(pmc_path))
-            if pj.get("n") == n and pj.get("nq") == nq and pj.get("L") == L and pj.get("rescore") == S:
-                traffic = pj.get("hbm_bytes_per_launch")
+            if pj.get("n") == n and pj.get("nq") == nq:
+                if pj.get("L") == L and pj.get("rescore") == S:
+                    traffic = pj.get("hbm_bytes_per_launch")
+                else:
+                    traffic_ref = {"hbm_bytes_per_launch": pj.get("hbm_bytes_per_launch"), "search_list_size": pj.get("L"),
+                                   "rescore": pj.get("rescore"), "file": os.path.basename(pmc_path)}
         except Exception:
             pass
     roofline = {"bound": "hbm", "kernel": "k_search_fast", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(achieved / 8000.0, 5), "traffic": traffic,
+                "frac": round(achieved / 8000.0, 5), "traffic": traffic, "traffic_other_operating_point": traffic_ref,
                 "alg_bytes_per_launch": int(per_launch), "avg_kernel_ms": round(avg_ms, 4), "launches": s_n,
                 "alg_bytes_per_query": round(alg_bytes_search / max(tot.get("queries", 1) - tot.get("fallback_scans", 0), 1), 1)}
     kernels = {name: {"ms_total": round(ms, 3), "launches": cnt} for name, (ms, cnt) in prof.items() if cnt}

@@ -26,6 +26,8 @@
 //
 // A scan whose state outgrows the LDS budget sets a status flag and is re-run by the general kernel
 // (vs_search.hip, unbounded global spill) in a follow-up launch that skips every scan that completed here.
+#include <cstdlib>
+
 #include "vs_device.h"
 
 #define MAX_QLABELS 64
@@ -955,6 +957,10 @@ static int launch_fast_t(vs_index* idx, const FastArgs& a, size_t lds) {
 
 int launch_search_fast(vs_index* idx, const FastLaunch& s) {
     if (s.nq == 0) return VS_OK;
+    {  // opt-in: the four-scans-per-wave kernel where it applies (vs_search_mx.hip)
+        const char* e = getenv("VS_MX");
+        if (e && *e == '1' && search_mx_eligible(idx, s)) return launch_search_mx(idx, s);
+    }
     FastArgs a;
     a.codes = idx->codes;
     a.nbrs = idx->nbrs;

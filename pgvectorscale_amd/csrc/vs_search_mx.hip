@@ -1,0 +1,626 @@
+// vs_search_mx.hip — K3, "four scans per wave" form of the streaming beam search (opt-in: VS_MX=1).
+//
+// Same semantics and citations as vs_search_fast.hip / vs_search.hip; what changes is the mapping.  k_search_fast gives a
+// whole wave64 to one scan and, at the occupancy it reaches in the table-less regime, is bound by instruction issue:
+// most of what a scan does between two memory phases (heap sift-up / sift-down, visited-list insert, loop control) is
+// wave-uniform bookkeeping that occupies a 64-lane instruction slot per step.  Here a scan owns
+// one DPP row of 16 lanes and a wave advances four scans in lockstep, so every such instruction does the bookkeeping of
+// four scans; the phases that were already lane-parallel (dedup probes, code gather) keep one lane per item.
+//
+//   * candidate heap (BinaryHeap<Reverse<ListSearchNeighbor>>, AM/graph/mod.rs:75): same 4-byte entries
+//     (hamming << sb | dedup slot) and the same LDS / spill split as k_search_fast; sift_up = lane r of the row compares
+//     with the r-th ancestor (one read, one 16-bit ballot, one store; heaps of < 2^16 entries); sift_down_to_bottom = one
+//     level per step (both children in one 8-byte read).  Rust std's array mechanics are replayed exactly.
+//   * dedup set: the per-scan global table of the table-less regime (L2 atomics), one lane per neighbor, 16 per step.
+//   * visited list: sorted array in registers, entry i = lane i % 16 of register i / 16; insert / remove(0) are DPP row
+//     shifts (row_shr / row_shl) with the carry between registers taken by a row rotate.
+//   * distances: 4 lanes per code row, 4 rows per row-of-16 per step.
+//
+// Scans whose state outgrows the kernel set the same status flags as in k_search_fast and are re-run by the general
+// kernel.  Results (streams, Hamming distances, GreedySearchStats counters) are bit-identical to k_search_fast's.
+#include "vs_device.h"
+
+#define MX_MAX_QLABELS 64
+#define MX_G 16  // lanes per scan (one DPP row)
+
+struct MxArgs {
+    const uint64_t* codes;
+    const uint32_t* nbrs;
+    const uint64_t* tids;
+    const uint32_t* label_off;
+    const int16_t* label_val;
+    const int16_t* ls_labels;
+    const uint32_t* ls_nodes;
+    uint32_t code_stride, nbr_stride, R, n, n_ls, default_start;
+    FastLaunch s;
+};
+
+namespace {
+
+__device__ __forceinline__ void mx_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ uint32_t mx_gload32(const uint32_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void mx_gstore32(uint32_t* p, uint32_t v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint64_t mx_gload64(const uint64_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// DPP row operations (a row = the 16 lanes of one scan)
+// lane i <- lane i-1 of its row; lane 0 of the row keeps `first`
+__device__ __forceinline__ uint32_t row_shr1(uint32_t v, uint32_t first) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)first, (int)v, 0x111, 0xF, 0xF, false);
+}
+// lane i <- lane i+1 of its row; lane 15 of the row keeps `last`
+__device__ __forceinline__ uint32_t row_shl1(uint32_t v, uint32_t last) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)last, (int)v, 0x101, 0xF, 0xF, false);
+}
+// lane i <- lane (i-1) mod 16 of its row / lane i <- lane (i+1) mod 16
+__device__ __forceinline__ uint32_t row_ror1(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x121, 0xF, 0xF, false);
+}
+__device__ __forceinline__ uint32_t row_rol1(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x12F, 0xF, 0xF, false);
+}
+
+struct Lane {
+    int lane, gl, gbase;  // lane in the wave, lane in the row, first lane of the row
+    // the row's 16 bits of a wave ballot
+    __device__ __forceinline__ uint32_t gballot(bool p) const { return (uint32_t)(__ballot(p) >> gbase) & 0xFFFFu; }
+    // value held by lane `src` (0..15, row-uniform) of this row
+    __device__ __forceinline__ uint32_t gbcast(uint32_t v, uint32_t src) const {
+        return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((uint32_t)gbase + (src & 15u)) << 2), (int)v);
+    }
+    // sum over the row, result in every lane (inclusive prefix by row shifts, then the last lane's value)
+    __device__ __forceinline__ uint32_t gsum(uint32_t v) const {
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);
+        return gbcast(v, 15);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// Heap of one scan.  Position i lives at l[i + 1] while i < hl (hl = 2^k - 1), else at g[i - hl]; l[0] is a sentinel with
+// key 0 ("ancestor of the root").  Every field is row-uniform; all four rows execute every step, `act` selects the rows
+// the operation applies to.
+// ---------------------------------------------------------------------------------------------------------------
+struct MxHeap {
+    uint32_t* l;
+    uint32_t* g;
+    uint32_t hl, sb, len;
+
+    __device__ __forceinline__ uint32_t get1(uint32_t idx) const { return idx <= hl ? l[idx] : mx_gload32(g + (idx - 1 - hl)); }
+    __device__ __forceinline__ void set1(uint32_t idx, uint32_t v) const {
+        if (idx <= hl) l[idx] = v;
+        else mx_gstore32(g + (idx - 1 - hl), v);
+    }
+    // sift_up(0, p1 - 1) of `elem` (not stored yet): while elem < parent (Reverse => smaller distance) the parent moves down
+    __device__ __forceinline__ void place(const Lane& L, uint32_t p1, uint32_t elem, bool act) const {
+        const uint32_t r = (uint32_t)L.gl;  // lane r looks at the r-th ancestor (1-based index p1 >> r; 0 = sentinel)
+        uint32_t e = 0;
+        if (act && r >= 1) e = get1(p1 >> r);
+        const bool cmp = act && r >= 1 && (elem >> sb) < (e >> sb);
+        const uint32_t bal = L.gballot(cmp) >> 1;                       // bit r-1 <-> ancestor r
+        const uint32_t t = (uint32_t)__builtin_ctz(~bal | 0x8000u);     // leading run of ancestors that move down (<= 15)
+        if (act && r <= t) {
+            const uint32_t dst = r == 0 ? (p1 >> t) : (p1 >> (r - 1));
+            set1(dst, r == 0 ? elem : e);
+        }
+        mx_wave_sync();
+    }
+    __device__ __forceinline__ void push(const Lane& L, uint32_t elem, bool act) {
+        place(L, len + 1, elem, act);
+        len += act ? 1u : 0u;
+    }
+    // BinaryHeap::pop after the caller has read data[0]: Vec::pop, swap with data[0], sift_down_to_bottom(0), sift_up
+    __device__ __forceinline__ void pop(const Lane& L, bool act) {
+        act = act && len > 0;
+        const uint32_t last = act ? len - 1 : 0;
+        uint32_t item = 0;
+        if (act) item = get1(last + 1);
+        len = act ? last : len;
+        bool go = act && len > 0;  // a heap that is empty now: nothing to restore
+        const uint32_t end = len;
+        uint32_t pos = 0, child = 1;
+        // while child <= end.saturating_sub(2): both children exist
+        while (__ballot(go && child + 1 < end)) {
+            const bool step = go && child + 1 < end;
+            uint32_t le = 0, ri = 0;
+            if (step) {
+                if (child < hl) {  // the pair (2a+1, 2a+2) is one aligned 8-byte word in LDS and in the spill array
+                    const uint2 p = *reinterpret_cast<const uint2*>(l + child + 1);
+                    le = p.x;
+                    ri = p.y;
+                } else {
+                    const uint64_t p = mx_gload64(reinterpret_cast<const uint64_t*>(g + (child - hl)));
+                    le = (uint32_t)p;
+                    ri = (uint32_t)(p >> 32);
+                }
+            }
+            // child += (data[child] <= data[child + 1]); Reverse => right.d <= left.d picks the right child
+            const bool pick = (ri >> sb) <= (le >> sb);
+            const uint32_t c = child + (pick ? 1u : 0u);
+            if (step && L.gl == 0) set1(pos + 1, pick ? ri : le);
+            pos = step ? c : pos;
+            child = step ? 2 * c + 1 : child;
+            mx_wave_sync();
+        }
+        // if child == end - 1: a single child
+        {
+            const bool one = go && child + 1 == end;
+            uint32_t v = 0;
+            if (one) v = get1(child + 1);
+            if (one && L.gl == 0) set1(pos + 1, v);
+            pos = one ? child : pos;
+            mx_wave_sync();
+        }
+        place(L, pos + 1, item, go);  // sift_up(0, pos) of the former last element
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// visited: Vec<ListSearchNeighbor> kept sorted (AM/graph/mod.rs:76,167-168,181): entry i = lane i % 16 of (h[i / 16], n[i / 16])
+// ---------------------------------------------------------------------------------------------------------------
+template <int VRR>
+struct MxVisited {
+    // entry i lives at position head + i; position p = lane p % 16 of (h[p / 16], n[p / 16]).  remove(0) only advances
+    // `head`; once a whole register has been consumed the registers rotate down by one (plain moves).
+    uint32_t h[VRR], n[VRR];
+    uint32_t len, head;
+
+    __device__ __forceinline__ void init() {
+        len = 0;
+        head = 0;
+#pragma unroll
+        for (int r = 0; r < VRR; ++r) { h[r] = 0; n[r] = 0; }
+    }
+    static __device__ __forceinline__ uint32_t capacity() { return 16u * (VRR - 1); }  // head < 16 always
+    __device__ __forceinline__ uint32_t at(const Lane& L, const uint32_t (&arr)[VRR], uint32_t p) const {
+        uint32_t sel = 0;
+#pragma unroll
+        for (int r = 0; r < VRR; ++r) sel = (p >> 4) == (uint32_t)r ? arr[r] : sel;
+        return L.gbcast(sel, p & 15u);
+    }
+    // hamming of entry i (row-uniform, i < len)
+    __device__ __forceinline__ uint32_t ham_at(const Lane& L, uint32_t i) const { return at(L, h, head + i); }
+    // visited.insert(partition_point(|x| *x < new), new): before the first element >= new
+    __device__ __forceinline__ void insert(const Lane& L, uint32_t hd, uint32_t node, bool act) {
+        const uint32_t lo = head, hi = head + len;  // occupied positions [lo, hi)
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int r = 0; r < VRR; ++r) {
+            const uint32_t gi = (uint32_t)r * 16u + (uint32_t)L.gl;
+            cnt += (gi >= lo && gi < hi && h[r] < hd) ? 1u : 0u;
+        }
+        const uint32_t at_pos = lo + L.gsum(cnt);
+#pragma unroll
+        for (int r = VRR - 1; r >= 0; --r) {
+            const uint32_t ch = r > 0 ? row_ror1(h[r > 0 ? r - 1 : 0]) : 0u;  // lane 0 <- lane 15 of the previous register
+            const uint32_t cn = r > 0 ? row_ror1(n[r > 0 ? r - 1 : 0]) : 0u;
+            const uint32_t sh = row_shr1(h[r], ch), sn = row_shr1(n[r], cn);
+            const uint32_t gi = (uint32_t)r * 16u + (uint32_t)L.gl;
+            const bool moved = act && gi > at_pos && gi <= hi, here = act && gi == at_pos;
+            h[r] = moved ? sh : (here ? hd : h[r]);
+            n[r] = moved ? sn : (here ? node : n[r]);
+        }
+        len += act ? 1u : 0u;
+    }
+    // visited.remove(0)
+    __device__ __forceinline__ void pop_front(const Lane& L, uint32_t& hd, uint32_t& node, bool act) {
+        hd = L.gbcast(h[0], head);
+        node = L.gbcast(n[0], head);
+        head += act ? 1u : 0u;
+        len -= act ? 1u : 0u;
+        if (__ballot(head == 16u)) {  // the first register is used up in some row: its registers move down by one
+            const bool rot = head == 16u;
+#pragma unroll
+            for (int r = 0; r + 1 < VRR; ++r) {
+                h[r] = rot ? h[r + 1] : h[r];
+                n[r] = rot ? n[r + 1] : n[r];
+            }
+            head = rot ? 0u : head;
+        }
+    }
+};
+
+template <int NCH>
+__device__ __forceinline__ uint32_t mx_ham_row(const uint64_t* __restrict__ row, const ulonglong2 (&qv)[NCH], int l4, uint32_t code_stride,
+                                               bool active) {
+    uint32_t acc = 0;
+    if (active) {
+        ulonglong2 r[NCH];
+#pragma unroll
+        for (int t = 0; t < NCH; ++t) {
+            const uint32_t w = 2u * (uint32_t)l4 + 8u * (uint32_t)t;
+            r[t] = w < code_stride ? *reinterpret_cast<const ulonglong2*>(row + w) : make_ulonglong2(0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < NCH; ++t) acc += (uint32_t)__popcll(r[t].x ^ qv[t].x) + (uint32_t)__popcll(r[t].y ^ qv[t].y);
+    }
+    return quad_sum(acc);
+}
+
+}  // namespace
+
+// NCH = 16-byte chunks of a code row per lane (4 lanes per row), VRR = visited-list registers (16 entries each)
+template <int NCH, int VRR>
+__global__ __launch_bounds__(WAVE) void k_search_mx(MxArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const FastLaunch& s = a.s;
+    Lane L;
+    L.lane = threadIdx.x;
+    L.gl = L.lane & 15;
+    L.gbase = L.lane & 48;
+    const int g = L.lane >> 4;
+    const uint32_t q = blockIdx.x * 4u + (uint32_t)g;
+    bool alive = q < s.nq;  // rows past the end of the batch idle
+    const uint32_t qs = alive ? q : 0u;
+
+    // ---- LDS carve (per row) ----
+    uint32_t* hp_all = reinterpret_cast<uint32_t*>(smem);                // 4 x (hl + 1)
+    uint32_t* surv_id_all = hp_all + 4 * (s.hl + 1);                    // 4 x 64
+    uint32_t* surv_e_all = surv_id_all + 4 * 64;                         // 4 x 64
+    int16_t* ql_all = reinterpret_cast<int16_t*>(surv_e_all + 4 * 64);   // 4 x MX_MAX_QLABELS
+    uint32_t* hp = hp_all + (size_t)g * (s.hl + 1);
+    uint32_t* surv_id = surv_id_all + g * 64;
+    uint32_t* surv_e = surv_e_all + g * 64;  // first the dedup slot, then (hamming << sb | slot)
+    int16_t* ql = ql_all + g * MX_MAX_QLABELS;
+
+    const int l4 = L.gl & 3;
+    ulonglong2 qv[NCH];
+#pragma unroll
+    for (int t = 0; t < NCH; ++t) {
+        const uint32_t w = 2u * (uint32_t)l4 + 8u * (uint32_t)t;
+        qv[t] = (alive && w < a.code_stride) ? *reinterpret_cast<const ulonglong2*>(s.qcodes + (size_t)qs * a.code_stride + w)
+                                             : make_ulonglong2(0, 0);
+    }
+    if (L.gl == 0) hp[0] = 0;  // heap sentinel
+    const bool labels_some = s.qlabel_off != nullptr;  // LabeledVector.labels is Some (AM/labels/mod.rs:222-236)
+    uint32_t nql = 0;
+    if (labels_some && alive) {
+        const uint32_t lb = s.qlabel_off[qs], le = s.qlabel_off[qs + 1];
+        nql = min(le - lb, (uint32_t)MX_MAX_QLABELS);
+        for (uint32_t i = L.gl; i < nql; i += MX_G) ql[i] = s.qlabels[lb + i];
+    }
+    const bool has_label_filter = labels_some && nql > 0;  // AM/scan.rs:189
+    mx_wave_sync();
+
+    MxHeap heap;
+    heap.l = hp;
+    heap.g = s.heap_g + (size_t)qs * s.gstride;
+    heap.hl = s.hl;
+    heap.sb = s.sb;
+    heap.len = 0;
+    MxVisited<VRR> vis;
+    vis.init();
+
+    const uint32_t smask = (1u << s.sb) - 1u;
+    const uint32_t gmask = s.gcap - 1;
+    uint32_t emitted = 0, status = 0, nins_g = 0, hmax = 0;
+    uint32_t st_visits = 0, st_cand = 0, st_dq = 0, st_reads = 0, st_pfhit = 0;
+
+    // ---- the scan's dedup table ("inserted", HashSet<ItemPointer>): claimed from the pool and cleared up front ----
+    uint32_t* ghash = s.ghash;
+    {
+        uint32_t slot = 0;
+        if (alive && L.gl == 0) slot = atomicAdd(s.pool_counter, 1u);
+        slot = L.gbcast(slot, 0);
+        if (alive && slot >= s.pool_slots) {
+            status |= OVF_POOL;
+            alive = false;
+        }
+        ghash = s.ghash + (size_t)(alive ? slot : 0u) * s.gcap;
+        if (alive)
+            for (uint32_t i = 4u * (uint32_t)L.gl; i < s.gcap; i += 4u * MX_G)
+                *reinterpret_cast<uint4*>(ghash + i) = make_uint4(VS_EMPTY, VS_EMPTY, VS_EMPTY, VS_EMPTY);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    }
+    // HashSet::insert of one id per lane; true where the id was not present before, slot_out = its handle
+    auto dedup_insert = [&](uint32_t nid, bool act, uint32_t& slot_out) -> bool {
+        bool fresh = false;
+        if (act) {
+            uint32_t gs = hash_u32(nid ^ 0x5bd1e995u) & gmask;
+            for (;;) {
+                const uint32_t o = atomicCAS(&ghash[gs], VS_EMPTY, nid);  // L2 atomic
+                if (o == VS_EMPTY) { fresh = true; break; }
+                if (o == nid) break;
+                gs = (gs + 1) & gmask;
+            }
+            slot_out = gs;
+        }
+        nins_g += (uint32_t)__builtin_popcount(L.gballot(fresh));
+        return fresh;
+    };
+    auto fail = [&](bool cond, uint32_t flag) {  // the scan is handed to the general kernel
+        if (alive && cond) {
+            status |= flag;
+            alive = false;
+        }
+    };
+
+    // ---- ListSearchResult::new: start nodes (AM/graph/mod.rs:97-124, AM/graph/start_nodes.rs:39-48) ----
+    {
+        uint32_t nstarts = labels_some ? nql : 1u;
+        if (a.default_start == VS_INVALID_NODE || a.n == 0) nstarts = 0;  // ListSearchResult::empty()
+        for (uint32_t si = 0; __ballot(alive && si < nstarts); ++si) {
+            const bool on = alive && si < nstarts;
+            uint32_t sn = VS_INVALID_NODE;
+            if (on) {
+                if (!labels_some) {
+                    sn = a.default_start;
+                } else {
+                    const int16_t lab = ql[si];
+                    int lo = 0, hi = (int)a.n_ls;
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        if (a.ls_labels[mid] < lab) lo = mid + 1;
+                        else hi = mid;
+                    }
+                    if (lo < (int)a.n_ls && a.ls_labels[lo] == lab) sn = a.ls_nodes[lo];
+                }
+            }
+            const bool have = on && sn != VS_INVALID_NODE;
+            fail(have && (nins_g + MX_G) * 4u > s.gcap * 3u, OVF_HASH);
+            // create_lsn_for_start_node (AM/sbq/storage.rs:365-391)
+            uint32_t slot = 0;
+            const bool fr_lane = dedup_insert(sn, have && alive && L.gl == 0, slot);
+            const bool fr = L.gbcast(fr_lane ? 1u : 0u, 0) != 0 && have && alive;
+            slot = L.gbcast(slot, 0);
+            st_reads += fr ? 1u : 0u;
+            const uint32_t d = L.gbcast(
+                mx_ham_row<NCH>(a.codes + (size_t)(fr ? sn : 0u) * a.code_stride, qv, l4, a.code_stride, fr && L.gl < 4), 0);
+            st_dq += fr ? 1u : 0u;
+            st_cand += fr ? 1u : 0u;
+            fail(fr && heap.len + 1 > s.hcap, OVF_HEAP);
+            heap.push(L, (d << s.sb) | slot, fr && alive);
+        }
+    }
+
+    // ---- TSVResponseIterator::next until M rows are emitted (AM/scan.rs:210-242): every round, each scan first consumes
+    // rows while it cannot visit (consume, AM/graph/mod.rs:174-184), then all scans that can do one visit_closest()
+    // expansion (greedy_search_iterate, AM/graph/mod.rs:357-385) ----
+    bool done = !alive;
+    uint32_t next_node = 0;  // node id of the heap root
+    if (alive && heap.len > 0) next_node = mx_gload32(ghash + (hp[1] & smask));
+    for (;;) {
+        done = done || !alive;
+        // can this scan visit?  visit_closest(L) stop rule (AM/graph/mod.rs:153-170)
+        auto can_visit_now = [&]() -> bool {
+            bool cv = !done && heap.len > 0;
+            uint32_t lim = 0;
+            const bool need = cv && vis.len > s.L;
+            if (__ballot(need)) lim = vis.ham_at(L, need ? s.L - 1 : 0);
+            if (need) cv = (hp[1] >> s.sb) < lim;
+            return cv;
+        };
+        bool cv = can_visit_now();
+        while (__ballot(!done && !cv)) {
+            const bool con = !done && !cv;
+            // ---- consume + return_lsn (AM/sbq/storage.rs:404-414) ----
+            const bool ended = con && vis.len == 0;  // None: the stream has ended
+            done = done || ended;
+            const bool take = con && !ended;
+            uint32_t fd, fnode;
+            vis.pop_front(L, fd, fnode, take);
+            st_reads += take ? 1u : 0u;
+            uint64_t tid = 1;
+            if (take) tid = a.tids[fnode];
+            const bool live_row = take && (tid & 0xFFFFull) != 0;  // InvalidOffsetNumber: deleted tuple (AM/scan.rs:231-234)
+            if (live_row && L.gl == 0) {
+                s.out_ids[(size_t)q * s.M + emitted] = fnode;
+                s.out_ham[(size_t)q * s.M + emitted] = fd;
+            }
+            emitted += live_row ? 1u : 0u;
+            done = done || (live_row && emitted == s.M);
+            cv = can_visit_now();
+        }
+        if (!__ballot(!done)) break;
+        const bool ex = !done && cv;  // this scan expands now
+        hmax = ex ? max(hmax, heap.len) : hmax;
+        const uint32_t top = ex ? hp[1] : 0u;
+        const uint32_t hd = top >> s.sb;
+        // handle -> node id: requested when the root last changed (end of the previous step), so it has arrived by now
+        const uint32_t node = ex ? next_node : 0u;
+        // the neighbor list (lane gl holds slots gl, gl + 16, gl + 32, gl + 48) is requested before the pop, which covers
+        // part of its latency
+        const uint32_t* nrow = a.nbrs + (size_t)node * a.nbr_stride;
+        uint32_t nb[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t sl = (uint32_t)k * 16u + (uint32_t)L.gl;
+            nb[k] = (ex && sl < a.R) ? nrow[sl] : VS_INVALID_NODE;
+        }
+        heap.pop(L, ex);
+        fail(ex && vis.len + 1 > vis.capacity(), OVF_VISITED);
+        const bool ex2 = ex && alive;
+        st_visits += ex2 ? 1u : 0u;
+        st_reads += ex2 ? 1u : 0u;  // SbqNode::read(visiting)
+        // visited.insert(partition_point(|x| *x < head), head)
+        vis.insert(L, hd, node, ex2);
+        // ---- visit_lsn_internal, Disk arm (AM/sbq/storage.rs:135-190) ----
+        uint32_t c = 0;          // survivors of this visit, in neighbor-list order
+        bool open = ex2;         // the list has not ended yet
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (!__ballot(open && (uint32_t)k * 16u < a.R)) break;
+            const uint32_t nid = nb[k];
+            // list ends at the first InvalidBlockNumber (AM/sbq/node.rs:260-285)
+            const uint32_t inval = L.gballot(nid == VS_INVALID_NODE);
+            const uint32_t nvalid = inval ? (uint32_t)__builtin_ctz(inval) : 16u;
+            const bool act = open && (uint32_t)L.gl < nvalid;
+            fail(open && (nins_g + MX_G) * 4u > s.gcap * 3u, OVF_HASH);
+            open = open && alive;
+            // prepare_insert marks BEFORE the label check (AM/sbq/storage.rs:148-172)
+            uint32_t hslot = 0;
+            const bool fresh = dedup_insert(nid, act && alive, hslot);
+            st_reads += (uint32_t)__builtin_popcount(L.gballot(fresh));  // SbqNode::read(neighbor)
+            // label filter: query.labels.overlaps(node.labels) (AM/labels/mod.rs:124-142)
+            bool pass = fresh;
+            if (has_label_filter && fresh) {
+                const uint32_t lb = a.label_off[nid], le = a.label_off[nid + 1];
+                uint32_t i = 0, j = lb;
+                bool ov = false;
+                while (i < nql && j < le) {
+                    const int16_t x = ql[i], y = a.label_val[j];
+                    if (x == y) { ov = true; break; }
+                    if (x < y) ++i;
+                    else ++j;
+                }
+                pass = ov;
+            }
+            const uint32_t pm = L.gballot(pass);
+            if (pass) {
+                const uint32_t rank = c + (uint32_t)__builtin_popcount(pm & ((1u << L.gl) - 1u));
+                surv_id[rank] = nid;
+                surv_e[rank] = hslot;
+            }
+            c += (uint32_t)__builtin_popcount(pm);
+            open = open && nvalid == 16u;
+        }
+        c = (ex2 && alive) ? c : 0u;
+        fail(c > 0 && heap.len + c > s.hcap, OVF_HEAP);
+        c = alive ? c : 0u;
+        mx_wave_sync();
+        // ---- distances: 4 lanes per code row, 4 rows per scan per step ----
+        st_dq += c;
+        st_cand += c;
+        // the largest c over the four rows (each row holds a uniform value: its first lane is enough)
+        const uint32_t cmax = max(max((uint32_t)__builtin_amdgcn_readlane((int)c, 0), (uint32_t)__builtin_amdgcn_readlane((int)c, 16)),
+                                  max((uint32_t)__builtin_amdgcn_readlane((int)c, 32), (uint32_t)__builtin_amdgcn_readlane((int)c, 48)));
+        for (uint32_t p0 = 0; p0 < cmax; p0 += 8) {  // two steps (8 rows per scan, 32 per wave) in flight
+            const uint32_t j0 = p0 + (uint32_t)(L.gl >> 2), j1 = j0 + 4;
+            const bool v0 = j0 < c, v1 = j1 < c;
+            const uint32_t id0 = v0 ? surv_id[j0] : 0u, id1 = v1 ? surv_id[j1] : 0u;
+            const uint64_t* row0 = a.codes + (size_t)id0 * a.code_stride;
+            const uint64_t* row1 = a.codes + (size_t)id1 * a.code_stride;
+            ulonglong2 r0[NCH], r1[NCH];
+#pragma unroll
+            for (int t = 0; t < NCH; ++t) {
+                const uint32_t w = 2u * (uint32_t)l4 + 8u * (uint32_t)t;
+                r0[t] = (v0 && w < a.code_stride) ? *reinterpret_cast<const ulonglong2*>(row0 + w) : make_ulonglong2(0, 0);
+                r1[t] = (v1 && w < a.code_stride) ? *reinterpret_cast<const ulonglong2*>(row1 + w) : make_ulonglong2(0, 0);
+            }
+            uint32_t a0 = 0, a1 = 0;
+#pragma unroll
+            for (int t = 0; t < NCH; ++t) {
+                a0 += (uint32_t)__popcll(r0[t].x ^ qv[t].x) + (uint32_t)__popcll(r0[t].y ^ qv[t].y);
+                a1 += (uint32_t)__popcll(r1[t].x ^ qv[t].x) + (uint32_t)__popcll(r1[t].y ^ qv[t].y);
+            }
+            a0 = v0 ? a0 : 0u;
+            a1 = v1 ? a1 : 0u;
+            const uint32_t d0 = quad_sum(a0), d1 = quad_sum(a1);
+            if (v0 && l4 == 0) surv_e[j0] = (d0 << s.sb) | surv_e[j0];
+            if (v1 && l4 == 0) surv_e[j1] = (d1 << s.sb) | surv_e[j1];
+        }
+        mx_wave_sync();
+        // ---- insert_neighbor in list order (AM/graph/mod.rs:144-147) ----
+        for (uint32_t j = 0; j < cmax; ++j) {
+            const bool on = j < c;
+            const uint32_t elem = on ? surv_e[j] : 0u;
+            heap.push(L, elem, on);
+        }
+        // the root can only change in an expansion: ask for the id of the next node to visit now
+        if (ex && alive && heap.len > 0) next_node = mx_gload32(ghash + (hp[1] & smask));
+    }
+
+    // one `next` call per emitted row, plus the call that found the stream exhausted
+    const uint32_t st_next = emitted + ((emitted < s.M && status == 0) ? 1u : 0u);
+    if (q < s.nq) {
+        if (status == 0) {
+            for (uint32_t i = emitted + (uint32_t)L.gl; i < s.M; i += MX_G) {
+                s.out_ids[(size_t)q * s.M + i] = VS_INVALID_NODE;
+                s.out_ham[(size_t)q * s.M + i] = 0xFFFFFFFFu;
+            }
+        }
+        if (L.gl == 0) {
+            s.status[q] = status;
+            s.out_cnt[q] = status ? 0 : emitted;  // a failed scan publishes an empty stream until the fallback re-runs it
+            if (status == 0) {
+                uint32_t* st = s.stats + (size_t)q * ST_N;
+                st[ST_VISITS] = st_visits;
+                st[ST_CAND] = st_cand;
+                st[ST_DQ] = st_dq;
+                st[ST_READS] = st_reads;
+                st[ST_NEXT] = st_next;
+                st[ST_GSPILL] = hmax;
+                st[ST_PFHIT] = st_pfhit;
+                st[7] = nins_g;
+            }
+        }
+    }
+}
+
+// ---- host side --------------------------------------------------------------------------------------------------------
+static size_t mx_lds_bytes(const FastLaunch& s) {
+    return ((size_t)4 * (s.hl + 1) * 4 + 2 * 4 * 64 * 4 + 4 * MX_MAX_QLABELS * 2 + 15) / 16 * 16;
+}
+
+// can this launch run on k_search_mx?  (table-less regime, query scans only, geometry the row-of-16 mapping covers)
+bool search_mx_eligible(const vs_index* idx, const FastLaunch& s) {
+    const uint32_t nch = (idx->code_stride + 7) / 8;
+    const uint32_t want_v = s.L + s.L / 2 + 32;
+    return s.lh == 0 && !s.build && !s.phase && s.hcap < 65535 && idx->d.num_neighbors <= 64 && nch >= 1 && nch <= 6 &&
+           want_v <= 16 * 32 && mx_lds_bytes(s) <= 64 * 1024;
+}
+
+template <int NCH, int VRR>
+static int launch_mx_tt(vs_index* idx, const MxArgs& a, size_t lds) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        VS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_search_mx<NCH, VRR>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_search_mx<NCH, VRR>), dim3((a.s.nq + 3) / 4), dim3(WAVE), lds, idx->ctx->stream, a);
+    VS_HIP(hipGetLastError());
+    return VS_OK;
+}
+
+template <int NCH>
+static int launch_mx_t(vs_index* idx, const MxArgs& a, size_t lds) {
+    const uint32_t want_v = a.s.L + a.s.L / 2 + 32;
+    // capacity of the register-resident visited list = 16 (VRR - 1) entries
+    if (want_v <= 16 * 12) return launch_mx_tt<NCH, 13>(idx, a, lds);
+    if (want_v <= 16 * 20) return launch_mx_tt<NCH, 21>(idx, a, lds);
+    return launch_mx_tt<NCH, 33>(idx, a, lds);
+}
+
+int launch_search_mx(vs_index* idx, const FastLaunch& s) {
+    if (s.nq == 0) return VS_OK;
+    VS_REQUIRE(search_mx_eligible(idx, s), "k_search_mx: launch outside the geometry this kernel covers");
+    MxArgs a;
+    a.codes = idx->codes;
+    a.nbrs = idx->nbrs;
+    a.tids = idx->tids;
+    a.label_off = idx->label_off;
+    a.label_val = idx->label_val;
+    a.ls_labels = idx->ls_labels;
+    a.ls_nodes = idx->ls_nodes;
+    a.code_stride = idx->code_stride;
+    a.nbr_stride = idx->nbr_stride;
+    a.R = idx->d.num_neighbors;
+    a.n = idx->d.n;
+    a.n_ls = idx->d.n_label_starts;
+    a.default_start = idx->d.default_start;
+    a.s = s;
+    const size_t lds = mx_lds_bytes(s);
+    const uint32_t nch = (idx->code_stride + 7) / 8;
+    switch (nch) {
+        case 1: return launch_mx_t<1>(idx, a, lds);
+        case 2: return launch_mx_t<2>(idx, a, lds);
+        case 3: return launch_mx_t<3>(idx, a, lds);
+        case 4: return launch_mx_t<4>(idx, a, lds);
+        case 5:
+        case 6: return launch_mx_t<6>(idx, a, lds);
+        default: break;
+    }
+    vs_set_error("k_search_mx: code width not covered");
+    return VS_ERR_INVALID;
+}

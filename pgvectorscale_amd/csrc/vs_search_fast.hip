@@ -958,8 +958,11 @@ static int launch_fast_t(vs_index* idx, const FastArgs& a, size_t lds) {
 int launch_search_fast(vs_index* idx, const FastLaunch& s) {
     if (s.nq == 0) return VS_OK;
     {  // opt-in: the four-scans-per-wave kernel where it applies (vs_search_mx.hip)
-        const char* e = getenv("VS_MX");
-        if (e && *e == '1' && search_mx_eligible(idx, s)) return launch_search_mx(idx, s);
+        const char* e = getenv("VS_MX");  // 1: where it applies; 2: insist (tests: a launch it does not cover is an error)
+        if (e && (*e == '1' || *e == '2')) {
+            if (search_mx_eligible(idx, s)) return launch_search_mx(idx, s);
+            VS_REQUIRE(*e != '2', "VS_MX=2: this launch is outside the geometry k_search_mx covers");
+        }
     }
     FastArgs a;
     a.codes = idx->codes;

@@ -22,6 +22,7 @@
 
 #define MX_MAX_QLABELS 64
 #define MX_G 16  // lanes per scan (one DPP row)
+#define MX_STG 152  // staged heap words per scan during a run of pushes (MxHeap::push_run_staged)
 
 struct MxArgs {
     const uint64_t* codes;
@@ -118,6 +119,58 @@ struct MxHeap {
     __device__ __forceinline__ void push(const Lane& L, uint32_t elem, bool act) {
         place(L, len + 1, elem, act);
         len += act ? 1u : 0u;
+    }
+    // ---- insert_neighbor x c (AM/graph/mod.rs:144-147): elements e[0..c) are pushed one after another, but memory is
+    // touched once per run.  The leaves of the run are positions p1f .. p1l (1-based), so their rank-r ancestors are the
+    // contiguous range (p1f >> r) .. (p1l >> r): every such range (and the leaves themselves, rank 0) is staged in LDS
+    // (stg, MX_STG words per row), the pushes run against the staged copy — lane r always works on rank r, so its slot
+    // is (p1 >> r) + a per-lane constant — and the ranges are written back afterwards.  One memory round trip per run
+    // instead of one per push when the bottom levels live in the spill array.  The caller keeps a run on ONE heap level
+    // (c <= 64 leaves of equal depth), so the ranges of different ranks lie on different levels and never overlap.
+    static __device__ __forceinline__ uint32_t stg_off(uint32_t r) {
+        return r == 0 ? 0u : r == 1 ? 64u : r == 2 ? 97u : r == 3 ? 114u : r == 4 ? 123u : r == 5 ? 128u : 131u + 2u * (r - 6u);
+    }
+    __device__ __forceinline__ void push_run_staged(const Lane& L, uint32_t* stg, const uint32_t* e, uint32_t c, uint32_t cmax) {
+        const bool row = c > 0;
+        const uint32_t p1f = len + 1, p1l = len + c;
+        const uint32_t r = (uint32_t)L.gl;
+        // deepest rank any row needs (ranks past the root read the sentinel)
+        uint32_t depth = row ? 32u - (uint32_t)__builtin_clz(p1l) : 0u;  // ranks 1 .. depth - 1 are real ancestors
+        depth = max(max((uint32_t)__builtin_amdgcn_readlane((int)depth, 0), (uint32_t)__builtin_amdgcn_readlane((int)depth, 16)),
+                    max((uint32_t)__builtin_amdgcn_readlane((int)depth, 32), (uint32_t)__builtin_amdgcn_readlane((int)depth, 48)));
+        // stage in: ranks 1 .. depth (rank `depth` is the sentinel for the deepest row)
+        for (uint32_t k = 1; k <= depth && k <= 15u; ++k) {
+            const uint32_t b = p1f >> k, n = row ? (p1l >> k) - b + 1u : 0u, o = stg_off(k);
+            for (uint32_t i = r; __ballot(i < n); i += MX_G)
+                if (i < n) stg[o + i] = get1(b + i);
+        }
+        mx_wave_sync();
+        const uint32_t cst = stg_off(r) - (p1f >> r);         // slot of rank-r index x = x + cst (mod 2^32)
+        const uint32_t cst_w = row_shr1(cst, 0);               // the same for rank r - 1 (lane r >= 1 writes there)
+        for (uint32_t j = 0; j < cmax; ++j) {
+            const bool on = j < c;
+            const uint32_t p1 = p1f + j;
+            const uint32_t elem = on ? e[j] : 0u;
+            uint32_t a = 0;
+            if (on && r >= 1) a = stg[(p1 >> r) + cst];
+            const bool cmp = on && r >= 1 && (elem >> sb) < (a >> sb);
+            const uint32_t bal = L.gballot(cmp) >> 1;                    // bit r-1 <-> ancestor r
+            const uint32_t t = (uint32_t)__builtin_ctz(~bal | 0x8000u);  // leading run of ancestors that move down
+            const uint32_t cst_t = L.gbcast(cst, t);
+            if (on && r <= t) {
+                const uint32_t slot = r == 0 ? (p1 >> t) + cst_t : (p1 >> (r - 1)) + cst_w;
+                stg[slot] = r == 0 ? elem : a;
+            }
+            mx_wave_sync();
+        }
+        // stage out: ranks 0 .. depth - 1 (the sentinel is never written)
+        for (uint32_t k = 0; k < depth && k <= 15u; ++k) {
+            const uint32_t b = p1f >> k, n = (row && (p1l >> k) >= 1u) ? (p1l >> k) - b + 1u : 0u, o = stg_off(k);
+            for (uint32_t i = r; __ballot(i < n); i += MX_G)
+                if (i < n && b + i >= 1u) set1(b + i, stg[o + i]);
+        }
+        len += c;
+        mx_wave_sync();
     }
     // BinaryHeap::pop after the caller has read data[0]: Vec::pop, swap with data[0], sift_down_to_bottom(0), sift_up
     __device__ __forceinline__ void pop(const Lane& L, bool act) {
@@ -267,10 +320,12 @@ __global__ __launch_bounds__(WAVE) void k_search_mx(MxArgs a) {
     uint32_t* hp_all = reinterpret_cast<uint32_t*>(smem);                // 4 x (hl + 1)
     uint32_t* surv_id_all = hp_all + 4 * (s.hl + 1);                    // 4 x 64
     uint32_t* surv_e_all = surv_id_all + 4 * 64;                         // 4 x 64
-    int16_t* ql_all = reinterpret_cast<int16_t*>(surv_e_all + 4 * 64);   // 4 x MX_MAX_QLABELS
+    uint32_t* stg_all = surv_e_all + 4 * 64;                             // 4 x MX_STG
+    int16_t* ql_all = reinterpret_cast<int16_t*>(stg_all + 4 * MX_STG);  // 4 x MX_MAX_QLABELS
     uint32_t* hp = hp_all + (size_t)g * (s.hl + 1);
     uint32_t* surv_id = surv_id_all + g * 64;
     uint32_t* surv_e = surv_e_all + g * 64;  // first the dedup slot, then (hamming << sb | slot)
+    uint32_t* stg = stg_all + g * MX_STG;
     int16_t* ql = ql_all + g * MX_MAX_QLABELS;
 
     const int l4 = L.gl & 3;
@@ -521,10 +576,25 @@ __global__ __launch_bounds__(WAVE) void k_search_mx(MxArgs a) {
         }
         mx_wave_sync();
         // ---- insert_neighbor in list order (AM/graph/mod.rs:144-147) ----
-        for (uint32_t j = 0; j < cmax; ++j) {
-            const bool on = j < c;
-            const uint32_t elem = on ? surv_e[j] : 0u;
-            heap.push(L, elem, on);
+        if (cmax > 0 && !__ballot(c > 0 && heap.len < 64u)) {
+            // runs stay on one heap level (all leaves of a run have the same depth, so the staged ranges of different
+            // ranks can never name the same position): a visit that crosses into the next level takes two runs
+            uint32_t jb = 0;
+            while (__ballot(jb < c)) {
+                const uint32_t p1f = heap.len + 1;
+                const uint32_t room = (2u << (31u - (uint32_t)__builtin_clz(p1f))) - p1f;  // leaves left on this level
+                const uint32_t n = jb < c ? min(c - jb, room) : 0u;
+                const uint32_t nmax = max(max((uint32_t)__builtin_amdgcn_readlane((int)n, 0), (uint32_t)__builtin_amdgcn_readlane((int)n, 16)),
+                                          max((uint32_t)__builtin_amdgcn_readlane((int)n, 32), (uint32_t)__builtin_amdgcn_readlane((int)n, 48)));
+                heap.push_run_staged(L, stg, surv_e + jb, n, nmax);
+                jb += n;
+            }
+        } else {  // a shallow heap somewhere (the first expansions of a scan): one push at a time
+            for (uint32_t j = 0; j < cmax; ++j) {
+                const bool on = j < c;
+                const uint32_t elem = on ? surv_e[j] : 0u;
+                heap.push(L, elem, on);
+            }
         }
         // the root can only change in an expansion: ask for the id of the next node to visit now
         if (ex && alive && heap.len > 0) next_node = mx_gload32(ghash + (hp[1] & smask));
@@ -559,7 +629,7 @@ __global__ __launch_bounds__(WAVE) void k_search_mx(MxArgs a) {
 
 // ---- host side --------------------------------------------------------------------------------------------------------
 static size_t mx_lds_bytes(const FastLaunch& s) {
-    return ((size_t)4 * (s.hl + 1) * 4 + 2 * 4 * 64 * 4 + 4 * MX_MAX_QLABELS * 2 + 15) / 16 * 16;
+    return ((size_t)4 * (s.hl + 1) * 4 + 2 * 4 * 64 * 4 + 4 * MX_STG * 4 + 4 * MX_MAX_QLABELS * 2 + 15) / 16 * 16;
 }
 
 // can this launch run on k_search_mx?  (table-less regime, query scans only, geometry the row-of-16 mapping covers)

@@ -150,9 +150,9 @@ struct MxHeap {
         for (uint32_t j = 0; j < cmax; ++j) {
             const bool on = j < c;
             const uint32_t p1 = p1f + j;
-            const uint32_t elem = on ? e[j] : 0u;
-            uint32_t a = 0;
-            if (on && r >= 1) a = stg[(p1 >> r) + cst];
+            // (both reads are unconditional: j < cmax <= 64 and the slot of any (p1, r) lie inside the row's arrays)
+            const uint32_t elem = e[j];
+            const uint32_t a = stg[(p1 >> r) + cst];
             const bool cmp = on && r >= 1 && (elem >> sb) < (a >> sb);
             const uint32_t bal = L.gballot(cmp) >> 1;                    // bit r-1 <-> ancestor r
             const uint32_t t = (uint32_t)__builtin_ctz(~bal | 0x8000u);  // leading run of ancestors that move down
@@ -172,49 +172,85 @@ struct MxHeap {
         len += c;
         mx_wave_sync();
     }
-    // BinaryHeap::pop after the caller has read data[0]: Vec::pop, swap with data[0], sift_down_to_bottom(0), sift_up
+    // ---- BinaryHeap::pop after the caller has read data[0]: Vec::pop, swap with data[0], sift_down_to_bottom(0), sift_up.
+    // sift_down_to_bottom: "which child moves up" is local to a node, so the row evaluates it for a whole 4-level subtree
+    // at once (lane j < 15 = node with relative heap index j, one 8-byte read of both children per lane, from LDS or from
+    // the spill array); a lane is on the root-to-leaf path iff the choices of its ancestors inside the subtree lead to
+    // it, and all moves of a round are one masked store.  Four levels per memory round trip.
+    uint32_t lvl, offm1, amask, dpat;  // per-lane constants of the subtree mapping
+    __device__ __forceinline__ void init_tree(const Lane& L) {
+        const uint32_t j1 = (uint32_t)L.gl + 1u;
+        lvl = 31u - (uint32_t)__builtin_clz(j1);
+        offm1 = L.gl < 15 ? j1 - (1u << lvl) - 1u : 0x40000000u;
+        amask = 0;
+        dpat = 0;
+        for (uint32_t k = 1; k <= lvl; ++k) {
+            const uint32_t anc = (j1 >> k) - 1u, dir = (j1 >> (k - 1)) & 1u;
+            amask |= 1u << anc;
+            dpat |= dir << anc;
+        }
+        if (L.gl >= 15) { amask = 0; dpat = 1; }  // never matches
+    }
     __device__ __forceinline__ void pop(const Lane& L, bool act) {
         act = act && len > 0;
         const uint32_t last = act ? len - 1 : 0;
         uint32_t item = 0;
-        if (act) item = get1(last + 1);
+        if (act) item = get1(last + 1);  // only needed once the hole has reached a leaf: stays in flight meanwhile
         len = act ? last : len;
-        bool go = act && len > 0;  // a heap that is empty now: nothing to restore
+        const bool go = act && len > 0;  // a heap that is empty now: nothing to restore
         const uint32_t end = len;
-        uint32_t pos = 0, child = 1;
-        // while child <= end.saturating_sub(2): both children exist
-        while (__ballot(go && child + 1 < end)) {
-            const bool step = go && child + 1 < end;
+        uint32_t root = 0, pos = 0;
+        uint32_t pkey = 0;  // key of the value now stored in the parent of the hole (0 at the heap root: never moves)
+        bool going = go;
+        while (__ballot(going)) {
+            const uint32_t aidx = ((root + 1) << lvl) + offm1;
+            const uint32_t c = 2 * aidx + 1;
+            const bool exists = going && aidx < end, have1 = going && c < end, have2 = going && c + 1 < end;
             uint32_t le = 0, ri = 0;
-            if (step) {
-                if (child < hl) {  // the pair (2a+1, 2a+2) is one aligned 8-byte word in LDS and in the spill array
-                    const uint2 p = *reinterpret_cast<const uint2*>(l + child + 1);
+            if (have1) {
+                if (c < hl) {  // the pair (2a+1, 2a+2) is one aligned 8-byte word in LDS and in the spill array
+                    const uint2 p = *reinterpret_cast<const uint2*>(l + c + 1);
                     le = p.x;
                     ri = p.y;
                 } else {
-                    const uint64_t p = mx_gload64(reinterpret_cast<const uint64_t*>(g + (child - hl)));
+                    const uint64_t p = mx_gload64(reinterpret_cast<const uint64_t*>(g + (c - hl)));
                     le = (uint32_t)p;
                     ri = (uint32_t)(p >> 32);
                 }
             }
             // child += (data[child] <= data[child + 1]); Reverse => right.d <= left.d picks the right child
-            const bool pick = (ri >> sb) <= (le >> sb);
-            const uint32_t c = child + (pick ? 1u : 0u);
-            if (step && L.gl == 0) set1(pos + 1, pick ? ri : le);
-            pos = step ? c : pos;
-            child = step ? 2 * c + 1 : child;
+            const bool pick = have2 && (ri >> sb) <= (le >> sb);
+            const uint32_t cv = pick ? ri : le;
+            const uint32_t B = L.gballot(pick);
+            // a node is on the path iff every ancestor inside this subtree chose the child leading to it
+            const bool onpath = exists && ((B & amask) == dpat);
+            const uint32_t pm = L.gballot(onpath);
+            if (onpath && have1) set1(aidx + 1, cv);
+            mx_wave_sync();
+            const uint32_t jd = 31u - (uint32_t)__builtin_clz(pm | 1u);  // deepest path node (the subtree root exists)
+            const uint32_t ad = L.gbcast(aidx, jd);
+            const uint32_t h1 = L.gballot(have1);
+            const bool leaf = !((h1 >> jd) & 1u);  // the hole ends here
+            const uint32_t par = L.gbcast(cv, leaf ? ((jd > 0 ? jd - 1 : 0) >> 1) : jd);  // what the hole's parent just received
+            if (going) {
+                if (leaf) {
+                    pos = ad;
+                    pkey = jd > 0 ? par >> sb : pkey;
+                    going = false;
+                } else {
+                    pkey = par >> sb;
+                    root = 2 * ad + 1 + ((B >> jd) & 1u);  // jd is on the subtree's last level: descend
+                }
+            }
+        }
+        // sift_up(0, pos) of the former last element: it only moves when it is smaller than the new parent value
+        const bool climb = go && (item >> sb) < pkey;
+        if (__ballot(climb)) {
+            place(L, pos + 1, item, go);
+        } else {
+            if (go && L.gl == 0) set1(pos + 1, item);
             mx_wave_sync();
         }
-        // if child == end - 1: a single child
-        {
-            const bool one = go && child + 1 == end;
-            uint32_t v = 0;
-            if (one) v = get1(child + 1);
-            if (one && L.gl == 0) set1(pos + 1, v);
-            pos = one ? child : pos;
-            mx_wave_sync();
-        }
-        place(L, pos + 1, item, go);  // sift_up(0, pos) of the former last element
     }
 };
 
@@ -353,6 +389,7 @@ __global__ __launch_bounds__(WAVE) void k_search_mx(MxArgs a) {
     heap.hl = s.hl;
     heap.sb = s.sb;
     heap.len = 0;
+    heap.init_tree(L);
     MxVisited<VRR> vis;
     vis.init();
 

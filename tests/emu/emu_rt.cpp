@@ -66,6 +66,41 @@ emu_switch:
 
 namespace emu {
 
+// ---- guarded "device" memory ------------------------------------------------------------------------------------------
+static std::mutex g_alloc_mu;
+struct AllocInfo { void* base; size_t map_bytes; };
+static std::vector<std::pair<void*, AllocInfo>> g_allocs;
+
+void* guarded_alloc(size_t bytes) {
+    const size_t page = 4096;
+    const size_t rounded = (std::max<size_t>(bytes, 1) + 255) / 256 * 256;
+    const size_t body = (rounded + page - 1) / page * page;
+    const size_t map_bytes = body + 2 * page;
+    char* base = static_cast<char*>(mmap(nullptr, map_bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0));
+    if (base == MAP_FAILED) return nullptr;
+    mprotect(base, page, PROT_NONE);                // below the buffer
+    mprotect(base + page + body, page, PROT_NONE);  // right after its last 256-byte unit
+    char* p = base + page + (body - rounded);
+    memset(p, 0xA5, rounded);  // device memory is not zero initialised
+    std::lock_guard<std::mutex> lk(g_alloc_mu);
+    g_allocs.push_back({p, AllocInfo{base, map_bytes}});
+    return p;
+}
+
+void guarded_free(void* p) {
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(g_alloc_mu);
+    for (size_t i = 0; i < g_allocs.size(); ++i)
+        if (g_allocs[i].first == p) {
+            munmap(g_allocs[i].second.base, g_allocs[i].second.map_bytes);
+            g_allocs[i] = g_allocs.back();
+            g_allocs.pop_back();
+            return;
+        }
+    fprintf(stderr, "emu: hipFree of a pointer hipMalloc never returned (%p)\n", p);
+    abort();
+}
+
 static constexpr size_t kStackBytes = 512 * 1024;
 static constexpr int kMaxThreadsPerBlock = 1024;
 
@@ -285,6 +320,14 @@ void run_grid(dim3 grid, dim3 block, size_t lds_bytes, void (*thunk)(void*), voi
             memset(smem, 0xCD, std::min(sizeof(smem), lds_bytes + 4096));  // LDS is not zero initialised
             const Idx bid{(unsigned)(b % grid.x), (unsigned)((b / grid.x) % grid.y), (unsigned)(b / ((uint64_t)grid.x * grid.y))};
             run_block(wk, bid, block, grid, fibers, waves);
+            // the words right after the launch's dynamic LDS segment must be untouched (an out-of-range LDS store is
+            // dropped by the hardware; here it would silently land in the next bytes)
+            for (size_t i = lds_bytes; i < std::min(sizeof(smem), lds_bytes + 4096); ++i)
+                if (smem[i] != 0xCD) {
+                    fprintf(stderr, "emu: workgroup (%u,%u,%u) wrote LDS byte %zu, past the %zu bytes of the launch\n", bid.x, bid.y, bid.z, i,
+                            lds_bytes);
+                    abort();
+                }
         }
     };
     const uint32_t T = (uint32_t)std::min<uint64_t>(max_threads, nblocks);

@@ -223,18 +223,23 @@ static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
     p->totalGlobalMem = (size_t)8 << 30;
     return hipSuccess;
 }
+// "Device" allocations end right before an inaccessible guard page, so an access past the end of a buffer faults here
+// the way it would fault (or silently corrupt a neighbour) on the GPU.  256-byte granularity like hipMalloc.
+namespace emu {
+void* guarded_alloc(size_t bytes);
+void guarded_free(void* p);
+}  // namespace emu
 template <class T>
 static inline hipError_t hipMalloc(T** p, size_t bytes) {
-    void* q = aligned_alloc(256, (bytes + 255) / 256 * 256 + 256);
+    void* q = emu::guarded_alloc(bytes);
     if (!q) return hipErrorOutOfMemory;
-    memset(q, 0xA5, bytes);  // device memory is not zero initialised
     *p = static_cast<T*>(q);
     return hipSuccess;
 }
-static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+static inline hipError_t hipFree(void* p) { emu::guarded_free(p); return hipSuccess; }
 template <class T>
 static inline hipError_t hipHostMalloc(T** p, size_t bytes, unsigned = 0) { return hipMalloc(p, bytes); }
-static inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
+static inline hipError_t hipHostFree(void* p) { emu::guarded_free(p); return hipSuccess; }
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t = nullptr) { memmove(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemcpy2D(void* d, size_t dpitch, const void* s, size_t spitch, size_t width, size_t height, hipMemcpyKind) {

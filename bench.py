@@ -67,6 +67,48 @@ def graph_cache_path(args, n, dim, seed, bits, R):
     return path
 
 
+def canary_verdict(returncode, stdout):
+    """Did a small run of this workload on k_search_mx (VS_MX=2) reproduce the oracle bit for bit?  -> (ok, reason)"""
+    if returncode != 0:
+        return False, f"exit code {returncode}"
+    line = next((ln for ln in reversed(stdout.strip().splitlines()) if ln.startswith("{")), None)
+    if line is None:
+        return False, "no JSON line"
+    try:
+        j = json.loads(line)
+    except ValueError as e:
+        return False, f"bad JSON ({e})"
+    cb = j.get("cpu_baseline") or {}
+    if cb.get("gpu_rows_identical") is not True or cb.get("gpu_dist_bit_identical_frac") != 1.0:
+        return False, f"rows differ from the oracle ({cb.get('sample')})"
+    if not j.get("recall_at_k", 0) > 0.9:
+        return False, f"recall {j.get('recall_at_k')}"
+    return True, f"{cb.get('sample', '').split(',')[0]} identical to the oracle"
+
+
+def mx_canary(args):
+    """k_search_mx (four scans per wave, vs_search_mx.hip) is newer than the measurements in profiles/: before it is even
+    tried in this process, a child process runs a small instance of the same workload on it with a time limit and
+    checks the rows against the oracle.  A crash, a hang or a single differing row keeps this run on k_search_fast."""
+    import subprocess
+    env = {k_: v_ for k_, v_ in os.environ.items() if k_ not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
+                                                                 "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "TORCHELASTIC_RUN_ID")}
+    env.update(VS_MX="2", VS_F_LDS_MAX_INS="0", VS_BENCH_CANARY="1")  # 2 = insist: every query launch must run on k_search_mx
+    cmd = [sys.executable, os.path.abspath(__file__), "--n", "200000", "--nq", "8192", "--steps", "1", "--warmup", "1", "--fixed",
+           "100,50", "--graph-cache", "none", "--scan-nq", "0", "--cpu-seconds", "3", "--dim", str(args.dim), "--distance",
+           args.distance, "--k", str(args.k)]
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    except subprocess.TimeoutExpired:
+        return False, "timed out (300 s)"
+    except Exception as e:
+        return False, repr(e)
+    ok, why = canary_verdict(r.returncode, r.stdout)
+    if not ok:
+        log("k_search_mx canary stderr tail:", r.stderr[-400:].replace("\n", " | "))
+    return ok, why
+
+
 def choose_operating_point(run_sample, k, target, sweep_log, err_type=Exception):
     """Cheapest (search_list_size, rescore) whose recall on the sample reaches `target`.
 
@@ -166,6 +208,19 @@ def main():
 
     ctx = P.Context(local_rank)
     log("device:", ctx.device_name())
+    # which search kernel: VS_MX set by the user is respected; otherwise k_search_mx is tried (canary first, then an A/B
+    # on a full batch of this run's queries, both outside the timed region) wherever the table-less regime applies
+    kernel_choice = {"chosen": "k_search_fast"}
+    try_mx = "VS_MX" not in os.environ and not os.environ.get("VS_BENCH_CANARY") and args.n >= 4_000_000
+    if try_mx and rank == 0:
+        t0 = time.time()
+        ok, why = mx_canary(args)
+        kernel_choice["canary"] = ("passed: " if ok else "failed: ") + why
+        kernel_choice["canary_s"] = round(time.time() - t0, 1)
+        log("k_search_mx canary", kernel_choice["canary"])
+        try_mx = ok
+    if os.environ.get("VS_MX", "0") not in ("", "0"):
+        kernel_choice["chosen"] = "k_search_mx where eligible (VS_MX set by the caller)"
     dt = {"l2": P.VS_L2, "cosine": P.VS_COSINE, "ip": P.VS_IP}[args.distance]
     n, dim, k = args.n, args.dim, args.k
     R = 50
@@ -286,6 +341,38 @@ def main():
             gather_topk(out_ids, out_dist)
         return st
 
+    if world > 1:  # every rank follows rank 0's canary
+        import torch.distributed as dist
+        flag = torch.tensor([1 if try_mx else 0], dtype=torch.int32, device=dev)
+        dist.broadcast(flag, 0)
+        try_mx = bool(flag.item())
+    if try_mx:
+        # A/B on batch 0: same queries through both kernels, results must be identical, the faster one is used
+        def timed(mx):
+            os.environ["VS_MX"] = "1" if mx else "0"
+            step(0)  # sizes the launch from its own statistics
+            barrier()
+            t1 = time.perf_counter()
+            step(0)
+            barrier()
+            return time.perf_counter() - t1, out_ids.clone(), out_dist.clone()
+        try:
+            t_fast, ids_f, dist_f = timed(False)
+            t_mx, ids_m, dist_m = timed(True)
+            same = bool(torch.equal(ids_f, ids_m)) and bool(torch.equal(dist_f.view(torch.int32), dist_m.view(torch.int32)))
+            kernel_choice.update(k_search_fast_ms_per_step=round(t_fast * 1e3, 3), k_search_mx_ms_per_step=round(t_mx * 1e3, 3),
+                                 results_identical=same)
+            use_mx = same and t_mx < 0.97 * t_fast
+        except P.VsError as e:
+            kernel_choice["ab_error"] = str(e)
+            use_mx = False
+        if world > 1:
+            flag = torch.tensor([1 if use_mx else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # all ranks run the same kernel
+            use_mx = bool(flag.item())
+        os.environ["VS_MX"] = "1" if use_mx else "0"
+        kernel_choice["chosen"] = "k_search_mx" if use_mx else "k_search_fast"
+        log("search kernel A/B:", kernel_choice)
     for b in range(args.warmup):
         step(b)
     ctx.profile_enable(True)
@@ -336,7 +423,7 @@ def main():
                                    "rescore": pj.get("rescore"), "file": os.path.basename(pmc_path)}
         except Exception:
             pass
-    roofline = {"bound": "hbm", "kernel": "k_search_fast", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
+    roofline = {"bound": "hbm", "kernel": "k_search_mx" if kernel_choice["chosen"].startswith("k_search_mx") else "k_search_fast", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(achieved / 8000.0, 5), "traffic": traffic, "traffic_other_operating_point": traffic_ref,
                 "alg_bytes_per_launch": int(per_launch), "avg_kernel_ms": round(avg_ms, 4), "launches": s_n,
                 "alg_bytes_per_query": round(alg_bytes_search / max(tot.get("queries", 1) - tot.get("fallback_scans", 0), 1), 1)}
@@ -396,6 +483,7 @@ def main():
         "recall_at_k": round(recall, 4),
         "recall_target_met": bool(recall >= args.recall_target),
         "recall_sweep": sweep_log,
+        "search_kernel": kernel_choice,
         "roofline": roofline,
         "sbq_scan_roofline": scan_roofline,
         "kernels": kernels,

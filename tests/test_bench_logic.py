@@ -61,3 +61,14 @@ def test_graph_cache_path():
     assert bench.graph_cache_path(a, 1_000_000, 768, 3, 2, 50) is None  # small builds are not worth caching
     p = bench.graph_cache_path(a, 10_000_000, 768, 5, 2, 50)
     assert p is None or ("vs_graph_cache_" in p and p.endswith(".10000000x768.l2.b2.R50.L100.s5"))
+
+
+def test_canary_verdict():
+    good = '{"recall_at_k": 0.995, "cpu_baseline": {"gpu_rows_identical": true, "gpu_dist_bit_identical_frac": 1.0, "sample": "8192 of the step"}}'
+    assert bench.canary_verdict(0, "noise\n" + good + "\n")[0]
+    assert not bench.canary_verdict(-11, good)[0]                       # crashed
+    assert not bench.canary_verdict(0, "")[0]                           # nothing printed
+    assert not bench.canary_verdict(0, good.replace("true", "false"))[0]
+    assert not bench.canary_verdict(0, good.replace("1.0", "0.99"))[0]
+    assert not bench.canary_verdict(0, good.replace("0.995", "0.2"))[0]
+    assert not bench.canary_verdict(0, '{"cpu_baseline": {"value": null}}')[0]

@@ -38,6 +38,19 @@ class _DevArr:
         self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
 
 
+# Dry run of THIS SCRIPT's control flow without a GPU (tests/test_bench_dry_run.py): with VS_EMU=1 the library is the
+# wave64 interpreter build of the same kernel sources (tests/emu/), "device" memory is host memory and torch stays on the
+# CPU.  The JSON line then says so ("dry_run") and its numbers mean nothing; nothing else in this file depends on it.
+EMU = bool(os.environ.get("VS_EMU"))
+
+
+def _dev_tensor(torch, np, ptr, shape, dev):
+    if not EMU:
+        return torch.as_tensor(_DevArr(ptr, shape, "<f4"), device=dev)
+    count = int(shape[0]) * int(shape[1])
+    return torch.from_numpy(np.ctypeslib.as_array((C.c_float * count).from_address(int(ptr))).reshape(shape))
+
+
 def graph_cache_path(args, n, dim, seed, bits, R):
     """Where the built neighbor array of this exact configuration is kept between runs (None = no cache)."""
     if args.graph_cache in (None, "", "none"):
@@ -94,7 +107,8 @@ def mx_canary(args):
     env = {k_: v_ for k_, v_ in os.environ.items() if k_ not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
                                                                  "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "TORCHELASTIC_RUN_ID")}
     env.update(VS_MX="2", VS_F_LDS_MAX_INS="0", VS_BENCH_CANARY="1")  # 2 = insist: every query launch must run on k_search_mx
-    cmd = [sys.executable, os.path.abspath(__file__), "--n", "200000", "--nq", "8192", "--steps", "1", "--warmup", "1", "--fixed",
+    small = ["--n", "4000", "--nq", "64", "--recall-queries", "16"] if EMU else ["--n", "200000", "--nq", "8192"]
+    cmd = [sys.executable, os.path.abspath(__file__), *small, "--steps", "1", "--warmup", "1", "--fixed",
            "100,50", "--graph-cache", "none", "--scan-nq", "0", "--cpu-seconds", "3", "--dim", str(args.dim), "--distance",
            args.distance, "--k", str(args.k)]
     try:
@@ -199,8 +213,14 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if EMU:
+        from pgvectorscale_amd import _lib as _l
+        _l.LIB_PATH = os.path.join(ROOT, "tests", "emu", "libvsgpu_emu.so")
+        dev = torch.device("cpu")
+        torch.cuda.synchronize = lambda *a_, **k_: None
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
 
     import pgvectorscale_amd as P
     from pgvectorscale_amd import _lib
@@ -211,7 +231,8 @@ def main():
     # which search kernel: VS_MX set by the user is respected; otherwise k_search_mx is tried (canary first, then an A/B
     # on a full batch of this run's queries, both outside the timed region) wherever the table-less regime applies
     kernel_choice = {"chosen": "k_search_fast"}
-    try_mx = "VS_MX" not in os.environ and not os.environ.get("VS_BENCH_CANARY") and args.n >= 4_000_000
+    try_mx = "VS_MX" not in os.environ and not os.environ.get("VS_BENCH_CANARY") and \
+        (args.n >= 4_000_000 or bool(os.environ.get("VS_BENCH_TRY_MX")))
     if try_mx and rank == 0:
         t0 = time.time()
         ok, why = mx_canary(args)
@@ -280,8 +301,8 @@ def main():
     nr = min(args.recall_queries, nq)
     rq_ptr = ctx.alloc(nr * dim * 4)
     fill_device(ctx, gp, QBASE - (1 << 30), nr, rq_ptr)
-    X = torch.as_tensor(_DevArr(vecs_ptr.value, (n, vstride), "<f4"), device=dev)[:, :dim]
-    Qs = torch.as_tensor(_DevArr(rq_ptr.value, (nr, dim), "<f4"), device=dev)
+    X = _dev_tensor(torch, np, vecs_ptr.value, (n, vstride), dev)[:, :dim]
+    Qs = _dev_tensor(torch, np, rq_ptr.value, (nr, dim), dev)
     t0 = time.time()
     best_d = torch.full((nr, k), float("inf"), device=dev)
     best_i = torch.zeros((nr, k), dtype=torch.int64, device=dev)
@@ -475,7 +496,7 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "u64 xor+popcount (SBQ) / f32 (rerank)",
-        "data": "synthetic",
+        "data": "synthetic" if not EMU else "synthetic (DRY RUN on the wave64 interpreter: no GPU, numbers meaningless)",
         "config": {"workload": f"{n}x{dim} synthetic clustered unit-norm f32, diskann index (SBQ {bits} bit, R={R}), "
                                f"{args.distance}, top-{k}", "n": n, "dim": dim, "bits": bits, "words": W,
                    "num_neighbors": R, "queries_per_step_per_gpu": nq, "search_list_size": L, "rescore": S, "k": k,

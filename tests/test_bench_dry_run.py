@@ -1,0 +1,35 @@
+"""bench.py end to end without a GPU: its whole control flow (on-device index manufacture, ground truth, operating-point
+search, k_search_mx canary child process + A/B, timed steps, flat-scan section, CPU baseline + closing parity check, JSON
+assembly) runs against the wave64 interpreter build of the kernels (VS_EMU=1).  The numbers of such a run mean nothing;
+the point is that a typo in the benchmark cannot wait for the round-end GPU run to be found.  ~2 minutes: only with
+VS_EMU_FULL=1."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.skipif(not os.environ.get("VS_EMU_FULL"), reason="slow (about 2 minutes); set VS_EMU_FULL=1")
+def test_bench_dry_run_on_the_interpreter():
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "emu"), "-j8", "-s"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    env = dict(os.environ, VS_EMU="1", VS_BENCH_TRY_MX="1", VS_F_LDS_MAX_INS="0")
+    env.pop("VS_MX", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--n", "6000", "--dim", "64", "--nq", "128", "--steps", "1", "--warmup", "1",
+           "--recall-queries", "16", "--scan-nq", "8", "--cpu-seconds", "1", "--graph-cache", "none"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, cwd=ROOT, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads(r.stdout.strip().splitlines()[-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in j, key
+    assert "DRY RUN" in j["data"] and j["config"]["workload"]
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(j["roofline"])
+    assert j["cpu_baseline"]["gpu_rows_identical"] is True and j["cpu_baseline"]["gpu_dist_bit_identical_frac"] == 1.0
+    sk = j["search_kernel"]
+    assert sk["canary"].startswith("passed") and sk["results_identical"] is True
+    assert j["recall_target_met"] is True

@@ -178,7 +178,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=50_000_000,
+    ap.add_argument("--n", "--corpus", dest="n", type=int, default=50_000_000,
                     help="corpus size (BASELINE configs: 1M / 10M / 50M); the default is the configuration BASELINE.json quotes "
                          "its metric on (50M x 768, L2): the whole index (177 GB) fits one MI355X; the on-device build takes "
                          "about 6 minutes of the run.  --n 10000000 --distance cosine is configs[2], --n 1000000 configs[1]")
@@ -210,8 +210,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if EMU:
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     if EMU:
         from pgvectorscale_amd import _lib as _l
@@ -226,7 +229,7 @@ def main():
     from pgvectorscale_amd import _lib
     from pgvectorscale_amd.datagen import DatagenParams, fill_device
 
-    ctx = P.Context(local_rank)
+    ctx = P.Context(0 if EMU else local_rank)
     log("device:", ctx.device_name())
     # which search kernel: VS_MX set by the user is respected; otherwise k_search_mx is tried (canary first, then an A/B
     # on a full batch of this run's queries, both outside the timed region) wherever the table-less regime applies

@@ -33,3 +33,21 @@ def test_bench_dry_run_on_the_interpreter():
     sk = j["search_kernel"]
     assert sk["canary"].startswith("passed") and sk["results_identical"] is True
     assert j["recall_target_met"] is True
+
+
+@pytest.mark.skipif(not os.environ.get("VS_EMU_FULL"), reason="slow (about 2 minutes); set VS_EMU_FULL=1")
+def test_bench_dry_run_two_ranks():
+    """the N > 1 launch line of the driver (torch.distributed.run, one rank per GPU), with gloo standing in for RCCL"""
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "emu"), "-j8", "-s"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    env = dict(os.environ, VS_EMU="1", VS_EMU_THREADS="4", VS_BENCH_TRY_MX="1", VS_F_LDS_MAX_INS="0")
+    env.pop("VS_MX", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29519", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--corpus", "4000", "--dim", "64", "--nq", "64",
+           "--steps", "1", "--warmup", "1", "--recall-queries", "16", "--scan-nq", "0", "--cpu-seconds", "1", "--graph-cache", "none",
+           "--fixed", "100,50"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, cwd=ROOT, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and "query-sharded x2" in j["config"]["parallelism"]
+    assert j["search_kernel"]["results_identical"] is True

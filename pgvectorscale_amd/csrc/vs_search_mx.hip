@@ -479,6 +479,7 @@ __global__ __launch_bounds__(WAVE) void k_search_mx(MxArgs a) {
     // rows while it cannot visit (consume, AM/graph/mod.rs:174-184), then all scans that can do one visit_closest()
     // expansion (greedy_search_iterate, AM/graph/mod.rs:357-385) ----
     bool done = !alive;
+    uint64_t ft_val = 1;     // heap tid of the visited list's front entry
     uint32_t next_node = 0;  // node id of the heap root
     if (alive && heap.len > 0) next_node = mx_gload32(ghash + (hp[1] & smask));
     for (;;) {
@@ -502,8 +503,11 @@ __global__ __launch_bounds__(WAVE) void k_search_mx(MxArgs a) {
             uint32_t fd, fnode;
             vis.pop_front(L, fd, fnode, take);
             st_reads += take ? 1u : 0u;
-            uint64_t tid = 1;
-            if (take) tid = a.tids[fnode];
+            const uint64_t tid = ft_val;  // requested when this entry became the front
+            if (__ballot(take && vis.len > 0)) {  // the new front's heap tid, should the scan consume again right away
+                const uint32_t fn = L.gbcast(vis.n[0], vis.head);
+                if (take && vis.len > 0) ft_val = a.tids[fn];
+            }
             const bool live_row = take && (tid & 0xFFFFull) != 0;  // InvalidOffsetNumber: deleted tuple (AM/scan.rs:231-234)
             if (live_row && L.gl == 0) {
                 s.out_ids[(size_t)q * s.M + emitted] = fnode;
@@ -538,21 +542,44 @@ __global__ __launch_bounds__(WAVE) void k_search_mx(MxArgs a) {
         vis.insert(L, hd, node, ex2);
         // ---- visit_lsn_internal, Disk arm (AM/sbq/storage.rs:135-190) ----
         uint32_t c = 0;          // survivors of this visit, in neighbor-list order
-        bool open = ex2;         // the list has not ended yet
+        fail(ex2 && (nins_g + 64u) * 4u > s.gcap * 3u, OVF_HASH);  // room for every id of this list
+        // prepare_insert marks BEFORE the label check (AM/sbq/storage.rs:148-172).  First the live slots of the list and
+        // the first probe of every one of them (up to four L2 atomics per lane in flight) ...
+        bool actk[4];
+        uint32_t gsk[4], oldk[4];
+        {
+            bool open = ex2 && alive;  // the list has not ended yet
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                // list ends at the first InvalidBlockNumber (AM/sbq/node.rs:260-285)
+                const uint32_t inval = L.gballot(nb[k] == VS_INVALID_NODE);
+                const uint32_t nvalid = inval ? (uint32_t)__builtin_ctz(inval) : 16u;
+                actk[k] = open && (uint32_t)L.gl < nvalid;
+                open = open && nvalid == 16u;
+                gsk[k] = hash_u32(nb[k] ^ 0x5bd1e995u) & gmask;
+                oldk[k] = VS_EMPTY;
+                if (actk[k]) oldk[k] = atomicCAS(&ghash[gsk[k]], VS_EMPTY, nb[k]);  // L2 atomic
+            }
+        }
+        // ... then the probe sequences are finished, the label filter applied and the survivors compacted in list order
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            if (!__ballot(open && (uint32_t)k * 16u < a.R)) break;
+            if (!__ballot(actk[k])) continue;
             const uint32_t nid = nb[k];
-            // list ends at the first InvalidBlockNumber (AM/sbq/node.rs:260-285)
-            const uint32_t inval = L.gballot(nid == VS_INVALID_NODE);
-            const uint32_t nvalid = inval ? (uint32_t)__builtin_ctz(inval) : 16u;
-            const bool act = open && (uint32_t)L.gl < nvalid;
-            fail(open && (nins_g + MX_G) * 4u > s.gcap * 3u, OVF_HASH);
-            open = open && alive;
-            // prepare_insert marks BEFORE the label check (AM/sbq/storage.rs:148-172)
-            uint32_t hslot = 0;
-            const bool fresh = dedup_insert(nid, act && alive, hslot);
-            st_reads += (uint32_t)__builtin_popcount(L.gballot(fresh));  // SbqNode::read(neighbor)
+            bool fresh = false;
+            uint32_t hslot = gsk[k];
+            if (actk[k]) {
+                uint32_t o = oldk[k];
+                for (;;) {
+                    if (o == VS_EMPTY) { fresh = true; break; }
+                    if (o == nid) break;
+                    hslot = (hslot + 1) & gmask;
+                    o = atomicCAS(&ghash[hslot], VS_EMPTY, nid);
+                }
+            }
+            const uint32_t fm = L.gballot(fresh);
+            nins_g += (uint32_t)__builtin_popcount(fm);
+            st_reads += (uint32_t)__builtin_popcount(fm);  // SbqNode::read(neighbor)
             // label filter: query.labels.overlaps(node.labels) (AM/labels/mod.rs:124-142)
             bool pass = fresh;
             if (has_label_filter && fresh) {
@@ -574,7 +601,6 @@ __global__ __launch_bounds__(WAVE) void k_search_mx(MxArgs a) {
                 surv_e[rank] = hslot;
             }
             c += (uint32_t)__builtin_popcount(pm);
-            open = open && nvalid == 16u;
         }
         c = (ex2 && alive) ? c : 0u;
         fail(c > 0 && heap.len + c > s.hcap, OVF_HEAP);
@@ -633,8 +659,13 @@ __global__ __launch_bounds__(WAVE) void k_search_mx(MxArgs a) {
                 heap.push(L, elem, on);
             }
         }
-        // the root can only change in an expansion: ask for the id of the next node to visit now
+        // the root can only change in an expansion: ask for the id of the next node to visit now, and for the heap tid of
+        // the visited list's front entry (what the next consume() returns)
         if (ex && alive && heap.len > 0) next_node = mx_gload32(ghash + (hp[1] & smask));
+        {
+            const uint32_t fn = L.gbcast(vis.n[0], vis.head);
+            if (ex && alive && vis.len > 0) ft_val = a.tids[fn];
+        }
     }
 
     // one `next` call per emitted row, plus the call that found the stream exhausted

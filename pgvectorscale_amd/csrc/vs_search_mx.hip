@@ -138,12 +138,23 @@ struct MxHeap {
         uint32_t depth = row ? 32u - (uint32_t)__builtin_clz(p1l) : 0u;  // ranks 1 .. depth - 1 are real ancestors
         depth = max(max((uint32_t)__builtin_amdgcn_readlane((int)depth, 0), (uint32_t)__builtin_amdgcn_readlane((int)depth, 16)),
                     max((uint32_t)__builtin_amdgcn_readlane((int)depth, 32), (uint32_t)__builtin_amdgcn_readlane((int)depth, 48)));
-        // stage in: ranks 1 .. depth (rank `depth` is the sentinel for the deepest row)
-        for (uint32_t k = 1; k <= depth && k <= 15u; ++k) {
-            const uint32_t b = p1f >> k, n = row ? (p1l >> k) - b + 1u : 0u, o = stg_off(k);
-            for (uint32_t i = r; __ballot(i < n); i += MX_G)
-                if (i < n) stg[o + i] = get1(b + i);
-        }
+        // stage in.  Rank k holds at most ceil(64 / 2^k) + 1 positions: ranks 1 and 2 take three and two steps of 16 lanes,
+        // ranks 3..5 one step each, ranks 6..13 (two positions each) one step together, ranks 14, 15 one more when the
+        // heap is that deep.  (Ranks past the root copy the sentinel l[0].)
+        auto in_rank = [&](uint32_t k, uint32_t i) {
+            const uint32_t b = p1f >> k, n = row ? (p1l >> k) - b + 1u : 0u;
+            if (i < n) stg[stg_off(k) + i] = get1(b + i);
+        };
+        in_rank(1, r);
+        in_rank(1, r + 16);
+        in_rank(1, r + 32);
+        in_rank(2, r);
+        in_rank(2, r + 16);
+        in_rank(3, r);
+        in_rank(4, r);
+        in_rank(5, r);
+        in_rank(6 + (r >> 1), r & 1u);
+        if (depth >= 14) in_rank(14 + ((r >> 1) & 1u), r < 4 ? (r & 1u) : 2u);
         mx_wave_sync();
         const uint32_t cst = stg_off(r) - (p1f >> r);         // slot of rank-r index x = x + cst (mod 2^32)
         const uint32_t cst_w = row_shr1(cst, 0);               // the same for rank r - 1 (lane r >= 1 writes there)
@@ -163,12 +174,25 @@ struct MxHeap {
             }
             mx_wave_sync();
         }
-        // stage out: ranks 0 .. depth - 1 (the sentinel is never written)
-        for (uint32_t k = 0; k < depth && k <= 15u; ++k) {
-            const uint32_t b = p1f >> k, n = (row && (p1l >> k) >= 1u) ? (p1l >> k) - b + 1u : 0u, o = stg_off(k);
-            for (uint32_t i = r; __ballot(i < n); i += MX_G)
-                if (i < n && b + i >= 1u) set1(b + i, stg[o + i]);
-        }
+        // stage out (same steps, plus the new leaves = rank 0; the sentinel, position 0, is never written back)
+        auto out_rank = [&](uint32_t k, uint32_t i) {
+            const uint32_t b = p1f >> k, n = row ? (p1l >> k) - b + 1u : 0u;
+            if (i < n && b + i >= 1u) set1(b + i, stg[stg_off(k) + i]);
+        };
+        out_rank(0, r);
+        out_rank(0, r + 16);
+        out_rank(0, r + 32);
+        out_rank(0, r + 48);
+        out_rank(1, r);
+        out_rank(1, r + 16);
+        out_rank(1, r + 32);
+        out_rank(2, r);
+        out_rank(2, r + 16);
+        out_rank(3, r);
+        out_rank(4, r);
+        out_rank(5, r);
+        out_rank(6 + (r >> 1), r & 1u);
+        if (depth >= 14) out_rank(14 + ((r >> 1) & 1u), r < 4 ? (r & 1u) : 2u);
         len += c;
         mx_wave_sync();
     }

@@ -364,7 +364,7 @@ __device__ __forceinline__ uint32_t mx_ham_row(const uint64_t* __restrict__ row,
 
 // NCH = 16-byte chunks of a code row per lane (4 lanes per row), VRR = visited-list registers (16 entries each)
 template <int NCH, int VRR>
-__global__ __launch_bounds__(WAVE) void k_search_mx(MxArgs a) {
+__global__ __launch_bounds__(WAVE, 3) void k_search_mx(MxArgs a) {  // 3 waves per SIMD: <= 168 VGPRs
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const FastLaunch& s = a.s;
     Lane L;

@@ -235,7 +235,7 @@ def main():
     # on a full batch of this run's queries, both outside the timed region) wherever the table-less regime applies
     kernel_choice = {"chosen": "k_search_fast"}
     try_mx = "VS_MX" not in os.environ and not os.environ.get("VS_BENCH_CANARY") and \
-        (args.n >= 4_000_000 or bool(os.environ.get("VS_BENCH_TRY_MX")))
+        (args.n >= 500_000 or bool(os.environ.get("VS_BENCH_TRY_MX")))
     if try_mx and rank == 0:
         t0 = time.time()
         ok, why = mx_canary(args)
@@ -372,8 +372,20 @@ def main():
         try_mx = bool(flag.item())
     if try_mx:
         # A/B on batch 0: same queries through both kernels, results must be identical, the faster one is used
-        def timed(mx):
+        # (k_search_mx covers the table-less regime; small corpora default to the LDS-table regime of k_search_fast, so the
+        # k_search_mx arm also switches the regime unless the caller pinned it)
+        force_tableless = "VS_F_LDS_MAX_INS" not in os.environ
+
+        def set_kernel(mx):
             os.environ["VS_MX"] = "1" if mx else "0"
+            if force_tableless:
+                if mx:
+                    os.environ["VS_F_LDS_MAX_INS"] = "0"
+                else:
+                    os.environ.pop("VS_F_LDS_MAX_INS", None)
+
+        def timed(mx):
+            set_kernel(mx)
             step(0)  # sizes the launch from its own statistics
             barrier()
             t1 = time.perf_counter()
@@ -394,7 +406,7 @@ def main():
             flag = torch.tensor([1 if use_mx else 0], dtype=torch.int32, device=dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # all ranks run the same kernel
             use_mx = bool(flag.item())
-        os.environ["VS_MX"] = "1" if use_mx else "0"
+        set_kernel(use_mx)
         kernel_choice["chosen"] = "k_search_mx" if use_mx else "k_search_fast"
         log("search kernel A/B:", kernel_choice)
     for b in range(args.warmup):

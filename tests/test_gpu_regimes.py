@@ -20,8 +20,6 @@ REGIMES = {
     "heap_spill": {"VS_F_HL": "63"},
     "heap_spill_tableless": {"VS_F_HL": "63", "VS_F_LDS_MAX_INS": "0"},
     "tiny_pool": {"VS_F_LH": "256", "VS_F_POOL": "0.01"},
-    "mx_four_scans_per_wave": {"VS_F_LDS_MAX_INS": "0", "VS_MX": "1"},
-    "mx_heap_spill": {"VS_F_LDS_MAX_INS": "0", "VS_MX": "1", "VS_F_HL": "63"},
     "general_kernel": {"VS_FAST": "0"},
     "general_kernel_spill": {"VS_FAST": "0", "VS_HL": "64", "VS_G0": "256"},
 }

@@ -220,10 +220,17 @@ static void run_block(Worker& wk, Idx bid, dim3 block, dim3 grid, std::vector<Fi
         for (int r = 3; r <= 8; ++r) top[-r] = 0;
         f.sp = top - 8;
     }
+    // VS_EMU_ORDER=reverse runs the lanes highest first: anything two lanes exchange through memory WITHOUT a rendezvous
+    // in between then sees the opposite order, so a result that survives both orders does not depend on it
+    static const bool reverse = [] {
+        const char* e = getenv("VS_EMU_ORDER");
+        return e && e[0] == 'r';
+    }();
     uint32_t done = 0;
     while (done < nthreads) {
         bool progress = false;
-        for (uint32_t t = 0; t < nthreads; ++t) {
+        for (uint32_t tt = 0; tt < nthreads; ++tt) {
+            const uint32_t t = reverse ? nthreads - 1 - tt : tt;
             Fiber& f = fibers[t];
             if (f.state == 3) continue;
             if (f.state == 1 && f.wave->gen == f.wait_gen) continue;

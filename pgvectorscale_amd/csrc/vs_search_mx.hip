@@ -18,6 +18,8 @@
 //
 // Scans whose state outgrows the kernel set the same status flags as in k_search_fast and are re-run by the general
 // kernel.  Results (streams, Hamming distances, GreedySearchStats counters) are bit-identical to k_search_fast's.
+#include <cstdlib>
+
 #include "vs_device.h"
 
 #define MX_MAX_QLABELS 64
@@ -363,8 +365,10 @@ __device__ __forceinline__ uint32_t mx_ham_row(const uint64_t* __restrict__ row,
 }  // namespace
 
 // NCH = 16-byte chunks of a code row per lane (4 lanes per row), VRR = visited-list registers (16 entries each)
-template <int NCH, int VRR>
-__global__ __launch_bounds__(WAVE, 3) void k_search_mx(MxArgs a) {  // 3 waves per SIMD: <= 168 VGPRs
+// GD = gather depth: steps of 4 code rows per scan whose loads are in flight together; MINW = waves per SIMD the register
+// allocator leaves room for (3: <= 168 VGPRs)
+template <int NCH, int VRR, int GD, int MINW>
+__global__ __launch_bounds__(WAVE, MINW) void k_search_mx(MxArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const FastLaunch& s = a.s;
     Lane L;
@@ -636,30 +640,30 @@ __global__ __launch_bounds__(WAVE, 3) void k_search_mx(MxArgs a) {  // 3 waves p
         // the largest c over the four rows (each row holds a uniform value: its first lane is enough)
         const uint32_t cmax = max(max((uint32_t)__builtin_amdgcn_readlane((int)c, 0), (uint32_t)__builtin_amdgcn_readlane((int)c, 16)),
                                   max((uint32_t)__builtin_amdgcn_readlane((int)c, 32), (uint32_t)__builtin_amdgcn_readlane((int)c, 48)));
-        for (uint32_t p0 = 0; p0 < cmax; p0 += 8) {  // two steps (8 rows per scan, 32 per wave) in flight
-            const uint32_t j0 = p0 + (uint32_t)(L.gl >> 2), j1 = j0 + 4;
-            const bool v0 = j0 < c, v1 = j1 < c;
-            const uint32_t id0 = v0 ? surv_id[j0] : 0u, id1 = v1 ? surv_id[j1] : 0u;
-            const uint64_t* row0 = a.codes + (size_t)id0 * a.code_stride;
-            const uint64_t* row1 = a.codes + (size_t)id1 * a.code_stride;
-            ulonglong2 r0[NCH], r1[NCH];
+        for (uint32_t p0 = 0; p0 < cmax; p0 += 4u * GD) {  // GD steps (4 GD rows per scan, 16 GD per wave) in flight
+            uint32_t jj[GD];
+            bool vv[GD];
+            ulonglong2 rr[GD][NCH];
 #pragma unroll
-            for (int t = 0; t < NCH; ++t) {
-                const uint32_t w = 2u * (uint32_t)l4 + 8u * (uint32_t)t;
-                r0[t] = (v0 && w < a.code_stride) ? *reinterpret_cast<const ulonglong2*>(row0 + w) : make_ulonglong2(0, 0);
-                r1[t] = (v1 && w < a.code_stride) ? *reinterpret_cast<const ulonglong2*>(row1 + w) : make_ulonglong2(0, 0);
-            }
-            uint32_t a0 = 0, a1 = 0;
+            for (int u = 0; u < GD; ++u) {
+                jj[u] = p0 + 4u * (uint32_t)u + (uint32_t)(L.gl >> 2);
+                vv[u] = jj[u] < c;
+                const uint32_t id = vv[u] ? surv_id[jj[u]] : 0u;
+                const uint64_t* row = a.codes + (size_t)id * a.code_stride;
 #pragma unroll
-            for (int t = 0; t < NCH; ++t) {
-                a0 += (uint32_t)__popcll(r0[t].x ^ qv[t].x) + (uint32_t)__popcll(r0[t].y ^ qv[t].y);
-                a1 += (uint32_t)__popcll(r1[t].x ^ qv[t].x) + (uint32_t)__popcll(r1[t].y ^ qv[t].y);
+                for (int t = 0; t < NCH; ++t) {
+                    const uint32_t w = 2u * (uint32_t)l4 + 8u * (uint32_t)t;
+                    rr[u][t] = (vv[u] && w < a.code_stride) ? *reinterpret_cast<const ulonglong2*>(row + w) : make_ulonglong2(0, 0);
+                }
             }
-            a0 = v0 ? a0 : 0u;
-            a1 = v1 ? a1 : 0u;
-            const uint32_t d0 = quad_sum(a0), d1 = quad_sum(a1);
-            if (v0 && l4 == 0) surv_e[j0] = (d0 << s.sb) | surv_e[j0];
-            if (v1 && l4 == 0) surv_e[j1] = (d1 << s.sb) | surv_e[j1];
+#pragma unroll
+            for (int u = 0; u < GD; ++u) {
+                uint32_t acc = 0;
+#pragma unroll
+                for (int t = 0; t < NCH; ++t) acc += (uint32_t)__popcll(rr[u][t].x ^ qv[t].x) + (uint32_t)__popcll(rr[u][t].y ^ qv[t].y);
+                const uint32_t d = quad_sum(vv[u] ? acc : 0u);
+                if (vv[u] && l4 == 0) surv_e[jj[u]] = (d << s.sb) | surv_e[jj[u]];
+            }
         }
         mx_wave_sync();
         // ---- insert_neighbor in list order (AM/graph/mod.rs:144-147) ----
@@ -732,17 +736,26 @@ bool search_mx_eligible(const vs_index* idx, const FastLaunch& s) {
            want_v <= 16 * 32 && mx_lds_bytes(s) <= 64 * 1024;
 }
 
-template <int NCH, int VRR>
-static int launch_mx_tt(vs_index* idx, const MxArgs& a, size_t lds) {
+template <int NCH, int VRR, int GD, int MINW>
+static int launch_mx_ttt(vs_index* idx, const MxArgs& a, size_t lds) {
     static bool attr_set = false;
     if (!attr_set) {
-        VS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_search_mx<NCH, VRR>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   160 * 1024));
+        VS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_search_mx<NCH, VRR, GD, MINW>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_search_mx<NCH, VRR>), dim3((a.s.nq + 3) / 4), dim3(WAVE), lds, idx->ctx->stream, a);
+    hipLaunchKernelGGL((k_search_mx<NCH, VRR, GD, MINW>), dim3((a.s.nq + 3) / 4), dim3(WAVE), lds, idx->ctx->stream, a);
     VS_HIP(hipGetLastError());
     return VS_OK;
+}
+
+template <int NCH, int VRR>
+static int launch_mx_tt(vs_index* idx, const MxArgs& a, size_t lds) {
+    // VS_MX_GD=4: 16 code rows per scan in flight (more registers: 2 waves per SIMD) instead of 8 — a tuning variant for
+    // the headline code width, to be decided by measurement
+    const char* e = getenv("VS_MX_GD");
+    if (NCH == 3 && e && *e == '4') return launch_mx_ttt<3, VRR, 4, 2>(idx, a, lds);
+    return launch_mx_ttt<NCH, VRR, 2, 3>(idx, a, lds);
 }
 
 template <int NCH>

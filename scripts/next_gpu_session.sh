@@ -12,6 +12,10 @@ for MX in 0 1; do
   VS_MX=$MX VS_F_LDS_MAX_INS=0 python bench.py --n 1000000 --fixed 100,50 --skip-cpu --scan-nq 0 2>gpurun_out/s_1m_mx$MX.err | tee gpurun_out/s_1m_mx$MX.json | cut -c1-400
   VS_MX=$MX python bench.py --n 10000000 --distance cosine --fixed 100,100 --skip-cpu --scan-nq 0 --graph-cache /tmp/vs_graph 2>gpurun_out/s_10m_mx$MX.err | tee gpurun_out/s_10m_mx$MX.json | cut -c1-400
 done
+# k_search_mx tuning variants at 10M: LDS heap top (255 / 511 / 1023 entries) x gather depth (8 / 16 rows per scan in flight)
+for HL in 255 511 1023; do for GD in 2 4; do
+  VS_MX=1 VS_F_HL=$HL VS_MX_GD=$GD python bench.py --n 10000000 --distance cosine --fixed 100,100 --skip-cpu --scan-nq 0 --graph-cache /tmp/vs_graph 2>/dev/null | python -c "import sys,json; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('mx hl=$HL gd=$GD', j['value'], j['kernels']['search'])" | tee -a gpurun_out/s_mx_variants.txt
+done; done
 for MX in 0 1; do
   VS_MX=$MX bash scripts/pmc_issue.sh 10000000 131072 100 100 /tmp/vs_graph 2>&1 | tail -30 | tee gpurun_out/s_pmc_issue_mx$MX.txt
   for p in A B; do mv gpurun_out/pmc_issue_$p.txt gpurun_out/s_pmc_issue_${p}_mx$MX.txt 2>/dev/null; done

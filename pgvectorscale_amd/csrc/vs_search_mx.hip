@@ -13,7 +13,7 @@
 //     level per step (both children in one 8-byte read).  Rust std's array mechanics are replayed exactly.
 //   * dedup set: the per-scan global table of the table-less regime (L2 atomics), one lane per neighbor, 16 per step.
 //   * visited list: sorted array in registers, entry i = lane i % 16 of register i / 16; insert / remove(0) are DPP row
-//     shifts (row_shr / row_shl) with the carry between registers taken by a row rotate.
+//     shift (row_shr) with the carry between registers taken by a row rotate; remove(0) advances a head offset.
 //   * distances: 4 lanes per code row, 4 rows per row-of-16 per step.
 //
 // Scans whose state outgrows the kernel set the same status flags as in k_search_fast and are re-run by the general
@@ -59,16 +59,9 @@ __device__ __forceinline__ uint64_t mx_gload64(const uint64_t* p) {
 __device__ __forceinline__ uint32_t row_shr1(uint32_t v, uint32_t first) {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)first, (int)v, 0x111, 0xF, 0xF, false);
 }
-// lane i <- lane i+1 of its row; lane 15 of the row keeps `last`
-__device__ __forceinline__ uint32_t row_shl1(uint32_t v, uint32_t last) {
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)last, (int)v, 0x101, 0xF, 0xF, false);
-}
-// lane i <- lane (i-1) mod 16 of its row / lane i <- lane (i+1) mod 16
+// lane i <- lane (i-1) mod 16 of its row
 __device__ __forceinline__ uint32_t row_ror1(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x121, 0xF, 0xF, false);
-}
-__device__ __forceinline__ uint32_t row_rol1(uint32_t v) {
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x12F, 0xF, 0xF, false);
 }
 
 struct Lane {

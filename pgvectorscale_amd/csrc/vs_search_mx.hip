@@ -25,6 +25,7 @@
 #define MX_MAX_QLABELS 64
 #define MX_G 16  // lanes per scan (one DPP row)
 #define MX_STG 152  // staged heap words per scan during a run of pushes (MxHeap::push_run_staged)
+#define MX_SURV 72  // survivor slots per scan (64 used; the stride keeps the rows' arrays in different LDS banks)
 
 struct MxArgs {
     const uint64_t* codes;
@@ -374,14 +375,17 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_mx(MxArgs a) {
     const uint32_t qs = alive ? q : 0u;
 
     // ---- LDS carve (per row) ----
-    uint32_t* hp_all = reinterpret_cast<uint32_t*>(smem);                // 4 x (hl + 1)
-    uint32_t* surv_id_all = hp_all + 4 * (s.hl + 1);                    // 4 x 64
-    uint32_t* surv_e_all = surv_id_all + 4 * 64;                         // 4 x 64
-    uint32_t* stg_all = surv_e_all + 4 * 64;                             // 4 x MX_STG
-    int16_t* ql_all = reinterpret_cast<int16_t*>(stg_all + 4 * MX_STG);  // 4 x MX_MAX_QLABELS
-    uint32_t* hp = hp_all + (size_t)g * (s.hl + 1);
-    uint32_t* surv_id = surv_id_all + g * 64;
-    uint32_t* surv_e = surv_e_all + g * 64;  // first the dedup slot, then (hamming << sb | slot)
+    // (row strides are padded so that the four rows' arrays start in different LDS banks: the rows execute the same
+    // instruction and touch the same relative index of their own array most of the time)
+    const uint32_t hp_stride = s.hl + 1 + 16;                                   // keeps the 8-byte alignment of sibling pairs
+    uint32_t* hp_all = reinterpret_cast<uint32_t*>(smem);                       // 4 x hp_stride
+    uint32_t* surv_id_all = hp_all + 4 * hp_stride;                             // 4 x MX_SURV
+    uint32_t* surv_e_all = surv_id_all + 4 * MX_SURV;                           // 4 x MX_SURV
+    uint32_t* stg_all = surv_e_all + 4 * MX_SURV;                               // 4 x MX_STG
+    int16_t* ql_all = reinterpret_cast<int16_t*>(stg_all + 4 * MX_STG);         // 4 x MX_MAX_QLABELS
+    uint32_t* hp = hp_all + (size_t)g * hp_stride;
+    uint32_t* surv_id = surv_id_all + g * MX_SURV;
+    uint32_t* surv_e = surv_e_all + g * MX_SURV;  // first the dedup slot, then (hamming << sb | slot)
     uint32_t* stg = stg_all + g * MX_STG;
     int16_t* ql = ql_all + g * MX_MAX_QLABELS;
 
@@ -718,7 +722,7 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_mx(MxArgs a) {
 
 // ---- host side --------------------------------------------------------------------------------------------------------
 static size_t mx_lds_bytes(const FastLaunch& s) {
-    return ((size_t)4 * (s.hl + 1) * 4 + 2 * 4 * 64 * 4 + 4 * MX_STG * 4 + 4 * MX_MAX_QLABELS * 2 + 15) / 16 * 16;
+    return ((size_t)4 * (s.hl + 1 + 16) * 4 + 2 * 4 * MX_SURV * 4 + 4 * MX_STG * 4 + 4 * MX_MAX_QLABELS * 2 + 15) / 16 * 16;
 }
 
 // can this launch run on k_search_mx?  (table-less regime, query scans only, geometry the row-of-16 mapping covers)

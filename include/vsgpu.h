@@ -264,6 +264,32 @@ int vs_scan_xs_recheck(const vs_scan* scan);
 int vs_scan_get_stats(const vs_scan* scan, vs_stats* out);
 void vs_endscan(vs_scan* scan);                                                   /* amendscan */
 
+/* ---- coalescing concurrent scans into batched launches (vs_broker.cpp) -------------------
+ * The reference serves one query per single-threaded backend (amcanparallel = false, AM/mod.rs:63); a GPU needs thousands
+ * of scans per launch.  A broker owns the index (its dispatcher thread is the only thread that touches the vs_ctx); any
+ * number of client threads call vs_broker_search(), which blocks until the scan's rows are ready.  The dispatcher
+ * gathers requests for at most max_wait_us after the oldest one (or until max_batch are waiting) and runs every group
+ * that shares (search_list_size, rescore, k, label key present) as one vs_search_batch().  In a PGRX deployment the
+ * queue lives in shared memory and the dispatcher is a background worker. */
+typedef struct vs_broker vs_broker;
+typedef struct vs_broker_config {
+    uint32_t max_batch;   /* scans per launch at most (0 = 8192)                                  */
+    uint32_t max_wait_us; /* how long the oldest waiting scan may be held back to let others join */
+} vs_broker_config;
+typedef struct vs_broker_stats {
+    uint64_t batches;   /* vs_search_batch calls made                */
+    uint64_t scans;     /* scans served                              */
+    uint64_t max_batch; /* largest number of scans in one launch     */
+} vs_broker_stats;
+int vs_broker_create(vs_index* idx, const vs_broker_config* cfg /* NULL = defaults */, vs_broker** out);
+/* one scan: the rows of its first k amgettuple calls (as vs_search_batch).  query == NULL: the SQL-NULL query (label keys
+ * ignored).  Thread safe; blocks.  out_tids / out_dist may be NULL. */
+int vs_broker_search(vs_broker* b, const float* query, const int16_t* labels, uint32_t n_labels, int has_label_key,
+                     uint32_t search_list_size, uint32_t rescore, uint32_t k, uint32_t* out_ids, uint64_t* out_tids,
+                     float* out_dist);
+int vs_broker_get_stats(vs_broker* b, vs_broker_stats* out);
+void vs_broker_destroy(vs_broker* b); /* serves what is queued, then stops the dispatcher */
+
 /* ---- build-side helpers (SURVEY.md §8f "next" rows; needed to manufacture device-resident indexes) ---------- */
 /* Welford pass over rows [0,n) in heap order, bit-exact to SbqQuantizer::add_sample (AM/sbq/quantize.rs:115-148):
  * one lane per dimension, sequential over rows.  Uses the (cosine-normalised) first dim_index dims of the vectors. */

@@ -52,6 +52,14 @@ class PagesInfo(C.Structure):
                 ("meta_version", C.c_uint32)]
 
 
+class BrokerConfig(C.Structure):
+    _fields_ = [("max_batch", C.c_uint32), ("max_wait_us", C.c_uint32)]
+
+
+class BrokerStats(C.Structure):
+    _fields_ = [("batches", C.c_uint64), ("scans", C.c_uint64), ("max_batch", C.c_uint64)]
+
+
 class Profile(C.Structure):
     _fields_ = [("ms", C.c_double * 8), ("launches", C.c_uint64 * 8)]
 
@@ -114,6 +122,10 @@ SYMBOLS = {
     "vs_scan_xs_recheck": (_i, [_vp]),
     "vs_scan_get_stats": (_i, [_vp, C.POINTER(Stats)]),
     "vs_endscan": (None, [_vp]),
+    "vs_broker_create": (_i, [_vp, C.POINTER(BrokerConfig), C.POINTER(_vp)]),
+    "vs_broker_search": (_i, [_vp, _vp, _vp, _u32, _i, _u32, _u32, _u32, _vp, _vp, _vp]),
+    "vs_broker_get_stats": (_i, [_vp, C.POINTER(BrokerStats)]),
+    "vs_broker_destroy": (None, [_vp]),
     "vs_sbq_train": (_i, [_vp]),
     "vs_sbq_quantize_corpus": (_i, [_vp]),
     "vs_build_graph": (_i, [_vp, _u32, C.c_double, _u32, _u64]),

@@ -1,0 +1,218 @@
+// vs_broker.cpp — coalescing many concurrent scans into batched launches (host side).
+//
+// PostgreSQL runs one single-threaded backend per connection and the reference serves one query per backend
+// (amcanparallel = false, AM/mod.rs:63; one TSVScanState per IndexScanDesc, AM/scan.rs:308-333).  A GPU does nothing
+// useful with one scan at a time — a launch of the search kernel is efficient from a few thousand scans up — and a HIP
+// context per backend is prohibitive.  The broker is the piece in between: ONE dispatcher thread owns the vs_index (and
+// with it the vs_ctx: the "one thread per ctx" rule of vsgpu.h holds by construction); any number of client threads call
+// vs_broker_search(), which enqueues the scan and blocks; the dispatcher gathers what arrived within a short window
+// (max_wait_us after the oldest waiting request, or max_batch requests), runs every group of scans that share the same
+// GUCs (search_list_size, rescore, k, label key present or not) as one vs_search_batch(), and hands each client its
+// rows.  Results are those of vs_search_batch, i.e. exactly the rows of the first k amgettuple calls.
+//
+// In a PGRX deployment the client side of this queue lives in shared memory (one slot per backend, a latch per slot)
+// and the dispatcher is a background worker; the queueing / grouping / batching logic is the same and is what this
+// file implements and tests (threads stand in for backends).
+#include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <cstdarg>
+#include <cstdint>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/vsgpu.h"
+
+void vs_set_error(const char* fmt, ...);
+
+namespace {
+
+struct Request {
+    const float* query;  // dim_full floats or nullptr (SQL NULL query)
+    std::vector<int16_t> labels;
+    bool has_label_key;
+    uint32_t L, rescore, k;
+    uint32_t* out_ids;
+    uint64_t* out_tids;
+    float* out_dist;
+    std::chrono::steady_clock::time_point t_arrive;
+    // completion
+    bool done = false;
+    int rc = VS_OK;
+    std::string err;
+    std::condition_variable cv;
+
+    bool same_group(const Request& o) const {
+        return L == o.L && rescore == o.rescore && k == o.k && has_label_key == o.has_label_key;
+    }
+};
+
+}  // namespace
+
+struct vs_broker {
+    vs_index* ix = nullptr;
+    vs_index_desc d{};
+    vs_broker_config cfg{};
+    std::mutex mu;
+    std::condition_variable cv_work;
+    std::deque<Request*> queue;
+    bool stop = false;
+    std::thread dispatcher;
+    vs_broker_stats st{};
+
+    void run();
+    void run_group(std::vector<Request*>& grp);
+};
+
+void vs_broker::run_group(std::vector<Request*>& grp) {
+    const uint32_t nq = (uint32_t)grp.size();
+    const Request& head = *grp[0];
+    const uint32_t k = head.k;
+    std::vector<float> q((size_t)nq * d.dim_full, 0.0f);  // a NULL query is the zero vector (AM/labels/mod.rs:214-216)
+    std::vector<int16_t> lab;
+    std::vector<uint32_t> off(nq + 1, 0);
+    for (uint32_t i = 0; i < nq; ++i) {
+        if (grp[i]->query) memcpy(&q[(size_t)i * d.dim_full], grp[i]->query, (size_t)d.dim_full * 4);
+        // (label keys are ignored for a NULL query, as amrescan does)
+        if (head.has_label_key && grp[i]->query) lab.insert(lab.end(), grp[i]->labels.begin(), grp[i]->labels.end());
+        off[i + 1] = (uint32_t)lab.size();
+    }
+    std::vector<uint32_t> ids((size_t)nq * k);
+    std::vector<uint64_t> tids((size_t)nq * k);
+    std::vector<float> dist((size_t)nq * k);
+    // scans with a label key and NULL-query scans (no key) cannot share a launch: the caller keeps them in separate groups
+    const bool keys = head.has_label_key;
+    vs_stats stats{};
+    const int rc = vs_search_batch(ix, q.data(), keys ? lab.data() : nullptr, keys ? off.data() : nullptr, nq, head.L, head.rescore, k,
+                                   ids.data(), tids.data(), dist.data(), &stats);
+    const std::string err = rc == VS_OK ? std::string() : std::string(vs_last_error());
+    std::lock_guard<std::mutex> lk(mu);
+    st.batches++;
+    st.scans += nq;
+    st.max_batch = std::max<uint64_t>(st.max_batch, nq);
+    for (uint32_t i = 0; i < nq; ++i) {
+        Request* r = grp[i];
+        if (rc == VS_OK) {
+            memcpy(r->out_ids, &ids[(size_t)i * k], (size_t)k * 4);
+            if (r->out_tids) memcpy(r->out_tids, &tids[(size_t)i * k], (size_t)k * 8);
+            if (r->out_dist) memcpy(r->out_dist, &dist[(size_t)i * k], (size_t)k * 4);
+        }
+        r->rc = rc;
+        r->err = err;
+        r->done = true;
+        r->cv.notify_one();
+    }
+}
+
+void vs_broker::run() {
+    std::unique_lock<std::mutex> lk(mu);
+    for (;;) {
+        cv_work.wait(lk, [&] { return stop || !queue.empty(); });
+        if (queue.empty()) {
+            if (stop) return;
+            continue;
+        }
+        // gather: until the oldest request has waited max_wait_us or max_batch requests are queued
+        const auto deadline = queue.front()->t_arrive + std::chrono::microseconds(cfg.max_wait_us);
+        while (!stop && queue.size() < cfg.max_batch && std::chrono::steady_clock::now() < deadline) cv_work.wait_until(lk, deadline);
+        // one group = the scans that share the oldest request's GUCs (a NULL query never carries a label key)
+        std::vector<Request*> grp;
+        Request* head = queue.front();
+        for (auto it = queue.begin(); it != queue.end() && grp.size() < cfg.max_batch;) {
+            if ((*it)->same_group(*head)) {
+                grp.push_back(*it);
+                it = queue.erase(it);
+            } else {
+                ++it;
+            }
+        }
+        lk.unlock();
+        run_group(grp);
+        lk.lock();
+    }
+}
+
+extern "C" {
+
+int vs_broker_create(vs_index* idx, const vs_broker_config* cfg, vs_broker** out) {
+    if (!idx || !out) {
+        vs_set_error("vs_broker_create: null argument");
+        return VS_ERR_INVALID;
+    }
+    *out = nullptr;
+    vs_broker* b = new (std::nothrow) vs_broker();
+    if (!b) {
+        vs_set_error("vs_broker_create: out of memory");
+        return VS_ERR_OOM;
+    }
+    b->ix = idx;
+    int rc = vs_index_get_desc(idx, &b->d);
+    if (rc != VS_OK) {
+        delete b;
+        return rc;
+    }
+    b->cfg.max_batch = cfg && cfg->max_batch ? cfg->max_batch : 8192;
+    b->cfg.max_wait_us = cfg ? cfg->max_wait_us : 200;
+    b->dispatcher = std::thread([b] { b->run(); });
+    *out = b;
+    return VS_OK;
+}
+
+int vs_broker_search(vs_broker* b, const float* query, const int16_t* labels, uint32_t n_labels, int has_label_key,
+                     uint32_t search_list_size, uint32_t rescore, uint32_t k, uint32_t* out_ids, uint64_t* out_tids, float* out_dist) {
+    if (!b || !out_ids || k == 0) {
+        vs_set_error("vs_broker_search: bad arguments");
+        return VS_ERR_INVALID;
+    }
+    Request r;
+    r.query = query;
+    // a NULL query ignores its keys (amrescan: LabeledVector::from_scan_key_data with a NULL vector)
+    r.has_label_key = has_label_key != 0 && query != nullptr;
+    if (r.has_label_key && labels) r.labels.assign(labels, labels + n_labels);
+    r.L = search_list_size;
+    r.rescore = rescore;
+    r.k = k;
+    r.out_ids = out_ids;
+    r.out_tids = out_tids;
+    r.out_dist = out_dist;
+    r.t_arrive = std::chrono::steady_clock::now();
+    std::unique_lock<std::mutex> lk(b->mu);
+    if (b->stop) {
+        vs_set_error("vs_broker_search: the broker is shutting down");
+        return VS_ERR_STATE;
+    }
+    b->queue.push_back(&r);
+    b->cv_work.notify_one();
+    r.cv.wait(lk, [&] { return r.done; });
+    lk.unlock();
+    if (r.rc != VS_OK) vs_set_error("%s", r.err.c_str());
+    return r.rc;
+}
+
+int vs_broker_get_stats(vs_broker* b, vs_broker_stats* out) {
+    if (!b || !out) {
+        vs_set_error("vs_broker_get_stats: null argument");
+        return VS_ERR_INVALID;
+    }
+    std::lock_guard<std::mutex> lk(b->mu);
+    *out = b->st;
+    return VS_OK;
+}
+
+void vs_broker_destroy(vs_broker* b) {
+    if (!b) return;
+    {
+        std::lock_guard<std::mutex> lk(b->mu);
+        b->stop = true;
+    }
+    b->cv_work.notify_all();
+    if (b->dispatcher.joinable()) b->dispatcher.join();  // drains what is queued first (run() only returns on an empty queue)
+    delete b;
+}
+
+}  // extern "C"

@@ -328,6 +328,40 @@ class DiskAnnIndex:
             self.h = None
 
 
+class Broker:
+    """Coalesces the scans of many client threads into batched launches (vs_broker_*; threads stand in for PostgreSQL
+    backends).  search() may be called from any thread; the library's dispatcher thread is the only one that touches the
+    device context."""
+
+    def __init__(self, index, max_batch=0, max_wait_us=200):
+        self.index = index
+        self._L = index._L
+        cfg = _lib.BrokerConfig(max_batch, max_wait_us)
+        h = C.c_void_p()
+        check(self._L.vs_broker_create(index.h, C.byref(cfg), C.byref(h)))
+        self.h = h
+
+    def search(self, query, labels=None, search_list_size=DEFAULT_QUERY_SEARCH_LIST_SIZE, rescore=DEFAULT_QUERY_RESCORE, k=10):
+        q = None if query is None else np.ascontiguousarray(query, np.float32).reshape(self.index.desc.dim_full)
+        lab = None if labels is None else np.ascontiguousarray(labels, np.int16)
+        ids = np.empty(k, np.uint32)
+        tids = np.empty(k, np.uint64)
+        dist = np.empty(k, np.float32)
+        check(self._L.vs_broker_search(self.h, _p(q), _p(lab), 0 if lab is None else lab.size, int(labels is not None),
+                                       search_list_size, rescore, k, _p(ids), _p(tids), _p(dist)))
+        return ids, tids, dist
+
+    def stats(self):
+        st = _lib.BrokerStats()
+        check(self._L.vs_broker_get_stats(self.h, C.byref(st)))
+        return {"batches": int(st.batches), "scans": int(st.scans), "max_batch": int(st.max_batch)}
+
+    def close(self):
+        if self.h:
+            self._L.vs_broker_destroy(self.h)
+            self.h = None
+
+
 class IndexScan:
     """IndexScanDesc + TSVScanState: rescan() = amrescan, gettuple() = amgettuple, endscan() = amendscan."""
 

@@ -1,0 +1,79 @@
+"""vs_broker_*: scans arriving from many client threads are coalesced into batched launches and every client gets exactly
+the rows a scan of its own would have returned (= the oracle's rows)."""
+import threading
+
+import numpy as np
+import pytest
+
+from helpers import TestIndex
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(600)]
+
+
+def test_concurrent_scans_are_batched_and_exact(gpu_ctx, oracle):
+    import pgvectorscale_amd as P
+    O = oracle
+    ti = TestIndex(n=2500, dim_full=64, bits=2, R=32, distance=O.L2, seed=21, kind="gauss", n_labels=5, deleted_frac=0.1, L_build=64)
+    ix = ti.upload(gpu_ctx)
+    nthreads, per_thread = 24, 6
+    q = ti.queries(nthreads * per_thread, seed=77, kind="gauss")
+    rng = np.random.default_rng(1)
+    # a mix the dispatcher has to keep apart: plain scans, scans with a label key, another (L, rescore), NULL queries
+    kinds = rng.integers(0, 4, len(q))
+    keys = [sorted(set(int(v) for v in rng.integers(1, 7, int(rng.integers(1, 3))))) for _ in range(len(q))]
+    want = {}
+    for i in range(len(q)):
+        kind = int(kinds[i])
+        if kind == 0:
+            oi, od, _ = ti.oracle.search_batch(q[i:i + 1], L=40, rescore=20, k=10)
+        elif kind == 1:
+            oi, od, _ = ti.oracle.search_batch(q[i:i + 1], L=40, rescore=20, k=10, qlabels=[keys[i]])
+        elif kind == 2:
+            oi, od, _ = ti.oracle.search_batch(q[i:i + 1], L=25, rescore=5, k=10)
+        else:
+            oi, od, _ = ti.oracle.search_batch(np.zeros((1, 64), np.float32), L=40, rescore=20, k=10)
+        want[i] = (oi[0], od[0])
+    broker = P.Broker(ix, max_batch=64, max_wait_us=20000)
+    got, errors = {}, []
+    start = threading.Barrier(nthreads)
+
+    def client(t):
+        try:
+            start.wait()
+            for j in range(per_thread):
+                i = t * per_thread + j
+                kind = int(kinds[i])
+                if kind == 0:
+                    got[i] = broker.search(q[i], None, 40, 20, 10)
+                elif kind == 1:
+                    got[i] = broker.search(q[i], list(reversed(keys[i])) + keys[i][:1], 40, 20, 10)  # unsorted, with a duplicate
+                elif kind == 2:
+                    got[i] = broker.search(q[i], None, 25, 5, 10)
+                else:
+                    got[i] = broker.search(None, [3], 40, 20, 10)  # NULL query: its key is ignored
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=client, args=(t,)) for t in range(nthreads)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors[:3]
+    for i in range(len(q)):
+        ids, tids, dist = got[i]
+        oi, od = want[i]
+        assert (ids == oi).all(), i
+        both_nan = np.isnan(dist) & np.isnan(od)
+        assert (both_nan | (dist.view(np.uint32) == od.view(np.uint32))).all(), i
+        live = ids != 0xFFFFFFFF
+        assert (tids[live] == ti.tids[ids[live]]).all()
+    st = broker.stats()
+    assert st["scans"] == len(q)
+    assert st["batches"] < len(q) / 2 and st["max_batch"] >= 4, st  # the scans really shared launches
+    # an invalid GUC is reported to the caller that sent it, and the broker keeps serving
+    with pytest.raises(P.VsError, match="query_rescore"):
+        broker.search(q[0], None, 40, 5000, 10)
+    ids, _, _ = broker.search(q[0], None, 40, 20, 10) if int(kinds[0]) != 0 else got[0]
+    broker.close()
+    ix.close()

@@ -288,6 +288,10 @@ int vs_broker_search(vs_broker* b, const float* query, const int16_t* labels, ui
                      uint32_t search_list_size, uint32_t rescore, uint32_t k, uint32_t* out_ids, uint64_t* out_tids,
                      float* out_dist);
 int vs_broker_get_stats(vs_broker* b, vs_broker_stats* out);
+vs_index* vs_broker_index(vs_broker* b);
+/* the amrescan / amgettuple mirror on top of a broker: like vs_beginscan, but every window of rows is fetched through
+ * vs_broker_search, so scans of many threads (backends) share launches; vs_rescan / vs_gettuple / vs_endscan as usual */
+int vs_beginscan_on_broker(vs_broker* b, vs_scan** out);
 void vs_broker_destroy(vs_broker* b); /* serves what is queued, then stops the dispatcher */
 
 /* ---- build-side helpers (SURVEY.md §8f "next" rows; needed to manufacture device-resident indexes) ---------- */

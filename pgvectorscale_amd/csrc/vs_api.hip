@@ -1151,6 +1151,7 @@ extern "C" int vs_search_batch_dev_finish(vs_index* ix, vs_stats* stats) {
 // ---------------------------------------------------------------------------------------------------------------
 struct vs_scan {
     vs_index* ix = nullptr;
+    vs_broker* broker = nullptr;  // non-null: windows are fetched through the broker (shared launches, any thread)
     bool active = false;
     bool null_query = false;
     std::vector<float> query;
@@ -1174,6 +1175,15 @@ extern "C" int vs_beginscan(vs_index* ix, vs_scan** out) {
     return VS_OK;
 }
 
+extern "C" int vs_beginscan_on_broker(vs_broker* b, vs_scan** out) {
+    VS_REQUIRE(b && out, "vs_beginscan_on_broker: bad args");
+    vs_scan* s = new vs_scan();
+    s->ix = vs_broker_index(b);
+    s->broker = b;
+    *out = s;
+    return VS_OK;
+}
+
 static int scan_fetch(vs_scan* s, uint32_t window) {
     vs_index* ix = s->ix;
     s->ids.assign(window, VS_INVALID_NODE);
@@ -1181,8 +1191,14 @@ static int scan_fetch(vs_scan* s, uint32_t window) {
     s->dist.assign(window, 0.f);
     uint32_t off[2] = {0, (uint32_t)s->labels.size()};
     const bool keys = s->has_label_key && !s->null_query;
-    VS_TRY(vs_search_batch(ix, s->query.data(), keys ? s->labels.data() : nullptr, keys ? off : nullptr, 1, s->L,
-                           s->rescore, window, s->ids.data(), s->tids.data(), s->dist.data(), &s->stats));
+    if (s->broker) {
+        VS_TRY(vs_broker_search(s->broker, s->null_query ? nullptr : s->query.data(), s->labels.data(), (uint32_t)s->labels.size(),
+                                keys ? 1 : 0, s->L, s->rescore, window, s->ids.data(), s->tids.data(), s->dist.data()));
+        s->stats = vs_stats{};  // the counters of a shared launch are not attributed to single scans
+    } else {
+        VS_TRY(vs_search_batch(ix, s->query.data(), keys ? s->labels.data() : nullptr, keys ? off : nullptr, 1, s->L,
+                               s->rescore, window, s->ids.data(), s->tids.data(), s->dist.data(), &s->stats));
+    }
     s->window = window;
     s->exhausted = false;
     for (uint32_t i = 0; i < window; ++i)

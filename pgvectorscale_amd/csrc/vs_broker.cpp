@@ -194,6 +194,8 @@ int vs_broker_search(vs_broker* b, const float* query, const int16_t* labels, ui
     return r.rc;
 }
 
+vs_index* vs_broker_index(vs_broker* b) { return b ? b->ix : nullptr; }
+
 int vs_broker_get_stats(vs_broker* b, vs_broker_stats* out) {
     if (!b || !out) {
         vs_set_error("vs_broker_get_stats: null argument");

@@ -351,6 +351,10 @@ class Broker:
                                        search_list_size, rescore, k, _p(ids), _p(tids), _p(dist)))
         return ids, tids, dist
 
+    def beginscan(self):
+        """ambeginscan for a backend whose scans go through this broker"""
+        return IndexScan(self.index, broker=self)
+
     def stats(self):
         st = _lib.BrokerStats()
         check(self._L.vs_broker_get_stats(self.h, C.byref(st)))
@@ -365,11 +369,14 @@ class Broker:
 class IndexScan:
     """IndexScanDesc + TSVScanState: rescan() = amrescan, gettuple() = amgettuple, endscan() = amendscan."""
 
-    def __init__(self, index):
+    def __init__(self, index, broker=None):
         self.index = index
         self._L = index._L
         h = C.c_void_p()
-        check(self._L.vs_beginscan(index.h, C.byref(h)))
+        if broker is None:
+            check(self._L.vs_beginscan(index.h, C.byref(h)))
+        else:  # windows of rows are fetched through the broker: scans of many threads share launches
+            check(self._L.vs_beginscan_on_broker(broker.h, C.byref(h)))
         self.h = h
 
     def rescan(self, query, labels=None, search_list_size=DEFAULT_QUERY_SEARCH_LIST_SIZE, rescore=DEFAULT_QUERY_RESCORE):

@@ -77,3 +77,51 @@ def test_concurrent_scans_are_batched_and_exact(gpu_ctx, oracle):
     ids, _, _ = broker.search(q[0], None, 40, 20, 10) if int(kinds[0]) != 0 else got[0]
     broker.close()
     ix.close()
+
+
+def test_amgettuple_mirror_on_a_broker(gpu_ctx, oracle):
+    """many "backends" (threads), each running amrescan + amgettuple loops on its own scan descriptor through one broker:
+    every row sequence equals the oracle's streaming scan, and windows of different scans shared launches"""
+    import pgvectorscale_amd as P
+    O = oracle
+    ti = TestIndex(n=1500, dim_full=48, bits=2, R=24, distance=O.COSINE, seed=33, kind="gauss", deleted_frac=0.1, L_build=50)
+    ix = ti.upload(gpu_ctx)
+    broker = P.Broker(ix, max_batch=32, max_wait_us=20000)
+    nthreads = 12
+    q = ti.queries(nthreads, seed=5, kind="gauss")
+    rows, errors = {}, []
+    start = threading.Barrier(nthreads)
+
+    def backend(t):
+        try:
+            scan = broker.beginscan()
+            start.wait()
+            scan.rescan(q[t], search_list_size=30, rescore=10)
+            out = []
+            for _ in range(45):  # past the first window of 16 rows: the scan is re-fetched with a doubled window
+                r = scan.gettuple()
+                if r is None:
+                    break
+                out.append(r)
+            rows[t] = out
+            scan.endscan()
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=backend, args=(t,)) for t in range(nthreads)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors[:3]
+    for t in range(nthreads):
+        os_ = ti.oracle.scan(q[t], L=30, rescore=10)
+        for (tid, node, d) in rows[t]:
+            o = os_.gettuple()
+            assert o is not None and node == o[0] and tid == o[1]
+            assert np.float32(d).view(np.uint32) == np.float32(o[2]).view(np.uint32)
+        assert len(rows[t]) == 45
+    st = broker.stats()
+    assert st["max_batch"] >= 3 and st["batches"] < st["scans"], st
+    broker.close()
+    ix.close()

@@ -35,6 +35,10 @@ extern "C" {
 #define VS_INVALID_NODE 0xFFFFFFFFu /* InvalidBlockNumber sentinel ending a neighbor list, AM/sbq/node.rs:260-285 */
 
 enum vs_distance_type { VS_COSINE = 0, VS_L2 = 1, VS_IP = 2 }; /* AM/distance/mod.rs:11-15 */
+/* memory_optimized (SbqSpeedupStorage: SBQ Hamming in the graph search + f32 rerank, the hot path of this library) or
+ * plain (PlainStorage, AM/plain/storage.rs: the graph search scores candidates with the full-precision distance to the
+ * vector stored in the node; no label filters; covered for num_dimensions_to_index == num_dimensions) */
+enum vs_storage_type { VS_STORAGE_SBQ = 0, VS_STORAGE_PLAIN = 1 };
 
 enum vs_status {
     VS_OK = 0,
@@ -61,6 +65,7 @@ typedef struct vs_index_desc {
     uint32_t has_labels;    /* MetaPage.has_labels                                                            */
     uint32_t default_start; /* StartNodes.default_node or VS_INVALID_NODE for an empty graph                  */
     uint32_t n_label_starts;/* entries of StartNodes.labeled_nodes (AM/graph/start_nodes.rs:17-22)            */
+    uint32_t storage_type;  /* vs_storage_type: which Storage the index was built with (AM/storage.rs)        */
 } vs_index_desc;
 
 /* Host-side flat arrays an exporter produces from the index relation's pages (SbqNode items, AM/sbq/node.rs:26-42;

@@ -498,8 +498,23 @@ struct vso_scan {
         return idx->label_val + a;
     }
     float bq_distance(uint32_t id) { /* AM/sbq/mod.rs:150-158 */
+        if (idx->storage_plain) return plain_distance(id);
         st.quantized_distance_comparisons++;
         return (float)vso_distance_xor(code(id), qcode.data(), idx->words);
+    }
+    /* PlainDistanceMeasure::calculate_distance(distance_fn, query.to_index_slice(), node.vector) (AM/plain/storage.rs:239-247,
+     * 273-281).  PlainNode.vector is the index slice of the inserted vector, cosine-normalised at insert time
+     * (PgVector::from_datum, AM/pg_vector.rs:143-157); the flat arrays keep the raw heap column, so it is re-derived here. */
+    float plain_distance(uint32_t id) {
+        st.full_distance_comparisons++;
+        const float* hv = idx->vecs + (size_t)id * idx->dim_full;
+        const float* v = hv;
+        if (idx->distance_type == VSO_COSINE) {
+            scratch.assign(hv, hv + idx->dim_index);
+            vso_preprocess_cosine(scratch.data(), idx->dim_index);
+            v = scratch.data();
+        }
+        return vso_distance_by_type((int)idx->distance_type, q_index.data(), v, idx->dim_index);
     }
     void insert_neighbor(const LSN& n) { /* AM/graph/mod.rs:144-147 */
         st.candidate_nodes++;
@@ -534,6 +549,8 @@ struct vso_scan {
     }
     /* AM/sbq/storage.rs:135-190 (GraphNeighborStore::Disk arm) */
     void visit_lsn(size_t lsn_idx, bool no_filter) {
+        /* (plain storage: assert!(no_filter, "Plain storage does not support label filters"), AM/plain/storage.rs:262 —
+         * vso_scan_begin refuses label keys on a plain index) */
         uint32_t visiting = visited[lsn_idx].id;
         st.node_reads++;
         const uint32_t* nb = idx->nbrs + (size_t)visiting * idx->nbr_stride;
@@ -669,9 +686,11 @@ vso_scan* vso_scan_begin(const vso_index* idx, const float* query, const int16_t
     } else {
         starts.push_back(idx->default_start);
     }
-    /* SbqSearchDistanceMeasure::new, AM/sbq/mod.rs:145-148 */
-    s->qcode.resize(idx->words);
-    vso_quantize(idx->mean, idx->m2, idx->count, idx->bits, s->q_index.data(), idx->dim_index, s->qcode.data());
+    /* SbqSearchDistanceMeasure::new, AM/sbq/mod.rs:145-148 (plain storage: PlainDistanceMeasure::Full(query)) */
+    if (!idx->storage_plain) {
+        s->qcode.resize(idx->words);
+        vso_quantize(idx->mean, idx->m2, idx->count, idx->bits, s->q_index.data(), idx->dim_index, s->qcode.data());
+    }
     /* ListSearchResult::new, AM/graph/mod.rs:97-124 */
     s->st.calls++;
     s->candidates.data.reserve((size_t)search_list_size * idx->num_neighbors);
@@ -684,7 +703,19 @@ int vso_scan_gettuple(vso_scan* s, uint32_t* node, uint64_t* heap_tid, float* di
     uint32_t n = VSO_INVALID_NODE;
     uint64_t t = 0;
     float d = std::numeric_limits<float>::quiet_NaN();
-    bool ok = s->next_with_resort(&n, &t, &d);
+    bool ok;
+    if (s->idx->storage_plain && s->idx->dim_full == s->idx->dim_index) {
+        /* amgettuple, Plain arm without truncation: "no need to resort" -> iter.next (AM/scan.rs:392-399).  The distance
+         * handed back here is the graph distance (already full precision); the reference returns none to the executor. */
+        LSN l{VSO_INVALID_NODE, 0.0f};
+        ok = s->next(&t, &l);
+        if (ok) {
+            n = l.id;
+            d = l.dist;
+        }
+    } else {
+        ok = s->next_with_resort(&n, &t, &d);
+    }
     if (node) *node = n;
     if (heap_tid) *heap_tid = t;
     if (dist) *dist = d;
@@ -697,7 +728,11 @@ int vso_scan_next_sbq(vso_scan* s, uint32_t* node, uint64_t* heap_tid, uint32_t*
     bool ok = s->next(&t, &l);
     if (node) *node = ok ? l.id : VSO_INVALID_NODE;
     if (heap_tid) *heap_tid = t;
-    if (ham) *ham = ok ? (uint32_t)l.dist : 0xFFFFFFFFu;
+    if (ham) {
+        if (!ok) *ham = 0xFFFFFFFFu;
+        else if (s->idx->storage_plain) std::memcpy(ham, &l.dist, 4); /* the f32 graph distance, bit for bit */
+        else *ham = (uint32_t)l.dist;
+    }
     return ok ? 1 : 0;
 }
 

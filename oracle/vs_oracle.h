@@ -92,6 +92,8 @@ typedef struct {
     const float* mean;         /* [dim_index] SbqMeans                                                    */
     const float* m2;           /* [dim_index] (bits > 1)                                                  */
     uint64_t count;
+    uint32_t storage_plain;    /* 1: `plain` storage (AM/plain/storage.rs): candidates are scored with the full-precision
+                                  distance to the node's stored vector instead of SBQ Hamming; no label filters     */
 } vso_index;
 
 typedef struct {

@@ -8,6 +8,7 @@ LIB_PATH = os.path.join(_HERE, "libvsgpu.so")
 
 VS_INVALID_NODE = 0xFFFFFFFF
 VS_COSINE, VS_L2, VS_IP = 0, 1, 2
+VS_STORAGE_SBQ, VS_STORAGE_PLAIN = 0, 1
 ARR_CODES, ARR_NBRS, ARR_TIDS, ARR_VECS, ARR_MEAN, ARR_M2, ARR_VNORM, ARR_LABEL_OFF, ARR_LABEL_VAL = range(9)
 
 
@@ -19,7 +20,7 @@ class VsError(RuntimeError):
 
 class IndexDesc(C.Structure):
     _fields_ = [(k, C.c_uint32) for k in ("n", "dim_full", "dim_index", "bits", "words", "num_neighbors",
-                                          "distance_type", "has_labels", "default_start", "n_label_starts")]
+                                          "distance_type", "has_labels", "default_start", "n_label_starts", "storage_type")]
 
 
 class IndexHost(C.Structure):

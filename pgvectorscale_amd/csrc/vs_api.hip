@@ -408,8 +408,18 @@ static int validate_graph(vs_index* ix) {
 }
 
 extern "C" int vs_index_upload(vs_ctx* c, const vs_index_desc* desc, const vs_index_host* h, vs_index** out) {
-    VS_REQUIRE(h && out, "vs_index_upload: bad args");
-    VS_REQUIRE(h->codes && h->nbrs && h->heap_tids && h->mean, "vs_index_upload: codes/nbrs/heap_tids/mean required");
+    VS_REQUIRE(h && out && desc, "vs_index_upload: bad args");
+    const bool plain = desc->storage_type == VS_STORAGE_PLAIN;
+    VS_REQUIRE(desc->storage_type == VS_STORAGE_SBQ || plain, "vs_index_upload: unknown storage_type %u", desc->storage_type);
+    if (plain) {
+        // PlainNode = vector + neighbor pointers + heap pointer (AM/plain/node.rs); no quantizer, no labels
+        VS_REQUIRE(h->nbrs && h->heap_tids && h->vecs, "vs_index_upload: plain storage needs nbrs / heap_tids / vecs");
+        VS_REQUIRE(desc->dim_index == desc->dim_full,
+                   "plain storage with num_dimensions_to_index < num_dimensions (resort on the full vector) is not covered");
+        VS_REQUIRE(!desc->has_labels, "Plain storage does not support label filters");
+    } else {
+        VS_REQUIRE(h->codes && h->nbrs && h->heap_tids && h->mean, "vs_index_upload: codes/nbrs/heap_tids/mean required");
+    }
     VS_REQUIRE(h->nbr_stride >= desc->num_neighbors, "nbr_stride < num_neighbors");
     VS_REQUIRE(!desc->has_labels || (h->label_off && h->label_val), "has_labels set but no label arrays");
     vs_index* ix = nullptr;
@@ -417,7 +427,12 @@ extern "C" int vs_index_upload(vs_ctx* c, const vs_index_desc* desc, const vs_in
     int r = VS_OK;
     const size_t n = desc->n;
     do {
-        if ((r = upload_rows(c, ix->codes, ix->code_stride * 8ull, h->codes, desc->words * 8ull, desc->words * 8ull, n))) break;
+        if (h->codes) {
+            if ((r = upload_rows(c, ix->codes, ix->code_stride * 8ull, h->codes, desc->words * 8ull, desc->words * 8ull, n))) break;
+        } else if (hipMemsetAsync(ix->codes, 0, (size_t)n * ix->code_stride * 8, c->stream) != hipSuccess) {
+            r = VS_ERR_HIP;
+            break;
+        }
         // neighbor rows: copy R ids, pad the device row with the end-of-list sentinel
         {
             std::vector<uint32_t> row_buf;
@@ -435,7 +450,8 @@ extern "C" int vs_index_upload(vs_ctx* c, const vs_index_desc* desc, const vs_in
         if ((r = vs_dev_upload(c, ix->tids, h->heap_tids, n * 8))) break;
         if (h->vecs)
             if ((r = upload_rows(c, ix->vecs, ix->vec_stride * 4ull, h->vecs, desc->dim_full * 4ull, desc->dim_full * 4ull, n))) break;
-        if ((r = vs_index_set_quantizer(ix, h->mean, h->m2, h->count))) break;
+        if (h->mean)
+            if ((r = vs_index_set_quantizer(ix, h->mean, h->m2, h->count))) break;
         if (desc->has_labels)
             if ((r = vs_index_set_labels(ix, h->label_off, h->label_val))) break;
         if ((r = vs_index_set_start_nodes(ix, desc->default_start, h->label_start_labels, h->label_start_nodes,
@@ -646,7 +662,7 @@ static Caps initial_caps(const vs_index* ix, uint32_t L, uint32_t M) {
     // and the LDS ring variant needs 87 VGPRs instead of 141 (5 instead of 3 waves per SIMD)
     c.f_vr = env_u32("VS_F_VR", (lds_table && want_v <= 512) ? 8 : 0);
     c.f_vcap = c.f_vr ? 512 : round_up_u32(std::max<uint32_t>(env_u32("VS_F_VCAP", 2 * want_v), 64), 64);
-    c.f_on = env_u32("VS_FAST", 1) != 0;
+    c.f_on = env_u32("VS_FAST", 1) != 0 && ix->d.storage_type != VS_STORAGE_PLAIN;  // the LDS-resident kernels score SBQ codes
     if (c.f_on) {
         if (c.f_lh) c.f_lh = round_up_u32(std::max<uint32_t>(c.f_lh, 256), 4);
         c.f_hl = std::max<uint32_t>(next_pow2_u32(c.f_hl + 1), 64) - 1;
@@ -959,7 +975,8 @@ static int collect_stats(vs_index* ix, uint32_t nq, uint32_t M, uint32_t rescore
         st->queries++;
         st->visited_nodes += hs[(size_t)q * ST_N + ST_VISITS];
         st->candidate_nodes += hs[(size_t)q * ST_N + ST_CAND];
-        st->quantized_distance_comparisons += hs[(size_t)q * ST_N + ST_DQ];
+        if (ix->d.storage_type == VS_STORAGE_PLAIN) st->full_distance_comparisons += hs[(size_t)q * ST_N + ST_DQ];
+        else st->quantized_distance_comparisons += hs[(size_t)q * ST_N + ST_DQ];
         st->node_reads += hs[(size_t)q * ST_N + ST_READS];
         st->next_calls += hs[(size_t)q * ST_N + ST_NEXT];
         if (fb[q]) {
@@ -1033,6 +1050,10 @@ static int search_host(vs_index* ix, const float* queries, const int16_t* qlabel
     VS_REQUIRE(L >= 1 && L <= 10000, "diskann.query_search_list_size %u outside [1,10000]", L);  // AM/guc.rs:11-26
     VS_REQUIRE(rescore <= 1000, "diskann.query_rescore %u outside [0,1000]", rescore);           // AM/guc.rs:28-43
     VS_REQUIRE(k >= 1, "k must be >= 1");
+    if (ix->d.storage_type == VS_STORAGE_PLAIN) {
+        VS_REQUIRE(!qlabel_off, "Plain storage does not support label filters");  // AM/plain/storage.rs:262
+        rescore = 0;  // amgettuple, Plain arm, num_dimensions == num_dimensions_to_index: "no need to resort" (AM/scan.rs:392-399)
+    }
     if (stats) memset(stats, 0, sizeof(*stats));
     if (nq == 0) return VS_OK;
     vs_ctx* c = ix->ctx;
@@ -1058,7 +1079,16 @@ static int search_host(vs_index* ix, const float* queries, const int16_t* qlabel
         VS_TRY(collect_stats(ix, cq, M, rescore, stream_only, stats, L));
         if (stream_only) {
             VS_TRY(vs_dev_download(c, out_ids + (size_t)q0 * k, w.stream_ids.p, (size_t)cq * k * 4));
-            if (out_ham) VS_TRY(vs_dev_download(c, out_ham + (size_t)q0 * k, w.stream_ham.p, (size_t)cq * k * 4));
+            if (out_ham) {
+                VS_TRY(vs_dev_download(c, out_ham + (size_t)q0 * k, w.stream_ham.p, (size_t)cq * k * 4));
+                if (ix->d.storage_type == VS_STORAGE_PLAIN)  // keys -> the f32 distances, bit for bit (rows past the end keep 0xFFFFFFFF)
+                    for (size_t i = (size_t)q0 * k; i < ((size_t)q0 + cq) * k; ++i)
+                        if (out_ids[i] != VS_INVALID_NODE) {
+                            int32_t b = (int32_t)(out_ham[i] ^ 0x80000000u);
+                            b ^= (int32_t)(((uint32_t)(b >> 31)) >> 1);
+                            out_ham[i] = (uint32_t)b;
+                        }
+            }
         } else {
             VS_TRY(vs_dev_download(c, out_ids + (size_t)q0 * k, w.out_ids.p, (size_t)cq * k * 4));
             if (out_tids) VS_TRY(vs_dev_download(c, out_tids + (size_t)q0 * k, w.out_tids.p, (size_t)cq * k * 8));
@@ -1088,6 +1118,10 @@ extern "C" int vs_search_batch_dev(vs_index* ix, const float* d_queries, const i
                                    uint32_t* d_out_ids, uint64_t* d_out_tids, float* d_out_dist) {
     VS_REQUIRE(ix && (nq == 0 || (d_queries && d_out_ids)), "vs_search_batch_dev: bad args");
     VS_REQUIRE(L >= 1 && L <= 10000 && rescore <= 1000 && k >= 1, "vs_search_batch_dev: GUC out of range");
+    if (ix->d.storage_type == VS_STORAGE_PLAIN) {
+        VS_REQUIRE(!d_qlabel_off, "Plain storage does not support label filters");
+        rescore = 0;
+    }
     SearchWorkspace& w = ix->ws;
     w.pending = false;
     if (nq == 0) return VS_OK;

@@ -323,7 +323,7 @@ __device__ __forceinline__ int32_t total_key(float f) {
 __global__ void k_resort(uint32_t nq, uint32_t M, uint32_t rescore, uint32_t k, const uint32_t* __restrict__ stream,
                          const uint32_t* __restrict__ cnt, const float* __restrict__ dist, const uint64_t* __restrict__ tids,
                          uint64_t* __restrict__ heap_ws, uint32_t* __restrict__ out_ids, uint64_t* __restrict__ out_tids,
-                         float* __restrict__ out_dist) {
+                         float* __restrict__ out_dist, const uint32_t* __restrict__ plain_keys) {
     uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nq) return;
     const uint32_t n = min(cnt[q], M);
@@ -335,7 +335,15 @@ __global__ void k_resort(uint32_t nq, uint32_t M, uint32_t rescore, uint32_t k, 
             uint32_t id = sid[produced];
             out_ids[(size_t)q * k + produced] = id;
             if (out_tids) out_tids[(size_t)q * k + produced] = tids[id];
-            if (out_dist) out_dist[(size_t)q * k + produced] = __int_as_float(0x7fc00000);
+            if (out_dist) {
+                float d = __int_as_float(0x7fc00000);
+                if (plain_keys) {  // plain storage: the graph distance IS the full-precision distance (key = total_cmp image)
+                    int32_t b = (int32_t)(plain_keys[(size_t)q * M + produced] ^ 0x80000000u);
+                    b ^= (int32_t)(((uint32_t)(b >> 31)) >> 1);
+                    d = __int_as_float(b);
+                }
+                out_dist[(size_t)q * k + produced] = d;
+            }
         }
     } else {
         uint64_t* h = heap_ws + (size_t)q * rescore;
@@ -407,7 +415,8 @@ int launch_prepare_queries(vs_index* idx, const float* d_raw, uint32_t nq, float
     VS_REQUIRE(lds <= 160 * 1024, "query too large for LDS staging (%u dims)", d.dim_full);
     hipLaunchKernelGGL(k_prepare_queries, dim3(nq), dim3(WAVE), lds, idx->ctx->stream, d_raw, nq, d.dim_full,
                        d.dim_index, idx->vec_stride, d.distance_type, d.bits, idx->mean, idx->m2,
-                       count_as_f32(idx->count), d.words, idx->code_stride, d_q_full, d_qcodes);
+                       count_as_f32(idx->count), d.storage_type == VS_STORAGE_PLAIN ? 0u : d.words /* plain: no SBQ code */,
+                       idx->code_stride, d_q_full, d_qcodes);
     VS_HIP(hipGetLastError());
     return VS_OK;
 }
@@ -449,8 +458,9 @@ int launch_resort(vs_index* idx, uint32_t nq, uint32_t M, uint32_t rescore, uint
                   const uint32_t* d_cnt, const float* d_dist, uint64_t* d_heap_ws, uint32_t* d_out_ids,
                   uint64_t* d_out_tids, float* d_out_dist) {
     if (nq == 0) return VS_OK;
+    const uint32_t* plain_keys = idx->d.storage_type == VS_STORAGE_PLAIN ? (const uint32_t*)idx->ws.stream_ham.p : nullptr;
     hipLaunchKernelGGL(k_resort, dim3((nq + 63) / 64), dim3(64), 0, idx->ctx->stream, nq, M, rescore, k, d_stream_ids,
-                       d_cnt, d_dist, idx->tids, d_heap_ws, d_out_ids, d_out_tids, d_out_dist);
+                       d_cnt, d_dist, idx->tids, d_heap_ws, d_out_ids, d_out_tids, d_out_dist, plain_keys);
     VS_HIP(hipGetLastError());
     return VS_OK;
 }

@@ -36,9 +36,95 @@ struct SearchArgs {
     const uint32_t* ls_nodes;
     uint32_t code_stride, nbr_stride, R, n, n_ls, default_start;
     SearchLaunch s;
+    // `plain` storage (AM/plain/storage.rs): candidates are scored with the full-precision distance to the node's vector
+    // (appended so that the kernel-argument layout of everything above is the one the SBQ kernels were measured with)
+    const float* vecs;
+    const float* vnorm;
+    const float* q_full;  // [nq][vec_stride] prepared (cosine-normalised) queries
+    uint32_t vec_stride, dim, distance_type;
 };
 
 #define MAX_QLABELS 64
+
+// monotone u32 image of f32::total_cmp (DistanceWithTieBreak compares distances with total_cmp,
+// AM/graph/neighbor_with_distance.rs:74-83): heap / visited keys of the plain-storage search
+__device__ __forceinline__ uint32_t plain_key(float f) {
+    int32_t b = __float_as_int(f);
+    b ^= (int32_t)(((uint32_t)(b >> 31)) >> 1);
+    return (uint32_t)b ^ 0x80000000u;
+}
+
+// PlainDistanceMeasure::calculate_distance (AM/plain/storage.rs:239-247,273-281): distance_fn(query index slice, node
+// vector) for the row each 8-lane group points at, in the reference's AVX2 accumulation order — the same arithmetic as
+// k_rerank (vs_kernels.hip): lane l8 owns elements 32t + 4 l8 .. +3, i.e. 4 of the 32 virtual AVX2 lanes; L2 is mul + add,
+// dot is FMA; horizontal_add_ps per accumulator, the four accumulators summed left to right, then the scalar tail.  The
+// stored vector is the cosine-normalised insert-time vector: the raw row divided by its cached norm.  Valid on l8 == 0.
+__device__ __forceinline__ float plain_dist8(const float* __restrict__ row, float sdiv, const float* qv, uint32_t dim,
+                                             uint32_t distance_type, int lane, bool valid) {
+    const int l8 = lane & 7;
+    const uint32_t steps = dim / 32;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (valid) {
+        if (distance_type == VS_L2) {
+            for (uint32_t t = 0; t < steps; ++t) {
+                const float4 x = *reinterpret_cast<const float4*>(row + 32 * t + 4 * l8);
+                const float4 y = *reinterpret_cast<const float4*>(qv + 32 * t + 4 * l8);
+                const float d0 = x.x - y.x, d1 = x.y - y.y, d2 = x.z - y.z, d3 = x.w - y.w;
+                const float p0 = d0 * d0, p1 = d1 * d1, p2 = d2 * d2, p3 = d3 * d3;
+                a0 = a0 + p0;
+                a1 = a1 + p1;
+                a2 = a2 + p2;
+                a3 = a3 + p3;
+            }
+        } else {
+            for (uint32_t t = 0; t < steps; ++t) {
+                float4 x = *reinterpret_cast<const float4*>(row + 32 * t + 4 * l8);
+                const float4 y = *reinterpret_cast<const float4*>(qv + 32 * t + 4 * l8);
+                if (sdiv != 0.0f) {
+                    x.x = x.x / sdiv;
+                    x.y = x.y / sdiv;
+                    x.z = x.z / sdiv;
+                    x.w = x.w / sdiv;
+                }
+                a0 = __builtin_fmaf(x.x, y.x, a0);
+                a1 = __builtin_fmaf(x.y, y.y, a1);
+                a2 = __builtin_fmaf(x.z, y.z, a2);
+                a3 = __builtin_fmaf(x.w, y.w, a3);
+            }
+        }
+    }
+    const float s0 = a0 + __shfl(a0, lane ^ 1, WAVE);
+    const float s1 = a1 + __shfl(a1, lane ^ 1, WAVE);
+    const float s2 = a2 + __shfl(a2, lane ^ 1, WAVE);
+    const float s3 = a3 + __shfl(a3, lane ^ 1, WAVE);
+    const float t0 = s0 + s1;
+    const float t1 = s2 + s3;
+    const float h = t0 + t1;
+    const int g0 = lane & ~7;
+    const float h0 = __shfl(h, g0 + 0, WAVE), h1 = __shfl(h, g0 + 2, WAVE), h2 = __shfl(h, g0 + 4, WAVE), h3 = __shfl(h, g0 + 6, WAVE);
+    float dist = h0 + h1;
+    dist = dist + h2;
+    dist = dist + h3;
+    float r = 0.0f;
+    if (valid && l8 == 0) {
+        for (uint32_t i = steps * 32; i < dim; ++i) {  // scalar tail, in element order
+            float x = row[i];
+            if (distance_type == VS_L2) {
+                const float diff = x - qv[i];
+                const float p = diff * diff;
+                dist = dist + p;
+            } else {
+                if (sdiv != 0.0f) x = x / sdiv;
+                const float p = x * qv[i];
+                dist = dist + p;
+            }
+        }
+        if (distance_type == VS_L2) r = dist;
+        else if (distance_type == VS_IP) r = -dist;
+        else r = fmaxf(1.0f - dist, 0.0f);
+    }
+    return r;
+}
 
 __device__ __forceinline__ uint64_t rfl64(uint64_t v) {
     uint32_t lo = rfl((uint32_t)v), hi = rfl((uint32_t)(v >> 32));
@@ -118,7 +204,7 @@ struct WaveHeap {
     }
 };
 
-template <bool BUILD>
+template <bool BUILD, bool PLAIN>
 __global__ __launch_bounds__(WAVE) void k_search(SearchArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
@@ -151,8 +237,13 @@ __global__ __launch_bounds__(WAVE) void k_search(SearchArgs a) {
     uint32_t* surv_d = surv_id + 64;
     uint64_t* qc = reinterpret_cast<uint64_t*>(surv_d + 64);
     int16_t* ql = reinterpret_cast<int16_t*>(qc + a.code_stride);
+    float* qf = reinterpret_cast<float*>(ql + MAX_QLABELS);  // PLAIN only: the prepared query, vec_stride floats (16-B aligned)
 
-    for (uint32_t w = lane; w < a.code_stride; w += WAVE) qc[w] = s.qcodes[(size_t)q * a.code_stride + w];
+    if (PLAIN) {
+        for (uint32_t i = lane; i < a.vec_stride; i += WAVE) qf[i] = a.q_full[(size_t)q * a.vec_stride + i];
+    } else {
+        for (uint32_t w = lane; w < a.code_stride; w += WAVE) qc[w] = s.qcodes[(size_t)q * a.code_stride + w];
+    }
     for (uint32_t i = lane; i < s.lh; i += WAVE) lhash[i] = VS_EMPTY;
     const bool labels_some = s.qlabel_off != nullptr;  // LabeledVector.labels is Some (AM/labels/mod.rs:222-236)
     uint32_t nql = 0;
@@ -279,7 +370,13 @@ __global__ __launch_bounds__(WAVE) void k_search(SearchArgs a) {
             bool fr = prepare_insert(sn, lane == 0);
             if (!rfl(fr ? 1u : 0u)) continue;
             st_reads++;
-            uint32_t d = rfl(ham_row4(a.codes + (size_t)sn * a.code_stride, qc, lane & 3, a.code_stride, lane < 4));
+            uint32_t d;
+            if (PLAIN) {
+                const float sdiv = a.distance_type == VS_COSINE ? a.vnorm[sn] : 0.0f;
+                d = rfl(plain_key(plain_dist8(a.vecs + (size_t)sn * a.vec_stride, sdiv, qf, a.dim, a.distance_type, lane, lane < 8)));
+            } else {
+                d = rfl(ham_row4(a.codes + (size_t)sn * a.code_stride, qc, lane & 3, a.code_stride, lane < 4));
+            }
             st_dq++;
             st_cand++;
             heap.push(((uint64_t)d << 32) | sn, lane);
@@ -384,6 +481,16 @@ __global__ __launch_bounds__(WAVE) void k_search(SearchArgs a) {
                     // compact survivors in neighbor-list order
                     if (pass) surv_id[__popcll(pm & ((1ull << lane) - 1ull))] = nid;
                     __syncthreads();
+                    if (PLAIN) {  // full-precision distances: 8 lanes per vector row, 8 rows per pass
+                        for (uint32_t p0 = 0; p0 < c; p0 += 8) {
+                            const uint32_t j = p0 + (uint32_t)(lane >> 3);
+                            const bool valid = j < c;
+                            const uint32_t id = valid ? surv_id[j] : 0;
+                            const float sdiv = (valid && a.distance_type == VS_COSINE) ? a.vnorm[id] : 0.0f;
+                            const float r = plain_dist8(a.vecs + (size_t)id * a.vec_stride, sdiv, qf, a.dim, a.distance_type, lane, valid);
+                            if (valid && (lane & 7) == 0) surv_d[j] = plain_key(r);
+                        }
+                    } else
                     // distances: 4 lanes per code row, 16 rows per pass, all loads of the chunk issued up front
 #pragma unroll
                     for (int pass_i = 0; pass_i < 4; ++pass_i) {
@@ -470,6 +577,7 @@ __global__ __launch_bounds__(WAVE) void k_search(SearchArgs a) {
 size_t search_lds_bytes(const vs_index* idx, const SearchLaunch& s) {
     size_t b = (size_t)round_up_u32(s.hl + 2, 2) * 8 + (size_t)round_up_u32(s.lh, 4) * 4 +
                2 * (size_t)round_up_u32(s.vcap, 4) * 4 + 128 * 4 + (size_t)idx->code_stride * 8 + MAX_QLABELS * 2 + 16;
+    if (idx->d.storage_type == VS_STORAGE_PLAIN) b += (size_t)idx->vec_stride * 4;
     return (b + 15) / 16 * 16;
 }
 
@@ -489,6 +597,15 @@ int launch_search(vs_index* idx, const SearchLaunch& s, bool build_mode) {
     a.n = idx->d.n;
     a.n_ls = idx->d.n_label_starts;
     a.default_start = idx->d.default_start;
+    const bool plain = idx->d.storage_type == VS_STORAGE_PLAIN;
+    a.vecs = idx->vecs;
+    a.vnorm = idx->vnorm;
+    a.q_full = (const float*)idx->ws.q_full.p;
+    a.vec_stride = idx->vec_stride;
+    a.dim = idx->d.dim_index;
+    a.distance_type = idx->d.distance_type;
+    VS_REQUIRE(!plain || (!build_mode && idx->vecs && a.q_full && !s.qlabel_off),
+               "plain storage search needs the vector column and takes no label keys (AM/plain/storage.rs:262)");
     a.s = s;
     size_t lds = search_lds_bytes(idx, s);
     if (lds > 160 * 1024) {
@@ -501,14 +618,17 @@ int launch_search(vs_index* idx, const SearchLaunch& s, bool build_mode) {
     }
     static bool attr_set = false;
     if (!attr_set) {
-        VS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_search<false>),
+        VS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_search<false, false>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        VS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_search<true>),
+        VS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_search<true, false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        VS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_search<false, true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    if (build_mode) hipLaunchKernelGGL(k_search<true>, dim3(s.nq), dim3(WAVE), lds, idx->ctx->stream, a);
-    else hipLaunchKernelGGL(k_search<false>, dim3(s.nq), dim3(WAVE), lds, idx->ctx->stream, a);
+    if (plain) hipLaunchKernelGGL((k_search<false, true>), dim3(s.nq), dim3(WAVE), lds, idx->ctx->stream, a);
+    else if (build_mode) hipLaunchKernelGGL((k_search<true, false>), dim3(s.nq), dim3(WAVE), lds, idx->ctx->stream, a);
+    else hipLaunchKernelGGL((k_search<false, false>), dim3(s.nq), dim3(WAVE), lds, idx->ctx->stream, a);
     VS_HIP(hipGetLastError());
     return VS_OK;
 }

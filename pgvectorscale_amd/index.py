@@ -100,7 +100,10 @@ class DiskAnnIndex:
     # -- construction ---------------------------------------------------------------------------------------------
     @classmethod
     def upload(cls, ctx, *, codes, nbrs, heap_tids, vecs, mean, m2, count, bits, dim_index, num_neighbors,
-               distance_type, default_start, label_off=None, label_val=None, label_starts=None):
+               distance_type, default_start, label_off=None, label_val=None, label_starts=None, storage_type=_lib.VS_STORAGE_SBQ):
+        if storage_type == _lib.VS_STORAGE_PLAIN:
+            return cls._upload_plain(ctx, nbrs=nbrs, heap_tids=heap_tids, vecs=vecs, num_neighbors=num_neighbors,
+                                     distance_type=distance_type, default_start=default_start)
         codes = np.ascontiguousarray(codes, np.uint64)
         nbrs = np.ascontiguousarray(nbrs, np.uint32)
         heap_tids = np.ascontiguousarray(heap_tids, np.uint64)
@@ -131,6 +134,23 @@ class DiskAnnIndex:
         h.label_val = None if lv is None else _p(lv).value
         h.label_start_labels = _p(lsl).value if len(ls) else None
         h.label_start_nodes = _p(lsn).value if len(ls) else None
+        out = C.c_void_p()
+        check(ctx._L.vs_index_upload(ctx.h, C.byref(d), C.byref(h), C.byref(out)))
+        return cls(ctx, out)
+
+    @classmethod
+    def _upload_plain(cls, ctx, *, nbrs, heap_tids, vecs, num_neighbors, distance_type, default_start):
+        """A `plain` storage index (AM/plain/storage.rs): vectors + neighbor lists, no SBQ codes."""
+        nbrs = np.ascontiguousarray(nbrs, np.uint32)
+        heap_tids = np.ascontiguousarray(heap_tids, np.uint64)
+        vecs = np.ascontiguousarray(vecs, np.float32)
+        d = IndexDesc()
+        d.n, d.dim_full, d.dim_index = vecs.shape[0], vecs.shape[1], vecs.shape[1]
+        d.bits, d.words = 1, quantized_size(vecs.shape[1], 1)
+        d.num_neighbors, d.distance_type, d.has_labels = num_neighbors, distance_type, 0
+        d.default_start, d.n_label_starts, d.storage_type = default_start, 0, _lib.VS_STORAGE_PLAIN
+        h = IndexHost()
+        h.nbrs, h.nbr_stride, h.heap_tids, h.vecs = _p(nbrs).value, nbrs.shape[1], _p(heap_tids).value, _p(vecs).value
         out = C.c_void_p()
         check(ctx._L.vs_index_upload(ctx.h, C.byref(d), C.byref(h), C.byref(out)))
         return cls(ctx, out)

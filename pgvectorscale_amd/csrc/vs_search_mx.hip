@@ -9,7 +9,7 @@
 //
 //   * candidate heap (BinaryHeap<Reverse<ListSearchNeighbor>>, AM/graph/mod.rs:75): same 4-byte entries
 //     (hamming << sb | dedup slot) and the same LDS / spill split as k_search_fast; sift_up = lane r of the row compares
-//     with the r-th ancestor (one read, one 16-bit ballot, one store; heaps of < 2^16 entries); sift_down_to_bottom = one
+//     with the r-th ancestor (one read, one 16-bit ballot, one store; heaps of < 2^15 entries); sift_down_to_bottom = one
 //     level per step (both children in one 8-byte read).  Rust std's array mechanics are replayed exactly.
 //   * dedup set: the per-scan global table of the table-less regime (L2 atomics), one lane per neighbor, 16 per step.
 //   * visited list: sorted array in registers, entry i = lane i % 16 of register i / 16; insert / remove(0) are DPP row
@@ -105,11 +105,9 @@ struct MxHeap {
         if (act && r >= 1) e = get1(p1 >> r);
         const bool cmp = act && r >= 1 && (elem >> sb) < (e >> sb);
         const uint32_t bal = L.gballot(cmp) >> 1;                       // bit r-1 <-> ancestor r
-        const uint32_t t = (uint32_t)__builtin_ctz(~bal | 0x8000u);     // leading run of ancestors that move down (<= 15)
-        if (act && r <= t) {
-            const uint32_t dst = r == 0 ? (p1 >> t) : (p1 >> (r - 1));
-            set1(dst, r == 0 ? elem : e);
-        }
+        const uint32_t t = (uint32_t)__builtin_ctz(~bal | 0x4000u);     // leading run of ancestors that move down (<= 14)
+        // lanes 1 .. t move their ancestor one rank down, lane t + 1 stores the element into the rank below itself
+        if (act && r >= 1 && r <= t + 1) set1(p1 >> (r - 1), r <= t ? e : elem);
         mx_wave_sync();
     }
     __device__ __forceinline__ void push(const Lane& L, uint32_t elem, bool act) {
@@ -162,12 +160,10 @@ struct MxHeap {
             const uint32_t a = stg[(p1 >> r) + cst];
             const bool cmp = on && r >= 1 && (elem >> sb) < (a >> sb);
             const uint32_t bal = L.gballot(cmp) >> 1;                    // bit r-1 <-> ancestor r
-            const uint32_t t = (uint32_t)__builtin_ctz(~bal | 0x8000u);  // leading run of ancestors that move down
-            const uint32_t cst_t = L.gbcast(cst, t);
-            if (on && r <= t) {
-                const uint32_t slot = r == 0 ? (p1 >> t) + cst_t : (p1 >> (r - 1)) + cst_w;
-                stg[slot] = r == 0 ? elem : a;
-            }
+            const uint32_t t = (uint32_t)__builtin_ctz(~bal | 0x4000u);  // leading run of ancestors that move down (<= 14)
+            // lanes 1 .. t move their ancestor one rank down; lane t + 1 (the first ancestor that stays, or the sentinel)
+            // drops the new element into the rank below itself.  Heaps of < 2^15 entries: rank 15 is the sentinel at most.
+            if (on && r >= 1 && r <= t + 1) stg[(p1 >> (r - 1)) + cst_w] = r <= t ? a : elem;
             mx_wave_sync();
         }
         // stage out (same steps, plus the new leaves = rank 0; the sentinel, position 0, is never written back)
@@ -420,6 +416,9 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_mx(MxArgs a) {
 
     const uint32_t smask = (1u << s.sb) - 1u;
     const uint32_t gmask = s.gcap - 1;
+    // heaps stay below 2^15 entries (depth <= 15: the lane of rank 15 only ever sees the sentinel, MxHeap::place); a scan
+    // that needs more is handed to the general kernel like any other overflow
+    const uint32_t hcap = min(s.hcap, 32767u);
     uint32_t emitted = 0, status = 0, nins_g = 0, hmax = 0;
     uint32_t st_visits = 0, st_cand = 0, st_dq = 0, st_reads = 0, st_pfhit = 0;
 
@@ -495,7 +494,7 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_mx(MxArgs a) {
                 mx_ham_row<NCH>(a.codes + (size_t)(fr ? sn : 0u) * a.code_stride, qv, l4, a.code_stride, fr && L.gl < 4), 0);
             st_dq += fr ? 1u : 0u;
             st_cand += fr ? 1u : 0u;
-            fail(fr && heap.len + 1 > s.hcap, OVF_HEAP);
+            fail(fr && heap.len + 1 > hcap, OVF_HEAP);
             heap.push(L, (d << s.sb) | slot, fr && alive);
         }
     }
@@ -628,7 +627,7 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_mx(MxArgs a) {
             c += (uint32_t)__builtin_popcount(pm);
         }
         c = (ex2 && alive) ? c : 0u;
-        fail(c > 0 && heap.len + c > s.hcap, OVF_HEAP);
+        fail(c > 0 && heap.len + c > hcap, OVF_HEAP);
         c = alive ? c : 0u;
         mx_wave_sync();
         // ---- distances: 4 lanes per code row, 4 rows per scan per step ----
@@ -729,7 +728,7 @@ static size_t mx_lds_bytes(const FastLaunch& s) {
 bool search_mx_eligible(const vs_index* idx, const FastLaunch& s) {
     const uint32_t nch = (idx->code_stride + 7) / 8;
     const uint32_t want_v = s.L + s.L / 2 + 32;
-    return s.lh == 0 && !s.build && !s.phase && s.hcap < 65535 && idx->d.num_neighbors <= 64 && nch >= 1 && nch <= 6 &&
+    return s.lh == 0 && !s.build && !s.phase && idx->d.num_neighbors <= 64 && nch >= 1 && nch <= 6 &&
            want_v <= 16 * 32 && mx_lds_bytes(s) <= 64 * 1024;
 }
 

@@ -216,6 +216,24 @@ int vs_pages_read_chain(const vs_pages* p, uint32_t block, uint32_t offset, int 
 int vs_pages_sbq_means(const vs_pages* p, uint32_t block, uint32_t offset, float* mean, float* m2, uint32_t dim_cap,
                        uint32_t* dim, uint64_t* count);
 void vs_pages_close(vs_pages* p);
+/* keep only the block table (page type / item count per block) and the metadata pages: node items are decoded elsewhere */
+int vs_pages_headers_only(vs_pages* p);
+int vs_pages_block_table(const vs_pages* p, const uint32_t** blk_base, const uint32_t** blk_cnt, uint32_t* n_blocks);
+
+/* The same, decoded ON the device (vs_pages_dev.hip): the blocks are copied to HBM as they are (pinned ring,
+ * hipMemcpyAsync), the host only reads the page headers on the way past, and one kernel (a wave per node page) walks the
+ * line pointers and rkyv relative pointers and writes codes / neighbor ids / heap tids into the index arrays.  Unlabeled
+ * memory_optimized indexes.  n_blocks_total = RelationGetNumberOfBlocks (the raw pages stay in HBM until the build). */
+typedef struct vs_pages_dev vs_pages_dev;
+int vs_pages_dev_open(vs_ctx* ctx, uint32_t page_size, const vs_node_layout* layout, uint32_t n_blocks_total, vs_pages_dev** out);
+int vs_pages_dev_add(vs_pages_dev* d, uint32_t first_block, const void* pages, uint32_t n_blocks); /* in block order */
+int vs_pages_dev_node_of(const vs_pages_dev* d, uint32_t block, uint32_t offset, uint32_t* node);
+int vs_pages_dev_sbq_means(const vs_pages_dev* d, uint32_t block, uint32_t offset, float* mean, float* m2, uint32_t dim_cap,
+                           uint32_t* dim, uint64_t* count);
+/* desc: the MetaPage fields (n is taken from the pages, default_start is a node id from vs_pages_dev_node_of);
+ * extras: vecs / mean / m2 / count (+ label start arrays unused: unlabeled); frees the raw pages */
+int vs_pages_dev_build(vs_pages_dev* d, const vs_index_desc* desc, const vs_index_host* extras, vs_pages_info* info, vs_index** out);
+void vs_pages_dev_close(vs_pages_dev* d);
 
 /* ---- K4: SBQ quantisation of queries (SbqQuantizer::quantize, AM/sbq/quantize.rs:52-102) --------------------- */
 /* q: host [nq][dim_index], already cosine-normalised by the caller if applicable; out: host [nq][words] */

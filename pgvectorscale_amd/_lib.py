@@ -109,6 +109,14 @@ SYMBOLS = {
     "vs_pages_read_chain": (_i, [_vp, _u32, _u32, _i, _vp, _sz, C.POINTER(_sz)]),
     "vs_pages_sbq_means": (_i, [_vp, _u32, _u32, _vp, _vp, _u32, C.POINTER(_u32), C.POINTER(_u64)]),
     "vs_pages_close": (None, [_vp]),
+    "vs_pages_headers_only": (_i, [_vp]),
+    "vs_pages_block_table": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_u32)]),
+    "vs_pages_dev_open": (_i, [_vp, _u32, C.POINTER(NodeLayout), _u32, C.POINTER(_vp)]),
+    "vs_pages_dev_add": (_i, [_vp, _u32, _vp, _u32]),
+    "vs_pages_dev_node_of": (_i, [_vp, _u32, _u32, C.POINTER(_u32)]),
+    "vs_pages_dev_sbq_means": (_i, [_vp, _u32, _u32, _vp, _vp, _u32, C.POINTER(_u32), C.POINTER(_u64)]),
+    "vs_pages_dev_build": (_i, [_vp, C.POINTER(IndexDesc), C.POINTER(IndexHost), C.POINTER(PagesInfo), C.POINTER(_vp)]),
+    "vs_pages_dev_close": (None, [_vp]),
     "vs_quantize": (_i, [_vp, _vp, _u32, _vp]),
     "vs_hamming_gather": (_i, [_vp, _vp, _vp, _vp, _u32, _vp]),
     "vs_rerank": (_i, [_vp, _vp, _vp, _vp, _u32, _vp]),

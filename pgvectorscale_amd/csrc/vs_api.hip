@@ -407,6 +407,12 @@ static int validate_graph(vs_index* ix) {
     return VS_OK;
 }
 
+// (used by vs_pages_dev.hip)
+int vs_upload_rows(vs_ctx* c, void* dst, size_t dev_row_bytes, const void* src, size_t host_row_bytes, size_t copy_bytes, size_t rows) {
+    return upload_rows(c, dst, dev_row_bytes, src, host_row_bytes, copy_bytes, rows);
+}
+int vs_validate_graph(vs_index* ix) { return validate_graph(ix); }
+
 extern "C" int vs_index_upload(vs_ctx* c, const vs_index_desc* desc, const vs_index_host* h, vs_index** out) {
     VS_REQUIRE(h && out && desc, "vs_index_upload: bad args");
     const bool plain = desc->storage_type == VS_STORAGE_PLAIN;

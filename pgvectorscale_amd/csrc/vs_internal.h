@@ -116,6 +116,9 @@ struct vs_index {
 };
 
 int devbuf_reserve(vs_ctx* ctx, DevBuf& b, size_t bytes);
+// row-wise staging through the pinned ring (device rows may be wider than host rows) / neighbor-list validation
+int vs_upload_rows(vs_ctx* c, void* dst, size_t dev_row_bytes, const void* src, size_t host_row_bytes, size_t copy_bytes, size_t rows);
+int vs_validate_graph(vs_index* ix);
 void devbuf_free(DevBuf& b);
 
 // ---- kernel launch wrappers (defined in the .hip files) -------------------------------------------------------

@@ -172,6 +172,7 @@ struct vs_pages {
     vs_node_layout lay{};
     uint32_t threads = 1;
     bool finished = false;
+    bool headers_only = false;  // vs_pages_headers_only: block table + metadata pages only (the device decodes the nodes)
     // per block
     std::vector<uint32_t> blk_base;  // dense id of the block's first node
     std::vector<uint32_t> blk_cnt;   // SbqNode items on the block (0 for every other page type)
@@ -302,6 +303,11 @@ int vs_pages_add(vs_pages* p, uint32_t first_block, const void* pages, uint32_t 
         return VS_OK;
     };
     if (n1 == n0) return commit_blocks();
+    if (p->headers_only) {  // node items are decoded elsewhere (vs_pages_dev_*): only the block table is kept
+        const int rc0 = commit_blocks();
+        if (rc0 == VS_OK) p->n = n1;
+        return rc0;
+    }
 
     // geometry (W, R) is fixed for an index: every node is written with num_neighbors slots (AM/sbq/node.rs:62-66) and
     // a quantized_size()-word code (AM/sbq/quantize.rs:37-45); take it from the first node seen
@@ -558,6 +564,9 @@ int vs_pages_finish(vs_pages* p, vs_pages_info* info) {
         }
         if (p->n == 0 && p->by_type[VS_PAGE_NODE] > 0)
             return fail("the relation holds `plain` storage nodes (PageType::Node); this path reads memory_optimized (SBQ) indexes");
+        if (p->headers_only) {
+            p->finished = true;
+        } else {
         // neighbor ItemPointers -> dense ids
         const uint32_t R = p->R;
         const uint64_t n = p->n;
@@ -597,6 +606,7 @@ int vs_pages_finish(vs_pages* p, vs_pages_info* info) {
         }
         std::vector<uint64_t>().swap(p->nbr_raw);
         p->finished = true;
+        }
     }
     if (info) {
         memset(info, 0, sizeof *info);
@@ -615,8 +625,30 @@ int vs_pages_finish(vs_pages* p, vs_pages_info* info) {
     return VS_OK;
 }
 
+int vs_pages_headers_only(vs_pages* p) {
+    if (!p) return fail("vs_pages_headers_only: null reader");
+    if (!p->blk_cnt.empty()) {
+        vs_set_error("vs_pages_headers_only after blocks were added");
+        return VS_ERR_STATE;
+    }
+    p->headers_only = true;
+    return VS_OK;
+}
+
+int vs_pages_block_table(const vs_pages* p, const uint32_t** blk_base, const uint32_t** blk_cnt, uint32_t* n_blocks) {
+    if (!p || !blk_base || !blk_cnt || !n_blocks) return fail("vs_pages_block_table: null argument");
+    *blk_base = p->blk_base.data();
+    *blk_cnt = p->blk_cnt.data();
+    *n_blocks = (uint32_t)p->blk_cnt.size();
+    return VS_OK;
+}
+
 int vs_pages_host(const vs_pages* p, vs_index_host* host) {
     if (!p || !host) return fail("vs_pages_host: null argument");
+    if (p->headers_only) {
+        vs_set_error("vs_pages_host: this reader only keeps the block table (vs_pages_headers_only)");
+        return VS_ERR_STATE;
+    }
     if (!p->finished) {
         vs_set_error("vs_pages_host before vs_pages_finish");
         return VS_ERR_STATE;

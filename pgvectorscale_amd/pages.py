@@ -160,3 +160,73 @@ class IndexPages:
             self.close()
         except Exception:
             pass
+
+
+class DevicePages:
+    """The same relation, decoded on the device (vs_pages_dev_*): blocks are copied to HBM as they are, a kernel decodes
+    the SbqNode items into the index arrays.  Unlabeled memory_optimized indexes."""
+
+    def __init__(self, ctx, n_blocks_total, page_size=BLCKSZ, layout=None):
+        self.ctx = ctx
+        self._L = ctx._L
+        lay = None if layout is None else NodeLayout(*layout)
+        h = C.c_void_p()
+        check(self._L.vs_pages_dev_open(ctx.h, page_size, None if lay is None else C.byref(lay), n_blocks_total, C.byref(h)))
+        self.h = h
+        self.page_size = page_size
+        self.n_blocks = 0
+        self.info = None
+
+    def add(self, pages, first_block=None):
+        buf = np.frombuffer(pages, np.uint8)
+        if buf.size % self.page_size:
+            raise ValueError(f"{buf.size} bytes is not a whole number of {self.page_size}-byte pages")
+        nb = buf.size // self.page_size
+        fb = self.n_blocks if first_block is None else first_block
+        check(self._L.vs_pages_dev_add(self.h, fb, buf.ctypes.data_as(C.c_void_p), nb))
+        self.n_blocks += nb
+
+    def node_of(self, block, offset):
+        out = C.c_uint32()
+        check(self._L.vs_pages_dev_node_of(self.h, block, offset, C.byref(out)))
+        return int(out.value)
+
+    def sbq_means(self, block, offset):
+        dim, cnt = C.c_uint32(), C.c_uint64()
+        check(self._L.vs_pages_dev_sbq_means(self.h, block, offset, None, None, 0, C.byref(dim), C.byref(cnt)))
+        mean = np.empty(dim.value, np.float32)
+        m2 = np.empty(dim.value, np.float32)
+        check(self._L.vs_pages_dev_sbq_means(self.h, block, offset, mean.ctypes.data_as(C.c_void_p), m2.ctypes.data_as(C.c_void_p),
+                                             dim.value, C.byref(dim), C.byref(cnt)))
+        return int(cnt.value), mean, m2
+
+    def build(self, *, words, num_neighbors, dim_index, bits, distance_type, default_start, quantizer_metadata=None, mean=None,
+              m2=None, count=0, vecs=None):
+        """default_start: IndexPointer (block, offset) or node id; quantizer_metadata: IndexPointer of the SbqMeans chain."""
+        from .index import DiskAnnIndex
+        if quantizer_metadata is not None:
+            count, mean, m2 = self.sbq_means(*quantizer_metadata)
+        mean = np.ascontiguousarray(mean, np.float32)
+        m2 = None if m2 is None else np.ascontiguousarray(m2, np.float32)
+        vecs = None if vecs is None else np.ascontiguousarray(vecs, np.float32)
+        d = IndexDesc()
+        d.dim_index, d.bits, d.words, d.num_neighbors = dim_index, bits, words, num_neighbors
+        d.dim_full = dim_index if vecs is None else vecs.shape[1]
+        d.distance_type, d.has_labels, d.n_label_starts, d.storage_type = distance_type, 0, 0, 0
+        d.default_start = (_lib.VS_INVALID_NODE if default_start is None
+                           else self.node_of(*default_start) if isinstance(default_start, tuple) else int(default_start))
+        h = IndexHost()
+        h.vecs = None if vecs is None else vecs.ctypes.data
+        h.mean = mean.ctypes.data
+        h.m2 = None if m2 is None else m2.ctypes.data
+        h.count = count
+        info = PagesInfo()
+        out = C.c_void_p()
+        check(self._L.vs_pages_dev_build(self.h, C.byref(d), C.byref(h), C.byref(info), C.byref(out)))
+        self.info = info
+        return DiskAnnIndex(self.ctx, out)
+
+    def close(self):
+        if self.h:
+            self._L.vs_pages_dev_close(self.h)
+            self.h = None

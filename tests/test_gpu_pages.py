@@ -54,3 +54,4 @@ def test_index_from_pages_searches_like_the_oracle(gpu_ctx, oracle, labeled):
     assert gst["visited_nodes"] == ost["visited_nodes"]
     assert gst["quantized_distance_comparisons"] == ost["quantized_distance_comparisons"]
     ix.close()
+

@@ -288,6 +288,10 @@ def main():
                 setup["graph_cache_write_s"] = round(time.time() - t1, 3)
             except Exception as e:  # the cache is a convenience only
                 log(f"graph cache not written: {e!r}")
+                try:
+                    os.remove(tmp)
+                except OSError:
+                    pass
     log("setup", setup)
 
     # ---- query batches resident in HBM (disjoint row range of the same stream) -------------------------------------

@@ -9,12 +9,15 @@
 //
 //   * candidate heap (BinaryHeap<Reverse<ListSearchNeighbor>>, AM/graph/mod.rs:75): same 4-byte entries
 //     (hamming << sb | dedup slot) and the same LDS / spill split as k_search_fast; sift_up = lane r of the row compares
-//     with the r-th ancestor (one read, one 16-bit ballot, one store; heaps of < 2^15 entries); sift_down_to_bottom = one
-//     level per step (both children in one 8-byte read).  Rust std's array mechanics are replayed exactly.
+//     with the r-th ancestor (one read, one 16-bit ballot, one store; heaps of < 2^15 entries); the pushes of a visit run
+//     against an LDS-staged copy of all their ancestors (one memory round trip per run); sift_down_to_bottom evaluates a
+//     4-level subtree per round (both children of every node in one 8-byte read).  Rust std's array mechanics are
+//     replayed exactly.
 //   * dedup set: the per-scan global table of the table-less regime (L2 atomics), one lane per neighbor, 16 per step.
 //   * visited list: sorted array in registers, entry i = lane i % 16 of register i / 16; insert / remove(0) are DPP row
 //     shift (row_shr) with the carry between registers taken by a row rotate; remove(0) advances a head offset.
-//   * distances: 4 lanes per code row, 4 rows per row-of-16 per step.
+//   * distances: 4 lanes per code row, 4 rows per row-of-16 per step, GD steps in flight.
+//   * the id of the next node to visit and the heap tid of the visited list's front are requested a step ahead.
 //
 // Scans whose state outgrows the kernel set the same status flags as in k_search_fast and are re-run by the general
 // kernel.  Results (streams, Hamming distances, GreedySearchStats counters) are bit-identical to k_search_fast's.

@@ -388,30 +388,63 @@ def main():
                 else:
                     os.environ.pop("VS_F_LDS_MAX_INS", None)
 
-        def timed(mx):
-            set_kernel(mx)
+        # the k_search_mx arms: its default LDS heap top (511 entries) and, unless the caller pinned VS_F_HL, 255 / 1023 — the
+        # same kernel binary with another LDS / occupancy trade
+        hl_free = "VS_F_HL" not in os.environ
+        variants = [("k_search_fast", False, None), ("k_search_mx", True, None)]
+        if hl_free:
+            variants += [("k_search_mx VS_F_HL=255", True, "255"), ("k_search_mx VS_F_HL=1023", True, "1023")]
+
+        def set_variant(v):
+            set_kernel(v[1])
+            if hl_free:
+                if v[2] is None:
+                    os.environ.pop("VS_F_HL", None)
+                else:
+                    os.environ["VS_F_HL"] = v[2]
+
+        def timed(v):
+            set_variant(v)
             step(0)  # sizes the launch from its own statistics
             barrier()
             t1 = time.perf_counter()
             step(0)
             barrier()
             return time.perf_counter() - t1, out_ids.clone(), out_dist.clone()
-        try:
-            t_fast, ids_f, dist_f = timed(False)
-            t_mx, ids_m, dist_m = timed(True)
-            same = bool(torch.equal(ids_f, ids_m)) and bool(torch.equal(dist_f.view(torch.int32), dist_m.view(torch.int32)))
-            kernel_choice.update(k_search_fast_ms_per_step=round(t_fast * 1e3, 3), k_search_mx_ms_per_step=round(t_mx * 1e3, 3),
-                                 results_identical=same)
-            use_mx = same and t_mx < 0.97 * t_fast
-        except P.VsError as e:
-            kernel_choice["ab_error"] = str(e)
-            use_mx = False
+
+        times, okv = [], []
+        ref_ids = ref_dist = None
+        for vi, v in enumerate(variants):
+            try:
+                t_v, ids_v, dist_v = timed(v)
+                if vi == 0:
+                    ref_ids, ref_dist = ids_v, dist_v
+                    same = True
+                else:
+                    same = bool(torch.equal(ref_ids, ids_v)) and bool(torch.equal(ref_dist.view(torch.int32), dist_v.view(torch.int32)))
+            except P.VsError as e:
+                kernel_choice.setdefault("ab_errors", {})[v[0]] = str(e)
+                t_v, same = float("inf"), False
+            times.append(t_v)
+            okv.append(same)
+        kernel_choice["ms_per_step"] = {v[0]: (round(t * 1e3, 3) if t != float("inf") else None) for v, t in zip(variants, times)}
+        kernel_choice["results_identical"] = {v[0]: o for v, o in zip(variants[1:], okv[1:])}
+        if world > 1:  # a variant counts only if it was identical on every rank; rank 0's clock decides
+            flags = torch.tensor([1 if o else 0 for o in okv], dtype=torch.int32, device=dev)
+            dist.all_reduce(flags, op=dist.ReduceOp.MIN)
+            okv = [bool(x) for x in flags.tolist()]
+        best = 0
+        for vi in range(1, len(variants)):
+            if okv[vi] and times[vi] < 0.97 * times[0] and times[vi] < times[best]:
+                best = vi
+        if not okv[0]:
+            best = 0
         if world > 1:
-            flag = torch.tensor([1 if use_mx else 0], dtype=torch.int32, device=dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # all ranks run the same kernel
-            use_mx = bool(flag.item())
-        set_kernel(use_mx)
-        kernel_choice["chosen"] = "k_search_mx" if use_mx else "k_search_fast"
+            pick = torch.tensor([best], dtype=torch.int32, device=dev)
+            dist.broadcast(pick, 0)
+            best = int(pick.item())
+        set_variant(variants[best])
+        kernel_choice["chosen"] = variants[best][0]
         log("search kernel A/B:", kernel_choice)
     for b in range(args.warmup):
         step(b)

@@ -31,7 +31,7 @@ def test_bench_dry_run_on_the_interpreter():
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(j["roofline"])
     assert j["cpu_baseline"]["gpu_rows_identical"] is True and j["cpu_baseline"]["gpu_dist_bit_identical_frac"] == 1.0
     sk = j["search_kernel"]
-    assert sk["canary"].startswith("passed") and sk["results_identical"] is True
+    assert sk["canary"].startswith("passed") and all(sk["results_identical"].values()) and len(sk["ms_per_step"]) == 4
     assert j["recall_target_met"] is True
 
 
@@ -50,4 +50,4 @@ def test_bench_dry_run_two_ranks():
     assert r.returncode == 0, r.stderr[-3000:]
     j = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
     assert j["n_gpus"] == 2 and j["scaling"] == "weak" and "query-sharded x2" in j["config"]["parallelism"]
-    assert j["search_kernel"]["results_identical"] is True
+    assert all(j["search_kernel"]["results_identical"].values())

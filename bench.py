@@ -99,7 +99,7 @@ def canary_verdict(returncode, stdout):
     return True, f"{cb.get('sample', '').split(',')[0]} identical to the oracle"
 
 
-def mx_canary(args):
+def mx_canary(args, extra_env=None):
     """k_search_mx (four scans per wave, vs_search_mx.hip) is newer than the measurements in profiles/: before it is even
     tried in this process, a child process runs a small instance of the same workload on it with a time limit and
     checks the rows against the oracle.  A crash, a hang or a single differing row keeps this run on k_search_fast."""
@@ -107,6 +107,7 @@ def mx_canary(args):
     env = {k_: v_ for k_, v_ in os.environ.items() if k_ not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
                                                                  "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "TORCHELASTIC_RUN_ID")}
     env.update(VS_MX="2", VS_F_LDS_MAX_INS="0", VS_BENCH_CANARY="1")  # 2 = insist: every query launch must run on k_search_mx
+    env.update(extra_env or {})
     small = ["--n", "4000", "--nq", "64", "--recall-queries", "16"] if EMU else ["--n", "200000", "--nq", "8192"]
     cmd = [sys.executable, os.path.abspath(__file__), *small, "--steps", "1", "--warmup", "1", "--fixed",
            "100,50", "--graph-cache", "none", "--scan-nq", "0", "--cpu-seconds", "3", "--dim", str(args.dim), "--distance",
@@ -234,6 +235,7 @@ def main():
     # which search kernel: VS_MX set by the user is respected; otherwise k_search_mx is tried (canary first, then an A/B
     # on a full batch of this run's queries, both outside the timed region) wherever the table-less regime applies
     kernel_choice = {"chosen": "k_search_fast"}
+    try_gd4 = False
     try_mx = "VS_MX" not in os.environ and not os.environ.get("VS_BENCH_CANARY") and \
         (args.n >= 500_000 or bool(os.environ.get("VS_BENCH_TRY_MX")))
     if try_mx and rank == 0:
@@ -243,6 +245,10 @@ def main():
         kernel_choice["canary_s"] = round(time.time() - t0, 1)
         log("k_search_mx canary", kernel_choice["canary"])
         try_mx = ok
+        if ok and "VS_MX_GD" not in os.environ:  # the 16-rows-in-flight gather variant is another kernel binary: its own canary
+            ok4, why4 = mx_canary(args, {"VS_MX_GD": "4"})
+            kernel_choice["canary_gd4"] = ("passed: " if ok4 else "failed: ") + why4
+            try_gd4 = ok4
     if os.environ.get("VS_MX", "0") not in ("", "0"):
         kernel_choice["chosen"] = "k_search_mx where eligible (VS_MX set by the caller)"
     dt = {"l2": P.VS_L2, "cosine": P.VS_COSINE, "ip": P.VS_IP}[args.distance]
@@ -371,9 +377,9 @@ def main():
 
     if world > 1:  # every rank follows rank 0's canary
         import torch.distributed as dist
-        flag = torch.tensor([1 if try_mx else 0], dtype=torch.int32, device=dev)
+        flag = torch.tensor([1 if try_mx else 0, 1 if try_gd4 else 0], dtype=torch.int32, device=dev)
         dist.broadcast(flag, 0)
-        try_mx = bool(flag.item())
+        try_mx, try_gd4 = bool(flag[0].item()), bool(flag[1].item())
     if try_mx:
         # A/B on batch 0: same queries through both kernels, results must be identical, the faster one is used
         # (k_search_mx covers the table-less regime; small corpora default to the LDS-table regime of k_search_fast, so the
@@ -391,9 +397,11 @@ def main():
         # the k_search_mx arms: its default LDS heap top (511 entries) and, unless the caller pinned VS_F_HL, 255 / 1023 — the
         # same kernel binary with another LDS / occupancy trade
         hl_free = "VS_F_HL" not in os.environ
-        variants = [("k_search_fast", False, None), ("k_search_mx", True, None)]
+        variants = [("k_search_fast", False, None, None), ("k_search_mx", True, None, None)]
         if hl_free:
-            variants += [("k_search_mx VS_F_HL=255", True, "255"), ("k_search_mx VS_F_HL=1023", True, "1023")]
+            variants += [("k_search_mx VS_F_HL=255", True, "255", None), ("k_search_mx VS_F_HL=1023", True, "1023", None)]
+        if try_gd4:
+            variants += [("k_search_mx VS_MX_GD=4", True, None, "4")]
 
         def set_variant(v):
             set_kernel(v[1])
@@ -402,6 +410,11 @@ def main():
                     os.environ.pop("VS_F_HL", None)
                 else:
                     os.environ["VS_F_HL"] = v[2]
+            if try_gd4:
+                if v[3] is None:
+                    os.environ.pop("VS_MX_GD", None)
+                else:
+                    os.environ["VS_MX_GD"] = v[3]
 
         def timed(v):
             set_variant(v)

@@ -31,7 +31,7 @@ def test_bench_dry_run_on_the_interpreter():
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(j["roofline"])
     assert j["cpu_baseline"]["gpu_rows_identical"] is True and j["cpu_baseline"]["gpu_dist_bit_identical_frac"] == 1.0
     sk = j["search_kernel"]
-    assert sk["canary"].startswith("passed") and all(sk["results_identical"].values()) and len(sk["ms_per_step"]) == 4
+    assert sk["canary"].startswith("passed") and all(sk["results_identical"].values()) and len(sk["ms_per_step"]) == 5 and sk["canary_gd4"].startswith("passed")
     assert j["recall_target_met"] is True
 
 

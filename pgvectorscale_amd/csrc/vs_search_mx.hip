@@ -127,7 +127,7 @@ struct MxHeap {
     static __device__ __forceinline__ uint32_t stg_off(uint32_t r) {
         return r == 0 ? 0u : r == 1 ? 64u : r == 2 ? 97u : r == 3 ? 114u : r == 4 ? 123u : r == 5 ? 128u : 131u + 2u * (r - 6u);
     }
-    __device__ __forceinline__ void push_run_staged(const Lane& L, uint32_t* stg, const uint32_t* e, uint32_t c, uint32_t cmax) {
+    __device__ __forceinline__ void push_run_staged(const Lane& L, uint32_t* stg, uint32_t* e, uint32_t* cl, uint32_t c, uint32_t cmax) {
         const bool row = c > 0;
         const uint32_t p1f = len + 1, p1l = len + c;
         const uint32_t r = (uint32_t)L.gl;
@@ -155,11 +155,34 @@ struct MxHeap {
         mx_wave_sync();
         const uint32_t cst = stg_off(r) - (p1f >> r);         // slot of rank-r index x = x + cst (mod 2^32)
         const uint32_t cst_w = row_shr1(cst, 0);               // the same for rank r - 1 (lane r >= 1 writes there)
-        for (uint32_t j = 0; j < cmax; ++j) {
-            const bool on = j < c;
-            const uint32_t p1 = p1f + j;
-            // (both reads are unconditional: j < cmax <= 64 and the slot of any (p1, r) lie inside the row's arrays)
-            const uint32_t elem = e[j];
+        // An element that is not smaller than the ORIGINAL parent of its leaf stays on the leaf whatever the earlier pushes
+        // of the run do (they can only lower that parent), and no push ever reads a leaf of the run: such elements — about
+        // a third — are stored right away, 16 per step; the others are compacted in run order (element into e[], its run
+        // index into cl[]) and only they go through the sequential loop.
+        uint32_t ncl = 0;
+        for (uint32_t j0 = 0; j0 < cmax; j0 += MX_G) {
+            const uint32_t j = j0 + r;
+            const bool in = j < c;
+            const uint32_t el = e[j];  // (in-bounds of the row arrays for every j < cmax + 16)
+            const uint32_t par = stg[64u + ((p1f + j) >> 1) - (p1f >> 1)];
+            const bool climb = in && (el >> sb) < (par >> sb);
+            const uint32_t cm = L.gballot(climb);
+            if (in && !climb) stg[j] = el;
+            if (climb) {
+                const uint32_t k = ncl + (uint32_t)__builtin_popcount(cm & ((1u << r) - 1u));
+                e[k] = el;
+                cl[k] = j;
+            }
+            ncl += (uint32_t)__builtin_popcount(cm);
+            mx_wave_sync();
+        }
+        const uint32_t nclmax = max(max((uint32_t)__builtin_amdgcn_readlane((int)ncl, 0), (uint32_t)__builtin_amdgcn_readlane((int)ncl, 16)),
+                                    max((uint32_t)__builtin_amdgcn_readlane((int)ncl, 32), (uint32_t)__builtin_amdgcn_readlane((int)ncl, 48)));
+        for (uint32_t k = 0; k < nclmax; ++k) {
+            const bool on = k < ncl;
+            // (both reads are unconditional: k < 64 and the slot of any (p1, r) lie inside the row's arrays)
+            const uint32_t elem = e[k];
+            const uint32_t p1 = p1f + (cl[k] & 63u);
             const uint32_t a = stg[(p1 >> r) + cst];
             const bool cmp = on && r >= 1 && (elem >> sb) < (a >> sb);
             const uint32_t bal = L.gballot(cmp) >> 1;                    // bit r-1 <-> ancestor r
@@ -676,7 +699,7 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_mx(MxArgs a) {
                 const uint32_t n = jb < c ? min(c - jb, room) : 0u;
                 const uint32_t nmax = max(max((uint32_t)__builtin_amdgcn_readlane((int)n, 0), (uint32_t)__builtin_amdgcn_readlane((int)n, 16)),
                                           max((uint32_t)__builtin_amdgcn_readlane((int)n, 32), (uint32_t)__builtin_amdgcn_readlane((int)n, 48)));
-                heap.push_run_staged(L, stg, surv_e + jb, n, nmax);
+                heap.push_run_staged(L, stg, surv_e + jb, surv_id, n, nmax);  // (surv_id is free after the gather)
                 jb += n;
             }
         } else {  // a shallow heap somewhere (the first expansions of a scan): one push at a time

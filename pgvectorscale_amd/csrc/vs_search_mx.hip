@@ -21,6 +21,7 @@
 //
 // Scans whose state outgrows the kernel set the same status flags as in k_search_fast and are re-run by the general
 // kernel.  Results (streams, Hamming distances, GreedySearchStats counters) are bit-identical to k_search_fast's.
+#include <algorithm>
 #include <cstdlib>
 
 #include "vs_device.h"
@@ -40,6 +41,8 @@ struct MxArgs {
     const uint32_t* ls_nodes;
     uint32_t code_stride, nbr_stride, R, n, n_ls, default_start;
     FastLaunch s;
+    uint32_t persist;  // 1: rows fetch scans from `queue` until it is empty (grid = resident waves); 0: one scan per row
+    uint32_t* queue;   // next scan id (zeroed by the host before the launch)
 };
 
 namespace {
@@ -392,10 +395,6 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_mx(MxArgs a) {
     L.gl = L.lane & 15;
     L.gbase = L.lane & 48;
     const int g = L.lane >> 4;
-    const uint32_t q = blockIdx.x * 4u + (uint32_t)g;
-    bool alive = q < s.nq;  // rows past the end of the batch idle
-    const uint32_t qs = alive ? q : 0u;
-
     // ---- LDS carve (per row) ----
     // (row strides are padded so that the four rows' arrays start in different LDS banks: the rows execute the same
     // instruction and touch the same relative index of their own array most of the time)
@@ -414,25 +413,14 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_mx(MxArgs a) {
     const int l4 = L.gl & 3;
     ulonglong2 qv[NCH];
 #pragma unroll
-    for (int t = 0; t < NCH; ++t) {
-        const uint32_t w = 2u * (uint32_t)l4 + 8u * (uint32_t)t;
-        qv[t] = (alive && w < a.code_stride) ? *reinterpret_cast<const ulonglong2*>(s.qcodes + (size_t)qs * a.code_stride + w)
-                                             : make_ulonglong2(0, 0);
-    }
+    for (int t = 0; t < NCH; ++t) qv[t] = make_ulonglong2(0, 0);
     if (L.gl == 0) hp[0] = 0;  // heap sentinel
     const bool labels_some = s.qlabel_off != nullptr;  // LabeledVector.labels is Some (AM/labels/mod.rs:222-236)
-    uint32_t nql = 0;
-    if (labels_some && alive) {
-        const uint32_t lb = s.qlabel_off[qs], le = s.qlabel_off[qs + 1];
-        nql = min(le - lb, (uint32_t)MX_MAX_QLABELS);
-        for (uint32_t i = L.gl; i < nql; i += MX_G) ql[i] = s.qlabels[lb + i];
-    }
-    const bool has_label_filter = labels_some && nql > 0;  // AM/scan.rs:189
     mx_wave_sync();
 
     MxHeap heap;
     heap.l = hp;
-    heap.g = s.heap_g + (size_t)qs * s.gstride;
+    heap.g = s.heap_g;
     heap.hl = s.hl;
     heap.sb = s.sb;
     heap.len = 0;
@@ -445,25 +433,20 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_mx(MxArgs a) {
     // heaps stay below 2^15 entries (depth <= 15: the lane of rank 15 only ever sees the sentinel, MxHeap::place); a scan
     // that needs more is handed to the general kernel like any other overflow
     const uint32_t hcap = min(s.hcap, 32767u);
+
+    // ---- the scan this row is working on.  A row is idle (no scan), or busy with a scan that is alive or has failed;
+    // `done` = nothing left to do for it but publish.  Rows take scans from a queue until it is empty (persist), so a wave
+    // does not idle three rows while its longest scan finishes.
+    uint32_t q = 0, nql = 0;
+    bool has_label_filter = false;  // AM/scan.rs:189
+    bool busy = false, alive = false, done = true;
+    bool more = true;  // the queue may still hold a scan for this row
     uint32_t emitted = 0, status = 0, nins_g = 0, hmax = 0;
     uint32_t st_visits = 0, st_cand = 0, st_dq = 0, st_reads = 0, st_pfhit = 0;
-
-    // ---- the scan's dedup table ("inserted", HashSet<ItemPointer>): claimed from the pool and cleared up front ----
     uint32_t* ghash = s.ghash;
-    {
-        uint32_t slot = 0;
-        if (alive && L.gl == 0) slot = atomicAdd(s.pool_counter, 1u);
-        slot = L.gbcast(slot, 0);
-        if (alive && slot >= s.pool_slots) {
-            status |= OVF_POOL;
-            alive = false;
-        }
-        ghash = s.ghash + (size_t)(alive ? slot : 0u) * s.gcap;
-        if (alive)
-            for (uint32_t i = 4u * (uint32_t)L.gl; i < s.gcap; i += 4u * MX_G)
-                *reinterpret_cast<uint4*>(ghash + i) = make_uint4(VS_EMPTY, VS_EMPTY, VS_EMPTY, VS_EMPTY);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    }
+    uint64_t ft_val = 1;     // heap tid of the visited list's front entry
+    uint32_t next_node = 0;  // node id of the heap root
+
     // HashSet::insert of one id per lane; true where the id was not present before, slot_out = its handle
     auto dedup_insert = [&](uint32_t nid, bool act, uint32_t& slot_out) -> bool {
         bool fresh = false;
@@ -487,12 +470,60 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_mx(MxArgs a) {
         }
     };
 
-    // ---- ListSearchResult::new: start nodes (AM/graph/mod.rs:97-124, AM/graph/start_nodes.rs:39-48) ----
-    {
+    // ---- a row begins scan `qn` (everything is predicated on `ini`: the other rows are in the middle of theirs) ----
+    auto start_scan = [&](bool ini, uint32_t qn) {
+        q = ini ? qn : q;
+        busy = busy || ini;
+        alive = ini ? true : alive;
+        done = ini ? false : done;
+        emitted = ini ? 0u : emitted;
+        status = ini ? 0u : status;
+        nins_g = ini ? 0u : nins_g;
+        hmax = ini ? 0u : hmax;
+        st_visits = ini ? 0u : st_visits;
+        st_cand = ini ? 0u : st_cand;
+        st_dq = ini ? 0u : st_dq;
+        st_reads = ini ? 0u : st_reads;
+        ft_val = ini ? 1ull : ft_val;
+        heap.len = ini ? 0u : heap.len;
+        heap.g = ini ? s.heap_g + (size_t)qn * s.gstride : heap.g;
+        vis.len = ini ? 0u : vis.len;
+        vis.head = ini ? 0u : vis.head;
+#pragma unroll
+        for (int t = 0; t < NCH; ++t) {
+            const uint32_t w = 2u * (uint32_t)l4 + 8u * (uint32_t)t;
+            if (ini) qv[t] = w < a.code_stride ? *reinterpret_cast<const ulonglong2*>(s.qcodes + (size_t)qn * a.code_stride + w)
+                                               : make_ulonglong2(0, 0);
+        }
+        nql = ini ? 0u : nql;
+        if (labels_some && ini) {
+            const uint32_t lb = s.qlabel_off[qn], le = s.qlabel_off[qn + 1];
+            nql = min(le - lb, (uint32_t)MX_MAX_QLABELS);
+            for (uint32_t i = L.gl; i < nql; i += MX_G) ql[i] = s.qlabels[lb + i];
+        }
+        has_label_filter = ini ? (labels_some && nql > 0) : has_label_filter;
+        mx_wave_sync();
+        // the scan's dedup table ("inserted", HashSet<ItemPointer>): claimed from the pool and cleared up front
+        {
+            uint32_t slot = 0;
+            if (ini && L.gl == 0) slot = atomicAdd(s.pool_counter, 1u);
+            slot = L.gbcast(slot, 0);
+            if (ini && slot >= s.pool_slots) {
+                status |= OVF_POOL;
+                alive = false;
+            }
+            const bool clr = ini && alive;
+            ghash = clr ? s.ghash + (size_t)slot * s.gcap : ghash;
+            if (clr)
+                for (uint32_t i = 4u * (uint32_t)L.gl; i < s.gcap; i += 4u * MX_G)
+                    *reinterpret_cast<uint4*>(ghash + i) = make_uint4(VS_EMPTY, VS_EMPTY, VS_EMPTY, VS_EMPTY);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        }
+        // ListSearchResult::new: start nodes (AM/graph/mod.rs:97-124, AM/graph/start_nodes.rs:39-48)
         uint32_t nstarts = labels_some ? nql : 1u;
         if (a.default_start == VS_INVALID_NODE || a.n == 0) nstarts = 0;  // ListSearchResult::empty()
-        for (uint32_t si = 0; __ballot(alive && si < nstarts); ++si) {
-            const bool on = alive && si < nstarts;
+        for (uint32_t si = 0; __ballot(ini && alive && si < nstarts); ++si) {
+            const bool on = ini && alive && si < nstarts;
             uint32_t sn = VS_INVALID_NODE;
             if (on) {
                 if (!labels_some) {
@@ -523,17 +554,61 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_mx(MxArgs a) {
             fail(fr && heap.len + 1 > hcap, OVF_HEAP);
             heap.push(L, (d << s.sb) | slot, fr && alive);
         }
-    }
+        if (ini && alive && heap.len > 0) next_node = mx_gload32(ghash + (hp[1] & smask));
+    };
+    // ---- a row publishes its finished (or failed) scan and becomes idle ----
+    auto finish_scan = [&](bool fin) {
+        // one `next` call per emitted row, plus the call that found the stream exhausted
+        const uint32_t st_next = emitted + ((emitted < s.M && status == 0) ? 1u : 0u);
+        if (fin) {
+            if (status == 0) {
+                for (uint32_t i = emitted + (uint32_t)L.gl; i < s.M; i += MX_G) {
+                    s.out_ids[(size_t)q * s.M + i] = VS_INVALID_NODE;
+                    s.out_ham[(size_t)q * s.M + i] = 0xFFFFFFFFu;
+                }
+            }
+            if (L.gl == 0) {
+                s.status[q] = status;
+                s.out_cnt[q] = status ? 0 : emitted;  // a failed scan publishes an empty stream until the fallback re-runs it
+                if (status == 0) {
+                    uint32_t* st = s.stats + (size_t)q * ST_N;
+                    st[ST_VISITS] = st_visits;
+                    st[ST_CAND] = st_cand;
+                    st[ST_DQ] = st_dq;
+                    st[ST_READS] = st_reads;
+                    st[ST_NEXT] = st_next;
+                    st[ST_GSPILL] = hmax;
+                    st[ST_PFHIT] = st_pfhit;
+                    st[7] = nins_g;
+                }
+            }
+        }
+        busy = fin ? false : busy;
+    };
 
     // ---- TSVResponseIterator::next until M rows are emitted (AM/scan.rs:210-242): every round, each scan first consumes
     // rows while it cannot visit (consume, AM/graph/mod.rs:174-184), then all scans that can do one visit_closest()
     // expansion (greedy_search_iterate, AM/graph/mod.rs:357-385) ----
-    bool done = !alive;
-    uint64_t ft_val = 1;     // heap tid of the visited list's front entry
-    uint32_t next_node = 0;  // node id of the heap root
-    if (alive && heap.len > 0) next_node = mx_gload32(ghash + (hp[1] & smask));
     for (;;) {
         done = done || !alive;
+        {  // publish what is finished, fetch what is next
+            const bool fin = busy && done;
+            if (__ballot(fin)) finish_scan(fin);
+            const bool want = !busy && more;
+            if (__ballot(want)) {
+                uint32_t qn = blockIdx.x * 4u + (uint32_t)g;  // one scan per row ...
+                if (a.persist) {                               // ... or the next one in the queue
+                    qn = 0xFFFFFFFFu;
+                    if (want && L.gl == 0) qn = atomicAdd(a.queue, 1u);
+                    qn = L.gbcast(qn, 0);
+                }
+                const bool got = want && qn < s.nq;
+                more = want ? (got && a.persist != 0) : more;
+                start_scan(got, qn);
+                done = done || !alive;
+            }
+            if (!__ballot(busy)) break;
+        }
         // can this scan visit?  visit_closest(L) stop rule (AM/graph/mod.rs:153-170)
         auto can_visit_now = [&]() -> bool {
             bool cv = !done && heap.len > 0;
@@ -567,7 +642,7 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_mx(MxArgs a) {
             done = done || (live_row && emitted == s.M);
             cv = can_visit_now();
         }
-        if (!__ballot(!done)) break;
+        if (!__ballot(!done)) continue;  // nothing to expand: publish / refill
         const bool ex = !done && cv;  // this scan expands now
         hmax = ex ? max(hmax, heap.len) : hmax;
         const uint32_t top = ex ? hp[1] : 0u;
@@ -718,31 +793,6 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_mx(MxArgs a) {
         }
     }
 
-    // one `next` call per emitted row, plus the call that found the stream exhausted
-    const uint32_t st_next = emitted + ((emitted < s.M && status == 0) ? 1u : 0u);
-    if (q < s.nq) {
-        if (status == 0) {
-            for (uint32_t i = emitted + (uint32_t)L.gl; i < s.M; i += MX_G) {
-                s.out_ids[(size_t)q * s.M + i] = VS_INVALID_NODE;
-                s.out_ham[(size_t)q * s.M + i] = 0xFFFFFFFFu;
-            }
-        }
-        if (L.gl == 0) {
-            s.status[q] = status;
-            s.out_cnt[q] = status ? 0 : emitted;  // a failed scan publishes an empty stream until the fallback re-runs it
-            if (status == 0) {
-                uint32_t* st = s.stats + (size_t)q * ST_N;
-                st[ST_VISITS] = st_visits;
-                st[ST_CAND] = st_cand;
-                st[ST_DQ] = st_dq;
-                st[ST_READS] = st_reads;
-                st[ST_NEXT] = st_next;
-                st[ST_GSPILL] = hmax;
-                st[ST_PFHIT] = st_pfhit;
-                st[7] = nins_g;
-            }
-        }
-    }
 }
 
 // ---- host side --------------------------------------------------------------------------------------------------------
@@ -766,7 +816,17 @@ static int launch_mx_ttt(vs_index* idx, const MxArgs& a, size_t lds) {
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_search_mx<NCH, VRR, GD, MINW>), dim3((a.s.nq + 3) / 4), dim3(WAVE), lds, idx->ctx->stream, a);
+    // persistent rows: as many waves as the chip holds at once (LDS and the register cap decide), each row fetching scans
+    // from the queue; VS_MX_PERSIST=0: one scan per row, (nq + 3) / 4 waves; VS_MX_GRID: number of waves (tests)
+    uint32_t grid = (a.s.nq + 3) / 4;
+    if (a.persist) {
+        const uint32_t per_cu = (uint32_t)std::min<size_t>((size_t)MINW * 4, (160 * 1024) / std::max<size_t>(lds, 1));
+        const uint32_t resident = (uint32_t)std::max(idx->ctx->prop.multiProcessorCount, 1) * std::max(per_cu, 1u);
+        grid = std::min(grid, resident);
+        const char* e = getenv("VS_MX_GRID");
+        if (e && *e) grid = std::max(1u, std::min(grid, (uint32_t)strtoul(e, nullptr, 10)));
+    }
+    hipLaunchKernelGGL((k_search_mx<NCH, VRR, GD, MINW>), dim3(grid), dim3(WAVE), lds, idx->ctx->stream, a);
     VS_HIP(hipGetLastError());
     return VS_OK;
 }
@@ -807,6 +867,11 @@ int launch_search_mx(vs_index* idx, const FastLaunch& s) {
     a.n_ls = idx->d.n_label_starts;
     a.default_start = idx->d.default_start;
     a.s = s;
+    {
+        const char* e = getenv("VS_MX_PERSIST");
+        a.persist = (e && *e == '0') ? 0u : 1u;
+        a.queue = s.pool_counter + 4;  // the 64-byte counter block is zeroed before every launch (vs_api.hip)
+    }
     const size_t lds = mx_lds_bytes(s);
     const uint32_t nch = (idx->code_stride + 7) / 8;
     switch (nch) {

@@ -31,6 +31,10 @@ CASES = {
                      {"VS_F_HL": "255"}, True),
     "deep_heap_14_levels": (dict(n=24000, dim_full=32, bits=2, R=50, distance=1, seed=4, kind="uniform", L_build=64), "uniform", 300, 300,
                             {}, True),
+    "scan_queue_two_waves": (dict(n=3000, dim_full=64, bits=2, R=32, distance=1, seed=11, kind="gauss", L_build=64, n_labels=6,
+                                  deleted_frac=0.15), "gauss", 100, 65, {"VS_MX_GRID": "2"}, True),
+    "one_scan_per_row": (dict(n=4000, dim_full=128, bits=2, R=50, distance=1, seed=1, kind="uniform", L_build=100), "uniform", 100, 65,
+                         {"VS_MX_PERSIST": "0"}, True),
     "pool_exhausted": (dict(n=3000, dim_full=64, bits=2, R=32, distance=1, seed=11, kind="gauss", L_build=64, n_labels=6,
                             deleted_frac=0.15), "gauss", 100, 65, {"VS_F_POOL": "0.01"}, False),
     "R80_not_covered": (dict(n=1500, dim_full=64, bits=2, R=80, distance=1, seed=9, kind="uniform", L_build=100), "uniform", 50, 40, {}, None),

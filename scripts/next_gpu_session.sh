@@ -16,6 +16,8 @@ done
 for HL in 255 511 1023; do for GD in 2 4; do
   VS_MX=1 VS_F_HL=$HL VS_MX_GD=$GD python bench.py --n 10000000 --distance cosine --fixed 100,100 --skip-cpu --scan-nq 0 --graph-cache /tmp/vs_graph 2>/dev/null | python -c "import sys,json; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('mx hl=$HL gd=$GD', j['value'], j['kernels']['search'])" | tee -a gpurun_out/s_mx_variants.txt
 done; done
+# ... and with one scan per row instead of the scan queue
+VS_MX=1 VS_MX_PERSIST=0 python bench.py --n 10000000 --distance cosine --fixed 100,100 --skip-cpu --scan-nq 0 --graph-cache /tmp/vs_graph 2>/dev/null | python -c "import sys,json; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('mx persist=0', j['value'], j['kernels']['search'])" | tee -a gpurun_out/s_mx_variants.txt
 for MX in 0 1; do
   VS_MX=$MX bash scripts/pmc_issue.sh 10000000 131072 100 100 /tmp/vs_graph 2>&1 | tail -30 | tee gpurun_out/s_pmc_issue_mx$MX.txt
   for p in A B; do mv gpurun_out/pmc_issue_$p.txt gpurun_out/s_pmc_issue_${p}_mx$MX.txt 2>/dev/null; done

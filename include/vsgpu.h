@@ -37,7 +37,8 @@ extern "C" {
 enum vs_distance_type { VS_COSINE = 0, VS_L2 = 1, VS_IP = 2 }; /* AM/distance/mod.rs:11-15 */
 /* memory_optimized (SbqSpeedupStorage: SBQ Hamming in the graph search + f32 rerank, the hot path of this library) or
  * plain (PlainStorage, AM/plain/storage.rs: the graph search scores candidates with the full-precision distance to the
- * vector stored in the node; no label filters; covered for num_dimensions_to_index == num_dimensions) */
+ * vector stored in the node (its index slice when num_dimensions_to_index < num_dimensions, then the rows are resorted on the
+ * full vectors); no label filters) */
 enum vs_storage_type { VS_STORAGE_SBQ = 0, VS_STORAGE_PLAIN = 1 };
 
 enum vs_status {

@@ -292,14 +292,14 @@ extern "C" void vs_index_free(vs_index* ix) {
     if (!ix) return;
     (void)hipSetDevice(ix->ctx->device);
     (void)hipStreamSynchronize(ix->ctx->stream);
-    void* ptrs[] = {ix->codes, ix->nbrs, ix->tids, ix->vecs, ix->vnorm, ix->mean, ix->m2,
+    void* ptrs[] = {ix->codes, ix->nbrs, ix->tids, ix->vecs, ix->vnorm, ix->vnorm_idx, ix->mean, ix->m2,
                     ix->label_off, ix->label_val, ix->ls_labels, ix->ls_nodes};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     SearchWorkspace& w = ix->ws;
     DevBuf* bufs[] = {&w.q_full, &w.qcodes, &w.qlabels, &w.qlabel_off, &w.hash, &w.heap_g, &w.heap_g4, &w.ghash4, &w.pool_ctr, &w.fb_flag, &w.phase, &w.stream_ids,
                       &w.stream_ham, &w.stream_cnt, &w.stats, &w.status, &w.rr_dist, &w.out_ids, &w.out_tids,
-                      &w.out_dist, &w.resort_heap, &w.raw_q, &w.misc};
+                      &w.out_dist, &w.resort_heap, &w.raw_q, &w.misc, &w.q_index};
     for (DevBuf* b : bufs) devbuf_free(*b);
     free(w.pend_blob);
     w.pend_blob = nullptr;
@@ -420,8 +420,7 @@ extern "C" int vs_index_upload(vs_ctx* c, const vs_index_desc* desc, const vs_in
     if (plain) {
         // PlainNode = vector + neighbor pointers + heap pointer (AM/plain/node.rs); no quantizer, no labels
         VS_REQUIRE(h->nbrs && h->heap_tids && h->vecs, "vs_index_upload: plain storage needs nbrs / heap_tids / vecs");
-        VS_REQUIRE(desc->dim_index == desc->dim_full,
-                   "plain storage with num_dimensions_to_index < num_dimensions (resort on the full vector) is not covered");
+        VS_REQUIRE(desc->dim_index <= desc->dim_full, "num_dimensions_to_index > num_dimensions");
         VS_REQUIRE(!desc->has_labels, "Plain storage does not support label filters");
     } else {
         VS_REQUIRE(h->codes && h->nbrs && h->heap_tids && h->mean, "vs_index_upload: codes/nbrs/heap_tids/mean required");
@@ -464,6 +463,18 @@ extern "C" int vs_index_upload(vs_ctx* c, const vs_index_desc* desc, const vs_in
                                           desc->n_label_starts))) break;
         if ((r = validate_graph(ix))) break;
         if ((r = vs_index_refresh_norms(ix))) break;
+        if (plain && desc->dim_index < desc->dim_full && desc->distance_type == VS_COSINE) {  // norms of the stored index slices
+            if (hipMalloc(&ix->vnorm_idx, (size_t)std::max<uint32_t>(desc->n, 1) * 4) != hipSuccess) {
+                vs_set_error("vs_index_upload: out of device memory");
+                r = VS_ERR_OOM;
+                break;
+            }
+            if ((r = launch_slice_norms(ix, ix->vnorm_idx))) break;
+            if (hipStreamSynchronize(c->stream) != hipSuccess) {
+                r = VS_ERR_HIP;
+                break;
+            }
+        }
     } while (0);
     if (r != VS_OK) {
         vs_index_free(ix);
@@ -826,6 +837,10 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
     {
         hipEvent_t ev = prof_begin(c);
         VS_TRY(launch_prepare_queries(ix, d_raw_q, nq, (float*)w.q_full.p, (uint64_t*)w.qcodes.p));
+        if (ix->d.storage_type == VS_STORAGE_PLAIN && ix->d.dim_index < ix->d.dim_full) {
+            VS_TRY(devbuf_reserve(c, w.q_index, (size_t)nq * ix->vec_stride * 4));
+            VS_TRY(launch_prepare_index_slice(ix, d_raw_q, nq, (float*)w.q_index.p));
+        }
         prof_end(c, PK_PREPARE, ev);
     }
     bool fast_done = false;
@@ -1058,7 +1073,8 @@ static int search_host(vs_index* ix, const float* queries, const int16_t* qlabel
     VS_REQUIRE(k >= 1, "k must be >= 1");
     if (ix->d.storage_type == VS_STORAGE_PLAIN) {
         VS_REQUIRE(!qlabel_off, "Plain storage does not support label filters");  // AM/plain/storage.rs:262
-        rescore = 0;  // amgettuple, Plain arm, num_dimensions == num_dimensions_to_index: "no need to resort" (AM/scan.rs:392-399)
+        // amgettuple, Plain arm: num_dimensions == num_dimensions_to_index => "no need to resort" (AM/scan.rs:392-399)
+        if (ix->d.dim_index == ix->d.dim_full) rescore = 0;
     }
     if (stats) memset(stats, 0, sizeof(*stats));
     if (nq == 0) return VS_OK;
@@ -1126,7 +1142,7 @@ extern "C" int vs_search_batch_dev(vs_index* ix, const float* d_queries, const i
     VS_REQUIRE(L >= 1 && L <= 10000 && rescore <= 1000 && k >= 1, "vs_search_batch_dev: GUC out of range");
     if (ix->d.storage_type == VS_STORAGE_PLAIN) {
         VS_REQUIRE(!d_qlabel_off, "Plain storage does not support label filters");
-        rescore = 0;
+        if (ix->d.dim_index == ix->d.dim_full) rescore = 0;
     }
     SearchWorkspace& w = ix->ws;
     w.pending = false;

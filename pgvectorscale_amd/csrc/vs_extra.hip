@@ -217,6 +217,14 @@ __global__ __launch_bounds__(WAVE) void k_slice_norms(const float* __restrict__ 
     }
 }
 
+int launch_slice_norms(vs_index* ix, float* d_out) {
+    if (ix->d.n == 0) return VS_OK;
+    const uint32_t blocks = std::min<uint32_t>((ix->d.n + 63) / 64, 8192);
+    hipLaunchKernelGGL(k_slice_norms, dim3(blocks), dim3(WAVE), 0, ix->ctx->stream, ix->vecs, ix->vec_stride, ix->d.dim_index, ix->d.n, d_out);
+    VS_HIP(hipGetLastError());
+    return VS_OK;
+}
+
 // the divisor array to use for the *index slice* of each heap vector, or nullptr when no normalisation applies
 static int index_slice_norms(vs_index* ix, float** out, bool* owned) {
     *out = nullptr;

@@ -72,7 +72,7 @@ struct DevBuf {
 
 struct SearchWorkspace {
     DevBuf q_full, qcodes, qlabels, qlabel_off, hash, heap_g, heap_g4, ghash4, pool_ctr, fb_flag, phase, stream_ids, stream_ham, stream_cnt, stats, status,
-        rr_dist, out_ids, out_tids, out_dist, resort_heap, raw_q, misc;
+        rr_dist, out_ids, out_tids, out_dist, resort_heap, raw_q, misc, q_index;
     // pending async call (vs_search_batch_dev)
     bool fb_valid = false;  // fb_flag holds the fallback marks of the last chunk
     bool pending = false;
@@ -101,6 +101,7 @@ struct vs_index {
     uint64_t* tids = nullptr;
     float* vecs = nullptr;
     float* vnorm = nullptr;  // per node: 0 => leave vector alone, else divisor sqrt(norm) (preprocess_cosine)
+    float* vnorm_idx = nullptr;  // the same for the index slice (plain storage, cosine, num_dimensions_to_index < num_dimensions)
     float* mean = nullptr;
     float* m2 = nullptr;
     uint64_t count = 0;
@@ -194,6 +195,8 @@ int launch_resort(vs_index* idx, uint32_t nq, uint32_t M, uint32_t rescore, uint
                   const uint32_t* d_cnt, const float* d_dist, uint64_t* d_heap_ws, uint32_t* d_out_ids,
                   uint64_t* d_out_tids, float* d_out_dist);
 int launch_row_norms(vs_index* idx);
+int launch_slice_norms(vs_index* idx, float* d_out);  // divisor of the first dim_index dims of every heap vector
+int launch_prepare_index_slice(vs_index* idx, const float* d_raw, uint32_t nq, float* d_q_index);
 int launch_validate_nbrs(vs_index* idx, uint32_t* d_flag);
 int launch_scan_topk(vs_index* idx, const uint64_t* d_qcodes, uint32_t nq, uint32_t k, uint32_t* d_out_ids,
                      uint32_t* d_out_ham);

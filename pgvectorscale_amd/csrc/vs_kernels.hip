@@ -115,6 +115,23 @@ __global__ __launch_bounds__(WAVE) void k_prepare_queries(const float* __restric
                   code_stride, lane);
 }
 
+// plain storage with num_dimensions_to_index < num_dimensions: the graph search compares the INDEX slice of the query,
+// cosine-normalised on its own (PgVector::from_datum, AM/pg_vector.rs:143-157), with the stored index-slice vectors
+__global__ __launch_bounds__(WAVE) void k_prepare_index_slice(const float* __restrict__ raw, uint32_t nq, uint32_t dim_full,
+                                                              uint32_t dim_index, uint32_t vec_stride, uint32_t distance_type,
+                                                              float* __restrict__ q_index) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* idxv = reinterpret_cast<float*>(smem);
+    float* bc = idxv + round_up_u32(dim_index, 4);
+    const int lane = threadIdx.x;
+    const uint32_t q = blockIdx.x;
+    if (q >= nq) return;
+    for (uint32_t i = lane; i < dim_index; i += WAVE) idxv[i] = raw[(size_t)q * dim_full + i];
+    __syncthreads();
+    if (distance_type == VS_COSINE) lds_preprocess_cosine(idxv, dim_index, lane, bc);
+    for (uint32_t i = lane; i < vec_stride; i += WAVE) q_index[(size_t)q * vec_stride + i] = i < dim_index ? idxv[i] : 0.0f;
+}
+
 // K4b: quantize rows that are already prepared (normalised if cosine): one wave per row.
 __global__ __launch_bounds__(WAVE) void k_quantize_rows(const float* __restrict__ rows, uint32_t row_stride,
                                                         uint32_t nrows, uint32_t dims, uint32_t bits,
@@ -421,6 +438,16 @@ int launch_prepare_queries(vs_index* idx, const float* d_raw, uint32_t nq, float
     return VS_OK;
 }
 
+int launch_prepare_index_slice(vs_index* idx, const float* d_raw, uint32_t nq, float* d_q_index) {
+    if (nq == 0) return VS_OK;
+    const vs_index_desc& d = idx->d;
+    const size_t lds = (round_up_u32(d.dim_index, 4) + 4) * sizeof(float);
+    hipLaunchKernelGGL(k_prepare_index_slice, dim3(nq), dim3(WAVE), lds, idx->ctx->stream, d_raw, nq, d.dim_full, d.dim_index,
+                       idx->vec_stride, d.distance_type, d_q_index);
+    VS_HIP(hipGetLastError());
+    return VS_OK;
+}
+
 int launch_quantize_rows(vs_index* idx, const float* d_rows, uint32_t row_stride, uint32_t nrows, uint64_t* d_codes,
                          uint32_t code_stride) {
     if (nrows == 0) return VS_OK;
@@ -458,7 +485,9 @@ int launch_resort(vs_index* idx, uint32_t nq, uint32_t M, uint32_t rescore, uint
                   const uint32_t* d_cnt, const float* d_dist, uint64_t* d_heap_ws, uint32_t* d_out_ids,
                   uint64_t* d_out_tids, float* d_out_dist) {
     if (nq == 0) return VS_OK;
-    const uint32_t* plain_keys = idx->d.storage_type == VS_STORAGE_PLAIN ? (const uint32_t*)idx->ws.stream_ham.p : nullptr;
+    // plain storage without truncation: the graph distance IS the full-precision distance (no resort, AM/scan.rs:392-399)
+    const uint32_t* plain_keys = (idx->d.storage_type == VS_STORAGE_PLAIN && idx->d.dim_index == idx->d.dim_full)
+                                     ? (const uint32_t*)idx->ws.stream_ham.p : nullptr;
     hipLaunchKernelGGL(k_resort, dim3((nq + 63) / 64), dim3(64), 0, idx->ctx->stream, nq, M, rescore, k, d_stream_ids,
                        d_cnt, d_dist, idx->tids, d_heap_ws, d_out_ids, d_out_tids, d_out_dist, plain_keys);
     VS_HIP(hipGetLastError());

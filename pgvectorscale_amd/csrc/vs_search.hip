@@ -599,8 +599,9 @@ int launch_search(vs_index* idx, const SearchLaunch& s, bool build_mode) {
     a.default_start = idx->d.default_start;
     const bool plain = idx->d.storage_type == VS_STORAGE_PLAIN;
     a.vecs = idx->vecs;
-    a.vnorm = idx->vnorm;
-    a.q_full = (const float*)idx->ws.q_full.p;
+    const bool truncated = plain && idx->d.dim_index < idx->d.dim_full;  // index slice: its own norm cache / prepared query
+    a.vnorm = truncated ? idx->vnorm_idx : idx->vnorm;
+    a.q_full = (const float*)(truncated ? idx->ws.q_index.p : idx->ws.q_full.p);
     a.vec_stride = idx->vec_stride;
     a.dim = idx->d.dim_index;
     a.distance_type = idx->d.distance_type;

@@ -103,7 +103,7 @@ class DiskAnnIndex:
                distance_type, default_start, label_off=None, label_val=None, label_starts=None, storage_type=_lib.VS_STORAGE_SBQ):
         if storage_type == _lib.VS_STORAGE_PLAIN:
             return cls._upload_plain(ctx, nbrs=nbrs, heap_tids=heap_tids, vecs=vecs, num_neighbors=num_neighbors,
-                                     distance_type=distance_type, default_start=default_start)
+                                     distance_type=distance_type, default_start=default_start, dim_index=dim_index)
         codes = np.ascontiguousarray(codes, np.uint64)
         nbrs = np.ascontiguousarray(nbrs, np.uint32)
         heap_tids = np.ascontiguousarray(heap_tids, np.uint64)
@@ -139,14 +139,14 @@ class DiskAnnIndex:
         return cls(ctx, out)
 
     @classmethod
-    def _upload_plain(cls, ctx, *, nbrs, heap_tids, vecs, num_neighbors, distance_type, default_start):
+    def _upload_plain(cls, ctx, *, nbrs, heap_tids, vecs, num_neighbors, distance_type, default_start, dim_index=None):
         """A `plain` storage index (AM/plain/storage.rs): vectors + neighbor lists, no SBQ codes."""
         nbrs = np.ascontiguousarray(nbrs, np.uint32)
         heap_tids = np.ascontiguousarray(heap_tids, np.uint64)
         vecs = np.ascontiguousarray(vecs, np.float32)
         d = IndexDesc()
-        d.n, d.dim_full, d.dim_index = vecs.shape[0], vecs.shape[1], vecs.shape[1]
-        d.bits, d.words = 1, quantized_size(vecs.shape[1], 1)
+        d.n, d.dim_full, d.dim_index = vecs.shape[0], vecs.shape[1], dim_index or vecs.shape[1]
+        d.bits, d.words = 1, quantized_size(d.dim_index, 1)
         d.num_neighbors, d.distance_type, d.has_labels = num_neighbors, distance_type, 0
         d.default_start, d.n_label_starts, d.storage_type = default_start, 0, _lib.VS_STORAGE_PLAIN
         h = IndexHost()

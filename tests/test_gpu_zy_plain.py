@@ -11,7 +11,7 @@ pytestmark = [pytest.mark.gpu, pytest.mark.timeout(900)]
 
 
 class PlainIndex:
-    def __init__(self, n, dim, R, distance, seed, kind, deleted_frac=0.0):
+    def __init__(self, n, dim, R, distance, seed, kind, deleted_frac=0.0, dim_index=None):
         self.vecs = make_vectors(n, dim, seed, kind)
         if kind == "gauss":
             self.vecs *= np.random.default_rng(seed).uniform(0.2, 3.0, (n, 1)).astype(np.float32)  # un-normalised rows
@@ -23,16 +23,19 @@ class PlainIndex:
         self.tids = ((np.arange(n, dtype=np.uint64) + 11) << np.uint64(16)) | np.uint64(1)
         if deleted_frac:
             self.tids[np.random.default_rng(seed + 1).random(n) < deleted_frac] &= ~np.uint64(0xFFFF)
-        self.n, self.dim, self.R, self.distance = n, dim, R, distance
+        self.n, self.dim, self.R, self.distance, self.dim_index = n, dim, R, distance, dim_index or dim
+        if self.dim_index != dim:  # the oracle derives its code width from dim_index
+            mean, m2, cnt = O.train(np.ascontiguousarray(self.vecs[:, :self.dim_index]), 2)
+            codes = O.quantize(mean, m2, cnt, 2, np.ascontiguousarray(self.vecs[:, :self.dim_index]))
         self.oracle = O.OracleIndex(codes=codes, nbrs=self.nbrs, heap_tids=self.tids, vecs=self.vecs, mean=mean, m2=m2, count=cnt,
-                                    bits=2, dim_index=dim, num_neighbors=R, distance_type=distance, default_start=self.start,
-                                    storage_plain=True)
+                                    bits=2, dim_index=self.dim_index, num_neighbors=R, distance_type=distance,
+                                    default_start=self.start, storage_plain=True)
 
     def upload(self, ctx):
         import pgvectorscale_amd as P
         from pgvectorscale_amd import _lib
         return P.DiskAnnIndex.upload(ctx, codes=None, nbrs=self.nbrs, heap_tids=self.tids, vecs=self.vecs, mean=None, m2=None,
-                                     count=0, bits=None, dim_index=self.dim, num_neighbors=self.R, distance_type=self.distance,
+                                     count=0, bits=None, dim_index=self.dim_index, num_neighbors=self.R, distance_type=self.distance,
                                      default_start=self.start, storage_type=_lib.VS_STORAGE_PLAIN)
 
 
@@ -81,4 +84,19 @@ def test_plain_storage_rows_match_the_oracle(gpu_ctx, oracle, dim, R, distance, 
     import pgvectorscale_amd as P
     with pytest.raises(P.VsError, match="label"):
         ix.search_batch(q[:2], search_list_size=L, rescore=0, k=5, qlabels=[[1], [2]])
+    ix.close()
+
+
+@pytest.mark.parametrize("distance", [O.COSINE, O.L2])
+def test_plain_storage_with_truncated_index_dimensions(gpu_ctx, oracle, distance):
+    """num_dimensions_to_index < num_dimensions: the graph search compares index slices (normalised on their own for cosine),
+    then the rows are resorted on the full vectors like an SBQ scan (amgettuple, Plain arm, AM/scan.rs:392-401)."""
+    pi = PlainIndex(n=1000, dim=96, R=24, distance=distance, seed=5, kind="gauss", deleted_frac=0.1, dim_index=64)
+    ix = pi.upload(gpu_ctx)
+    q = make_vectors(32, 96, 3, "gauss")
+    gi, gt, gd, gst = ix.search_batch(q, search_list_size=30, rescore=15, k=12)
+    oi, od, ost = pi.oracle.search_batch(q, L=30, rescore=15, k=12)
+    assert (gi == oi).all() and (gd.view(np.uint32) == od.view(np.uint32)).all()
+    for key in ("visited_nodes", "candidate_nodes", "full_distance_comparisons", "node_reads"):
+        assert gst[key] == ost[key], key
     ix.close()

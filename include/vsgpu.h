@@ -223,8 +223,9 @@ int vs_pages_block_table(const vs_pages* p, const uint32_t** blk_base, const uin
 
 /* The same, decoded ON the device (vs_pages_dev.hip): the blocks are copied to HBM as they are (pinned ring,
  * hipMemcpyAsync), the host only reads the page headers on the way past, and one kernel (a wave per node page) walks the
- * line pointers and rkyv relative pointers and writes codes / neighbor ids / heap tids into the index arrays.  Unlabeled
- * memory_optimized indexes.  n_blocks_total = RelationGetNumberOfBlocks (the raw pages stay in HBM until the build). */
+ * line pointers and rkyv relative pointers and writes codes / neighbor ids / heap tids into the index arrays; label sets
+ * (desc->has_labels, LabeledSbqNode) take a count pass and a copy pass over the same staged pages.  memory_optimized
+ * indexes.  layout NULL = the default layout for desc->has_labels.  n_blocks_total = RelationGetNumberOfBlocks (the raw pages stay in HBM until the build). */
 typedef struct vs_pages_dev vs_pages_dev;
 int vs_pages_dev_open(vs_ctx* ctx, uint32_t page_size, const vs_node_layout* layout, uint32_t n_blocks_total, vs_pages_dev** out);
 int vs_pages_dev_add(vs_pages_dev* d, uint32_t first_block, const void* pages, uint32_t n_blocks); /* in block order */
@@ -232,7 +233,7 @@ int vs_pages_dev_node_of(const vs_pages_dev* d, uint32_t block, uint32_t offset,
 int vs_pages_dev_sbq_means(const vs_pages_dev* d, uint32_t block, uint32_t offset, float* mean, float* m2, uint32_t dim_cap,
                            uint32_t* dim, uint64_t* count);
 /* desc: the MetaPage fields (n is taken from the pages, default_start is a node id from vs_pages_dev_node_of);
- * extras: vecs / mean / m2 / count (+ label start arrays unused: unlabeled); frees the raw pages */
+ * extras: vecs / mean / m2 / count / label_start_labels / label_start_nodes (node ids); frees the raw pages */
 int vs_pages_dev_build(vs_pages_dev* d, const vs_index_desc* desc, const vs_index_host* extras, vs_pages_info* info, vs_index** out);
 void vs_pages_dev_close(vs_pages_dev* d);
 

@@ -7,8 +7,9 @@
 // line pointers, follows the rkyv relative pointers of every archived node (same layout facts and the same bounds checks
 // as the host reader, vs_pages.cpp) and writes codes / neighbor ids / heap tids straight into the index arrays, neighbor
 // IndexPointers translated through the block table.  33 GB of pages for a 50M-node index is 0.6 s of PCIe instead of
-// tens of seconds of host decoding.  Unlabeled (ClassicSbqNode) indexes; labeled ones take the host reader.
+// tens of seconds of host decoding.  Label sets (LabeledSbqNode) take two more passes over the staged pages: count, then copy.
 #include <algorithm>
+#include <vector>
 
 #include "vs_device.h"
 
@@ -19,10 +20,11 @@ struct vs_pages_dev {
     uint32_t page_size = VS_BLCKSZ;
     uint32_t cap_blocks = 0, n_blocks = 0;
     vs_node_layout lay{};
+    bool layout_given = false;
 };
 
 enum { PE_OK = 0, PE_LINE_POINTER = 1, PE_ITEM_BOUNDS = 2, PE_SHORT_ITEM = 3, PE_VEC_BOUNDS = 4, PE_CODE_WIDTH = 5, PE_NEIGHBOR_SLOTS = 6,
-       PE_DANGLING = 7 };
+       PE_DANGLING = 7, PE_LABELS = 8 };
 
 __device__ __forceinline__ uint32_t ld16(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
 __device__ __forceinline__ uint32_t ld32(const uint8_t* p) {  // items are MAXALIGNed: 4-byte aligned words
@@ -127,6 +129,45 @@ __global__ __launch_bounds__(WAVE) void k_pages_decode(const uint8_t* __restrict
     }
 }
 
+// LabeledSbqNode.labels (ArchivedLabelSet = ArchivedVec<i16>, sorted and de-duplicated, AM/labels/mod.rs:15-37): WRITE = false
+// counts the labels of every node (and checks them), WRITE = true copies them to label_val[label_off[node] ..].  The items
+// were located and bounds-checked by k_pages_decode before.
+template <bool WRITE>
+__global__ __launch_bounds__(WAVE) void k_pages_labels(const uint8_t* __restrict__ pages, uint32_t page_size, uint32_t n_blocks,
+                                                       const uint32_t* __restrict__ blk_base, const uint32_t* __restrict__ blk_cnt,
+                                                       vs_node_layout lay, uint32_t* __restrict__ label_cnt,
+                                                       const uint32_t* __restrict__ label_off, int16_t* __restrict__ label_val,
+                                                       uint32_t* __restrict__ err) {
+    const int lane = threadIdx.x;
+    for (uint32_t b = blockIdx.x; b < n_blocks; b += gridDim.x) {
+        const uint32_t cnt = blk_cnt[b];
+        if (cnt == 0) continue;
+        const uint8_t* page = pages + (size_t)b * page_size;
+        for (uint32_t off = 1; off <= cnt; ++off) {
+            const uint32_t node = blk_base[b] + off - 1;
+            const uint32_t lp = ld32(page + 24 + 4 * (off - 1));
+            const uint32_t lp_off = lp & 0x7FFFu, len = lp >> 17;
+            const uint8_t* item = page + lp_off;
+            const uint32_t fld = len - lay.root_size + lay.off_labels;
+            const int64_t tgt = (int64_t)fld + (int32_t)ld32(item + fld);
+            const uint32_t n = ld32(item + fld + 4);
+            if (n && (tgt < 0 || (uint64_t)tgt + (uint64_t)n * 2 > len || (tgt & 1))) {
+                if (lane == 0) page_error(err, PE_VEC_BOUNDS, b, off, fld);
+                if (!WRITE && lane == 0) label_cnt[node] = 0;
+                continue;
+            }
+            if (!WRITE) {
+                for (uint32_t j = 1 + (uint32_t)lane; j < n; j += WAVE)
+                    if ((int16_t)ld16(item + tgt + 2 * j) <= (int16_t)ld16(item + tgt + 2 * j - 2)) page_error(err, PE_LABELS, b, off, j);
+                if (lane == 0) label_cnt[node] = n;
+            } else {
+                const uint32_t o = label_off[node];
+                for (uint32_t j = lane; j < n; j += WAVE) label_val[o + j] = (int16_t)ld16(item + tgt + 2 * j);
+            }
+        }
+    }
+}
+
 extern "C" int vs_pages_dev_open(vs_ctx* ctx, uint32_t page_size, const vs_node_layout* layout, uint32_t n_blocks_total,
                                  vs_pages_dev** out) {
     VS_REQUIRE(ctx && out, "vs_pages_dev_open: bad args");
@@ -141,6 +182,7 @@ extern "C" int vs_pages_dev_open(vs_ctx* ctx, uint32_t page_size, const vs_node_
         delete d;
         return r;
     }
+    d->layout_given = layout != nullptr;
     if (layout) d->lay = *layout;
     else vs_node_layout_default(0, &d->lay);
     d->cap_blocks = std::max<uint32_t>(n_blocks_total, 1);
@@ -190,7 +232,9 @@ extern "C" int vs_pages_dev_build(vs_pages_dev* d, const vs_index_desc* desc, co
                                   vs_index** out) {
     VS_REQUIRE(d && desc && extras && out, "vs_pages_dev_build: bad args");
     VS_REQUIRE(d->d_pages, "vs_pages_dev_build: already built");
-    VS_REQUIRE(!desc->has_labels, "vs_pages_dev_build: labeled indexes (LabeledSbqNode) take the host reader (vs_pages_*)");
+    if (!d->layout_given) vs_node_layout_default(desc->has_labels ? 1 : 0, &d->lay);
+    VS_REQUIRE(!desc->has_labels || (d->lay.off_labels <= d->lay.root_size && d->lay.root_size - d->lay.off_labels >= 8),
+               "vs_pages_dev_build: the node layout has no labels field");
     VS_REQUIRE(desc->storage_type == VS_STORAGE_SBQ, "vs_pages_dev_build: memory_optimized (SBQ) indexes only");
     *out = nullptr;
     vs_pages_info pi{};
@@ -232,6 +276,46 @@ extern "C" int vs_pages_dev_build(vs_pages_dev* d, const vs_index_desc* desc, co
             hip_ok(hipStreamSynchronize(c->stream), "k_pages_decode");
         }
     }
+    // labels: count per node, prefix sum on the host (4 bytes per node), then the values
+    if (r == VS_OK && herr[0] == PE_OK && desc->has_labels && pi.n_nodes > 0) {
+        const uint32_t n = pi.n_nodes;
+        const uint32_t grid = std::min<uint32_t>(nb, 1u << 20);
+        uint32_t* d_lcnt = nullptr;
+        hip_ok(hipMalloc(&d_lcnt, (size_t)n * 4), "label counts");
+        if (r == VS_OK) {
+            hipLaunchKernelGGL((k_pages_labels<false>), dim3(grid), dim3(WAVE), 0, c->stream, d->d_pages, d->page_size, nb, d_base, d_cnt,
+                               d->lay, d_lcnt, (const uint32_t*)nullptr, (int16_t*)nullptr, d_err);
+            hip_ok(hipGetLastError(), "k_pages_labels");
+        }
+        std::vector<uint32_t> off((size_t)n + 1, 0);
+        if (r == VS_OK) r = vs_dev_download(c, off.data() + 1, d_lcnt, (size_t)n * 4);
+        if (r == VS_OK) hip_ok(hipMemcpy(herr, d_err, 16, hipMemcpyDeviceToHost), "error record");
+        if (d_lcnt) (void)hipFree(d_lcnt);
+        if (r == VS_OK && herr[0] == PE_OK) {
+            uint64_t tot = 0;
+            for (uint32_t i = 0; i < n; ++i) {
+                tot += off[i + 1];
+                off[i + 1] = (uint32_t)tot;
+            }
+            if (tot >= 0xFFFFFFFFull) {
+                vs_set_error("label CSR exceeds 2^32 entries");
+                r = VS_ERR_INVALID;
+            }
+            if (r == VS_OK) {
+                hip_ok(hipMalloc(&ix->label_off, ((size_t)n + 1) * 4), "label offsets");
+                hip_ok(hipMalloc(&ix->label_val, std::max<uint64_t>(tot, 1) * 2), "label values");
+            }
+            if (r == VS_OK) r = vs_dev_upload(c, ix->label_off, off.data(), ((size_t)n + 1) * 4);
+            if (r == VS_OK) {
+                hipLaunchKernelGGL((k_pages_labels<true>), dim3(grid), dim3(WAVE), 0, c->stream, d->d_pages, d->page_size, nb, d_base,
+                                   d_cnt, d->lay, (uint32_t*)nullptr, (const uint32_t*)ix->label_off, ix->label_val, d_err);
+                hip_ok(hipGetLastError(), "k_pages_labels");
+                hip_ok(hipStreamSynchronize(c->stream), "k_pages_labels");
+                ix->n_label_vals = tot;
+                ix->d.has_labels = 1;
+            }
+        }
+    }
     if (d_base) (void)hipFree(d_base);
     if (d_cnt) (void)hipFree(d_cnt);
     if (d_err) (void)hipFree(d_err);
@@ -240,8 +324,9 @@ extern "C" int vs_pages_dev_build(vs_pages_dev* d, const vs_index_desc* desc, co
                                      "item shorter than the archived node", "ArchivedVec points outside the item",
                                      "bq_vector length differs from the index's code width",
                                      "neighbor slot count differs from the index's num_neighbors",
-                                     "neighbor points at something that is not an SbqNode item of this relation"};
-        vs_set_error("block %u item %u: %s (detail %u)", herr[1], herr[2], what[herr[0] <= PE_DANGLING ? herr[0] : 0], herr[3]);
+                                     "neighbor points at something that is not an SbqNode item of this relation",
+                                     "label set is not strictly increasing"};
+        vs_set_error("block %u item %u: %s (detail %u)", herr[1], herr[2], what[herr[0] <= PE_LABELS ? herr[0] : 0], herr[3]);
         r = VS_ERR_INVALID;
     }
     // the raw pages are no longer needed

@@ -164,7 +164,7 @@ class IndexPages:
 
 class DevicePages:
     """The same relation, decoded on the device (vs_pages_dev_*): blocks are copied to HBM as they are, a kernel decodes
-    the SbqNode items into the index arrays.  Unlabeled memory_optimized indexes."""
+    the SbqNode items (label sets included) into the index arrays.  memory_optimized indexes."""
 
     def __init__(self, ctx, n_blocks_total, page_size=BLCKSZ, layout=None):
         self.ctx = ctx
@@ -201,8 +201,9 @@ class DevicePages:
         return int(cnt.value), mean, m2
 
     def build(self, *, words, num_neighbors, dim_index, bits, distance_type, default_start, quantizer_metadata=None, mean=None,
-              m2=None, count=0, vecs=None):
-        """default_start: IndexPointer (block, offset) or node id; quantizer_metadata: IndexPointer of the SbqMeans chain."""
+              m2=None, count=0, vecs=None, has_labels=False, label_starts=None):
+        """default_start / label_starts values: IndexPointer (block, offset) or node id; quantizer_metadata: IndexPointer of
+        the SbqMeans chain."""
         from .index import DiskAnnIndex
         if quantizer_metadata is not None:
             count, mean, m2 = self.sbq_means(*quantizer_metadata)
@@ -212,10 +213,18 @@ class DevicePages:
         d = IndexDesc()
         d.dim_index, d.bits, d.words, d.num_neighbors = dim_index, bits, words, num_neighbors
         d.dim_full = dim_index if vecs is None else vecs.shape[1]
-        d.distance_type, d.has_labels, d.n_label_starts, d.storage_type = distance_type, 0, 0, 0
-        d.default_start = (_lib.VS_INVALID_NODE if default_start is None
-                           else self.node_of(*default_start) if isinstance(default_start, tuple) else int(default_start))
+
+        def node(x):
+            return self.node_of(*x) if isinstance(x, tuple) else int(x)
+
+        ls = sorted((int(k), node(v)) for k, v in (label_starts or {}).items())
+        lsl = np.array([k for k, _ in ls], np.int16)
+        lsn = np.array([v for _, v in ls], np.uint32)
+        d.distance_type, d.has_labels, d.n_label_starts, d.storage_type = distance_type, int(bool(has_labels)), len(ls), 0
+        d.default_start = _lib.VS_INVALID_NODE if default_start is None else node(default_start)
         h = IndexHost()
+        h.label_start_labels = lsl.ctypes.data if ls else None
+        h.label_start_nodes = lsn.ctypes.data if ls else None
         h.vecs = None if vecs is None else vecs.ctypes.data
         h.mean = mean.ctypes.data
         h.m2 = None if m2 is None else m2.ctypes.data

@@ -261,16 +261,9 @@ static int check_desc(const vs_index_desc* d) {
     return VS_OK;
 }
 
-static int index_alloc_common(vs_ctx* c, const vs_index_desc* desc, bool with_vecs, vs_index** out) {
-    VS_REQUIRE(c && out, "index alloc: bad args");
-    VS_TRY(check_desc(desc));
-    VS_HIP(hipSetDevice(c->device));
-    vs_index* ix = new vs_index();
-    ix->ctx = c;
-    ix->d = *desc;
-    ix->code_stride = round_up_u32(desc->words, 2);
-    ix->nbr_stride = round_up_u32(desc->num_neighbors, 16);
-    ix->vec_stride = round_up_u32(desc->dim_full, 4);
+extern "C" void vs_index_free(vs_index* ix);
+
+static int index_alloc_arrays(vs_ctx* c, const vs_index_desc* desc, bool with_vecs, vs_index* ix) {
     const size_t n = std::max<uint32_t>(desc->n, 1);
     VS_HIP(hipMalloc(&ix->codes, n * ix->code_stride * sizeof(uint64_t)));
     VS_HIP(hipMalloc(&ix->nbrs, n * ix->nbr_stride * sizeof(uint32_t)));
@@ -283,6 +276,25 @@ static int index_alloc_common(vs_ctx* c, const vs_index_desc* desc, bool with_ve
         VS_HIP(hipMalloc(&ix->vecs, n * ix->vec_stride * sizeof(float)));
         VS_HIP(hipMalloc(&ix->vnorm, n * sizeof(float)));
         VS_HIP(hipMemsetAsync(ix->vnorm, 0, n * sizeof(float), c->stream));
+    }
+    return VS_OK;
+}
+
+static int index_alloc_common(vs_ctx* c, const vs_index_desc* desc, bool with_vecs, vs_index** out) {
+    VS_REQUIRE(c && out, "index alloc: bad args");
+    *out = nullptr;
+    VS_TRY(check_desc(desc));
+    VS_HIP(hipSetDevice(c->device));
+    vs_index* ix = new vs_index();
+    ix->ctx = c;
+    ix->d = *desc;
+    ix->code_stride = round_up_u32(desc->words, 2);
+    ix->nbr_stride = round_up_u32(desc->num_neighbors, 16);
+    ix->vec_stride = round_up_u32(desc->dim_full, 4);
+    const int r = index_alloc_arrays(c, desc, with_vecs, ix);
+    if (r != VS_OK) {  // a 150 GB vector array that does not fit must not leave the other arrays behind
+        vs_index_free(ix);
+        return r;
     }
     *out = ix;
     return VS_OK;
@@ -306,9 +318,7 @@ extern "C" void vs_index_free(vs_index* ix) {
     delete ix;
 }
 
-extern "C" int vs_index_alloc(vs_ctx* c, const vs_index_desc* desc, int with_vecs, vs_index** out) {
-    VS_TRY(index_alloc_common(c, desc, with_vecs != 0, out));
-    vs_index* ix = *out;
+static int index_alloc_fill(vs_ctx* c, const vs_index_desc* desc, vs_index* ix) {
     // empty graph, live tuples with tid = (node<<16)|1 until told otherwise
     VS_HIP(hipMemsetAsync(ix->nbrs, 0xFF, (size_t)std::max<uint32_t>(desc->n, 1) * ix->nbr_stride * 4, c->stream));
     VS_HIP(hipMemsetAsync(ix->codes, 0, (size_t)std::max<uint32_t>(desc->n, 1) * ix->code_stride * 8, c->stream));
@@ -317,6 +327,16 @@ extern "C" int vs_index_alloc(vs_ctx* c, const vs_index_desc* desc, int with_vec
     VS_TRY(vs_dev_upload(c, ix->tids, t.data(), t.size() * 8));
     VS_HIP(hipStreamSynchronize(c->stream));
     return VS_OK;
+}
+
+extern "C" int vs_index_alloc(vs_ctx* c, const vs_index_desc* desc, int with_vecs, vs_index** out) {
+    VS_TRY(index_alloc_common(c, desc, with_vecs != 0, out));
+    const int r = index_alloc_fill(c, desc, *out);
+    if (r != VS_OK) {
+        vs_index_free(*out);
+        *out = nullptr;
+    }
+    return r;
 }
 
 extern "C" int vs_index_set_quantizer(vs_index* ix, const float* mean, const float* m2, uint64_t count) {
@@ -389,8 +409,12 @@ extern "C" int vs_index_refresh_norms(vs_index* ix) {
 static int validate_graph(vs_index* ix) {
     uint32_t* d_flag = nullptr;
     VS_HIP(hipMalloc(&d_flag, 4));
-    VS_HIP(hipMemsetAsync(d_flag, 0, 4, ix->ctx->stream));
-    int r = launch_validate_nbrs(ix, d_flag);
+    int r = VS_OK;
+    if (hipMemsetAsync(d_flag, 0, 4, ix->ctx->stream) != hipSuccess) {
+        vs_set_error("validate_graph: hipMemsetAsync failed");
+        r = VS_ERR_HIP;
+    }
+    if (r == VS_OK) r = launch_validate_nbrs(ix, d_flag);
     uint32_t flag = 0;
     if (r == VS_OK) {
         hipError_t e = hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, ix->ctx->stream);

@@ -112,7 +112,13 @@ extern "C" int vs_datagen_fill(vs_ctx* c, const vs_datagen_params* p, uint64_t f
     VS_HIP(hipSetDevice(c->device));
     int16_t *proj = nullptr, *centers = nullptr;
     VS_HIP(hipMalloc(&proj, (size_t)p->latent_dim * p->dim * 2));
-    VS_HIP(hipMalloc(&centers, (size_t)p->n_clusters * p->latent_dim * 2));
+    {
+        hipError_t ea = hipMalloc(&centers, (size_t)p->n_clusters * p->latent_dim * 2);
+        if (ea != hipSuccess) {
+            (void)hipFree(proj);
+            VS_HIP(ea);
+        }
+    }
     uint32_t tmax = std::max(p->latent_dim * p->dim, p->n_clusters * p->latent_dim);
     hipLaunchKernelGGL(k_dg_tables, dim3((tmax + 255) / 256), dim3(256), 0, c->stream, p->seed, p->dim, p->latent_dim,
                        p->n_clusters, proj, centers);

@@ -174,6 +174,36 @@ def choose_operating_point(run_sample, k, target, sweep_log, err_type=Exception)
     return L, S, tried[(L, S)][0]
 
 
+def supervised_run(argv, try_mx_possible):
+    """N = 1: the run proper happens in a child process.  k_search_mx has never run on hardware with this corpus size
+    before its A/B arm does (the canary is a smaller instance); if the child dies or hangs there, the run is repeated
+    once with the exploration off (VS_BENCH_NO_MX=1: k_search_fast, the kernel profiles/ was measured on) instead of
+    leaving the round without a bench line.  Returns None when this process should run the benchmark itself."""
+    import subprocess
+    if (int(os.environ.get("WORLD_SIZE", "1")) != 1 or not try_mx_possible or os.environ.get("VS_BENCH_CHILD")
+            or os.environ.get("VS_BENCH_CANARY") or os.environ.get("VS_BENCH_INPROC") or os.environ.get("VS_BENCH_NO_MX")
+            or "VS_MX" in os.environ or any(k_.startswith(("ROCP_", "ROCPROF")) for k_ in os.environ)):  # under a profiler: one process
+        return None
+    limit = float(os.environ.get("VS_BENCH_CHILD_TIMEOUT", "2700"))
+    why = None
+    for attempt in (0, 1):
+        env = dict(os.environ, VS_BENCH_CHILD="1")
+        if attempt == 1:
+            env.update(VS_BENCH_NO_MX="1", VS_BENCH_FIRST_ATTEMPT=why)
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), *argv], env=env, stdout=subprocess.PIPE, text=True,
+                               timeout=limit)
+            line = next((ln for ln in reversed(r.stdout.strip().splitlines()) if ln.startswith("{")), None)
+            if r.returncode == 0 and line is not None:
+                print(line, flush=True)
+                return 0
+            why = f"exit code {r.returncode}" + ("" if line is not None else ", no JSON line")
+        except subprocess.TimeoutExpired:
+            why = f"no result within {limit:.0f} s"
+        log(f"attempt {attempt + 1} failed ({why})" + ("; repeating on k_search_fast only" if attempt == 0 else ""))
+    return 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -202,6 +232,9 @@ def main():
                          "disk has room; 'none': always rebuild")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
+    rc = supervised_run(sys.argv[1:], args.n >= 500_000 or bool(os.environ.get("VS_BENCH_TRY_MX")))
+    if rc is not None:
+        sys.exit(rc)
 
     import numpy as np
     import torch
@@ -236,8 +269,10 @@ def main():
     # on a full batch of this run's queries, both outside the timed region) wherever the table-less regime applies
     kernel_choice = {"chosen": "k_search_fast"}
     try_gd4 = False
-    try_mx = "VS_MX" not in os.environ and not os.environ.get("VS_BENCH_CANARY") and \
+    try_mx = "VS_MX" not in os.environ and not os.environ.get("VS_BENCH_CANARY") and not os.environ.get("VS_BENCH_NO_MX") and \
         (args.n >= 500_000 or bool(os.environ.get("VS_BENCH_TRY_MX")))
+    if os.environ.get("VS_BENCH_FIRST_ATTEMPT"):
+        kernel_choice["first_attempt"] = os.environ["VS_BENCH_FIRST_ATTEMPT"] + " (with the k_search_mx A/B); this is the repeat without it"
     if try_mx and rank == 0:
         t0 = time.time()
         ok, why = mx_canary(args)
@@ -425,9 +460,19 @@ def main():
             barrier()
             return time.perf_counter() - t1, out_ids.clone(), out_dist.clone()
 
+        if os.environ.get("VS_BENCH_TEST_CRASH") == "ab":  # tests/test_bench_dry_run.py: a kernel fault in the A/B
+            os.abort()
         times, okv = [], []
         ref_ids = ref_dist = None
         for vi, v in enumerate(variants):
+            # a k_search_mx arm that hangs must not take the run with it: past 50x the k_search_fast arm (at least 60 s)
+            # the process ends with code 86 and the supervising parent repeats the run without the exploration
+            watchdog = None
+            if vi > 0 and times[0] != float("inf") and not EMU:
+                import threading
+                watchdog = threading.Timer(max(60.0, 50 * times[0]), lambda: os._exit(86))
+                watchdog.daemon = True
+                watchdog.start()
             try:
                 t_v, ids_v, dist_v = timed(v)
                 if vi == 0:
@@ -438,6 +483,9 @@ def main():
             except P.VsError as e:
                 kernel_choice.setdefault("ab_errors", {})[v[0]] = str(e)
                 t_v, same = float("inf"), False
+            finally:
+                if watchdog is not None:
+                    watchdog.cancel()
             times.append(t_v)
             okv.append(same)
         kernel_choice["ms_per_step"] = {v[0]: (round(t * 1e3, 3) if t != float("inf") else None) for v, t in zip(variants, times)}

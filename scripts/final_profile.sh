@@ -11,7 +11,7 @@ CACHE=/tmp/vs_graph
 python bench.py --n $N --distance $DIST --graph-cache $CACHE 2> gpurun_out/final_bench.err > gpurun_out/final_bench.json
 tail -4 gpurun_out/final_bench.err
 rm -rf gpurun_out/prof_final
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_final -o bench -- python bench.py --n $N --distance $DIST --skip-cpu --graph-cache $CACHE > gpurun_out/final_bench_prof.json 2> gpurun_out/final_bench_prof.err
+VS_BENCH_INPROC=1 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_final -o bench -- python bench.py --n $N --distance $DIST --skip-cpu --graph-cache $CACHE > gpurun_out/final_bench_prof.json 2> gpurun_out/final_bench_prof.err
 python scripts/summarize_rocprof.py gpurun_out/prof_final/bench_kernel_stats.csv gpurun_out/final_kernel_stats.csv "rocprofv3 --kernel-trace --stats -- python bench.py --skip-cpu --graph-cache ... ($N x 768 $DIST, 131072 scans per launch; index loaded from the cache the plain bench run wrote)"
 head -8 gpurun_out/final_kernel_stats.csv
 if [ "$DIST" = "l2" ]; then bash scripts/pmc_traffic.sh $N 131072 $L $S $CACHE 2>&1 | tail -25; fi

@@ -51,3 +51,20 @@ def test_bench_dry_run_two_ranks():
     j = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
     assert j["n_gpus"] == 2 and j["scaling"] == "weak" and "query-sharded x2" in j["config"]["parallelism"]
     assert all(j["search_kernel"]["results_identical"].values())
+
+
+@pytest.mark.skipif(not os.environ.get("VS_EMU_FULL"), reason="slow (about 2 minutes); set VS_EMU_FULL=1")
+def test_bench_repeats_without_the_exploration_when_the_ab_dies():
+    """N = 1 runs in a supervised child: a fault inside the k_search_mx A/B (simulated: abort()) must cost a repeat on
+    k_search_fast, not the bench line"""
+    env = dict(os.environ, VS_EMU="1", VS_BENCH_TRY_MX="1", VS_F_LDS_MAX_INS="0", VS_BENCH_TEST_CRASH="ab")
+    env.pop("VS_MX", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--n", "4000", "--dim", "64", "--nq", "64", "--steps", "1", "--warmup", "1",
+           "--recall-queries", "16", "--scan-nq", "0", "--cpu-seconds", "1", "--graph-cache", "none", "--fixed", "100,50"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, cwd=ROOT, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["search_kernel"]["chosen"] == "k_search_fast" and "exit code" in j["search_kernel"]["first_attempt"]
+    assert j["cpu_baseline"]["gpu_rows_identical"] is True

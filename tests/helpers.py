@@ -25,7 +25,7 @@ class TestIndex:
     __test__ = False
 
     def __init__(self, n=2000, dim_full=64, dim_index=None, bits=None, R=32, distance=O.L2, seed=1, kind="uniform",
-                 n_labels=0, deleted_frac=0.0, L_build=50):
+                 n_labels=0, deleted_frac=0.0, L_build=50, label_zipf=False):
         dim_index = dim_index or dim_full
         bits = bits or O.default_bits(dim_index)
         self.n, self.dim_full, self.dim_index, self.bits, self.R, self.distance = n, dim_full, dim_index, bits, R, distance
@@ -49,9 +49,14 @@ class TestIndex:
         if n_labels:
             off = np.zeros(n + 1, np.uint32)
             vals = []
+            pz = 1.0 / np.arange(1, n_labels + 1)  # Zipf, s = 1
+            pz /= pz.sum()
             for i in range(n):
                 k = int(rng.integers(1, 4))
-                ls = sorted(set(int(v) for v in rng.integers(1, n_labels + 1, k)))
+                if label_zipf:
+                    ls = sorted(set(int(v) + 1 for v in rng.choice(n_labels, k, p=pz)))
+                else:
+                    ls = sorted(set(int(v) for v in rng.integers(1, n_labels + 1, k)))
                 vals.extend(ls)
                 off[i + 1] = len(vals)
                 for l in ls:  # first node carrying a label becomes that label's start node

@@ -8,6 +8,7 @@ scoring, f32 rerank, rescore window) over one batch of `--nq` synthetic queries 
                                         # metric of BASELINE.json is quoted on; 177 GB index on ONE GPU; ~7 min, 6 of them
                                         # the on-device index build)
   python bench.py --n 10000000 --distance cosine   # configs[2] (~1.5 min);   --n 1000000: configs[1] (~20 s)
+  python bench.py --n 20000000 --dim 1536 --distance cosine --labels 32   # configs[4]: label-filtered scans
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W   # index replicated per GPU, queries sharded, RCCL all_gather of top-k
 
@@ -111,7 +112,7 @@ def mx_canary(args, extra_env=None):
     small = ["--n", "4000", "--nq", "64", "--recall-queries", "16"] if EMU else ["--n", "200000", "--nq", "8192"]
     cmd = [sys.executable, os.path.abspath(__file__), *small, "--steps", "1", "--warmup", "1", "--fixed",
            "100,50", "--graph-cache", "none", "--scan-nq", "0", "--cpu-seconds", "3", "--dim", str(args.dim), "--distance",
-           args.distance, "--k", str(args.k)]
+           args.distance, "--k", str(args.k), "--labels", str(args.labels)]
     try:
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     except subprocess.TimeoutExpired:
@@ -174,6 +175,40 @@ def choose_operating_point(run_sample, k, target, sweep_log, err_type=Exception)
     return L, S, tried[(L, S)][0]
 
 
+def zipf_labels(np, rows, n_labels, seed, kmin, kmax):
+    """Label sets for `rows` rows: kmin..kmax draws per row from n_labels labels (1-based) with Zipf(s = 1) frequencies,
+    sorted and de-duplicated (LabelSet is a sorted set, AM/labels/mod.rs:15-37) -> (off[rows + 1] u32, val i16)."""
+    rng = np.random.default_rng(seed)
+    pz = 1.0 / np.arange(1, n_labels + 1)
+    pz /= pz.sum()
+    SENT = np.int16(32767)
+    draws = (rng.choice(n_labels, size=(rows, kmax), p=pz) + 1).astype(np.int16)
+    cnt = rng.integers(kmin, kmax + 1, size=rows)
+    draws[np.arange(kmax)[None, :] >= cnt[:, None]] = SENT
+    draws.sort(axis=1)
+    dup = np.zeros_like(draws, dtype=bool)
+    dup[:, 1:] = draws[:, 1:] == draws[:, :-1]
+    draws[dup] = SENT
+    draws.sort(axis=1)
+    keep = draws != SENT
+    off = np.zeros(rows + 1, np.uint32)
+    np.cumsum(keep.sum(1), out=off[1:])
+    return off, draws[keep]
+
+
+def label_start_nodes(np, off, val):
+    """first node carrying each label (the role of MetaPage start nodes per label, AM/graph/start_nodes.rs:39-48)"""
+    owner = np.repeat(np.arange(off.size - 1, dtype=np.uint32), np.diff(off).astype(np.int64))
+    labels, first = np.unique(val, return_index=True)
+    return {int(l): int(owner[i]) for l, i in zip(labels, first)}
+
+
+def label_masks(np, off, val):
+    """one bit per label (n_labels <= 62) for the filtered ground truth"""
+    assert (np.diff(off.astype(np.int64)) > 0).all()  # reduceat needs non-empty rows
+    return np.bitwise_or.reduceat(np.int64(1) << val.astype(np.int64), off[:-1].astype(np.int64))
+
+
 def supervised_run(argv, try_mx_possible):
     """N = 1: the run proper happens in a child process.  k_search_mx has never run on hardware with this corpus size
     before its A/B arm does (the canary is a smaller instance); if the child dies or hangs there, the run is repeated
@@ -231,6 +266,10 @@ def main():
                          "'auto' (default): $TMPDIR/vs_graph_cache_<hash of the kernel sources> for n >= 10M when the "
                          "disk has room; 'none': always rebuild")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--labels", type=int, default=0,
+                    help="label-filtered scans (BASELINE configs[4]: --n 20000000 --dim 1536 --distance cosine --labels 32): every "
+                         "vector carries 1-3 of this many labels (Zipf frequencies), query keys alternate between one and two "
+                         "labels; ground truth is the exact filtered top-k")
     args = ap.parse_args()
     rc = supervised_run(sys.argv[1:], args.n >= 500_000 or bool(os.environ.get("VS_BENCH_TRY_MX")))
     if rc is not None:
@@ -333,7 +372,35 @@ def main():
                     os.remove(tmp)
                 except OSError:
                     pass
+    NL = args.labels
+    lab_off = lab_val = lab_starts = None
+    if NL:
+        assert 1 <= NL <= 62
+        t0 = time.time()
+        lab_off, lab_val = zipf_labels(np, n, NL, seed + 100, 1, 3)
+        lab_starts = label_start_nodes(np, lab_off, lab_val)
+        ix.set_labels(lab_off, lab_val)
+        ix.set_start_nodes(ix.desc.default_start, lab_starts)
+        setup["labels_s"] = round(time.time() - t0, 3)
     log("setup", setup)
+
+    def query_keys(first_row, rows):
+        """label keys of a query batch: one label (even rows) or two draws (odd rows) -> host CSR + device copies"""
+        off, val = zipf_labels(np, rows, NL, seed + 200 + first_row % 1000003, 1, 2)
+        # even rows keep their first label only
+        cnt = np.diff(off.astype(np.int64))
+        keep = np.ones(val.size, bool)
+        two = np.nonzero((cnt == 2) & (np.arange(rows) % 2 == 0))[0]
+        keep[off[two].astype(np.int64) + 1] = False
+        cnt[two] = 1
+        val = val[keep]
+        off = np.zeros(rows + 1, np.uint32)
+        np.cumsum(cnt, out=off[1:])
+        d_val = ctx.alloc(max(val.size, 1) * 2)
+        d_off = ctx.alloc((rows + 1) * 4)
+        ctx.upload(d_val, np.ascontiguousarray(val, np.int16))
+        ctx.upload(d_off, off)
+        return off, val, d_val, d_off
 
     # ---- query batches resident in HBM (disjoint row range of the same stream) -------------------------------------
     nq = args.nq
@@ -342,6 +409,7 @@ def main():
     qbuf = [ctx.alloc(nq * dim * 4) for _ in range(n_batches)]
     for b in range(n_batches):
         fill_device(ctx, gp, QBASE + (rank * n_batches + b) * nq, nq, qbuf[b])
+    qkeys = [query_keys((rank * n_batches + b) * nq, nq) for b in range(n_batches)] if NL else [None] * n_batches
     out_ids = torch.empty((nq, k), dtype=torch.int32, device=dev)  # u32 node ids (viewed as i32 for torch)
     out_dist = torch.empty((nq, k), dtype=torch.float32, device=dev)
 
@@ -356,6 +424,11 @@ def main():
     best_i = torch.zeros((nr, k), dtype=torch.int64, device=dev)
     chunk = 1 << 18
     Qn = torch.nn.functional.normalize(Qs, dim=1) if dt == P.VS_COSINE else Qs
+    rkeys = None
+    if NL:
+        rkeys = query_keys(QBASE - (1 << 30), nr)
+        node_mask = torch.from_numpy(label_masks(np, lab_off, lab_val)).to(dev)
+        q_mask = torch.from_numpy(label_masks(np, rkeys[0], rkeys[1])).to(dev)
     for s in range(0, n, chunk):
         xc = X[s:s + chunk]
         if dt == P.VS_L2:
@@ -364,24 +437,34 @@ def main():
             d = -(Qn @ torch.nn.functional.normalize(xc, dim=1).T)
         else:
             d = -(Qn @ xc.T)
-        cd, ci = torch.topk(d, k, dim=1, largest=False)
+        if NL:  # the predicate: the label sets overlap (AM/labels/mod.rs:124-142)
+            d = d.masked_fill((node_mask[s:s + chunk][None, :] & q_mask[:, None]) == 0, float("inf"))
+        cd, ci = torch.topk(d, min(k, d.shape[1]), dim=1, largest=False)
         alld = torch.cat([best_d, cd], 1)
         alli = torch.cat([best_i, ci + s], 1)
         sel = torch.topk(alld, k, dim=1, largest=False)
         best_d, best_i = sel.values, torch.gather(alli, 1, sel.indices)
     torch.cuda.synchronize()
     gt = best_i.cpu().numpy()
+    gt_valid = torch.isfinite(best_d).cpu().numpy()  # fewer than k rows may satisfy a rare key
     setup["ground_truth_s"] = round(time.time() - t0, 3)
     del X, Qs, Qn
+    if NL:
+        del node_mask, q_mask
 
     rq_ids = torch.empty((nr, k), dtype=torch.int32, device=dev)
 
     def run_sample(L, S):
-        ix.search_batch_dev(rq_ptr, nr, L, S, k, C.c_void_p(rq_ids.data_ptr()))
+        ix.search_batch_dev(rq_ptr, nr, L, S, k, C.c_void_p(rq_ids.data_ptr()), d_qlabels=rkeys and rkeys[2],
+                            d_qlabel_off=rkeys and rkeys[3])
         st = ix.search_batch_dev_finish()
         got = rq_ids.cpu().numpy().view(np.uint32)
-        rec = float(np.mean([len(set(got[i].tolist()) & set(gt[i].tolist())) / k for i in range(nr)]))
-        return rec, st
+        hit = tot_gt = 0
+        for i in range(nr):
+            want = set(gt[i][gt_valid[i]].tolist())
+            hit += len(set(got[i].tolist()) & want)
+            tot_gt += len(want)
+        return hit / max(tot_gt, 1), st
 
     # ---- recall sweep: cheapest (L, rescore) reaching the target (choose_operating_point) --------------------------
     sweep_log = []
@@ -404,7 +487,8 @@ def main():
     from pgvectorscale_amd.sharding import gather_topk
 
     def step(b):
-        ix.search_batch_dev(qbuf[b], nq, L, S, k, C.c_void_p(out_ids.data_ptr()), None, C.c_void_p(out_dist.data_ptr()))
+        ix.search_batch_dev(qbuf[b], nq, L, S, k, C.c_void_p(out_ids.data_ptr()), None, C.c_void_p(out_dist.data_ptr()),
+                            d_qlabels=qkeys[b] and qkeys[b][2], d_qlabel_off=qkeys[b] and qkeys[b][3])
         st = ix.search_batch_dev_finish()  # waits for the kernels, checks overflow flags, sums the work counters
         if world > 1:  # final top-k gather over RCCL/xGMI (the only collective on this path)
             gather_topk(out_ids, out_dist)
@@ -611,7 +695,9 @@ def main():
         "dtype": "u64 xor+popcount (SBQ) / f32 (rerank)",
         "data": "synthetic" if not EMU else "synthetic (DRY RUN on the wave64 interpreter: no GPU, numbers meaningless)",
         "config": {"workload": f"{n}x{dim} synthetic clustered unit-norm f32, diskann index (SBQ {bits} bit, R={R}), "
-                               f"{args.distance}, top-{k}", "n": n, "dim": dim, "bits": bits, "words": W,
+                               f"{args.distance}, top-{k}" + (f", label-filtered scans ({NL} labels, Zipf, 1-3 per vector, keys of one / "
+                                                             f"two labels; graph built without label awareness)" if NL else ""),
+                   "labels": NL, "n": n, "dim": dim, "bits": bits, "words": W,
                    "num_neighbors": R, "queries_per_step_per_gpu": nq, "search_list_size": L, "rescore": S, "k": k,
                    "parallelism": f"query-sharded x{world}, index replicated" if world > 1 else "single GPU"},
         "recall_at_k": round(recall, 4),
@@ -635,26 +721,32 @@ def main():
             mean, m2, cnt = ix.get_quantizer()
             oidx = O.OracleIndex(codes=host["codes"], nbrs=host["nbrs"], heap_tids=host["heap_tids"], vecs=host["vecs"],
                                  mean=mean, m2=m2, count=cnt, bits=bits, dim_index=dim, num_neighbors=R,
-                                 distance_type=dt, default_start=ix.desc.default_start)
+                                 distance_type=dt, default_start=ix.desc.default_start, label_off=lab_off, label_val=lab_val,
+                                 label_starts=lab_starts)
+            hk = None
+            if NL:
+                ko, kv = qkeys[args.warmup][0], qkeys[args.warmup][1]
+                hk = [kv[ko[i]:ko[i + 1]].tolist() for i in range(nq)]
             cores = os.cpu_count() or 1
             qh = ctx.download(qbuf[args.warmup], np.empty((nq, dim), np.float32))
             log(f"cpu_baseline: index on host in {time.time() - t0:.1f}s, {cores} cores")
             probe = min(nq, 32 * cores)
             t1 = time.time()
-            oidx.search_batch(qh[:probe], L=L, rescore=S, k=k, threads=cores)
+            oidx.search_batch(qh[:probe], L=L, rescore=S, k=k, threads=cores, qlabels=hk and hk[:probe])
             per_q = (time.time() - t1) / probe
             sample = int(max(probe, min(nq, args.cpu_seconds / max(per_q, 1e-9))))
             t1 = time.time()
-            o_ids, o_dist, o_st = oidx.search_batch(qh[:sample], L=L, rescore=S, k=k, threads=cores)
+            o_ids, o_dist, o_st = oidx.search_batch(qh[:sample], L=L, rescore=S, k=k, threads=cores, qlabels=hk and hk[:sample])
             cpu_t = time.time() - t1
             t1 = time.time()
             one = min(sample, 64)
-            oidx.search_batch(qh[:one], L=L, rescore=S, k=k, threads=1)
+            oidx.search_batch(qh[:one], L=L, rescore=S, k=k, threads=1, qlabels=hk and hk[:one])
             cpu1 = (time.time() - t1) / one
             # and the same sample through the GPU path: identical rows expected
             g_ids = out_ids.cpu().numpy().view(np.uint32) if False else None
             ix.search_batch_dev(qbuf[args.warmup], nq, L, S, k, C.c_void_p(out_ids.data_ptr()), None,
-                                C.c_void_p(out_dist.data_ptr()))
+                                C.c_void_p(out_dist.data_ptr()), d_qlabels=qkeys[args.warmup] and qkeys[args.warmup][2],
+                                d_qlabel_off=qkeys[args.warmup] and qkeys[args.warmup][3])
             ix.search_batch_dev_finish()
             g_ids = out_ids.cpu().numpy().view(np.uint32)[:sample]
             g_dist = out_dist.cpu().numpy()[:sample]

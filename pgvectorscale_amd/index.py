@@ -322,8 +322,10 @@ class DiskAnnIndex:
                                       C.byref(st)))
         return ids, ham, st.as_dict()
 
-    def search_batch_dev(self, d_queries, nq, search_list_size, rescore, k, d_out_ids, d_out_tids=None, d_out_dist=None):
-        check(self._L.vs_search_batch_dev(self.h, d_queries, None, None, nq, search_list_size, rescore, k, d_out_ids,
+    def search_batch_dev(self, d_queries, nq, search_list_size, rescore, k, d_out_ids, d_out_tids=None, d_out_dist=None,
+                         d_qlabels=None, d_qlabel_off=None):
+        """d_qlabels / d_qlabel_off: device CSR of the label keys (sorted, de-duplicated per query) or None"""
+        check(self._L.vs_search_batch_dev(self.h, d_queries, d_qlabels, d_qlabel_off, nq, search_list_size, rescore, k, d_out_ids,
                                           d_out_tids, d_out_dist))
 
     def search_batch_dev_finish(self):

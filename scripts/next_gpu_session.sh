@@ -23,3 +23,6 @@ for MX in 0 1; do
   for p in A B; do mv gpurun_out/pmc_issue_$p.txt gpurun_out/s_pmc_issue_${p}_mx$MX.txt 2>/dev/null; done
 done
 bash scripts/final_profile.sh 2>&1 | tail -40
+
+# BASELINE configs[4] (20M x 1536, label-filtered): 123 GB of vectors + 3.8 GB codes; ~4 min of build
+python bench.py --n 20000000 --dim 1536 --distance cosine --labels 32 --skip-cpu --scan-nq 0 2>gpurun_out/s_cfg5.err | tee gpurun_out/s_cfg5.json | cut -c1-600

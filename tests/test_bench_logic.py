@@ -72,3 +72,27 @@ def test_canary_verdict():
     assert not bench.canary_verdict(0, good.replace("1.0", "0.99"))[0]
     assert not bench.canary_verdict(0, good.replace("0.995", "0.2"))[0]
     assert not bench.canary_verdict(0, '{"cpu_baseline": {"value": null}}')[0]
+
+
+def test_label_workload_helpers():
+    """--labels: label sets are sorted sets of 1..NL with 1-3 members, start nodes are first carriers, masks match the CSR"""
+    import numpy as np
+    import bench
+    off, val = bench.zipf_labels(np, 5000, 32, 7, 1, 3)
+    assert off[0] == 0 and off[-1] == val.size and val.dtype == np.int16
+    cnt = np.diff(off.astype(np.int64))
+    assert cnt.min() >= 1 and cnt.max() <= 3 and val.min() >= 1 and val.max() <= 32
+    for i in range(0, 5000, 97):
+        row = val[off[i]:off[i + 1]].tolist()
+        assert row == sorted(set(row))
+    freq = np.bincount(val, minlength=33)
+    assert freq[1] > freq[4] > freq[16] > 0  # Zipf: frequencies fall with the label number
+    starts = bench.label_start_nodes(np, off, val)
+    for l, v in starts.items():
+        assert l in val[off[v]:off[v + 1]]
+        assert not any(l in val[off[u]:off[u + 1]] for u in range(v))
+    m = bench.label_masks(np, off, val)
+    for i in (0, 1, 4999):
+        assert m[i] == sum(1 << int(x) for x in val[off[i]:off[i + 1]])
+    off2, val2 = bench.zipf_labels(np, 5000, 32, 7, 1, 3)
+    assert (off2 == off).all() and (val2 == val).all()  # deterministic

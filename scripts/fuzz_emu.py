@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""Differential fuzzing of the search path against the oracle on the wave64 interpreter (tests/emu; no GPU needed).
+
+Random index geometries (size, dimensions, bits, R, distance, labels, deleted tuples, matryoshka slice) x random scan
+parameters (L, rescore, k, label keys, NULL queries) x the kernels and regimes the library can be steered into
+(k_search_fast regimes, k_search_mx, the general kernel).  Every case must reproduce the oracle: ids bit for bit, distances
+within 1e-5, the SBQ stream (ids + Hamming distances) and the work counters exactly.
+
+  make -C tests/emu && python scripts/fuzz_emu.py --seconds 600 [--seed 1] [--gpu]
+
+--gpu runs the same cases against libvsgpu.so on a real device instead.  A failing case prints the line that reproduces
+it (`--only <case seed>`)."""
+import argparse
+import os
+import sys
+import time
+import traceback
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+
+REGIMES = [
+    {},
+    {"VS_F_LDS_MAX_INS": "0"},
+    {"VS_F_LDS_MAX_INS": "0", "VS_MX": "1"},
+    {"VS_F_LDS_MAX_INS": "0", "VS_MX": "1", "VS_MX_GD": "4"},
+    {"VS_F_LDS_MAX_INS": "0", "VS_MX": "1", "VS_MX_PERSIST": "0"},
+    {"VS_F_LDS_MAX_INS": "0", "VS_MX": "1", "VS_MX_GRID": "1"},
+    {"VS_F_LDS_MAX_INS": "0", "VS_MX": "1", "VS_F_HL": "63"},
+    {"VS_F_LDS_MAX_INS": "0", "VS_F_VR": "8", "VS_F_MINW": "4"},
+    {"VS_F_LH": "256"},
+    {"VS_F_VR": "0", "VS_F_VCAP": "64"},
+    {"VS_F_HL": "63"},
+    {"VS_F_HL": "63", "VS_F_LDS_MAX_INS": "0"},
+    {"VS_F_LH": "256", "VS_F_POOL": "0.01"},
+    {"VS_FAST": "0"},
+    {"VS_FAST": "0", "VS_HL": "64", "VS_G0": "256"},
+]
+TUNING = sorted({k for r in REGIMES for k in r})
+
+
+def close(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    nan = np.isnan(a) & np.isnan(b)
+    return bool(np.all(nan | (np.abs(a - b) <= 1e-5 * np.maximum(np.abs(b), 1e-30) + 1e-12)))
+
+
+def gettuple_mirror(ix, oracle, q, keys, L, rescore, rng, where, exact_dist):
+    """amrescan / amgettuple one row at a time: two scans on one handle (the second a rescan, sometimes a NULL query),
+    a random number of rows each, sometimes to exhaustion"""
+    scan = ix.beginscan()
+    try:
+        for rnd in range(2):
+            i = int(rng.integers(0, q.shape[0]))
+            null = rng.random() < 0.2
+            lab = None if keys is None else keys[i]
+            rows = int(rng.choice([1, 7, 60, 10 ** 9]))
+            scan.rescan(None if null else q[i], labels=lab, search_list_size=L, rescore=rescore)
+            osc = oracle.scan(None if null else q[i], labels=lab, L=L, rescore=rescore)
+            got = 0
+            while got < rows:
+                r, o = scan.gettuple(), osc.gettuple()
+                assert (r is None) == (o is None), f"{where}: gettuple row {got} of scan {rnd}: end of scan differs"
+                if r is None:
+                    break
+                assert r[1] == o[0] and r[0] == o[1], f"{where}: gettuple row {got} of scan {rnd}: {r} vs {o}"
+                if exact_dist:
+                    assert np.float32(r[2]).view(np.uint32) == np.float32(o[2]).view(np.uint32), f"{where}: gettuple distance bits"
+                else:
+                    assert close(r[2], o[2]), f"{where}: gettuple distance {r[2]} vs {o[2]}"
+                got += 1
+    finally:
+        scan.endscan()
+
+
+def plain_case(ctx, O, case_seed, verbose):
+    """`plain` storage: f32 distances in the graph, ids and distance bits must equal the oracle's"""
+    from test_gpu_zy_plain import PlainIndex
+    from helpers import make_vectors
+    rng = np.random.default_rng(case_seed)
+    dim = int(rng.choice([3, 8, 17, 36, 64, 100, 128, 384]))
+    n = int(rng.choice([1, 2, 40, 300, 1200]))
+    R = int(rng.choice([4, 16, 24, 50]))
+    distance = int(rng.choice([0, 1, 2]))
+    kind = str(rng.choice(["uniform", "gauss", "clustered"]))
+    dim_index = None if rng.random() < 0.7 or dim < 8 else int(rng.integers(2, dim))
+    pi = PlainIndex(n=max(n, 4) if kind == "gauss" else n, dim=dim, R=R, distance=distance, seed=int(rng.integers(1, 1 << 30)), kind=kind,
+                    deleted_frac=float(rng.choice([0.0, 0.1, 0.5])), dim_index=dim_index)
+    nq = int(rng.choice([1, 5, 33]))
+    q = make_vectors(nq, dim, int(rng.integers(1, 1 << 30)), kind)
+    L = int(rng.choice([1, 5, 30, 100]))
+    k = int(rng.choice([1, 10, 40]))
+    where = f"plain case {case_seed}: n={pi.n} dim={dim}/{pi.dim_index} R={R} dist={distance} {kind} nq={nq} L={L} k={k}"
+    if verbose:
+        print(where, flush=True)
+    for v in TUNING:
+        os.environ.pop(v, None)
+    ix = pi.upload(ctx)
+    try:
+        gi, gt, gd, gst = ix.search_batch(q, search_list_size=L, rescore=50, k=k)
+        oi, od, ost = pi.oracle.search_batch(q, L=L, rescore=50, k=k)
+        assert (gi == oi).all(), f"{where}: ids differ"
+        assert (gd.view(np.uint32) == od.view(np.uint32)).all(), f"{where}: distance bits differ"
+        for c in ("visited_nodes", "candidate_nodes", "full_distance_comparisons"):
+            assert gst[c] == ost[c], f"{where}: counter {c}"
+        gettuple_mirror(ix, pi.oracle, q, None, L, 50, np.random.default_rng(case_seed + 1), where, exact_dist=True)
+    finally:
+        ix.close()
+
+
+def one_case(ctx, O, case_seed, verbose):
+    from helpers import TestIndex
+    if case_seed % 5 == 4:
+        return plain_case(ctx, O, case_seed, verbose)
+    rng = np.random.default_rng(case_seed)
+    dim_full = int(rng.choice([3, 8, 17, 32, 48, 64, 65, 100, 128, 200, 384, 768]))
+    bits = int(rng.choice([0, 1, 2, 3]))  # 0 = the reference's default for the dimension count
+    if bits and dim_full * bits > 1600:
+        bits = 1
+    dim_index = dim_full if rng.random() < 0.8 or dim_full < 8 else int(rng.integers(2, dim_full))
+    n = int(rng.choice([1, 2, 5, 40, 300, 900, 1500, 2500]))
+    R = int(rng.choice([4, 8, 16, 20, 32, 50, 64, 80]))
+    distance = int(rng.choice([0, 1, 2]))
+    n_labels = int(rng.choice([0, 0, 3, 8, 32]))
+    deleted = float(rng.choice([0.0, 0.0, 0.1, 0.6]))
+    kind = str(rng.choice(["uniform", "gauss", "clustered"]))
+    ti = TestIndex(n=n, dim_full=dim_full, dim_index=dim_index, bits=bits or None, R=R, distance=distance, seed=int(rng.integers(1, 1 << 30)),
+                   kind=kind, n_labels=n_labels, deleted_frac=deleted, L_build=int(rng.choice([10, 50, 100])),
+                   label_zipf=bool(rng.random() < 0.5))
+    desc = f"n={n} dim={dim_full}/{dim_index} bits={ti.bits} R={R} dist={distance} labels={n_labels} del={deleted} {kind}"
+    nq = int(rng.choice([1, 3, 17, 64]))
+    q = ti.queries(nq, seed=int(rng.integers(1, 1 << 30)), kind=kind)
+    if rng.random() < 0.2:  # duplicates of corpus rows: distance ties
+        for i in range(0, nq, 2):
+            q[i] = ti.vecs[int(rng.integers(0, n))]
+    keys = None
+    if n_labels and rng.random() < 0.8:
+        keys = []
+        for _ in range(nq):
+            kk = int(rng.choice([0, 1, 1, 2, 2, 5]))
+            keys.append([int(x) for x in rng.integers(1, n_labels + 2, kk)])  # unsorted, duplicates, one label nobody has
+    L = int(rng.choice([1, 2, 10, 30, 64, 100, 150, 300]))
+    rescore = int(rng.choice([0, 1, 10, 50, 115]))
+    k = int(rng.choice([1, 5, 10, 40]))
+    m = int(rng.choice([1, 20, 75]))
+    regimes = [REGIMES[i] for i in rng.choice(len(REGIMES), 4, replace=False)]
+    oi, od, ost = ti.oracle.search_batch(q, L=L, rescore=rescore, k=k, qlabels=keys)
+    si, sh, sst = ti.oracle.stream_batch(q, L=L, m=m, qlabels=keys)
+    for reg in regimes:
+        for v in TUNING:
+            os.environ.pop(v, None)
+        os.environ.update(reg)
+        where = f"case {case_seed}: {desc} nq={nq} L={L} rescore={rescore} k={k} m={m} keys={'yes' if keys else 'no'} regime={reg}"
+        if verbose:
+            print(where, flush=True)
+        ix = ti.upload(ctx)
+        try:
+            for rep in range(2):  # the second call runs with launch sizes adapted to the first one's statistics
+                gi, gt, gd, gst = ix.search_batch(q, search_list_size=L, rescore=rescore, k=k, qlabels=keys)
+                assert (gi == oi).all(), f"{where}: ids differ (rep {rep})"
+                assert close(gd, od), f"{where}: distances differ (rep {rep})"
+                live = gi != 0xFFFFFFFF
+                assert (gt[live] == ti.tids[gi[live]]).all(), f"{where}: heap tids differ"
+                for c in ("visited_nodes", "quantized_distance_comparisons", "full_distance_comparisons"):
+                    assert gst[c] == ost[c], f"{where}: counter {c} {gst[c]} != {ost[c]}"
+            gi2, gh2, gst2 = ix.stream_batch(q, search_list_size=L, m=m, qlabels=keys)
+            assert (gi2 == si).all() and (gh2 == sh).all(), f"{where}: stream differs"
+            assert gst2["candidate_nodes"] == sst["candidate_nodes"], f"{where}: stream counters differ"
+            gettuple_mirror(ix, ti.oracle, q, keys, L, rescore, np.random.default_rng(case_seed + 1), where, exact_dist=False)
+        finally:
+            ix.close()
+    return desc
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=300)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--only", type=int, default=None, help="run this one case seed")
+    ap.add_argument("--gpu", action="store_true")
+    ap.add_argument("-v", "--verbose", action="store_true")
+    args = ap.parse_args()
+    from pgvectorscale_amd import _lib
+    if not args.gpu:
+        _lib.LIB_PATH = os.path.join(ROOT, "tests", "emu", "libvsgpu_emu.so")
+        assert os.path.exists(_lib.LIB_PATH), "make -C tests/emu first"
+    import pgvectorscale_amd as P
+    from oracle import oracle_py as O
+    O.build()
+    ctx = P.Context(0)
+    t0 = time.time()
+    cases = failures = 0
+    seeds = [args.only] if args.only is not None else (args.seed * 1_000_000 + i for i in range(1 << 30))
+    for cs in seeds:
+        if args.only is None and time.time() - t0 > args.seconds:
+            break
+        try:
+            one_case(ctx, O, cs, args.verbose or args.only is not None)
+        except AssertionError as e:
+            failures += 1
+            print("FAIL", e, flush=True)
+        except Exception:
+            failures += 1
+            print(f"ERROR in case {cs}:", flush=True)
+            traceback.print_exc()
+        cases += 1
+    print(f"{cases} cases, {failures} failures, {time.time() - t0:.0f} s")
+    ctx.close()
+    sys.exit(1 if failures else 0)
+
+
+if __name__ == "__main__":
+    main()

@@ -8,6 +8,7 @@
 # 4. the default bench (50M; canary + A/B decide the kernel) with its rocprofv3 summary
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" && mkdir -p gpurun_out
 python -m pytest tests -m gpu -x -q 2>&1 | tail -5 | tee gpurun_out/s_tests.txt
+timeout 400 python scripts/fuzz_emu.py --gpu --seconds 180 --seed 11 2>&1 | tail -8 | tee gpurun_out/s_fuzz.txt  # random cases on the device
 for MX in 0 1; do
   VS_MX=$MX VS_F_LDS_MAX_INS=0 python bench.py --n 1000000 --fixed 100,50 --skip-cpu --scan-nq 0 2>gpurun_out/s_1m_mx$MX.err | tee gpurun_out/s_1m_mx$MX.json | cut -c1-400
   VS_MX=$MX python bench.py --n 10000000 --distance cosine --fixed 100,100 --skip-cpu --scan-nq 0 --graph-cache /tmp/vs_graph 2>gpurun_out/s_10m_mx$MX.err | tee gpurun_out/s_10m_mx$MX.json | cut -c1-400

@@ -5,6 +5,10 @@ the scan: start nodes per label, LabelSet overlap, the empty key, labels nobody 
   * test_build_index_on_nonempty_table   AM/labels/filtering_tests.rs:112-167
   * test_label_size_bounds         AM/labels/filtering_tests.rs:718-793 (labels 0, 32767 and -1 are legal smallints; the
     reference checks them with the `&&` operator alone, here they also go through the index scan)
+and on tiny unlabeled ones:
+  * test_l2_sanity_check / test_ip_sanity_check   AM/build.rs:1476-1556 (the first row of ORDER BY ... LIMIT 1)
+  * test_empty_table_insert / test_insert_empty_insert   AM/build.rs:1559-1611 (counts; deleted rows stay in the graph with
+    a dead heap pointer)
 The graph of a 3-4 row table with num_neighbors = 15 is complete; start node of a label = the first row carrying it
 (AM/graph/start_nodes.rs).  The oracle must give the reference's counts (CPU tier), the HIP path must give the oracle's rows
 (GPU tier)."""
@@ -27,11 +31,12 @@ IDS = ["test_tiny_labeled_index", "test_null_and_empty_labels", "test_build_inde
 
 
 class TinyTable:
-    def __init__(self, vecs, labels, R=15):
+    def __init__(self, vecs, labels, R=15, distance=O.COSINE, deleted=()):
         self.vecs = np.array(vecs, np.float32)
         n, dim = self.vecs.shape
-        self.n, self.dim, self.R = n, dim, R
-        unit = np.stack([O.preprocess_cosine(v)[0] for v in self.vecs])  # `<=>`: the index stores the normalised vector's code
+        self.n, self.dim, self.R, self.distance = n, dim, R, distance
+        # `<=>`: the index stores the normalised vector's code
+        unit = np.stack([O.preprocess_cosine(v)[0] for v in self.vecs]) if distance == O.COSINE else self.vecs
         self.bits = O.default_bits(dim)
         self.mean, self.m2, self.count = O.train(unit, self.bits)
         self.codes = O.quantize(self.mean, self.m2, self.count, self.bits, unit)
@@ -40,17 +45,21 @@ class TinyTable:
             others = [j for j in range(n) if j != i]
             self.nbrs[i, :len(others)] = others
         self.tids = ((np.arange(n, dtype=np.uint64) + 1) << np.uint64(16)) | np.uint64(1)
-        self.label_off = np.zeros(n + 1, np.uint32)
-        vals = []
+        for i in deleted:
+            self.tids[i] &= ~np.uint64(0xFFFF)
+        self.label_off = self.label_val = None
         self.label_starts = {}
-        for i, ls in enumerate(labels):
-            vals.extend(sorted(set(ls)))
-            self.label_off[i + 1] = len(vals)
-            for l in ls:
-                self.label_starts.setdefault(l, i)
-        self.label_val = np.array(vals, np.int16)
+        if labels is not None:
+            self.label_off = np.zeros(n + 1, np.uint32)
+            vals = []
+            for i, ls in enumerate(labels):
+                vals.extend(sorted(set(ls)))
+                self.label_off[i + 1] = len(vals)
+                for l in ls:
+                    self.label_starts.setdefault(l, i)
+            self.label_val = np.array(vals, np.int16)
         self.oracle = O.OracleIndex(codes=self.codes, nbrs=self.nbrs, heap_tids=self.tids, vecs=self.vecs, mean=self.mean, m2=self.m2,
-                                    count=self.count, bits=self.bits, dim_index=dim, num_neighbors=R, distance_type=O.COSINE,
+                                    count=self.count, bits=self.bits, dim_index=dim, num_neighbors=R, distance_type=distance,
                                     default_start=0, label_off=self.label_off, label_val=self.label_val,
                                     label_starts=self.label_starts)
 
@@ -58,7 +67,7 @@ class TinyTable:
         import pgvectorscale_amd as P
         return P.DiskAnnIndex.upload(ctx, codes=self.codes, nbrs=self.nbrs, heap_tids=self.tids, vecs=self.vecs, mean=self.mean,
                                      m2=self.m2, count=self.count, bits=self.bits, dim_index=self.dim, num_neighbors=self.R,
-                                     distance_type=O.COSINE, default_start=0, label_off=self.label_off, label_val=self.label_val,
+                                     distance_type=self.distance, default_start=0, label_off=self.label_off, label_val=self.label_val,
                                      label_starts=self.label_starts)
 
 
@@ -99,3 +108,58 @@ def test_hip_path_gives_the_reference_counts(gpu_ctx, oracle, table):
         assert scan.xs_recheck == (key is not None)
     scan.endscan()
     ix.close()
+
+
+# (distance, rows, [(query, the row ORDER BY ... LIMIT 1 returns)])
+SANITY = {
+    "test_l2_sanity_check": (O.L2, [[1, 1, 1], [2, 2, 2], [3, 3, 3]], [([1, 1, 1], 0), ([2, 2, 2], 1), ([3, 3, 3], 2)]),
+    "test_ip_sanity_check": (O.IP, [[1, 1, 1], [2, 2, 2], [3, 3, 3]], [([1, 1, 1], 2), ([2, 2, 2], 2), ([3, 3, 3], 2)]),
+}
+# (rows, deleted rows, count of `order by embedding <=> '[0,0,0]'`)
+COUNTS = {
+    "test_empty_table_insert": ([[1, 2, 3], [4, 5, 6], [7, 8, 10]], (), 3),
+    "test_insert_empty_insert": ([[1, 2, 3], [4, 5, 6], [7, 8, 10], [1, 2, 3], [14, 15, 16]], (0, 1, 2), 2),
+}
+
+
+@pytest.mark.parametrize("name", list(SANITY))
+def test_oracle_first_row_of_the_sanity_checks(oracle, name):
+    distance, rows, expect = SANITY[name]
+    t = TinyTable(rows, None, R=10, distance=distance)
+    for q, first in expect:
+        r = t.oracle.scan(np.array(q, np.float32), L=100, rescore=50).gettuple()
+        assert r is not None and r[0] == first
+
+
+@pytest.mark.parametrize("name", list(COUNTS))
+def test_oracle_counts_with_deleted_rows(oracle, name):
+    rows, deleted, count = COUNTS[name]
+    t = TinyTable(rows, None, deleted=deleted)
+    got = drain(t.oracle.scan(np.zeros(3, np.float32), L=100, rescore=50))
+    assert len(got) == count and not ({r[0] for r in got} & set(deleted))
+
+
+@pytest.mark.gpu
+def test_hip_path_on_the_unlabeled_tiny_tables(gpu_ctx, oracle):
+    for name, (distance, rows, expect) in SANITY.items():
+        t = TinyTable(rows, None, R=10, distance=distance)
+        ix = t.upload(gpu_ctx)
+        scan = ix.beginscan()
+        for q, first in expect:
+            scan.rescan(np.array(q, np.float32), search_list_size=100, rescore=50)
+            r = scan.gettuple()
+            assert r is not None and r[1] == first, name
+        scan.endscan()
+        gi, _, _, _ = ix.search_batch(np.array([q for q, _ in expect], np.float32), search_list_size=100, rescore=50, k=1)
+        assert gi[:, 0].tolist() == [f for _, f in expect], name
+        ix.close()
+    for name, (rows, deleted, count) in COUNTS.items():
+        t = TinyTable(rows, None, deleted=deleted)
+        ix = t.upload(gpu_ctx)
+        scan = ix.beginscan()
+        scan.rescan(np.zeros(3, np.float32), search_list_size=100, rescore=50)
+        got = drain(scan)
+        want = drain(t.oracle.scan(np.zeros(3, np.float32), L=100, rescore=50))
+        assert len(got) == count and [r[1] for r in got] == [w[0] for w in want], name
+        scan.endscan()
+        ix.close()

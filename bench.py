@@ -114,9 +114,9 @@ def mx_canary(args, extra_env=None):
            "100,50", "--graph-cache", "none", "--scan-nq", "0", "--cpu-seconds", "3", "--dim", str(args.dim), "--distance",
            args.distance, "--k", str(args.k), "--labels", str(args.labels)]
     try:
-        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)  # (other ranks wait in a broadcast)
     except subprocess.TimeoutExpired:
-        return False, "timed out (300 s)"
+        return False, "timed out (240 s)"
     except Exception as e:
         return False, repr(e)
     ok, why = canary_verdict(r.returncode, r.stdout)
@@ -319,7 +319,7 @@ def main():
         kernel_choice["canary_s"] = round(time.time() - t0, 1)
         log("k_search_mx canary", kernel_choice["canary"])
         try_mx = ok
-        if ok and "VS_MX_GD" not in os.environ:  # the 16-rows-in-flight gather variant is another kernel binary: its own canary
+        if ok and "VS_MX_GD" not in os.environ and kernel_choice["canary_s"] < 150:  # the 16-rows-in-flight gather variant is another kernel binary: its own canary
             ok4, why4 = mx_canary(args, {"VS_MX_GD": "4"})
             kernel_choice["canary_gd4"] = ("passed: " if ok4 else "failed: ") + why4
             try_gd4 = ok4

@@ -754,6 +754,7 @@ def main():
                 "value": round(sample / cpu_t, 1), "unit": "queries/s", "cores": cores, "kind": "port",
                 "sample": f"{sample} of the step's queries, same index/L/rescore, {cores} threads (one query per thread); "
                           f"single-thread latency {cpu1 * 1e3:.2f} ms/query; flat arrays, no PostgreSQL buffer/heap cost",
+                "micro_ns_per_call": O.micro_bench(),  # the reference's criterion bench shapes (benches/distance.rs), one thread
                 "gpu_rows_identical": bool((g_ids == o_ids).all()),
                 "gpu_dist_bit_identical_frac": float((g_dist.view(np.uint32) == o_dist.view(np.uint32)).mean()),
             }

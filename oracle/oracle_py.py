@@ -67,6 +67,8 @@ def lib():
         f.restype = C.c_float
         f.argtypes = [vp, vp, sz]
     L.vso_have_avx2.restype = C.c_int
+    L.vso_micro_bench.restype = C.c_double
+    L.vso_micro_bench.argtypes = [C.c_int, C.c_uint64]
     L.vso_preprocess_cosine.restype = C.c_int
     L.vso_preprocess_cosine.argtypes = [vp, sz]
     L.vso_distance_by_type.restype = C.c_float
@@ -146,6 +148,13 @@ def distance_cosine_unoptimized(a, b): return _dist("vso_distance_cosine_unoptim
 def distance_l2_avx2(a, b): return _dist("vso_distance_l2_avx2", a, b)
 def inner_product_avx2(a, b): return _dist("vso_inner_product_avx2", a, b)
 def have_avx2(): return bool(lib().vso_have_avx2())
+
+
+def micro_bench(iters=200000):
+    """ns per call on the inputs of the reference's criterion benches (benches/distance.rs:144-161,299-338), one thread"""
+    names = ["distance_l2_2000d", "distance_cosine_2000d", "inner_product_2000d", "distance_xor_optimized_1536bit"]
+    return {n: round(float(lib().vso_micro_bench(i, iters * (20 if i == 3 else 1))), 2) for i, n in enumerate(names)}
+
 
 
 def distance_by_type(t, a, b):

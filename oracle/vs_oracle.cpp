@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <chrono>
 #include <cstring>
 #include <limits>
 #include <thread>
@@ -276,6 +277,39 @@ float vso_distance_cosine_unoptimized(const float* a, const float* b, size_t n) 
 }
 
 int vso_have_avx2(void) { return VSO_AVX2; }
+
+/* Micro timings in the style of the reference's criterion benches (benches/distance.rs:144-161: D = 2000 f32 ramps
+ * v+1000.1 / v+2000.2 through distance_l2 / distance_cosine / inner product; :299-338: 1536-bit patterns i%2==0 vs i%3==0
+ * through distance_xor_optimized).  which: 0 = l2, 1 = cosine, 2 = inner product, 3 = xor.  Returns ns per call. */
+double vso_micro_bench(int which, uint64_t iters) {
+    std::vector<float> r(2000), l(2000);
+    for (int v = 0; v < 2000; ++v) {
+        r[v] = (float)v + 1000.1f;
+        l[v] = (float)v + 2000.2f;
+    }
+    uint64_t a[24] = {0}, b[24] = {0};
+    for (int i = 0; i < 1536; ++i) {
+        if (i % 2 == 0) a[i / 64] |= 1ull << (i % 64);
+        if (i % 3 == 0) b[i / 64] |= 1ull << (i % 64);
+    }
+    const float* rp = r.data();
+    const float* lp = l.data();
+    const uint64_t *ap = a, *bp = b;
+    double sink = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint64_t it = 0; it < iters; ++it) {
+        __asm__ volatile("" : "+r"(rp), "+r"(lp), "+r"(ap), "+r"(bp) : : "memory");  // black_box
+        switch (which) {
+            case 0: sink += vso_distance_l2(rp, lp, 2000); break;
+            case 1: sink += vso_distance_cosine(rp, lp, 2000); break;
+            case 2: sink += vso_inner_product(rp, lp, 2000); break;
+            default: sink += (double)vso_distance_xor(ap, bp, 24); break;
+        }
+    }
+    const auto t1 = std::chrono::steady_clock::now();
+    __asm__ volatile("" : : "r"(&sink) : "memory");
+    return std::chrono::duration<double, std::nano>(t1 - t0).count() / (double)(iters ? iters : 1);
+}
 
 #if VSO_AVX2
 static inline float hadd_ps_avx2(__m256 a) {

@@ -152,3 +152,10 @@ def test_preprocess_cosine(oracle):
     out, ch = O.preprocess_cosine(v)
     assert ch and abs(float(np.dot(out, out)) - 1) < 1e-5
     assert not O.preprocess_cosine(out)[1]               # idempotent (debug_assert :246-249)
+
+
+def test_micro_bench_runs(oracle):
+    """the timing loop over the reference's criterion bench inputs (benches/distance.rs:144-161,299-338) that bench.py reports"""
+    m = oracle.micro_bench(iters=2000)
+    assert set(m) == {"distance_l2_2000d", "distance_cosine_2000d", "inner_product_2000d", "distance_xor_optimized_1536bit"}
+    assert all(0 < v < 1e6 for v in m.values())

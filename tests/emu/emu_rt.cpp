@@ -222,15 +222,33 @@ static void run_block(Worker& wk, Idx bid, dim3 block, dim3 grid, std::vector<Fi
     }
     // VS_EMU_ORDER=reverse runs the lanes highest first: anything two lanes exchange through memory WITHOUT a rendezvous
     // in between then sees the opposite order, so a result that survives both orders does not depend on it
-    static const bool reverse = [] {
+    // VS_EMU_ORDER=shuffle: another pseudo-random permutation of the lanes in every scheduling pass
+    static const char order = [] {
         const char* e = getenv("VS_EMU_ORDER");
-        return e && e[0] == 'r';
+        return e ? e[0] : 'f';
     }();
-    uint32_t done = 0;
+    const bool reverse = order == 'r';
+    uint32_t done = 0, pass = 0;
     while (done < nthreads) {
         bool progress = false;
+        uint32_t stride = 1, offset = 0;
+        if (order == 's') {
+            static const uint32_t primes[] = {7919, 104729, 15485863, 32452843, 49979687, 67867967};
+            ++pass;
+            stride = primes[pass % 6] % nthreads;
+            auto gcd = [](uint32_t a, uint32_t b) {
+                while (b) {
+                    const uint32_t r = a % b;
+                    a = b;
+                    b = r;
+                }
+                return a;
+            };
+            while (stride == 0 || gcd(stride, nthreads) != 1) ++stride;
+            offset = (pass * 2654435761u >> 7) % nthreads;
+        }
         for (uint32_t tt = 0; tt < nthreads; ++tt) {
-            const uint32_t t = reverse ? nthreads - 1 - tt : tt;
+            const uint32_t t = reverse ? nthreads - 1 - tt : (uint32_t)(((uint64_t)tt * stride + offset) % nthreads);
             Fiber& f = fibers[t];
             if (f.state == 3) continue;
             if (f.state == 1 && f.wave->gen == f.wait_gen) continue;

@@ -111,10 +111,73 @@ def plain_case(ctx, O, case_seed, verbose):
         ix.close()
 
 
+def pages_case(ctx, O, case_seed, verbose):
+    """index relation pages (written byte by byte in the reference's layout, oracle/pages_py.py) -> host decode and device
+    decode -> the arrays the pages were written from, and scans equal to the oracle's"""
+    from helpers import TestIndex
+    from oracle import pages_py as PG
+    from pgvectorscale_amd import _lib
+    from pgvectorscale_amd.pages import DevicePages, IndexPages
+    rng = np.random.default_rng(case_seed)
+    dim = int(rng.choice([8, 33, 64, 128, 200, 768]))
+    n = int(rng.choice([1, 3, 60, 400, 1300]))
+    R = int(rng.choice([4, 15, 24, 50]))
+    n_labels = int(rng.choice([0, 0, 5, 32]))
+    ti = TestIndex(n=n, dim_full=dim, R=R, distance=int(rng.choice([0, 1])), seed=int(rng.integers(1, 1 << 30)), kind="gauss",
+                   n_labels=n_labels, deleted_frac=float(rng.choice([0.0, 0.2])), L_build=30, label_zipf=bool(rng.random() < 0.5))
+    zp = int(rng.choice([0, 7, 100]))
+    mf = bool(rng.random() < 0.5)
+    where = f"pages case {case_seed}: n={n} dim={dim} bits={ti.bits} R={R} labels={n_labels} zero_page_every={zp} means_first={mf}"
+    if verbose:
+        print(where, flush=True)
+    for v in TUNING:
+        os.environ.pop(v, None)
+    w = PG.write_index(codes=ti.codes, nbrs=ti.nbrs, heap_tids=ti.tids, mean=ti.mean, m2=ti.m2, count=ti.count, label_off=ti.label_off,
+                       label_val=ti.label_val, zero_page_every=zp, means_first=mf)
+    data = w.rel.tobytes()
+    nblk = len(w.rel.pages)
+    cut = int(rng.integers(0, nblk + 1)) * PG.BLCKSZ
+    starts = {l: w.node_ptrs[v] for l, v in ti.label_starts.items()}
+    common = dict(dim_index=ti.dim_index, bits=ti.bits, distance_type=ti.distance, default_start=w.node_ptrs[ti.start],
+                  quantizer_metadata=w.means_ptr, vecs=ti.vecs, label_starts=starts)
+    hp = IndexPages(has_labels=bool(n_labels))
+    hp.add(data[:cut])
+    hp.add(data[cut:])
+    hp.finish()
+    ix_h = hp.upload(ctx, **common)
+    hp.close()
+    dp = DevicePages(ctx, nblk)
+    dp.add(data[:cut])
+    dp.add(data[cut:])
+    ix_d = dp.build(words=ti.codes.shape[1], num_neighbors=R, has_labels=bool(n_labels), **common)
+    dp.close()
+    try:
+        q = ti.queries(9, seed=int(rng.integers(1, 1 << 30)), kind="gauss")
+        keys = None
+        if n_labels:
+            keys = [[int(x) for x in rng.integers(1, n_labels + 1, int(rng.integers(1, 3)))] for _ in range(9)]
+        oi, od, ost = ti.oracle.search_batch(q, L=40, rescore=20, k=10, qlabels=keys)
+        for name, ix in (("host decode", ix_h), ("device decode", ix_d)):
+            dev = ix.download()
+            assert (dev["codes"] == ti.codes).all() and (dev["nbrs"] == ti.nbrs).all() and (dev["heap_tids"] == ti.tids).all(), \
+                f"{where}: {name}: arrays differ"
+            if n_labels:
+                lo = ctx.download(ix.array(_lib.ARR_LABEL_OFF)[0], np.empty(n + 1, np.uint32))
+                lv = ctx.download(ix.array(_lib.ARR_LABEL_VAL)[0], np.empty(max(len(ti.label_val), 1), np.int16))[:len(ti.label_val)]
+                assert (lo == ti.label_off).all() and (lv == ti.label_val).all(), f"{where}: {name}: label sets differ"
+            gi, gt, gd, gst = ix.search_batch(q, search_list_size=40, rescore=20, k=10, qlabels=keys)
+            assert (gi == oi).all() and close(gd, od), f"{where}: {name}: rows differ"
+    finally:
+        ix_h.close()
+        ix_d.close()
+
+
 def one_case(ctx, O, case_seed, verbose):
     from helpers import TestIndex
     if case_seed % 5 == 4:
         return plain_case(ctx, O, case_seed, verbose)
+    if case_seed % 7 == 6:
+        return pages_case(ctx, O, case_seed, verbose)
     rng = np.random.default_rng(case_seed)
     dim_full = int(rng.choice([3, 8, 17, 32, 48, 64, 65, 100, 128, 200, 384, 768]))
     bits = int(rng.choice([0, 1, 2, 3]))  # 0 = the reference's default for the dimension count

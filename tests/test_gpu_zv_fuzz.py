@@ -1,5 +1,5 @@
 """A fixed handful of the cases scripts/fuzz_emu.py draws (random geometry x random scan parameters x four of the library's
-kernels / regimes each, `plain` storage every fifth case, the amgettuple mirror on top): everything must equal the oracle.
+kernels / regimes each, `plain` storage every fifth case, the amgettuple mirror on top, page-path round trips every seventh): everything must equal the oracle.
 The open-ended run is `python scripts/fuzz_emu.py --seconds N` (interpreter) or `--gpu` (device)."""
 import os
 import sys
@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.join(ROOT, "scripts"))
 pytestmark = [pytest.mark.gpu, pytest.mark.timeout(900)]
 
 
-@pytest.mark.parametrize("case_seed", [7000001, 7000002, 7000003, 7000004, 7000005, 7000006, 7000007, 7000008, 7000009, 7000014])
+@pytest.mark.parametrize("case_seed", [7000001, 7000002, 7000003, 7000004, 7000005, 7000006, 7000007, 7000008, 7000009, 7000014, 7000013, 7000020])
 def test_fuzz_case(gpu_ctx, oracle, case_seed):
     import fuzz_emu
     saved = {v: os.environ.get(v) for v in fuzz_emu.TUNING}

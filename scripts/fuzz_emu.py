@@ -172,8 +172,89 @@ def pages_case(ctx, O, case_seed, verbose):
         ix_d.close()
 
 
+def build_case(ctx, O, case_seed, verbose):
+    """index manufacture on the device: SBQ training and corpus quantisation bit for bit against the oracle; the graph the
+    device builds is well formed, identical when built twice, and searched identically by the device and the oracle"""
+    import pgvectorscale_amd as P
+    from helpers import make_vectors
+    rng = np.random.default_rng(case_seed)
+    dim = int(rng.choice([8, 40, 64, 96, 128, 384]))
+    bits = int(rng.choice([0, 1, 2, 3]))
+    if bits and dim * bits > 1200:
+        bits = 1
+    n = int(rng.choice([1, 2, 50, 700, 2500]))
+    R = int(rng.choice([8, 16, 32, 50]))
+    distance = int(rng.choice([0, 1, 2]))
+    dim_index = None if rng.random() < 0.7 else int(rng.integers(2, dim))
+    kind = str(rng.choice(["uniform", "gauss", "clustered"]))
+    Lb = int(rng.choice([10, 40, 100]))
+    where = f"build case {case_seed}: n={n} dim={dim}/{dim_index} bits={bits} R={R} dist={distance} {kind} L_build={Lb}"
+    if verbose:
+        print(where, flush=True)
+    for v in TUNING:
+        os.environ.pop(v, None)
+    X = make_vectors(n, dim, int(rng.integers(1, 1 << 30)), kind)
+    scaled = kind == "gauss" and n > 8  # rows of very different norms: the cosine rescale path of the quantiser runs; such a
+    if scaled:                           # corpus prunes to a sparse graph (the oracle's builder too), so no navigability claim
+        X[::3] *= 2.5
+        X[7] = 0
+    graphs = []
+    for rep in range(2):
+        ix = P.DiskAnnIndex.alloc(ctx, n=n, dim_full=dim, dim_index=dim_index, bits=bits or None, num_neighbors=R, distance_type=distance)
+        try:
+            ctx.upload(ix.array(P._lib.ARR_VECS)[0], X) if ix.array(P._lib.ARR_VECS)[1] == dim else None
+            if ix.array(P._lib.ARR_VECS)[1] != dim:  # padded rows on the device
+                vp, stride = ix.array(P._lib.ARR_VECS)
+                Xp = np.zeros((n, stride), np.float32)
+                Xp[:, :dim] = X
+                ctx.upload(vp, Xp)
+            ix.refresh_norms()
+            ix.sbq_train()
+            ix.sbq_quantize_corpus()
+            ix.build_graph(search_list_size=Lb, max_alpha=1.2)
+            host = ix.download(vecs=True)
+            assert (host["vecs"] == X).all(), f"{where}: vectors did not round-trip"
+            di = dim_index or dim
+            b = ix.desc.bits
+            sl = np.ascontiguousarray(X[:, :di]).copy()
+            if distance == 0:
+                for i in range(n):
+                    sl[i] = O.preprocess_cosine(sl[i])[0]
+            mean, m2, cnt = O.train(sl, b)
+            gmean, gm2, gcnt = ix.get_quantizer()
+            assert gcnt == cnt == n and gmean.tobytes() == mean.tobytes(), f"{where}: SBQ means differ"
+            if b > 1:
+                assert gm2.tobytes() == m2.tobytes(), f"{where}: SBQ m2 differs"
+            assert (host["codes"] == O.quantize(mean, m2, cnt, b, sl)).all(), f"{where}: codes differ"
+            nb = host["nbrs"]
+            graphs.append(nb.copy())
+            for i in range(n):
+                row = nb[i]
+                live = row[row != 0xFFFFFFFF]
+                assert (row[:len(live)] != 0xFFFFFFFF).all() and len(set(live.tolist())) == len(live) and i not in live \
+                    and (live < n).all(), f"{where}: neighbor list of node {i} malformed: {row}"
+            if rep == 0:
+                oidx = O.OracleIndex(codes=host["codes"], nbrs=nb, heap_tids=host["heap_tids"], vecs=X, mean=mean, m2=m2, count=cnt,
+                                     bits=b, dim_index=di, num_neighbors=R, distance_type=distance, default_start=ix.desc.default_start)
+                q = make_vectors(16, dim, int(rng.integers(1, 1 << 30)), kind)
+                gi, gt, gd, gst = ix.search_batch(q, search_list_size=50, rescore=25, k=10)
+                oi, od, ost = oidx.search_batch(q, L=50, rescore=25, k=10)
+                assert (gi == oi).all() and close(gd, od), f"{where}: rows on the device-built graph differ"
+                if n >= 50 and not scaled:  # navigable: an exhaustive scan reaches every node (AM/build.rs:1254-1269)
+                    sc = oidx.scan(q[0], L=2, rescore=0)
+                    seen = 0
+                    while sc.next_sbq() is not None:
+                        seen += 1
+                    assert seen == n, f"{where}: exhaustive scan reached {seen} of {n} nodes"
+        finally:
+            ix.close()
+    assert (graphs[0] == graphs[1]).all(), f"{where}: the build is not deterministic"
+
+
 def one_case(ctx, O, case_seed, verbose):
     from helpers import TestIndex
+    if case_seed % 11 == 10:
+        return build_case(ctx, O, case_seed, verbose)
     if case_seed % 5 == 4:
         return plain_case(ctx, O, case_seed, verbose)
     if case_seed % 7 == 6:

@@ -325,6 +325,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--only", type=int, default=None, help="run this one case seed")
     ap.add_argument("--gpu", action="store_true")
+    ap.add_argument("--kind", default="any", choices=["any", "search", "plain", "pages", "build"], help="only cases of this kind")
     ap.add_argument("-v", "--verbose", action="store_true")
     args = ap.parse_args()
     from pgvectorscale_amd import _lib
@@ -338,9 +339,14 @@ def main():
     t0 = time.time()
     cases = failures = 0
     seeds = [args.only] if args.only is not None else (args.seed * 1_000_000 + i for i in range(1 << 30))
+    def kind_of(cs):
+        return "build" if cs % 11 == 10 else "plain" if cs % 5 == 4 else "pages" if cs % 7 == 6 else "search"
+
     for cs in seeds:
         if args.only is None and time.time() - t0 > args.seconds:
             break
+        if args.only is None and args.kind != "any" and kind_of(cs) != args.kind:
+            continue
         try:
             one_case(ctx, O, cs, args.verbose or args.only is not None)
         except AssertionError as e:

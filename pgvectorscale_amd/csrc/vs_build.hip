@@ -352,7 +352,7 @@ static int build_graph_impl(vs_index* ix, uint32_t L, double max_alpha_d, uint32
     uint32_t vmax = std::max<uint32_t>(round_up_u32(3 * L + 64, 64), 128);      // visited list cap (candidates of prune)
     uint32_t hl = 512, lh = 0;                                       // LDS-resident parts of the search state
     uint32_t hcap = (2 * L + 64) * R;                                // heap capacity (global spill beyond hl)
-    uint32_t hashcap = next_pow2_u32(2ull * hcap);
+    uint32_t hashcap = std::max<uint32_t>(next_pow2_u32(2ull * hcap), 256);
     uint32_t cmax = 1;
     while (cmax < R + 128) cmax <<= 1;  // back-edge candidate cap (pow2, >= R + new sources kept)
     const size_t code_bytes = (size_t)stride * 8;
@@ -394,9 +394,9 @@ static int build_graph_impl(vs_index* ix, uint32_t L, double max_alpha_d, uint32
         f.L = L;
         f.M = vmax;
         f.hl = 1023;
-        f.hcap = hcap;
-        f.gstride = round_up_u32(hcap - f.hl + 2, 2);
-        f.lh = lds_table ? round_up_u32(typ_ins, 64) : 0;
+        f.hcap = std::max(hcap, f.hl);  // small L * R: the whole heap fits the LDS part (the launcher wants hcap >= hl)
+        f.gstride = round_up_u32(f.hcap - f.hl + 2, 2);
+        f.lh = lds_table ? std::max<uint32_t>(round_up_u32(typ_ins, 64), 256) : 0;
         f.gcap = next_pow2_u32(std::max<uint32_t>(4 * typ_ins, 1024));
         f.sb = 0;
         while ((1ull << f.sb) < (uint64_t)f.lh + f.gcap) f.sb++;
@@ -438,7 +438,7 @@ static int build_graph_impl(vs_index* ix, uint32_t L, double max_alpha_d, uint32
             s.vcap = vmax + 64;
             s.lh = lh;
             s.hashcap = hashcap;
-            s.g0 = 4096;
+            s.g0 = std::min<uint32_t>(4096, hashcap);  // first level of the dedup ladder (small L * R: the whole table)
             s.qcodes = qcodes;
             s.qlabels = nullptr;
             s.qlabel_off = nullptr;
@@ -451,7 +451,7 @@ static int build_graph_impl(vs_index* ix, uint32_t L, double max_alpha_d, uint32
             s.status = B.status;
             if (use_fast && attempt == 0) {
                 f.nq = bn;
-                f.hcap = hcap;
+                f.hcap = std::max(std::min(hcap, f.hl + f.gstride - 2), f.hl);  // (the spill area was sized before the loop)
                 f.qcodes = s.qcodes;
                 f.qlabels = nullptr;
                 f.qlabel_off = nullptr;

@@ -172,6 +172,20 @@ def pages_case(ctx, O, case_seed, verbose):
         ix_d.close()
 
 
+def reachable(nbrs, start):
+    n = nbrs.shape[0]
+    seen = np.zeros(n, bool)
+    seen[start] = True
+    stack = [int(start)]
+    while stack:
+        v = stack.pop()
+        for u in nbrs[v]:
+            if u != 0xFFFFFFFF and not seen[u]:
+                seen[u] = True
+                stack.append(int(u))
+    return int(seen.sum())
+
+
 def build_case(ctx, O, case_seed, verbose):
     """index manufacture on the device: SBQ training and corpus quantisation bit for bit against the oracle; the graph the
     device builds is well formed, identical when built twice, and searched identically by the device and the oracle"""
@@ -183,11 +197,11 @@ def build_case(ctx, O, case_seed, verbose):
     if bits and dim * bits > 1200:
         bits = 1
     n = int(rng.choice([1, 2, 50, 700, 2500]))
-    R = int(rng.choice([8, 16, 32, 50]))
+    R = int(rng.choice([4, 8, 16, 32, 50]))
     distance = int(rng.choice([0, 1, 2]))
     dim_index = None if rng.random() < 0.7 else int(rng.integers(2, dim))
     kind = str(rng.choice(["uniform", "gauss", "clustered"]))
-    Lb = int(rng.choice([10, 40, 100]))
+    Lb = int(rng.choice([1, 10, 40, 100]))
     where = f"build case {case_seed}: n={n} dim={dim}/{dim_index} bits={bits} R={R} dist={distance} {kind} L_build={Lb}"
     if verbose:
         print(where, flush=True)
@@ -240,12 +254,16 @@ def build_case(ctx, O, case_seed, verbose):
                 gi, gt, gd, gst = ix.search_batch(q, search_list_size=50, rescore=25, k=10)
                 oi, od, ost = oidx.search_batch(q, L=50, rescore=25, k=10)
                 assert (gi == oi).all() and close(gd, od), f"{where}: rows on the device-built graph differ"
-                if n >= 50 and not scaled:  # navigable: an exhaustive scan reaches every node (AM/build.rs:1254-1269)
-                    sc = oidx.scan(q[0], L=2, rescore=0)
-                    seen = 0
-                    while sc.next_sbq() is not None:
-                        seen += 1
-                    assert seen == n, f"{where}: exhaustive scan reached {seen} of {n} nodes"
+                # navigable: an exhaustive scan reaches every node (AM/build.rs:1254-1269) wherever the reference's own
+                # sequential algorithm (the oracle's builder) achieves that on these codes, and never fewer nodes than it does
+                sc = oidx.scan(q[0], L=2, rescore=0)
+                seen = 0
+                while sc.next_sbq() is not None:
+                    seen += 1
+                onb, ostart = O.build_graph(host["codes"], num_neighbors=R, search_list_size=Lb)
+                want = reachable(onb, ostart)
+                assert seen == reachable(nb, ix.desc.default_start), f"{where}: the scan and a BFS disagree"
+                assert seen >= want, f"{where}: exhaustive scan reached {seen} of {n} nodes, the sequential builder's graph {want}"
         finally:
             ix.close()
     assert (graphs[0] == graphs[1]).all(), f"{where}: the build is not deterministic"

@@ -102,3 +102,73 @@ def test_gpu_built_graph_quality_and_search_parity(gpu_ctx, oracle):
         seen += 1
     assert seen == n
     ix.close()
+
+
+def _reach(nbrs, start):
+    n = nbrs.shape[0]
+    seen = np.zeros(n, bool)
+    seen[start] = True
+    stack = [int(start)]
+    while stack:
+        v = stack.pop()
+        for u in nbrs[v]:
+            if u != 0xFFFFFFFF and not seen[u]:
+                seen[u] = True
+                stack.append(int(u))
+    return int(seen.sum())
+
+
+def test_duplicate_vectors_stay_reachable(gpu_ctx, oracle):
+    """Two identical vectors inserted in the same batch do not see each other; the repair pass re-inserts the one that ended
+    up without an in-edge.  700 rows with only 242 distinct 8-bit codes: every row must have an in-edge, and at least as many
+    rows must be reachable as in the graph of the sequential (reference-order) builder.  (Found by scripts/fuzz_emu.py: 56 unreachable rows before the repair pass.)"""
+    import pgvectorscale_amd as P
+    from helpers import make_vectors
+    n, dim, R = 700, 8, 8
+    X = make_vectors(n, dim, 20, "uniform")
+    ix = P.DiskAnnIndex.alloc(gpu_ctx, n=n, dim_full=dim, bits=1, num_neighbors=R, distance_type=P.VS_L2)
+    vp, stride = ix.array(P._lib.ARR_VECS)
+    Xp = np.zeros((n, stride), np.float32)
+    Xp[:, :dim] = X
+    gpu_ctx.upload(vp, Xp)
+    ix.refresh_norms()
+    ix.sbq_train()
+    ix.sbq_quantize_corpus()
+    ix.build_graph(search_list_size=40, max_alpha=1.2)
+    host = ix.download()
+    assert len({c.tobytes() for c in host["codes"]}) < n // 2
+    onb, ostart = oracle.build_graph(host["codes"], num_neighbors=R, search_list_size=40)
+    ind = np.bincount(host["nbrs"][host["nbrs"] != 0xFFFFFFFF], minlength=n)
+    assert (ind[1:] > 0).all()  # every row but the entry point has an in-edge
+    got, ref = _reach(host["nbrs"], ix.desc.default_start), _reach(onb, ostart)
+    assert got >= ref and got >= n - 2, (got, ref)  # (at R = 8 the sequential builder itself can miss a row or two)
+    ix.close()
+
+
+@pytest.mark.parametrize("n,R,L", [(60, 8, 10), (2, 8, 10), (300, 4, 1)])
+def test_build_with_a_small_search_list(gpu_ctx, oracle, n, R, L):
+    """(2L + 64) * R below the LDS heap top of the build-mode search: capacities must not wrap (they did: a 16 TB hipMalloc)"""
+    import pgvectorscale_amd as P
+    from helpers import make_vectors
+    dim = 64
+    X = make_vectors(n, dim, 21, "gauss")
+    ix = P.DiskAnnIndex.alloc(gpu_ctx, n=n, dim_full=dim, num_neighbors=R, distance_type=P.VS_COSINE)
+    gpu_ctx.upload(ix.array(P._lib.ARR_VECS)[0], X)
+    ix.refresh_norms()
+    ix.sbq_train()
+    ix.sbq_quantize_corpus()
+    ix.build_graph(search_list_size=L, max_alpha=1.2)
+    host = ix.download()
+    nb = host["nbrs"]
+    for i in range(n):
+        live = nb[i][nb[i] != 0xFFFFFFFF]
+        assert len(set(live.tolist())) == len(live) and i not in live and (live < n).all()
+    mean, m2, cnt = ix.get_quantizer()
+    oidx = oracle.OracleIndex(codes=host["codes"], nbrs=nb, heap_tids=host["heap_tids"], vecs=X, mean=mean, m2=m2, count=cnt,
+                              bits=ix.desc.bits, dim_index=dim, num_neighbors=R, distance_type=oracle.COSINE,
+                              default_start=ix.desc.default_start)
+    q = make_vectors(8, dim, 22, "gauss")
+    gi, _, gd, _ = ix.search_batch(q, search_list_size=20, rescore=10, k=5)
+    oi, od, _ = oidx.search_batch(q, L=20, rescore=10, k=5)
+    assert (gi == oi).all()
+    ix.close()

@@ -172,6 +172,75 @@ def pages_case(ctx, O, case_seed, verbose):
         ix_d.close()
 
 
+def kernels_case(ctx, O, case_seed, verbose):
+    """the standalone kernels of the C ABI: vs_quantize, vs_hamming_gather, vs_rerank, vs_scan_topk, vs_bruteforce_topk"""
+    from helpers import TestIndex
+    rng = np.random.default_rng(case_seed)
+    dim = int(rng.choice([3, 8, 33, 64, 100, 128, 384, 768, 1536]))
+    bits = int(rng.choice([0, 1, 2, 3]))
+    if bits and dim * bits > 1600:
+        bits = 1
+    n = int(rng.choice([1, 7, 100, 1000, 5000]))
+    distance = int(rng.choice([0, 1, 2]))
+    kind = str(rng.choice(["uniform", "gauss", "clustered"]))
+    ti = TestIndex(n=n, dim_full=dim, bits=bits or None, R=8, distance=distance, seed=int(rng.integers(1, 1 << 30)), kind=kind, L_build=10)
+    if kind == "gauss" and n > 8:  # rows of very different norms, a zero row
+        ti.vecs[::3] *= 2.5
+        ti.vecs[5] = 0
+    where = f"kernels case {case_seed}: n={n} dim={dim} bits={ti.bits} dist={distance} {kind}"
+    if verbose:
+        print(where, flush=True)
+    for v in TUNING:
+        os.environ.pop(v, None)
+    ix = ti.upload(ctx)
+    try:
+        nq = int(rng.choice([1, 5, 40]))
+        Q = ti.queries(nq, seed=int(rng.integers(1, 1 << 30)), kind=kind)
+        Q[0, 0] = np.float32("inf") if rng.random() < 0.1 else Q[0, 0]
+        if rng.random() < 0.1:
+            Q[-1] = np.float32("nan")
+        # SbqQuantizer::quantize
+        qc = ix.quantize(Q)
+        assert (qc == O.quantize(ti.mean, ti.m2, ti.count, ti.bits, Q)).all(), f"{where}: vs_quantize"
+        # distance_xor_optimized over gathered nodes
+        lists = [rng.integers(0, n, int(rng.choice([0, 1, 9, 130]))).astype(np.uint32) for _ in range(nq)]
+        got = ix.hamming_gather(qc, lists)
+        for i in range(nq):
+            want = np.array([O.distance_xor(qc[i], ti.codes[v]) for v in lists[i]], np.uint32)
+            assert (got[i] == want).all(), f"{where}: vs_hamming_gather query {i}"
+        # exact (hamming, id) top-k of the flat scan
+        k = int(rng.choice([1, 10, 64]))
+        ids, ham = ix.scan_topk(qc, k)
+        wi, wh = O.hamming_scan_topk(ti.codes, qc, k)
+        assert (ids == wi).all() and (ham == wh).all(), f"{where}: vs_scan_topk k={k}"
+        # full-precision distances in the reference's accumulation order (finite queries only)
+        fin = [i for i in range(nq) if np.isfinite(Q[i]).all()]
+        if fin:
+            Qf = Q[fin]
+            rl = [lists[i] for i in fin]
+            gotd = ix.rerank(Qf, rl)
+            for a, qi in enumerate(fin):
+                q = O.preprocess_cosine(Q[qi])[0] if distance == 0 else Q[qi]
+                for j, node in enumerate(rl[a]):
+                    v = O.preprocess_cosine(ti.vecs[node])[0] if distance == 0 else ti.vecs[node]
+                    want = O.distance_by_type(distance, v, q)
+                    assert np.float32(gotd[a][j]).tobytes() == np.float32(want).tobytes(), \
+                        f"{where}: vs_rerank query {qi} node {node}: {gotd[a][j]} vs {want}"
+            dq = ctx.alloc(Qf.nbytes)
+            ctx.upload(dq, Qf)
+            kb = min(k, 32)
+            bi, bd = ix.bruteforce_topk(dq, len(Qf), kb)
+            ctx.free(dq)
+            # the oracle's brute force scores the uploaded vectors (ti.oracle holds the unmodified copy: rebuild its view)
+            oidx = O.OracleIndex(codes=ti.codes, nbrs=ti.nbrs, heap_tids=ti.tids, vecs=ti.vecs, mean=ti.mean, m2=ti.m2, count=ti.count,
+                                 bits=ti.bits, dim_index=ti.dim_index, num_neighbors=ti.R, distance_type=distance, default_start=ti.start)
+            oi, od = oidx.bruteforce(Qf, k=kb)
+            assert (bi == oi).all(), f"{where}: vs_bruteforce_topk ids"
+            assert (bd.view(np.uint32) == np.asarray(od, np.float32).view(np.uint32)).all(), f"{where}: vs_bruteforce_topk distances"
+    finally:
+        ix.close()
+
+
 def reachable(nbrs, start):
     n = nbrs.shape[0]
     seen = np.zeros(n, bool)
@@ -273,6 +342,8 @@ def one_case(ctx, O, case_seed, verbose):
     from helpers import TestIndex
     if case_seed % 11 == 10:
         return build_case(ctx, O, case_seed, verbose)
+    if case_seed % 13 == 12:
+        return kernels_case(ctx, O, case_seed, verbose)
     if case_seed % 5 == 4:
         return plain_case(ctx, O, case_seed, verbose)
     if case_seed % 7 == 6:
@@ -343,7 +414,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--only", type=int, default=None, help="run this one case seed")
     ap.add_argument("--gpu", action="store_true")
-    ap.add_argument("--kind", default="any", choices=["any", "search", "plain", "pages", "build"], help="only cases of this kind")
+    ap.add_argument("--kind", default="any", choices=["any", "search", "plain", "pages", "build", "kernels"], help="only cases of this kind")
     ap.add_argument("-v", "--verbose", action="store_true")
     args = ap.parse_args()
     from pgvectorscale_amd import _lib
@@ -358,7 +429,8 @@ def main():
     cases = failures = 0
     seeds = [args.only] if args.only is not None else (args.seed * 1_000_000 + i for i in range(1 << 30))
     def kind_of(cs):
-        return "build" if cs % 11 == 10 else "plain" if cs % 5 == 4 else "pages" if cs % 7 == 6 else "search"
+        return ("build" if cs % 11 == 10 else "kernels" if cs % 13 == 12 else "plain" if cs % 5 == 4 else "pages" if cs % 7 == 6
+                else "search")
 
     for cs in seeds:
         if args.only is None and time.time() - t0 > args.seconds:

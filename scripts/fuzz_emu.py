@@ -406,6 +406,18 @@ def one_case(ctx, O, case_seed, verbose):
             assert (gi2 == si).all() and (gh2 == sh).all(), f"{where}: stream differs"
             assert gst2["candidate_nodes"] == sst["candidate_nodes"], f"{where}: stream counters differ"
             gettuple_mirror(ix, ti.oracle, q, keys, L, rescore, np.random.default_rng(case_seed + 1), where, exact_dist=False)
+            if reg is regimes[0] and n > 1:  # tuples deleted after the upload (vs_index_mark_deleted): skipped by the scans from now on
+                dead = np.unique(rng.integers(0, n, max(1, n // 7))).astype(np.uint32)
+                ix.mark_deleted(dead)
+                tids2 = ti.tids.copy()
+                tids2[dead] &= ~np.uint64(0xFFFF)
+                o2 = O.OracleIndex(codes=ti.codes, nbrs=ti.nbrs, heap_tids=tids2, vecs=ti.vecs, mean=ti.mean, m2=ti.m2, count=ti.count,
+                                   bits=ti.bits, dim_index=ti.dim_index, num_neighbors=ti.R, distance_type=ti.distance,
+                                   default_start=ti.start, label_off=ti.label_off, label_val=ti.label_val, label_starts=ti.label_starts)
+                gi3, gt3, gd3, _ = ix.search_batch(q, search_list_size=L, rescore=rescore, k=k, qlabels=keys)
+                oi3, od3, _ = o2.search_batch(q, L=L, rescore=rescore, k=k, qlabels=keys)
+                assert (gi3 == oi3).all() and close(gd3, od3), f"{where}: rows after vs_index_mark_deleted differ"
+                assert not (set(gi3.ravel().tolist()) & set(dead.tolist())), f"{where}: a deleted tuple was returned"
         finally:
             ix.close()
     return desc

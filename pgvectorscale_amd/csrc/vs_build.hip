@@ -309,6 +309,14 @@ __global__ void k_mark_pointed_at(const uint32_t* __restrict__ nbrs, uint32_t nb
     if (v != VS_INVALID_NODE) mark[v] = 1;
 }
 
+__global__ void k_count_pointed_at(const uint32_t* __restrict__ nbrs, uint32_t nbr_stride, uint32_t R, uint32_t n,
+                                   uint32_t* __restrict__ indeg) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)n * R) return;
+    const uint32_t v = nbrs[(i / R) * nbr_stride + (i % R)];
+    if (v != VS_INVALID_NODE) atomicAdd(&indeg[v], 1u);
+}
+
 __global__ void k_gather_codes(const uint64_t* __restrict__ codes, uint32_t stride, const uint32_t* __restrict__ ids, uint32_t m,
                                uint64_t* __restrict__ out) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -528,7 +536,7 @@ static int build_graph_impl(vs_index* ix, uint32_t L, double max_alpha_d, uint32
         std::vector<uint8_t> mark(n);
         std::vector<uint32_t> orphans;
         size_t prev = SIZE_MAX;
-        for (int round = 0; round < 3; ++round) {
+        for (int round = 0;; ++round) {
             VS_HIP(hipMemsetAsync(B.mark, 0, n, st));
             const size_t cells = (size_t)n * R;
             hipLaunchKernelGGL(k_mark_pointed_at, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, ix->nbrs, ix->nbr_stride, R, n,
@@ -539,7 +547,7 @@ static int build_graph_impl(vs_index* ix, uint32_t L, double max_alpha_d, uint32
             orphans.clear();
             for (uint32_t i = 1; i < n; ++i)  // node 0 is the entry point
                 if (!mark[i]) orphans.push_back(i);
-            if (orphans.empty() || orphans.size() >= prev) break;  // done, or no longer shrinking
+            if (orphans.empty() || orphans.size() >= prev || round == 3) break;  // done, no longer shrinking, or three rounds spent
             prev = orphans.size();
             for (size_t o0 = 0; o0 < orphans.size(); o0 += batch_max) {
                 const uint32_t m = (uint32_t)std::min<size_t>(batch_max, orphans.size() - o0);
@@ -551,6 +559,49 @@ static int build_graph_impl(vs_index* ix, uint32_t L, double max_alpha_d, uint32
                 VS_TRY(insert_batch(B.rep_codes, B.rep_ids, 0, m));
                 VS_HIP(hipStreamSynchronize(st));  // `orphans` must outlive the copy
             }
+        }
+        // Whoever is still without an in-edge (its only out-neighbors are full and prune it every time) is given one by
+        // hand: it takes a slot in the list of its closest out-neighbor — a free one, else that of the last entry that is
+        // pointed at from elsewhere too.  A handful of nodes at most, so this runs on the host.
+        if (!orphans.empty()) {
+            uint32_t* d_indeg = nullptr;
+            VS_HIP(hipMalloc(&d_indeg, (size_t)n * 4));
+            std::vector<uint32_t> indeg(n), rowx(R), row0(R);
+            int r = VS_OK;
+            auto hip_ok = [&](hipError_t e) {
+                if (r == VS_OK && e != hipSuccess) {
+                    vs_set_error("vs_build_graph (repair): %s", hipGetErrorString(e));
+                    r = VS_ERR_HIP;
+                }
+            };
+            hip_ok(hipMemsetAsync(d_indeg, 0, (size_t)n * 4, st));
+            const size_t cells = (size_t)n * R;
+            hipLaunchKernelGGL(k_count_pointed_at, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, ix->nbrs, ix->nbr_stride, R, n,
+                               d_indeg);
+            hip_ok(hipGetLastError());
+            hip_ok(hipMemcpyAsync(indeg.data(), d_indeg, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+            hip_ok(hipStreamSynchronize(st));
+            (void)hipFree(d_indeg);
+            for (size_t oi = 0; oi < orphans.size() && r == VS_OK; ++oi) {
+                const uint32_t x = orphans[oi];
+                if (indeg[x]) continue;
+                hip_ok(hipMemcpy(rowx.data(), ix->nbrs + (size_t)x * ix->nbr_stride, (size_t)R * 4, hipMemcpyDeviceToHost));
+                if (r != VS_OK || rowx[0] == VS_INVALID_NODE) continue;
+                const uint32_t n0 = rowx[0];
+                hip_ok(hipMemcpy(row0.data(), ix->nbrs + (size_t)n0 * ix->nbr_stride, (size_t)R * 4, hipMemcpyDeviceToHost));
+                if (r != VS_OK) break;
+                int slot = -1;
+                for (uint32_t t = 0; t < R && slot < 0; ++t)
+                    if (row0[t] == VS_INVALID_NODE) slot = (int)t;
+                for (int t = (int)R - 1; t >= 0 && slot < 0; --t)
+                    if (indeg[row0[t]] >= 2) slot = t;
+                if (slot < 0) continue;
+                if (row0[slot] != VS_INVALID_NODE) indeg[row0[slot]]--;
+                row0[slot] = x;
+                indeg[x]++;
+                hip_ok(hipMemcpy(ix->nbrs + (size_t)n0 * ix->nbr_stride, row0.data(), (size_t)R * 4, hipMemcpyHostToDevice));
+            }
+            VS_TRY(r);
         }
     }
     return VS_OK;

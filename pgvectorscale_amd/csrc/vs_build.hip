@@ -145,8 +145,7 @@ __device__ uint32_t wave_prune(const uint32_t* cand_id, const uint32_t* cand_d, 
 }
 
 // ---- out-edges of the new nodes of one batch ------------------------------------------------------------------
-// one wave per new node p = b0 + blockIdx.x (or ids[blockIdx.x] in the repair pass).  Input: its visited list (sorted) from
-// k_search<BUILD>.
+// one wave per new node p = b0 + blockIdx.x.  Input: its visited list (sorted) from k_search<BUILD>.
 __global__ __launch_bounds__(WAVE) void k_build_prune_new(const uint64_t* __restrict__ codes, uint32_t stride,
                                                           uint32_t* __restrict__ nbrs, uint32_t nbr_stride, uint32_t R,
                                                           float max_alpha, uint32_t b0, uint32_t bn,
@@ -154,12 +153,12 @@ __global__ __launch_bounds__(WAVE) void k_build_prune_new(const uint64_t* __rest
                                                           const uint32_t* __restrict__ vis_d,
                                                           const uint32_t* __restrict__ vis_cnt, uint32_t vmax,
                                                           uint32_t use_lds_codes, uint32_t* __restrict__ edge_q,
-                                                          uint64_t* __restrict__ edge_pd, const uint32_t* __restrict__ ids) {
+                                                          uint64_t* __restrict__ edge_pd) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
     const uint32_t b = blockIdx.x;
     if (b >= bn) return;
-    const uint32_t p = ids ? ids[b] : b0 + b;
+    const uint32_t p = b0 + b;
     uint32_t C = min(vis_cnt[b], vmax);
     uint32_t* cid = reinterpret_cast<uint32_t*>(smem);
     uint32_t* cd = cid + vmax;
@@ -175,7 +174,14 @@ __global__ __launch_bounds__(WAVE) void k_build_prune_new(const uint64_t* __rest
         stage_codes(ccode, codes, cid, C, stride, lane);
         __syncthreads();
     }
-    uint32_t nres = wave_prune(cid, cd, C, use_lds_codes ? ccode : nullptr, codes, stride, R, max_alpha, maxf, sel, lane);
+    uint32_t nres;
+    if (C <= R) {  // Graph::add_neighbors prunes only a candidate list longer than num_neighbors (AM/graph/mod.rs:243-256)
+        for (uint32_t t = lane; t < C; t += WAVE) sel[t] = t;
+        nres = C;
+        __syncthreads();
+    } else {
+        nres = wave_prune(cid, cd, C, use_lds_codes ? ccode : nullptr, codes, stride, R, max_alpha, maxf, sel, lane);
+    }
     uint32_t* row = nbrs + (size_t)p * nbr_stride;
     for (uint32_t t = lane; t < nbr_stride; t += WAVE) row[t] = t < nres ? cid[sel[t]] : VS_INVALID_NODE;
     // back-edge requests (q <- p, d)
@@ -299,8 +305,8 @@ __global__ __launch_bounds__(WAVE) void k_build_backedges(const uint64_t* __rest
 // ---- repair pass: nodes nobody points at ----------------------------------------------------------------------------
 // Nodes of one batch do not see each other, so of two (near-)identical vectors that arrive together one can lose every
 // back-edge to the other (the target prunes it as covered) without gaining the edge between the two that sequential
-// insertion gives; with no in-edge it would never be returned by a scan.  After the last batch such nodes are inserted
-// once more: by then their twins are part of the graph.
+// insertion gives; with no in-edge it would never be returned by a scan.  After the last batch every such node is given a
+// slot in the list of its closest out-neighbor (vs_build_graph).
 __global__ void k_mark_pointed_at(const uint32_t* __restrict__ nbrs, uint32_t nbr_stride, uint32_t R, uint32_t n,
                                   uint8_t* __restrict__ mark) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -317,13 +323,6 @@ __global__ void k_count_pointed_at(const uint32_t* __restrict__ nbrs, uint32_t n
     if (v != VS_INVALID_NODE) atomicAdd(&indeg[v], 1u);
 }
 
-__global__ void k_gather_codes(const uint64_t* __restrict__ codes, uint32_t stride, const uint32_t* __restrict__ ids, uint32_t m,
-                               uint64_t* __restrict__ out) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (size_t)m * stride) return;
-    out[i] = codes[(size_t)ids[i / stride] * stride + (i % stride)];
-}
-
 struct BuildBufs {
     uint32_t *vis_ids = nullptr, *vis_d = nullptr, *vis_cnt = nullptr, *stats = nullptr, *status = nullptr;
     uint32_t* hash = nullptr;
@@ -334,11 +333,9 @@ struct BuildBufs {
     size_t cub_bytes = 0;
     uint32_t *f_ghash = nullptr, *f_heap = nullptr, *f_pool = nullptr;  // fast-kernel overflow table / heap spill / pool counter
     uint8_t* mark = nullptr;                                             // repair pass: node has an in-edge
-    uint32_t* rep_ids = nullptr;
-    uint64_t* rep_codes = nullptr;
     void free_all() {
         void* ps[] = {vis_ids, vis_d, vis_cnt, stats, status, hash, heap_g, edge_q, edge_q_sorted, seg_start, nseg,
-                      edge_pd, edge_pd_sorted, cub_tmp, f_ghash, f_heap, f_pool, mark, rep_ids, rep_codes};
+                      edge_pd, edge_pd_sorted, cub_tmp, f_ghash, f_heap, f_pool, mark};
         for (void* p : ps)
             if (p) (void)hipFree(p);
     }
@@ -420,9 +417,9 @@ static int build_graph_impl(vs_index* ix, uint32_t L, double max_alpha_d, uint32
         }
     }
 
-    // one batch: searches for bn new nodes (their codes at qcodes), out-edges, back-edges.  d_ids == nullptr: the nodes are
-    // b0 .. b0 + bn - 1
-    auto insert_batch = [&](const uint64_t* qcodes, const uint32_t* d_ids, uint32_t b0, uint32_t bn) -> int {
+    // one batch: searches for the new nodes b0 .. b0 + bn - 1, their out-edges, the back-edges
+    auto insert_batch = [&](uint32_t b0, uint32_t bn) -> int {
+        const uint64_t* qcodes = ix->codes + (size_t)b0 * stride;
         for (int attempt = 0;; ++attempt) {
             if ((size_t)bn * hashcap * 4 > hash_alloc || !B.hash) {
                 if (B.hash) VS_HIP(hipFree(B.hash));
@@ -500,7 +497,7 @@ static int build_graph_impl(vs_index* ix, uint32_t L, double max_alpha_d, uint32
         // out-edges of the new nodes + back-edge requests
         hipLaunchKernelGGL(k_build_prune_new, dim3(bn), dim3(WAVE), lds_new, st, ix->codes, stride, ix->nbrs,
                            ix->nbr_stride, R, max_alpha, b0, bn, B.vis_ids, B.vis_d, B.vis_cnt, vmax, use_lds_new,
-                           B.edge_q, B.edge_pd, d_ids);
+                           B.edge_q, B.edge_pd);
         VS_HIP(hipGetLastError());
         const uint32_t ne = bn * R;
         size_t tmp_bytes = B.cub_bytes;
@@ -521,22 +518,19 @@ static int build_graph_impl(vs_index* ix, uint32_t L, double max_alpha_d, uint32
     uint32_t bsz = 1;
     while (b0 < n) {
         const uint32_t bn = std::min<uint32_t>(std::min<uint32_t>(bsz, batch_max), n - b0);
-        VS_TRY(insert_batch(ix->codes + (size_t)b0 * stride, nullptr, b0, bn));
+        VS_TRY(insert_batch(b0, bn));
         b0 += bn;
         if (bsz < batch_max) bsz = std::min<uint32_t>(batch_max, bsz * 2);
     }
     VS_HIP(hipStreamSynchronize(st));
 
-    // repair pass (see k_mark_pointed_at): at most three rounds, each re-inserting the nodes without an in-edge
+    // repair pass (see k_mark_pointed_at)
     const char* rep_env = getenv("VS_BUILD_REPAIR");
     if (n > 2 && !(rep_env && *rep_env == '0')) {
         VS_HIP(hipMalloc(&B.mark, n));
-        VS_HIP(hipMalloc(&B.rep_ids, bm * 4));
-        VS_HIP(hipMalloc(&B.rep_codes, bm * code_bytes));
         std::vector<uint8_t> mark(n);
         std::vector<uint32_t> orphans;
-        size_t prev = SIZE_MAX;
-        for (int round = 0;; ++round) {
+        {
             VS_HIP(hipMemsetAsync(B.mark, 0, n, st));
             const size_t cells = (size_t)n * R;
             hipLaunchKernelGGL(k_mark_pointed_at, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, ix->nbrs, ix->nbr_stride, R, n,
@@ -544,25 +538,12 @@ static int build_graph_impl(vs_index* ix, uint32_t L, double max_alpha_d, uint32
             VS_HIP(hipGetLastError());
             VS_HIP(hipMemcpyAsync(mark.data(), B.mark, n, hipMemcpyDeviceToHost, st));
             VS_HIP(hipStreamSynchronize(st));
-            orphans.clear();
             for (uint32_t i = 1; i < n; ++i)  // node 0 is the entry point
                 if (!mark[i]) orphans.push_back(i);
-            if (orphans.empty() || orphans.size() >= prev || round == 3) break;  // done, no longer shrinking, or three rounds spent
-            prev = orphans.size();
-            for (size_t o0 = 0; o0 < orphans.size(); o0 += batch_max) {
-                const uint32_t m = (uint32_t)std::min<size_t>(batch_max, orphans.size() - o0);
-                VS_HIP(hipMemcpyAsync(B.rep_ids, orphans.data() + o0, (size_t)m * 4, hipMemcpyHostToDevice, st));
-                const size_t words = (size_t)m * stride;
-                hipLaunchKernelGGL(k_gather_codes, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, ix->codes, stride, B.rep_ids, m,
-                                   B.rep_codes);
-                VS_HIP(hipGetLastError());
-                VS_TRY(insert_batch(B.rep_codes, B.rep_ids, 0, m));
-                VS_HIP(hipStreamSynchronize(st));  // `orphans` must outlive the copy
-            }
         }
-        // Whoever is still without an in-edge (its only out-neighbors are full and prune it every time) is given one by
-        // hand: it takes a slot in the list of its closest out-neighbor — a free one, else that of the last entry that is
-        // pointed at from elsewhere too.  A handful of nodes at most, so this runs on the host.
+        // Each of them takes a slot in the list of its closest out-neighbor — a free one, else that of the last entry that is
+        // pointed at from elsewhere too (so nobody loses its only in-edge).  Rare (none on the bench corpora), so this runs
+        // on the host, in node order.
         if (!orphans.empty()) {
             uint32_t* d_indeg = nullptr;
             VS_HIP(hipMalloc(&d_indeg, (size_t)n * 4));
@@ -586,20 +567,21 @@ static int build_graph_impl(vs_index* ix, uint32_t L, double max_alpha_d, uint32
                 const uint32_t x = orphans[oi];
                 if (indeg[x]) continue;
                 hip_ok(hipMemcpy(rowx.data(), ix->nbrs + (size_t)x * ix->nbr_stride, (size_t)R * 4, hipMemcpyDeviceToHost));
-                if (r != VS_OK || rowx[0] == VS_INVALID_NODE) continue;
-                const uint32_t n0 = rowx[0];
-                hip_ok(hipMemcpy(row0.data(), ix->nbrs + (size_t)n0 * ix->nbr_stride, (size_t)R * 4, hipMemcpyDeviceToHost));
-                if (r != VS_OK) break;
-                int slot = -1;
-                for (uint32_t t = 0; t < R && slot < 0; ++t)
-                    if (row0[t] == VS_INVALID_NODE) slot = (int)t;
-                for (int t = (int)R - 1; t >= 0 && slot < 0; --t)
-                    if (indeg[row0[t]] >= 2) slot = t;
-                if (slot < 0) continue;
-                if (row0[slot] != VS_INVALID_NODE) indeg[row0[slot]]--;
-                row0[slot] = x;
-                indeg[x]++;
-                hip_ok(hipMemcpy(ix->nbrs + (size_t)n0 * ix->nbr_stride, row0.data(), (size_t)R * 4, hipMemcpyHostToDevice));
+                for (uint32_t c = 0; c < R && r == VS_OK && !indeg[x] && rowx[c] != VS_INVALID_NODE; ++c) {  // closest first
+                    const uint32_t n0 = rowx[c];
+                    hip_ok(hipMemcpy(row0.data(), ix->nbrs + (size_t)n0 * ix->nbr_stride, (size_t)R * 4, hipMemcpyDeviceToHost));
+                    if (r != VS_OK) break;
+                    int slot = -1;
+                    for (uint32_t t = 0; t < R && slot < 0; ++t)
+                        if (row0[t] == VS_INVALID_NODE) slot = (int)t;
+                    for (int t = (int)R - 1; t >= 0 && slot < 0; --t)
+                        if (indeg[row0[t]] >= 2) slot = t;
+                    if (slot < 0) continue;
+                    if (row0[slot] != VS_INVALID_NODE) indeg[row0[slot]]--;
+                    row0[slot] = x;
+                    indeg[x]++;
+                    hip_ok(hipMemcpy(ix->nbrs + (size_t)n0 * ix->nbr_stride, row0.data(), (size_t)R * 4, hipMemcpyHostToDevice));
+                }
             }
             VS_TRY(r);
         }

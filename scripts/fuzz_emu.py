@@ -378,9 +378,9 @@ def one_case(ctx, O, case_seed, verbose):
         for _ in range(nq):
             kk = int(rng.choice([0, 1, 1, 2, 2, 5]))
             keys.append([int(x) for x in rng.integers(1, n_labels + 2, kk)])  # unsorted, duplicates, one label nobody has
-    L = int(rng.choice([1, 2, 10, 30, 64, 100, 150, 300]))
-    rescore = int(rng.choice([0, 1, 10, 50, 115]))
-    k = int(rng.choice([1, 5, 10, 40]))
+    L = int(rng.choice([1, 2, 10, 30, 64, 100, 150, 300, 1000]))
+    rescore = int(rng.choice([0, 1, 10, 50, 115, 400]))
+    k = int(rng.choice([1, 5, 10, 40, 200]))
     m = int(rng.choice([1, 20, 75]))
     regimes = [REGIMES[i] for i in rng.choice(len(REGIMES), 4, replace=False)]
     oi, od, ost = ti.oracle.search_batch(q, L=L, rescore=rescore, k=k, qlabels=keys)

@@ -302,23 +302,30 @@ __global__ __launch_bounds__(WAVE) void k_build_backedges(const uint64_t* __rest
     }
 }
 
-// ---- repair pass: nodes nobody points at ----------------------------------------------------------------------------
+// ---- repair pass: nodes no scan can reach ---------------------------------------------------------------------------
 // Nodes of one batch do not see each other, so of two (near-)identical vectors that arrive together one can lose every
 // back-edge to the other (the target prunes it as covered) without gaining the edge between the two that sequential
-// insertion gives; with no in-edge it would never be returned by a scan.  After the last batch every such node is given a
-// slot in the list of its closest out-neighbor (vs_build_graph).
-__global__ void k_mark_pointed_at(const uint32_t* __restrict__ nbrs, uint32_t nbr_stride, uint32_t R, uint32_t n,
-                                  uint8_t* __restrict__ mark) {
+// insertion gives; a node that cannot be reached from the start node is never returned by a scan.  After the last batch
+// the reachable set is computed (level-synchronous sweeps over the neighbor array) and every node outside it is given a
+// slot in the list of its closest reachable out-neighbor (vs_build_graph).
+__global__ void k_reach_sweep(const uint32_t* __restrict__ nbrs, uint32_t nbr_stride, uint32_t R, uint32_t n,
+                              uint8_t* __restrict__ reached, uint32_t* __restrict__ changed) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)n * R) return;
+    if (!reached[i / R]) return;
     const uint32_t v = nbrs[(i / R) * nbr_stride + (i % R)];
-    if (v != VS_INVALID_NODE) mark[v] = 1;
+    if (v != VS_INVALID_NODE && !reached[v]) {
+        reached[v] = 1;
+        *changed = 1;
+    }
 }
 
-__global__ void k_count_pointed_at(const uint32_t* __restrict__ nbrs, uint32_t nbr_stride, uint32_t R, uint32_t n,
-                                   uint32_t* __restrict__ indeg) {
+// in-edges that come from reachable nodes
+__global__ void k_count_reached_sources(const uint32_t* __restrict__ nbrs, uint32_t nbr_stride, uint32_t R, uint32_t n,
+                                        const uint8_t* __restrict__ reached, uint32_t* __restrict__ indeg) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)n * R) return;
+    if (!reached[i / R]) return;
     const uint32_t v = nbrs[(i / R) * nbr_stride + (i % R)];
     if (v != VS_INVALID_NODE) atomicAdd(&indeg[v], 1u);
 }
@@ -332,7 +339,7 @@ struct BuildBufs {
     void* cub_tmp = nullptr;
     size_t cub_bytes = 0;
     uint32_t *f_ghash = nullptr, *f_heap = nullptr, *f_pool = nullptr;  // fast-kernel overflow table / heap spill / pool counter
-    uint8_t* mark = nullptr;                                             // repair pass: node has an in-edge
+    uint8_t* mark = nullptr;                                             // repair pass: node is reachable from the start node
     void free_all() {
         void* ps[] = {vis_ids, vis_d, vis_cnt, stats, status, hash, heap_g, edge_q, edge_q_sorted, seg_start, nseg,
                       edge_pd, edge_pd_sorted, cub_tmp, f_ghash, f_heap, f_pool, mark};
@@ -524,30 +531,43 @@ static int build_graph_impl(vs_index* ix, uint32_t L, double max_alpha_d, uint32
     }
     VS_HIP(hipStreamSynchronize(st));
 
-    // repair pass (see k_mark_pointed_at)
+    // repair pass (see k_reach_sweep): at most three rounds of { reachable set, in-edges for the nodes outside it }
     const char* rep_env = getenv("VS_BUILD_REPAIR");
     if (n > 2 && !(rep_env && *rep_env == '0')) {
-        VS_HIP(hipMalloc(&B.mark, n));
-        std::vector<uint8_t> mark(n);
-        std::vector<uint32_t> orphans;
-        {
-            VS_HIP(hipMemsetAsync(B.mark, 0, n, st));
-            const size_t cells = (size_t)n * R;
-            hipLaunchKernelGGL(k_mark_pointed_at, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, ix->nbrs, ix->nbr_stride, R, n,
-                               B.mark);
-            VS_HIP(hipGetLastError());
-            VS_HIP(hipMemcpyAsync(mark.data(), B.mark, n, hipMemcpyDeviceToHost, st));
+        VS_HIP(hipMalloc(&B.mark, (size_t)n + 4));
+        uint32_t* d_changed = reinterpret_cast<uint32_t*>(B.mark + (((size_t)n + 3) & ~(size_t)3));
+        std::vector<uint8_t> reached(n);
+        std::vector<uint32_t> lost, indeg, rowx(R), row0(R);
+        const size_t cells = (size_t)n * R;
+        const dim3 cgrid((unsigned)((cells + 255) / 256));
+        const uint32_t start = ix->d.default_start;
+        for (int round = 0; round < 3; ++round) {
+            VS_HIP(hipMemsetAsync(B.mark, 0, (size_t)n + 4, st));
+            const uint8_t one = 1;
+            VS_HIP(hipMemcpyAsync(B.mark + start, &one, 1, hipMemcpyHostToDevice, st));
+            bool converged = false;
+            for (int sweep = 0; sweep < 256 && !converged; ++sweep) {  // a sweep follows edges to higher node ids within itself
+                uint32_t changed = 0;
+                VS_HIP(hipMemsetAsync(d_changed, 0, 4, st));
+                hipLaunchKernelGGL(k_reach_sweep, cgrid, dim3(256), 0, st, ix->nbrs, ix->nbr_stride, R, n, B.mark, d_changed);
+                VS_HIP(hipGetLastError());
+                VS_HIP(hipMemcpyAsync(&changed, d_changed, 4, hipMemcpyDeviceToHost, st));
+                VS_HIP(hipStreamSynchronize(st));
+                converged = changed == 0;
+            }
+            if (!converged) break;  // a graph this deep is not one this pass can judge
+            VS_HIP(hipMemcpyAsync(reached.data(), B.mark, n, hipMemcpyDeviceToHost, st));
             VS_HIP(hipStreamSynchronize(st));
-            for (uint32_t i = 1; i < n; ++i)  // node 0 is the entry point
-                if (!mark[i]) orphans.push_back(i);
-        }
-        // Each of them takes a slot in the list of its closest out-neighbor — a free one, else that of the last entry that is
-        // pointed at from elsewhere too (so nobody loses its only in-edge).  Rare (none on the bench corpora), so this runs
-        // on the host, in node order.
-        if (!orphans.empty()) {
+            lost.clear();
+            for (uint32_t i = 0; i < n; ++i)
+                if (!reached[i]) lost.push_back(i);
+            if (lost.empty()) break;
+            // Each of them takes a slot in the list of its closest reachable out-neighbor — a free one, else that of the last
+            // entry that two or more reachable nodes point at (so nobody loses its only way in).  Rare (none on the bench
+            // corpora), so this runs on the host, in node order.
             uint32_t* d_indeg = nullptr;
             VS_HIP(hipMalloc(&d_indeg, (size_t)n * 4));
-            std::vector<uint32_t> indeg(n), rowx(R), row0(R);
+            indeg.assign(n, 0);
             int r = VS_OK;
             auto hip_ok = [&](hipError_t e) {
                 if (r == VS_OK && e != hipSuccess) {
@@ -556,19 +576,18 @@ static int build_graph_impl(vs_index* ix, uint32_t L, double max_alpha_d, uint32
                 }
             };
             hip_ok(hipMemsetAsync(d_indeg, 0, (size_t)n * 4, st));
-            const size_t cells = (size_t)n * R;
-            hipLaunchKernelGGL(k_count_pointed_at, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, ix->nbrs, ix->nbr_stride, R, n,
-                               d_indeg);
+            hipLaunchKernelGGL(k_count_reached_sources, cgrid, dim3(256), 0, st, ix->nbrs, ix->nbr_stride, R, n, B.mark, d_indeg);
             hip_ok(hipGetLastError());
             hip_ok(hipMemcpyAsync(indeg.data(), d_indeg, (size_t)n * 4, hipMemcpyDeviceToHost, st));
             hip_ok(hipStreamSynchronize(st));
             (void)hipFree(d_indeg);
-            for (size_t oi = 0; oi < orphans.size() && r == VS_OK; ++oi) {
-                const uint32_t x = orphans[oi];
-                if (indeg[x]) continue;
+            for (size_t oi = 0; oi < lost.size() && r == VS_OK; ++oi) {
+                const uint32_t x = lost[oi];
                 hip_ok(hipMemcpy(rowx.data(), ix->nbrs + (size_t)x * ix->nbr_stride, (size_t)R * 4, hipMemcpyDeviceToHost));
-                for (uint32_t c = 0; c < R && r == VS_OK && !indeg[x] && rowx[c] != VS_INVALID_NODE; ++c) {  // closest first
+                bool placed = false;
+                for (uint32_t c = 0; c < R && r == VS_OK && !placed && rowx[c] != VS_INVALID_NODE; ++c) {  // closest first
                     const uint32_t n0 = rowx[c];
+                    if (!reached[n0]) continue;
                     hip_ok(hipMemcpy(row0.data(), ix->nbrs + (size_t)n0 * ix->nbr_stride, (size_t)R * 4, hipMemcpyDeviceToHost));
                     if (r != VS_OK) break;
                     int slot = -1;
@@ -580,6 +599,7 @@ static int build_graph_impl(vs_index* ix, uint32_t L, double max_alpha_d, uint32
                     if (row0[slot] != VS_INVALID_NODE) indeg[row0[slot]]--;
                     row0[slot] = x;
                     indeg[x]++;
+                    placed = true;
                     hip_ok(hipMemcpy(ix->nbrs + (size_t)n0 * ix->nbr_stride, row0.data(), (size_t)R * 4, hipMemcpyHostToDevice));
                 }
             }

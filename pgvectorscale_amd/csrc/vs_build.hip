@@ -309,13 +309,13 @@ __global__ __launch_bounds__(WAVE) void k_build_backedges(const uint64_t* __rest
 // the reachable set is computed (level-synchronous sweeps over the neighbor array) and every node outside it is given a
 // slot in the list of its closest reachable out-neighbor (vs_build_graph).
 __global__ void k_reach_sweep(const uint32_t* __restrict__ nbrs, uint32_t nbr_stride, uint32_t R, uint32_t n,
-                              uint8_t* __restrict__ reached, uint32_t* __restrict__ changed) {
+                              uint8_t* __restrict__ reached, uint32_t level, uint32_t* __restrict__ changed) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)n * R) return;
-    if (!reached[i / R]) return;
+    if (reached[i / R] != level) return;  // reached[] holds 1 + the BFS level: only the frontier expands
     const uint32_t v = nbrs[(i / R) * nbr_stride + (i % R)];
     if (v != VS_INVALID_NODE && !reached[v]) {
-        reached[v] = 1;
+        reached[v] = (uint8_t)(level + 1);
         *changed = 1;
     }
 }
@@ -546,16 +546,16 @@ static int build_graph_impl(vs_index* ix, uint32_t L, double max_alpha_d, uint32
             const uint8_t one = 1;
             VS_HIP(hipMemcpyAsync(B.mark + start, &one, 1, hipMemcpyHostToDevice, st));
             bool converged = false;
-            for (int sweep = 0; sweep < 256 && !converged; ++sweep) {  // a sweep follows edges to higher node ids within itself
+            for (uint32_t level = 1; level < 255 && !converged; ++level) {  // one BFS level per sweep
                 uint32_t changed = 0;
                 VS_HIP(hipMemsetAsync(d_changed, 0, 4, st));
-                hipLaunchKernelGGL(k_reach_sweep, cgrid, dim3(256), 0, st, ix->nbrs, ix->nbr_stride, R, n, B.mark, d_changed);
+                hipLaunchKernelGGL(k_reach_sweep, cgrid, dim3(256), 0, st, ix->nbrs, ix->nbr_stride, R, n, B.mark, level, d_changed);
                 VS_HIP(hipGetLastError());
                 VS_HIP(hipMemcpyAsync(&changed, d_changed, 4, hipMemcpyDeviceToHost, st));
                 VS_HIP(hipStreamSynchronize(st));
                 converged = changed == 0;
             }
-            if (!converged) break;  // a graph this deep is not one this pass can judge
+            if (!converged) break;  // more than 254 levels deep: not a graph this pass can judge
             VS_HIP(hipMemcpyAsync(reached.data(), B.mark, n, hipMemcpyDeviceToHost, st));
             VS_HIP(hipStreamSynchronize(st));
             lost.clear();

@@ -537,7 +537,7 @@ static int build_graph_impl(vs_index* ix, uint32_t L, double max_alpha_d, uint32
         VS_HIP(hipMalloc(&B.mark, (size_t)n + 4));
         uint32_t* d_changed = reinterpret_cast<uint32_t*>(B.mark + (((size_t)n + 3) & ~(size_t)3));
         std::vector<uint8_t> reached(n);
-        std::vector<uint32_t> lost, indeg, rowx(R), row0(R);
+        std::vector<uint32_t> lost, indeg, row0(R);
         const size_t cells = (size_t)n * R;
         const dim3 cgrid((unsigned)((cells + 255) / 256));
         const uint32_t start = ix->d.default_start;
@@ -581,26 +581,56 @@ static int build_graph_impl(vs_index* ix, uint32_t L, double max_alpha_d, uint32
             hip_ok(hipMemcpyAsync(indeg.data(), d_indeg, (size_t)n * 4, hipMemcpyDeviceToHost, st));
             hip_ok(hipStreamSynchronize(st));
             (void)hipFree(d_indeg);
+            // the lists of the lost nodes, so that what becomes reachable through a node that was just given a way in is known
+            // without another sweep
+            std::vector<uint32_t> lrows(lost.size() * (size_t)R), lidx(n, 0xFFFFFFFFu), stack;
             for (size_t oi = 0; oi < lost.size() && r == VS_OK; ++oi) {
-                const uint32_t x = lost[oi];
-                hip_ok(hipMemcpy(rowx.data(), ix->nbrs + (size_t)x * ix->nbr_stride, (size_t)R * 4, hipMemcpyDeviceToHost));
-                bool placed = false;
-                for (uint32_t c = 0; c < R && r == VS_OK && !placed && rowx[c] != VS_INVALID_NODE; ++c) {  // closest first
-                    const uint32_t n0 = rowx[c];
-                    if (!reached[n0]) continue;
-                    hip_ok(hipMemcpy(row0.data(), ix->nbrs + (size_t)n0 * ix->nbr_stride, (size_t)R * 4, hipMemcpyDeviceToHost));
-                    if (r != VS_OK) break;
-                    int slot = -1;
-                    for (uint32_t t = 0; t < R && slot < 0; ++t)
-                        if (row0[t] == VS_INVALID_NODE) slot = (int)t;
-                    for (int t = (int)R - 1; t >= 0 && slot < 0; --t)
-                        if (indeg[row0[t]] >= 2) slot = t;
-                    if (slot < 0) continue;
-                    if (row0[slot] != VS_INVALID_NODE) indeg[row0[slot]]--;
-                    row0[slot] = x;
-                    indeg[x]++;
-                    placed = true;
-                    hip_ok(hipMemcpy(ix->nbrs + (size_t)n0 * ix->nbr_stride, row0.data(), (size_t)R * 4, hipMemcpyHostToDevice));
+                lidx[lost[oi]] = (uint32_t)oi;
+                hip_ok(hipMemcpy(&lrows[oi * R], ix->nbrs + (size_t)lost[oi] * ix->nbr_stride, (size_t)R * 4, hipMemcpyDeviceToHost));
+            }
+            for (bool progress = true; progress && r == VS_OK;) {
+                progress = false;
+                for (size_t oi = 0; oi < lost.size() && r == VS_OK; ++oi) {
+                    const uint32_t x = lost[oi];
+                    if (reached[x]) continue;
+                    const uint32_t* rowx = &lrows[oi * R];
+                    bool placed = false;
+                    for (uint32_t c = 0; c < R && r == VS_OK && !placed && rowx[c] != VS_INVALID_NODE; ++c) {  // closest first
+                        const uint32_t n0 = rowx[c];
+                        if (!reached[n0]) continue;
+                        uint32_t* rown = lidx[n0] != 0xFFFFFFFFu ? &lrows[(size_t)lidx[n0] * R] : row0.data();
+                        if (rown == row0.data())
+                            hip_ok(hipMemcpy(row0.data(), ix->nbrs + (size_t)n0 * ix->nbr_stride, (size_t)R * 4, hipMemcpyDeviceToHost));
+                        if (r != VS_OK) break;
+                        int slot = -1;
+                        for (uint32_t t = 0; t < R && slot < 0; ++t)
+                            if (rown[t] == VS_INVALID_NODE) slot = (int)t;
+                        for (int t = (int)R - 1; t >= 0 && slot < 0; --t)
+                            if (indeg[rown[t]] >= 2) slot = t;
+                        if (slot < 0) continue;
+                        if (rown[slot] != VS_INVALID_NODE) indeg[rown[slot]]--;
+                        rown[slot] = x;
+                        indeg[x]++;
+                        placed = true;
+                        hip_ok(hipMemcpy(ix->nbrs + (size_t)n0 * ix->nbr_stride, rown, (size_t)R * 4, hipMemcpyHostToDevice));
+                    }
+                    if (!placed) continue;
+                    progress = true;
+                    reached[x] = 1;
+                    stack.assign(1, x);
+                    while (!stack.empty()) {  // everything x leads to is reachable now
+                        const uint32_t u = stack.back();
+                        stack.pop_back();
+                        const uint32_t* rowu = &lrows[(size_t)lidx[u] * R];
+                        for (uint32_t t = 0; t < R && rowu[t] != VS_INVALID_NODE; ++t) {
+                            const uint32_t v = rowu[t];
+                            indeg[v]++;
+                            if (!reached[v]) {
+                                reached[v] = 1;
+                                stack.push_back(v);
+                            }
+                        }
+                    }
                 }
             }
             VS_TRY(r);

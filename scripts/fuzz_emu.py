@@ -334,7 +334,9 @@ def build_case(ctx, O, case_seed, verbose):
                 assert seen == reachable(nb, ix.desc.default_start), f"{where}: the scan and a BFS disagree"
                 # (within the reference's option ranges: num_neighbors >= 10, search_list_size in 10..1000, AM/options.rs:55-64,
                 # 213-232; below them neither builder makes a navigable graph and the case only checks form and parity)
-                assert seen >= want or R < 10 or Lb < 10, \
+                # (a corpus on which the sequential builder itself reaches under 90 % of the nodes — SBQ codes of rows with very
+                # different norms around a zero vector under L2 — is not navigable either way)
+                assert seen >= want or R < 10 or Lb < 10 or want < 0.9 * n, \
                     f"{where}: exhaustive scan reached {seen} of {n} nodes, the sequential builder's graph {want}"
         finally:
             ix.close()

@@ -534,7 +534,7 @@ static int build_graph_impl(vs_index* ix, uint32_t L, double max_alpha_d, uint32
     // repair pass (see k_reach_sweep): at most three rounds of { reachable set, in-edges for the nodes outside it }
     const char* rep_env = getenv("VS_BUILD_REPAIR");
     if (n > 2 && !(rep_env && *rep_env == '0')) {
-        VS_HIP(hipMalloc(&B.mark, (size_t)n + 4));
+        VS_HIP(hipMalloc(&B.mark, (size_t)n + 8));  // n flags, then (4-byte aligned) the `changed` word
         uint32_t* d_changed = reinterpret_cast<uint32_t*>(B.mark + (((size_t)n + 3) & ~(size_t)3));
         std::vector<uint8_t> reached(n);
         std::vector<uint32_t> lost, indeg, row0(R);
@@ -542,7 +542,7 @@ static int build_graph_impl(vs_index* ix, uint32_t L, double max_alpha_d, uint32
         const dim3 cgrid((unsigned)((cells + 255) / 256));
         const uint32_t start = ix->d.default_start;
         for (int round = 0; round < 3; ++round) {
-            VS_HIP(hipMemsetAsync(B.mark, 0, (size_t)n + 4, st));
+            VS_HIP(hipMemsetAsync(B.mark, 0, (size_t)n + 8, st));
             const uint8_t one = 1;
             VS_HIP(hipMemcpyAsync(B.mark + start, &one, 1, hipMemcpyHostToDevice, st));
             bool converged = false;

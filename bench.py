@@ -81,50 +81,6 @@ def graph_cache_path(args, n, dim, seed, bits, R):
     return path
 
 
-def canary_verdict(returncode, stdout):
-    """Did a small run of this workload on k_search_mx (VS_MX=2) reproduce the oracle bit for bit?  -> (ok, reason)"""
-    if returncode != 0:
-        return False, f"exit code {returncode}"
-    line = next((ln for ln in reversed(stdout.strip().splitlines()) if ln.startswith("{")), None)
-    if line is None:
-        return False, "no JSON line"
-    try:
-        j = json.loads(line)
-    except ValueError as e:
-        return False, f"bad JSON ({e})"
-    cb = j.get("cpu_baseline") or {}
-    if cb.get("gpu_rows_identical") is not True or cb.get("gpu_dist_bit_identical_frac") != 1.0:
-        return False, f"rows differ from the oracle ({cb.get('sample')})"
-    if not j.get("recall_at_k", 0) > 0.9:
-        return False, f"recall {j.get('recall_at_k')}"
-    return True, f"{cb.get('sample', '').split(',')[0]} identical to the oracle"
-
-
-def mx_canary(args, extra_env=None):
-    """k_search_mx (four scans per wave, vs_search_mx.hip) is newer than the measurements in profiles/: before it is even
-    tried in this process, a child process runs a small instance of the same workload on it with a time limit and
-    checks the rows against the oracle.  A crash, a hang or a single differing row keeps this run on k_search_fast."""
-    import subprocess
-    env = {k_: v_ for k_, v_ in os.environ.items() if k_ not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
-                                                                 "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "TORCHELASTIC_RUN_ID")}
-    env.update(VS_MX="2", VS_F_LDS_MAX_INS="0", VS_BENCH_CANARY="1")  # 2 = insist: every query launch must run on k_search_mx
-    env.update(extra_env or {})
-    small = ["--n", "4000", "--nq", "64", "--recall-queries", "16"] if EMU else ["--n", "200000", "--nq", "8192"]
-    cmd = [sys.executable, os.path.abspath(__file__), *small, "--steps", "1", "--warmup", "1", "--fixed",
-           "100,50", "--graph-cache", "none", "--scan-nq", "0", "--cpu-seconds", "3", "--dim", str(args.dim), "--distance",
-           args.distance, "--k", str(args.k), "--labels", str(args.labels)]
-    try:
-        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)  # (shares the GPU with the parent's setup)
-    except subprocess.TimeoutExpired:
-        return False, "timed out (300 s)"
-    except Exception as e:
-        return False, repr(e)
-    ok, why = canary_verdict(r.returncode, r.stdout)
-    if not ok:
-        log("k_search_mx canary stderr tail:", r.stderr[-400:].replace("\n", " | "))
-    return ok, why
-
-
 def choose_operating_point(run_sample, k, target, sweep_log, err_type=Exception):
     """Cheapest (search_list_size, rescore) whose recall on the sample reaches `target`.
 
@@ -209,36 +165,6 @@ def label_masks(np, off, val):
     return np.bitwise_or.reduceat(np.int64(1) << val.astype(np.int64), off[:-1].astype(np.int64))
 
 
-def supervised_run(argv, try_mx_possible):
-    """N = 1: the run proper happens in a child process.  k_search_mx has never run on hardware with this corpus size
-    before its A/B arm does (the canary is a smaller instance); if the child dies or hangs there, the run is repeated
-    once with the exploration off (VS_BENCH_NO_MX=1: k_search_fast, the kernel profiles/ was measured on) instead of
-    leaving the round without a bench line.  Returns None when this process should run the benchmark itself."""
-    import subprocess
-    if (int(os.environ.get("WORLD_SIZE", "1")) != 1 or not try_mx_possible or os.environ.get("VS_BENCH_CHILD")
-            or os.environ.get("VS_BENCH_CANARY") or os.environ.get("VS_BENCH_INPROC") or os.environ.get("VS_BENCH_NO_MX")
-            or "VS_MX" in os.environ or any(k_.startswith(("ROCP_", "ROCPROF")) for k_ in os.environ)):  # under a profiler: one process
-        return None
-    limit = float(os.environ.get("VS_BENCH_CHILD_TIMEOUT", "2700"))
-    why = None
-    for attempt in (0, 1):
-        env = dict(os.environ, VS_BENCH_CHILD="1")
-        if attempt == 1:
-            env.update(VS_BENCH_NO_MX="1", VS_BENCH_FIRST_ATTEMPT=why)
-        try:
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), *argv], env=env, stdout=subprocess.PIPE, text=True,
-                               timeout=limit)
-            line = next((ln for ln in reversed(r.stdout.strip().splitlines()) if ln.startswith("{")), None)
-            if r.returncode == 0 and line is not None:
-                print(line, flush=True)
-                return 0
-            why = f"exit code {r.returncode}" + ("" if line is not None else ", no JSON line")
-        except subprocess.TimeoutExpired:
-            why = f"no result within {limit:.0f} s"
-        log(f"attempt {attempt + 1} failed ({why})" + ("; repeating on k_search_fast only" if attempt == 0 else ""))
-    return 1
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -271,9 +197,6 @@ def main():
                          "vector carries 1-3 of this many labels (Zipf frequencies), query keys alternate between one and two "
                          "labels; ground truth is the exact filtered top-k")
     args = ap.parse_args()
-    rc = supervised_run(sys.argv[1:], args.n >= 500_000 or bool(os.environ.get("VS_BENCH_TRY_MX")))
-    if rc is not None:
-        sys.exit(rc)
 
     import numpy as np
     import torch
@@ -304,31 +227,6 @@ def main():
 
     ctx = P.Context(0 if EMU else local_rank)
     log("device:", ctx.device_name())
-    # which search kernel: VS_MX set by the user is respected; otherwise k_search_mx is tried (canary first, then an A/B
-    # on a full batch of this run's queries, both outside the timed region) wherever the table-less regime applies
-    kernel_choice = {"chosen": "k_search_fast"}
-    try_gd4 = False
-    try_mx = "VS_MX" not in os.environ and not os.environ.get("VS_BENCH_CANARY") and not os.environ.get("VS_BENCH_NO_MX") and \
-        (args.n >= 500_000 or bool(os.environ.get("VS_BENCH_TRY_MX")))
-    if os.environ.get("VS_BENCH_FIRST_ATTEMPT"):
-        kernel_choice["first_attempt"] = os.environ["VS_BENCH_FIRST_ATTEMPT"] + " (with the k_search_mx A/B); this is the repeat without it"
-    canary_thread, canary_out = None, {}
-    if try_mx and rank == 0:
-        # the canaries are child processes on the same GPU; they run while this process manufactures its index (minutes at
-        # 50M) and are collected before the A/B
-        import threading
-
-        def run_canaries():
-            t0 = time.time()
-            canary_out["mx"] = mx_canary(args)
-            canary_out["mx_s"] = round(time.time() - t0, 1)
-            if canary_out["mx"][0] and "VS_MX_GD" not in os.environ:  # the 16-rows-in-flight gather variant is another kernel binary
-                canary_out["gd4"] = mx_canary(args, {"VS_MX_GD": "4"})
-
-        canary_thread = threading.Thread(target=run_canaries, daemon=True)
-        canary_thread.start()
-    if os.environ.get("VS_MX", "0") not in ("", "0"):
-        kernel_choice["chosen"] = "k_search_mx where eligible (VS_MX set by the caller)"
     dt = {"l2": P.VS_L2, "cosine": P.VS_COSINE, "ip": P.VS_IP}[args.distance]
     n, dim, k = args.n, args.dim, args.k
     R = 50
@@ -498,114 +396,6 @@ def main():
             gather_topk(out_ids, out_dist)
         return st
 
-    if canary_thread is not None:
-        canary_thread.join()
-        ok, why = canary_out.get("mx", (False, "the canary thread died"))
-        kernel_choice["canary"] = ("passed: " if ok else "failed: ") + why
-        kernel_choice["canary_s"] = canary_out.get("mx_s")
-        log("k_search_mx canary", kernel_choice["canary"])
-        try_mx = ok
-        if "gd4" in canary_out:
-            ok4, why4 = canary_out["gd4"]
-            kernel_choice["canary_gd4"] = ("passed: " if ok4 else "failed: ") + why4
-            try_gd4 = ok4
-    if world > 1:  # every rank follows rank 0's canary
-        import torch.distributed as dist
-        flag = torch.tensor([1 if try_mx else 0, 1 if try_gd4 else 0], dtype=torch.int32, device=dev)
-        dist.broadcast(flag, 0)
-        try_mx, try_gd4 = bool(flag[0].item()), bool(flag[1].item())
-    if try_mx:
-        # A/B on batch 0: same queries through both kernels, results must be identical, the faster one is used
-        # (k_search_mx covers the table-less regime; small corpora default to the LDS-table regime of k_search_fast, so the
-        # k_search_mx arm also switches the regime unless the caller pinned it)
-        force_tableless = "VS_F_LDS_MAX_INS" not in os.environ
-
-        def set_kernel(mx):
-            os.environ["VS_MX"] = "1" if mx else "0"
-            if force_tableless:
-                if mx:
-                    os.environ["VS_F_LDS_MAX_INS"] = "0"
-                else:
-                    os.environ.pop("VS_F_LDS_MAX_INS", None)
-
-        # the k_search_mx arms: its default LDS heap top (511 entries) and, unless the caller pinned VS_F_HL, 255 / 1023 — the
-        # same kernel binary with another LDS / occupancy trade
-        hl_free = "VS_F_HL" not in os.environ
-        variants = [("k_search_fast", False, None, None), ("k_search_mx", True, None, None)]
-        if hl_free:
-            variants += [("k_search_mx VS_F_HL=255", True, "255", None), ("k_search_mx VS_F_HL=1023", True, "1023", None)]
-        if try_gd4:
-            variants += [("k_search_mx VS_MX_GD=4", True, None, "4")]
-
-        def set_variant(v):
-            set_kernel(v[1])
-            if hl_free:
-                if v[2] is None:
-                    os.environ.pop("VS_F_HL", None)
-                else:
-                    os.environ["VS_F_HL"] = v[2]
-            if try_gd4:
-                if v[3] is None:
-                    os.environ.pop("VS_MX_GD", None)
-                else:
-                    os.environ["VS_MX_GD"] = v[3]
-
-        def timed(v):
-            set_variant(v)
-            step(0)  # sizes the launch from its own statistics
-            barrier()
-            t1 = time.perf_counter()
-            step(0)
-            barrier()
-            return time.perf_counter() - t1, out_ids.clone(), out_dist.clone()
-
-        if os.environ.get("VS_BENCH_TEST_CRASH") == "ab":  # tests/test_bench_dry_run.py: a kernel fault in the A/B
-            os.abort()
-        times, okv = [], []
-        ref_ids = ref_dist = None
-        for vi, v in enumerate(variants):
-            # a k_search_mx arm that hangs must not take the run with it: past 50x the k_search_fast arm (at least 60 s)
-            # the process ends with code 86 and the supervising parent repeats the run without the exploration
-            watchdog = None
-            if vi > 0 and times[0] != float("inf") and not EMU:
-                import threading
-                watchdog = threading.Timer(max(60.0, 50 * times[0]), lambda: os._exit(86))
-                watchdog.daemon = True
-                watchdog.start()
-            try:
-                t_v, ids_v, dist_v = timed(v)
-                if vi == 0:
-                    ref_ids, ref_dist = ids_v, dist_v
-                    same = True
-                else:
-                    same = bool(torch.equal(ref_ids, ids_v)) and bool(torch.equal(ref_dist.view(torch.int32), dist_v.view(torch.int32)))
-            except P.VsError as e:
-                kernel_choice.setdefault("ab_errors", {})[v[0]] = str(e)
-                t_v, same = float("inf"), False
-            finally:
-                if watchdog is not None:
-                    watchdog.cancel()
-            times.append(t_v)
-            okv.append(same)
-        kernel_choice["ms_per_step"] = {v[0]: (round(t * 1e3, 3) if t != float("inf") else None) for v, t in zip(variants, times)}
-        kernel_choice["results_identical"] = {v[0]: o for v, o in zip(variants[1:], okv[1:])}
-        if world > 1:  # a variant counts only if it was identical on every rank; rank 0's clock decides
-            flags = torch.tensor([1 if o else 0 for o in okv], dtype=torch.int32, device=dev)
-            dist.all_reduce(flags, op=dist.ReduceOp.MIN)
-            okv = [bool(x) for x in flags.tolist()]
-        best = 0
-        for vi in range(1, len(variants)):
-            if okv[vi] and times[vi] < 0.97 * times[0] and times[vi] < times[best]:
-                best = vi
-        if not okv[0]:
-            best = 0
-        if world > 1:
-            pick = torch.tensor([best], dtype=torch.int32, device=dev)
-            dist.broadcast(pick, 0)
-            best = int(pick.item())
-        set_variant(variants[best])
-        kernel_choice["chosen"] = variants[best][0]
-        log("search kernel A/B:", kernel_choice)
     for b in range(args.warmup):
         step(b)
     ctx.profile_enable(True)
@@ -656,7 +446,7 @@ def main():
                                    "rescore": pj.get("rescore"), "file": os.path.basename(pmc_path)}
         except Exception:
             pass
-    roofline = {"bound": "hbm", "kernel": "k_search_mx" if kernel_choice["chosen"].startswith("k_search_mx") else "k_search_fast", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
+    roofline = {"bound": "hbm", "kernel": "k_search_fast", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(achieved / 8000.0, 5), "traffic": traffic, "traffic_other_operating_point": traffic_ref,
                 "alg_bytes_per_launch": int(per_launch), "avg_kernel_ms": round(avg_ms, 4), "launches": s_n,
                 "alg_bytes_per_query": round(alg_bytes_search / max(tot.get("queries", 1) - tot.get("fallback_scans", 0), 1), 1)}
@@ -718,7 +508,6 @@ def main():
         "recall_at_k": round(recall, 4),
         "recall_target_met": bool(recall >= args.recall_target),
         "recall_sweep": sweep_log,
-        "search_kernel": kernel_choice,
         "roofline": roofline,
         "sbq_scan_roofline": scan_roofline,
         "kernels": kernels,

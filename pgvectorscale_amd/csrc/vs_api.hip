@@ -694,9 +694,6 @@ static Caps initial_caps(const vs_index* ix, uint32_t L, uint32_t M) {
         const double want = 0.75 * ix->obs.ins_mean;
         hl_auto = want > 2047 ? 4095 : (want > 1023 ? 2047 : 1023);
     }
-    // k_search_mx (VS_MX): four heaps per wave share the LDS, and runs of pushes are staged, so a smaller resident top
-    // (12 waves of 13 KB per CU) is the better trade there
-    if (!lds_table && env_u32("VS_MX", 0)) hl_auto = 511;
     c.f_hl = env_u32("VS_F_HL", hl_auto);
     const uint32_t want_v = (uint32_t)std::min<uint64_t>((uint64_t)L + L / 2 + 32, 1u << 20);
     // visited list: register resident (8 VGPR pairs) while LDS is the limiter; in the table-less regime registers are,

@@ -16,6 +16,13 @@ __device__ __forceinline__ uint32_t quad_sum(uint32_t v) {
     return v;
 }
 
+// 16 bytes of a code row read once per scan: a non-temporal load (global_load_dwordx4 ... nt), so the stream of gathered
+// rows does not push the scans' own working sets (dedup tables, heap spill) out of L2
+__device__ __forceinline__ ulonglong2 load_stream16(const uint64_t* p) {
+    const __uint128_t v = __builtin_nontemporal_load(reinterpret_cast<const __uint128_t*>(p));
+    return make_ulonglong2((unsigned long long)v, (unsigned long long)(v >> 64));
+}
+
 __device__ __forceinline__ uint32_t hash_u32(uint32_t x) {
     x ^= x >> 16;
     x *= 0x7feb352dU;

@@ -175,9 +175,6 @@ struct FastLaunch {
     uint64_t* phase = nullptr;  // optional [nq][8] per-phase shader-clock sums (VS_PHASE=1, diagnostics only)
 };
 size_t fast_lds_bytes(const vs_index* idx, const FastLaunch& s);
-// four-scans-per-wave form of the same kernel (vs_search_mx.hip; table-less regime; opt-in through VS_MX=1)
-bool search_mx_eligible(const vs_index* idx, const FastLaunch& s);
-int launch_search_mx(vs_index* idx, const FastLaunch& s);
 int launch_search_fast(vs_index* idx, const FastLaunch& s);
 enum { ST_VISITS = 0, ST_CAND = 1, ST_DQ = 2, ST_READS = 3, ST_NEXT = 4, ST_GSPILL = 5, ST_PFHIT = 6, ST_N = 8 };
 enum { OVF_HEAP = 1, OVF_VISITED = 2, OVF_HASH = 4, OVF_POOL = 8 };

@@ -18,7 +18,11 @@
 //   * dedup set ("inserted", HashSet<ItemPointer>): exact open-addressing table in LDS (ds_cmpst), never rehashed, so
 //     a slot index is a stable handle for the node id.  When it reaches 87.5 % load it is frozen (read-only) and new
 //     ids go to a per-scan global table (handles >= lh) that the wave clears lazily — the long tail of scans pays L2
-//     latency for its last inserts instead of forcing every scan to reserve LDS for the worst case.
+//     latency for its last inserts instead of forcing every scan to reserve LDS for the worst case.  Big scans (lh == 0,
+//     the "table-less" regime) keep every id there.  The global table belongs to ONE wave, so it needs no atomics (an L2
+//     atomic costs a 64-byte write to the memory side each; scripts/microbench/randmem.hip: 26 G/s for the whole chip
+//     against 60-100 G/s for loads): a probe is one 16-byte load of a bucket of four slots, an insert a 4-byte store, and
+//     lanes that want the same bucket in the same step are told apart by an LDS counter.
 //   * visited list (sorted Vec<ListSearchNeighbor>): sorted array in REGISTERS (entry i = lane i % 64 of register
 //     i / 64); insert / remove(0) are DPP wave shifts, no LDS traffic.  (LDS ring buffer when it does not fit.)
 //   * the query code lives in registers (4 lanes x 16 B per code row, NCH steps).
@@ -31,6 +35,7 @@
 #include "vs_device.h"
 
 #define MAX_QLABELS 64
+#define ARB_SLOTS 128
 
 struct FastArgs {
     const uint64_t* codes;
@@ -51,15 +56,13 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-__device__ __forceinline__ uint32_t gload32(const uint32_t* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void gstore32(uint32_t* p, uint32_t v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ uint64_t gload64u(const uint64_t* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
+// Per-scan global state (heap spill array, dedup table) is private to one wave: plain loads and stores.  The vector memory
+// operations of a wave reach its CU's L1 in program order and no other CU ever writes these lines, so a lane reads what any
+// lane of the wave stored earlier (wave_sync() keeps the compiler from reordering across the hand-over); the lines stay
+// write-back in L2 instead of costing a fabric write per store as agent-scope stores do.
+__device__ __forceinline__ uint32_t gload32(const uint32_t* p) { return *p; }
+__device__ __forceinline__ void gstore32(uint32_t* p, uint32_t v) { *p = v; }
+__device__ __forceinline__ uint64_t gload64u(const uint64_t* p) { return *p; }
 __device__ __forceinline__ uint32_t readlane_u32(uint32_t v, uint32_t l) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l);
 }
@@ -435,7 +438,7 @@ __device__ __forceinline__ uint32_t ham_row_reg(const uint64_t* __restrict__ row
 #pragma unroll
             for (int t = 0; t < NCH; ++t) {
                 const uint32_t w = 2u * (uint32_t)l4 + 8u * (uint32_t)t;
-                r[t] = w < code_stride ? *reinterpret_cast<const ulonglong2*>(row + w) : make_ulonglong2(0, 0);
+                r[t] = w < code_stride ? load_stream16(row + w) : make_ulonglong2(0, 0);
             }
 #pragma unroll
             for (int t = 0; t < NCH; ++t)
@@ -473,7 +476,8 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
     uint32_t* surv_id = lhash + s.lh;                                 // 64
     uint32_t* surv_slot = surv_id + 64;                               // 64
     uint32_t* surv_d = surv_slot + 64;                                // 64
-    uint64_t* ring = reinterpret_cast<uint64_t*>(surv_d + 64);        // vcap entries (VR == 0 only)
+    uint32_t* arb = surv_d + 64;                                      // ARB_SLOTS rank counters of the global dedup table (zero between uses)
+    uint64_t* ring = reinterpret_cast<uint64_t*>(arb + ARB_SLOTS);    // vcap entries (VR == 0 only)
     int16_t* ql = reinterpret_cast<int16_t*>(ring + (VR > 0 ? 0 : s.vcap));  // MAX_QLABELS
     uint64_t* qc_l = reinterpret_cast<uint64_t*>(ql + MAX_QLABELS);   // code_stride words (NCH == 0 only)
 
@@ -493,6 +497,7 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
     for (uint32_t i = 4u * lane; i < s.lh; i += 4u * WAVE)
         *reinterpret_cast<uint4*>(lhash + i) = make_uint4(VS_EMPTY, VS_EMPTY, VS_EMPTY, VS_EMPTY);
     if (lane == 0) hp[0] = 0;  // heap sentinel
+    for (uint32_t i = lane; i < ARB_SLOTS; i += WAVE) arb[i] = 0;
     const bool labels_some = s.qlabel_off != nullptr;  // LabeledVector.labels is Some (AM/labels/mod.rs:222-236)
     uint32_t nql = 0;
     if (labels_some) {
@@ -553,7 +558,7 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
     // uniform with rfl() where it is needed, so the latency overlaps whatever runs in between.
     auto node_load = [&](uint32_t handle) -> uint32_t {
         if (handle < s.lh) return lhash[handle];
-        return gload32(ghash + (handle - s.lh));
+        return ghash[handle - s.lh];
     };
     // true where the id was not present before; slot_out = its handle
     auto finish_insert = [&](uint32_t nid, bool act, uint32_t slot, uint32_t old, uint32_t& slot_out) -> bool {
@@ -570,8 +575,67 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
         nins += (uint32_t)__popcll(__ballot(fresh));
         return fresh;
     };
+    // ---- the per-scan global table (handles lh .. lh + gcap - 1).  Buckets of four slots (one aligned 16-byte load); the
+    // probe sequence of an id starts at its home bucket and moves to the next bucket only past a FULL one, so "the id is not
+    // in this bucket and the bucket has an empty slot" means the id is absent.  Lanes that want a slot of their bucket in
+    // the same step draw distinct ranks from an LDS counter (lanes of other buckets sharing the counter only waste ranks)
+    // and take the rank-th empty slot; a lane whose rank is past the bucket's empties looks at the bucket again.
+    const bool gmode = s.lh == 0;  // table-less regime: every id lives in the global table
+    auto ghash_home = [&](uint32_t nid) -> uint32_t { return hash_u32(nid ^ 0x5bd1e995u) & gmask & ~3u; };
+    auto bucket_load = [&](uint32_t b0) -> uint4 { return *reinterpret_cast<const uint4*>(ghash + b0); };
+    // v = the bucket at b0 as loaded by the caller (where act).  true where the id was not present before
+    auto global_insert = [&](uint32_t nid, bool act, uint32_t b0, uint4 v, uint32_t& slot_out) -> bool {
+        bool fresh = false, pend = act;
+        for (;;) {
+            uint32_t em = 0;
+            if (pend) {
+                const uint32_t hit = (v.x == nid ? 1u : 0u) | (v.y == nid ? 2u : 0u) | (v.z == nid ? 4u : 0u) | (v.w == nid ? 8u : 0u);
+                if (hit) {
+                    slot_out = s.lh + b0 + (uint32_t)__builtin_ctz(hit);
+                    pend = false;
+                } else {
+                    em = (v.x == VS_EMPTY ? 1u : 0u) | (v.y == VS_EMPTY ? 2u : 0u) | (v.z == VS_EMPTY ? 4u : 0u) | (v.w == VS_EMPTY ? 8u : 0u);
+                    if (em == 0) b0 = (b0 + 4u) & gmask;
+                }
+            }
+            const bool want = pend && em != 0;
+            uint32_t* ctr = arb + ((b0 >> 2) & (ARB_SLOTS - 1u));
+            uint32_t rank = 0;
+            if (want) rank = atomicAdd(ctr, 1u);  // ds_add_rtn_u32
+            wave_sync();
+            if (want) {
+                *ctr = 0;
+                if (rank < (uint32_t)__popc(em)) {
+                    uint32_t m = em;
+                    if (rank > 0) m &= m - 1u;
+                    if (rank > 1) m &= m - 1u;
+                    if (rank > 2) m &= m - 1u;
+                    const uint32_t at = b0 + (uint32_t)__builtin_ctz(m);
+                    ghash[at] = nid;
+                    slot_out = s.lh + at;
+                    fresh = true;
+                    pend = false;
+                }
+            }
+            wave_sync();
+            if (!__ballot(pend)) break;
+            if (pend) v = bucket_load(b0);  // (this wave's stores of the round above are visible: same CU, program order)
+        }
+        nins_g += (uint32_t)__popcll(__ballot(fresh));
+        return fresh;
+    };
+    auto open_table = [&]() -> bool {  // first use: this wave claims and clears its own table
+        if (g_open) return true;
+        if (!claim_region()) return false;
+        g_open = true;
+        for (uint32_t i = 4u * lane; i < s.gcap; i += 4u * WAVE)
+            *reinterpret_cast<uint4*>(ghash + i) = make_uint4(VS_EMPTY, VS_EMPTY, VS_EMPTY, VS_EMPTY);
+        wave_sync();
+        return true;
+    };
+    // Frozen mode (LDS table at its load limit): read-only probe of the LDS table, then the global table
     auto frozen_insert = [&](uint32_t nid, bool act, uint32_t& slot_out) -> bool {
-        bool need_g = act, fresh = false;
+        bool need_g = act;
         if (act && s.lh) {
             uint32_t slot = hash_home(nid);
             for (;;) {
@@ -581,58 +645,19 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
                 slot = slot + 1 == s.lh ? 0 : slot + 1;
             }
         }
-        if (__ballot(need_g)) {
-            if (!g_open) {  // first use: this wave claims and clears its own table
-                if (!claim_region()) return false;
-                g_open = true;
-                for (uint32_t i = 4u * lane; i < s.gcap; i += 4u * WAVE)
-                    *reinterpret_cast<uint4*>(ghash + i) = make_uint4(VS_EMPTY, VS_EMPTY, VS_EMPTY, VS_EMPTY);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            }
-            if ((nins_g + WAVE) * 4u > s.gcap * 3u) {
-                status |= OVF_HASH;
-                return false;
-            }
-            if (need_g) {
-                uint32_t gs = hash_u32(nid ^ 0x5bd1e995u) & gmask;
-                for (;;) {
-                    const uint32_t o = atomicCAS(&ghash[gs], VS_EMPTY, nid);  // L2 atomic
-                    if (o == VS_EMPTY) { fresh = true; break; }
-                    if (o == nid) break;
-                    gs = (gs + 1) & gmask;
-                }
-                slot_out = s.lh + gs;
-            }
-            nins_g += (uint32_t)__popcll(__ballot(fresh));
+        if (!__ballot(need_g)) return false;
+        if (!open_table()) return false;
+        if ((nins_g + WAVE) * 4u > s.gcap * 3u) {
+            status |= OVF_HASH;
+            return false;
         }
-        return fresh;
+        const uint32_t b0 = ghash_home(nid);
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (need_g) v = bucket_load(b0);
+        return global_insert(nid, need_g, b0, v, slot_out);
     };
 
-    // ---- table-less mode (lh == 0): every id lives in the global table; the first CAS is issued by the caller
-    const bool gmode = s.lh == 0;
-    auto ghash_home = [&](uint32_t nid) -> uint32_t { return hash_u32(nid ^ 0x5bd1e995u) & gmask; };
-    auto finish_global = [&](uint32_t nid, bool act, uint32_t gs, uint32_t old, uint32_t& slot_out) -> bool {
-        bool fresh = false;
-        if (act) {
-            for (;;) {
-                if (old == VS_EMPTY) { fresh = true; break; }
-                if (old == nid) break;
-                gs = (gs + 1) & gmask;
-                old = atomicCAS(&ghash[gs], VS_EMPTY, nid);  // L2 atomic
-            }
-            slot_out = gs;  // handle = lh + gs with lh == 0
-        }
-        nins_g += (uint32_t)__popcll(__ballot(fresh));
-        return fresh;
-    };
-    if (gmode) {  // claim and clear this scan's table up front
-        if (claim_region()) {
-            g_open = true;
-            for (uint32_t i = 4u * lane; i < s.gcap; i += 4u * WAVE)
-                *reinterpret_cast<uint4*>(ghash + i) = make_uint4(VS_EMPTY, VS_EMPTY, VS_EMPTY, VS_EMPTY);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        }
-    }
+    if (gmode) open_table();  // claimed and cleared up front
 
     // ---- ListSearchResult::new: start nodes (AM/graph/mod.rs:97-124, AM/graph/start_nodes.rs:39-48) ----
     {
@@ -761,11 +786,12 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
             const bool act = (uint32_t)lane < nvalid;
             lap(1);
             // prepare_insert (marks BEFORE the label check, AM/sbq/storage.rs:148-172): first probe issued, ...
-            const bool frozen = nins + WAVE > slot_limit;
+            const bool frozen = !gmode && nins + WAVE > slot_limit;
             uint32_t hslot = gmode ? ghash_home(nid) : hash_home(nid), old = VS_EMPTY;
+            uint4 gbk = make_uint4(0, 0, 0, 0);
             if (gmode) {
                 if ((nins_g + WAVE) * 4u > s.gcap * 3u) { status |= OVF_HASH; break; }
-                if (act) old = atomicCAS(&ghash[hslot], VS_EMPTY, nid);  // L2 atomic, in flight during the visited insert
+                if (act) gbk = bucket_load(hslot);  // in flight during the visited insert
             } else if (!frozen && act) {
                 old = atomicCAS(&lhash[hslot], VS_EMPTY, nid);
             }
@@ -778,7 +804,7 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
             // ... then the probe sequence is finished
             bool fresh;
             if (gmode) {
-                fresh = finish_global(nid, act, hslot, old, hslot);
+                fresh = global_insert(nid, act, hslot, gbk, hslot);
             } else if (frozen) {
                 fresh = frozen_insert(nid, act, hslot);
                 if (status) break;
@@ -913,7 +939,7 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
 
 size_t fast_lds_bytes(const vs_index* idx, const FastLaunch& s) {
     const size_t qcopy = (idx->code_stride + 7) / 8 > 6 ? (size_t)idx->code_stride * 8 : 0;  // NCH == 0 variant only
-    size_t b = (size_t)(s.hl + 1) * 4 + (size_t)s.lh * 4 + 3 * 64 * 4 + (s.vr ? 0 : (size_t)s.vcap * 8) + MAX_QLABELS * 2 + qcopy + 16;
+    size_t b = (size_t)(s.hl + 1) * 4 + (size_t)s.lh * 4 + 3 * 64 * 4 + ARB_SLOTS * 4 + (s.vr ? 0 : (size_t)s.vcap * 8) + MAX_QLABELS * 2 + qcopy + 16;
     return (b + 15) / 16 * 16;
 }
 
@@ -957,13 +983,6 @@ static int launch_fast_t(vs_index* idx, const FastArgs& a, size_t lds) {
 
 int launch_search_fast(vs_index* idx, const FastLaunch& s) {
     if (s.nq == 0) return VS_OK;
-    {  // opt-in: the four-scans-per-wave kernel where it applies (vs_search_mx.hip)
-        const char* e = getenv("VS_MX");  // 1: where it applies; 2: insist (tests: a launch it does not cover is an error)
-        if (e && (*e == '1' || *e == '2')) {
-            if (search_mx_eligible(idx, s)) return launch_search_mx(idx, s);
-            VS_REQUIRE(*e != '2' || s.build, "VS_MX=2: this launch is outside the geometry k_search_mx covers");
-        }
-    }
     FastArgs a;
     a.codes = idx->codes;
     a.nbrs = idx->nbrs;

@@ -3,7 +3,7 @@
 
 Random index geometries (size, dimensions, bits, R, distance, labels, deleted tuples, matryoshka slice) x random scan
 parameters (L, rescore, k, label keys, NULL queries) x the kernels and regimes the library can be steered into
-(k_search_fast regimes, k_search_mx, the general kernel).  Every case must reproduce the oracle: ids bit for bit, distances
+(k_search_fast regimes, the general kernel).  Every case must reproduce the oracle: ids bit for bit, distances
 within 1e-5, the SBQ stream (ids + Hamming distances) and the work counters exactly.
 
   make -C tests/emu && python scripts/fuzz_emu.py --seconds 600 [--seed 1] [--gpu]
@@ -25,11 +25,6 @@ import numpy as np  # noqa: E402
 REGIMES = [
     {},
     {"VS_F_LDS_MAX_INS": "0"},
-    {"VS_F_LDS_MAX_INS": "0", "VS_MX": "1"},
-    {"VS_F_LDS_MAX_INS": "0", "VS_MX": "1", "VS_MX_GD": "4"},
-    {"VS_F_LDS_MAX_INS": "0", "VS_MX": "1", "VS_MX_PERSIST": "0"},
-    {"VS_F_LDS_MAX_INS": "0", "VS_MX": "1", "VS_MX_GRID": "1"},
-    {"VS_F_LDS_MAX_INS": "0", "VS_MX": "1", "VS_F_HL": "63"},
     {"VS_F_LDS_MAX_INS": "0", "VS_F_VR": "8", "VS_F_MINW": "4"},
     {"VS_F_LH": "256"},
     {"VS_F_VR": "0", "VS_F_VCAP": "64"},

@@ -159,6 +159,7 @@ static inline T emu_shfl(T v, int from, const char* f, int l) {
 #define __popcll(x) __builtin_popcountll((unsigned long long)(x))
 #define __popc(x) __builtin_popcount((unsigned)(x))
 #define __builtin_readcyclecounter() ((uint64_t)__rdtsc())
+#define __builtin_nontemporal_load(p) (*(p))
 #define __HIP_MEMORY_SCOPE_AGENT 4
 #define __HIP_MEMORY_SCOPE_WAVEFRONT 2
 #define __HIP_MEMORY_SCOPE_WORKGROUP 3

@@ -1,5 +1,5 @@
 """bench.py end to end without a GPU: its whole control flow (on-device index manufacture, ground truth, operating-point
-search, k_search_mx canary child process + A/B, timed steps, flat-scan section, CPU baseline + closing parity check, JSON
+search, timed steps, flat-scan section, CPU baseline + closing parity check, JSON
 assembly) runs against the wave64 interpreter build of the kernels (VS_EMU=1).  The numbers of such a run mean nothing;
 the point is that a typo in the benchmark cannot wait for the round-end GPU run to be found.  ~2 minutes: only with
 VS_EMU_FULL=1."""
@@ -17,8 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_bench_dry_run_on_the_interpreter():
     r = subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "emu"), "-j8", "-s"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
-    env = dict(os.environ, VS_EMU="1", VS_BENCH_TRY_MX="1", VS_F_LDS_MAX_INS="0")
-    env.pop("VS_MX", None)
+    env = dict(os.environ, VS_EMU="1", VS_F_LDS_MAX_INS="0")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--n", "6000", "--dim", "64", "--nq", "128", "--steps", "1", "--warmup", "1",
            "--recall-queries", "16", "--scan-nq", "8", "--cpu-seconds", "1", "--graph-cache", "none"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, cwd=ROOT, timeout=1500)
@@ -30,8 +29,6 @@ def test_bench_dry_run_on_the_interpreter():
     assert "DRY RUN" in j["data"] and j["config"]["workload"]
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(j["roofline"])
     assert j["cpu_baseline"]["gpu_rows_identical"] is True and j["cpu_baseline"]["gpu_dist_bit_identical_frac"] == 1.0
-    sk = j["search_kernel"]
-    assert sk["canary"].startswith("passed") and all(sk["results_identical"].values()) and len(sk["ms_per_step"]) == 5 and sk["canary_gd4"].startswith("passed")
     assert j["recall_target_met"] is True
 
 
@@ -40,8 +37,7 @@ def test_bench_dry_run_two_ranks():
     """the N > 1 launch line of the driver (torch.distributed.run, one rank per GPU), with gloo standing in for RCCL"""
     r = subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "emu"), "-j8", "-s"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
-    env = dict(os.environ, VS_EMU="1", VS_EMU_THREADS="4", VS_BENCH_TRY_MX="1", VS_F_LDS_MAX_INS="0")
-    env.pop("VS_MX", None)
+    env = dict(os.environ, VS_EMU="1", VS_EMU_THREADS="4", VS_F_LDS_MAX_INS="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29519", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--corpus", "4000", "--dim", "64", "--nq", "64",
            "--steps", "1", "--warmup", "1", "--recall-queries", "16", "--scan-nq", "0", "--cpu-seconds", "1", "--graph-cache", "none",
@@ -50,21 +46,3 @@ def test_bench_dry_run_two_ranks():
     assert r.returncode == 0, r.stderr[-3000:]
     j = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
     assert j["n_gpus"] == 2 and j["scaling"] == "weak" and "query-sharded x2" in j["config"]["parallelism"]
-    assert all(j["search_kernel"]["results_identical"].values())
-
-
-@pytest.mark.skipif(not os.environ.get("VS_EMU_FULL"), reason="slow (about 2 minutes); set VS_EMU_FULL=1")
-def test_bench_repeats_without_the_exploration_when_the_ab_dies():
-    """N = 1 runs in a supervised child: a fault inside the k_search_mx A/B (simulated: abort()) must cost a repeat on
-    k_search_fast, not the bench line"""
-    env = dict(os.environ, VS_EMU="1", VS_BENCH_TRY_MX="1", VS_F_LDS_MAX_INS="0", VS_BENCH_TEST_CRASH="ab")
-    env.pop("VS_MX", None)
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--n", "4000", "--dim", "64", "--nq", "64", "--steps", "1", "--warmup", "1",
-           "--recall-queries", "16", "--scan-nq", "0", "--cpu-seconds", "1", "--graph-cache", "none", "--fixed", "100,50"]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, cwd=ROOT, timeout=1500)
-    assert r.returncode == 0, r.stderr[-3000:]
-    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
-    assert len(lines) == 1
-    j = json.loads(lines[0])
-    assert j["search_kernel"]["chosen"] == "k_search_fast" and "exit code" in j["search_kernel"]["first_attempt"]
-    assert j["cpu_baseline"]["gpu_rows_identical"] is True

@@ -1,7 +1,7 @@
 """BASELINE.json configs[4] in miniature: 1536-d unit-norm mixture ("OpenAI-like"), SBQ 1 bit (24-word codes), 32 labels with
 Zipf frequencies and 1-3 labels per vector, label-filtered scans with one and with two labels in the key
 (Filtered-DiskANN predicate = LabelSet overlap, AM/labels/mod.rs:124-142; start nodes per label, AM/graph/start_nodes.rs:39-48).
-Rows and work counters must equal the oracle's on k_search_fast and on k_search_mx."""
+Rows and work counters must equal the oracle's in the LDS-table and in the table-less regime of k_search_fast."""
 import os
 
 import numpy as np
@@ -21,12 +21,11 @@ def _close(a, b):
     return np.all(nan | (np.abs(a - b) <= 1e-5 * np.maximum(np.abs(b), 1e-30) + 1e-12))
 
 
-@pytest.mark.parametrize("kernel", ["k_search_fast", "k_search_mx"])
-def test_label_filtered_1536d_one_bit(gpu_ctx, oracle, kernel, monkeypatch):
+@pytest.mark.parametrize("regime", ["lds_table", "tableless"])
+def test_label_filtered_1536d_one_bit(gpu_ctx, oracle, regime, monkeypatch):
     ti = cached_index(**KW)
     assert ti.bits == 1 and ti.codes.shape[1] == 24
-    if kernel == "k_search_mx":
-        monkeypatch.setenv("VS_MX", "2")
+    if regime == "tableless":
         monkeypatch.setenv("VS_F_LDS_MAX_INS", "0")
     ix = ti.upload(gpu_ctx)
     nq = 48

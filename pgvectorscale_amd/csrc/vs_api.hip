@@ -694,6 +694,9 @@ static Caps initial_caps(const vs_index* ix, uint32_t L, uint32_t M) {
         const double want = 0.75 * ix->obs.ins_mean;
         hl_auto = want > 2047 ? 4095 : (want > 1023 ? 2047 : 1023);
     }
+    // k_search_mx (VS_MX): four heaps per wave share the LDS, and runs of pushes are staged, so a smaller resident top
+    // (12 waves of 13 KB per CU) is the better trade there
+    if (!lds_table && env_u32("VS_MX", 0)) hl_auto = 511;
     c.f_hl = env_u32("VS_F_HL", hl_auto);
     const uint32_t want_v = (uint32_t)std::min<uint64_t>((uint64_t)L + L / 2 + 32, 1u << 20);
     // visited list: register resident (8 VGPR pairs) while LDS is the limiter; in the table-less regime registers are,
@@ -706,6 +709,7 @@ static Caps initial_caps(const vs_index* ix, uint32_t L, uint32_t M) {
         c.f_hl = std::max<uint32_t>(next_pow2_u32(c.f_hl + 1), 64) - 1;
         // overflow table: room for every candidate the worst scan could insert beyond the LDS table
         c.f_gcap = next_pow2_u32(std::min<uint64_t>(std::max<uint64_t>(std::min<uint64_t>(pushes, 4 * typ_ins), 1024), 1u << 22));
+        if (const uint32_t g = env_u32("VS_F_GCAP", 0)) c.f_gcap = next_pow2_u32(std::max<uint32_t>(g, 256));
         c.f_sb = 0;
         while ((1ull << c.f_sb) < (uint64_t)c.f_lh + c.f_gcap) c.f_sb++;
         c.f_hcap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(pushes, c.f_hl), 1u << 22);
@@ -889,6 +893,7 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
         f.pool_slots = fslots;
         f.lh = caps.f_lh;
         f.minw = env_u32("VS_F_MINW", (caps.f_lh == 0 && caps.f_vr) ? 4 : 1);
+        f.flags = env_u32("VS_F_FLAGS", 0);
         f.sb = caps.f_sb;
         f.vcap = caps.f_vcap;
         f.qcodes = (const uint64_t*)w.qcodes.p;

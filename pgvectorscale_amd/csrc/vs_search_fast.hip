@@ -430,7 +430,7 @@ struct Visited {
 
 template <int NCH>
 __device__ __forceinline__ uint32_t ham_row_reg(const uint64_t* __restrict__ row, const ulonglong2 (&qv)[NCH > 0 ? NCH : 1],
-                                                const uint64_t* qc_l, int l4, uint32_t code_stride, bool active) {
+                                                const uint64_t* qc_l, int l4, uint32_t code_stride, bool active, bool stream) {
     uint32_t acc = 0;
     if (NCH > 0) {
         if (active) {
@@ -438,7 +438,8 @@ __device__ __forceinline__ uint32_t ham_row_reg(const uint64_t* __restrict__ row
 #pragma unroll
             for (int t = 0; t < NCH; ++t) {
                 const uint32_t w = 2u * (uint32_t)l4 + 8u * (uint32_t)t;
-                r[t] = w < code_stride ? load_stream16(row + w) : make_ulonglong2(0, 0);
+                r[t] = w >= code_stride ? make_ulonglong2(0, 0)
+                       : stream ? load_stream16(row + w) : *reinterpret_cast<const ulonglong2*>(row + w);
             }
 #pragma unroll
             for (int t = 0; t < NCH; ++t)
@@ -482,6 +483,7 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
     uint64_t* qc_l = reinterpret_cast<uint64_t*>(ql + MAX_QLABELS);   // code_stride words (NCH == 0 only)
 
     const int l4 = lane & 3;
+    const bool stream_rows = !(s.flags & FAST_PLAIN_ROW_LOADS);
     ulonglong2 qv[NCH > 0 ? NCH : 1];
     if (NCH > 0) {
 #pragma unroll
@@ -521,6 +523,7 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
     const uint32_t smask = (1u << s.sb) - 1u;
     uint32_t emitted = 0, status = 0, nins = 0, hmax = 0;
     uint32_t st_visits = 0, st_cand = 0, st_dq = 0, st_reads = 0, st_pfhit = 0;
+    uint32_t xdummy = 0;
     // optional phase clock (s_memtime): 0 pop, 1 row wait, 2 visited, 3 dedup, 4 gather, 5 push, 6 other
     uint64_t ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t tmark = TIMING ? __builtin_readcyclecounter() : 0;
@@ -587,6 +590,7 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
     auto global_insert = [&](uint32_t nid, bool act, uint32_t b0, uint4 v, uint32_t& slot_out) -> bool {
         bool fresh = false, pend = act;
         for (;;) {
+            wave_sync();  // every lane holds its snapshot before any lane stores (the loads are earlier instructions)
             uint32_t em = 0;
             if (pend) {
                 const uint32_t hit = (v.x == nid ? 1u : 0u) | (v.y == nid ? 2u : 0u) | (v.z == nid ? 4u : 0u) | (v.w == nid ? 8u : 0u);
@@ -693,7 +697,7 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
             slot = rfl(slot);
             st_reads++;
             const uint32_t d =
-                rfl(ham_row_reg<NCH>(a.codes + (size_t)sn * a.code_stride, qv, qc_l, l4, a.code_stride, lane < 4));
+                rfl(ham_row_reg<NCH>(a.codes + (size_t)sn * a.code_stride, qv, qc_l, l4, a.code_stride, lane < 4, stream_rows));
             st_dq++;
             st_cand++;
             if (heap.len + 1 > s.hcap) { status |= OVF_HEAP; break; }
@@ -792,6 +796,10 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
             if (gmode) {
                 if ((nins_g + WAVE) * 4u > s.gcap * 3u) { status |= OVF_HASH; break; }
                 if (act) gbk = bucket_load(hslot);  // in flight during the visited insert
+                if ((s.flags & FAST_X_BUCKET) && act) {  // measurement: what does one more probe per id cost?
+                    const uint4 x = bucket_load(hash_u32(nid * 2654435761u + 17u) & gmask & ~3u);
+                    xdummy += x.x ^ x.w;
+                }
             } else if (!frozen && act) {
                 old = atomicCAS(&lhash[hslot], VS_EMPTY, nid);
             }
@@ -857,7 +865,10 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
                         pfa_val = ((uint32_t)lane < a.R) ? a.nbrs[(size_t)pfa_node * a.nbr_stride + lane] : VS_INVALID_NODE;
                     }
                 }
-                const uint32_t d = ham_row_reg<NCH>(crow, qv, qc_l, l4, a.code_stride, valid);
+                if (s.flags & FAST_X_ROWS)  // measurement: what does one more code row per candidate cost?
+                    xdummy += ham_row_reg<NCH>(a.codes + (size_t)(hash_u32(id + 1u) % a.n) * a.code_stride, qv, qc_l, l4,
+                                               a.code_stride, valid, stream_rows);
+                const uint32_t d = ham_row_reg<NCH>(crow, qv, qc_l, l4, a.code_stride, valid, stream_rows);
                 if (valid && l4 == 0) surv_d[j] = d;
             }
             st_dq += c;
@@ -916,6 +927,7 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
             s.out_ham[(size_t)q * s.M + i] = 0xFFFFFFFFu;
         }
     }
+    if (xdummy == 0x12345677u && lane == 77) s.status[q] = 1;  // (keeps the measurement loads alive; never true)
     if (lane == 0) {
         s.status[q] = status;
         s.out_cnt[q] = status ? 0 : emitted;  // a failed scan publishes an empty stream until the fallback re-runs it
@@ -963,8 +975,9 @@ static int launch_fast_t(vs_index* idx, const FastArgs& a, size_t lds) {
         return launch_fast_tt<NCH, 0, false, 1, true>(idx, a, lds);
     }
     if (a.s.phase) {
-        VS_REQUIRE(NCH == 3 && a.s.vr == 8, "VS_PHASE diagnostics are built for 17..24-word codes / register visited list only");
-        return launch_fast_tt<3, 8, true, 1, false>(idx, a, lds);
+        VS_REQUIRE(NCH == 3, "VS_PHASE diagnostics are built for 17..24-word codes only");
+        if (a.s.vr == 8) return launch_fast_tt<3, 8, true, 1, false>(idx, a, lds);
+        return launch_fast_tt<3, 0, true, 1, false>(idx, a, lds);
     }
     if (a.s.vr == 8) {
         if (NCH == 3) {  // the headline geometry (768 x 2 bit, 1536 x 1 bit): register-capped variants for the occupancy-bound regime
@@ -983,6 +996,13 @@ static int launch_fast_t(vs_index* idx, const FastArgs& a, size_t lds) {
 
 int launch_search_fast(vs_index* idx, const FastLaunch& s) {
     if (s.nq == 0) return VS_OK;
+    {  // the four-scans-per-wave kernel where it applies (vs_search_mx.hip)
+        const char* e = getenv("VS_MX");  // 1: where it applies; 2: insist (tests: a launch it does not cover is an error)
+        if (e && (*e == '1' || *e == '2')) {
+            if (search_mx_eligible(idx, s)) return launch_search_mx(idx, s);
+            VS_REQUIRE(*e != '2' || s.build, "VS_MX=2: this launch is outside the geometry k_search_mx covers");
+        }
+    }
     FastArgs a;
     a.codes = idx->codes;
     a.nbrs = idx->nbrs;

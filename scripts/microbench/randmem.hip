@@ -44,7 +44,11 @@ __global__ __launch_bounds__(64) void k_mix(const uint8_t* __restrict__ codes, u
                 uint32_t old;
                 if (PROBE == 0 || PROBE == 3) old = atomicCAS(&tab[slot], PROBE == 3 ? 0xFFFFFFFEu : 0xFFFFFFFFu, nid);
                 else if (PROBE == 1) old = __hip_atomic_load(&tab[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                else {
+                else if (PROBE == 4) {
+                    const uint4 b = *reinterpret_cast<const uint4*>(tab + (slot & ~3u));
+                    old = b.x ^ b.y ^ b.z ^ b.w;
+                    if ((h >> 24) < 156u) tab[slot] = nid;  // 61 % of the probes insert
+                } else {
                     old = __hip_atomic_load(&tab[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (old == 0xFFFFFFFFu) old = atomicCAS(&tab[slot], 0xFFFFFFFFu, nid);
                 }
@@ -88,7 +92,7 @@ static double run(const char* name, const uint8_t* codes, uint64_t nrows, uint32
                   uint32_t fillv) {
     const uint32_t nwaves = 256 * waves_per_cu;
     const size_t lds = (160 * 1024) / waves_per_cu - 64;  // pins the number of resident waves per CU
-    static bool attr[8][4][2];
+    static bool attr[8][5][2];
     if (!attr[MODE][PROBE][NT]) {
         CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mix<MODE, PROBE, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr[MODE][PROBE][NT] = true;
@@ -120,12 +124,24 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&codes, nrows * 256));
     CK(hipMemset(codes, 0x5a, nrows * 256));
     uint32_t* tables;
-    const size_t tab_max = (size_t)256 * 32 * 32768;  // up to 32 waves / CU x 128 KB
+    const size_t tab_max = (size_t)256 * 32 * 65536;  // up to 32 waves / CU x 128 KB
     CK(hipMalloc(&tables, tab_max * 4));
     uint64_t* sink;
     CK(hipMalloc(&sink, 8));
     const uint32_t E = 0xFFFFFFFFu;
     const uint32_t it = 4000;
+    if (argc > 1) {  // table-size sweep of the non-atomic bucket scheme (16-byte load + 4-byte store for 61 % of the probes)
+        for (uint32_t w : {20u, 12u}) {
+            for (uint32_t tw : {1024u, 2048u, 4096u, 8192u, 16384u, 32768u, 65536u})
+                run<3, 4, 1>("mix 50 bucket-load/store + 32 rows nt", codes, nrows, 192, tables, tw, w, it, 32, 50, sink, E);
+            run<1, 0, 1>("rows only nt", codes, nrows, 192, tables, 1024, w, it, 32, 0, sink, E);
+            run<2, 4, 1>("bucket-load/store only", codes, nrows, 192, tables, 2048, w, it, 0, 50, sink, E);
+            run<2, 4, 1>("bucket-load/store only", codes, nrows, 192, tables, 16384, w, it, 0, 50, sink, E);
+        }
+        run<3, 4, 1>("mix 50 bucket-load/store + 32 rows nt", codes, nrows, 192, tables, 8192, 32, it, 32, 50, sink, E);
+        run<3, 4, 1>("mix 50 bucket-load/store + 32 rows nt", codes, nrows, 192, tables, 16384, 32, it, 32, 50, sink, E);
+        return 0;
+    }
     // ---- rows only: stride, occupancy, non-temporal
     for (uint32_t w : {8u, 16u, 20u, 32u}) run<1, 0, 0>("rows only", codes, nrows, 192, tables, 16384, w, it, 32, 0, sink, E);
     run<1, 0, 0>("rows only, 256-B stride", codes, nrows, 256, tables, 16384, 20, it, 32, 0, sink, E);

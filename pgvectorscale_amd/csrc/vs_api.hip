@@ -309,7 +309,7 @@ extern "C" void vs_index_free(vs_index* ix) {
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     SearchWorkspace& w = ix->ws;
-    DevBuf* bufs[] = {&w.q_full, &w.qcodes, &w.qlabels, &w.qlabel_off, &w.hash, &w.heap_g, &w.heap_g4, &w.ghash4, &w.pool_ctr, &w.fb_flag, &w.phase, &w.stream_ids,
+    DevBuf* bufs[] = {&w.q_full, &w.qcodes, &w.qlabels, &w.qlabel_off, &w.hash, &w.heap_g, &w.heap_g4, &w.ghash4, &w.heap_g4b, &w.ghash4b, &w.pool_ctr, &w.fb_flag, &w.phase, &w.stream_ids,
                       &w.stream_ham, &w.stream_cnt, &w.stats, &w.status, &w.rr_dist, &w.out_ids, &w.out_tids,
                       &w.out_dist, &w.resort_heap, &w.raw_q, &w.misc, &w.q_index};
     for (DevBuf* b : bufs) devbuf_free(*b);
@@ -694,9 +694,6 @@ static Caps initial_caps(const vs_index* ix, uint32_t L, uint32_t M) {
         const double want = 0.75 * ix->obs.ins_mean;
         hl_auto = want > 2047 ? 4095 : (want > 1023 ? 2047 : 1023);
     }
-    // k_search_mx (VS_MX): four heaps per wave share the LDS, and runs of pushes are staged, so a smaller resident top
-    // (12 waves of 13 KB per CU) is the better trade there
-    if (!lds_table && env_u32("VS_MX", 0)) hl_auto = 511;
     c.f_hl = env_u32("VS_F_HL", hl_auto);
     const uint32_t want_v = (uint32_t)std::min<uint64_t>((uint64_t)L + L / 2 + 32, 1u << 20);
     // visited list: register resident (8 VGPR pairs) while LDS is the limiter; in the table-less regime registers are,
@@ -913,6 +910,33 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
         VS_TRY(launch_search_fast(ix, f));
         prof_end(c, PK_SEARCH, ev);
         fast_done = true;
+        // second attempt of the scans that outgrew these capacities (a handful per launch at the tail of the distribution):
+        // the same kernel with a four times larger dedup table, twice the heap and visited-list room, regions from a small
+        // pool.  Scans finished above return at once; what still does not fit goes to the general kernel below.
+        if (env_u32("VS_F_RETRY", 1)) {
+            FastLaunch r = f;
+            r.only_failed = 1;
+            r.fb_flag = (uint32_t*)w.fb_flag.p;
+            r.phase = nullptr;
+            r.gcap = (uint32_t)std::min<uint64_t>(4ull * f.gcap, 1u << 22);
+            r.hcap = (uint32_t)std::min<uint64_t>(2ull * f.hcap, 1u << 22);
+            r.gstride = round_up_u32(r.hcap - r.hl + 2, 2);
+            if (!r.vr) r.vcap = 2 * f.vcap;
+            r.sb = 0;
+            while ((1ull << r.sb) < (uint64_t)r.lh + r.gcap) r.sb++;
+            r.pool_slots = general_pool_slots(nq);
+            r.pool_counter = (uint32_t*)((char*)w.pool_ctr.p + 16);
+            const uint64_t nbits = (uint64_t)ix->d.dim_index * ix->d.bits;
+            if (nbits < (1ull << (32 - r.sb)) && fast_lds_bytes(ix, r) <= 64 * 1024) {
+                VS_TRY(devbuf_reserve(c, w.heap_g4b, (size_t)r.pool_slots * r.gstride * 4));
+                VS_TRY(devbuf_reserve(c, w.ghash4b, (size_t)r.pool_slots * r.gcap * 4));
+                r.heap_g = (uint32_t*)w.heap_g4b.p;
+                r.ghash = (uint32_t*)w.ghash4b.p;
+                hipEvent_t ev2 = prof_begin(c);
+                VS_TRY(launch_search_fast(ix, r));
+                prof_end(c, PK_SEARCH_FB, ev2);
+            }
+        }
         if (env_u32("VS_DEBUG_STATUS", 0)) {  // diagnostics: which flags did the fast kernel leave behind?
             std::vector<uint32_t> stv(nq);
             VS_HIP(hipMemcpyAsync(stv.data(), w.status.p, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));

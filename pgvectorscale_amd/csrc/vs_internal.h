@@ -71,7 +71,7 @@ struct DevBuf {
 };
 
 struct SearchWorkspace {
-    DevBuf q_full, qcodes, qlabels, qlabel_off, hash, heap_g, heap_g4, ghash4, pool_ctr, fb_flag, phase, stream_ids, stream_ham, stream_cnt, stats, status,
+    DevBuf q_full, qcodes, qlabels, qlabel_off, hash, heap_g, heap_g4, ghash4, heap_g4b, ghash4b, pool_ctr, fb_flag, phase, stream_ids, stream_ham, stream_cnt, stats, status,
         rr_dist, out_ids, out_tids, out_dist, resort_heap, raw_q, misc, q_index;
     // pending async call (vs_search_batch_dev)
     bool fb_valid = false;  // fb_flag holds the fallback marks of the last chunk
@@ -160,6 +160,11 @@ struct FastLaunch {
     uint32_t minw;     // register cap variant: waves per SIMD to leave room for (1 = unconstrained)
     uint32_t build = 0; // 1: greedy_search_for_build (the visited list is the output; needs vr == 0)
     uint32_t flags = 0; // FAST_* (measurement switches)
+    // second attempt of the scans a first launch gave up on (bigger capacities): only scans whose status[q] != 0 run, their
+    // heap spill array comes with the dedup table region claimed from the pool (heap_g is [pool_slots][gstride] then), and
+    // fb_flag[q] is set for the statistics
+    uint32_t only_failed = 0;
+    uint32_t* fb_flag = nullptr;
     const uint64_t* qcodes;
     const int16_t* qlabels;
     const uint32_t* qlabel_off;
@@ -175,13 +180,8 @@ struct FastLaunch {
     uint32_t* status;
     uint64_t* phase = nullptr;  // optional [nq][8] per-phase shader-clock sums (VS_PHASE=1, diagnostics only)
 };
-// FAST_PLAIN_ROW_LOADS: code rows through the normal cache policy instead of non-temporal loads; FAST_X_*: sensitivity
-// measurements (one extra random bucket load per probed id / one extra random code row per candidate; results unchanged)
-enum { FAST_PLAIN_ROW_LOADS = 1, FAST_X_BUCKET = 2, FAST_X_ROWS = 4 };
+enum { FAST_PLAIN_ROW_LOADS = 1 };  // code rows through the normal cache policy instead of non-temporal loads
 size_t fast_lds_bytes(const vs_index* idx, const FastLaunch& s);
-// four-scans-per-wave form of the same kernel (vs_search_mx.hip; table-less regime)
-bool search_mx_eligible(const vs_index* idx, const FastLaunch& s);
-int launch_search_mx(vs_index* idx, const FastLaunch& s);
 int launch_search_fast(vs_index* idx, const FastLaunch& s);
 enum { ST_VISITS = 0, ST_CAND = 1, ST_DQ = 2, ST_READS = 3, ST_NEXT = 4, ST_GSPILL = 5, ST_PFHIT = 6, ST_N = 8 };
 enum { OVF_HEAP = 1, OVF_VISITED = 2, OVF_HASH = 4, OVF_POOL = 8 };

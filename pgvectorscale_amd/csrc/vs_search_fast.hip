@@ -470,6 +470,7 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
     const uint32_t q = blockIdx.x;
     const FastLaunch& s = a.s;
     if (q >= s.nq) return;
+    if (s.only_failed && s.status[q] == 0) return;  // (wave-uniform) finished by the first launch
 
     // ---- LDS carve ----
     uint32_t* hp = reinterpret_cast<uint32_t*>(smem);                 // hl + 1 (hl + 1 is a power of two >= 64)
@@ -512,7 +513,7 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
 
     FastHeap heap;
     heap.l = hp;
-    heap.g = s.heap_g + (size_t)q * s.gstride;
+    heap.g = s.only_failed ? s.heap_g : s.heap_g + (size_t)q * s.gstride;  // (second attempt: set with the pool region)
     heap.hl = s.hl;
     heap.sb = s.sb;
     heap.init(lane);
@@ -523,7 +524,6 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
     const uint32_t smask = (1u << s.sb) - 1u;
     uint32_t emitted = 0, status = 0, nins = 0, hmax = 0;
     uint32_t st_visits = 0, st_cand = 0, st_dq = 0, st_reads = 0, st_pfhit = 0;
-    uint32_t xdummy = 0;
     // optional phase clock (s_memtime): 0 pop, 1 row wait, 2 visited, 3 dedup, 4 gather, 5 push, 6 other
     uint64_t ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t tmark = TIMING ? __builtin_readcyclecounter() : 0;
@@ -554,6 +554,7 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
         }
         region = true;
         ghash = s.ghash + (size_t)slot * s.gcap;
+        if (s.only_failed) heap.g = s.heap_g + (size_t)slot * s.gstride;
         return true;
     };
     auto hash_home = [&](uint32_t nid) -> uint32_t { return (uint32_t)(((uint64_t)hash_u32(nid) * s.lh) >> 32); };
@@ -662,6 +663,7 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
     };
 
     if (gmode) open_table();  // claimed and cleared up front
+    else if (s.only_failed) claim_region();  // (the heap spill array of a second attempt comes with the region)
 
     // ---- ListSearchResult::new: start nodes (AM/graph/mod.rs:97-124, AM/graph/start_nodes.rs:39-48) ----
     {
@@ -716,8 +718,8 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
     uint32_t ft_node = VS_INVALID_NODE;  // heap tid of the visited list's front entry, requested ahead of consume()
     uint64_t ft_val = 0;
     while (status == 0) {
-        if (VR > 0 && vis.len > 0) {
-            const uint32_t fn = readlane_u32(vis.n[0], 0);
+        if (vis.len > 0) {
+            const uint32_t fn = VR > 0 ? readlane_u32(vis.n[0], 0) : rfl((uint32_t)vis.ring[vis.head]);
             if (fn != ft_node) {
                 ft_node = fn;
                 ft_val = a.tids[fn];
@@ -737,7 +739,7 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
             uint32_t fd, fnode;
             vis.pop_front(fd, fnode);
             st_reads++;
-            const uint64_t tid = (VR > 0 && fnode == ft_node) ? ft_val : a.tids[fnode];
+            const uint64_t tid = fnode == ft_node ? ft_val : a.tids[fnode];
             if ((tid & 0xFFFFull) == 0) continue;  // InvalidOffsetNumber: deleted tuple (AM/scan.rs:231-234)
             if (lane == 0) {
                 s.out_ids[(size_t)q * s.M + emitted] = fnode;
@@ -796,10 +798,6 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
             if (gmode) {
                 if ((nins_g + WAVE) * 4u > s.gcap * 3u) { status |= OVF_HASH; break; }
                 if (act) gbk = bucket_load(hslot);  // in flight during the visited insert
-                if ((s.flags & FAST_X_BUCKET) && act) {  // measurement: what does one more probe per id cost?
-                    const uint4 x = bucket_load(hash_u32(nid * 2654435761u + 17u) & gmask & ~3u);
-                    xdummy += x.x ^ x.w;
-                }
             } else if (!frozen && act) {
                 old = atomicCAS(&lhash[hslot], VS_EMPTY, nid);
             }
@@ -865,9 +863,6 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
                         pfa_val = ((uint32_t)lane < a.R) ? a.nbrs[(size_t)pfa_node * a.nbr_stride + lane] : VS_INVALID_NODE;
                     }
                 }
-                if (s.flags & FAST_X_ROWS)  // measurement: what does one more code row per candidate cost?
-                    xdummy += ham_row_reg<NCH>(a.codes + (size_t)(hash_u32(id + 1u) % a.n) * a.code_stride, qv, qc_l, l4,
-                                               a.code_stride, valid, stream_rows);
                 const uint32_t d = ham_row_reg<NCH>(crow, qv, qc_l, l4, a.code_stride, valid, stream_rows);
                 if (valid && l4 == 0) surv_d[j] = d;
             }
@@ -927,8 +922,8 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
             s.out_ham[(size_t)q * s.M + i] = 0xFFFFFFFFu;
         }
     }
-    if (xdummy == 0x12345677u && lane == 77) s.status[q] = 1;  // (keeps the measurement loads alive; never true)
     if (lane == 0) {
+        if (s.only_failed && s.fb_flag) s.fb_flag[q] = 1;
         s.status[q] = status;
         s.out_cnt[q] = status ? 0 : emitted;  // a failed scan publishes an empty stream until the fallback re-runs it
         if (status == 0) {
@@ -996,13 +991,6 @@ static int launch_fast_t(vs_index* idx, const FastArgs& a, size_t lds) {
 
 int launch_search_fast(vs_index* idx, const FastLaunch& s) {
     if (s.nq == 0) return VS_OK;
-    {  // the four-scans-per-wave kernel where it applies (vs_search_mx.hip)
-        const char* e = getenv("VS_MX");  // 1: where it applies; 2: insist (tests: a launch it does not cover is an error)
-        if (e && (*e == '1' || *e == '2')) {
-            if (search_mx_eligible(idx, s)) return launch_search_mx(idx, s);
-            VS_REQUIRE(*e != '2' || s.build, "VS_MX=2: this launch is outside the geometry k_search_mx covers");
-        }
-    }
     FastArgs a;
     a.codes = idx->codes;
     a.nbrs = idx->nbrs;

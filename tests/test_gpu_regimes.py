@@ -20,6 +20,10 @@ REGIMES = {
     "heap_spill": {"VS_F_HL": "63"},
     "heap_spill_tableless": {"VS_F_HL": "63", "VS_F_LDS_MAX_INS": "0"},
     "tiny_pool": {"VS_F_LH": "256", "VS_F_POOL": "0.01"},
+    # dedup table too small for most scans: they are finished by the second attempt of k_search_fast (four times the table) ...
+    "second_attempt": {"VS_F_LDS_MAX_INS": "0", "VS_F_GCAP": "1024"},
+    # ... or, with that attempt switched off, by the general kernel
+    "second_attempt_off": {"VS_F_LDS_MAX_INS": "0", "VS_F_GCAP": "1024", "VS_F_RETRY": "0"},
     "general_kernel": {"VS_FAST": "0"},
     "general_kernel_spill": {"VS_FAST": "0", "VS_HL": "64", "VS_G0": "256"},
 }
@@ -62,6 +66,8 @@ def test_every_regime_is_exact(regime_indexes, iname, regime):
             assert (gi == oi).all() and (gh == oh).all()
             for key in ("visited_nodes", "candidate_nodes", "quantized_distance_comparisons", "node_reads", "next_calls"):
                 assert gst[key] == ost[key], (key, gst[key], ost[key])
+            if regime.startswith("second_attempt") and iname == "l2_R50":
+                assert gst["fallback_scans"] > 0
             si, _, sd, _ = ix.search_batch(q, search_list_size=L, rescore=rescore, k=10, qlabels=qlabels)
             assert (si == osi).all()
             assert (sd.view(np.uint32) == osd.view(np.uint32)).all()

@@ -145,6 +145,15 @@ int vs_index_array(const vs_index* idx, int which, void** dev_ptr, uint32_t* row
 int vs_index_set_quantizer(vs_index* idx, const float* mean, const float* m2, uint64_t count);
 int vs_index_set_start_nodes(vs_index* idx, uint32_t default_start, const int16_t* labels, const uint32_t* nodes, uint32_t n);
 int vs_index_set_labels(vs_index* idx, const uint32_t* label_off, const int16_t* label_val);
+/* Heap visibility under the scan's snapshot, one byte per node (0 = index_fetch_tuple finds no tuple this snapshot can see).
+ * Replaces the `None` arm of get_full_distance_for_resort (AM/sbq/storage.rs:313-317, AM/plain/storage.rs:181-184, reached
+ * from next_with_resort, AM/scan.rs:258-272): with query_rescore > 0 such a candidate is fetched (counted as a heap read and a
+ * full-distance comparison) and dropped BEFORE it enters the rescore window; with query_rescore = 0 the access method does not
+ * look at the heap (the executor does) and the mask is ignored.  `visible` is a host array of n bytes, NULL = every tuple
+ * visible (the default).  The mask applies to every scan started afterwards (a PGRX shim sets it per snapshot / batch). */
+int vs_index_set_visibility(vs_index* idx, const uint8_t* visible);
+/* the same with the mask already in device memory (n bytes, kept by the caller until replaced; NULL clears it) */
+int vs_index_set_visibility_dev(vs_index* idx, const uint8_t* d_visible);
 int vs_index_get_quantizer(const vs_index* idx, float* mean, float* m2, uint64_t* count);
 /* copy index arrays back to host (tests / cpu_baseline leg); any pointer may be NULL */
 int vs_index_download(const vs_index* idx, uint64_t* codes, uint32_t* nbrs /*[n][num_neighbors]*/, uint64_t* heap_tids,

@@ -32,7 +32,7 @@ class VsoIndex(C.Structure):
         ("label_start_labels", C.c_void_p), ("label_start_nodes", C.c_void_p),
         ("codes", C.c_void_p), ("nbrs", C.c_void_p), ("heap_tids", C.c_void_p), ("vecs", C.c_void_p),
         ("label_off", C.c_void_p), ("label_val", C.c_void_p), ("mean", C.c_void_p), ("m2", C.c_void_p),
-        ("count", C.c_uint64), ("storage_plain", C.c_uint32),
+        ("count", C.c_uint64), ("storage_plain", C.c_uint32), ("visible", C.c_void_p),
     ]
 
 
@@ -231,7 +231,8 @@ class OracleIndex:
     """Flat-array diskann index as the oracle sees it. Keeps numpy arrays alive for the C struct."""
 
     def __init__(self, *, codes, nbrs, heap_tids, vecs, mean, m2, count, bits, dim_index, num_neighbors,
-                 distance_type, default_start, label_off=None, label_val=None, label_starts=None, storage_plain=False):
+                 distance_type, default_start, label_off=None, label_val=None, label_starts=None, storage_plain=False,
+                 visible=None):
         self.codes = np.ascontiguousarray(codes, np.uint64)
         self.nbrs = np.ascontiguousarray(nbrs, np.uint32)
         self.heap_tids = np.ascontiguousarray(heap_tids, np.uint64)
@@ -256,8 +257,17 @@ class OracleIndex:
         s.label_val = None if self.label_val is None else _p(self.label_val).value
         s.mean, s.m2, s.count = _p(self.mean).value, _p(self.m2).value, count
         s.storage_plain = int(storage_plain)
+        self.visible = None
+        s.visible = None
         self.c = s
+        self.set_visibility(visible)
         self.n, self.words, self.dim_full = n, w, self.vecs.shape[1]
+
+    def set_visibility(self, visible):
+        """per-node result of the heap fetch under the scan's snapshot (None: everything visible)"""
+        self.visible = None if visible is None else np.ascontiguousarray(visible, np.uint8)
+        assert self.visible is None or self.visible.shape == (self.c.n,)
+        self.c.visible = None if self.visible is None else _p(self.visible).value
 
     def _labels_csr(self, qlabels, nq):
         if qlabels is None:

@@ -658,8 +658,14 @@ struct vso_scan {
             LSN l;
             uint64_t tid;
             if (!next(&tid, &l)) break;
+            if (idx->visible && !idx->visible[l.id]) {
+                /* TableSlot::from_index_heap_pointer found no tuple this snapshot can see: the heap read is recorded
+                 * (UT/table_slot.rs:45), the candidate never enters the window (AM/scan.rs:268-272) */
+                st.node_heap_reads++;
+                st.full_distance_comparisons++; /* AM/scan.rs:258: counted before the fetch */
+                continue;
+            }
             float d = full_distance(l.id);
-            /* (the Option::None "tuple not visible" arm, AM/scan.rs:268-272, needs a heap snapshot: not modelled) */
             resort_buffer.push(Resort{tid, l.id, d});
         }
         if (resort_buffer.empty()) return false;

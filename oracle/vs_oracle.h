@@ -97,6 +97,8 @@ typedef struct {
     uint64_t count;
     uint32_t storage_plain;    /* 1: `plain` storage (AM/plain/storage.rs): candidates are scored with the full-precision
                                   distance to the node's stored vector instead of SBQ Hamming; no label filters     */
+    const uint8_t* visible;    /* [n] or NULL (= every tuple visible): what index_fetch_tuple(xs_snapshot) says about the node's
+                                  heap tuple; 0 => get_full_distance_for_resort returns None (AM/sbq/storage.rs:313-317)   */
 } vso_index;
 
 typedef struct {

@@ -95,6 +95,8 @@ SYMBOLS = {
     "vs_index_set_quantizer": (_i, [_vp, _vp, _vp, _u64]),
     "vs_index_set_start_nodes": (_i, [_vp, _u32, _vp, _vp, _u32]),
     "vs_index_set_labels": (_i, [_vp, _vp, _vp]),
+    "vs_index_set_visibility": (_i, [_vp, _vp]),
+    "vs_index_set_visibility_dev": (_i, [_vp, _vp]),
     "vs_index_get_quantizer": (_i, [_vp, _vp, _vp, C.POINTER(_u64)]),
     "vs_index_download": (_i, [_vp, _vp, _vp, _vp, _vp, _u32, _u32]),
     "vs_index_refresh_norms": (_i, [_vp]),

@@ -304,7 +304,7 @@ extern "C" void vs_index_free(vs_index* ix) {
     if (!ix) return;
     (void)hipSetDevice(ix->ctx->device);
     (void)hipStreamSynchronize(ix->ctx->stream);
-    void* ptrs[] = {ix->codes, ix->nbrs, ix->tids, ix->vecs, ix->vnorm, ix->vnorm_idx, ix->mean, ix->m2,
+    void* ptrs[] = {ix->codes, ix->nbrs, ix->tids, ix->vecs, ix->vnorm, ix->vnorm_idx, ix->mean, ix->m2, ix->visible_own,
                     ix->label_off, ix->label_val, ix->ls_labels, ix->ls_nodes};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -396,6 +396,24 @@ extern "C" int vs_index_set_labels(vs_index* ix, const uint32_t* label_off, cons
     VS_TRY(vs_dev_upload(ix->ctx, ix->label_off, label_off, ((size_t)n + 1) * 4));
     if (ix->n_label_vals) VS_TRY(vs_dev_upload(ix->ctx, ix->label_val, label_val, ix->n_label_vals * 2));
     ix->d.has_labels = 1;
+    return VS_OK;
+}
+
+extern "C" int vs_index_set_visibility_dev(vs_index* ix, const uint8_t* d_visible) {
+    VS_REQUIRE(ix, "vs_index_set_visibility_dev: index is NULL");
+    ix->visible = d_visible;
+    return VS_OK;
+}
+
+extern "C" int vs_index_set_visibility(vs_index* ix, const uint8_t* visible) {
+    VS_REQUIRE(ix, "vs_index_set_visibility: index is NULL");
+    if (!visible) {
+        ix->visible = nullptr;
+        return VS_OK;
+    }
+    if (!ix->visible_own) VS_HIP(hipMalloc(&ix->visible_own, std::max<size_t>(ix->d.n, 1)));
+    if (ix->d.n) VS_TRY(vs_dev_upload(ix->ctx, ix->visible_own, visible, ix->d.n));
+    ix->visible = ix->visible_own;
     return VS_OK;
 }
 
@@ -837,6 +855,7 @@ static int retry_failed_scans(vs_index* ix, const BatchPlan& bp, const int16_t* 
         s.fb_flag = w.fb_valid ? (uint32_t*)w.fb_flag.p : nullptr;
         s.pool_counter = (uint32_t*)((char*)w.pool_ctr.p + 32);
         s.pool_slots = gslots;
+        s.visible = (!bp.stream_only && bp.rescore > 0) ? ix->visible : nullptr;
         hipEvent_t ev = prof_begin(c);
         VS_TRY(launch_search(ix, s));
         prof_end(c, PK_SEARCH_FB, ev);
@@ -891,6 +910,7 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
         f.lh = caps.f_lh;
         f.minw = env_u32("VS_F_MINW", (caps.f_lh == 0 && caps.f_vr) ? 4 : 1);
         f.flags = env_u32("VS_F_FLAGS", 0);
+        f.visible = (!bp.stream_only && bp.rescore > 0) ? ix->visible : nullptr;  // the heap is only fetched for the rescore window
         f.sb = caps.f_sb;
         f.vcap = caps.f_vcap;
         f.qcodes = (const uint64_t*)w.qcodes.p;
@@ -985,6 +1005,7 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
         s.fb_flag = fast_done ? (uint32_t*)w.fb_flag.p : nullptr;
         s.pool_counter = fast_done ? (uint32_t*)((char*)w.pool_ctr.p + 32) : nullptr;
         s.pool_slots = gslots;
+        s.visible = (!bp.stream_only && bp.rescore > 0) ? ix->visible : nullptr;
         {
             hipEvent_t ev = prof_begin(c);
             VS_TRY(launch_search(ix, s));
@@ -1056,7 +1077,9 @@ static int collect_stats(vs_index* ix, uint32_t nq, uint32_t M, uint32_t rescore
             st->fallback_quantized_distance_comparisons += hs[(size_t)q * ST_N + ST_DQ];
         }
         if (!stream_only && rescore > 0) {
-            uint32_t nr = std::min(cnt[q], M);
+            // every row handed to the rescore window was fetched from the heap; so was every candidate the snapshot cannot
+            // see (counted by the kernel, AM/scan.rs:258 + UT/table_slot.rs:45)
+            const uint32_t nr = std::min(cnt[q], M) + (ix->visible ? hs[(size_t)q * ST_N + ST_INVIS] : 0u);
             st->full_distance_comparisons += nr;
             st->node_heap_reads += nr;
         }

@@ -99,6 +99,8 @@ struct vs_index {
     uint64_t* codes = nullptr;
     uint32_t* nbrs = nullptr;
     uint64_t* tids = nullptr;
+    const uint8_t* visible = nullptr;  // per node, 0 = the heap fetch finds nothing under the scan's snapshot (nullptr: all visible)
+    uint8_t* visible_own = nullptr;    // the library's own copy (vs_index_set_visibility)
     float* vecs = nullptr;
     float* vnorm = nullptr;  // per node: 0 => leave vector alone, else divisor sqrt(norm) (preprocess_cosine)
     float* vnorm_idx = nullptr;  // the same for the index slice (plain storage, cosine, num_dimensions_to_index < num_dimensions)
@@ -145,6 +147,7 @@ struct SearchLaunch {
     uint32_t* pool_counter = nullptr;  // non-null: heap_g / hash hold pool_slots regions claimed with an atomic counter
     uint32_t pool_slots = 0;
     uint32_t* fb_flag = nullptr;   // [nq] set to 1 for every scan this launch ran in only_failed mode
+    const uint8_t* visible = nullptr;  // non-null: rows whose node has visible[node] == 0 are counted and left out of the stream
 };
 // fast path (vs_search_fast.hip): all hot state in LDS
 struct FastLaunch {
@@ -165,6 +168,7 @@ struct FastLaunch {
     // fb_flag[q] is set for the statistics
     uint32_t only_failed = 0;
     uint32_t* fb_flag = nullptr;
+    const uint8_t* visible = nullptr;  // non-null: rows whose node has visible[node] == 0 are counted and left out of the stream
     const uint64_t* qcodes;
     const int16_t* qlabels;
     const uint32_t* qlabel_off;
@@ -183,7 +187,7 @@ struct FastLaunch {
 enum { FAST_PLAIN_ROW_LOADS = 1 };  // code rows through the normal cache policy instead of non-temporal loads
 size_t fast_lds_bytes(const vs_index* idx, const FastLaunch& s);
 int launch_search_fast(vs_index* idx, const FastLaunch& s);
-enum { ST_VISITS = 0, ST_CAND = 1, ST_DQ = 2, ST_READS = 3, ST_NEXT = 4, ST_GSPILL = 5, ST_PFHIT = 6, ST_N = 8 };
+enum { ST_VISITS = 0, ST_CAND = 1, ST_DQ = 2, ST_READS = 3, ST_NEXT = 4, ST_GSPILL = 5, ST_INVIS = 6, ST_N = 8 };
 enum { OVF_HEAP = 1, OVF_VISITED = 2, OVF_HASH = 4, OVF_POOL = 8 };
 size_t search_lds_bytes(const vs_index* idx, const SearchLaunch& s);
 

@@ -267,7 +267,7 @@ __global__ __launch_bounds__(WAVE) void k_search(SearchArgs a) {
 
     WaveHeap heap{heap_l, s.heap_g + (size_t)wslot * (s.hcap > s.hl ? s.hcap - s.hl : 0), s.hl, 0, 0};
     uint32_t vlen = 0, emitted = 0, status = 0;
-    uint32_t st_visits = 0, st_cand = 0, st_dq = 0, st_reads = 0, st_next = 0, st_pfhit = 0;
+    uint32_t st_visits = 0, st_cand = 0, st_dq = 0, st_reads = 0, st_next = 0, st_invis = 0;
 
     auto open_level = [&]() {  // uniform
         glev++;
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(WAVE) void k_search(SearchArgs a) {
                 uint32_t row0;
                 if (node == pf_node) {
                     row0 = pf_val;
-                    st_pfhit++;
+                    (void)0;
                 } else {
                     row0 = ((uint32_t)lane < a.R) ? nrow[lane] : VS_INVALID_NODE;
                 }
@@ -537,6 +537,11 @@ __global__ __launch_bounds__(WAVE) void k_search(SearchArgs a) {
             st_reads++;
             const uint64_t tid = a.tids[fnode];
             if ((tid & 0xFFFFull) == 0) continue;  // InvalidOffsetNumber: deleted tuple (AM/scan.rs:231-234)
+            if (s.visible && s.visible[fnode] == 0) {  // get_full_distance_for_resort -> None (AM/scan.rs:268-272)
+                st_invis++;
+                st_next++;  // the caller's loop asks `next` again
+                continue;
+            }
             if (lane == 0) {
                 s.out_ids[(size_t)q * s.M + emitted] = fnode;
                 s.out_ham[(size_t)q * s.M + emitted] = fd;
@@ -569,7 +574,7 @@ __global__ __launch_bounds__(WAVE) void k_search(SearchArgs a) {
         st[ST_READS] = st_reads;
         st[ST_NEXT] = st_next;
         st[ST_GSPILL] = heap.maxlen;
-        st[ST_PFHIT] = st_pfhit;
+        st[ST_INVIS] = st_invis;
         st[7] = nins_g;
     }
 }

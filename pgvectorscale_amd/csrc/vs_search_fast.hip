@@ -523,7 +523,7 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
     const uint32_t slot_limit = s.lh - s.lh / 8;  // stop at 87.5 % load: the scan is handed to the general kernel
     const uint32_t smask = (1u << s.sb) - 1u;
     uint32_t emitted = 0, status = 0, nins = 0, hmax = 0;
-    uint32_t st_visits = 0, st_cand = 0, st_dq = 0, st_reads = 0, st_pfhit = 0;
+    uint32_t st_visits = 0, st_cand = 0, st_dq = 0, st_reads = 0;
     // optional phase clock (s_memtime): 0 pop, 1 row wait, 2 visited, 3 dedup, 4 gather, 5 push, 6 other
     uint64_t ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t tmark = TIMING ? __builtin_readcyclecounter() : 0;
@@ -715,14 +715,16 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
 
     // ---- TSVResponseIterator::next until M rows are emitted (AM/scan.rs:210-242), flattened: every iteration is
     // either one visit_closest() expansion (greedy_search_iterate, AM/graph/mod.rs:357-385) or one consume() ----
-    uint32_t ft_node = VS_INVALID_NODE;  // heap tid of the visited list's front entry, requested ahead of consume()
+    uint32_t ft_node = VS_INVALID_NODE;  // heap tid (and visibility) of the visited list's front entry, requested ahead of consume()
     uint64_t ft_val = 0;
+    uint32_t ft_vis = 1, st_invis = 0;
     while (status == 0) {
         if (vis.len > 0) {
             const uint32_t fn = VR > 0 ? readlane_u32(vis.n[0], 0) : rfl((uint32_t)vis.ring[vis.head]);
             if (fn != ft_node) {
                 ft_node = fn;
                 ft_val = a.tids[fn];
+                if (s.visible) ft_vis = s.visible[fn];
             }
         }
         uint32_t top = 0;
@@ -741,6 +743,13 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
             st_reads++;
             const uint64_t tid = fnode == ft_node ? ft_val : a.tids[fnode];
             if ((tid & 0xFFFFull) == 0) continue;  // InvalidOffsetNumber: deleted tuple (AM/scan.rs:231-234)
+            if (s.visible) {  // get_full_distance_for_resort -> None: fetched, counted, never enters the window (AM/scan.rs:268-272)
+                const uint32_t v = fnode == ft_node ? ft_vis : (uint32_t)s.visible[fnode];
+                if (rfl(v) == 0) {
+                    st_invis++;
+                    continue;
+                }
+            }
             if (lane == 0) {
                 s.out_ids[(size_t)q * s.M + emitted] = fnode;
                 s.out_ham[(size_t)q * s.M + emitted] = fd;
@@ -760,10 +769,10 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
         uint32_t row0;
         if (node == pfa_node) {
             row0 = pfa_val;
-            st_pfhit++;
+            (void)0;
         } else if (node == pfb_node) {
             row0 = pfb_val;
-            st_pfhit++;
+            (void)0;
         } else {
             row0 = ((uint32_t)lane < a.R) ? nrow[lane] : VS_INVALID_NODE;
         }
@@ -915,7 +924,7 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
         }
     }
     // one `next` call per emitted row, plus the call that found the stream exhausted
-    const uint32_t st_next = emitted + ((emitted < s.M && status == 0) ? 1u : 0u);
+    const uint32_t st_next = emitted + st_invis + ((emitted < s.M && status == 0) ? 1u : 0u);
     if (status == 0) {
         for (uint32_t i = emitted + lane; i < s.M; i += WAVE) {
             s.out_ids[(size_t)q * s.M + i] = VS_INVALID_NODE;
@@ -934,7 +943,7 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
             st[ST_READS] = st_reads;
             st[ST_NEXT] = st_next;
             st[ST_GSPILL] = hmax;
-            st[ST_PFHIT] = st_pfhit;
+            st[ST_INVIS] = st_invis;
             st[7] = nins + nins_g;
         }
         if (TIMING && s.phase) {

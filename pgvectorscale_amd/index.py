@@ -202,6 +202,17 @@ class DiskAnnIndex:
         check(self._L.vs_index_set_labels(self.h, _p(lo), _p(lv)))
         self._refresh()
 
+    def set_visibility(self, visible):
+        """Heap visibility under the scans' snapshot: uint8 [n], 0 = the heap fetch of get_full_distance_for_resort finds no
+        visible tuple (the candidate is counted and dropped before the rescore window, AM/scan.rs:268-272); None = all visible."""
+        if visible is None:
+            check(self._L.vs_index_set_visibility(self.h, None))
+            return
+        v = np.ascontiguousarray(visible, np.uint8)
+        if v.shape != (self.desc.n,):
+            raise ValueError(f"visibility mask must have shape ({self.desc.n},), got {v.shape}")
+        check(self._L.vs_index_set_visibility(self.h, _p(v)))
+
     def download(self, codes=True, nbrs=True, tids=True, vecs=False, row_begin=0, row_count=None):
         n = self.desc.n if row_count is None else row_count
         out = {}

@@ -125,3 +125,30 @@ def test_matryoshka_truncation(oracle):
         for j in range(5):
             vn = O.preprocess_cosine(ti.vecs[nodes[i, j]])[0]
             assert dist[i, j].tobytes() == O.distance_cosine(vn, qn).tobytes()
+
+
+def test_invisible_heap_tuples_are_fetched_counted_and_dropped():
+    """The `None` arm of get_full_distance_for_resort (AM/scan.rs:268-272): a candidate whose heap tuple the snapshot cannot see
+    costs a heap read and a full-distance comparison and never enters the rescore window; with query_rescore = 0 the access
+    method does not look at the heap at all."""
+    from helpers import cached_index
+    ti = cached_index(n=1500, dim_full=128, bits=2, R=50, distance=1, seed=1, kind="uniform", L_build=64)
+    q = ti.queries(16, seed=9)
+    try:
+        a_ids, _, a_st = ti.oracle.search_batch(q, L=100, rescore=50, k=10)
+        vis = np.ones(ti.n, np.uint8)
+        vis[a_ids[:, 0]] = 0  # hide every query's best row
+        ti.oracle.set_visibility(vis)
+        b_ids, _, b_st = ti.oracle.search_batch(q, L=100, rescore=50, k=10)
+        assert vis[b_ids].all()
+        for i in range(len(q)):  # the rest of the answer moves up, order preserved
+            rest = [v for v in a_ids[i] if vis[v]]
+            assert list(b_ids[i][:len(rest)]) == rest
+        assert b_st["full_distance_comparisons"] > a_st["full_distance_comparisons"]
+        assert b_st["full_distance_comparisons"] == b_st["node_heap_reads"]
+        c_ids, _, _ = ti.oracle.search_batch(q, L=100, rescore=0, k=10)
+        ti.oracle.set_visibility(None)
+        d_ids, _, _ = ti.oracle.search_batch(q, L=100, rescore=0, k=10)
+        assert (c_ids == d_ids).all()
+    finally:
+        ti.oracle.set_visibility(None)

@@ -109,6 +109,9 @@ def lib():
                                    vp, vp, C.POINTER(VsoStats)]
     L.vso_build_graph.restype = None
     L.vso_build_graph.argtypes = [C.c_uint32, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, vp, u32p]
+    L.vso_build_graph_labeled.restype = C.c_uint32
+    L.vso_build_graph_labeled.argtypes = [C.c_uint32, C.c_uint32, vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, vp,
+                                          u32p, vp, vp]
     L.vso_bruteforce_topk.restype = None
     L.vso_bruteforce_topk.argtypes = [C.POINTER(VsoIndex), vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]
     L.vso_hamming_scan_topk.restype = None
@@ -359,6 +362,22 @@ def build_graph(codes, num_neighbors=50, nbr_stride=None, search_list_size=100, 
     start = C.c_uint32()
     lib().vso_build_graph(n, w, _p(codes), num_neighbors, stride, search_list_size, max_alpha, _p(nbrs), C.byref(start))
     return nbrs, int(start.value)
+
+
+def build_graph_labeled(codes, label_off, label_val, num_neighbors=50, nbr_stride=None, search_list_size=100, max_alpha=1.2):
+    """Graph::insert over a labeled vector set -> (nbrs, default start, {label: start node})"""
+    codes = np.ascontiguousarray(codes, np.uint64)
+    lo = np.ascontiguousarray(label_off, np.uint32)
+    lv = np.ascontiguousarray(label_val, np.int16)
+    n, w = codes.shape
+    stride = nbr_stride or num_neighbors
+    nbrs = np.empty((n, stride), np.uint32)
+    start = C.c_uint32()
+    nl = max(len(set(lv.tolist())), 1)
+    sl, sn = np.zeros(nl, np.int16), np.zeros(nl, np.uint32)
+    k = lib().vso_build_graph_labeled(n, w, _p(codes), _p(lo), _p(lv), num_neighbors, stride, search_list_size, max_alpha,
+                                      _p(nbrs), C.byref(start), _p(sl), _p(sn))
+    return nbrs, int(start.value), {int(sl[i]): int(sn[i]) for i in range(k)}
 
 
 def hamming_scan_topk(codes, qcodes, k):

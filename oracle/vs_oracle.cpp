@@ -14,6 +14,7 @@
 #include <chrono>
 #include <cstring>
 #include <limits>
+#include <map>
 #include <thread>
 #include <vector>
 
@@ -901,6 +902,12 @@ struct Builder {
     double max_alpha;
     const uint64_t* codes;
     uint32_t* nbrs;
+    /* labeled vector sets (nullptr: none): CSR label sets; per-label start nodes are assigned as nodes arrive */
+    const uint32_t* loff = nullptr;
+    const int16_t* lval = nullptr;
+    std::map<int16_t, uint32_t> label_start;
+    const int16_t* lab(uint32_t i) const { return lval + loff[i]; }
+    size_t nlab(uint32_t i) const { return loff[i + 1] - loff[i]; }
     const uint64_t* code(uint32_t i) const { return codes + (size_t)i * w; }
     uint32_t ham(uint32_t a, uint32_t b) const { return (uint32_t)vso_distance_xor(code(a), code(b), w); }
     uint32_t degree(uint32_t i) const {
@@ -914,7 +921,7 @@ struct Builder {
         for (uint32_t s = 0; s < stride; ++s) r[s] = s < l.size() ? l[s].id : VSO_INVALID_NODE;
     }
     /* prune_neighbors with alpha ladder 1.0, 1.2, ... <= max_alpha; distance factor as get_factor (ratio, 0-safe) */
-    std::vector<Cand> prune(std::vector<Cand> cands) {
+    std::vector<Cand> prune(std::vector<Cand> cands, uint32_t of) {
         std::sort(cands.begin(), cands.end(), cand_lt);
         std::vector<Cand> results;
         std::vector<double> max_factors(cands.size(), 0.0);
@@ -927,6 +934,11 @@ struct Builder {
                 results.push_back(cands[i]);
                 for (size_t j = i + 1; j < cands.size(); ++j) {
                     if (max_factors[j] > max_alpha) continue;
+                    /* "Does it contain essential labels?"  A candidate is only occluded by an existing neighbor that carries
+                     * every label the candidate shares with the point (AM/graph/mod.rs:442-456) */
+                    if (loff && !vso_labels_contains_intersection(lab(cands[i].id), nlab(cands[i].id), lab(cands[j].id),
+                                                                  nlab(cands[j].id), lab(of), nlab(of)))
+                        continue;
                     uint32_t dce = ham(cands[j].id, cands[i].id);
                     double factor;
                     if (dce == 0) factor = cands[j].d == 0 ? 1.0 : std::numeric_limits<double>::max();
@@ -939,13 +951,17 @@ struct Builder {
         return results;
     }
     /* greedy_search_for_build: all visited nodes, stop rule identical to visit_closest */
-    std::vector<Cand> search(uint32_t q, uint32_t start) {
+    /* filter: visit_lsn_internal's label test with the new node's own labels as the query (insert_internal with
+     * no_filter = false, AM/graph/mod.rs:664-672) */
+    std::vector<Cand> search(uint32_t q, const std::vector<uint32_t>& starts, bool filter) {
         RustBinaryHeap<LSN, ReverseLsnLe> cand;
         std::vector<LSN> visited;
         U32Set inserted(L * R);
         std::vector<Cand> out;
-        inserted.insert(start);
-        cand.push(LSN{start, (float)ham(q, start)});
+        for (uint32_t start : starts) {
+            if (!inserted.insert(start)) continue;
+            cand.push(LSN{start, (float)ham(q, start)});
+        }
         while (!cand.empty()) {
             if (visited.size() > L && lsn_cmp(cand.peek(), visited[L - 1]) >= 0) break;
             LSN head = cand.pop();
@@ -959,7 +975,8 @@ struct Builder {
             out.push_back(Cand{head.id, (uint32_t)head.dist});
             const uint32_t* r = nbrs + (size_t)head.id * stride;
             for (uint32_t s = 0; s < R && r[s] != VSO_INVALID_NODE; ++s) {
-                if (!inserted.insert(r[s])) continue;
+                if (!inserted.insert(r[s])) continue; /* marked before the label test (AM/sbq/storage.rs:148-172) */
+                if (filter && !vso_labels_overlap(lab(q), nlab(q), lab(r[s]), nlab(r[s]))) continue;
                 cand.push(LSN{r[s], (float)ham(q, r[s])});
             }
         }
@@ -980,16 +997,29 @@ struct Builder {
                 }
             if (!dup) cands.push_back(c);
         }
-        std::vector<Cand> nl = cands.size() > R ? prune(cands) : cands;
+        std::vector<Cand> nl = cands.size() > R ? prune(cands, of) : cands;
         set_neighbors(of, nl);
         return nl;
     }
+    /* insert_internal (AM/graph/mod.rs:664-717) */
+    void insert_internal(uint32_t p, const std::vector<uint32_t>& starts, bool filter) {
+        std::vector<Cand> v = search(p, starts, filter);
+        std::vector<Cand> nl = add_neighbors(p, v);
+        for (const Cand& q : nl) add_neighbors(q.id, std::vector<Cand>{Cand{p, q.d}});
+    }
     void run() {
         for (size_t i = 0; i < (size_t)n * stride; ++i) nbrs[i] = VSO_INVALID_NODE;
-        for (uint32_t p = 1; p < n; ++p) {
-            std::vector<Cand> v = search(p, 0);
-            std::vector<Cand> nl = add_neighbors(p, v);
-            for (const Cand& q : nl) add_neighbors(q.id, std::vector<Cand>{Cand{p, q.d}});
+        for (uint32_t p = 0; p < n; ++p) {
+            /* update_start_nodes (AM/graph/mod.rs:490-531): node 0 is the default start node; a node is the start node of
+             * every label it is the first to carry */
+            if (loff)
+                for (size_t t = 0; t < nlab(p); ++t) label_start.emplace(lab(p)[t], p);
+            if (loff) { /* from the label start nodes, with the label filter (Graph::insert, AM/graph/mod.rs:649-652) */
+                std::vector<uint32_t> starts;
+                for (size_t t = 0; t < nlab(p); ++t) starts.push_back(label_start[lab(p)[t]]);
+                insert_internal(p, starts, true);
+            }
+            if (p > 0) insert_internal(p, std::vector<uint32_t>{0u}, false); /* from the default start node, no filter */
         }
     }
 };
@@ -999,9 +1029,31 @@ extern "C" {
 
 void vso_build_graph(uint32_t n, uint32_t words, const uint64_t* codes, uint32_t num_neighbors, uint32_t nbr_stride,
                      uint32_t search_list_size, double max_alpha, uint32_t* nbrs, uint32_t* default_start) {
-    Builder b{n, words, num_neighbors, nbr_stride, search_list_size, max_alpha, codes, nbrs};
+    Builder b{n, words, num_neighbors, nbr_stride, search_list_size, max_alpha, codes, nbrs, nullptr, nullptr, {}};
     b.run();
     if (default_start) *default_start = n ? 0 : VSO_INVALID_NODE; /* first inserted node, AM/graph/mod.rs:490-540 */
+}
+
+/* Graph::insert over a labeled vector set (AM/graph/mod.rs:637-662): every node is inserted twice — from the start nodes of
+ * its labels with the label filter, then from the default start node without it — and pruning keeps a candidate that shares a
+ * label with the point which the occluding neighbor lacks.  start_labels / start_nodes (room for every distinct label, in
+ * ascending label order) receive the per-label start nodes; returns their number. */
+uint32_t vso_build_graph_labeled(uint32_t n, uint32_t words, const uint64_t* codes, const uint32_t* label_off,
+                                 const int16_t* label_val, uint32_t num_neighbors, uint32_t nbr_stride,
+                                 uint32_t search_list_size, double max_alpha, uint32_t* nbrs, uint32_t* default_start,
+                                 int16_t* start_labels, uint32_t* start_nodes) {
+    Builder b{n, words, num_neighbors, nbr_stride, search_list_size, max_alpha, codes, nbrs, nullptr, nullptr, {}};
+    b.loff = label_off;
+    b.lval = label_val;
+    b.run();
+    if (default_start) *default_start = n ? 0 : VSO_INVALID_NODE;
+    uint32_t k = 0;
+    for (const auto& kv : b.label_start) {
+        start_labels[k] = kv.first;
+        start_nodes[k] = kv.second;
+        ++k;
+    }
+    return k;
 }
 
 void vso_bruteforce_topk(const vso_index* idx, const float* queries, uint32_t nq, uint32_t k, uint32_t n_threads,

@@ -140,6 +140,12 @@ void vso_stream_batch(const vso_index* idx, const float* queries, const int16_t*
 void vso_build_graph(uint32_t n, uint32_t words, const uint64_t* codes, uint32_t num_neighbors, uint32_t nbr_stride,
                      uint32_t search_list_size, double max_alpha, uint32_t* nbrs /* out [n][nbr_stride] */,
                      uint32_t* default_start /* out */);
+/* the same over a labeled vector set: Graph::insert's two passes + label-aware pruning (AM/graph/mod.rs:392-488,637-662,
+ * AM/labels/mod.rs:85-111); returns the number of per-label start nodes written (ascending label order) */
+uint32_t vso_build_graph_labeled(uint32_t n, uint32_t words, const uint64_t* codes, const uint32_t* label_off,
+                                 const int16_t* label_val, uint32_t num_neighbors, uint32_t nbr_stride,
+                                 uint32_t search_list_size, double max_alpha, uint32_t* nbrs, uint32_t* default_start,
+                                 int16_t* start_labels, uint32_t* start_nodes);
 /* exact f32 brute-force top-k by the reference distance function (ground truth for recall) */
 void vso_bruteforce_topk(const vso_index* idx, const float* queries, uint32_t nq, uint32_t k, uint32_t n_threads,
                          uint32_t* out_nodes, float* out_dist);

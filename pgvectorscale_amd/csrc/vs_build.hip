@@ -11,7 +11,15 @@
 // out-edges are pruned, then back-edges are grouped per target (radix sort) and each target's list is re-pruned once.
 // The result is deterministic for a given (codes, parameters); it is not claimed to be edge-identical to the
 // reference's sequential build (which is itself HashSet-order dependent, AM/graph/mod.rs:317-326).
+// Labeled vector sets (vs_index_set_labels before the build): as in Graph::insert (AM/graph/mod.rs:637-662) every node is
+// inserted twice — from the start nodes of its labels with the label filter on, then from the default start node without
+// it, the second pass merging into the list the first one left — a node is the start node of every label it is the first
+// to carry (update_start_nodes, AM/graph/mod.rs:490-531), and prune_neighbors only lets an existing neighbor occlude a
+// candidate when it carries every label the candidate shares with the point (contains_intersection,
+// AM/labels/mod.rs:85-111, used at AM/graph/mod.rs:442-456).
 #include <cstdlib>
+#include <map>
+#include <vector>
 
 #include <hipcub/hipcub.hpp>
 
@@ -65,12 +73,37 @@ __device__ __forceinline__ void stage_codes(uint64_t* ccode, const uint64_t* __r
     }
 }
 
+// contains_intersection(existing, candidate, point) for label sets relative to ONE point: bit t of a node's mask says that
+// the point's t-th label is in the node's set, so  (candidate ∩ point) ⊆ existing  <=>  (mask[candidate] & ~mask[existing]) == 0.
+// (a point carries at most 64 labels: vs_build_graph checks)
+__device__ __forceinline__ uint64_t label_pmask(const uint32_t* __restrict__ label_off, const int16_t* __restrict__ label_val,
+                                                uint32_t of, uint32_t node) {
+    const uint32_t ob = label_off[of], oe = label_off[of + 1];
+    uint32_t j = label_off[node];
+    const uint32_t je = label_off[node + 1];
+    uint64_t m = 0;
+    for (uint32_t t = ob; t < oe && j < je;) {
+        const int16_t x = label_val[t], y = label_val[j];
+        if (x == y) {
+            m |= 1ull << (t - ob);
+            ++t;
+            ++j;
+        } else if (x < y) {
+            ++t;
+        } else {
+            ++j;
+        }
+    }
+    return m;
+}
+
 // prune_neighbors for one node by one wave.  cand_id/cand_d: C candidates sorted ascending by (distance, id)
 // (LDS).  ccode: optional LDS copy of the candidate codes [C][stride] (nullptr => read codes from global).
 // Writes up to R selected candidate *positions* into sel[] (LDS) and returns their number.
 __device__ uint32_t wave_prune(const uint32_t* cand_id, const uint32_t* cand_d, uint32_t C, const uint64_t* ccode,
                                const uint64_t* __restrict__ codes, uint32_t stride, uint32_t R, float max_alpha,
-                               float* maxf /*LDS [C]*/, uint32_t* sel /*LDS [R]*/, int lane) {
+                               float* maxf /*LDS [C]*/, uint32_t* sel /*LDS [R]*/, int lane,
+                               const uint64_t* pm = nullptr /*LDS [C] label masks (label_pmask) or nullptr*/) {
     const float FMAX = 3.0e38f;
     if (ccode && stride == 24 && C <= WAVE) {
         // register form of the same loop (768 x 2 bit / 1536 x 1 bit codes, at most one candidate per lane): lane j keeps
@@ -82,6 +115,7 @@ __device__ uint32_t wave_prune(const uint32_t* cand_id, const uint32_t* cand_d, 
         for (int t = 0; t < 12; ++t)
             mine[t] = mine_ok ? *reinterpret_cast<const ulonglong2*>(ccode + (size_t)lane * 24 + 2 * t) : make_ulonglong2(0, 0);
         const uint32_t myd = mine_ok ? cand_d[lane] : 0u;
+        const uint64_t mypm = (pm && mine_ok) ? pm[lane] : 0ull;
         float mymax = 0.0f;
         uint32_t nres = 0;
         float alpha = 1.0f;
@@ -92,7 +126,9 @@ __device__ uint32_t wave_prune(const uint32_t* cand_id, const uint32_t* cand_d, 
                 if ((uint32_t)lane == i) mymax = FMAX;
                 if (lane == 0) sel[nres] = i;
                 nres++;
-                if ((uint32_t)lane > i && mine_ok && !(mymax > max_alpha)) {
+                // "Does it contain essential labels?" (AM/graph/mod.rs:442-456)
+                const bool essential = pm ? (mypm & ~pm[i]) != 0 : false;
+                if ((uint32_t)lane > i && mine_ok && !(mymax > max_alpha) && !essential) {
                     const uint64_t* ci = ccode + (size_t)i * 24;
                     uint32_t dij = 0;
 #pragma unroll
@@ -129,6 +165,7 @@ __device__ uint32_t wave_prune(const uint32_t* cand_id, const uint32_t* cand_d, 
             for (uint32_t j = i + 1 + lane; j < C; j += WAVE) {
                 float mj = maxf[j];
                 if (mj > max_alpha) continue;
+                if (pm && (pm[j] & ~pm[i]) != 0) continue;  // "Does it contain essential labels?" (AM/graph/mod.rs:442-456)
                 const uint64_t* cj = ccode ? ccode + (size_t)j * stride : codes + (size_t)cand_id[j] * stride;
                 uint32_t dij = ham_words(cj, ci, stride);
                 float factor;
@@ -227,6 +264,90 @@ __device__ void wave_bitonic_sort(uint64_t* keys, uint32_t npow2, int lane) {
     }
 }
 
+// ---- out-edges of the new nodes of one batch, labeled vector sets -------------------------------------------------
+// Same job as k_build_prune_new with what Graph::insert does for a labeled vector (AM/graph/mod.rs:637-662, 212-266): the
+// node itself is dropped from its candidates (it is the start node of a label it is the first to carry), the second pass
+// (merge_existing) adds the neighbors the filtered pass left in the row, and pruning uses the label rule.  Candidates are
+// re-sorted by (distance, id) after the merge.  cap = power of two >= vmax + R.
+__global__ __launch_bounds__(WAVE) void k_build_prune_merge(const uint64_t* __restrict__ codes, uint32_t stride,
+                                                            uint32_t* __restrict__ nbrs, uint32_t nbr_stride, uint32_t R,
+                                                            float max_alpha, uint32_t b0, uint32_t bn,
+                                                            const uint32_t* __restrict__ vis_ids,
+                                                            const uint32_t* __restrict__ vis_d,
+                                                            const uint32_t* __restrict__ vis_cnt, uint32_t vmax, uint32_t cap,
+                                                            uint32_t use_lds_codes, uint32_t merge_existing,
+                                                            const uint32_t* __restrict__ label_off,
+                                                            const int16_t* __restrict__ label_val,
+                                                            uint32_t* __restrict__ edge_q, uint64_t* __restrict__ edge_pd) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x;
+    const uint32_t b = blockIdx.x;
+    if (b >= bn) return;
+    const uint32_t p = b0 + b;
+    uint64_t* keys = reinterpret_cast<uint64_t*>(smem);  // [cap]
+    uint64_t* pm = keys + cap;                            // [cap]
+    uint32_t* cid = reinterpret_cast<uint32_t*>(pm + cap);
+    uint32_t* cd = cid + cap;
+    float* maxf = reinterpret_cast<float*>(cd + cap);
+    uint32_t* sel = reinterpret_cast<uint32_t*>(maxf + cap);
+    uint64_t* ccode = reinterpret_cast<uint64_t*>(sel + round_up_u32(R, 4));
+    const uint32_t C0 = min(vis_cnt[b], vmax);
+    for (uint32_t t = lane; t < cap; t += WAVE) {
+        uint64_t key = ~0ull;
+        if (t < C0) {
+            const uint32_t id = vis_ids[(size_t)b * vmax + t];
+            if (id != p) key = ((uint64_t)vis_d[(size_t)b * vmax + t] << 32) | id;  // "remove myself"
+        }
+        keys[t] = key;
+    }
+    __syncthreads();
+    uint32_t* row = nbrs + (size_t)p * nbr_stride;
+    if (merge_existing) {  // add_neighbors: the list so far + the new candidates, each id once
+        const uint64_t* cp = codes + (size_t)p * stride;
+        for (uint32_t t = lane; t < R; t += WAVE) {
+            const uint32_t id = row[t];
+            if (id == VS_INVALID_NODE || id == p) continue;
+            bool dup = false;
+            for (uint32_t u = 0; u < C0 && !dup; ++u) dup = (uint32_t)keys[u] == id && keys[u] != ~0ull;
+            if (!dup) keys[C0 + t] = ((uint64_t)ham_words(codes + (size_t)id * stride, cp, stride) << 32) | id;
+        }
+        __syncthreads();
+    }
+    wave_bitonic_sort(keys, cap, lane);
+    uint32_t T = 0;
+    for (uint32_t t0 = 0; t0 < cap; t0 += WAVE) T += (uint32_t)__popcll(__ballot(keys[t0 + lane] != ~0ull));
+    for (uint32_t t = lane; t < T; t += WAVE) {
+        cid[t] = (uint32_t)keys[t];
+        cd[t] = (uint32_t)(keys[t] >> 32);
+        pm[t] = label_off ? label_pmask(label_off, label_val, p, (uint32_t)keys[t]) : 0ull;
+    }
+    __syncthreads();
+    if (use_lds_codes) {
+        stage_codes(ccode, codes, cid, T, stride, lane);
+        __syncthreads();
+    }
+    uint32_t nres;
+    if (T <= R) {  // Graph::add_neighbors prunes only a candidate list longer than num_neighbors (AM/graph/mod.rs:243-256)
+        for (uint32_t t = lane; t < T; t += WAVE) sel[t] = t;
+        nres = T;
+        __syncthreads();
+    } else {
+        nres = wave_prune(cid, cd, T, use_lds_codes ? ccode : nullptr, codes, stride, R, max_alpha, maxf, sel, lane,
+                          label_off ? pm : nullptr);
+    }
+    for (uint32_t t = lane; t < nbr_stride; t += WAVE) row[t] = t < nres ? cid[sel[t]] : VS_INVALID_NODE;
+    for (uint32_t t = lane; t < R; t += WAVE) {  // back-edge requests (q <- p, d)
+        const size_t e = (size_t)b * R + t;
+        if (t < nres) {
+            edge_q[e] = cid[sel[t]];
+            edge_pd[e] = ((uint64_t)cd[sel[t]] << 32) | p;
+        } else {
+            edge_q[e] = VS_INVALID_NODE;
+            edge_pd[e] = 0;
+        }
+    }
+}
+
 // ---- back-edges: one wave per target node q ---------------------------------------------------------------------
 __global__ __launch_bounds__(WAVE) void k_build_backedges(const uint64_t* __restrict__ codes, uint32_t stride,
                                                           uint32_t* __restrict__ nbrs, uint32_t nbr_stride, uint32_t R,
@@ -234,12 +355,14 @@ __global__ __launch_bounds__(WAVE) void k_build_backedges(const uint64_t* __rest
                                                           const uint64_t* __restrict__ pd_sorted, uint32_t ne,
                                                           const uint32_t* __restrict__ seg_start,
                                                           const uint32_t* __restrict__ nseg_p, uint32_t cmax,
-                                                          uint32_t use_lds_codes) {
+                                                          uint32_t use_lds_codes, const uint32_t* __restrict__ label_off,
+                                                          const int16_t* __restrict__ label_val) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
     const uint32_t nseg = *nseg_p;
     uint64_t* keys = reinterpret_cast<uint64_t*>(smem);  // [cmax] (pow2)
-    uint32_t* cid = reinterpret_cast<uint32_t*>(keys + cmax);
+    uint64_t* pm = keys + cmax;                           // [cmax] label masks relative to the target (labeled sets only)
+    uint32_t* cid = reinterpret_cast<uint32_t*>(pm + cmax);
     uint32_t* cd = cid + cmax;
     float* maxf = reinterpret_cast<float*>(cd + cmax);
     uint32_t* sel = reinterpret_cast<uint32_t*>(maxf + cmax);
@@ -290,13 +413,15 @@ __global__ __launch_bounds__(WAVE) void k_build_backedges(const uint64_t* __rest
         for (uint32_t t = lane; t < T; t += WAVE) {
             cid[t] = (uint32_t)keys[t];
             cd[t] = (uint32_t)(keys[t] >> 32);
+            if (label_off) pm[t] = label_pmask(label_off, label_val, q, (uint32_t)keys[t]);  // add_neighbors(q, from_labels = q's)
         }
         __syncthreads();
         if (use_lds_codes) {
             stage_codes(ccode, codes, cid, T, stride, lane);
             __syncthreads();
         }
-        uint32_t nres = wave_prune(cid, cd, T, use_lds_codes ? ccode : nullptr, codes, stride, R, max_alpha, maxf, sel, lane);
+        uint32_t nres = wave_prune(cid, cd, T, use_lds_codes ? ccode : nullptr, codes, stride, R, max_alpha, maxf, sel, lane,
+                                   label_off ? pm : nullptr);
         for (uint32_t t = lane; t < nbr_stride; t += WAVE) row[t] = t < nres ? cid[sel[t]] : VS_INVALID_NODE;
         __syncthreads();
     }
@@ -359,6 +484,27 @@ static int build_graph_impl(vs_index* ix, uint32_t L, double max_alpha_d, uint32
         return VS_OK;
     }
     ix->d.default_start = 0;
+    const bool labeled = ix->label_off != nullptr;
+    if (labeled) {
+        // update_start_nodes (AM/graph/mod.rs:490-531): a node is the start node of every label it is the first to carry;
+        // nodes arrive in id order, so that is the smallest id per label
+        std::vector<uint32_t> off((size_t)n + 1);
+        VS_HIP(hipMemcpy(off.data(), ix->label_off, off.size() * 4, hipMemcpyDeviceToHost));
+        std::vector<int16_t> val(std::max<size_t>(off[n], 1));
+        if (off[n]) VS_HIP(hipMemcpy(val.data(), ix->label_val, (size_t)off[n] * 2, hipMemcpyDeviceToHost));
+        std::map<int16_t, uint32_t> first;
+        for (uint32_t i = 0; i < n; ++i) {
+            VS_REQUIRE(off[i + 1] - off[i] <= 64, "vs_build_graph: node %u carries more than 64 labels", i);
+            for (uint32_t j = off[i]; j < off[i + 1]; ++j) first.emplace(val[j], i);
+        }
+        std::vector<int16_t> sl;
+        std::vector<uint32_t> sn;
+        for (const auto& kv : first) {
+            sl.push_back(kv.first);
+            sn.push_back(kv.second);
+        }
+        VS_TRY(vs_index_set_start_nodes(ix, 0, sl.data(), sn.data(), (uint32_t)sl.size()));
+    }
     if (batch_max == 0) batch_max = std::min<uint32_t>(65536, std::max<uint32_t>(1024, n / 64));
     // capacities of the build-mode search
     uint32_t vmax = std::max<uint32_t>(round_up_u32(3 * L + 64, 64), 128);      // visited list cap (candidates of prune)
@@ -369,12 +515,17 @@ static int build_graph_impl(vs_index* ix, uint32_t L, double max_alpha_d, uint32
     while (cmax < R + 128) cmax <<= 1;  // back-edge candidate cap (pow2, >= R + new sources kept)
     const size_t code_bytes = (size_t)stride * 8;
     const uint32_t use_lds_new = (vmax * code_bytes + vmax * 12 + R * 4 + 64 <= 150 * 1024) ? 1 : 0;
-    const uint32_t use_lds_back = (cmax * code_bytes + cmax * 20 + R * 4 + 64 <= 150 * 1024) ? 1 : 0;
+    const uint32_t use_lds_back = (cmax * code_bytes + cmax * 28 + R * 4 + 64 <= 150 * 1024) ? 1 : 0;
     const size_t lds_new = (size_t)vmax * 12 + round_up_u32(R, 4) * 4 + (use_lds_new ? vmax * code_bytes : 0) + 64;
-    const size_t lds_back = (size_t)cmax * 20 + round_up_u32(R, 4) * 4 + (use_lds_back ? cmax * code_bytes : 0) + 64;
+    const size_t lds_back = (size_t)cmax * 28 + round_up_u32(R, 4) * 4 + (use_lds_back ? cmax * code_bytes : 0) + 64;
+    const uint32_t mcap = next_pow2_u32((uint64_t)vmax + R);  // candidates of k_build_prune_merge
+    const uint32_t use_lds_merge = (mcap * code_bytes + mcap * 28 + R * 4 + 64 <= 150 * 1024) ? 1 : 0;
+    const size_t lds_merge = (size_t)mcap * 28 + round_up_u32(R, 4) * 4 + (use_lds_merge ? mcap * code_bytes : 0) + 64;
     VS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_build_prune_new),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     VS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_build_backedges),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    VS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_build_prune_merge),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 
     const size_t bm = batch_max;
@@ -425,8 +576,13 @@ static int build_graph_impl(vs_index* ix, uint32_t L, double max_alpha_d, uint32
     }
 
     // one batch: searches for the new nodes b0 .. b0 + bn - 1, their out-edges, the back-edges
-    auto insert_batch = [&](uint32_t b0, uint32_t bn) -> int {
+    // filtered: the pass from the label start nodes with the label filter (labeled sets only); otherwise from the default
+    // start node.  A labeled set's unfiltered pass merges into the rows the filtered pass wrote.
+    auto insert_batch = [&](uint32_t b0, uint32_t bn, bool filtered) -> int {
         const uint64_t* qcodes = ix->codes + (size_t)b0 * stride;
+        // label keys of the searches = the new nodes' own label sets (CSR offsets are absolute into label_val)
+        const int16_t* ql = filtered ? ix->label_val : nullptr;
+        const uint32_t* qlo = filtered ? ix->label_off + b0 : nullptr;
         for (int attempt = 0;; ++attempt) {
             if ((size_t)bn * hashcap * 4 > hash_alloc || !B.hash) {
                 if (B.hash) VS_HIP(hipFree(B.hash));
@@ -452,8 +608,8 @@ static int build_graph_impl(vs_index* ix, uint32_t L, double max_alpha_d, uint32
             s.hashcap = hashcap;
             s.g0 = std::min<uint32_t>(4096, hashcap);  // first level of the dedup ladder (small L * R: the whole table)
             s.qcodes = qcodes;
-            s.qlabels = nullptr;
-            s.qlabel_off = nullptr;
+            s.qlabels = ql;
+            s.qlabel_off = qlo;
             s.heap_g = B.heap_g;
             s.hash = B.hash;
             s.out_ids = B.vis_ids;
@@ -465,8 +621,8 @@ static int build_graph_impl(vs_index* ix, uint32_t L, double max_alpha_d, uint32
                 f.nq = bn;
                 f.hcap = std::max(std::min(hcap, f.hl + f.gstride - 2), f.hl);  // (the spill area was sized before the loop)
                 f.qcodes = s.qcodes;
-                f.qlabels = nullptr;
-                f.qlabel_off = nullptr;
+                f.qlabels = ql;
+                f.qlabel_off = qlo;
                 f.heap_g = B.f_heap;
                 f.ghash = B.f_ghash;
                 f.pool_counter = B.f_pool;
@@ -502,9 +658,14 @@ static int build_graph_impl(vs_index* ix, uint32_t L, double max_alpha_d, uint32
             if (ovf & OVF_HASH) hashcap *= 2;
         }
         // out-edges of the new nodes + back-edge requests
-        hipLaunchKernelGGL(k_build_prune_new, dim3(bn), dim3(WAVE), lds_new, st, ix->codes, stride, ix->nbrs,
-                           ix->nbr_stride, R, max_alpha, b0, bn, B.vis_ids, B.vis_d, B.vis_cnt, vmax, use_lds_new,
-                           B.edge_q, B.edge_pd);
+        if (labeled)
+            hipLaunchKernelGGL(k_build_prune_merge, dim3(bn), dim3(WAVE), lds_merge, st, ix->codes, stride, ix->nbrs,
+                               ix->nbr_stride, R, max_alpha, b0, bn, B.vis_ids, B.vis_d, B.vis_cnt, vmax, mcap, use_lds_merge,
+                               filtered ? 0u : 1u, ix->label_off, ix->label_val, B.edge_q, B.edge_pd);
+        else
+            hipLaunchKernelGGL(k_build_prune_new, dim3(bn), dim3(WAVE), lds_new, st, ix->codes, stride, ix->nbrs,
+                               ix->nbr_stride, R, max_alpha, b0, bn, B.vis_ids, B.vis_d, B.vis_cnt, vmax, use_lds_new,
+                               B.edge_q, B.edge_pd);
         VS_HIP(hipGetLastError());
         const uint32_t ne = bn * R;
         size_t tmp_bytes = B.cub_bytes;
@@ -516,7 +677,7 @@ static int build_graph_impl(vs_index* ix, uint32_t L, double max_alpha_d, uint32
         uint32_t grid = std::min<uint32_t>(ne, 16384);
         hipLaunchKernelGGL(k_build_backedges, dim3(grid), dim3(WAVE), lds_back, st, ix->codes, stride, ix->nbrs,
                            ix->nbr_stride, R, max_alpha, B.edge_q_sorted, B.edge_pd_sorted, ne, B.seg_start, B.nseg, cmax,
-                           use_lds_back);
+                           use_lds_back, labeled ? ix->label_off : nullptr, labeled ? ix->label_val : nullptr);
         VS_HIP(hipGetLastError());
         return VS_OK;
     };
@@ -525,7 +686,8 @@ static int build_graph_impl(vs_index* ix, uint32_t L, double max_alpha_d, uint32
     uint32_t bsz = 1;
     while (b0 < n) {
         const uint32_t bn = std::min<uint32_t>(std::min<uint32_t>(bsz, batch_max), n - b0);
-        VS_TRY(insert_batch(b0, bn));
+        if (labeled) VS_TRY(insert_batch(b0, bn, true));  // Graph::insert: first with the label filter ...
+        VS_TRY(insert_batch(b0, bn, false));              // ... then from the default start node without it
         b0 += bn;
         if (bsz < batch_max) bsz = std::min<uint32_t>(batch_max, bsz * 2);
     }

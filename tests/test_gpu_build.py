@@ -172,3 +172,91 @@ def test_build_with_a_small_search_list(gpu_ctx, oracle, n, R, L):
     oi, od, _ = oidx.search_batch(q, L=20, rescore=10, k=5)
     assert (gi == oi).all()
     ix.close()
+
+
+def _label_sets(n, n_labels, seed):
+    rng = np.random.default_rng(seed)
+    off = np.zeros(n + 1, np.uint32)
+    vals = []
+    for i in range(n):
+        vals += sorted(set(int(v) for v in rng.integers(1, n_labels + 1, int(rng.integers(1, 4)))))
+        off[i + 1] = len(vals)
+    return off, np.array(vals, np.int16)
+
+
+def _reach_with_label(nbrs, carries, start):
+    """nodes a scan filtered on one label can get to: the walk only pushes neighbors that carry the label"""
+    seen = np.zeros(nbrs.shape[0], bool)
+    seen[start] = True
+    stack = [int(start)]
+    while stack:
+        v = stack.pop()
+        for u in nbrs[v]:
+            if u != 0xFFFFFFFF and carries[u] and not seen[u]:
+                seen[u] = True
+                stack.append(int(u))
+    return int(seen.sum())
+
+
+def test_label_aware_build(gpu_ctx, oracle):
+    """Graph::insert over a labeled vector set on the device (AM/graph/mod.rs:637-662: a filtered pass from the label start
+    nodes, an unfiltered one from the default start node, label-aware pruning, AM/graph/mod.rs:442-456): on the shape of the
+    reference's test_labeled_recall (1000 x 128, 32 labels, AM/labels/filtering_tests.rs:880-1025) the filtered recall must
+    reach the reference's 0.9 bar, every label's carriers must be reachable under that label's filter about as well as in the
+    sequential builder's graph, and the scans on the device-built graph must equal the oracle's."""
+    O = oracle
+    import pgvectorscale_amd as P
+    from helpers import make_vectors
+    n, dim, R, NL = 1000, 128, 50, 32
+    X = make_vectors(n, dim, 1, "uniform")
+    off, vals = _label_sets(n, NL, 3)
+    first = {}
+    for i in range(n):
+        for l in vals[off[i]:off[i + 1]]:
+            first.setdefault(int(l), i)
+    ix = P.DiskAnnIndex.alloc(gpu_ctx, n=n, dim_full=dim, num_neighbors=R, distance_type=P.VS_L2)
+    vp, _ = ix.array(P._lib.ARR_VECS)
+    gpu_ctx.upload(vp, X)
+    ix.refresh_norms()
+    ix.sbq_train()
+    ix.sbq_quantize_corpus()
+    ix.set_labels(off, vals)
+    ix.build_graph(search_list_size=100, max_alpha=1.2)
+    host = ix.download(vecs=True)
+    nb = host["nbrs"]
+    ix.build_graph(search_list_size=100, max_alpha=1.2)
+    assert (ix.download()["nbrs"] == nb).all()  # deterministic
+    assert not (nb == np.arange(n, dtype=np.uint32)[:, None]).any()  # no self loops
+    for r in nb[::97]:
+        live = r[r != 0xFFFFFFFF]
+        assert len(set(live.tolist())) == len(live) and (r[: len(live)] != 0xFFFFFFFF).all()
+    # the sequential label-aware builder on the same codes
+    onb, ostart, ols = O.build_graph_labeled(host["codes"], off, vals, num_neighbors=R, search_list_size=100)
+    assert ostart == 0 and ols == first
+    for l in range(1, NL + 1):
+        carries = np.array([l in vals[off[i]:off[i + 1]] for i in range(n)])
+        got = _reach_with_label(nb, carries, first[l])
+        want = _reach_with_label(onb, carries, first[l])
+        assert got >= 0.98 * want and got >= 0.95 * carries.sum(), (l, got, want, int(carries.sum()))
+    assert _reach(nb, 0) == n
+    mean, m2, cnt = ix.get_quantizer()
+    oidx = O.OracleIndex(codes=host["codes"], nbrs=nb, heap_tids=host["heap_tids"], vecs=host["vecs"], mean=mean, m2=m2,
+                         count=cnt, bits=ix.desc.bits, dim_index=dim, num_neighbors=R, distance_type=O.L2, default_start=0,
+                         label_off=off, label_val=vals, label_starts=first)
+    q = make_vectors(100, dim, 7, "uniform")
+    rng = np.random.default_rng(8)
+    keys = [[int(rng.integers(1, NL + 1))] for _ in range(len(q))]
+    gi, _, gd, _ = ix.search_batch(q, search_list_size=100, rescore=50, k=10, qlabels=keys)  # start nodes as the build set them
+    oi, od, _ = oidx.search_batch(q, L=100, rescore=50, k=10, qlabels=keys)
+    assert (gi == oi).all() and (gd.view(np.uint32) == od.view(np.uint32)).all()
+    hit = tot = 0
+    for i in range(len(q)):
+        carries = np.array([keys[i][0] in vals[off[j]:off[j + 1]] for j in range(n)])
+        dd = ((X - q[i]) ** 2).sum(1)
+        dd[~carries] = np.inf
+        want = set(np.argsort(dd)[:min(10, int(carries.sum()))].tolist())
+        hit += len(want & set(gi[i].tolist()))
+        tot += len(want)
+    print("filtered recall@10 on the device-built labeled graph:", hit / tot)
+    assert hit / tot >= 0.9
+    ix.close()

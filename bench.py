@@ -56,7 +56,7 @@ def graph_cache_path(args, n, dim, seed, bits, R):
     """Where the built neighbor array of this exact configuration is kept between runs (None = no cache)."""
     if args.graph_cache in (None, "", "none"):
         return None
-    key = f"{n}x{dim}.{args.distance}.b{bits}.R{R}.L{args.build_l}.s{seed}" + ("" if args.corpus == "lowrank" else f".{args.corpus}")
+    key = f"{n}x{dim}.{args.distance}.b{bits}.R{R}.L{args.build_l}.s{seed}" + ("" if args.corpus == "lowrank" else f".{args.corpus}") + (f".lab{args.labels}" if args.labels else "")
     if args.graph_cache != "auto":
         return f"{args.graph_cache}.{key}"
     if n < 10_000_000:
@@ -282,6 +282,15 @@ def main():
     t0 = time.time()
     ix.sbq_quantize_corpus()
     setup["quantize_s"] = round(time.time() - t0, 3)
+    NL = args.labels
+    lab_off = lab_val = lab_starts = None
+    if NL:
+        assert 1 <= NL <= 62
+        t0 = time.time()
+        lab_off, lab_val = zipf_labels(np, n, NL, seed + 100, 1, 3)
+        lab_starts = label_start_nodes(np, lab_off, lab_val)
+        ix.set_labels(lab_off, lab_val)  # before the build: a labeled vector set is built label-aware (Graph::insert)
+        setup["labels_s"] = round(time.time() - t0, 3)
     t0 = time.time()
     cache = graph_cache_path(args, n, dim, seed, bits, R)
     loaded = False
@@ -309,16 +318,8 @@ def main():
                     os.remove(tmp)
                 except OSError:
                     pass
-    NL = args.labels
-    lab_off = lab_val = lab_starts = None
-    if NL:
-        assert 1 <= NL <= 62
-        t0 = time.time()
-        lab_off, lab_val = zipf_labels(np, n, NL, seed + 100, 1, 3)
-        lab_starts = label_start_nodes(np, lab_off, lab_val)
-        ix.set_labels(lab_off, lab_val)
-        ix.set_start_nodes(ix.desc.default_start, lab_starts)
-        setup["labels_s"] = round(time.time() - t0, 3)
+    if NL:  # (a graph loaded from the cache carries no start nodes; after a build this repeats what the build set)
+        ix.set_start_nodes(0, lab_starts)
     log("setup", setup)
 
     def query_keys(first_row, rows):
@@ -570,7 +571,7 @@ def main():
                               "sigma_inter (SURVEY.md 8(d))"),
                    "workload": f"{n}x{dim} synthetic clustered unit-norm f32, diskann index (SBQ {bits} bit, R={R}), "
                                f"{args.distance}, top-{k}" + (f", label-filtered scans ({NL} labels, Zipf, 1-3 per vector, keys of one / "
-                                                             f"two labels; graph built without label awareness)" if NL else ""),
+                                                             f"two labels; label-aware build: filtered + unfiltered insert pass, per-label start nodes)" if NL else ""),
                    "labels": NL, "n": n, "dim": dim, "bits": bits, "words": W,
                    "num_neighbors": R, "queries_per_step_per_gpu": nq, "search_list_size": L, "rescore": S, "k": k,
                    "parallelism": f"query-sharded x{world}, index replicated" if world > 1 else "single GPU"},

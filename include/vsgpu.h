@@ -335,8 +335,15 @@ int vs_sbq_train(vs_index* idx);
 /* codes[i] = quantize(normalised index slice of vecs[i]) for all nodes */
 int vs_sbq_quantize_corpus(vs_index* idx);
 /* Batched Vamana build over the SBQ codes (greedy search + robust prune with alpha ladder, Hamming distances),
- * the GPU counterpart of Graph::insert / prune_neighbors (AM/graph/mod.rs:392-488,637-717). */
+ * the GPU counterpart of Graph::insert / prune_neighbors (AM/graph/mod.rs:392-488,637-717).  With label sets attached
+ * (vs_index_set_labels before the call) the build is label-aware as Graph::insert is: a filtered pass from the label start
+ * nodes, an unfiltered pass from the default start node, contains_intersection in the pruning rule, and a node becomes the
+ * start node of every label it is the first to carry (at most 64 labels per node). */
 int vs_build_graph(vs_index* idx, uint32_t search_list_size, double max_alpha, uint32_t batch_max, uint64_t seed);
+/* nodes the last vs_build_graph could not make reachable from the default start node (its repair pass gives every such
+ * node an in-edge where that strands nobody else; 0 on well-formed input, 0xFFFFFFFF = graph deeper than the pass can judge).
+ * The reference's build gives no reachability guarantee either (AM/graph/mod.rs:700-715 only warns about orphans). */
+uint32_t vs_index_build_unreachable(const vs_index* idx);
 
 /* ---- synthetic corpora generated in HBM (bench / tests; bit-reproducible on the CPU, see pgvectorscale_amd/datagen.py) */
 typedef struct vs_datagen_params {

@@ -142,6 +142,7 @@ SYMBOLS = {
     "vs_sbq_train": (_i, [_vp]),
     "vs_sbq_quantize_corpus": (_i, [_vp]),
     "vs_build_graph": (_i, [_vp, _u32, C.c_double, _u32, _u64]),
+    "vs_index_build_unreachable": (_u32, [_vp]),
     "vs_datagen_fill": (_i, [_vp, C.POINTER(DatagenParams), _u64, _u64, _vp]),
     "vs_bruteforce_topk": (_i, [_vp, _vp, _u32, _u32, _vp, _vp]),
 }

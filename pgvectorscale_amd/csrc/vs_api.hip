@@ -399,6 +399,8 @@ extern "C" int vs_index_set_labels(vs_index* ix, const uint32_t* label_off, cons
     return VS_OK;
 }
 
+extern "C" uint32_t vs_index_build_unreachable(const vs_index* ix) { return ix ? ix->build_unreachable : 0xFFFFFFFFu; }
+
 extern "C" int vs_index_set_visibility_dev(vs_index* ix, const uint8_t* d_visible) {
     VS_REQUIRE(ix, "vs_index_set_visibility_dev: index is NULL");
     ix->visible = d_visible;
@@ -1298,7 +1300,8 @@ struct vs_scan {
 
 extern "C" int vs_beginscan(vs_index* ix, vs_scan** out) {
     VS_REQUIRE(ix && out, "vs_beginscan: bad args");
-    vs_scan* s = new vs_scan();
+    vs_scan* s = new (std::nothrow) vs_scan();
+    VS_REQUIRE_OOM(s, "vs_beginscan: out of host memory");
     s->ix = ix;
     *out = s;
     return VS_OK;
@@ -1306,7 +1309,8 @@ extern "C" int vs_beginscan(vs_index* ix, vs_scan** out) {
 
 extern "C" int vs_beginscan_on_broker(vs_broker* b, vs_scan** out) {
     VS_REQUIRE(b && out, "vs_beginscan_on_broker: bad args");
-    vs_scan* s = new vs_scan();
+    vs_scan* s = new (std::nothrow) vs_scan();
+    VS_REQUIRE_OOM(s, "vs_beginscan_on_broker: out of host memory");
     s->ix = vs_broker_index(b);
     s->broker = b;
     *out = s;

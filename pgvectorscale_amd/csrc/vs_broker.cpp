@@ -67,30 +67,26 @@ struct vs_broker {
 
     void run();
     void run_group(std::vector<Request*>& grp);
+    void run_group_launch(std::vector<Request*>& grp, std::vector<float>& q, std::vector<int16_t>& lab, std::vector<uint32_t>& off,
+                          std::vector<uint32_t>& ids, std::vector<uint64_t>& tids, std::vector<float>& dist, int& rc, std::string& err);
 };
 
 void vs_broker::run_group(std::vector<Request*>& grp) {
     const uint32_t nq = (uint32_t)grp.size();
     const Request& head = *grp[0];
     const uint32_t k = head.k;
-    std::vector<float> q((size_t)nq * d.dim_full, 0.0f);  // a NULL query is the zero vector (AM/labels/mod.rs:214-216)
+    int rc = VS_OK;
+    std::string err;
+    std::vector<float> q, dist;
     std::vector<int16_t> lab;
-    std::vector<uint32_t> off(nq + 1, 0);
-    for (uint32_t i = 0; i < nq; ++i) {
-        if (grp[i]->query) memcpy(&q[(size_t)i * d.dim_full], grp[i]->query, (size_t)d.dim_full * 4);
-        // (label keys are ignored for a NULL query, as amrescan does)
-        if (head.has_label_key && grp[i]->query) lab.insert(lab.end(), grp[i]->labels.begin(), grp[i]->labels.end());
-        off[i + 1] = (uint32_t)lab.size();
+    std::vector<uint32_t> off, ids;
+    std::vector<uint64_t> tids;
+    try {  // (this is the dispatcher thread: an exception here would terminate the process with every client still blocked)
+        run_group_launch(grp, q, lab, off, ids, tids, dist, rc, err);
+    } catch (const std::bad_alloc&) {
+        rc = VS_ERR_OOM;
+        err = "vs_broker: out of host memory while assembling a batch";
     }
-    std::vector<uint32_t> ids((size_t)nq * k);
-    std::vector<uint64_t> tids((size_t)nq * k);
-    std::vector<float> dist((size_t)nq * k);
-    // scans with a label key and NULL-query scans (no key) cannot share a launch: the caller keeps them in separate groups
-    const bool keys = head.has_label_key;
-    vs_stats stats{};
-    const int rc = vs_search_batch(ix, q.data(), keys ? lab.data() : nullptr, keys ? off.data() : nullptr, nq, head.L, head.rescore, k,
-                                   ids.data(), tids.data(), dist.data(), &stats);
-    const std::string err = rc == VS_OK ? std::string() : std::string(vs_last_error());
     std::lock_guard<std::mutex> lk(mu);
     st.batches++;
     st.scans += nq;
@@ -107,6 +103,31 @@ void vs_broker::run_group(std::vector<Request*>& grp) {
         r->done = true;
         r->cv.notify_one();
     }
+}
+
+void vs_broker::run_group_launch(std::vector<Request*>& grp, std::vector<float>& q, std::vector<int16_t>& lab,
+                                 std::vector<uint32_t>& off, std::vector<uint32_t>& ids, std::vector<uint64_t>& tids,
+                                 std::vector<float>& dist, int& rc, std::string& err) {
+    const uint32_t nq = (uint32_t)grp.size();
+    const Request& head = *grp[0];
+    const uint32_t k = head.k;
+    q.assign((size_t)nq * d.dim_full, 0.0f);  // a NULL query is the zero vector (AM/labels/mod.rs:214-216)
+    off.assign(nq + 1, 0);
+    for (uint32_t i = 0; i < nq; ++i) {
+        if (grp[i]->query) memcpy(&q[(size_t)i * d.dim_full], grp[i]->query, (size_t)d.dim_full * 4);
+        // (label keys are ignored for a NULL query, as amrescan does)
+        if (head.has_label_key && grp[i]->query) lab.insert(lab.end(), grp[i]->labels.begin(), grp[i]->labels.end());
+        off[i + 1] = (uint32_t)lab.size();
+    }
+    ids.assign((size_t)nq * k, 0);
+    tids.assign((size_t)nq * k, 0);
+    dist.assign((size_t)nq * k, 0.0f);
+    // scans with a label key and NULL-query scans (no key) cannot share a launch: the caller keeps them in separate groups
+    const bool keys = head.has_label_key;
+    vs_stats stats{};
+    rc = vs_search_batch(ix, q.data(), keys ? lab.data() : nullptr, keys ? off.data() : nullptr, nq, head.L, head.rescore, k,
+                         ids.data(), tids.data(), dist.data(), &stats);
+    if (rc != VS_OK) err = vs_last_error();
 }
 
 void vs_broker::run() {

@@ -189,7 +189,7 @@ __global__ __launch_bounds__(WAVE) void k_build_prune_new(const uint64_t* __rest
                                                           const uint32_t* __restrict__ vis_ids,
                                                           const uint32_t* __restrict__ vis_d,
                                                           const uint32_t* __restrict__ vis_cnt, uint32_t vmax,
-                                                          uint32_t use_lds_codes, uint32_t* __restrict__ edge_q,
+                                                          uint32_t use_lds_codes, uint64_t* __restrict__ edge_q,
                                                           uint64_t* __restrict__ edge_pd) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
@@ -225,23 +225,23 @@ __global__ __launch_bounds__(WAVE) void k_build_prune_new(const uint64_t* __rest
     for (uint32_t t = lane; t < R; t += WAVE) {
         size_t e = (size_t)b * R + t;
         if (t < nres) {
-            edge_q[e] = cid[sel[t]];
+            edge_q[e] = ((uint64_t)cid[sel[t]] << 32) | cd[sel[t]];  // sort key: target, then distance (closest requests first)
             edge_pd[e] = ((uint64_t)cd[sel[t]] << 32) | p;
         } else {
-            edge_q[e] = VS_INVALID_NODE;
+            edge_q[e] = ~0ull;
             edge_pd[e] = 0;
         }
     }
 }
 
 // segment heads of the sorted back-edge list
-__global__ void k_seg_heads(const uint32_t* __restrict__ q_sorted, uint32_t ne, uint32_t* __restrict__ seg_start,
+__global__ void k_seg_heads(const uint64_t* __restrict__ q_sorted, uint32_t ne, uint32_t* __restrict__ seg_start,
                             uint32_t* __restrict__ nseg) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= ne) return;
-    uint32_t q = q_sorted[i];
+    uint32_t q = (uint32_t)(q_sorted[i] >> 32);
     if (q == VS_INVALID_NODE) return;
-    if (i == 0 || q_sorted[i - 1] != q) seg_start[atomicAdd(nseg, 1u)] = i;
+    if (i == 0 || (uint32_t)(q_sorted[i - 1] >> 32) != q) seg_start[atomicAdd(nseg, 1u)] = i;
 }
 
 // in-LDS bitonic sort of u64 keys (n padded to pow2 with ~0)
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(WAVE) void k_build_prune_merge(const uint64_t* __re
                                                             uint32_t use_lds_codes, uint32_t merge_existing,
                                                             const uint32_t* __restrict__ label_off,
                                                             const int16_t* __restrict__ label_val,
-                                                            uint32_t* __restrict__ edge_q, uint64_t* __restrict__ edge_pd) {
+                                                            uint64_t* __restrict__ edge_q, uint64_t* __restrict__ edge_pd) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
     const uint32_t b = blockIdx.x;
@@ -339,10 +339,10 @@ __global__ __launch_bounds__(WAVE) void k_build_prune_merge(const uint64_t* __re
     for (uint32_t t = lane; t < R; t += WAVE) {  // back-edge requests (q <- p, d)
         const size_t e = (size_t)b * R + t;
         if (t < nres) {
-            edge_q[e] = cid[sel[t]];
+            edge_q[e] = ((uint64_t)cid[sel[t]] << 32) | cd[sel[t]];  // sort key: target, then distance (closest requests first)
             edge_pd[e] = ((uint64_t)cd[sel[t]] << 32) | p;
         } else {
-            edge_q[e] = VS_INVALID_NODE;
+            edge_q[e] = ~0ull;
             edge_pd[e] = 0;
         }
     }
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(WAVE) void k_build_prune_merge(const uint64_t* __re
 // ---- back-edges: one wave per target node q ---------------------------------------------------------------------
 __global__ __launch_bounds__(WAVE) void k_build_backedges(const uint64_t* __restrict__ codes, uint32_t stride,
                                                           uint32_t* __restrict__ nbrs, uint32_t nbr_stride, uint32_t R,
-                                                          float max_alpha, const uint32_t* __restrict__ q_sorted,
+                                                          float max_alpha, const uint64_t* __restrict__ q_sorted,
                                                           const uint64_t* __restrict__ pd_sorted, uint32_t ne,
                                                           const uint32_t* __restrict__ seg_start,
                                                           const uint32_t* __restrict__ nseg_p, uint32_t cmax,
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(WAVE) void k_build_backedges(const uint64_t* __rest
     uint64_t* ccode = reinterpret_cast<uint64_t*>(sel + round_up_u32(R, 4));
     for (uint32_t sidx = blockIdx.x; sidx < nseg; sidx += gridDim.x) {
         const uint32_t e0 = seg_start[sidx];
-        const uint32_t q = q_sorted[e0];
+        const uint32_t q = (uint32_t)(q_sorted[e0] >> 32);
         uint32_t* row = nbrs + (size_t)q * nbr_stride;
         // existing degree
         uint32_t deg = 0;
@@ -386,12 +386,28 @@ __global__ __launch_bounds__(WAVE) void k_build_backedges(const uint64_t* __rest
         deg = min(deg, R);
         // segment length
         uint32_t m = 0;
-        while (e0 + m < ne && q_sorted[e0 + m] == q) ++m;  // uniform scalar loop (short)
+        while (e0 + m < ne && (uint32_t)(q_sorted[e0 + m] >> 32) == q) ++m;  // uniform scalar loop (short)
+        // add_neighbors takes every id once (AM/graph/mod.rs:227-235): a source that already is in the list — the second
+        // pass of a labeled set asks again for the back-edges its first pass created — is dropped
+        auto in_row = [&](uint32_t pid) -> bool {
+            for (uint32_t u = 0; u < deg; ++u)
+                if (row[u] == pid) return true;
+            return false;
+        };
         if (deg + m <= R) {  // room: append in (sorted) order
-            for (uint32_t t = lane; t < m; t += WAVE) row[deg + t] = (uint32_t)pd_sorted[e0 + t];
+            uint32_t w = deg;
+            for (uint32_t base = 0; base < m; base += WAVE) {
+                const uint32_t t = base + lane;
+                const uint32_t pid = t < m ? (uint32_t)pd_sorted[e0 + t] : VS_INVALID_NODE;
+                const bool ok = t < m && !in_row(pid);
+                const uint64_t okm = __ballot(ok);
+                if (ok) row[w + (uint32_t)__popcll(okm & ((1ull << lane) - 1ull))] = pid;
+                w += (uint32_t)__popcll(okm);
+            }
             continue;
         }
-        // candidates = existing neighbors (distance computed) + new sources; keep the closest cmax
+        // candidates = existing neighbors (distance computed) + new sources.  A hub can receive more requests in one batch than
+        // the candidate array holds: the requests of a target are sorted by distance, so the ones kept are its closest
         const uint32_t take_new = min(m, cmax - deg);
         const uint32_t T = deg + take_new;
         uint32_t np2 = 1;
@@ -404,24 +420,33 @@ __global__ __launch_bounds__(WAVE) void k_build_backedges(const uint64_t* __rest
                 key = ((uint64_t)ham_words(codes + (size_t)id * stride, cq, stride) << 32) | id;
             } else if (t < T) {
                 uint64_t pd = pd_sorted[e0 + (t - deg)];
-                key = pd;  // (dist << 32) | p
+                if (!in_row((uint32_t)pd)) key = pd;  // (dist << 32) | p
             }
             keys[t] = key;
         }
         __syncthreads();
         wave_bitonic_sort(keys, np2, lane);
-        for (uint32_t t = lane; t < T; t += WAVE) {
+        uint32_t Tv = 0;  // candidates left once the repeated sources are gone (they sorted to the end)
+        for (uint32_t t0 = 0; t0 < np2; t0 += WAVE) Tv += (uint32_t)__popcll(__ballot(t0 + lane < np2 && keys[t0 + lane] != ~0ull));
+        for (uint32_t t = lane; t < Tv; t += WAVE) {
             cid[t] = (uint32_t)keys[t];
             cd[t] = (uint32_t)(keys[t] >> 32);
             if (label_off) pm[t] = label_pmask(label_off, label_val, q, (uint32_t)keys[t]);  // add_neighbors(q, from_labels = q's)
         }
         __syncthreads();
         if (use_lds_codes) {
-            stage_codes(ccode, codes, cid, T, stride, lane);
+            stage_codes(ccode, codes, cid, Tv, stride, lane);
             __syncthreads();
         }
-        uint32_t nres = wave_prune(cid, cd, T, use_lds_codes ? ccode : nullptr, codes, stride, R, max_alpha, maxf, sel, lane,
-                                   label_off ? pm : nullptr);
+        uint32_t nres;
+        if (Tv <= R) {  // (only repeated sources made the list look too long)
+            for (uint32_t t = lane; t < Tv; t += WAVE) sel[t] = t;
+            nres = Tv;
+            __syncthreads();
+        } else {
+            nres = wave_prune(cid, cd, Tv, use_lds_codes ? ccode : nullptr, codes, stride, R, max_alpha, maxf, sel, lane,
+                              label_off ? pm : nullptr);
+        }
         for (uint32_t t = lane; t < nbr_stride; t += WAVE) row[t] = t < nres ? cid[sel[t]] : VS_INVALID_NODE;
         __syncthreads();
     }
@@ -445,21 +470,24 @@ __global__ void k_reach_sweep(const uint32_t* __restrict__ nbrs, uint32_t nbr_st
     }
 }
 
-// in-edges that come from reachable nodes
+// in-edges that come from reachable nodes of a strictly LOWER BFS level than their target: such a source is reached on a
+// path that does not pass through the target, so a target that keeps one of these edges stays reachable whatever else it loses
 __global__ void k_count_reached_sources(const uint32_t* __restrict__ nbrs, uint32_t nbr_stride, uint32_t R, uint32_t n,
                                         const uint8_t* __restrict__ reached, uint32_t* __restrict__ indeg) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)n * R) return;
-    if (!reached[i / R]) return;
+    const uint8_t ls = reached[i / R];
+    if (!ls) return;
     const uint32_t v = nbrs[(i / R) * nbr_stride + (i % R)];
-    if (v != VS_INVALID_NODE) atomicAdd(&indeg[v], 1u);
+    if (v != VS_INVALID_NODE && reached[v] > ls) atomicAdd(&indeg[v], 1u);
 }
 
 struct BuildBufs {
     uint32_t *vis_ids = nullptr, *vis_d = nullptr, *vis_cnt = nullptr, *stats = nullptr, *status = nullptr;
     uint32_t* hash = nullptr;
     uint64_t* heap_g = nullptr;
-    uint32_t *edge_q = nullptr, *edge_q_sorted = nullptr, *seg_start = nullptr, *nseg = nullptr;
+    uint32_t *seg_start = nullptr, *nseg = nullptr;
+    uint64_t *edge_q = nullptr, *edge_q_sorted = nullptr;  // (target << 32) | distance
     uint64_t *edge_pd = nullptr, *edge_pd_sorted = nullptr;
     void* cub_tmp = nullptr;
     size_t cub_bytes = 0;
@@ -534,14 +562,14 @@ static int build_graph_impl(vs_index* ix, uint32_t L, double max_alpha_d, uint32
     VS_HIP(hipMalloc(&B.vis_cnt, bm * 4));
     VS_HIP(hipMalloc(&B.stats, bm * ST_N * 4));
     VS_HIP(hipMalloc(&B.status, bm * 4));
-    VS_HIP(hipMalloc(&B.edge_q, bm * R * 4));
-    VS_HIP(hipMalloc(&B.edge_q_sorted, bm * R * 4));
+    VS_HIP(hipMalloc(&B.edge_q, bm * R * 8));
+    VS_HIP(hipMalloc(&B.edge_q_sorted, bm * R * 8));
     VS_HIP(hipMalloc(&B.edge_pd, bm * R * 8));
     VS_HIP(hipMalloc(&B.edge_pd_sorted, bm * R * 8));
     VS_HIP(hipMalloc(&B.seg_start, bm * R * 4));
     VS_HIP(hipMalloc(&B.nseg, 4));
     VS_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, B.cub_bytes, B.edge_q, B.edge_q_sorted, B.edge_pd,
-                                              B.edge_pd_sorted, (int)(bm * R), 0, 32, st));
+                                              B.edge_pd_sorted, (int)(bm * R), 0, 64, st));
     VS_HIP(hipMalloc(&B.cub_tmp, B.cub_bytes + 16));
     size_t hash_alloc = 0, ids_alloc = 0;
 
@@ -649,8 +677,8 @@ static int build_graph_impl(vs_index* ix, uint32_t L, double max_alpha_d, uint32
                 return VS_ERR_CAPACITY;
             }
             if (ovf & OVF_VISITED) {
-                // the visited list outgrew the prune candidate cap: keep the closest vmax (list is sorted) — retry
-                // with a larger in-LDS list only
+                // the visited list outgrew the prune candidate cap (the build-mode fast kernel truncates to the closest
+                // entries itself; this is the general kernel's ring at vcap = vmax + 64): not a combination the LDS holds
                 vs_set_error("vs_build_graph: visited list overflow (search_list_size too large for LDS)");
                 return VS_ERR_CAPACITY;
             }
@@ -670,7 +698,7 @@ static int build_graph_impl(vs_index* ix, uint32_t L, double max_alpha_d, uint32
         const uint32_t ne = bn * R;
         size_t tmp_bytes = B.cub_bytes;
         VS_HIP(hipcub::DeviceRadixSort::SortPairs(B.cub_tmp, tmp_bytes, B.edge_q, B.edge_q_sorted, B.edge_pd,
-                                                  B.edge_pd_sorted, (int)ne, 0, 32, st));
+                                                  B.edge_pd_sorted, (int)ne, 0, 64, st));
         VS_HIP(hipMemsetAsync(B.nseg, 0, 4, st));
         hipLaunchKernelGGL(k_seg_heads, dim3((ne + 255) / 256), dim3(256), 0, st, B.edge_q_sorted, ne, B.seg_start, B.nseg);
         VS_HIP(hipGetLastError());
@@ -693,7 +721,8 @@ static int build_graph_impl(vs_index* ix, uint32_t L, double max_alpha_d, uint32
     }
     VS_HIP(hipStreamSynchronize(st));
 
-    // repair pass (see k_reach_sweep): at most three rounds of { reachable set, in-edges for the nodes outside it }
+    // repair pass (see k_reach_sweep): rounds of { reachable set, in-edges for the nodes outside it } until a sweep finds every
+    // node (at most eight); what the last sweep still could not reach is reported by vs_index_build_unreachable()
     const char* rep_env = getenv("VS_BUILD_REPAIR");
     if (n > 2 && !(rep_env && *rep_env == '0')) {
         VS_HIP(hipMalloc(&B.mark, (size_t)n + 8));  // n flags, then (4-byte aligned) the `changed` word
@@ -703,7 +732,8 @@ static int build_graph_impl(vs_index* ix, uint32_t L, double max_alpha_d, uint32
         const size_t cells = (size_t)n * R;
         const dim3 cgrid((unsigned)((cells + 255) / 256));
         const uint32_t start = ix->d.default_start;
-        for (int round = 0; round < 3; ++round) {
+        ix->build_unreachable = 0;
+        for (int round = 0; round < 8; ++round) {
             VS_HIP(hipMemsetAsync(B.mark, 0, (size_t)n + 8, st));
             const uint8_t one = 1;
             VS_HIP(hipMemcpyAsync(B.mark + start, &one, 1, hipMemcpyHostToDevice, st));
@@ -717,16 +747,22 @@ static int build_graph_impl(vs_index* ix, uint32_t L, double max_alpha_d, uint32
                 VS_HIP(hipStreamSynchronize(st));
                 converged = changed == 0;
             }
-            if (!converged) break;  // more than 254 levels deep: not a graph this pass can judge
+            if (!converged) {  // more than 254 levels deep: not a graph this pass can judge
+                ix->build_unreachable = 0xFFFFFFFFu;
+                break;
+            }
             VS_HIP(hipMemcpyAsync(reached.data(), B.mark, n, hipMemcpyDeviceToHost, st));
             VS_HIP(hipStreamSynchronize(st));
             lost.clear();
             for (uint32_t i = 0; i < n; ++i)
                 if (!reached[i]) lost.push_back(i);
-            if (lost.empty()) break;
+            ix->build_unreachable = (uint32_t)lost.size();  // (what the last completed sweep found; 0 when the loop ends here)
+            if (lost.empty() || round == 7) break;
             // Each of them takes a slot in the list of its closest reachable out-neighbor — a free one, else that of the last
-            // entry that two or more reachable nodes point at (so nobody loses its only way in).  Rare (none on the bench
-            // corpora), so this runs on the host, in node order.
+            // entry that keeps an in-edge from a node of a strictly lower BFS level (indeg[] counts only those: a lower-level
+            // source is reached without passing through the entry, so the entry cannot be stranded by losing this edge —
+            // counting every reachable source would let two nodes that only reach each other vouch for one another).  Rare
+            // (none on the bench corpora), so this runs on the host, in node order; the sweep of the next round re-checks.
             uint32_t* d_indeg = nullptr;
             VS_HIP(hipMalloc(&d_indeg, (size_t)n * 4));
             indeg.assign(n, 0);
@@ -745,7 +781,8 @@ static int build_graph_impl(vs_index* ix, uint32_t L, double max_alpha_d, uint32
             (void)hipFree(d_indeg);
             // the lists of the lost nodes, so that what becomes reachable through a node that was just given a way in is known
             // without another sweep
-            std::vector<uint32_t> lrows(lost.size() * (size_t)R), lidx(n, 0xFFFFFFFFu), stack;
+            std::vector<uint32_t> lrows(lost.size() * (size_t)R), lidx(n, 0xFFFFFFFFu), stack, level(n);
+            for (uint32_t i = 0; i < n; ++i) level[i] = reached[i];  // 1 + BFS level (0: not reached); grows past 255 on the host
             for (size_t oi = 0; oi < lost.size() && r == VS_OK; ++oi) {
                 lidx[lost[oi]] = (uint32_t)oi;
                 hip_ok(hipMemcpy(&lrows[oi * R], ix->nbrs + (size_t)lost[oi] * ix->nbr_stride, (size_t)R * 4, hipMemcpyDeviceToHost));
@@ -767,11 +804,15 @@ static int build_graph_impl(vs_index* ix, uint32_t L, double max_alpha_d, uint32
                         int slot = -1;
                         for (uint32_t t = 0; t < R && slot < 0; ++t)
                             if (rown[t] == VS_INVALID_NODE) slot = (int)t;
-                        for (int t = (int)R - 1; t >= 0 && slot < 0; --t)
-                            if (indeg[rown[t]] >= 2) slot = t;
+                        for (int t = (int)R - 1; t >= 0 && slot < 0; --t) {
+                            const uint32_t y = rown[t];
+                            const uint32_t mine = (reached[y] && level[n0] < level[y]) ? 1u : 0u;  // is n0 -> y one of the counted edges?
+                            if (indeg[y] >= mine + 1u) slot = t;
+                        }
                         if (slot < 0) continue;
-                        if (rown[slot] != VS_INVALID_NODE) indeg[rown[slot]]--;
+                        if (rown[slot] != VS_INVALID_NODE && reached[rown[slot]] && level[n0] < level[rown[slot]]) indeg[rown[slot]]--;
                         rown[slot] = x;
+                        level[x] = level[n0] + 1;
                         indeg[x]++;
                         placed = true;
                         hip_ok(hipMemcpy(ix->nbrs + (size_t)n0 * ix->nbr_stride, rown, (size_t)R * 4, hipMemcpyHostToDevice));
@@ -786,10 +827,13 @@ static int build_graph_impl(vs_index* ix, uint32_t L, double max_alpha_d, uint32
                         const uint32_t* rowu = &lrows[(size_t)lidx[u] * R];
                         for (uint32_t t = 0; t < R && rowu[t] != VS_INVALID_NODE; ++t) {
                             const uint32_t v = rowu[t];
-                            indeg[v]++;
                             if (!reached[v]) {
                                 reached[v] = 1;
+                                level[v] = level[u] + 1;
+                                indeg[v]++;
                                 stack.push_back(v);
+                            } else if (level[u] < level[v]) {
+                                indeg[v]++;
                             }
                         }
                     }
@@ -811,5 +855,8 @@ extern "C" int vs_build_graph(vs_index* ix, uint32_t search_list_size, double ma
     int r = build_graph_impl(ix, search_list_size, max_alpha, batch_max, B);
     (void)hipStreamSynchronize(ix->ctx->stream);
     B.free_all();
+    // the scan kernels rely on every neighbor list naming a node at most once (as vs_index_upload checks for staged
+    // indexes): a list that does not is a defect of this builder, not something to search on
+    if (r == VS_OK) r = vs_validate_graph(ix);
     return r;
 }

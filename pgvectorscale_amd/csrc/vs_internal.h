@@ -31,6 +31,14 @@ void vs_set_error(const char* fmt, ...);
         }                             \
     } while (0)
 
+#define VS_REQUIRE_OOM(cond, ...)     \
+    do {                              \
+        if (!(cond)) {                \
+            vs_set_error(__VA_ARGS__);\
+            return VS_ERR_OOM;        \
+        }                             \
+    } while (0)
+
 #define VS_TRY(expr)            \
     do {                        \
         int _r = (expr);        \
@@ -99,6 +107,7 @@ struct vs_index {
     uint64_t* codes = nullptr;
     uint32_t* nbrs = nullptr;
     uint64_t* tids = nullptr;
+    uint32_t build_unreachable = 0;    // nodes the last vs_build_graph left unreachable from the start node (0xFFFFFFFF: not judged)
     const uint8_t* visible = nullptr;  // per node, 0 = the heap fetch finds nothing under the scan's snapshot (nullptr: all visible)
     uint8_t* visible_own = nullptr;    // the library's own copy (vs_index_set_visibility)
     float* vecs = nullptr;

@@ -242,6 +242,10 @@ class DiskAnnIndex:
         check(self._L.vs_build_graph(self.h, search_list_size, max_alpha, batch_max, seed))
         self._refresh()
 
+    def build_unreachable(self):
+        """nodes the last build_graph left unreachable from the default start node (0 on well-formed input)"""
+        return int(self._L.vs_index_build_unreachable(self.h))
+
     # -- single kernels ------------------------------------------------------------------------------------------------
     def save_graph(self, path):
         """Dump the neighbor array (device layout [n][nbr_stride] u32) to a file (benchmark convenience: the on-device

@@ -145,6 +145,40 @@ def test_duplicate_vectors_stay_reachable(gpu_ctx, oracle):
     ix.close()
 
 
+def test_repair_never_strands_and_reports_what_it_could_not_reach(gpu_ctx, oracle):
+    """Many identical codes, short lists (6 dims x 1 bit = 64 distinct codes for 2126 rows, R = 10, L = 20): the sequential
+    builder itself leaves most rows unreachable here.  The repair pass may only evict an entry that keeps an in-edge from a
+    strictly lower BFS level (so it cannot strand what was reachable), iterates to a fixed point, and the count it reports is
+    the count a walk over the final graph finds."""
+    import pgvectorscale_amd as P
+    from helpers import make_vectors
+    n, dim, R = 2126, 6, 10
+    X = make_vectors(n, dim, 31, "uniform")
+    ix = P.DiskAnnIndex.alloc(gpu_ctx, n=n, dim_full=dim, bits=1, num_neighbors=R, distance_type=P.VS_L2)
+    vp, stride = ix.array(P._lib.ARR_VECS)
+    Xp = np.zeros((n, stride), np.float32)
+    Xp[:, :dim] = X
+    gpu_ctx.upload(vp, Xp)
+    ix.refresh_norms()
+    ix.sbq_train()
+    ix.sbq_quantize_corpus()
+    ix.build_graph(search_list_size=20, max_alpha=1.2)
+    host = ix.download()
+    got = _reach(host["nbrs"], ix.desc.default_start)
+    assert ix.build_unreachable() == n - got
+    onb, ostart = oracle.build_graph(host["codes"], num_neighbors=R, search_list_size=20)
+    assert got >= _reach(onb, ostart)
+    # without the repair pass (VS_BUILD_REPAIR=0) fewer rows are reachable: the pass only ever adds
+    import os
+    os.environ["VS_BUILD_REPAIR"] = "0"
+    try:
+        ix.build_graph(search_list_size=20, max_alpha=1.2)
+    finally:
+        os.environ.pop("VS_BUILD_REPAIR")
+    assert got >= _reach(ix.download()["nbrs"], ix.desc.default_start)
+    ix.close()
+
+
 @pytest.mark.parametrize("n,R,L", [(60, 8, 10), (2, 8, 10), (300, 4, 1)])
 def test_build_with_a_small_search_list(gpu_ctx, oracle, n, R, L):
     """(2L + 64) * R below the LDS heap top of the build-mode search: capacities must not wrap (they did: a 16 TB hipMalloc)"""
@@ -227,8 +261,8 @@ def test_label_aware_build(gpu_ctx, oracle):
     ix.build_graph(search_list_size=100, max_alpha=1.2)
     assert (ix.download()["nbrs"] == nb).all()  # deterministic
     assert not (nb == np.arange(n, dtype=np.uint32)[:, None]).any()  # no self loops
-    for r in nb[::97]:
-        live = r[r != 0xFFFFFFFF]
+    for r in nb:  # every list names a node at most once (the second insert pass asks again for the back-edges of the first:
+        live = r[r != 0xFFFFFFFF]  # found on hardware at 2M nodes, where lists have room and the requests were appended twice)
         assert len(set(live.tolist())) == len(live) and (r[: len(live)] != 0xFFFFFFFF).all()
     # the sequential label-aware builder on the same codes
     onb, ostart, ols = O.build_graph_labeled(host["codes"], off, vals, num_neighbors=R, search_list_size=100)

@@ -56,7 +56,7 @@ def graph_cache_path(args, n, dim, seed, bits, R):
     """Where the built neighbor array of this exact configuration is kept between runs (None = no cache)."""
     if args.graph_cache in (None, "", "none"):
         return None
-    key = f"{n}x{dim}.{args.distance}.b{bits}.R{R}.L{args.build_l}.s{seed}" + ("" if args.corpus == "lowrank" else f".{args.corpus}") + (f".lab{args.labels}" if args.labels else "")
+    key = f"{n}x{dim}.{args.distance}.b{bits}.R{R}.L{args.build_l}.s{seed}" + ("" if getattr(args, "corpus", "lowrank") == "lowrank" else f".{args.corpus}") + (f".lab{args.labels}" if getattr(args, "labels", 0) else "")
     if args.graph_cache != "auto":
         return f"{args.graph_cache}.{key}"
     if n < 10_000_000:

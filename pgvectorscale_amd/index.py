@@ -111,6 +111,17 @@ class DiskAnnIndex:
         mean = np.ascontiguousarray(mean, np.float32)
         m2 = None if m2 is None else np.ascontiguousarray(m2, np.float32)
         n, w = codes.shape
+        # the C side reads n rows of every array: a shorter one would be read past its end
+        if nbrs.ndim != 2 or nbrs.shape[0] != n or nbrs.shape[1] < num_neighbors:
+            raise ValueError(f"nbrs must be [{n}][>= {num_neighbors}], got {nbrs.shape}")
+        if heap_tids.shape != (n,):
+            raise ValueError(f"heap_tids must have shape ({n},), got {heap_tids.shape}")
+        if vecs is not None and (vecs.ndim != 2 or vecs.shape[0] != n or vecs.shape[1] < dim_index):
+            raise ValueError(f"vecs must be [{n}][>= {dim_index}], got {vecs.shape}")
+        if mean.shape != (dim_index,) or (m2 is not None and m2.shape != (dim_index,)):
+            raise ValueError(f"mean / m2 must have shape ({dim_index},)")
+        if label_off is not None and np.asarray(label_off).shape != (n + 1,):
+            raise ValueError(f"label_off must have shape ({n + 1},)")
         d = IndexDesc()
         d.n, d.dim_index, d.bits, d.words = n, dim_index, bits, w
         d.dim_full = dim_index if vecs is None else vecs.shape[1]
@@ -418,7 +429,9 @@ class IndexScan:
 
     def rescan(self, query, labels=None, search_list_size=DEFAULT_QUERY_SEARCH_LIST_SIZE, rescore=DEFAULT_QUERY_RESCORE):
         """query=None is the SQL NULL query; labels=None means no scan key (nkeys == 0)."""
-        q = None if query is None else np.ascontiguousarray(query, np.float32)
+        q = None if query is None else np.ascontiguousarray(query, np.float32).reshape(-1)
+        if q is not None and q.size != self.index.desc.dim_full:  # (vs_rescan reads dim_full floats)
+            raise ValueError(f"query has {q.size} dimensions, the index {self.index.desc.dim_full}")
         lv = None if labels is None else np.array(labels, np.int16)
         check(self._L.vs_rescan(self.h, _p(q), _p(lv), 0 if lv is None else lv.size, int(labels is not None),
                                 search_list_size, rescore))

@@ -63,15 +63,12 @@ def test_graph_cache_path():
     assert p is None or ("vs_graph_cache_" in p and p.endswith(".10000000x768.l2.b2.R50.L100.s5"))
 
 
-def test_canary_verdict():
-    good = '{"recall_at_k": 0.995, "cpu_baseline": {"gpu_rows_identical": true, "gpu_dist_bit_identical_frac": 1.0, "sample": "8192 of the step"}}'
-    assert bench.canary_verdict(0, "noise\n" + good + "\n")[0]
-    assert not bench.canary_verdict(-11, good)[0]                       # crashed
-    assert not bench.canary_verdict(0, "")[0]                           # nothing printed
-    assert not bench.canary_verdict(0, good.replace("true", "false"))[0]
-    assert not bench.canary_verdict(0, good.replace("1.0", "0.99"))[0]
-    assert not bench.canary_verdict(0, good.replace("0.995", "0.2"))[0]
-    assert not bench.canary_verdict(0, '{"cpu_baseline": {"value": null}}')[0]
+def test_usable_cores_respects_affinity_and_quota():
+    """cpu_baseline.cores must describe what ran: the affinity mask capped by the cgroup quota, not os.cpu_count()"""
+    c = bench.usable_cores()
+    assert 1 <= c["usable"] <= c["affinity"] <= max(c["os_cpu_count"], c["affinity"])
+    if c["cgroup_quota"]:
+        assert c["usable"] <= int(c["cgroup_quota"] + 0.5) or c["usable"] == 1
 
 
 def test_label_workload_helpers():

@@ -107,6 +107,8 @@ def lib():
     L.vso_stream_batch.restype = None
     L.vso_stream_batch.argtypes = [C.POINTER(VsoIndex), vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                    vp, vp, C.POINTER(VsoStats)]
+    L.vso_heap_replay.restype = sz
+    L.vso_heap_replay.argtypes = [vp, sz, vp]
     L.vso_build_graph.restype = None
     L.vso_build_graph.argtypes = [C.c_uint32, C.c_uint32, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, vp, u32p]
     L.vso_build_graph_labeled.restype = C.c_uint32
@@ -362,6 +364,14 @@ def build_graph(codes, num_neighbors=50, nbr_stride=None, search_list_size=100, 
     start = C.c_uint32()
     lib().vso_build_graph(n, w, _p(codes), num_neighbors, stride, search_list_size, max_alpha, _p(nbrs), C.byref(start))
     return nbrs, int(start.value)
+
+
+def heap_replay(ops):
+    """ops: [(key, id)] pushes, (0xFFFFFFFF, 0) pops -> ids in pop order (the rest is popped at the end)"""
+    a = np.ascontiguousarray(ops, np.uint32).reshape(-1, 2)
+    out = np.empty(a.shape[0], np.uint32)
+    k = lib().vso_heap_replay(_p(a), a.shape[0], _p(out))
+    return out[:k].tolist()
 
 
 def build_graph_labeled(codes, label_off, label_val, num_neighbors=50, nbr_stride=None, search_list_size=100, max_alpha=1.2):

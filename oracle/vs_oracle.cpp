@@ -1027,6 +1027,23 @@ struct Builder {
 
 extern "C" {
 
+/* Replays a push / pop sequence on the candidate heap (BinaryHeap<Reverse<ListSearchNeighbor>>, Ord on the distance only):
+ * ops[i] = (key, id), key == 0xFFFFFFFF means pop; the remaining entries are popped at the end.  Writes the ids in pop order
+ * and returns their number.  (What oracle/ref_kat.rs prints for the real std::collections::BinaryHeap.) */
+size_t vso_heap_replay(const uint32_t* ops, size_t n_ops, uint32_t* out_ids) {
+    RustBinaryHeap<LSN, ReverseLsnLe> h;
+    size_t k = 0;
+    for (size_t i = 0; i < n_ops; ++i) {
+        if (ops[2 * i] == 0xFFFFFFFFu) {
+            if (!h.empty()) out_ids[k++] = h.pop().id;
+        } else {
+            h.push(LSN{ops[2 * i + 1], (float)ops[2 * i]});
+        }
+    }
+    while (!h.empty()) out_ids[k++] = h.pop().id;
+    return k;
+}
+
 void vso_build_graph(uint32_t n, uint32_t words, const uint64_t* codes, uint32_t num_neighbors, uint32_t nbr_stride,
                      uint32_t search_list_size, double max_alpha, uint32_t* nbrs, uint32_t* default_start) {
     Builder b{n, words, num_neighbors, nbr_stride, search_list_size, max_alpha, codes, nbrs, nullptr, nullptr, {}};

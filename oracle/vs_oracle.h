@@ -137,6 +137,8 @@ void vso_stream_batch(const vso_index* idx, const float* queries, const int16_t*
 /* Sequential Vamana build with SBQ Hamming distances, modelled on Graph::insert / prune_neighbors
  * (AM/graph/mod.rs:392-488,637-717) — used only to manufacture test graphs; not claimed bit-identical
  * to the reference build (which itself is HashSet-order dependent, AM/graph/mod.rs:317-326). */
+/* push / pop replay on the candidate heap; ops = [n_ops][2] (key, id), key 0xFFFFFFFF = pop; returns the number of ids written */
+size_t vso_heap_replay(const uint32_t* ops, size_t n_ops, uint32_t* out_ids);
 void vso_build_graph(uint32_t n, uint32_t words, const uint64_t* codes, uint32_t num_neighbors, uint32_t nbr_stride,
                      uint32_t search_list_size, double max_alpha, uint32_t* nbrs /* out [n][nbr_stride] */,
                      uint32_t* default_start /* out */);

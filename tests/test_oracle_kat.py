@@ -1,5 +1,7 @@
 """Oracle vs every known-answer test / golden vector the reference holds for this path.
 CPU only."""
+import os
+
 import numpy as np
 import pytest
 
@@ -159,3 +161,100 @@ def test_micro_bench_runs(oracle):
     m = oracle.micro_bench(iters=2000)
     assert set(m) == {"distance_l2_2000d", "distance_cosine_2000d", "inner_product_2000d", "distance_xor_optimized_1536bit"}
     assert all(0 < v < 1e6 for v in m.values())
+
+
+# ---- known answers generated BY THE REFERENCE (oracle/ref_kat.rs, one `cargo test` for anyone with its toolchain) ----------
+REF_KAT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_kat.txt")
+
+
+def _kat_sample(i, d):
+    return np.float32(np.float32((i * 31 + d * 17) % 97) / np.float32(97.0)) - np.float32(0.5)
+
+
+def _heap_ops(seed, steps, nkeys):
+    """the push / pop sequence of ref_kat_binary_heap_tie_order (a pop on an empty heap becomes a push there too)"""
+    ops, size, x = [], 0, seed
+    for i in range(steps):
+        x = (x * 1103515245 + 12345) & 0x7FFFFFFF
+        if (x >> 16) % 3 != 0 or size == 0:
+            ops.append(((x >> 8) % nkeys, i))
+            size += 1
+        else:
+            ops.append((0xFFFFFFFF, 0))
+            size -= 1
+    return ops
+
+
+def check_ref_kat_lines(oracle, lines):
+    """every `KAT ...` line of oracle/ref_kat.rs against the oracle; returns the number of lines checked"""
+    O = oracle
+    from oracle import pages_py as PG
+    trained = {}
+    checked = 0
+    for ln in lines:
+        f = dict(kv.split("=", 1) for kv in ln.split()[2:])
+        kind = ln.split()[1]
+        if kind == "train":
+            dims, bits, n = int(f["dims"]), int(f["bits"]), int(f["n"])
+            rows = np.array([[_kat_sample(i, d) for d in range(dims)] for i in range(n)], np.float32)
+            mean, m2, cnt = O.train(rows, bits)
+            trained[(dims, bits, n)] = (mean, m2, cnt)
+            assert cnt == int(f["count"])
+            assert [f"{v:08x}" for v in mean.view(np.uint32)] == f["mean"].split(",")
+            if bits > 1:
+                assert [f"{v:08x}" for v in m2.view(np.uint32)] == f["m2"].split(",")
+        elif kind == "code":
+            dims, bits, n, j = int(f["dims"]), int(f["bits"]), int(f["n"]), int(f["q"])
+            mean, m2, cnt = trained[(dims, bits, n)]
+            v = np.array([[np.float32(_kat_sample(1000 + 7 * j, d) * np.float32(1.5)) for d in range(dims)]], np.float32)
+            code = O.quantize(mean, m2, cnt, bits, v)[0]
+            assert [f"{w:016x}" for w in code] == f["words"].split(",")
+        elif kind == "heap":
+            want = [int(x) for x in f["pops"].split(",")]
+            assert O.heap_replay(_heap_ops(int(f["seed"]), int(f["steps"]), int(f["nkeys"]))) == want
+        elif kind == "node":
+            layout = (int(f["size"]), int(f["off_heap"]), int(f["off_code"]), int(f["off_nbrs"]), int(f["off_last"]))
+            inv = (0xFFFFFFFF, 0)
+            got = PG.rkyv_sbq_node((7, 3), [0x0123456789abcdef, 0xfedcba9876543210, 0x00000000ffffffff],
+                                   [(1, 1), (2, 5), inv, inv], labels=[2, 5, 9] if f["kind"] == "labeled" else None, layout=layout)
+            assert got.hex() == f["bytes"]
+        elif kind == "simd":
+            d = int(f["d"])
+            a = np.array([np.float32(np.float32(i * 37 % 101) / np.float32(101.0)) - np.float32(0.3) for i in range(d)], np.float32)
+            b = np.array([np.float32(np.float32(i * 53 % 103) / np.float32(103.0)) - np.float32(0.7) for i in range(d)], np.float32)
+            assert f"{np.float32(O.distance_l2(a, b)).view(np.uint32):08x}" == f["l2"]
+            assert f"{np.float32(O.inner_product(a, b)).view(np.uint32):08x}" == f["ip"]
+        else:
+            raise AssertionError(f"unknown KAT line: {ln[:60]}")
+        checked += 1
+    return checked
+
+
+def test_reference_generated_kats(oracle):
+    if not os.path.exists(REF_KAT):
+        pytest.skip("tests/golden/ref_kat.txt absent: generate it with the reference's toolchain (oracle/ref_kat.rs)")
+    lines = [ln.strip() for ln in open(REF_KAT) if ln.startswith("KAT ")]
+    assert check_ref_kat_lines(oracle, lines) == len(lines) > 0
+
+
+def test_ref_kat_loader_on_oracle_made_lines(oracle):
+    """the loader itself is exercised on lines in the generator's format produced from the oracle (self-consistency only: it
+    proves the parsing and the closed-form inputs, not the reference)"""
+    O = oracle
+    from oracle import pages_py as PG
+    lines = []
+    for dims, bits, n in ((10, 2, 50), (70, 1, 33)):
+        rows = np.array([[_kat_sample(i, d) for d in range(dims)] for i in range(n)], np.float32)
+        mean, m2, cnt = O.train(rows, bits)
+        lines.append(f"KAT train dims={dims} bits={bits} n={n} count={cnt} mean=" + ",".join(f"{v:08x}" for v in mean.view(np.uint32)) +
+                     " m2=" + ",".join(f"{v:08x}" for v in (m2.view(np.uint32) if bits > 1 else [])))
+        v = np.array([[np.float32(_kat_sample(1000, d) * np.float32(1.5)) for d in range(dims)]], np.float32)
+        code = O.quantize(mean, m2, cnt, bits, v)[0]
+        lines.append(f"KAT code dims={dims} bits={bits} n={n} q=0 words=" + ",".join(f"{w:016x}" for w in code))
+    pops = O.heap_replay(_heap_ops(1, 400, 7))
+    assert sorted(pops) == sorted(i for i, (kk, _) in enumerate(_heap_ops(1, 400, 7)) if kk != 0xFFFFFFFF)
+    lines.append("KAT heap seed=1 steps=400 nkeys=7 pops=" + ",".join(str(x) for x in pops))
+    inv = (0xFFFFFFFF, 0)
+    b = PG.rkyv_sbq_node((7, 3), [0x0123456789abcdef, 0xfedcba9876543210, 0x00000000ffffffff], [(1, 1), (2, 5), inv, inv], labels=[2, 5, 9])
+    lines.append(f"KAT node kind=labeled size=32 off_heap=0 off_code=8 off_nbrs=16 off_last=24 bytes={b.hex()}")
+    assert check_ref_kat_lines(oracle, lines) == len(lines)

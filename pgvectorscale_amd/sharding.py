@@ -14,28 +14,32 @@ def shard_range(nq_total: int, world: int, rank: int):
     return begin, begin + base + (1 if rank < rem else 0)
 
 
-def gather_topk(ids: torch.Tensor, dists: torch.Tensor, group=None):
-    """all_gather of per-rank [nq_local, k] blocks -> ([nq_total, k] ids, dists) in rank order.
-    Uneven shards are padded to the largest block for the collective and trimmed afterwards."""
+def gather_topk(ids: torch.Tensor, dists: torch.Tensor, group=None, counts=None):
+    """all_gather of per-rank [nq_local, k] blocks -> ([nq_total, k] ids, dists) in rank order, as ONE collective and without
+    a host synchronisation: ids and the bit patterns of the f32 distances travel in one int32 block of 2k columns
+    (`all_gather_into_tensor`), and the shard sizes are arithmetic, not exchanged — `counts` lists the rows of every rank
+    (`shard_range`); None means equal shards (the benchmark: every rank runs the same number of scans).  Uneven shards are
+    padded to the largest block for the collective and trimmed afterwards."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return ids, dists
     world = dist.get_world_size(group)
-    n_local = torch.tensor([ids.shape[0]], dtype=torch.int64, device=ids.device)
-    counts = [torch.zeros_like(n_local) for _ in range(world)]
-    dist.all_gather(counts, n_local, group=group)
-    counts = [int(c.item()) for c in counts]
+    n, k = ids.shape
+    counts = [n] * world if counts is None else [int(c) for c in counts]
+    assert len(counts) == world and counts[dist.get_rank(group)] == n
     m = max(counts)
-    k = ids.shape[1]
-
-    def pad(t, fill):
-        if t.shape[0] == m:
-            return t.contiguous()
-        p = torch.full((m, k), fill, dtype=t.dtype, device=t.device)
-        p[: t.shape[0]] = t
-        return p
-
-    gi = [torch.empty((m, k), dtype=ids.dtype, device=ids.device) for _ in range(world)]
-    gd = [torch.empty((m, k), dtype=dists.dtype, device=dists.device) for _ in range(world)]
-    dist.all_gather(gi, pad(ids, -1), group=group)
-    dist.all_gather(gd, pad(dists, float("nan")), group=group)
-    return (torch.cat([g[:c] for g, c in zip(gi, counts)], 0), torch.cat([g[:c] for g, c in zip(gd, counts)], 0))
+    packed = torch.zeros((m, 2 * k), dtype=torch.int32, device=ids.device)
+    packed[:n, :k] = ids if ids.dtype == torch.int32 else ids.to(torch.int32)  # (u32 node ids: 0xFFFFFFFF travels as -1)
+    packed[:n, k:] = dists.contiguous().view(torch.int32)
+    out = torch.empty((world * m, 2 * k), dtype=torch.int32, device=ids.device)
+    dist.all_gather_into_tensor(out, packed, group=group)
+    out = out.view(world, m, 2 * k)
+    if min(counts) != m:
+        out = torch.cat([out[r, :c] for r, c in enumerate(counts)], 0)
+    else:
+        out = out.reshape(world * m, 2 * k)
+    gi = out[:, :k].contiguous()
+    if ids.dtype != torch.int32:
+        gi = gi.to(ids.dtype)
+        if ids.dtype == torch.int64:
+            gi = gi & 0xFFFFFFFF
+    return gi, out[:, k:].contiguous().view(torch.float32)

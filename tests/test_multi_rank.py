@@ -33,7 +33,8 @@ def _worker(rank, world, port, nq_total, out_path):
     q = ti.queries(nq_total, seed=55)
     b, e = shard_range(nq_total, world, rank)
     ids, d, _ = ti.oracle.search_batch(q[b:e], L=30, rescore=10, k=7)
-    gi, gd = gather_topk(torch.from_numpy(ids.astype(np.int64)), torch.from_numpy(d))
+    counts = [shard_range(nq_total, world, r)[1] - shard_range(nq_total, world, r)[0] for r in range(world)]
+    gi, gd = gather_topk(torch.from_numpy(ids.astype(np.int64)), torch.from_numpy(d), counts=counts)
     if rank == 0:
         np.savez(out_path, ids=gi.numpy(), dist=gd.numpy())
     dist.barrier()

@@ -54,6 +54,19 @@ def main():
         wb = sum(w) / len(w) * 1024
         out[kern] = {"FETCH_SIZE_bytes": round(fb), "WRITE_SIZE_bytes": round(wb), "read_bytes_calibrated": round(fb * cal),
                      "hbm_bytes_per_launch": round(fb * cal + wb)}
+    # FETCH_SIZE = read requests x 64 B, and a 128-byte request is tallied as 64 (MI355X_MICROARCH.md, HBM section; the flat scan
+    # above measures exactly that factor of two).  k_search_fast mixes request sizes: a 192-byte code row is one 128-byte and
+    # one 64-byte request (scripts/microbench/randmem.hip: FETCH_SIZE = 2/3 of the bytes of a pure row gather), a 256-byte
+    # neighbor row two 128-byte requests, everything else (dedup buckets, heap spill) 64-byte requests.  So its read bytes are
+    # FETCH_SIZE + 64 B per 128-byte request, with the request counts taken from the kernel's own work counters.
+    m2 = re.search(r"visits/q ([0-9.]+) dq/q ([0-9.]+)", log)
+    if m2 and "k_search_fast" in out:
+        visits, dq = float(m2.group(1)) * args.nq, float(m2.group(2)) * args.nq
+        ks = out["k_search_fast"]
+        ks["requests_of_128_bytes"] = round(dq + 2 * visits)
+        ks["read_bytes_corrected"] = round(ks["FETCH_SIZE_bytes"] + 64 * (dq + 2 * visits))
+        ks["hbm_bytes_per_launch"] = ks["read_bytes_corrected"] + ks["WRITE_SIZE_bytes"]
+        ks["algorithmic_bytes_per_launch"] = round(dq * 192 + visits * 200) if True else None
     out["hbm_bytes_per_launch"] = out.get("k_search_fast", {}).get("hbm_bytes_per_launch")
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     dst = os.path.join(args.dir, "pmc_search_traffic.json")

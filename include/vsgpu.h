@@ -263,6 +263,13 @@ int vs_rerank(vs_index* idx, const float* q_full, const uint32_t* ids, const uin
 
 /* ---- K5: flat scan — top-k of Hamming distance over ALL codes, order (hamming asc, node id asc) ------------- */
 int vs_scan_topk(vs_index* idx, const uint64_t* qcodes, uint32_t nq, uint32_t k, uint32_t* out_ids, uint32_t* out_ham);
+/* The same with the scan's predicate: only rows whose label set overlaps the query's key (qlabels / qlabel_off: CSR per query, an
+ * empty key filters nothing — LabelSetView::overlaps, AM/labels/mod.rs:124-142, AM/scan.rs:189) and, with live_only, whose heap
+ * tuple is not deleted (AM/scan.rs:231-234) are ranked: the EXACT filtered SBQ top-k, what the label-filtered graph walk
+ * approximates.  An explicit entry point (ground truth of the SBQ ranking, exact mode for very selective keys); the access-method
+ * callbacks never switch to it on their own, because their rows must be the reference's graph walk's. */
+int vs_scan_topk_filtered(vs_index* idx, const uint64_t* qcodes, const int16_t* qlabels, const uint32_t* qlabel_off, int live_only,
+                          uint32_t nq, uint32_t k, uint32_t* out_ids, uint32_t* out_ham);
 
 /* ---- K3 (+K2 + resort window): batched scans ------------------------------------------------------------------
  * For each query: exactly the rows the reference returns from the first k amgettuple calls after amrescan

@@ -118,6 +118,8 @@ def lib():
     L.vso_bruteforce_topk.argtypes = [C.POINTER(VsoIndex), vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]
     L.vso_hamming_scan_topk.restype = None
     L.vso_hamming_scan_topk.argtypes = [vp, C.c_uint32, C.c_uint32, vp, C.c_uint32, C.c_uint32, vp, vp]
+    L.vso_hamming_scan_topk_filtered.restype = None
+    L.vso_hamming_scan_topk_filtered.argtypes = [vp, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp, vp, C.c_uint32, C.c_uint32, vp, vp]
     _lib = L
     return L
 
@@ -390,11 +392,28 @@ def build_graph_labeled(codes, label_off, label_val, num_neighbors=50, nbr_strid
     return nbrs, int(start.value), {int(sl[i]): int(sn[i]) for i in range(k)}
 
 
-def hamming_scan_topk(codes, qcodes, k):
+def hamming_scan_topk(codes, qcodes, k, label_off=None, label_val=None, heap_tids=None, qlabels=None):
+    """exact SBQ top-k, order (hamming, id); with label sets + one key per query (and heap tids) only the rows a label-filtered
+    scan may return are ranked"""
     codes = np.ascontiguousarray(codes, np.uint64)
     qcodes = np.ascontiguousarray(qcodes, np.uint64)
     nq = qcodes.shape[0]
     nodes = np.empty((nq, k), np.uint32)
     ham = np.empty((nq, k), np.uint32)
-    lib().vso_hamming_scan_topk(_p(codes), codes.shape[0], codes.shape[1], _p(qcodes), nq, k, _p(nodes), _p(ham))
+    if qlabels is None and heap_tids is None:
+        lib().vso_hamming_scan_topk(_p(codes), codes.shape[0], codes.shape[1], _p(qcodes), nq, k, _p(nodes), _p(ham))
+        return nodes, ham
+    lo = None if label_off is None else np.ascontiguousarray(label_off, np.uint32)
+    lv = None if label_val is None else np.ascontiguousarray(label_val, np.int16)
+    ht = None if heap_tids is None else np.ascontiguousarray(heap_tids, np.uint64)
+    qo = qv = None
+    if qlabels is not None:
+        qo = np.zeros(nq + 1, np.uint32)
+        flat = []
+        for i, l in enumerate(qlabels):
+            flat += sorted(set(l))
+            qo[i + 1] = len(flat)
+        qv = np.array(flat, np.int16)
+    lib().vso_hamming_scan_topk_filtered(_p(codes), codes.shape[0], codes.shape[1], _p(lo), _p(lv), _p(ht), _p(qcodes), _p(qv), _p(qo),
+                                         nq, k, _p(nodes), _p(ham))
     return nodes, ham

@@ -1110,10 +1110,24 @@ void vso_bruteforce_topk(const vso_index* idx, const float* queries, uint32_t nq
 
 void vso_hamming_scan_topk(const uint64_t* codes, uint32_t n, uint32_t words, const uint64_t* qcodes, uint32_t nq,
                            uint32_t k, uint32_t* out_nodes, uint32_t* out_ham) {
+    vso_hamming_scan_topk_filtered(codes, n, words, nullptr, nullptr, nullptr, qcodes, nullptr, nullptr, nq, k, out_nodes, out_ham);
+}
+
+/* exact SBQ top-k among the rows a label-filtered scan may return: label sets overlap (an empty key filters nothing), heap tuple
+ * not deleted (heap_tids == nullptr: not checked) */
+void vso_hamming_scan_topk_filtered(const uint64_t* codes, uint32_t n, uint32_t words, const uint32_t* label_off,
+                                    const int16_t* label_val, const uint64_t* heap_tids, const uint64_t* qcodes,
+                                    const int16_t* qlabels, const uint32_t* qlabel_off, uint32_t nq, uint32_t k,
+                                    uint32_t* out_nodes, uint32_t* out_ham) {
     for (uint32_t q = 0; q < nq; ++q) {
         std::vector<uint64_t> best; /* (ham<<32 | id) ascending */
         const uint64_t* qc = qcodes + (size_t)q * words;
         for (uint32_t i = 0; i < n; ++i) {
+            if (heap_tids && (heap_tids[i] & 0xFFFFu) == 0) continue;
+            if (qlabel_off && qlabel_off[q + 1] > qlabel_off[q] &&
+                !vso_labels_overlap(qlabels + qlabel_off[q], qlabel_off[q + 1] - qlabel_off[q], label_val + label_off[i],
+                                    label_off[i + 1] - label_off[i]))
+                continue;
             uint64_t key = (vso_distance_xor(codes + (size_t)i * words, qc, words) << 32) | i;
             if (best.size() < k) best.insert(std::upper_bound(best.begin(), best.end(), key), key);
             else if (key < best.back()) {

@@ -154,6 +154,10 @@ void vso_bruteforce_topk(const vso_index* idx, const float* queries, uint32_t nq
 /* flat Hamming scan top-k with (hamming, node id) ascending order — oracle for the K5 scan kernel */
 void vso_hamming_scan_topk(const uint64_t* codes, uint32_t n, uint32_t words, const uint64_t* qcodes, uint32_t nq,
                            uint32_t k, uint32_t* out_nodes, uint32_t* out_ham);
+void vso_hamming_scan_topk_filtered(const uint64_t* codes, uint32_t n, uint32_t words, const uint32_t* label_off,
+                                    const int16_t* label_val, const uint64_t* heap_tids, const uint64_t* qcodes,
+                                    const int16_t* qlabels, const uint32_t* qlabel_off, uint32_t nq, uint32_t k,
+                                    uint32_t* out_nodes, uint32_t* out_ham);
 
 #ifdef __cplusplus
 }

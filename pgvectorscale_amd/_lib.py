@@ -123,6 +123,7 @@ SYMBOLS = {
     "vs_hamming_gather": (_i, [_vp, _vp, _vp, _vp, _u32, _vp]),
     "vs_rerank": (_i, [_vp, _vp, _vp, _vp, _u32, _vp]),
     "vs_scan_topk": (_i, [_vp, _vp, _u32, _u32, _vp, _vp]),
+    "vs_scan_topk_filtered": (_i, [_vp, _vp, _vp, _vp, _i, _u32, _u32, _vp, _vp]),
     "vs_search_batch": (_i, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp, C.POINTER(Stats)]),
     "vs_stream_batch": (_i, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, C.POINTER(Stats)]),
     "vs_search_batch_dev": (_i, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp]),

@@ -340,7 +340,20 @@ extern "C" int vs_sbq_quantize_corpus(vs_index* ix) {
 // ===============================================================================================================
 // K5 host entry: flat SBQ scan (kernels in vs_scan.hip)
 // ===============================================================================================================
+static int scan_topk_host(vs_index* ix, const uint64_t* qcodes, const int16_t* qlabels, const uint32_t* qlabel_off, int live_only,
+                          uint32_t nq, uint32_t k, uint32_t* out_ids, uint32_t* out_ham);
+
 extern "C" int vs_scan_topk(vs_index* ix, const uint64_t* qcodes, uint32_t nq, uint32_t k, uint32_t* out_ids, uint32_t* out_ham) {
+    return scan_topk_host(ix, qcodes, nullptr, nullptr, 0, nq, k, out_ids, out_ham);
+}
+
+extern "C" int vs_scan_topk_filtered(vs_index* ix, const uint64_t* qcodes, const int16_t* qlabels, const uint32_t* qlabel_off,
+                                     int live_only, uint32_t nq, uint32_t k, uint32_t* out_ids, uint32_t* out_ham) {
+    return scan_topk_host(ix, qcodes, qlabels, qlabel_off, live_only, nq, k, out_ids, out_ham);
+}
+
+static int scan_topk_host(vs_index* ix, const uint64_t* qcodes, const int16_t* qlabels, const uint32_t* qlabel_off, int live_only,
+                          uint32_t nq, uint32_t k, uint32_t* out_ids, uint32_t* out_ham) {
     VS_REQUIRE(ix && (nq == 0 || (qcodes && out_ids)), "vs_scan_topk: bad args");
     if (nq == 0) return VS_OK;
     vs_ctx* c = ix->ctx;
@@ -354,7 +367,29 @@ extern "C" int vs_scan_topk(vs_index* ix, const uint64_t* qcodes, uint32_t nq, u
     VS_TRY(devbuf_reserve(c, w.out_ids, (size_t)nq * k * 4));
     VS_TRY(devbuf_reserve(c, w.stream_ham, (size_t)nq * k * 4));
     VS_TRY(vs_dev_upload(c, w.qcodes.p, padded.data(), padded.size() * 8));
-    VS_TRY(launch_scan_topk(ix, (const uint64_t*)w.qcodes.p, nq, k, (uint32_t*)w.out_ids.p, (uint32_t*)w.stream_ham.p));
+    const int16_t* d_ql = nullptr;
+    const uint32_t* d_qo = nullptr;
+    if (qlabel_off) {  // keys as LabelSet::from makes them: sorted, de-duplicated (AM/labels/mod.rs:30-37)
+        VS_REQUIRE(ix->d.has_labels && ix->label_off, "vs_scan_topk_filtered: label keys on an index without labels");
+        std::vector<int16_t> vals;
+        std::vector<uint32_t> off(nq + 1, 0);
+        for (uint32_t q = 0; q < nq; ++q) {
+            VS_REQUIRE(qlabel_off[q] <= qlabel_off[q + 1], "qlabel_off must be non-decreasing");
+            std::vector<int16_t> l(qlabels + qlabel_off[q], qlabels + qlabel_off[q + 1]);
+            std::sort(l.begin(), l.end());
+            l.erase(std::unique(l.begin(), l.end()), l.end());
+            vals.insert(vals.end(), l.begin(), l.end());
+            off[q + 1] = (uint32_t)vals.size();
+        }
+        VS_TRY(devbuf_reserve(c, w.qlabels, std::max<size_t>(vals.size(), 1) * 2));
+        VS_TRY(devbuf_reserve(c, w.qlabel_off, off.size() * 4));
+        if (!vals.empty()) VS_TRY(vs_dev_upload(c, w.qlabels.p, vals.data(), vals.size() * 2));
+        VS_TRY(vs_dev_upload(c, w.qlabel_off.p, off.data(), off.size() * 4));
+        d_ql = (const int16_t*)w.qlabels.p;
+        d_qo = (const uint32_t*)w.qlabel_off.p;
+    }
+    VS_TRY(launch_scan_topk(ix, (const uint64_t*)w.qcodes.p, nq, k, (uint32_t*)w.out_ids.p, (uint32_t*)w.stream_ham.p, d_ql, d_qo,
+                            live_only != 0));
     VS_TRY(vs_dev_download(c, out_ids, w.out_ids.p, (size_t)nq * k * 4));
     if (out_ham) VS_TRY(vs_dev_download(c, out_ham, w.stream_ham.p, (size_t)nq * k * 4));
     return VS_OK;

@@ -216,4 +216,5 @@ int launch_slice_norms(vs_index* idx, float* d_out);  // divisor of the first di
 int launch_prepare_index_slice(vs_index* idx, const float* d_raw, uint32_t nq, float* d_q_index);
 int launch_validate_nbrs(vs_index* idx, uint32_t* d_flag);
 int launch_scan_topk(vs_index* idx, const uint64_t* d_qcodes, uint32_t nq, uint32_t k, uint32_t* d_out_ids,
-                     uint32_t* d_out_ham);
+                     uint32_t* d_out_ham, const int16_t* d_qlabels = nullptr, const uint32_t* d_qlabel_off = nullptr,
+                     bool live_only = false);

@@ -27,7 +27,33 @@ struct ScanArgs {
     uint64_t* partial;       // [tiles][waves_total][Q][k]
     uint32_t q_tile;         // Q (for the merge kernel)
     uint32_t waves_total;
+    // optional predicate (vs_scan_topk_filtered): a row is admitted for query q only when its label set overlaps the key
+    // qlabels[qlabel_off[q] .. qlabel_off[q + 1]) (LabelSetView::overlaps, AM/labels/mod.rs:124-142; an empty key filters
+    // nothing, AM/scan.rs:189) and, with live_only, its heap tid is not deleted (AM/scan.rs:231-234)
+    const uint32_t* label_off = nullptr;
+    const int16_t* label_val = nullptr;
+    const int16_t* qlabels = nullptr;
+    const uint32_t* qlabel_off = nullptr;
+    const uint64_t* tids = nullptr;
 };
+
+// (row and query are wave-uniform: scalar loads)
+__device__ __forceinline__ bool scan_row_admitted(const ScanArgs& a, uint32_t row, uint32_t q) {
+    if (a.tids && (a.tids[row] & 0xFFFFull) == 0) return false;
+    if (!a.qlabel_off) return true;
+    uint32_t i = a.qlabel_off[q];
+    const uint32_t ie = a.qlabel_off[q + 1];
+    if (i == ie) return true;
+    uint32_t j = a.label_off[row];
+    const uint32_t je = a.label_off[row + 1];
+    while (i < ie && j < je) {
+        const int16_t x = a.qlabels[i], y = a.label_val[j];
+        if (x == y) return true;
+        if (x < y) ++i;
+        else ++j;
+    }
+    return false;
+}
 
 // insert key into the wave's sorted list (ascending, k entries, list[i] in LDS); wave-uniform key
 __device__ __forceinline__ void list_insert(uint64_t* list, uint32_t k, uint64_t key, int lane) {
@@ -115,8 +141,9 @@ __global__ __launch_bounds__(SCAN_WAVES* WAVE) void k_scan_topk(ScanArgs a) {
                         const int src = __builtin_ctzll(h);
                         h &= h - 1;
                         const uint32_t hk = (uint32_t)__builtin_amdgcn_readlane((int)ham[p], src);
-                        if (hk < th[qi]) {
-                            const uint64_t kk = ((uint64_t)hk << 32) | (r0 + (uint32_t)p * 16 + (uint32_t)(src >> 2));
+                        const uint32_t rid = r0 + (uint32_t)p * 16 + (uint32_t)(src >> 2);
+                        if (hk < th[qi] && scan_row_admitted(a, rid, q0 + (uint32_t)qi)) {
+                            const uint64_t kk = ((uint64_t)hk << 32) | rid;
                             uint64_t* lst = mylists + (size_t)qi * a.k;
                             list_insert(lst, a.k, kk, lane);
                             th[qi] = rfl((uint32_t)(lst[a.k - 1] >> 32));
@@ -196,7 +223,8 @@ static int launch_scan_t(vs_index* idx, const ScanArgs& a, dim3 grid, size_t lds
 }
 
 // d_qcodes: device [nq][code_stride]; d_out_*: device [nq][k]
-int launch_scan_topk(vs_index* idx, const uint64_t* d_qcodes, uint32_t nq, uint32_t k, uint32_t* d_out_ids, uint32_t* d_out_ham) {
+int launch_scan_topk(vs_index* idx, const uint64_t* d_qcodes, uint32_t nq, uint32_t k, uint32_t* d_out_ids, uint32_t* d_out_ham,
+                     const int16_t* d_qlabels, const uint32_t* d_qlabel_off, bool live_only) {
     if (nq == 0) return VS_OK;
     VS_REQUIRE(k >= 1 && k <= SCAN_KMAX, "vs_scan_topk: k must be in [1, %d]", SCAN_KMAX);
     const uint32_t nch = (idx->code_stride + 7) / 8;
@@ -232,6 +260,14 @@ int launch_scan_topk(vs_index* idx, const uint64_t* d_qcodes, uint32_t nq, uint3
     a.partial = (uint64_t*)w.misc.p;
     a.waves_total = waves_total;
     a.q_tile = Q;
+    if (d_qlabel_off) {
+        VS_REQUIRE(idx->label_off && idx->label_val, "vs_scan_topk_filtered: the index has no label sets");
+        a.label_off = idx->label_off;
+        a.label_val = idx->label_val;
+        a.qlabels = d_qlabels;
+        a.qlabel_off = d_qlabel_off;
+    }
+    a.tids = live_only ? idx->tids : nullptr;
     const size_t lds = ((size_t)Q * idx->code_stride + (size_t)SCAN_WAVES * Q * k) * 8;
     const dim3 grid(blocks, tiles);
     hipEvent_t ev = prof_begin(c);

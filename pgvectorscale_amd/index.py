@@ -302,12 +302,18 @@ class DiskAnnIndex:
         check(self._L.vs_rerank(self.h, _p(q), _p(ids), _p(off), q.shape[0], _p(out)))
         return [out[off[i]:off[i + 1]] for i in range(len(id_lists))]
 
-    def scan_topk(self, qcodes, k):
+    def scan_topk(self, qcodes, k, qlabels=None, live_only=False):
+        """flat SBQ scan: exact top-k of the Hamming distance, order (hamming, node id); qlabels (one label list per query) /
+        live_only restrict it to the rows a label-filtered scan may return"""
         qcodes = np.ascontiguousarray(qcodes, np.uint64).reshape(-1, self.desc.words)
         nq = qcodes.shape[0]
         ids = np.empty((nq, k), np.uint32)
         ham = np.empty((nq, k), np.uint32)
-        check(self._L.vs_scan_topk(self.h, _p(qcodes), nq, k, _p(ids), _p(ham)))
+        if qlabels is None and not live_only:
+            check(self._L.vs_scan_topk(self.h, _p(qcodes), nq, k, _p(ids), _p(ham)))
+            return ids, ham
+        lv, lo = self._label_keys(qlabels, nq) if qlabels is not None else (None, None)
+        check(self._L.vs_scan_topk_filtered(self.h, _p(qcodes), _p(lv), _p(lo), int(live_only), nq, k, _p(ids), _p(ham)))
         return ids, ham
 
     # -- batched scans ---------------------------------------------------------------------------------------------------

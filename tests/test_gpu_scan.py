@@ -77,3 +77,34 @@ def test_bruteforce_topk_matches_oracle(gpu_ctx, oracle, distance):
     assert (dist.view(np.uint32) == np.asarray(gt_d, np.float32).view(np.uint32)).all()
     gpu_ctx.free(dq)
     ix.close()
+
+
+def test_scan_topk_filtered_is_the_exact_filtered_ranking(gpu_ctx, oracle):
+    """vs_scan_topk_filtered: exact SBQ top-k among the rows a label-filtered scan may return (label sets overlap, an empty key
+    filters nothing, deleted tuples skipped with live_only) — against the oracle twin, with keys from common to absent labels,
+    and as the upper bound of what the label-filtered graph walk finds (its stream is a subsequence of this ranking's rows)."""
+    ti = cached_index(n=3000, dim_full=64, bits=2, R=32, distance=1, seed=11, kind="gauss", L_build=64, n_labels=6, deleted_frac=0.1)
+    ix = ti.upload(gpu_ctx)
+    q = ti.queries(24, seed=3, kind="gauss")
+    qcodes = ix.quantize(q)
+    rng = np.random.default_rng(4)
+    keys = [sorted(set(int(v) for v in rng.integers(1, 7, int(rng.integers(0, 3))))) for _ in range(len(q))]
+    keys[0], keys[1], keys[2] = [], [6], [99]  # no filter / one label / a label nobody carries
+    for live in (False, True):
+        for k in (1, 10, 64):
+            gi, gh = ix.scan_topk(qcodes, k, qlabels=keys, live_only=live)
+            oi, oh = oracle.hamming_scan_topk(ti.codes, qcodes, k, label_off=ti.label_off, label_val=ti.label_val,
+                                              heap_tids=ti.tids if live else None, qlabels=keys)
+            assert (gi == oi).all() and (gh == oh).all()
+    assert (gi[2] == 0xFFFFFFFF).all()
+    # no key at all = the plain flat scan
+    a, _ = ix.scan_topk(qcodes, 10)
+    b, _ = ix.scan_topk(qcodes, 10, qlabels=[[] for _ in keys])
+    assert (a == b).all()
+    # the graph walk's SBQ-ordered stream only ever returns rows of the filtered set, at Hamming distances no smaller than the
+    # exact ranking's at the same position
+    si, sh, _ = ix.stream_batch(q[3:], search_list_size=100, m=10, qlabels=keys[3:])
+    gi, gh = ix.scan_topk(qcodes[3:], 10, qlabels=keys[3:], live_only=True)
+    live = sh != 0xFFFFFFFF
+    assert (sh[live] >= gh[live]).all()
+    ix.close()

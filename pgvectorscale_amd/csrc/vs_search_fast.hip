@@ -210,28 +210,48 @@ struct FastHeap {
                 const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((rank_ok ? src : 0u) << 2), (int)anc);
                 return rank_ok ? v : 0u;
             };
-            uint32_t p1 = p1f;
-            uint32_t chain = fresh_of(p1);
-            asm volatile("" : "+v"(chain));  // the chain is complete before the loop
-            for (uint32_t e = 0; e < n; ++e, ++j) {
-                const uint32_t elem = readlane_u32(entry, j);
-                const uint32_t p1n = p1 + 1;
-                const uint32_t nxt = fresh_of(p1n);  // in flight during this push (unused after the last leaf)
-                const bool cmp = (elem >> sb) < (chain >> sb);
-                const uint32_t bal = ((uint32_t)__ballot(cmp) & 0x1FFFFEu) >> 1;  // bit r-1 <-> ancestor r (ranks 1..20)
-                const uint32_t t = (uint32_t)__builtin_ctz(~bal);                   // leading run of ancestors that move down
-                if (r <= t) {
-                    const uint32_t dst = r == 0 ? (p1 >> t) : (p1 >> (r - 1));
-                    const uint32_t val = r == 0 ? elem : chain;
-                    if (spill) set1(dst, val);
-                    else l[dst] = val;
-                }
-                const uint32_t sh = 32u - (uint32_t)__builtin_clz(p1 ^ p1n);
-                const uint32_t up = wave_shl1(chain, 0);  // rank r+1 value
-                const uint32_t patched = r < t ? up : (r == t ? elem : chain);
-                chain = r >= sh ? patched : nxt;
-                p1 = p1n;
+            // An element that is not smaller than the ORIGINAL parent of its leaf stays on the leaf whatever the earlier
+            // pushes of the run do (a push only ever lowers the values on its path: a position receives the pushed element or
+            // its own parent's old value), and no push reads a leaf of the run: those elements — about a third — are stored
+            // right away, all at once; only the climbers go through the sequential loop below.  Between two climbers the
+            // skipped leaves touch no ancestor, so the shared part of the chain carries over exactly as between neighbours.
+            const uint32_t mine = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((j + (uint32_t)lane) << 2), (int)entry);
+            const uint32_t myp1 = p1f + (uint32_t)lane;
+            const uint32_t par = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((myp1 >> 1) - (p1f >> 1)) << 2), (int)anc);
+            const bool inrun = (uint32_t)lane < n;
+            const bool climbs = inrun && (mine >> sb) < (par >> sb);
+            uint64_t cm = __ballot(climbs);
+            if (inrun && !climbs) {
+                if (spill) set1(myp1, mine);
+                else l[myp1] = mine;
             }
+            if (cm) {
+                uint32_t p1 = p1f + (uint32_t)__builtin_ctzll(cm);
+                uint32_t chain = fresh_of(p1);
+                asm volatile("" : "+v"(chain));  // the chain is complete before the loop
+                while (cm) {
+                    const uint32_t e = (uint32_t)__builtin_ctzll(cm);
+                    cm &= cm - 1;
+                    const uint32_t elem = readlane_u32(entry, j + e);
+                    p1 = p1f + e;
+                    const uint32_t p1n = cm ? p1f + (uint32_t)__builtin_ctzll(cm) : p1 + 1;  // next climber's leaf
+                    const uint32_t nxt = fresh_of(p1n);  // in flight during this push (unused after the last climber)
+                    const bool cmp = (elem >> sb) < (chain >> sb);
+                    const uint32_t bal = ((uint32_t)__ballot(cmp) & 0x1FFFFEu) >> 1;  // bit r-1 <-> ancestor r (ranks 1..20)
+                    const uint32_t t = (uint32_t)__builtin_ctz(~bal);                   // leading run of ancestors that move down
+                    if (r <= t) {
+                        const uint32_t dst = r == 0 ? (p1 >> t) : (p1 >> (r - 1));
+                        const uint32_t val = r == 0 ? elem : chain;
+                        if (spill) set1(dst, val);
+                        else l[dst] = val;
+                    }
+                    const uint32_t sh = 32u - (uint32_t)__builtin_clz(p1 ^ p1n);
+                    const uint32_t up = wave_shl1(chain, 0);  // rank r+1 value
+                    const uint32_t patched = r < t ? up : (r == t ? elem : chain);
+                    chain = r >= sh ? patched : nxt;
+                }
+            }
+            j += n;
             len += n;
             wave_sync();
         }

@@ -145,25 +145,26 @@ struct FastHeap {
     }
 
     // ---- insert_neighbor x c (AM/graph/mod.rs:144-147): elements 0..c-1 (lanes 0..c-1 of `entry`, neighbor-list order)
-    // are pushed one after another, but memory is touched once per RUN of up to 24 leaves on one level:
-    //   * the distinct ancestors of such a run are few (<= 13 parents, 7 grandparents, 4, 3, then <= 2 per rank), so one
+    // are pushed one after another, but memory is touched once per RUN of up to 32 leaves on one level (the ~31 candidates of a
+    // typical visit are one run, i.e. one round trip to the spill array):
+    //   * the distinct ancestors of such a run are few (<= 17 parents, 9 grandparents, 5, 3, then <= 2 per rank), so one
     //     wave-wide load (lane -> fixed (rank, slot) layout below) brings all of them in, from LDS or from the spill array;
     //   * consecutive leaves P, P+1 share their ancestors from rank sh = bitlen((P+1) xor (P+2)) upwards, and what push j
     //     did to that shared chain is known in registers (ranks r < t_j now hold the old rank r+1 value, rank t_j holds
     //     element j); the ranks below sh are positions no earlier push of the run can have touched, so push j+1 takes
     //     them from the wide load (ds_bpermute) and the rest from the patched chain of push j.
-    // lane layout of the wide load: rank 1 -> lanes 0..15, rank 2 -> 16..23, rank 3 -> 24..28, rank 4 -> 29..31,
-    // rank r >= 5 -> lanes 32 + 2 (r - 5), +1  (ranks up to 20: heaps of up to 2^20 entries)
+    // lane layout of the wide load: rank 1 -> lanes 0..16, rank 2 -> 17..25, rank 3 -> 26..30, rank 4 -> 31..33,
+    // rank r >= 5 -> lanes 34 + 2 (r - 5), +1  (ranks up to 19: heaps of up to 2^19 entries)
     uint32_t wl_rank, wl_slot, wl_base;  // this lane's (rank, slot) as a wide-load lane; first lane of rank `lane`
     __device__ __forceinline__ void init_wide() {
         const uint32_t i = (uint32_t)lane;
-        if (i < 16) { wl_rank = 1; wl_slot = i; }
-        else if (i < 24) { wl_rank = 2; wl_slot = i - 16; }
-        else if (i < 29) { wl_rank = 3; wl_slot = i - 24; }
-        else if (i < 32) { wl_rank = 4; wl_slot = i - 29; }
-        else { wl_rank = 5 + ((i - 32) >> 1); wl_slot = (i - 32) & 1u; }
+        if (i < 17) { wl_rank = 1; wl_slot = i; }
+        else if (i < 26) { wl_rank = 2; wl_slot = i - 17; }
+        else if (i < 31) { wl_rank = 3; wl_slot = i - 26; }
+        else if (i < 34) { wl_rank = 4; wl_slot = i - 31; }
+        else { wl_rank = 5 + ((i - 34) >> 1); wl_slot = (i - 34) & 1u; }
         const uint32_t r = i;  // as a chain lane: where do rank-r values start
-        wl_base = r <= 1 ? 0u : (r == 2 ? 16u : (r == 3 ? 24u : (r == 4 ? 29u : 32u + 2u * (r - 5u))));
+        wl_base = r <= 1 ? 0u : (r == 2 ? 17u : (r == 3 ? 26u : (r == 4 ? 31u : 34u + 2u * (r - 5u))));
     }
     // entry at index idx (= heap position + 1; 0 = sentinel)
     __device__ __forceinline__ uint32_t get1(uint32_t idx) const { return idx <= hl ? l[idx] : gload32(g + (idx - 1 - hl)); }
@@ -174,9 +175,9 @@ struct FastHeap {
     // geometry of the first run of c pushes starting at the current length (0 = "one at a time" path)
     __device__ __forceinline__ uint32_t first_run(uint32_t c) const {
         const uint32_t p1f = len + 1;
-        if (len < 64 || p1f >= (1u << 20)) return 0;
+        if (len < 64 || p1f >= (1u << 19)) return 0;
         const uint32_t room = (2u << (31u - (uint32_t)__builtin_clz(p1f))) - p1f;
-        return min(min(c, 24u), room);
+        return min(min(c, 32u), room);
     }
     // the wide ancestor load of a run of n leaves starting at the current length (only ISSUES the reads)
     __device__ __forceinline__ uint32_t wide_load(uint32_t n) const {
@@ -191,10 +192,10 @@ struct FastHeap {
         uint32_t j = 0;
         while (j < c) {
             const uint32_t p1f = len + 1;  // (position of the run's first leaf) + 1
-            // a run stays on one heap level, has at most 24 leaves, and needs a heap of >= 64 entries / depth <= 20
+            // a run stays on one heap level, has at most 32 leaves, and needs a heap of >= 64 entries / depth <= 19
             const uint32_t room = (2u << (31u - (uint32_t)__builtin_clz(p1f))) - p1f;  // leaves left on this level
-            const uint32_t n = min(min(c - j, 24u), room);
-            if (len < 64 || p1f >= (1u << 20)) {  // tiny or huge heap: one at a time
+            const uint32_t n = min(min(c - j, 32u), room);
+            if (len < 64 || p1f >= (1u << 19)) {  // tiny or huge heap: one at a time
                 push(readlane_u32(entry, j));
                 ++j;
                 continue;
@@ -204,7 +205,7 @@ struct FastHeap {
             // ---- wide load of every distinct ancestor of the run (the first run's may already be in flight)
             const uint32_t anc = (j == 0 && pre_n == n) ? pre_anc : wide_load(n);
             const uint32_t r = (uint32_t)lane;       // chain lane = ancestor rank (lane 0 and lanes > 20 unused)
-            const bool rank_ok = r >= 1 && r <= 20;
+            const bool rank_ok = r >= 1 && r <= 19;
             auto fresh_of = [&](uint32_t p1) -> uint32_t {  // rank-r ancestor of leaf p1 as loaded at the start of the run
                 const uint32_t src = wl_base + ((p1 >> (r & 31u)) - (p1f >> (r & 31u)));
                 const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((rank_ok ? src : 0u) << 2), (int)anc);
@@ -237,7 +238,7 @@ struct FastHeap {
                     const uint32_t p1n = cm ? p1f + (uint32_t)__builtin_ctzll(cm) : p1 + 1;  // next climber's leaf
                     const uint32_t nxt = fresh_of(p1n);  // in flight during this push (unused after the last climber)
                     const bool cmp = (elem >> sb) < (chain >> sb);
-                    const uint32_t bal = ((uint32_t)__ballot(cmp) & 0x1FFFFEu) >> 1;  // bit r-1 <-> ancestor r (ranks 1..20)
+                    const uint32_t bal = ((uint32_t)__ballot(cmp) & 0xFFFFEu) >> 1;  // bit r-1 <-> ancestor r (ranks 1..19)
                     const uint32_t t = (uint32_t)__builtin_ctz(~bal);                   // leading run of ancestors that move down
                     if (r <= t) {
                         const uint32_t dst = r == 0 ? (p1 >> t) : (p1 >> (r - 1));

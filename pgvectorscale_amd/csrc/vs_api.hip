@@ -1277,7 +1277,7 @@ extern "C" int vs_search_batch_dev_finish(vs_index* ix, vs_stats* stats) {
 
 // ---------------------------------------------------------------------------------------------------------------
 // amrescan / amgettuple mirror.  A scan prefetches `rescore + window` rows with one batched launch and hands them
-// out one at a time; asking past the prefetched rows re-runs the (deterministic) scan with a doubled window — the
+// out one at a time; asking past the prefetched rows re-runs the (deterministic) scan with a four times larger window — the
 // stream is a pure function of (index, query, GUCs), so the already returned prefix is reproduced exactly.
 // ---------------------------------------------------------------------------------------------------------------
 struct vs_scan {
@@ -1369,7 +1369,9 @@ extern "C" int vs_gettuple(vs_scan* s, uint64_t* heap_tid, uint32_t* node, float
         return VS_ERR_STATE;
     }
     if (s->cursor >= s->window && !s->exhausted) {
-        uint32_t want = s->window == 0 ? 16u : s->window * 2;
+        // windows grow by four (16, 64, 256, ...): the scan is deterministic, so a larger window reproduces the rows already
+        // handed out and an executor that keeps pulling pays at most 4/3 of its final scan in re-runs (a LIMIT <= 16 pays one)
+        uint32_t want = s->window == 0 ? 16u : s->window * 4;
         int r = scan_fetch(s, want);
         if (r != VS_OK) return r;
     }

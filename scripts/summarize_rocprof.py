@@ -24,6 +24,7 @@ def full_launches(trace_path, kernel="k_search_fast", min_ms=1.0):
     d = [x for x in d if x >= min_ms]
     if not d:
         return None
+    d = [x for x in d if x >= 0.5 * max(d)]  # (a second attempt that had a scan or two to finish is not a full launch)
     r0 = max((r for r in rows if int(r["Grid_Size_X"]) == gmax), key=lambda r: int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     return {"grid": gmax, "calls": len(d), "avg_ms": sum(d) / len(d), "min_ms": min(d), "max_ms": max(d), "vgpr": r0["VGPR_Count"],
             "sgpr": r0["SGPR_Count"], "lds": r0["LDS_Block_Size"], "scratch": r0["Scratch_Size"]}

@@ -276,7 +276,9 @@ int vs_scan_topk_filtered(vs_index* idx, const uint64_t* qcodes, const int16_t* 
  * (TSVResponseIterator::next_with_resort, AM/scan.rs:244-305) with GUCs diskann.query_search_list_size =
  * search_list_size and diskann.query_rescore = rescore (AM/guc.rs:3-4).
  *   queries   host [nq][dim_full] raw f32
- *   qlabels / qlabel_off: CSR of the smallint[] scan keys, qlabel_off == NULL => no scan key on any query
+ *   qlabels / qlabel_off: CSR of the smallint[] scan keys, qlabel_off == NULL => no scan key on any query.  A key may hold at
+ *             most 64 distinct labels (VS_ERR_INVALID beyond; the reference has no limit — the key of a scan sits in 128 bytes
+ *             of on-chip memory here; the device-resident variant reads the first 64), a node at most 64 for a label-aware build
  *   out_ids   [nq][k] node ids (VS_INVALID_NODE past the end of a scan), out_tids [nq][k] heap TIDs (may be NULL),
  *   out_dist  [nq][k] reranked f32 distance (NaN when rescore == 0) (may be NULL)                               */
 int vs_search_batch(vs_index* idx, const float* queries, const int16_t* qlabels, const uint32_t* qlabel_off, uint32_t nq,

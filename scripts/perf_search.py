@@ -27,6 +27,10 @@ def main():
     ap.add_argument("--kind", default="clustered", choices=["clustered", "hard"])
     ap.add_argument("--graph-cache", default=None, help="neighbor-array file (see bench.py --graph-cache)")
     ap.add_argument("--scan", type=int, default=0, help="also run the flat SBQ scan (K5) with this many queries (PMC calibration)")
+    ap.add_argument("--order", default="asis", choices=["asis", "cluster", "cluster_xcd"],
+                    help="experiment: order of the queries inside the batch — as generated, sorted by the cluster they were drawn "
+                         "from (scans that run at the same time touch the same part of the graph), or sorted and dealt to the 8 XCDs "
+                         "by cluster (block b runs on XCD b %% 8)")
     args = ap.parse_args()
     import numpy as np
     import torch  # noqa: F401
@@ -57,6 +61,21 @@ def main():
     nq, k = args.nq, args.k
     q = ctx.alloc(nq * args.dim * 4)
     fill_device(ctx, gp, 1 << 40, nq, q)
+    if args.order != "asis":
+        from pgvectorscale_amd.datagen import _hash
+        qh = ctx.download(q, np.empty((nq, args.dim), np.float32))
+        cl = (_hash(gp.seed, np.arange((1 << 40), (1 << 40) + nq, dtype=np.uint64), np.uint64(0)) % np.uint64(gp.n_clusters)).astype(np.int64)
+        order = np.argsort(cl, kind="stable")
+        if args.order == "cluster_xcd":
+            lists = [order[(cl[order] % 8) == x] for x in range(8)]
+            m = max(len(l) for l in lists)
+            dealt = np.full((m, 8), -1, np.int64)
+            for x, l in enumerate(lists):
+                dealt[:len(l), x] = l
+            order = dealt.reshape(-1)
+            order = order[order >= 0]
+        ctx.upload(q, np.ascontiguousarray(qh[order]))
+        print(f"queries ordered: {args.order}", flush=True)
     out = ctx.alloc(nq * k * 4)
     W, R = ix.desc.words, ix.desc.num_neighbors
     ref_ids = None

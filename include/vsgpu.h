@@ -337,6 +337,27 @@ vs_index* vs_broker_index(vs_broker* b);
 int vs_beginscan_on_broker(vs_broker* b, vs_scan** out);
 void vs_broker_destroy(vs_broker* b); /* serves what is queued, then stops the dispatcher */
 
+/* ---- the same across PROCESSES (vs_shm.cpp): PostgreSQL backends are processes, so the request queue is a POSIX shared-memory
+ * segment (`name`, "/..."): one slot per in-flight scan (query vector, keys, GUCs, the k result rows, a futex).  The process that
+ * owns the vs_ctx / vs_index creates the segment and runs the dispatcher (groups posted scans exactly like vs_broker); a client
+ * needs no HIP: it maps the segment, posts a scan with vs_shm_client_search() and sleeps until its rows are in the slot.  In a
+ * PGRX deployment the segment is a DSM segment, the futex a latch, the dispatcher a background worker. */
+typedef struct vs_shm_server vs_shm_server;
+typedef struct vs_shm_client vs_shm_client;
+int vs_shm_server_create(vs_index* idx, const char* name, uint32_t nslots /* scans in flight at most (max_connections) */,
+                         uint32_t kmax /* rows per scan at most */, const vs_broker_config* cfg /* NULL = defaults */,
+                         vs_shm_server** out);
+int vs_shm_server_get_stats(vs_shm_server* s, vs_broker_stats* out);
+void vs_shm_server_destroy(vs_shm_server* s); /* fails what is still posted, unlinks the segment */
+int vs_shm_client_open(const char* name, vs_shm_client** out);
+uint32_t vs_shm_client_dim(const vs_shm_client* c); /* dim_full of the index behind the segment */
+/* one scan: the rows of its first k amgettuple calls (as vs_search_batch).  query == NULL: the SQL-NULL query (label keys
+ * ignored).  Blocks; one call at a time per client handle.  out_tids / out_dist may be NULL. */
+int vs_shm_client_search(vs_shm_client* c, const float* query, const int16_t* labels, uint32_t n_labels, int has_label_key,
+                         uint32_t search_list_size, uint32_t rescore, uint32_t k, uint32_t* out_ids, uint64_t* out_tids,
+                         float* out_dist);
+void vs_shm_client_close(vs_shm_client* c);
+
 /* ---- build-side helpers (SURVEY.md §8f "next" rows; needed to manufacture device-resident indexes) ---------- */
 /* Welford pass over rows [0,n) in heap order, bit-exact to SbqQuantizer::add_sample (AM/sbq/quantize.rs:115-148):
  * one lane per dimension, sequential over rows.  Uses the (cosine-normalised) first dim_index dims of the vectors. */

@@ -5,4 +5,4 @@ the thin host-side mirror of the reference's scan interface (index.py) plus the 
 tests and bench (datagen.py).
 """
 from ._lib import VS_COSINE, VS_INVALID_NODE, VS_IP, VS_L2, VsError, load  # noqa: F401
-from .index import Broker, Context, DiskAnnIndex, IndexScan  # noqa: F401
+from .index import Broker, Context, DiskAnnIndex, IndexScan, ShmClient, ShmServer  # noqa: F401

@@ -140,6 +140,13 @@ SYMBOLS = {
     "vs_broker_destroy": (None, [_vp]),
     "vs_broker_index": (_vp, [_vp]),
     "vs_beginscan_on_broker": (_i, [_vp, C.POINTER(_vp)]),
+    "vs_shm_server_create": (_i, [_vp, C.c_char_p, _u32, _u32, C.POINTER(BrokerConfig), C.POINTER(_vp)]),
+    "vs_shm_server_get_stats": (_i, [_vp, C.POINTER(BrokerStats)]),
+    "vs_shm_server_destroy": (None, [_vp]),
+    "vs_shm_client_open": (_i, [C.c_char_p, C.POINTER(_vp)]),
+    "vs_shm_client_dim": (_u32, [_vp]),
+    "vs_shm_client_search": (_i, [_vp, _vp, _vp, _u32, _i, _u32, _u32, _u32, _vp, _vp, _vp]),
+    "vs_shm_client_close": (None, [_vp]),
     "vs_sbq_train": (_i, [_vp]),
     "vs_sbq_quantize_corpus": (_i, [_vp]),
     "vs_build_graph": (_i, [_vp, _u32, C.c_double, _u32, _u64]),

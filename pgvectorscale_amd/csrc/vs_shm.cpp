@@ -1,0 +1,421 @@
+// vs_shm.cpp — the cross-process half of the broker: PostgreSQL serves every connection from its own
+// single-threaded backend PROCESS (amcanparallel = false, AM/mod.rs:63; one TSVScanState per IndexScanDesc,
+// AM/scan.rs:308-333), so the scans that must share a launch arrive from different address spaces.  This file is the
+// transport: a POSIX shared-memory segment with one slot per in-flight scan, a dispatcher (in the one process that owns the
+// vs_ctx / vs_index) that gathers posted slots and runs every group sharing (search_list_size, rescore, k, label key present)
+// as one vs_search_batch(), and a client side that needs no HIP at all — a backend maps the segment, posts its query, sleeps on
+// a futex in its slot and wakes with the rows of its first k amgettuple calls.  In a PGRX deployment the segment is a DSM
+// segment, the futex a latch and the dispatcher a background worker; slots, states, grouping and batching are what is built
+// and tested here (tests/test_gpu_zu_shm.py: client PROCESSES against one dispatcher).
+//
+// Slot life cycle (state word, all transitions by compare-and-swap or release stores):
+//   FREE -> CLAIMED (client fills the request) -> READY (posted) -> RUNNING (dispatcher took it) -> DONE (results in the slot)
+//   -> FREE (client copied them out).  A slot whose owner process died is reclaimed by the dispatcher.
+#include <atomic>
+#include <cerrno>
+#include <chrono>
+#include <climits>
+#include <csignal>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include <fcntl.h>
+#include <linux/futex.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+
+#include "../../include/vsgpu.h"
+
+void vs_set_error(const char* fmt, ...);
+
+namespace {
+
+constexpr uint32_t SHM_MAGIC = 0x56534851u;  // "VSHQ"
+constexpr uint32_t SHM_VERSION = 1;
+constexpr uint32_t SHM_MAX_LABELS = 64;
+enum : uint32_t { S_FREE = 0, S_CLAIMED = 1, S_READY = 2, S_RUNNING = 3, S_DONE = 4 };
+
+struct ShmHeader {
+    uint32_t magic, version;
+    uint32_t nslots, dim_full, kmax;
+    uint32_t slot_bytes;
+    std::atomic<uint32_t> serving;   // 1 while a dispatcher is attached
+    std::atomic<uint32_t> work_seq;  // bumped (and futex-woken) by every post
+    int32_t server_pid;
+    uint32_t pad[7];
+};
+
+struct SlotHead {
+    std::atomic<uint32_t> state;
+    int32_t owner_pid;
+    uint32_t L, rescore, k, n_labels, has_label_key, null_query;
+    int32_t rc;
+    char err[172];
+    int16_t labels[SHM_MAX_LABELS];
+    // followed by: float query[dim_full]; uint64_t out_tids[kmax]; uint32_t out_ids[kmax]; float out_dist[kmax]
+};
+
+inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+size_t slot_size(uint32_t dim_full, uint32_t kmax) {
+    return align16(sizeof(SlotHead) + (size_t)dim_full * 4 + (size_t)kmax * 16);
+}
+
+struct Mapping {
+    void* base = nullptr;
+    size_t bytes = 0;
+    ShmHeader* hdr() const { return static_cast<ShmHeader*>(base); }
+    SlotHead* slot(uint32_t i) const {
+        return reinterpret_cast<SlotHead*>(static_cast<char*>(base) + align16(sizeof(ShmHeader)) + (size_t)i * hdr()->slot_bytes);
+    }
+    static float* query(SlotHead* s) { return reinterpret_cast<float*>(reinterpret_cast<char*>(s) + sizeof(SlotHead)); }
+    uint64_t* tids(SlotHead* s) const { return reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(query(s)) + align16((size_t)hdr()->dim_full * 4)); }
+    uint32_t* ids(SlotHead* s) const { return reinterpret_cast<uint32_t*>(tids(s) + hdr()->kmax); }
+    float* dist(SlotHead* s) const { return reinterpret_cast<float*>(ids(s) + hdr()->kmax); }
+};
+
+int futex_wait(std::atomic<uint32_t>* addr, uint32_t expected, int timeout_us) {
+    timespec ts{timeout_us / 1000000, (timeout_us % 1000000) * 1000L};
+    return (int)syscall(SYS_futex, reinterpret_cast<uint32_t*>(addr), FUTEX_WAIT, expected, timeout_us >= 0 ? &ts : nullptr, nullptr, 0);
+}
+void futex_wake(std::atomic<uint32_t>* addr, int n) { syscall(SYS_futex, reinterpret_cast<uint32_t*>(addr), FUTEX_WAKE, n, nullptr, nullptr, 0); }
+
+}  // namespace
+
+struct vs_shm_server {
+    vs_index* ix = nullptr;
+    vs_index_desc d{};
+    vs_broker_config cfg{};
+    std::string name;
+    Mapping m;
+    std::atomic<bool> stop{false};
+    std::thread dispatcher;
+    std::atomic<uint64_t> batches{0}, scans{0}, max_batch{0};
+    void run();
+    void run_group(const std::vector<uint32_t>& grp);
+};
+
+struct vs_shm_client {
+    Mapping m;
+};
+
+void vs_shm_server::run_group(const std::vector<uint32_t>& grp) {
+    const uint32_t nq = (uint32_t)grp.size();
+    SlotHead* head = m.slot(grp[0]);
+    const uint32_t k = head->k;
+    const bool keys = head->has_label_key != 0;
+    int rc = VS_OK;
+    std::string err;
+    std::vector<float> q;
+    std::vector<int16_t> lab;
+    std::vector<uint32_t> off, ids;
+    std::vector<uint64_t> tids;
+    std::vector<float> dist;
+    try {
+        q.assign((size_t)nq * d.dim_full, 0.0f);  // a NULL query is the zero vector (AM/labels/mod.rs:214-216)
+        off.assign(nq + 1, 0);
+        for (uint32_t i = 0; i < nq; ++i) {
+            SlotHead* s = m.slot(grp[i]);
+            if (!s->null_query) memcpy(&q[(size_t)i * d.dim_full], Mapping::query(s), (size_t)d.dim_full * 4);
+            if (keys && !s->null_query) lab.insert(lab.end(), s->labels, s->labels + std::min(s->n_labels, SHM_MAX_LABELS));
+            off[i + 1] = (uint32_t)lab.size();
+        }
+        ids.assign((size_t)nq * k, 0);
+        tids.assign((size_t)nq * k, 0);
+        dist.assign((size_t)nq * k, 0.0f);
+        vs_stats st{};
+        rc = vs_search_batch(ix, q.data(), keys ? lab.data() : nullptr, keys ? off.data() : nullptr, nq, head->L, head->rescore, k,
+                             ids.data(), tids.data(), dist.data(), &st);
+        if (rc != VS_OK) err = vs_last_error();
+    } catch (const std::bad_alloc&) {
+        rc = VS_ERR_OOM;
+        err = "vs_shm: out of host memory while assembling a batch";
+    }
+    batches++;
+    scans += nq;
+    if (nq > max_batch.load()) max_batch = nq;
+    for (uint32_t i = 0; i < nq; ++i) {
+        SlotHead* s = m.slot(grp[i]);
+        if (rc == VS_OK) {
+            memcpy(m.ids(s), &ids[(size_t)i * k], (size_t)k * 4);
+            memcpy(m.tids(s), &tids[(size_t)i * k], (size_t)k * 8);
+            memcpy(m.dist(s), &dist[(size_t)i * k], (size_t)k * 4);
+        }
+        s->rc = rc;
+        snprintf(s->err, sizeof(s->err), "%s", err.c_str());
+        s->state.store(S_DONE, std::memory_order_release);
+        futex_wake(&s->state, 1);
+    }
+}
+
+void vs_shm_server::run() {
+    ShmHeader* h = m.hdr();
+    std::vector<uint32_t> ready;
+    auto last_reap = std::chrono::steady_clock::now();
+    while (!stop.load()) {
+        const uint32_t seq = h->work_seq.load(std::memory_order_acquire);
+        ready.clear();
+        for (uint32_t i = 0; i < h->nslots; ++i)
+            if (m.slot(i)->state.load(std::memory_order_acquire) == S_READY) ready.push_back(i);
+        if (ready.empty()) {
+            futex_wait(&h->work_seq, seq, 50000);  // (50 ms: also the cadence of the dead-owner check below)
+        } else {
+            // gather: give the others max_wait_us to post, then take what is there (at most max_batch per group)
+            if (cfg.max_wait_us && ready.size() < cfg.max_batch) {
+                futex_wait(&h->work_seq, seq, (int)cfg.max_wait_us);
+                ready.clear();
+                for (uint32_t i = 0; i < h->nslots; ++i)
+                    if (m.slot(i)->state.load(std::memory_order_acquire) == S_READY) ready.push_back(i);
+            }
+            std::vector<bool> taken(ready.size(), false);
+            for (size_t a = 0; a < ready.size(); ++a) {
+                if (taken[a]) continue;
+                SlotHead* ha = m.slot(ready[a]);
+                std::vector<uint32_t> grp;
+                for (size_t b = a; b < ready.size() && grp.size() < cfg.max_batch; ++b) {
+                    SlotHead* hb = m.slot(ready[b]);
+                    if (!taken[b] && hb->L == ha->L && hb->rescore == ha->rescore && hb->k == ha->k && hb->has_label_key == ha->has_label_key) {
+                        taken[b] = true;
+                        hb->state.store(S_RUNNING, std::memory_order_relaxed);
+                        grp.push_back(ready[b]);
+                    }
+                }
+                run_group(grp);
+            }
+        }
+        // a backend that died between CLAIMED and FREE would hold its slot forever
+        const auto now = std::chrono::steady_clock::now();
+        if (now - last_reap > std::chrono::milliseconds(200)) {
+            last_reap = now;
+            for (uint32_t i = 0; i < h->nslots; ++i) {
+                SlotHead* s = m.slot(i);
+                const uint32_t st = s->state.load(std::memory_order_acquire);
+                if ((st == S_CLAIMED || st == S_DONE) && s->owner_pid > 0 && kill(s->owner_pid, 0) != 0 && errno == ESRCH)
+                    s->state.store(S_FREE, std::memory_order_release);
+            }
+        }
+    }
+    // shutting down: fail what is still posted so that no client sleeps forever
+    for (uint32_t i = 0; i < h->nslots; ++i) {
+        SlotHead* s = m.slot(i);
+        uint32_t exp = S_READY;
+        if (s->state.compare_exchange_strong(exp, S_RUNNING)) {
+            s->rc = VS_ERR_STATE;
+            snprintf(s->err, sizeof(s->err), "vs_shm: the dispatcher is shutting down");
+            s->state.store(S_DONE, std::memory_order_release);
+            futex_wake(&s->state, 1);
+        }
+    }
+}
+
+extern "C" {
+
+int vs_shm_server_create(vs_index* idx, const char* name, uint32_t nslots, uint32_t kmax, const vs_broker_config* cfg,
+                         vs_shm_server** out) {
+    if (!idx || !name || !out || nslots == 0 || kmax == 0 || name[0] != '/') {
+        vs_set_error("vs_shm_server_create: bad arguments (the name must start with '/')");
+        return VS_ERR_INVALID;
+    }
+    *out = nullptr;
+    vs_shm_server* s = new (std::nothrow) vs_shm_server();
+    if (!s) {
+        vs_set_error("vs_shm_server_create: out of memory");
+        return VS_ERR_OOM;
+    }
+    s->ix = idx;
+    s->name = name;
+    int rc = vs_index_get_desc(idx, &s->d);
+    if (rc != VS_OK) {
+        delete s;
+        return rc;
+    }
+    s->cfg.max_batch = cfg && cfg->max_batch ? cfg->max_batch : 8192;
+    s->cfg.max_wait_us = cfg ? cfg->max_wait_us : 200;
+    const size_t sb = slot_size(s->d.dim_full, kmax);
+    const size_t bytes = align16(sizeof(ShmHeader)) + sb * nslots;
+    shm_unlink(name);
+    const int fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+    if (fd < 0 || ftruncate(fd, (off_t)bytes) != 0) {
+        vs_set_error("vs_shm_server_create: shm_open/ftruncate(%s, %zu): %s", name, bytes, strerror(errno));
+        if (fd >= 0) close(fd);
+        delete s;
+        return VS_ERR_OOM;
+    }
+    void* p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) {
+        vs_set_error("vs_shm_server_create: mmap: %s", strerror(errno));
+        shm_unlink(name);
+        delete s;
+        return VS_ERR_OOM;
+    }
+    memset(p, 0, bytes);
+    s->m.base = p;
+    s->m.bytes = bytes;
+    ShmHeader* h = s->m.hdr();
+    h->version = SHM_VERSION;
+    h->nslots = nslots;
+    h->dim_full = s->d.dim_full;
+    h->kmax = kmax;
+    h->slot_bytes = (uint32_t)sb;
+    h->server_pid = (int32_t)getpid();
+    h->serving.store(1);
+    std::atomic_thread_fence(std::memory_order_release);
+    h->magic = SHM_MAGIC;  // last: a client that sees the magic sees a complete header
+    s->dispatcher = std::thread([s] { s->run(); });
+    *out = s;
+    return VS_OK;
+}
+
+int vs_shm_server_get_stats(vs_shm_server* s, vs_broker_stats* out) {
+    if (!s || !out) {
+        vs_set_error("vs_shm_server_get_stats: null argument");
+        return VS_ERR_INVALID;
+    }
+    out->batches = s->batches.load();
+    out->scans = s->scans.load();
+    out->max_batch = s->max_batch.load();
+    return VS_OK;
+}
+
+void vs_shm_server_destroy(vs_shm_server* s) {
+    if (!s) return;
+    s->m.hdr()->serving.store(0);
+    s->stop.store(true);
+    s->m.hdr()->work_seq.fetch_add(1);
+    futex_wake(&s->m.hdr()->work_seq, INT_MAX);
+    if (s->dispatcher.joinable()) s->dispatcher.join();
+    munmap(s->m.base, s->m.bytes);
+    shm_unlink(s->name.c_str());
+    delete s;
+}
+
+int vs_shm_client_open(const char* name, vs_shm_client** out) {
+    if (!name || !out) {
+        vs_set_error("vs_shm_client_open: null argument");
+        return VS_ERR_INVALID;
+    }
+    *out = nullptr;
+    const int fd = shm_open(name, O_RDWR, 0600);
+    if (fd < 0) {
+        vs_set_error("vs_shm_client_open: shm_open(%s): %s", name, strerror(errno));
+        return VS_ERR_STATE;
+    }
+    struct stat sb;
+    if (fstat(fd, &sb) != 0 || (size_t)sb.st_size < sizeof(ShmHeader)) {
+        vs_set_error("vs_shm_client_open: %s is not a request segment", name);
+        close(fd);
+        return VS_ERR_INVALID;
+    }
+    void* p = mmap(nullptr, (size_t)sb.st_size, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) {
+        vs_set_error("vs_shm_client_open: mmap: %s", strerror(errno));
+        return VS_ERR_OOM;
+    }
+    const ShmHeader* h = static_cast<const ShmHeader*>(p);
+    if (h->magic != SHM_MAGIC || h->version != SHM_VERSION ||
+        align16(sizeof(ShmHeader)) + (size_t)h->slot_bytes * h->nslots > (size_t)sb.st_size || h->slot_bytes != slot_size(h->dim_full, h->kmax)) {
+        vs_set_error("vs_shm_client_open: %s has no valid header (magic %08x, version %u)", name, h->magic, h->version);
+        munmap(p, (size_t)sb.st_size);
+        return VS_ERR_INVALID;
+    }
+    vs_shm_client* c = new (std::nothrow) vs_shm_client();
+    if (!c) {
+        munmap(p, (size_t)sb.st_size);
+        vs_set_error("vs_shm_client_open: out of memory");
+        return VS_ERR_OOM;
+    }
+    c->m.base = p;
+    c->m.bytes = (size_t)sb.st_size;
+    *out = c;
+    return VS_OK;
+}
+
+uint32_t vs_shm_client_dim(const vs_shm_client* c) { return c ? c->m.hdr()->dim_full : 0; }
+
+int vs_shm_client_search(vs_shm_client* c, const float* query, const int16_t* labels, uint32_t n_labels, int has_label_key,
+                         uint32_t search_list_size, uint32_t rescore, uint32_t k, uint32_t* out_ids, uint64_t* out_tids,
+                         float* out_dist) {
+    if (!c || !out_ids || k == 0) {
+        vs_set_error("vs_shm_client_search: bad arguments");
+        return VS_ERR_INVALID;
+    }
+    ShmHeader* h = c->m.hdr();
+    if (k > h->kmax) {
+        vs_set_error("vs_shm_client_search: k = %u exceeds the segment's %u rows per scan", k, h->kmax);
+        return VS_ERR_INVALID;
+    }
+    if (has_label_key && query && n_labels > SHM_MAX_LABELS) {
+        vs_set_error("vs_shm_client_search: more than %u labels in one scan key", SHM_MAX_LABELS);
+        return VS_ERR_INVALID;
+    }
+    // claim a slot (every backend holds at most one; the segment is sized for max_connections)
+    SlotHead* s = nullptr;
+    const uint32_t start = (uint32_t)getpid() % h->nslots;
+    for (int spin = 0; !s; ++spin) {
+        if (!h->serving.load(std::memory_order_acquire)) {
+            vs_set_error("vs_shm_client_search: no dispatcher is attached to the segment");
+            return VS_ERR_STATE;
+        }
+        for (uint32_t i = 0; i < h->nslots && !s; ++i) {
+            SlotHead* cand = c->m.slot((start + i) % h->nslots);
+            uint32_t exp = S_FREE;
+            if (cand->state.compare_exchange_strong(exp, S_CLAIMED, std::memory_order_acq_rel)) s = cand;
+        }
+        if (!s) usleep(spin < 10 ? 50 : 1000);  // every slot busy: more scans in flight than slots
+    }
+    s->owner_pid = (int32_t)getpid();
+    s->L = search_list_size;
+    s->rescore = rescore;
+    s->k = k;
+    s->null_query = query ? 0u : 1u;
+    // a NULL query ignores its keys (amrescan: LabeledVector::from_scan_key_data with a NULL vector)
+    s->has_label_key = (has_label_key && query) ? 1u : 0u;
+    s->n_labels = s->has_label_key ? n_labels : 0u;
+    if (s->n_labels) memcpy(s->labels, labels, (size_t)s->n_labels * 2);
+    if (query) memcpy(Mapping::query(s), query, (size_t)h->dim_full * 4);
+    s->rc = VS_OK;
+    s->state.store(S_READY, std::memory_order_release);
+    h->work_seq.fetch_add(1, std::memory_order_acq_rel);
+    futex_wake(&h->work_seq, 1);
+    for (;;) {
+        const uint32_t st = s->state.load(std::memory_order_acquire);
+        if (st == S_DONE) break;
+        if (!h->serving.load(std::memory_order_acquire) && st == S_READY) {  // the dispatcher went away before taking it
+            uint32_t exp = S_READY;
+            if (s->state.compare_exchange_strong(exp, S_FREE)) {
+                vs_set_error("vs_shm_client_search: the dispatcher went away");
+                return VS_ERR_STATE;
+            }
+            continue;
+        }
+        futex_wait(&s->state, st, 100000);
+    }
+    const int rc = s->rc;
+    if (rc == VS_OK) {
+        memcpy(out_ids, c->m.ids(s), (size_t)k * 4);
+        if (out_tids) memcpy(out_tids, c->m.tids(s), (size_t)k * 8);
+        if (out_dist) memcpy(out_dist, c->m.dist(s), (size_t)k * 4);
+    } else {
+        vs_set_error("%s", s->err);
+    }
+    s->owner_pid = 0;
+    s->state.store(S_FREE, std::memory_order_release);
+    return rc;
+}
+
+void vs_shm_client_close(vs_shm_client* c) {
+    if (!c) return;
+    munmap(c->m.base, c->m.bytes);
+    delete c;
+}
+
+}  // extern "C"

@@ -420,6 +420,55 @@ class Broker:
             self.h = None
 
 
+class ShmServer:
+    """The dispatcher side of the cross-process request queue (vs_shm_server_*): lives in the one process that owns the device
+    context; client processes post scans into the POSIX shared-memory segment `name` and get the rows of vs_search_batch."""
+
+    def __init__(self, index, name, nslots=256, kmax=64, max_batch=0, max_wait_us=200):
+        self.index = index
+        self._L = index._L
+        cfg = _lib.BrokerConfig(max_batch, max_wait_us)
+        h = C.c_void_p()
+        check(self._L.vs_shm_server_create(index.h, name.encode(), nslots, kmax, C.byref(cfg), C.byref(h)))
+        self.h = h
+
+    def stats(self):
+        st = _lib.BrokerStats()
+        check(self._L.vs_shm_server_get_stats(self.h, C.byref(st)))
+        return {"batches": int(st.batches), "scans": int(st.scans), "max_batch": int(st.max_batch)}
+
+    def close(self):
+        if self.h:
+            self._L.vs_shm_server_destroy(self.h)
+            self.h = None
+
+
+class ShmClient:
+    """A backend's end of the queue (vs_shm_client_*): needs no GPU and no device context, only the segment's name."""
+
+    def __init__(self, name):
+        self._L = _lib.load()
+        h = C.c_void_p()
+        check(self._L.vs_shm_client_open(name.encode(), C.byref(h)))
+        self.h = h
+        self.dim = int(self._L.vs_shm_client_dim(h))
+
+    def search(self, query, labels=None, search_list_size=DEFAULT_QUERY_SEARCH_LIST_SIZE, rescore=DEFAULT_QUERY_RESCORE, k=10):
+        q = None if query is None else np.ascontiguousarray(query, np.float32).reshape(self.dim)
+        lab = None if labels is None else np.ascontiguousarray(labels, np.int16)
+        ids = np.empty(k, np.uint32)
+        tids = np.empty(k, np.uint64)
+        dist = np.empty(k, np.float32)
+        check(self._L.vs_shm_client_search(self.h, _p(q), _p(lab), 0 if lab is None else lab.size, int(labels is not None),
+                                           search_list_size, rescore, k, _p(ids), _p(tids), _p(dist)))
+        return ids, tids, dist
+
+    def close(self):
+        if self.h:
+            self._L.vs_shm_client_close(self.h)
+            self.h = None
+
+
 class IndexScan:
     """IndexScanDesc + TSVScanState: rescan() = amrescan, gettuple() = amgettuple, endscan() = amendscan."""
 

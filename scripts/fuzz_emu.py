@@ -33,6 +33,8 @@ REGIMES = [
     {"VS_F_LH": "256", "VS_F_POOL": "0.01"},
     {"VS_FAST": "0"},
     {"VS_FAST": "0", "VS_HL": "64", "VS_G0": "256"},
+    {"VS_F_LDS_MAX_INS": "0", "VS_F_GCAP": "512"},                      # tiny global dedup table: second attempt of k_search_fast
+    {"VS_F_LDS_MAX_INS": "0", "VS_F_GCAP": "512", "VS_F_RETRY": "0"},   # ... or straight to the general kernel
 ]
 TUNING = sorted({k for r in REGIMES for k in r})
 

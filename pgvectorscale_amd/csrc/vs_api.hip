@@ -714,6 +714,9 @@ static Caps initial_caps(const vs_index* ix, uint32_t L, uint32_t M) {
         const double want = 0.75 * ix->obs.ins_mean;
         hl_auto = want > 2047 ? 4095 : (want > 1023 ? 2047 : 1023);
     }
+    // table-less regime: 80 VGPRs (6 waves per SIMD = 24 scans per CU) need 6.6 KB of LDS per scan at most: a 511-entry heap
+    // top (measured: 105.2 vs 108.1 ms at 50M against 5 waves with 1023 entries)
+    if (!lds_table) hl_auto = 511;
     c.f_hl = env_u32("VS_F_HL", hl_auto);
     const uint32_t want_v = (uint32_t)std::min<uint64_t>((uint64_t)L + L / 2 + 32, 1u << 20);
     // visited list: register resident (8 VGPR pairs) while LDS is the limiter; in the table-less regime registers are,
@@ -910,7 +913,7 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
         f.pool_counter = (uint32_t*)w.pool_ctr.p;
         f.pool_slots = fslots;
         f.lh = caps.f_lh;
-        f.minw = env_u32("VS_F_MINW", (caps.f_lh == 0 && caps.f_vr) ? 4 : 1);
+        f.minw = env_u32("VS_F_MINW", caps.f_lh == 0 ? (caps.f_vr ? 4 : 6) : 1);
         f.flags = env_u32("VS_F_FLAGS", 0);
         f.visible = (!bp.stream_only && bp.rescore > 0) ? ix->visible : nullptr;  // the heap is only fetched for the rescore window
         f.sb = caps.f_sb;

@@ -329,7 +329,12 @@ struct FastHeap {
 
 // ---------------------------------------------------------------------------------------------------------------
 // visited: Vec<ListSearchNeighbor> kept sorted (AM/graph/mod.rs:76,167-168,181).  VR > 0: in registers, entry i is
-// lane i % 64 of (h[i / 64], n[i / 64]).  VR == 0: ring buffer of (hamming << 32 | node) in LDS.
+// lane i % 64 of (h[i / 64], n[i / 64]).  VR == 0: ring buffer of (flags << 62 | hamming << 32 | node) in LDS; the two flag
+// bits (VIS_DEAD: heap tid deleted, VIS_HIDDEN: heap tuple invisible to the snapshot) are what consume() needs to know about
+// the node: they are looked up when the node is VISITED, so a run of consume() calls never waits for memory.
+#define VIS_DEAD 2u
+#define VIS_HIDDEN 1u
+#define VIS_HAM_MASK 0x3FFFFFFFu
 // ---------------------------------------------------------------------------------------------------------------
 template <int VR>
 struct Visited {
@@ -364,10 +369,10 @@ struct Visited {
                 if ((i >> 6) == (uint32_t)r) v = readlane_u32(h[r], i & 63u);
             return v;
         }
-        return rfl((uint32_t)(ring[slot(i)] >> 32));
+        return rfl((uint32_t)(ring[slot(i)] >> 32) & VIS_HAM_MASK);
     }
     // visited.insert(partition_point(|x| *x < new), new): before the first element >= new  (caller checked capacity)
-    __device__ __forceinline__ void insert(uint32_t hd, uint32_t node) {
+    __device__ __forceinline__ void insert(uint32_t hd, uint32_t node, uint32_t flags = 0) {
         if (VR > 0) {
             uint32_t idx = 0;
 #pragma unroll
@@ -394,7 +399,7 @@ struct Visited {
         uint32_t idx = 0;
         for (uint32_t base = 0; base < len; base += WAVE) {
             const uint32_t i = base + lane;
-            const bool lt = i < len && (uint32_t)(ring[slot(i)] >> 32) < hd;
+            const bool lt = i < len && ((uint32_t)(ring[slot(i)] >> 32) & VIS_HAM_MASK) < hd;
             idx += (uint32_t)__popcll(__ballot(lt));
         }
         if (2 * idx < len) {  // move [0, idx) one slot towards the front, lowest chunk first
@@ -420,12 +425,13 @@ struct Visited {
                 hi = lo;
             }
         }
-        if (lane == 0) ring[slot(idx)] = ((uint64_t)hd << 32) | node;
+        if (lane == 0) ring[slot(idx)] = ((uint64_t)(hd | (flags << 30)) << 32) | node;
         len++;
         wave_sync();
     }
     // visited.remove(0) (len > 0)
-    __device__ __forceinline__ void pop_front(uint32_t& hd, uint32_t& node) {
+    __device__ __forceinline__ void pop_front(uint32_t& hd, uint32_t& node, uint32_t& flags) {
+        flags = 0;
         if (VR > 0) {
             hd = readlane_u32(h[0], 0);
             node = readlane_u32(n[0], 0);
@@ -443,6 +449,8 @@ struct Visited {
         }
         const uint64_t front = ring[head];
         hd = rfl((uint32_t)(front >> 32));
+        flags = hd >> 30;
+        hd &= VIS_HAM_MASK;
         node = rfl((uint32_t)front);
         head = head + 1 == vcapv ? 0 : head + 1;
         len--;
@@ -740,8 +748,8 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
     uint64_t ft_val = 0;
     uint32_t ft_vis = 1, st_invis = 0;
     while (status == 0) {
-        if (vis.len > 0) {
-            const uint32_t fn = VR > 0 ? readlane_u32(vis.n[0], 0) : rfl((uint32_t)vis.ring[vis.head]);
+        if (VR > 0 && vis.len > 0) {  // (the ring carries what consume() needs in its entries)
+            const uint32_t fn = readlane_u32(vis.n[0], 0);
             if (fn != ft_node) {
                 ft_node = fn;
                 ft_val = a.tids[fn];
@@ -759,17 +767,18 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
             if (BUILD) break;  // greedy_search_for_build stops here: the visited list is the candidate set
             // ---- consume (AM/graph/mod.rs:174-184) + return_lsn (AM/sbq/storage.rs:404-414) ----
             if (vis.len == 0) break;  // None: the stream has ended
-            uint32_t fd, fnode;
-            vis.pop_front(fd, fnode);
+            uint32_t fd, fnode, fflags;
+            vis.pop_front(fd, fnode, fflags);
             st_reads++;
-            const uint64_t tid = fnode == ft_node ? ft_val : a.tids[fnode];
-            if ((tid & 0xFFFFull) == 0) continue;  // InvalidOffsetNumber: deleted tuple (AM/scan.rs:231-234)
-            if (s.visible) {  // get_full_distance_for_resort -> None: fetched, counted, never enters the window (AM/scan.rs:268-272)
-                const uint32_t v = fnode == ft_node ? ft_vis : (uint32_t)s.visible[fnode];
-                if (rfl(v) == 0) {
-                    st_invis++;
-                    continue;
-                }
+            if (VR > 0) {
+                const uint64_t tid = fnode == ft_node ? ft_val : a.tids[fnode];
+                fflags = (tid & 0xFFFFull) == 0 ? VIS_DEAD : 0u;
+                if (s.visible) fflags |= rfl(fnode == ft_node ? ft_vis : (uint32_t)s.visible[fnode]) == 0 ? VIS_HIDDEN : 0u;
+            }
+            if (fflags & VIS_DEAD) continue;  // InvalidOffsetNumber: deleted tuple (AM/scan.rs:231-234)
+            if (s.visible && (fflags & VIS_HIDDEN)) {  // get_full_distance_for_resort -> None: fetched, counted, never enters
+                st_invis++;                              // the window (AM/scan.rs:268-272)
+                continue;
             }
             if (lane == 0) {
                 s.out_ids[(size_t)q * s.M + emitted] = fnode;
@@ -786,6 +795,13 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
         const uint32_t node_v = node_load(top & smask);
         heap.pop();
         const uint32_t node = rfl(node_v);
+        // what consume() will need to know about this node: requested now, folded into the ring entry at the insert below
+        uint64_t vtid = 1;
+        uint32_t vvis = 1;
+        if (VR == 0 && !BUILD) {
+            vtid = a.tids[node];
+            if (s.visible) vvis = s.visible[node];
+        }
         const uint32_t* nrow = a.nbrs + (size_t)node * a.nbr_stride;
         uint32_t row0;
         if (node == pfa_node) {
@@ -834,7 +850,7 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
             // ... visited.insert(partition_point(|x| *x < head), head) runs in registers meanwhile ...
             if (!vis_done) {
                 vis_done = true;
-                vis.insert(hd, node);
+                vis.insert(hd, node, ((vtid & 0xFFFFull) == 0 ? VIS_DEAD : 0u) | (vvis == 0 ? VIS_HIDDEN : 0u));
                 lap(2);
             }
             // ... then the probe sequence is finished
@@ -926,7 +942,7 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
             lap(5);
         }
         if (status) break;
-        if (!vis_done) vis.insert(hd, node);  // (an empty neighbor list)
+        if (!vis_done) vis.insert(hd, node, ((vtid & 0xFFFFull) == 0 ? VIS_DEAD : 0u) | (vvis == 0 ? VIS_HIDDEN : 0u));  // (an empty neighbor list)
         if (!pfa_issued) {  // nothing new to score: the old root is the next expansion
             pfa_node = VS_INVALID_NODE;
             if (root_after != 0xFFFFFFFFu) {
@@ -941,7 +957,7 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
         for (uint32_t i = lane; i < emitted; i += WAVE) {
             const uint64_t e = vis.ring[vis.slot(i)];
             s.out_ids[(size_t)q * s.M + i] = (uint32_t)e;
-            s.out_ham[(size_t)q * s.M + i] = (uint32_t)(e >> 32);
+            s.out_ham[(size_t)q * s.M + i] = (uint32_t)(e >> 32) & VIS_HAM_MASK;
         }
     }
     // one `next` call per emitted row, plus the call that found the stream exhausted

@@ -356,7 +356,7 @@ extern "C" int vs_index_get_quantizer(const vs_index* ix, float* mean, float* m2
     return VS_OK;
 }
 
-extern "C" int vs_index_set_start_nodes(vs_index* ix, uint32_t default_start, const int16_t* labels,
+static int vs_index_set_start_nodes_impl(vs_index* ix, uint32_t default_start, const int16_t* labels,
                                         const uint32_t* nodes, uint32_t n) {
     VS_REQUIRE(ix, "vs_index_set_start_nodes: index is NULL");
     VS_REQUIRE(default_start == VS_INVALID_NODE || default_start < ix->d.n, "default_start out of range");
@@ -378,8 +378,13 @@ extern "C" int vs_index_set_start_nodes(vs_index* ix, uint32_t default_start, co
     }
     return VS_OK;
 }
+extern "C" int vs_index_set_start_nodes(vs_index* ix, uint32_t default_start, const int16_t* labels,
+                                        const uint32_t* nodes, uint32_t n) {
+    return vs_guard("vs_index_set_start_nodes", [&] { return vs_index_set_start_nodes_impl(ix, default_start, labels, nodes, n); });
+}
 
-extern "C" int vs_index_set_labels(vs_index* ix, const uint32_t* label_off, const int16_t* label_val) {
+
+static int vs_index_set_labels_impl(vs_index* ix, const uint32_t* label_off, const int16_t* label_val) {
     VS_REQUIRE(ix && label_off, "vs_index_set_labels: bad args");
     const uint32_t n = ix->d.n;
     VS_REQUIRE(label_off[0] == 0, "label_off[0] must be 0");
@@ -398,6 +403,10 @@ extern "C" int vs_index_set_labels(vs_index* ix, const uint32_t* label_off, cons
     ix->d.has_labels = 1;
     return VS_OK;
 }
+extern "C" int vs_index_set_labels(vs_index* ix, const uint32_t* label_off, const int16_t* label_val) {
+    return vs_guard("vs_index_set_labels", [&] { return vs_index_set_labels_impl(ix, label_off, label_val); });
+}
+
 
 extern "C" uint32_t vs_index_build_unreachable(const vs_index* ix) { return ix ? ix->build_unreachable : 0xFFFFFFFFu; }
 
@@ -457,7 +466,7 @@ int vs_upload_rows(vs_ctx* c, void* dst, size_t dev_row_bytes, const void* src, 
 }
 int vs_validate_graph(vs_index* ix) { return validate_graph(ix); }
 
-extern "C" int vs_index_upload(vs_ctx* c, const vs_index_desc* desc, const vs_index_host* h, vs_index** out) {
+static int vs_index_upload_impl(vs_ctx* c, const vs_index_desc* desc, const vs_index_host* h, vs_index** out) {
     VS_REQUIRE(h && out && desc, "vs_index_upload: bad args");
     const bool plain = desc->storage_type == VS_STORAGE_PLAIN;
     VS_REQUIRE(desc->storage_type == VS_STORAGE_SBQ || plain, "vs_index_upload: unknown storage_type %u", desc->storage_type);
@@ -527,6 +536,10 @@ extern "C" int vs_index_upload(vs_ctx* c, const vs_index_desc* desc, const vs_in
     *out = ix;
     return VS_OK;
 }
+extern "C" int vs_index_upload(vs_ctx* c, const vs_index_desc* desc, const vs_index_host* h, vs_index** out) {
+    return vs_guard("vs_index_upload", [&] { return vs_index_upload_impl(c, desc, h, out); });
+}
+
 
 extern "C" int vs_index_get_desc(const vs_index* ix, vs_index_desc* out) {
     VS_REQUIRE(ix && out, "vs_index_get_desc: bad args");
@@ -591,7 +604,7 @@ extern "C" int vs_index_mark_deleted(vs_index* ix, const uint32_t* nodes, uint32
 // ---------------------------------------------------------------------------------------------------------------
 // single-kernel entry points (host pointers in/out)
 // ---------------------------------------------------------------------------------------------------------------
-extern "C" int vs_quantize(vs_index* ix, const float* q, uint32_t nq, uint64_t* out_codes) {
+static int vs_quantize_impl(vs_index* ix, const float* q, uint32_t nq, uint64_t* out_codes) {
     VS_REQUIRE(ix && (nq == 0 || (q && out_codes)), "vs_quantize: bad args");
     if (nq == 0) return VS_OK;
     vs_ctx* c = ix->ctx;
@@ -606,6 +619,10 @@ extern "C" int vs_quantize(vs_index* ix, const float* q, uint32_t nq, uint64_t* 
                        hipMemcpyDeviceToHost));
     return VS_OK;
 }
+extern "C" int vs_quantize(vs_index* ix, const float* q, uint32_t nq, uint64_t* out_codes) {
+    return vs_guard("vs_quantize", [&] { return vs_quantize_impl(ix, q, nq, out_codes); });
+}
+
 
 static int upload_qcodes(vs_index* ix, const uint64_t* qcodes, uint32_t nq) {
     SearchWorkspace& w = ix->ws;
@@ -613,7 +630,7 @@ static int upload_qcodes(vs_index* ix, const uint64_t* qcodes, uint32_t nq) {
     return upload_rows(ix->ctx, w.qcodes.p, ix->code_stride * 8ull, qcodes, ix->d.words * 8ull, ix->d.words * 8ull, nq);
 }
 
-extern "C" int vs_hamming_gather(vs_index* ix, const uint64_t* qcodes, const uint32_t* ids, const uint32_t* off,
+static int vs_hamming_gather_impl(vs_index* ix, const uint64_t* qcodes, const uint32_t* ids, const uint32_t* off,
                                  uint32_t nq, uint32_t* out) {
     VS_REQUIRE(ix && (nq == 0 || (qcodes && off)), "vs_hamming_gather: bad args");
     if (nq == 0) return VS_OK;
@@ -634,8 +651,13 @@ extern "C" int vs_hamming_gather(vs_index* ix, const uint64_t* qcodes, const uin
     VS_TRY(vs_dev_download(c, out, w.stream_ham.p, (size_t)total * 4));
     return VS_OK;
 }
+extern "C" int vs_hamming_gather(vs_index* ix, const uint64_t* qcodes, const uint32_t* ids, const uint32_t* off,
+                                 uint32_t nq, uint32_t* out) {
+    return vs_guard("vs_hamming_gather", [&] { return vs_hamming_gather_impl(ix, qcodes, ids, off, nq, out); });
+}
 
-extern "C" int vs_rerank(vs_index* ix, const float* q_full, const uint32_t* ids, const uint32_t* off, uint32_t nq,
+
+static int vs_rerank_impl(vs_index* ix, const float* q_full, const uint32_t* ids, const uint32_t* off, uint32_t nq,
                          float* out) {
     VS_REQUIRE(ix && (nq == 0 || (q_full && off)), "vs_rerank: bad args");
     if (nq == 0) return VS_OK;
@@ -661,6 +683,11 @@ extern "C" int vs_rerank(vs_index* ix, const float* q_full, const uint32_t* ids,
     VS_TRY(vs_dev_download(c, out, w.rr_dist.p, (size_t)total * 4));
     return VS_OK;
 }
+extern "C" int vs_rerank(vs_index* ix, const float* q_full, const uint32_t* ids, const uint32_t* off, uint32_t nq,
+                         float* out) {
+    return vs_guard("vs_rerank", [&] { return vs_rerank_impl(ix, q_full, ids, off, nq, out); });
+}
+
 
 // ---------------------------------------------------------------------------------------------------------------
 // batched scans
@@ -1199,21 +1226,32 @@ static int search_host(vs_index* ix, const float* queries, const int16_t* qlabel
     return VS_OK;
 }
 
-extern "C" int vs_search_batch(vs_index* ix, const float* queries, const int16_t* qlabels, const uint32_t* qlabel_off,
+static int vs_search_batch_impl(vs_index* ix, const float* queries, const int16_t* qlabels, const uint32_t* qlabel_off,
                                uint32_t nq, uint32_t L, uint32_t rescore, uint32_t k, uint32_t* out_ids,
                                uint64_t* out_tids, float* out_dist, vs_stats* stats) {
     VS_REQUIRE(nq == 0 || out_ids, "vs_search_batch: out_ids is NULL");
     return search_host(ix, queries, qlabels, qlabel_off, nq, L, rescore, k, false, out_ids, out_tids, out_dist, nullptr,
                        stats);
 }
+extern "C" int vs_search_batch(vs_index* ix, const float* queries, const int16_t* qlabels, const uint32_t* qlabel_off,
+                               uint32_t nq, uint32_t L, uint32_t rescore, uint32_t k, uint32_t* out_ids,
+                               uint64_t* out_tids, float* out_dist, vs_stats* stats) {
+    return vs_guard("vs_search_batch", [&] { return vs_search_batch_impl(ix, queries, qlabels, qlabel_off, nq, L, rescore, k, out_ids, out_tids, out_dist, stats); });
+}
 
-extern "C" int vs_stream_batch(vs_index* ix, const float* queries, const int16_t* qlabels, const uint32_t* qlabel_off,
+
+static int vs_stream_batch_impl(vs_index* ix, const float* queries, const int16_t* qlabels, const uint32_t* qlabel_off,
                                uint32_t nq, uint32_t L, uint32_t m, uint32_t* out_ids, uint32_t* out_ham, vs_stats* stats) {
     VS_REQUIRE(nq == 0 || out_ids, "vs_stream_batch: out_ids is NULL");
     return search_host(ix, queries, qlabels, qlabel_off, nq, L, 0, m, true, out_ids, nullptr, nullptr, out_ham, stats);
 }
+extern "C" int vs_stream_batch(vs_index* ix, const float* queries, const int16_t* qlabels, const uint32_t* qlabel_off,
+                               uint32_t nq, uint32_t L, uint32_t m, uint32_t* out_ids, uint32_t* out_ham, vs_stats* stats) {
+    return vs_guard("vs_stream_batch", [&] { return vs_stream_batch_impl(ix, queries, qlabels, qlabel_off, nq, L, m, out_ids, out_ham, stats); });
+}
 
-extern "C" int vs_search_batch_dev(vs_index* ix, const float* d_queries, const int16_t* d_qlabels,
+
+static int vs_search_batch_dev_impl(vs_index* ix, const float* d_queries, const int16_t* d_qlabels,
                                    const uint32_t* d_qlabel_off, uint32_t nq, uint32_t L, uint32_t rescore, uint32_t k,
                                    uint32_t* d_out_ids, uint64_t* d_out_tids, float* d_out_dist) {
     VS_REQUIRE(ix && (nq == 0 || (d_queries && d_out_ids)), "vs_search_batch_dev: bad args");
@@ -1246,8 +1284,14 @@ extern "C" int vs_search_batch_dev(vs_index* ix, const float* d_queries, const i
     ix->last_stats = vs_stats{};
     return VS_OK;
 }
+extern "C" int vs_search_batch_dev(vs_index* ix, const float* d_queries, const int16_t* d_qlabels,
+                                   const uint32_t* d_qlabel_off, uint32_t nq, uint32_t L, uint32_t rescore, uint32_t k,
+                                   uint32_t* d_out_ids, uint64_t* d_out_tids, float* d_out_dist) {
+    return vs_guard("vs_search_batch_dev", [&] { return vs_search_batch_dev_impl(ix, d_queries, d_qlabels, d_qlabel_off, nq, L, rescore, k, d_out_ids, d_out_tids, d_out_dist); });
+}
 
-extern "C" int vs_search_batch_dev_finish(vs_index* ix, vs_stats* stats) {
+
+static int vs_search_batch_dev_finish_impl(vs_index* ix, vs_stats* stats) {
     VS_REQUIRE(ix, "vs_search_batch_dev_finish: index is NULL");
     SearchWorkspace& w = ix->ws;
     if (!w.pending) {
@@ -1277,6 +1321,10 @@ extern "C" int vs_search_batch_dev_finish(vs_index* ix, vs_stats* stats) {
     if (stats) *stats = st;
     return VS_OK;
 }
+extern "C" int vs_search_batch_dev_finish(vs_index* ix, vs_stats* stats) {
+    return vs_guard("vs_search_batch_dev_finish", [&] { return vs_search_batch_dev_finish_impl(ix, stats); });
+}
+
 
 // ---------------------------------------------------------------------------------------------------------------
 // amrescan / amgettuple mirror.  A scan prefetches `rescore + window` rows with one batched launch and hands them
@@ -1346,7 +1394,7 @@ static int scan_fetch(vs_scan* s, uint32_t window) {
     return VS_OK;
 }
 
-extern "C" int vs_rescan(vs_scan* s, const float* query, const int16_t* labels, uint32_t n_labels, int has_label_key,
+static int vs_rescan_impl(vs_scan* s, const float* query, const int16_t* labels, uint32_t n_labels, int has_label_key,
                          uint32_t L, uint32_t rescore) {
     VS_REQUIRE(s, "vs_rescan: scan is NULL");
     VS_REQUIRE(L >= 1 && L <= 10000, "diskann.query_search_list_size %u outside [1,10000]", L);
@@ -1365,8 +1413,13 @@ extern "C" int vs_rescan(vs_scan* s, const float* query, const int16_t* labels, 
     s->active = true;
     return VS_OK;
 }
+extern "C" int vs_rescan(vs_scan* s, const float* query, const int16_t* labels, uint32_t n_labels, int has_label_key,
+                         uint32_t L, uint32_t rescore) {
+    return vs_guard("vs_rescan", [&] { return vs_rescan_impl(s, query, labels, n_labels, has_label_key, L, rescore); });
+}
 
-extern "C" int vs_gettuple(vs_scan* s, uint64_t* heap_tid, uint32_t* node, float* dist) {
+
+static int vs_gettuple_impl(vs_scan* s, uint64_t* heap_tid, uint32_t* node, float* dist) {
     if (!s || !s->active) {
         vs_set_error("vs_gettuple before vs_rescan");
         return VS_ERR_STATE;
@@ -1385,6 +1438,10 @@ extern "C" int vs_gettuple(vs_scan* s, uint64_t* heap_tid, uint32_t* node, float
     s->cursor++;
     return 1;
 }
+extern "C" int vs_gettuple(vs_scan* s, uint64_t* heap_tid, uint32_t* node, float* dist) {
+    return vs_guard("vs_gettuple", [&] { return vs_gettuple_impl(s, heap_tid, node, dist); });
+}
+
 
 extern "C" int vs_scan_xs_recheck(const vs_scan* s) { return (s && s->has_label_key) ? 1 : 0; }  // AM/scan.rs:350-352
 

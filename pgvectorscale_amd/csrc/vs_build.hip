@@ -845,7 +845,7 @@ static int build_graph_impl(vs_index* ix, uint32_t L, double max_alpha_d, uint32
     return VS_OK;
 }
 
-extern "C" int vs_build_graph(vs_index* ix, uint32_t search_list_size, double max_alpha, uint32_t batch_max, uint64_t seed) {
+static int vs_build_graph_impl(vs_index* ix, uint32_t search_list_size, double max_alpha, uint32_t batch_max, uint64_t seed) {
     (void)seed;
     VS_REQUIRE(ix, "vs_build_graph: index is NULL");
     VS_REQUIRE(search_list_size >= 1 && search_list_size <= 1000, "vs_build_graph: search_list_size outside [1,1000]");
@@ -860,3 +860,7 @@ extern "C" int vs_build_graph(vs_index* ix, uint32_t search_list_size, double ma
     if (r == VS_OK) r = vs_validate_graph(ix);
     return r;
 }
+extern "C" int vs_build_graph(vs_index* ix, uint32_t search_list_size, double max_alpha, uint32_t batch_max, uint64_t seed) {
+    return vs_guard("vs_build_graph", [&] { return vs_build_graph_impl(ix, search_list_size, max_alpha, batch_max, seed); });
+}
+

@@ -343,14 +343,23 @@ extern "C" int vs_sbq_quantize_corpus(vs_index* ix) {
 static int scan_topk_host(vs_index* ix, const uint64_t* qcodes, const int16_t* qlabels, const uint32_t* qlabel_off, int live_only,
                           uint32_t nq, uint32_t k, uint32_t* out_ids, uint32_t* out_ham);
 
-extern "C" int vs_scan_topk(vs_index* ix, const uint64_t* qcodes, uint32_t nq, uint32_t k, uint32_t* out_ids, uint32_t* out_ham) {
+static int vs_scan_topk_impl(vs_index* ix, const uint64_t* qcodes, uint32_t nq, uint32_t k, uint32_t* out_ids, uint32_t* out_ham) {
     return scan_topk_host(ix, qcodes, nullptr, nullptr, 0, nq, k, out_ids, out_ham);
 }
+extern "C" int vs_scan_topk(vs_index* ix, const uint64_t* qcodes, uint32_t nq, uint32_t k, uint32_t* out_ids, uint32_t* out_ham) {
+    return vs_guard("vs_scan_topk", [&] { return vs_scan_topk_impl(ix, qcodes, nq, k, out_ids, out_ham); });
+}
 
-extern "C" int vs_scan_topk_filtered(vs_index* ix, const uint64_t* qcodes, const int16_t* qlabels, const uint32_t* qlabel_off,
+
+static int vs_scan_topk_filtered_impl(vs_index* ix, const uint64_t* qcodes, const int16_t* qlabels, const uint32_t* qlabel_off,
                                      int live_only, uint32_t nq, uint32_t k, uint32_t* out_ids, uint32_t* out_ham) {
     return scan_topk_host(ix, qcodes, qlabels, qlabel_off, live_only, nq, k, out_ids, out_ham);
 }
+extern "C" int vs_scan_topk_filtered(vs_index* ix, const uint64_t* qcodes, const int16_t* qlabels, const uint32_t* qlabel_off,
+                                     int live_only, uint32_t nq, uint32_t k, uint32_t* out_ids, uint32_t* out_ham) {
+    return vs_guard("vs_scan_topk_filtered", [&] { return vs_scan_topk_filtered_impl(ix, qcodes, qlabels, qlabel_off, live_only, nq, k, out_ids, out_ham); });
+}
+
 
 static int scan_topk_host(vs_index* ix, const uint64_t* qcodes, const int16_t* qlabels, const uint32_t* qlabel_off, int live_only,
                           uint32_t nq, uint32_t k, uint32_t* out_ids, uint32_t* out_ham) {

@@ -45,6 +45,22 @@ void vs_set_error(const char* fmt, ...);
         if (_r != VS_OK) return _r; \
     } while (0)
 
+// extern "C" entry points never let a C++ exception cross the boundary (vsgpu.h: errors are return codes)
+#include <exception>
+#include <new>
+template <class F>
+static inline int vs_guard(const char* what, F&& f) {
+    try {
+        return f();
+    } catch (const std::bad_alloc&) {
+        vs_set_error("%s: out of host memory", what);
+        return VS_ERR_OOM;
+    } catch (const std::exception& e) {
+        vs_set_error("%s: %s", what, e.what());
+        return VS_ERR_INVALID;
+    }
+}
+
 __host__ __device__ static inline uint32_t round_up_u32(uint32_t x, uint32_t m) { return (x + m - 1) / m * m; }
 static inline uint32_t next_pow2_u32(uint64_t x) {
     uint64_t p = 1;

@@ -651,6 +651,7 @@ def main():
                 if best is None or rows / dt_ > best[0]:
                     best = (rows / dt_, tc, rows, r_)
             cpu_qps, cpu_threads, sample, (o_ids, o_dist, o_st) = best
+            cpu1 = min(cpu1, 1.0 / max(sweep[0]["qps"], 1e-9))  # (the first probe runs on cold caches: the sweep's one-thread point counts too)
             # the final sample for the parity check: at least 2048 rows (or the step), at the best thread count
             sample = int(min(nq, max(sample, 2048)))
             cpu_t, (o_ids, o_dist, o_st) = cpu_run(sample, cpu_threads)

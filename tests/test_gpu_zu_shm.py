@@ -94,3 +94,48 @@ def test_client_processes_share_launches_and_get_the_oracles_rows(gpu_ctx, oracl
     with pytest.raises(P.VsError):
         P.ShmClient(name)  # the segment is gone
     ix.close()
+
+
+def _doomed_client(name, lib_path, q):
+    from pgvectorscale_amd import _lib
+    if lib_path:
+        _lib.LIB_PATH = lib_path
+    import pgvectorscale_amd as P
+    c = P.ShmClient(name)
+    c.search(q, None, 40, 20, 10)  # the parent kills this process while the request waits for its batch
+
+
+def test_slot_of_a_dead_client_is_reclaimed(gpu_ctx, oracle):
+    """a backend that dies while its scan is queued must not leak its slot: with ONE slot in the segment the next client can
+    only be served if the dispatcher took the slot back"""
+    import signal
+    import time
+    import pgvectorscale_amd as P
+    from pgvectorscale_amd import _lib
+    ti = TestIndex(**KW)
+    ix = ti.upload(gpu_ctx)
+    q = ti.queries(2, seed=5, kind="gauss")
+    name = f"/vs_shm_dead_{os.getpid()}"
+    srv = P.ShmServer(ix, name, nslots=1, kmax=16, max_batch=64, max_wait_us=1_500_000)  # requests wait 1.5 s for company
+    ctx = mp.get_context("spawn")
+    p = ctx.Process(target=_doomed_client, args=(name, _lib.LIB_PATH, q[0]))
+    p.start()
+    deadline = time.time() + 120
+    while srv.stats()["scans"] == 0 and p.is_alive() and time.time() < deadline:  # wait until the request is in the segment ...
+        time.sleep(0.05)
+        if p.pid and os.path.exists(f"/proc/{p.pid}"):
+            try:  # ... (posted = the child sleeps in its futex) and kill it before the batch window closes
+                if "futex" in open(f"/proc/{p.pid}/wchan").read():
+                    break
+            except OSError:
+                pass
+    time.sleep(0.2)
+    os.kill(p.pid, signal.SIGKILL)
+    p.join(30)
+    c = P.ShmClient(name)
+    ids, _, _ = c.search(q[1], None, 40, 20, 10)  # blocks in the slot claim until the dead client's slot is free again
+    oi, _, _ = ti.oracle.search_batch(q[1:2], L=40, rescore=20, k=10)
+    assert (ids == oi[0]).all()
+    c.close()
+    srv.close()
+    ix.close()

@@ -135,7 +135,7 @@ def choose_operating_point(run_sample, k, target, sweep_log, err_type=Exception)
         return tried[(cl, cs)]
 
     s_grid = [25, 50, 100, 200, 400]
-    for cl in (25, 35, 50, 75, 100, 150, 200, 400):
+    for cl in (3, 5, 10, 15, 25, 35, 50, 75, 100, 150, 200, 400):
         for cs in s_grid:
             r_, _ = try_point(cl, cs)
             if r_ >= target:

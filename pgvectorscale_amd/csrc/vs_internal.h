@@ -209,7 +209,10 @@ struct FastLaunch {
     uint32_t* status;
     uint64_t* phase = nullptr;  // optional [nq][8] per-phase shader-clock sums (VS_PHASE=1, diagnostics only)
 };
-enum { FAST_PLAIN_ROW_LOADS = 1 };  // code rows through the normal cache policy instead of non-temporal loads
+enum {
+    FAST_PLAIN_ROW_LOADS = 1,  // code rows through the normal cache policy instead of non-temporal loads
+    FAST_FULL_VARIANT = 8,     // run the instantiation that handles label keys and a visibility mask even when the batch has neither
+};
 size_t fast_lds_bytes(const vs_index* idx, const FastLaunch& s);
 int launch_search_fast(vs_index* idx, const FastLaunch& s);
 enum { ST_VISITS = 0, ST_CAND = 1, ST_DQ = 2, ST_READS = 3, ST_NEXT = 4, ST_GSPILL = 5, ST_INVIS = 6, ST_N = 8 };

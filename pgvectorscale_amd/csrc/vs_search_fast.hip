@@ -60,9 +60,17 @@ __device__ __forceinline__ void wave_sync() {
 // operations of a wave reach its CU's L1 in program order and no other CU ever writes these lines, so a lane reads what any
 // lane of the wave stored earlier (wave_sync() keeps the compiler from reordering across the hand-over); the lines stay
 // write-back in L2 instead of costing a fabric write per store as agent-scope stores do.
-__device__ __forceinline__ uint32_t gload32(const uint32_t* p) { return *p; }
-__device__ __forceinline__ void gstore32(uint32_t* p, uint32_t v) { *p = v; }
-__device__ __forceinline__ uint64_t gload64u(const uint64_t* p) { return *p; }
+// The address space is spelled out: heap.l / heap.g are members the compiler cannot always trace back to the __shared__ array
+// and the kernel argument, and "position < hl ? LDS : spill array" then becomes ONE flat access through a selected pointer — LDS
+// traffic through the vector memory path, and a wait on every outstanding load (row prefetches included) behind each of them.
+typedef __attribute__((address_space(1))) uint32_t glb_u32;
+typedef __attribute__((address_space(1))) uint64_t glb_u64;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+__device__ __forceinline__ uint32_t gload32(const uint32_t* p) { return *(const glb_u32*)p; }
+__device__ __forceinline__ void gstore32(uint32_t* p, uint32_t v) { *(glb_u32*)p = v; }
+__device__ __forceinline__ uint64_t gload64u(const uint64_t* p) { return *(const glb_u64*)p; }
+__device__ __forceinline__ uint32_t lload32(const uint32_t* p) { return *(const lds_u32*)p; }
+__device__ __forceinline__ void lstore32(uint32_t* p, uint32_t v) { *(lds_u32*)p = v; }
 __device__ __forceinline__ uint32_t readlane_u32(uint32_t v, uint32_t l) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l);
 }
@@ -78,20 +86,32 @@ __device__ __forceinline__ uint32_t wave_shl1(uint32_t v, uint32_t carry) {
 // Heap position i lives at l[i + 1] while i < hl (hl = 2^k - 1, so a sibling pair (2a+1, 2a+2) is one aligned 8-byte
 // word both in LDS and in the spill array g[i - hl]); l[0] is a sentinel with key 0 ("ancestor of the root").
 // ---------------------------------------------------------------------------------------------------------------
+// PK: the per-lane constants below are kept packed in one register and unpacked where they are used (the 64-VGPR variant)
+template <bool PK>
 struct FastHeap {
     uint32_t* l;
     uint32_t* g;
     uint32_t hl, sb, len;
     int lane;
-    uint32_t lvl, offm1;   // this lane's level / (offset - 1) inside a 6-level subtree (lane 63: never a node)
+    uint32_t lvl_, offm1_;  // this lane's level / (offset - 1) inside a 6-level subtree (lane 63: never a node)
+    uint32_t pk;            // PK: wl_rank | wl_slot << 5 | wl_base << 10 | lvl << 16
+    __device__ __forceinline__ uint32_t lvl() const { return PK ? (pk >> 16) : lvl_; }
+    __device__ __forceinline__ uint32_t offm1() const {
+        if (!PK) return offm1_;
+        return lane < 63 ? (uint32_t)lane - (1u << (pk >> 16)) : 0x40000000u;
+    }
+    __device__ __forceinline__ uint32_t wl_rank() const { return PK ? (pk & 31u) : wl_rank_; }
+    __device__ __forceinline__ uint32_t wl_slot() const { return PK ? ((pk >> 5) & 31u) : wl_slot_; }
+    __device__ __forceinline__ uint32_t wl_base() const { return PK ? ((pk >> 10) & 63u) : wl_base_; }
     uint32_t amask, dpat;  // lane j is on the sift-down path iff (pick_bits & amask) == dpat (ancestor choices)
 
     __device__ __forceinline__ void init(int lane_) {
         lane = lane_;
         len = 0;
         const uint32_t j1 = (uint32_t)lane + 1u;
-        lvl = 31u - (uint32_t)__builtin_clz(j1);
-        offm1 = lane < 63 ? j1 - (1u << lvl) - 1u : 0x40000000u;
+        const uint32_t lvl = 31u - (uint32_t)__builtin_clz(j1);
+        lvl_ = lvl;
+        offm1_ = lane < 63 ? j1 - (1u << lvl) - 1u : 0x40000000u;
         amask = 0;
         dpat = 0;
         for (uint32_t k = 1; k <= lvl; ++k) {
@@ -104,9 +124,9 @@ struct FastHeap {
     }
     __device__ __forceinline__ uint32_t root() const { return rfl(l[1]); }
 
-    __device__ __forceinline__ uint32_t get(uint32_t i) const { return i < hl ? l[i + 1] : gload32(g + (i - hl)); }
+    __device__ __forceinline__ uint32_t get(uint32_t i) const { return i < hl ? lload32(l + i + 1) : gload32(g + (i - hl)); }
     __device__ __forceinline__ void set(uint32_t i, uint32_t v) const {
-        if (i < hl) l[i + 1] = v;
+        if (i < hl) lstore32(l + i + 1, v);
         else gstore32(g + (i - hl), v);
     }
     // ---- sift_up(0, pos) of `elem` (not yet stored): while elem < parent (Reverse => smaller distance) move parent down
@@ -155,21 +175,26 @@ struct FastHeap {
     //     them from the wide load (ds_bpermute) and the rest from the patched chain of push j.
     // lane layout of the wide load: rank 1 -> lanes 0..16, rank 2 -> 17..25, rank 3 -> 26..30, rank 4 -> 31..33,
     // rank r >= 5 -> lanes 34 + 2 (r - 5), +1  (ranks up to 19: heaps of up to 2^19 entries)
-    uint32_t wl_rank, wl_slot, wl_base;  // this lane's (rank, slot) as a wide-load lane; first lane of rank `lane`
+    uint32_t wl_rank_, wl_slot_, wl_base_;  // this lane's (rank, slot) as a wide-load lane; first lane of rank `lane`
     __device__ __forceinline__ void init_wide() {
         const uint32_t i = (uint32_t)lane;
+        uint32_t wl_rank, wl_slot;
         if (i < 17) { wl_rank = 1; wl_slot = i; }
         else if (i < 26) { wl_rank = 2; wl_slot = i - 17; }
         else if (i < 31) { wl_rank = 3; wl_slot = i - 26; }
         else if (i < 34) { wl_rank = 4; wl_slot = i - 31; }
         else { wl_rank = 5 + ((i - 34) >> 1); wl_slot = (i - 34) & 1u; }
         const uint32_t r = i;  // as a chain lane: where do rank-r values start
-        wl_base = r <= 1 ? 0u : (r == 2 ? 17u : (r == 3 ? 26u : (r == 4 ? 31u : 34u + 2u * (r - 5u))));
+        const uint32_t wl_base = r <= 1 ? 0u : (r == 2 ? 17u : (r == 3 ? 26u : (r == 4 ? 31u : 34u + 2u * (r - 5u))));
+        wl_rank_ = wl_rank;
+        wl_slot_ = wl_slot;
+        wl_base_ = wl_base;
+        pk = (wl_rank & 31u) | (wl_slot << 5) | ((wl_base & 63u) << 10) | (lvl_ << 16);
     }
     // entry at index idx (= heap position + 1; 0 = sentinel)
-    __device__ __forceinline__ uint32_t get1(uint32_t idx) const { return idx <= hl ? l[idx] : gload32(g + (idx - 1 - hl)); }
+    __device__ __forceinline__ uint32_t get1(uint32_t idx) const { return idx <= hl ? lload32(l + idx) : gload32(g + (idx - 1 - hl)); }
     __device__ __forceinline__ void set1(uint32_t idx, uint32_t v) const {
-        if (idx <= hl) l[idx] = v;
+        if (idx <= hl) lstore32(l + idx, v);
         else gstore32(g + (idx - 1 - hl), v);
     }
     // geometry of the first run of c pushes starting at the current length (0 = "one at a time" path)
@@ -182,9 +207,9 @@ struct FastHeap {
     // the wide ancestor load of a run of n leaves starting at the current length (only ISSUES the reads)
     __device__ __forceinline__ uint32_t wide_load(uint32_t n) const {
         const uint32_t p1f = len + 1, p1l = p1f + n - 1;
-        const uint32_t idx = (p1f >> wl_rank) + wl_slot;
+        const uint32_t idx = (p1f >> wl_rank()) + wl_slot();
         uint32_t anc = 0;
-        if (idx <= (p1l >> wl_rank)) anc = p1l > hl ? get1(idx) : l[idx];
+        if (idx <= (p1l >> wl_rank())) anc = p1l > hl ? get1(idx) : l[idx];
         return anc;
     }
     // pre_n / pre_anc: a wide load the caller already issued for the first run (pre_n = first_run(c)), or pre_n = 0
@@ -207,7 +232,7 @@ struct FastHeap {
             const uint32_t r = (uint32_t)lane;       // chain lane = ancestor rank (lane 0 and lanes > 20 unused)
             const bool rank_ok = r >= 1 && r <= 19;
             auto fresh_of = [&](uint32_t p1) -> uint32_t {  // rank-r ancestor of leaf p1 as loaded at the start of the run
-                const uint32_t src = wl_base + ((p1 >> (r & 31u)) - (p1f >> (r & 31u)));
+                const uint32_t src = wl_base() + ((p1 >> (r & 31u)) - (p1f >> (r & 31u)));
                 const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((rank_ok ? src : 0u) << 2), (int)anc);
                 return rank_ok ? v : 0u;
             };
@@ -273,7 +298,7 @@ struct FastHeap {
         uint32_t pkey = 0;  // key of the value now stored in the parent of `root` (0 for the heap root: never moves)
         for (;;) {
             // one 6-level subtree per iteration: lane j < 63 is the node with relative heap index j
-            const uint32_t aidx = ((root + 1) << lvl) + offm1;
+            const uint32_t aidx = ((root + 1) << lvl()) + offm1();
             const uint32_t c = 2 * aidx + 1;
             const bool exists = aidx < end, have1 = c < end, have2 = c + 1 < end;
             uint32_t le = 0, ri = 0;
@@ -457,7 +482,9 @@ struct Visited {
     }
 };
 
-template <int NCH>
+// QL: the query code is read from its LDS copy (8 NCH words, zero padded) instead of 4 NCH registers per lane — the variant that
+// has to fit 64 VGPRs (8 waves per SIMD)
+template <int NCH, bool QL = false>
 __device__ __forceinline__ uint32_t ham_row_reg(const uint64_t* __restrict__ row, const ulonglong2 (&qv)[NCH > 0 ? NCH : 1],
                                                 const uint64_t* qc_l, int l4, uint32_t code_stride, bool active, bool stream) {
     uint32_t acc = 0;
@@ -471,8 +498,10 @@ __device__ __forceinline__ uint32_t ham_row_reg(const uint64_t* __restrict__ row
                        : stream ? load_stream16(row + w) : *reinterpret_cast<const ulonglong2*>(row + w);
             }
 #pragma unroll
-            for (int t = 0; t < NCH; ++t)
-                acc += (uint32_t)__popcll(r[t].x ^ qv[t].x) + (uint32_t)__popcll(r[t].y ^ qv[t].y);
+            for (int t = 0; t < NCH; ++t) {
+                const ulonglong2 qq = QL ? *reinterpret_cast<const ulonglong2*>(qc_l + 2u * (uint32_t)l4 + 8u * (uint32_t)t) : qv[t];
+                acc += (uint32_t)__popcll(r[t].x ^ qq.x) + (uint32_t)__popcll(r[t].y ^ qq.y);
+            }
         }
         return quad_sum(acc);
     }
@@ -492,7 +521,9 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 // kernel is occupancy bound and LDS no longer limits it, so fewer VGPRs (some cold values in scratch) can pay.
 // BUILD = greedy_search_for_build (AM/graph/mod.rs:285-327): no rows are consumed; the sorted visited list (capped at the
 // ring capacity, farthest entry dropped) is the result.
-template <int NCH, int VR, bool TIMING, int MINW, bool BUILD>
+// FULL = label keys and / or a visibility mask may be present; the plain instantiation (neither) leaves their pointers, counters
+// and branches out of a kernel whose scalar registers are its tightest resource.
+template <int NCH, int VR, bool TIMING, int MINW, bool BUILD, bool FULL = true>
 __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
@@ -514,8 +545,13 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
 
     const int l4 = lane & 3;
     const bool stream_rows = !(s.flags & FAST_PLAIN_ROW_LOADS);
+    constexpr bool QL = NCH > 0 && MINW >= 7;
     ulonglong2 qv[NCH > 0 ? NCH : 1];
-    if (NCH > 0) {
+    if (QL) {
+        qv[0] = make_ulonglong2(0, 0);
+        for (uint32_t w = lane; w < 8u * (uint32_t)NCH; w += WAVE)
+            qc_l[w] = w < a.code_stride ? s.qcodes[(size_t)q * a.code_stride + w] : 0ull;
+    } else if (NCH > 0) {
 #pragma unroll
         for (int t = 0; t < NCH; ++t) {
             const uint32_t w = 2u * (uint32_t)l4 + 8u * (uint32_t)t;
@@ -530,7 +566,8 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
         *reinterpret_cast<uint4*>(lhash + i) = make_uint4(VS_EMPTY, VS_EMPTY, VS_EMPTY, VS_EMPTY);
     if (lane == 0) hp[0] = 0;  // heap sentinel
     for (uint32_t i = lane; i < ARB_SLOTS; i += WAVE) arb[i] = 0;
-    const bool labels_some = s.qlabel_off != nullptr;  // LabeledVector.labels is Some (AM/labels/mod.rs:222-236)
+    const uint8_t* const visible = FULL ? s.visible : nullptr;
+    const bool labels_some = FULL && s.qlabel_off != nullptr;  // LabeledVector.labels is Some (AM/labels/mod.rs:222-236)
     uint32_t nql = 0;
     if (labels_some) {
         const uint32_t lb = s.qlabel_off[q], le = s.qlabel_off[q + 1];
@@ -540,7 +577,7 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
     const bool has_label_filter = labels_some && nql > 0;  // AM/scan.rs:189
     wave_sync();
 
-    FastHeap heap;
+    FastHeap<(MINW >= 7)> heap;
     heap.l = hp;
     heap.g = s.only_failed ? s.heap_g : s.heap_g + (size_t)q * s.gstride;  // (second attempt: set with the pool region)
     heap.hl = s.hl;
@@ -590,8 +627,8 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
     // handle -> node id.  node_load only ISSUES the read (LDS, or L2 for ids in the overflow table); the value is made
     // uniform with rfl() where it is needed, so the latency overlaps whatever runs in between.
     auto node_load = [&](uint32_t handle) -> uint32_t {
-        if (handle < s.lh) return lhash[handle];
-        return ghash[handle - s.lh];
+        if (handle < s.lh) return lload32(lhash + handle);
+        return gload32(ghash + (handle - s.lh));
     };
     // true where the id was not present before; slot_out = its handle
     auto finish_insert = [&](uint32_t nid, bool act, uint32_t slot, uint32_t old, uint32_t& slot_out) -> bool {
@@ -728,7 +765,7 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
             slot = rfl(slot);
             st_reads++;
             const uint32_t d =
-                rfl(ham_row_reg<NCH>(a.codes + (size_t)sn * a.code_stride, qv, qc_l, l4, a.code_stride, lane < 4, stream_rows));
+                rfl(ham_row_reg<NCH, QL>(a.codes + (size_t)sn * a.code_stride, qv, qc_l, l4, a.code_stride, lane < 4, stream_rows));
             st_dq++;
             st_cand++;
             if (heap.len + 1 > s.hcap) { status |= OVF_HEAP; break; }
@@ -753,7 +790,7 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
             if (fn != ft_node) {
                 ft_node = fn;
                 ft_val = a.tids[fn];
-                if (s.visible) ft_vis = s.visible[fn];
+                if (visible) ft_vis = visible[fn];
             }
         }
         uint32_t top = 0;
@@ -773,10 +810,10 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
             if (VR > 0) {
                 const uint64_t tid = fnode == ft_node ? ft_val : a.tids[fnode];
                 fflags = (tid & 0xFFFFull) == 0 ? VIS_DEAD : 0u;
-                if (s.visible) fflags |= rfl(fnode == ft_node ? ft_vis : (uint32_t)s.visible[fnode]) == 0 ? VIS_HIDDEN : 0u;
+                if (visible) fflags |= rfl(fnode == ft_node ? ft_vis : (uint32_t)visible[fnode]) == 0 ? VIS_HIDDEN : 0u;
             }
             if (fflags & VIS_DEAD) continue;  // InvalidOffsetNumber: deleted tuple (AM/scan.rs:231-234)
-            if (s.visible && (fflags & VIS_HIDDEN)) {  // get_full_distance_for_resort -> None: fetched, counted, never enters
+            if (visible && (fflags & VIS_HIDDEN)) {  // get_full_distance_for_resort -> None: fetched, counted, never enters
                 st_invis++;                              // the window (AM/scan.rs:268-272)
                 continue;
             }
@@ -800,7 +837,7 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
         uint32_t vvis = 1;
         if (VR == 0 && !BUILD) {
             vtid = a.tids[node];
-            if (s.visible) vvis = s.visible[node];
+            if (visible) vvis = visible[node];
         }
         const uint32_t* nrow = a.nbrs + (size_t)node * a.nbr_stride;
         uint32_t row0;
@@ -909,7 +946,7 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
                         pfa_val = ((uint32_t)lane < a.R) ? a.nbrs[(size_t)pfa_node * a.nbr_stride + lane] : VS_INVALID_NODE;
                     }
                 }
-                const uint32_t d = ham_row_reg<NCH>(crow, qv, qc_l, l4, a.code_stride, valid, stream_rows);
+                const uint32_t d = ham_row_reg<NCH, QL>(crow, qv, qc_l, l4, a.code_stride, valid, stream_rows);
                 if (valid && l4 == 0) surv_d[j] = d;
             }
             st_dq += c;
@@ -991,20 +1028,22 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
 }
 
 size_t fast_lds_bytes(const vs_index* idx, const FastLaunch& s) {
-    const size_t qcopy = (idx->code_stride + 7) / 8 > 6 ? (size_t)idx->code_stride * 8 : 0;  // NCH == 0 variant only
+    const size_t nch = (idx->code_stride + 7) / 8;
+    // LDS copy of the query code: the generic variant (NCH == 0), and the register-capped variants (minw >= 7: 8 NCH words, zero padded)
+    const size_t qcopy = nch > 6 ? (size_t)idx->code_stride * 8 : (s.minw >= 7 && !s.build && !s.phase ? nch * 64 : 0);
     size_t b = (size_t)(s.hl + 1) * 4 + (size_t)s.lh * 4 + 3 * 64 * 4 + ARB_SLOTS * 4 + (s.vr ? 0 : (size_t)s.vcap * 8) + MAX_QLABELS * 2 + qcopy + 16;
     return (b + 15) / 16 * 16;
 }
 
-template <int NCH, int VR, bool TIMING, int MINW, bool BUILD>
+template <int NCH, int VR, bool TIMING, int MINW, bool BUILD, bool FULL = true>
 static int launch_fast_tt(vs_index* idx, const FastArgs& a, size_t lds) {
     static bool attr_set = false;
     if (!attr_set) {
-        VS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_search_fast<NCH, VR, TIMING, MINW, BUILD>),
+        VS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_search_fast<NCH, VR, TIMING, MINW, BUILD, FULL>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_search_fast<NCH, VR, TIMING, MINW, BUILD>), dim3(a.s.nq), dim3(WAVE), lds, idx->ctx->stream, a);
+    hipLaunchKernelGGL((k_search_fast<NCH, VR, TIMING, MINW, BUILD, FULL>), dim3(a.s.nq), dim3(WAVE), lds, idx->ctx->stream, a);
     VS_HIP(hipGetLastError());
     return VS_OK;
 }
@@ -1029,7 +1068,10 @@ static int launch_fast_t(vs_index* idx, const FastArgs& a, size_t lds) {
         return launch_fast_tt<NCH, 8, false, 1, false>(idx, a, lds);
     }
     if (NCH == 3) {
+        const bool plain = !a.s.qlabel_off && !a.s.visible && !(a.s.flags & FAST_FULL_VARIANT);  // no label keys, no visibility mask
+        if (a.s.minw == 6 && plain) return launch_fast_tt<3, 0, false, 6, false, false>(idx, a, lds);
         if (a.s.minw == 6) return launch_fast_tt<3, 0, false, 6, false>(idx, a, lds);
+        if (a.s.minw == 7) return launch_fast_tt<3, 0, false, 7, false>(idx, a, lds);
         if (a.s.minw == 8) return launch_fast_tt<3, 0, false, 8, false>(idx, a, lds);
     }
     return launch_fast_tt<NCH, 0, false, 1, false>(idx, a, lds);

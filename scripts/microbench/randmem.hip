@@ -84,6 +84,95 @@ __global__ void k_fill(uint32_t* p, size_t n, uint32_t v) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }
 
+// The same requests as the mix above, but issued the way a scan issues them: one expansion = a neighbor row (256 B, address
+// known only after the previous expansion), then the bucket loads + stores (addresses from that row), then the code rows
+// (addresses from the buckets' contents), then `pad` dependent ALU steps standing in for the heap work, whose result names the
+// next row.  DEPTH independent chains per wave (1 = what k_search_fast does; 2, 4 = what overlapping expansions would give).
+template <int DEPTH>
+__global__ __launch_bounds__(64) void k_chain(const uint8_t* __restrict__ codes, uint64_t nrows, const uint32_t* __restrict__ nbrs,
+                                              uint64_t nnodes, uint32_t* tables, uint32_t tab_words, uint32_t iters,
+                                              uint32_t rows_per_iter, uint32_t probes_per_iter, uint32_t pad, uint64_t* sink) {
+    extern __shared__ unsigned char pad_lds[];
+    const uint32_t lane = threadIdx.x, wave = blockIdx.x;
+    const uint32_t l4 = lane & 3, grp = lane >> 2;
+    uint32_t* tab = tables + (size_t)wave * tab_words;
+    uint64_t acc = 0;
+    uint32_t dep[DEPTH];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) dep[d] = mix(wave * 0x9E3779B9u + 12345u + d * 0x51ed27u);
+    for (uint32_t it = 0; it < iters; it += DEPTH) {
+        uint32_t nb[DEPTH], pr[DEPTH];
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {  // stage 1: the neighbor row of the node the last expansion chose
+            const uint64_t node = ((uint64_t)dep[d] * nnodes) >> 32;
+            nb[d] = nbrs[node * 64 + lane];
+        }
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {  // stage 2: one bucket per neighbor id, a store for 61 % of them
+            const uint32_t h = mix(nb[d] + dep[d] + lane * 0x85ebca6bu);
+            pr[d] = h;
+            if (lane < probes_per_iter) {
+                const uint32_t slot = h & (tab_words - 1);
+                const uint4 b = *reinterpret_cast<const uint4*>(tab + (slot & ~3u));
+                pr[d] = h ^ ((b.x ^ b.y ^ b.z ^ b.w) & 1u);
+                if ((h >> 24) < 156u) tab[slot] = (h >> 4) | 1u;
+            }
+        }
+        uint32_t sum[DEPTH];
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {  // stage 3: the code rows of the ids that were new
+            sum[d] = 0;
+            for (uint32_t p = 0; p < rows_per_iter; p += 16) {
+                const uint32_t src = __shfl(pr[d], (int)(p + grp) & 63);
+                const uint64_t row = ((uint64_t)mix(src ^ (p * 0x9E3779B1u)) * nrows) >> 32;
+                const uint8_t* r = codes + row * 192 + 16u * l4;
+                typedef unsigned long long v2u64 __attribute__((ext_vector_type(2)));
+                const v2u64 a = __builtin_nontemporal_load(reinterpret_cast<const v2u64*>(r));
+                const v2u64 b = __builtin_nontemporal_load(reinterpret_cast<const v2u64*>(r + 64));
+                const v2u64 c = __builtin_nontemporal_load(reinterpret_cast<const v2u64*>(r + 128));
+                sum[d] += __popcll(a.x) + __popcll(a.y) + __popcll(b.x) + __popcll(b.y) + __popcll(c.x) + __popcll(c.y);
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {  // stage 4: the heap work (dependent ALU steps), then the next node is known
+            uint32_t x = sum[d] + pr[d];
+            for (uint32_t k = 0; k < pad; ++k) x = mix(x + k);
+            x = (uint32_t)__shfl((int)x, 0);
+            dep[d] = mix(x + it);
+            acc += x;
+        }
+    }
+    if (acc == 0x123456789abcull) sink[0] = acc;
+}
+
+template <int DEPTH>
+static double run_chain(const uint8_t* codes, uint64_t nrows, const uint32_t* nbrs, uint64_t nnodes, uint32_t* tables,
+                        uint32_t tab_words, uint32_t waves_per_cu, uint32_t iters, uint32_t pad, uint64_t* sink) {
+    const uint32_t nwaves = 256 * waves_per_cu;
+    const size_t lds = (160 * 1024) / waves_per_cu - 64;
+    static bool attr = false;
+    if (!attr) {
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain<DEPTH>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    k_fill<<<2048, 256>>>(tables, (size_t)nwaves * tab_words, 0xFFFFFFFFu);
+    CK(hipDeviceSynchronize());
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL((k_chain<DEPTH>), dim3(nwaves), dim3(64), lds, 0, codes, nrows, nbrs, nnodes, tables, tab_words, iters, 32u, 50u,
+                       pad, sink);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    const double rows = (double)nwaves * iters * 32;
+    printf("chain depth=%d pad=%4u ALU steps              w/CU=%2u tabKB=%4u  %8.2f ms  rows %6.2f G/s (%6.0f GB/s alg)  %6.2f us per expansion\n",
+           DEPTH, pad, waves_per_cu, tab_words / 256, ms, rows / ms / 1e6, rows * 192.0 / ms / 1e6, ms * 1e3 / iters * DEPTH);
+    fflush(stdout);
+    return ms;
+}
+
 struct Res { double ms; };
 
 template <int MODE, int PROBE, int NT>
@@ -130,6 +219,21 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&sink, 8));
     const uint32_t E = 0xFFFFFFFFu;
     const uint32_t it = 4000;
+    if (argc > 1 && argv[1][0] == 'c') {  // "chain": the closed loop of one scan, see k_chain
+        const uint64_t nnodes = 50000000ull;
+        uint32_t* nbrs;
+        CK(hipMalloc(&nbrs, nnodes * 64 * 4));
+        k_fill<<<2048, 256>>>(nbrs, nnodes * 64, 0x1234567u);
+        CK(hipDeviceSynchronize());
+        const uint32_t itc = 2000;
+        for (uint32_t w : {12u, 20u, 24u, 32u})
+            for (uint32_t pad : {0u, 64u, 256u}) {
+                run_chain<1>(codes, nrows, nbrs, nnodes, tables, 16384, w, itc, pad, sink);
+                run_chain<2>(codes, nrows, nbrs, nnodes, tables, 16384, w, itc, pad, sink);
+                run_chain<4>(codes, nrows, nbrs, nnodes, tables, 16384, w, itc, pad, sink);
+            }
+        return 0;
+    }
     if (argc > 1) {  // table-size sweep of the non-atomic bucket scheme (16-byte load + 4-byte store for 61 % of the probes)
         for (uint32_t w : {20u, 12u}) {
             for (uint32_t tw : {1024u, 2048u, 4096u, 8192u, 16384u, 32768u, 65536u})

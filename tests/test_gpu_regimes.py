@@ -109,3 +109,34 @@ def test_code_width_specialisations(gpu_ctx, wname, regime):
             else:
                 os.environ[k] = v
         ix.close()
+
+
+# the register-capped variants of the headline geometry (W = 24: 768 x 2 bit / 1536 x 1 bit) in the table-less regime:
+# waves per SIMD the kernel is compiled for (7 and 8 read the query code from LDS and keep the heap's lane constants packed)
+@pytest.mark.parametrize("minw", [6, 7, 8])
+@pytest.mark.parametrize("wname", ["w24_two_bit", "w24_one_bit"])
+def test_register_capped_variants(gpu_ctx, wname, minw):
+    dims, bits = {"w24_two_bit": (768, 2), "w24_one_bit": (1536, 1)}[wname]
+    ti = cached_index(n=500, dim_full=dims, bits=bits, R=20, distance=1, seed=23, kind="gauss", L_build=40)
+    ix = ti.upload(gpu_ctx)
+    q = ti.queries(32, seed=6, kind="gauss")
+    oi, oh, ost = ti.oracle.stream_batch(q, L=3, m=60)
+    osi, osd, _ = ti.oracle.search_batch(q, L=3, rescore=40, k=10)
+    env = {"VS_F_LDS_MAX_INS": "0", "VS_F_VR": "0", "VS_F_MINW": str(minw), "VS_F_HL": "63"}
+    saved = {k: os.environ.get(k) for k in env}
+    try:
+        os.environ.update(env)
+        gi, gh, gst = ix.stream_batch(q, search_list_size=3, m=60)
+        assert (gi == oi).all() and (gh == oh).all()
+        for key in ("visited_nodes", "quantized_distance_comparisons", "node_reads"):
+            assert gst[key] == ost[key], (key, gst[key], ost[key])
+        si, _, sd, _ = ix.search_batch(q, search_list_size=3, rescore=40, k=10)
+        assert (si == osi).all()
+        assert (sd.view(np.uint32) == osd.view(np.uint32)).all()
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        ix.close()

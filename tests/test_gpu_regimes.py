@@ -140,3 +140,28 @@ def test_register_capped_variants(gpu_ctx, wname, minw):
             else:
                 os.environ[k] = v
         ix.close()
+
+
+# Few distinct keys, deep heap, long runs: 24-dimensional 1-bit codes give Hamming distances 0..24, so thousands of heap entries
+# tie and the row order is decided by the array mechanics of BinaryHeap alone (which leaf a push lands on, which child a pop
+# prefers, where a carried value stops) — with R = 48 a visit pushes up to 48 candidates in one run.
+@pytest.mark.parametrize("regime", ["default", "tableless", "heap_spill_tableless"])
+def test_heavy_ties_deep_heap(gpu_ctx, regime):
+    ti = cached_index(n=6000, dim_full=24, bits=1, R=48, distance=1, seed=31, kind="gauss", L_build=60)
+    ix = ti.upload(gpu_ctx)
+    q = ti.queries(24, seed=9, kind="gauss")
+    oi, oh, ost = ti.oracle.stream_batch(q, L=150, m=400)
+    saved = {k: os.environ.get(k) for k in REGIMES[regime]}
+    try:
+        os.environ.update(REGIMES[regime])
+        gi, gh, gst = ix.stream_batch(q, search_list_size=150, m=400)
+        assert (gi == oi).all() and (gh == oh).all()
+        for key in ("visited_nodes", "candidate_nodes", "quantized_distance_comparisons", "node_reads"):
+            assert gst[key] == ost[key], (key, gst[key], ost[key])
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        ix.close()

@@ -1,16 +1,27 @@
 #!/bin/bash
-# On the GPU box: this tree's libvsgpu.so against pgvectorscale_amd/libvsgpu_alt.so (scripts/ab_branch.sh) on one index geometry.
-#   bash scripts/ab_libs_gpu.sh [n=10000000] [L=3] [rescore=196]
-# Order: the parity tier with the ALTERNATIVE library first (it is the unproven one, and the first python process on a fresh box
-# pays the minute-long import of torch — never put a short timeout on it), then both timings.
+# On the GPU box: this tree's libvsgpu.so against every pgvectorscale_amd/libvsgpu_alt_*.so (scripts/ab_branch.sh), one index
+# geometry, one session.   bash scripts/ab_libs_gpu.sh [n=10000000] [L=3] [rescore=196]
+# Order: the parity tier with the LAST alternative library first (the branch tip is the unproven one, and the first python
+# process on a fresh box pays the minute-long import of torch — never put a short timeout on it); then every library is timed on
+# the same graph (built once, cached in /tmp).
 N=${1:-10000000}; L=${2:-3}; S=${3:-196}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" && mkdir -p gpurun_out/ab
 O=gpurun_out/ab/ab_${N}_${L}_${S}.txt
-cp pgvectorscale_amd/libvsgpu.so /tmp/libvsgpu_main.so
-cp pgvectorscale_amd/libvsgpu_alt.so pgvectorscale_amd/libvsgpu.so
-timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -2 | tee gpurun_out/ab/gpu_tests_alt.txt
-echo "# alternative library" > $O
-timeout 600 python scripts/perf_search.py --n $N --nq 131072 --L $L --rescore $S --reps 3 --configs VS_FAST=1 2>&1 | grep -E "search " | tee -a $O
-cp /tmp/libvsgpu_main.so pgvectorscale_amd/libvsgpu.so
-echo "# this tree" >> $O
-timeout 600 python scripts/perf_search.py --n $N --nq 131072 --L $L --rescore $S --reps 3 --configs VS_FAST=1 2>&1 | grep -E "search " | tee -a $O
+LIBS=$(ls pgvectorscale_amd/libvsgpu_alt_*.so 2>/dev/null | sort -t_ -k3 -n)
+TIP=$(echo "$LIBS" | tail -1)
+if [ -n "$TIP" ]; then
+    cp pgvectorscale_amd/libvsgpu.so /tmp/libvsgpu_main.so
+    cp "$TIP" pgvectorscale_amd/libvsgpu.so
+    timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -2 | tee gpurun_out/ab/gpu_tests_tip.txt
+    cp /tmp/libvsgpu_main.so pgvectorscale_amd/libvsgpu.so
+fi
+run() { timeout 600 python scripts/perf_search.py --n $N --nq 131072 --L $L --rescore $S --reps 3 --configs VS_FAST=1 --graph-cache /tmp/vs_ab_graph "$@" 2>&1 | grep -E "search "; }
+echo "# this tree" | tee $O
+run | tee -a $O
+for lib in $LIBS; do
+    echo "# $lib" | tee -a $O
+    run --lib $lib | tee -a $O
+done
+echo "# this tree again" | tee -a $O
+run | tee -a $O
+rm -f /tmp/vs_ab_graph.*

@@ -31,12 +31,15 @@ def main():
                     help="experiment: order of the queries inside the batch — as generated, sorted by the cluster they were drawn "
                          "from (scans that run at the same time touch the same part of the graph), or sorted and dealt to the 8 XCDs "
                          "by cluster (block b runs on XCD b %% 8)")
+    ap.add_argument("--lib", default=None, help="time this libvsgpu build instead of pgvectorscale_amd/libvsgpu.so (scripts/ab_branch.sh)")
     args = ap.parse_args()
     import numpy as np
     import torch  # noqa: F401
     import pgvectorscale_amd as P
     from pgvectorscale_amd import _lib
     from pgvectorscale_amd.datagen import DatagenParams, fill_device
+    if args.lib:
+        _lib.LIB_PATH = os.path.abspath(args.lib)
 
     ctx = P.Context(0)
     ix = P.DiskAnnIndex.alloc(ctx, n=args.n, dim_full=args.dim, num_neighbors=50, distance_type=P.VS_L2)

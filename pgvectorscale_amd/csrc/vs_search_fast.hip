@@ -229,12 +229,12 @@ struct FastHeap {
             const bool spill = p1l > hl;  // some leaf (hence possibly some parent) lives in the spill array
             // ---- wide load of every distinct ancestor of the run (the first run's may already be in flight)
             const uint32_t anc = (j == 0 && pre_n == n) ? pre_anc : wide_load(n);
-            const uint32_t r = (uint32_t)lane;       // chain lane = ancestor rank (lane 0 and lanes > 20 unused)
-            const bool rank_ok = r >= 1 && r <= 19;
-            auto fresh_of = [&](uint32_t p1) -> uint32_t {  // rank-r ancestor of leaf p1 as loaded at the start of the run
-                const uint32_t src = wl_base() + ((p1 >> (r & 31u)) - (p1f >> (r & 31u)));
-                const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((rank_ok ? src : 0u) << 2), (int)anc);
-                return rank_ok ? v : 0u;
+            const uint32_t r = (uint32_t)lane;  // chain lane = ancestor rank (ranks 1..19 are ancestors; lane 0 stands for the leaf)
+            // rank-r ancestor of leaf p1 as loaded at the start of the run: wide-load lane wl_base(r) + (p1 >> r) - (p1f >> r)
+            // (any lane index is a legal bpermute source; what lanes without a rank read is never used)
+            const uint32_t fbase4 = (wl_base() - (p1f >> (r & 31u))) << 2;
+            auto fresh_of = [&](uint32_t p1) -> uint32_t {
+                return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((p1 >> (r & 31u)) << 2) + fbase4), (int)anc);
             };
             // An element that is not smaller than the ORIGINAL parent of its leaf stays on the leaf whatever the earlier
             // pushes of the run do (a push only ever lowers the values on its path: a position receives the pushed element or
@@ -246,34 +246,36 @@ struct FastHeap {
             const uint32_t par = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((myp1 >> 1) - (p1f >> 1)) << 2), (int)anc);
             const bool inrun = (uint32_t)lane < n;
             const bool climbs = inrun && (mine >> sb) < (par >> sb);
-            uint64_t cm = __ballot(climbs);
+            uint32_t cm = (uint32_t)__ballot(climbs);  // (n <= 32)
             if (inrun && !climbs) {
                 if (spill) set1(myp1, mine);
                 else l[myp1] = mine;
             }
             if (cm) {
-                uint32_t p1 = p1f + (uint32_t)__builtin_ctzll(cm);
-                uint32_t chain = fresh_of(p1);
+                const uint32_t keymask = (1u << sb) - 1u;
+                uint32_t chain = fresh_of(p1f + (uint32_t)__builtin_ctz(cm));
                 asm volatile("" : "+v"(chain));  // the chain is complete before the loop
                 while (cm) {
-                    const uint32_t e = (uint32_t)__builtin_ctzll(cm);
+                    const uint32_t e = (uint32_t)__builtin_ctz(cm);
                     cm &= cm - 1;
                     const uint32_t elem = readlane_u32(entry, j + e);
-                    p1 = p1f + e;
-                    const uint32_t p1n = cm ? p1f + (uint32_t)__builtin_ctzll(cm) : p1 + 1;  // next climber's leaf
-                    const uint32_t nxt = fresh_of(p1n);  // in flight during this push (unused after the last climber)
-                    const bool cmp = (elem >> sb) < (chain >> sb);
-                    const uint32_t bal = ((uint32_t)__ballot(cmp) & 0xFFFFEu) >> 1;  // bit r-1 <-> ancestor r (ranks 1..19)
-                    const uint32_t t = (uint32_t)__builtin_ctz(~bal);                   // leading run of ancestors that move down
-                    if (r <= t) {
-                        const uint32_t dst = r == 0 ? (p1 >> t) : (p1 >> (r - 1));
-                        const uint32_t val = r == 0 ? elem : chain;
-                        if (spill) set1(dst, val);
-                        else l[dst] = val;
-                    }
-                    const uint32_t sh = 32u - (uint32_t)__builtin_clz(p1 ^ p1n);
+                    const uint32_t p1 = p1f + e;
+                    const uint32_t p1n = p1f + (uint32_t)__builtin_ctz(cm | 0x80000000u);  // next climber's leaf (any leaf after the last)
+                    const uint32_t nxt = fresh_of(p1n);  // in flight during this push
+                    // key(elem) < key(chain)  <=>  (elem | keymask) < chain   (keys are the bits above the slot handle)
+                    const bool cmp = (elem | keymask) < chain;
+                    const uint32_t bal = ((uint32_t)__ballot(cmp) >> 1) & 0x7FFFFu;  // bit r-1 <-> ancestor r (ranks 1..19)
+                    const uint32_t t = (uint32_t)__builtin_ctz(~bal);                  // leading run of ancestors that move down
+                    // after the push position p1 >> k holds the old rank k+1 value for k < t and the element for k == t: lane k
+                    // writes it, and the same values are the chain the next push sees from rank sh upwards
                     const uint32_t up = wave_shl1(chain, 0);  // rank r+1 value
                     const uint32_t patched = r < t ? up : (r == t ? elem : chain);
+                    if (r <= t) {
+                        const uint32_t dst = p1 >> (r & 31u);
+                        if (spill) set1(dst, patched);
+                        else l[dst] = patched;
+                    }
+                    const uint32_t sh = 32u - (uint32_t)__builtin_clz(p1 ^ p1n);
                     chain = r >= sh ? patched : nxt;
                 }
             }

@@ -212,6 +212,145 @@ struct FastHeap {
         if (idx <= (p1l >> wl_rank())) anc = p1l > hl ? get1(idx) : l[idx];
         return anc;
     }
+    // ---- a run of n pushes, level by level instead of element by element -------------------------------------------------
+    // A push is also a walk DOWN the root-to-leaf path with the element in hand: at the first node whose key is greater the
+    // element stays and the node's old value is carried on, and from there on every node takes what is carried and hands its own
+    // value down (that is sift_up's shift of the path by one position; "at the first greater key" is where sift_up stops
+    // climbing).  Read that way, what push i meets at a node depends only on the pushes before it at that node and on what it
+    // was handed from above — so all pushes of the run can do one LEVEL at a time.  At a node the pushes of its leaves arrive
+    // in leaf order; the node holds the minimum seen so far (a carried value wins ties, an element loses them), i.e. an
+    // exclusive prefix minimum inside the node's block of leaves seeded with the node's original value, and a push hands down
+    // the loser of (what it brought, what the node held).  Lanes are the leaves (lane = leaf index mod 32-aligned window, so
+    // the leaves of a rank-k node are an aligned block of 2^k lanes); ranks 1..5 are done this way, which settles everything
+    // that stays inside the 32-leaf subtrees.  The few elements small enough to get above rank 5 first walk the part of the
+    // path above it one after another (the chain-in-registers loop, with the rank-5 node in the role of the leaf).
+    __device__ __forceinline__ void push_run_scan(uint32_t entry, uint32_t j, uint32_t n, uint32_t anc, bool spill) {
+        const uint32_t IDENT = 0xFFFFFFFFu;
+        const uint32_t p1f = len + 1;
+        const uint32_t off = p1f & 31u;
+        // where ranks 0..5 of the run live: all in the spill array (the usual case of a deep heap), mixed, or all in LDS
+        const bool deep = (p1f >> 5) > hl;
+        auto put = [&](uint32_t idx, uint32_t v) {
+            if (deep) gstore32(g + (idx - 1 - hl), v);
+            else if (spill) set1(idx, v);
+            else l[idx] = v;
+        };
+        const uint32_t i = (uint32_t)lane - off;            // this lane's element (leaf order); >= n: not a leaf of the run
+        const bool in = i < n;
+        const uint32_t p1 = (p1f & ~31u) + (uint32_t)lane;  // its leaf (position + 1)
+        uint32_t c = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((j + i) << 2), (int)entry);  // what the push carries
+        // original value of the leaf's ancestor of rank k (wide-load lane layout, see push_run)
+        auto anc_of = [&](uint32_t rank, uint32_t base) -> uint32_t {
+            return (uint32_t)__builtin_amdgcn_ds_bpermute((int)((base + (p1 >> rank) - (p1f >> rank)) << 2), (int)anc);
+        };
+        // deepest rank (<= 5) any element can reach against the ORIGINAL ancestors (values only fall during the run), and the
+        // elements that can get above rank 5 (bit e <-> element e).  (The ancestors are fetched again level by level below:
+        // registers are what this kernel is short of.)
+        uint32_t K = 0, hm;
+        {
+            const uint32_t kc = in ? c >> sb : IDENT;  // (every lane takes part in the fetches: they are cross-lane operations)
+            auto below = [&](uint32_t rank, uint32_t base) -> uint64_t {
+                const uint32_t ak = anc_of(rank, base);
+                return __ballot(kc < (ak >> sb));
+            };
+            if (below(1, 0)) K = 1;
+            if (K == 1 && below(2, 17)) K = 2;
+            if (K == 2 && below(3, 26)) K = 3;
+            if (K == 3 && below(4, 31)) K = 4;
+            if (K == 4 && below(5, 34)) K = 5;
+            hm = K == 5 ? (uint32_t)(below(6, 36) >> off) : 0u;
+        }
+        bool forced = false;
+        // ---- above rank 5: the elements that can get there, one after another
+        if (hm) {
+            const uint32_t r = (uint32_t)lane;  // chain lane r <-> rank 5 + r (lane 0: what is handed down to rank 5)
+            const uint32_t keymask = (1u << sb) - 1u;
+            const uint32_t rsh = (5u + r) & 31u;
+            const uint32_t fbase4 = (34u + 2u * r - (p1f >> rsh)) << 2;
+            auto fresh_of = [&](uint32_t pp) -> uint32_t {
+                return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((pp >> rsh) << 2) + fbase4), (int)anc);
+            };
+            uint32_t chain = fresh_of(p1f + (uint32_t)__builtin_ctz(hm));
+            asm volatile("" : "+v"(chain));
+            while (hm) {
+                const uint32_t e = (uint32_t)__builtin_ctz(hm);
+                hm &= hm - 1;
+                const uint32_t elem = readlane_u32(entry, j + e);
+                const uint32_t pp = p1f + e;
+                const uint32_t ppn = p1f + (uint32_t)__builtin_ctz(hm | 0x80000000u);
+                const uint32_t nxt = fresh_of(ppn);
+                const bool cmp = (elem | keymask) < chain;
+                const uint32_t bal = ((uint32_t)__ballot(cmp) >> 1) & 0x3FFFu;  // bit r-1 <-> rank 5 + r (ranks 6..19)
+                const uint32_t t = (uint32_t)__builtin_ctz(~bal);
+                const uint32_t up = wave_shl1(chain, 0);
+                const uint32_t patched = r < t ? up : (r == t ? elem : chain);  // lane 0: the old rank-6 value when t >= 1
+                if (r >= 1 && r <= t) {
+                    const uint32_t dst = pp >> rsh;
+                    if (spill) set1(dst, patched);
+                    else l[dst] = patched;
+                }
+                const uint32_t out = readlane_u32(patched, 0);
+                if ((uint32_t)lane == off + e && t >= 1) {
+                    c = out;
+                    forced = true;
+                }
+                const uint32_t shr = 32u - (uint32_t)__builtin_clz((pp ^ ppn) | 1u);  // ranks >= shr are shared (|1: clz(0))
+                chain = 5u + r >= shr ? patched : nxt;
+            }
+            if (__ballot(forced)) K = 5;
+        }
+        // ---- ranks 5..1, all leaves at once
+        auto level = [&](const uint32_t k, const uint32_t base) {
+            const uint32_t B1 = (1u << k) - 1u;
+            const uint32_t ak = anc_of(k, base);  // the node's original value
+            const uint32_t comp = in ? (((c >> sb) << 7) | (forced ? 63u - i : 65u + i)) : IDENT;
+            // exclusive prefix minimum inside the aligned block of 2^k lanes
+            uint32_t x = wave_shr1(comp, IDENT);
+            if (((uint32_t)lane & B1) == 0) x = IDENT;
+            if (k >= 2) {
+                uint32_t t1 = (uint32_t)__builtin_amdgcn_update_dpp((int)IDENT, (int)x, 0x111, 0xF, 0xF, false);
+                if (B1 < 15u && ((uint32_t)lane & B1) < 1u) t1 = IDENT;
+                x = min(x, t1);
+                uint32_t t2 = (uint32_t)__builtin_amdgcn_update_dpp((int)IDENT, (int)x, 0x112, 0xF, 0xF, false);
+                if (B1 < 15u && ((uint32_t)lane & B1) < 2u) t2 = IDENT;
+                x = min(x, t2);
+            }
+            if (k >= 3) {
+                uint32_t t4 = (uint32_t)__builtin_amdgcn_update_dpp((int)IDENT, (int)x, 0x114, 0xF, 0xF, false);
+                if (B1 < 15u && ((uint32_t)lane & B1) < 4u) t4 = IDENT;
+                x = min(x, t4);
+            }
+            if (k >= 4) {
+                const uint32_t t8 = (uint32_t)__builtin_amdgcn_update_dpp((int)IDENT, (int)x, 0x118, 0xF, 0xF, false);
+                x = min(x, t8);
+            }
+            if (k >= 5) {
+                const uint32_t t16 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((((uint32_t)lane & ~31u) + 15u) << 2), (int)x);
+                if ((uint32_t)lane & 16u) x = min(x, t16);
+            }
+            const uint32_t cur = min(x, ((ak >> sb) << 7) | 64u);  // what the node holds when this push arrives
+            const uint32_t tb = cur & 127u;
+            const uint32_t src = (tb < 64u ? 63u - tb : tb - 65u) + off;  // lane of the push that brought it
+            const uint32_t hv = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)c);
+            const uint32_t curv = tb == 64u ? ak : hv;
+            const bool wins = in && comp < cur;
+            const bool last = in && ((((uint32_t)lane & B1) == B1) || i + 1 == n);  // last push of the node: its final value
+            if (last) {
+                const uint32_t fin = wins ? c : curv;
+                if (fin != ak) put(p1 >> k, fin);
+            }
+            if (wins) {
+                c = curv;
+                forced = true;
+            }
+        };
+        if (K >= 5) level(5, 34);
+        if (K >= 4) level(4, 31);
+        if (K >= 3) level(3, 26);
+        if (K >= 2) level(2, 17);
+        if (K >= 1) level(1, 0);
+        if (in) put(p1, c);
+    }
     // pre_n / pre_anc: a wide load the caller already issued for the first run (pre_n = first_run(c)), or pre_n = 0
     __device__ __forceinline__ void push_run(uint32_t entry, uint32_t c, uint32_t pre_n, uint32_t pre_anc) {
         uint32_t j = 0;
@@ -229,6 +368,13 @@ struct FastHeap {
             const bool spill = p1l > hl;  // some leaf (hence possibly some parent) lives in the spill array
             // ---- wide load of every distinct ancestor of the run (the first run's may already be in flight)
             const uint32_t anc = (j == 0 && pre_n == n) ? pre_anc : wide_load(n);
+            if (n >= 6) {  // level by level; short runs cost less element by element
+                push_run_scan(entry, j, n, anc, spill);
+                j += n;
+                len += n;
+                wave_sync();
+                continue;
+            }
             const uint32_t r = (uint32_t)lane;  // chain lane = ancestor rank (ranks 1..19 are ancestors; lane 0 stands for the leaf)
             // rank-r ancestor of leaf p1 as loaded at the start of the run: wide-load lane wl_base(r) + (p1 >> r) - (p1f >> r)
             // (any lane index is a legal bpermute source; what lanes without a rank read is never used)
@@ -548,7 +694,7 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
 
     const int l4 = lane & 3;
     const bool stream_rows = !(s.flags & FAST_PLAIN_ROW_LOADS);
-    constexpr bool QL = NCH > 0 && MINW >= 7;
+    constexpr bool QL = NCH > 0 && MINW >= 6;
     ulonglong2 qv[NCH > 0 ? NCH : 1];
     if (QL) {
         qv[0] = make_ulonglong2(0, 0);
@@ -1032,8 +1178,8 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
 
 size_t fast_lds_bytes(const vs_index* idx, const FastLaunch& s) {
     const size_t nch = (idx->code_stride + 7) / 8;
-    // LDS copy of the query code: the generic variant (NCH == 0), and the register-capped variants (minw >= 7: 8 NCH words, zero padded)
-    const size_t qcopy = nch > 6 ? (size_t)idx->code_stride * 8 : (s.minw >= 7 && !s.build && !s.phase ? nch * 64 : 0);
+    // LDS copy of the query code: the generic variant (NCH == 0), and the register-capped variants (minw >= 6: 8 NCH words, zero padded)
+    const size_t qcopy = nch > 6 ? (size_t)idx->code_stride * 8 : (s.minw >= 6 && !s.build && !s.phase ? nch * 64 : 0);
     size_t b = (size_t)(s.hl + 1) * 4 + (size_t)s.lh * 4 + 3 * 64 * 4 + ARB_SLOTS * 4 + (s.vr ? 0 : (size_t)s.vcap * 8) + MAX_QLABELS * 2 + qcopy + 16;
     return (b + 15) / 16 * 16;
 }

@@ -484,6 +484,10 @@ struct FastHeap {
             }
             pkey = readlane_u32(cv, jd) >> sb;
             root = 2 * ad + 1 + (uint32_t)((B >> jd) & 1ull);  // jd is on the subtree's last level: descend
+            if (2 * root + 1 >= end) {  // ... unless the child is a leaf (a heap of 4096..8190 entries ends every path here)
+                pos = root;
+                break;
+            }
         }
         // sift_up(0, pos) of the former last element: it only moves when it is smaller than the new parent value
         const uint32_t item = rfl(item_v);

@@ -929,8 +929,8 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
     // Neighbor rows are requested ahead of the pop that needs them: slot A = the heap root left by the last pop (asked
     // for together with the code gather, so both latencies overlap), slot B = the best new candidate when it beats that
     // root (asked for as soon as its distance is known; the pushes / pop / visited insert cover the latency).
-    uint32_t pfa_node = VS_INVALID_NODE, pfa_val = VS_INVALID_NODE;
-    uint32_t pfb_node = VS_INVALID_NODE, pfb_val = VS_INVALID_NODE;
+    uint32_t pfa_node = VS_INVALID_NODE, pfa_val = VS_INVALID_NODE, pfa_h = 0xFFFFFFFFu;  // (_h: the node's dedup handle)
+    uint32_t pfb_node = VS_INVALID_NODE, pfb_val = VS_INVALID_NODE, pfb_h = 0xFFFFFFFFu;
 
     // ---- TSVResponseIterator::next until M rows are emitted (AM/scan.rs:210-242), flattened: every iteration is
     // either one visit_closest() expansion (greedy_search_iterate, AM/graph/mod.rs:357-385) or one consume() ----
@@ -982,27 +982,42 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
         hmax = max(hmax, heap.len);
         lap(6);
         const uint32_t hd = top >> s.sb;
-        const uint32_t node_v = node_load(top & smask);
+        // The node about to be visited is, almost always, one of the two whose neighbor rows were requested during the last
+        // visit; its dedup handle says so without a memory access.  Then everything the visit needs from memory before it can
+        // touch the heap again — heap tid, visibility, and (table-less regime) the dedup buckets of the row's ids — is requested
+        // BEFORE the pop and arrives while the pop works.
+        const uint32_t th = top & smask;
+        const bool hit_a = th == pfa_h, hit_b = th == pfb_h;
+        const bool hit = hit_a || hit_b;
+        uint32_t node_v = hit_a ? pfa_node : pfb_node;
+        if (!hit) node_v = node_load(th);
+        uint32_t row0 = hit_a ? pfa_val : pfb_val;
+        uint64_t vtid = 1;
+        uint32_t vvis = 1;
+        bool early = false;
+        uint32_t hslot0 = 0;
+        uint4 gbk0 = make_uint4(0, 0, 0, 0);
+        if (hit) {
+            if (VR == 0 && !BUILD) {
+                vtid = a.tids[node_v];
+                if (visible) vvis = visible[node_v];
+            }
+            if (gmode && (nins_g + WAVE) * 4u <= s.gcap * 3u) {
+                early = true;
+                hslot0 = ghash_home(row0);
+                const uint64_t inval0 = __ballot(row0 == VS_INVALID_NODE);
+                if ((uint32_t)lane < (inval0 ? (uint32_t)__builtin_ctzll(inval0) : WAVE)) gbk0 = bucket_load(hslot0);
+            }
+        }
         heap.pop();
         const uint32_t node = rfl(node_v);
         // what consume() will need to know about this node: requested now, folded into the ring entry at the insert below
-        uint64_t vtid = 1;
-        uint32_t vvis = 1;
-        if (VR == 0 && !BUILD) {
+        if (!hit && VR == 0 && !BUILD) {
             vtid = a.tids[node];
             if (visible) vvis = visible[node];
         }
         const uint32_t* nrow = a.nbrs + (size_t)node * a.nbr_stride;
-        uint32_t row0;
-        if (node == pfa_node) {
-            row0 = pfa_val;
-            (void)0;
-        } else if (node == pfb_node) {
-            row0 = pfb_val;
-            (void)0;
-        } else {
-            row0 = ((uint32_t)lane < a.R) ? nrow[lane] : VS_INVALID_NODE;
-        }
+        if (!hit) row0 = ((uint32_t)lane < a.R) ? nrow[lane] : VS_INVALID_NODE;
         lap(0);
         if (vis.len + 1 > vis.capacity()) {
             if (BUILD) vis.len = vis.capacity() - 1;  // build mode keeps the closest entries as prune candidates
@@ -1031,7 +1046,10 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
             const bool frozen = !gmode && nins + WAVE > slot_limit;
             uint32_t hslot = gmode ? ghash_home(nid) : hash_home(nid), old = VS_EMPTY;
             uint4 gbk = make_uint4(0, 0, 0, 0);
-            if (gmode) {
+            if (gmode && early && c0 == 0) {
+                hslot = hslot0;  // requested before the pop
+                gbk = gbk0;
+            } else if (gmode) {
                 if ((nins_g + WAVE) * 4u > s.gcap * 3u) { status |= OVF_HASH; break; }
                 if (act) gbk = bucket_load(hslot);  // in flight during the visited insert
             } else if (!frozen && act) {
@@ -1094,8 +1112,10 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
                 if (pass_i == 0 && !pfa_issued) {
                     pfa_issued = true;
                     pfa_node = VS_INVALID_NODE;
+                    pfa_h = 0xFFFFFFFFu;
                     if (root_after != 0xFFFFFFFFu) {
                         pfa_node = rfl(root_node_v);
+                        pfa_h = root_after & smask;
                         pfa_val = ((uint32_t)lane < a.R) ? a.nbrs[(size_t)pfa_node * a.nbr_stride + lane] : VS_INVALID_NODE;
                     }
                 }
@@ -1122,8 +1142,10 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
             if ((list_ended || c0 + WAVE >= a.R) && !pfb_issued) {
                 pfb_issued = true;
                 pfb_node = VS_INVALID_NODE;
+                pfb_h = 0xFFFFFFFFu;
                 if (best != 0xFFFFFFFFu && (best >> s.sb) < (root_after >> s.sb)) {
                     pfb_node = best_node;  // a candidate of this visit: its id is known without a table lookup
+                    pfb_h = best & smask;
                     pfb_val = ((uint32_t)lane < a.R) ? a.nbrs[(size_t)pfb_node * a.nbr_stride + lane] : VS_INVALID_NODE;
                 }
             }
@@ -1135,12 +1157,17 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
         if (!vis_done) vis.insert(hd, node, ((vtid & 0xFFFFull) == 0 ? VIS_DEAD : 0u) | (vvis == 0 ? VIS_HIDDEN : 0u));  // (an empty neighbor list)
         if (!pfa_issued) {  // nothing new to score: the old root is the next expansion
             pfa_node = VS_INVALID_NODE;
+            pfa_h = 0xFFFFFFFFu;
             if (root_after != 0xFFFFFFFFu) {
                 pfa_node = rfl(root_node_v);
+                pfa_h = root_after & smask;
                 pfa_val = ((uint32_t)lane < a.R) ? a.nbrs[(size_t)pfa_node * a.nbr_stride + lane] : VS_INVALID_NODE;
             }
         }
-        if (!pfb_issued) pfb_node = VS_INVALID_NODE;
+        if (!pfb_issued) {
+            pfb_node = VS_INVALID_NODE;
+            pfb_h = 0xFFFFFFFFu;
+        }
     }
     if (BUILD && VR == 0 && status == 0) {  // the visited list itself is the output (sorted by (hamming, recency))
         emitted = min(vis.len, s.M);

@@ -723,6 +723,9 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
     uint64_t* ring = reinterpret_cast<uint64_t*>(arb + ARB_SLOTS);    // vcap entries (VR == 0 only)
     int16_t* ql = reinterpret_cast<int16_t*>(ring + (VR > 0 ? 0 : s.vcap));  // MAX_QLABELS
     uint64_t* qc_l = reinterpret_cast<uint64_t*>(ql + MAX_QLABELS);   // code_stride words (NCH == 0 only)
+    // (optional) cache of ids known to be in the dedup table: a hit answers a duplicate probe without touching the table in HBM
+    uint32_t* rc = reinterpret_cast<uint32_t*>(qc_l + (NCH == 0 ? ((a.code_stride + 1u) & ~1u) : (NCH > 0 && MINW >= 6 ? 8u * (uint32_t)NCH : 0u)));
+    const uint32_t rcm = s.rc - 1u;  // (s.rc: 0 or a power of two)
 
     const int l4 = lane & 3;
     const bool stream_rows = !(s.flags & FAST_PLAIN_ROW_LOADS);
@@ -747,6 +750,7 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
         *reinterpret_cast<uint4*>(lhash + i) = make_uint4(VS_EMPTY, VS_EMPTY, VS_EMPTY, VS_EMPTY);
     if (lane == 0) hp[0] = 0;  // heap sentinel
     for (uint32_t i = lane; i < ARB_SLOTS; i += WAVE) arb[i] = 0;
+    for (uint32_t i = lane; i < s.rc; i += WAVE) rc[i] = VS_EMPTY;
     const uint8_t* const visible = FULL ? s.visible : nullptr;
     const bool labels_some = FULL && s.qlabel_off != nullptr;  // LabeledVector.labels is Some (AM/labels/mod.rs:222-236)
     uint32_t nql = 0;
@@ -1025,6 +1029,7 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
         bool early = false;
         uint32_t hslot0 = 0;
         uint4 gbk0 = make_uint4(0, 0, 0, 0);
+        bool rchit0 = false;  // this lane's id of the first chunk was found in the id cache
         if (hit) {
             if (VR == 0 && !BUILD) {
                 vtid = a.tids[node_v];
@@ -1034,7 +1039,8 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
                 early = true;
                 hslot0 = ghash_home(row0);
                 const uint64_t inval0 = __ballot(row0 == VS_INVALID_NODE);
-                if ((uint32_t)lane < (inval0 ? (uint32_t)__builtin_ctzll(inval0) : WAVE)) gbk0 = bucket_load(hslot0);
+                if (s.rc) rchit0 = rc[hash_u32(row0 ^ 0x9e3779b9u) & rcm] == row0;
+                if ((uint32_t)lane < (inval0 ? (uint32_t)__builtin_ctzll(inval0) : WAVE) && !rchit0) gbk0 = bucket_load(hslot0);
             }
         }
         heap.pop();
@@ -1074,12 +1080,15 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
             const bool frozen = !gmode && nins + WAVE > slot_limit;
             uint32_t hslot = gmode ? ghash_home(nid) : hash_home(nid), old = VS_EMPTY;
             uint4 gbk = make_uint4(0, 0, 0, 0);
+            bool rchit = false;
             if (gmode && early && c0 == 0) {
                 hslot = hslot0;  // requested before the pop
                 gbk = gbk0;
+                rchit = rchit0;
             } else if (gmode) {
                 if ((nins_g + WAVE) * 4u > s.gcap * 3u) { status |= OVF_HASH; break; }
-                if (act) gbk = bucket_load(hslot);  // in flight during the visited insert
+                if (s.rc && act) rchit = rc[hash_u32(nid ^ 0x9e3779b9u) & rcm] == nid;
+                if (act && !rchit) gbk = bucket_load(hslot);  // in flight during the visited insert
             } else if (!frozen && act) {
                 old = atomicCAS(&lhash[hslot], VS_EMPTY, nid);
             }
@@ -1092,7 +1101,8 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
             // ... then the probe sequence is finished
             bool fresh;
             if (gmode) {
-                fresh = global_insert(nid, act, hslot, gbk, hslot);
+                fresh = global_insert(nid, act && !rchit, hslot, gbk, hslot);
+                if (s.rc && act && !rchit) rc[hash_u32(nid ^ 0x9e3779b9u) & rcm] = nid;  // (now in the table, new or not)
             } else if (frozen) {
                 fresh = frozen_insert(nid, act, hslot);
                 if (status) break;
@@ -1248,7 +1258,7 @@ size_t fast_lds_bytes(const vs_index* idx, const FastLaunch& s) {
     const size_t nch = (idx->code_stride + 7) / 8;
     // LDS copy of the query code: the generic variant (NCH == 0), and the register-capped variants (minw >= 6: 8 NCH words, zero padded)
     const size_t qcopy = nch > 6 ? (size_t)idx->code_stride * 8 : (s.minw >= 6 && !s.build && !s.phase ? nch * 64 : 0);
-    size_t b = (size_t)(s.hl + 1) * 4 + (size_t)s.lh * 4 + 3 * 64 * 4 + ARB_SLOTS * 4 + (s.vr ? 0 : (size_t)s.vcap * 8) + MAX_QLABELS * 2 + qcopy + 16;
+    size_t b = (size_t)(s.hl + 1) * 4 + (size_t)s.lh * 4 + 3 * 64 * 4 + ARB_SLOTS * 4 + (s.vr ? 0 : (size_t)s.vcap * 8) + MAX_QLABELS * 2 + qcopy + (size_t)s.rc * 4 + 32;
     return (b + 15) / 16 * 16;
 }
 

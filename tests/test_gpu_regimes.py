@@ -18,6 +18,8 @@ REGIMES = {
     "frozen_overflow": {"VS_F_LH": "256"},
     "lds_ring_small": {"VS_F_VR": "0", "VS_F_VCAP": "64"},
     "heap_spill": {"VS_F_HL": "63"},
+    # table-less with a small LDS cache of ids known to be in the table in front of it (duplicate probes answered on chip)
+    "tableless_idcache": {"VS_F_LDS_MAX_INS": "0", "VS_F_RC": "128"},
     "heap_spill_tableless": {"VS_F_HL": "63", "VS_F_LDS_MAX_INS": "0"},
     "tiny_pool": {"VS_F_LH": "256", "VS_F_POOL": "0.01"},
     # dedup table too small for most scans: they are finished by the second attempt of k_search_fast (four times the table) ...

@@ -305,7 +305,7 @@ extern "C" void vs_index_free(vs_index* ix) {
     (void)hipSetDevice(ix->ctx->device);
     (void)hipStreamSynchronize(ix->ctx->stream);
     void* ptrs[] = {ix->codes, ix->nbrs, ix->tids, ix->vecs, ix->vnorm, ix->vnorm_idx, ix->mean, ix->m2, ix->visible_own,
-                    ix->label_off, ix->label_val, ix->ls_labels, ix->ls_nodes};
+                    ix->label_off, ix->label_val, ix->label_mask, ix->ls_labels, ix->ls_nodes};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     SearchWorkspace& w = ix->ws;
@@ -401,7 +401,7 @@ static int vs_index_set_labels_impl(vs_index* ix, const uint32_t* label_off, con
     VS_TRY(vs_dev_upload(ix->ctx, ix->label_off, label_off, ((size_t)n + 1) * 4));
     if (ix->n_label_vals) VS_TRY(vs_dev_upload(ix->ctx, ix->label_val, label_val, ix->n_label_vals * 2));
     ix->d.has_labels = 1;
-    return VS_OK;
+    return vs_refresh_label_masks(ix);
 }
 extern "C" int vs_index_set_labels(vs_index* ix, const uint32_t* label_off, const int16_t* label_val) {
     return vs_guard("vs_index_set_labels", [&] { return vs_index_set_labels_impl(ix, label_off, label_val); });

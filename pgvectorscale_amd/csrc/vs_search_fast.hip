@@ -43,6 +43,7 @@ struct FastArgs {
     const uint64_t* tids;
     const uint32_t* label_off;
     const int16_t* label_val;
+    const uint64_t* label_mask;  // may be null
     const int16_t* ls_labels;
     const uint32_t* ls_nodes;
     uint32_t code_stride, nbr_stride, R, n, n_ls, default_start;
@@ -761,6 +762,14 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
     }
     const bool has_label_filter = labels_some && nql > 0;  // AM/scan.rs:189
     wave_sync();
+    // the query's labels as a mask, for an index whose node label sets are masks (all labels in 0..63): a query label outside that
+    // range cannot be in any node's set and simply contributes no bit
+    uint64_t qmask = 0;
+    if (has_label_filter && a.label_mask)
+        for (uint32_t i = 0; i < nql; ++i) {
+            const int v = ql[i];
+            if (v >= 0 && v < 64) qmask |= 1ull << v;
+        }
 
     FastHeap<(MINW >= 7)> heap;
     heap.l = hp;
@@ -1112,7 +1121,9 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
             st_reads += (uint32_t)__popcll(__ballot(fresh));  // SbqNode::read(neighbor)
             // label filter: query.labels.overlaps(node.labels) (AM/labels/mod.rs:124-142)
             bool pass = fresh;
-            if (has_label_filter && fresh) {
+            if (has_label_filter && a.label_mask) {
+                if (fresh) pass = (a.label_mask[nid] & qmask) != 0;
+            } else if (has_label_filter && fresh) {
                 const uint32_t lb = a.label_off[nid], le = a.label_off[nid + 1];
                 uint32_t i = 0, j = lb;
                 bool ov = false;
@@ -1312,6 +1323,7 @@ int launch_search_fast(vs_index* idx, const FastLaunch& s) {
     a.tids = idx->tids;
     a.label_off = idx->label_off;
     a.label_val = idx->label_val;
+    a.label_mask = idx->label_mask;
     a.ls_labels = idx->ls_labels;
     a.ls_nodes = idx->ls_nodes;
     a.code_stride = idx->code_stride;

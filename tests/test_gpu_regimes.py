@@ -167,3 +167,31 @@ def test_heavy_ties_deep_heap(gpu_ctx, regime):
             else:
                 os.environ[k] = v
         ix.close()
+
+
+# label sets: an index whose labels all lie in 0..63 is filtered through 64-bit masks, any other through the sorted merge
+@pytest.mark.parametrize("n_labels", [40, 100])
+def test_label_filter_masks_and_merge(gpu_ctx, n_labels):
+    ti = cached_index(n=2500, dim_full=64, bits=2, R=32, distance=1, seed=51, kind="gauss", L_build=60, n_labels=n_labels)
+    ix = ti.upload(gpu_ctx)
+    try:
+        q = ti.queries(64, seed=3, kind="gauss")
+        rng = np.random.default_rng(8)
+        qlabels = [sorted(set(int(v) for v in rng.integers(1, n_labels + 1, int(rng.integers(1, 4))))) for _ in range(len(q))]
+        qlabels[0] = [1, 70] if n_labels > 63 else [1, 39]
+        for regime in ("default", "tableless"):
+            saved = {k: os.environ.get(k) for k in REGIMES[regime]}
+            try:
+                os.environ.update(REGIMES[regime])
+                oi, oh, ost = ti.oracle.stream_batch(q, L=50, m=40, qlabels=qlabels)
+                gi, gh, gst = ix.stream_batch(q, search_list_size=50, m=40, qlabels=qlabels)
+                assert (gi == oi).all() and (gh == oh).all()
+                assert gst["quantized_distance_comparisons"] == ost["quantized_distance_comparisons"]
+            finally:
+                for k, v in saved.items():
+                    if v is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = v
+    finally:
+        ix.close()

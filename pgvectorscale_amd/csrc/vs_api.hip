@@ -305,7 +305,7 @@ extern "C" void vs_index_free(vs_index* ix) {
     (void)hipSetDevice(ix->ctx->device);
     (void)hipStreamSynchronize(ix->ctx->stream);
     void* ptrs[] = {ix->codes, ix->nbrs, ix->tids, ix->vecs, ix->vnorm, ix->vnorm_idx, ix->mean, ix->m2, ix->visible_own,
-                    ix->label_off, ix->label_val, ix->ls_labels, ix->ls_nodes};
+                    ix->label_off, ix->label_val, ix->label_mask, ix->ls_labels, ix->ls_nodes};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     SearchWorkspace& w = ix->ws;
@@ -401,7 +401,7 @@ static int vs_index_set_labels_impl(vs_index* ix, const uint32_t* label_off, con
     VS_TRY(vs_dev_upload(ix->ctx, ix->label_off, label_off, ((size_t)n + 1) * 4));
     if (ix->n_label_vals) VS_TRY(vs_dev_upload(ix->ctx, ix->label_val, label_val, ix->n_label_vals * 2));
     ix->d.has_labels = 1;
-    return VS_OK;
+    return vs_refresh_label_masks(ix);
 }
 extern "C" int vs_index_set_labels(vs_index* ix, const uint32_t* label_off, const int16_t* label_val) {
     return vs_guard("vs_index_set_labels", [&] { return vs_index_set_labels_impl(ix, label_off, label_val); });
@@ -942,6 +942,8 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
         f.lh = caps.f_lh;
         f.minw = env_u32("VS_F_MINW", caps.f_lh == 0 ? (caps.f_vr ? 4 : 6) : 1);
         f.flags = env_u32("VS_F_FLAGS", 0);
+        f.rc = caps.f_lh == 0 ? env_u32("VS_F_RC", 0) : 0;  // (measurement: LDS id cache in front of the dedup table in HBM)
+        if (f.rc) f.rc = next_pow2_u32(f.rc);
         f.visible = (!bp.stream_only && bp.rescore > 0) ? ix->visible : nullptr;  // the heap is only fetched for the rescore window
         f.sb = caps.f_sb;
         f.vcap = caps.f_vcap;

@@ -493,3 +493,57 @@ extern "C" int vs_bruteforce_topk(vs_index* ix, const float* d_queries, uint32_t
     }
     return VS_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Label sets as 64-bit masks (an index whose labels all lie in 0..63 — the usual smallint tags): the overlap test of the scan
+// (LabelSetView::overlaps, AM/labels/mod.rs:124-142) becomes one 8-byte load and an AND instead of two dependent loads and a merge.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_label_masks(const uint32_t* __restrict__ off, const int16_t* __restrict__ val, uint32_t n,
+                                                     uint64_t* __restrict__ mask, uint32_t* __restrict__ out_of_range) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t m = 0;
+    bool bad = false;
+    for (uint32_t j = off[i]; j < off[i + 1]; ++j) {
+        const int v = val[j];
+        if (v < 0 || v > 63) bad = true;
+        else m |= 1ull << v;
+    }
+    mask[i] = m;
+    if (bad) atomicOr(out_of_range, 1u);
+}
+
+int vs_refresh_label_masks(vs_index* ix) {
+    vs_ctx* c = ix->ctx;
+    if (ix->label_mask) {
+        VS_HIP(hipFree(ix->label_mask));
+        ix->label_mask = nullptr;
+    }
+    if (!ix->label_off || !ix->label_val || ix->d.n == 0) return VS_OK;
+    uint64_t* m = nullptr;
+    uint32_t* flag = nullptr;
+    VS_HIP(hipMalloc(&m, (size_t)ix->d.n * 8));
+    if (hipMalloc(&flag, 4) != hipSuccess) {
+        (void)hipFree(m);
+        vs_set_error("out of device memory");
+        return VS_ERR_OOM;
+    }
+    (void)hipMemsetAsync(flag, 0, 4, c->stream);
+    hipLaunchKernelGGL(k_label_masks, dim3((ix->d.n + 255) / 256), dim3(256), 0, c->stream, ix->label_off, ix->label_val, ix->d.n, m, flag);
+    uint32_t h = 1;
+    const hipError_t e1 = hipGetLastError();
+    const hipError_t e2 = hipMemcpyAsync(&h, flag, 4, hipMemcpyDeviceToHost, c->stream);
+    const hipError_t e3 = hipStreamSynchronize(c->stream);
+    (void)hipFree(flag);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || h) {  // (a label outside 0..63: the scans keep the merge)
+        (void)hipFree(m);
+        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
+            vs_set_error("k_label_masks failed");
+            return VS_ERR_HIP;
+        }
+        return VS_OK;
+    }
+    ix->label_mask = m;
+    return VS_OK;
+}

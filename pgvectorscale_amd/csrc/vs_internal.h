@@ -134,6 +134,7 @@ struct vs_index {
     uint64_t count = 0;
     uint32_t* label_off = nullptr;
     int16_t* label_val = nullptr;
+    uint64_t* label_mask = nullptr;  // per node: bit l set <=> label l in its set; only when every label of the index is in 0..63
     uint64_t n_label_vals = 0;
     int16_t* ls_labels = nullptr;
     uint32_t* ls_nodes = nullptr;
@@ -147,6 +148,7 @@ int devbuf_reserve(vs_ctx* ctx, DevBuf& b, size_t bytes);
 // row-wise staging through the pinned ring (device rows may be wider than host rows) / neighbor-list validation
 int vs_upload_rows(vs_ctx* c, void* dst, size_t dev_row_bytes, const void* src, size_t host_row_bytes, size_t copy_bytes, size_t rows);
 int vs_validate_graph(vs_index* ix);
+int vs_refresh_label_masks(vs_index* ix);  // (re)derives label_mask from the label CSR, or drops it when a label is outside 0..63
 void devbuf_free(DevBuf& b);
 
 // ---- kernel launch wrappers (defined in the .hip files) -------------------------------------------------------
@@ -186,6 +188,7 @@ struct FastLaunch {
     uint32_t vr;       // visited list: 8 = eight register pairs (512 entries), 0 = LDS ring of vcap entries
     uint32_t vcap;     // visited ring capacity (vr == 0)
     uint32_t minw;     // register cap variant: waves per SIMD to leave room for (1 = unconstrained)
+    uint32_t rc = 0;   // entries of the LDS cache of ids known to be in the table (table-less regime; 0 or a power of two)
     uint32_t build = 0; // 1: greedy_search_for_build (the visited list is the output; needs vr == 0)
     uint32_t flags = 0; // FAST_* (measurement switches)
     // second attempt of the scans a first launch gave up on (bigger capacities): only scans whose status[q] != 0 run, their

@@ -313,6 +313,7 @@ extern "C" int vs_pages_dev_build(vs_pages_dev* d, const vs_index_desc* desc, co
                 hip_ok(hipStreamSynchronize(c->stream), "k_pages_labels");
                 ix->n_label_vals = tot;
                 ix->d.has_labels = 1;
+                if (r == VS_OK) r = vs_refresh_label_masks(ix);
             }
         }
     }

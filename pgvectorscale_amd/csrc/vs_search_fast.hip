@@ -43,6 +43,7 @@ struct FastArgs {
     const uint64_t* tids;
     const uint32_t* label_off;
     const int16_t* label_val;
+    const uint64_t* label_mask;  // may be null
     const int16_t* ls_labels;
     const uint32_t* ls_nodes;
     uint32_t code_stride, nbr_stride, R, n, n_ls, default_start;
@@ -212,6 +213,145 @@ struct FastHeap {
         if (idx <= (p1l >> wl_rank())) anc = p1l > hl ? get1(idx) : l[idx];
         return anc;
     }
+    // ---- a run of n pushes, level by level instead of element by element -------------------------------------------------
+    // A push is also a walk DOWN the root-to-leaf path with the element in hand: at the first node whose key is greater the
+    // element stays and the node's old value is carried on, and from there on every node takes what is carried and hands its own
+    // value down (that is sift_up's shift of the path by one position; "at the first greater key" is where sift_up stops
+    // climbing).  Read that way, what push i meets at a node depends only on the pushes before it at that node and on what it
+    // was handed from above — so all pushes of the run can do one LEVEL at a time.  At a node the pushes of its leaves arrive
+    // in leaf order; the node holds the minimum seen so far (a carried value wins ties, an element loses them), i.e. an
+    // exclusive prefix minimum inside the node's block of leaves seeded with the node's original value, and a push hands down
+    // the loser of (what it brought, what the node held).  Lanes are the leaves (lane = leaf index mod 32-aligned window, so
+    // the leaves of a rank-k node are an aligned block of 2^k lanes); ranks 1..5 are done this way, which settles everything
+    // that stays inside the 32-leaf subtrees.  The few elements small enough to get above rank 5 first walk the part of the
+    // path above it one after another (the chain-in-registers loop, with the rank-5 node in the role of the leaf).
+    __device__ __forceinline__ void push_run_scan(uint32_t entry, uint32_t j, uint32_t n, uint32_t anc, bool spill) {
+        const uint32_t IDENT = 0xFFFFFFFFu;
+        const uint32_t p1f = len + 1;
+        const uint32_t off = p1f & 31u;
+        // where ranks 0..5 of the run live: all in the spill array (the usual case of a deep heap), mixed, or all in LDS
+        const bool deep = (p1f >> 5) > hl;
+        auto put = [&](uint32_t idx, uint32_t v) {
+            if (deep) gstore32(g + (idx - 1 - hl), v);
+            else if (spill) set1(idx, v);
+            else l[idx] = v;
+        };
+        const uint32_t i = (uint32_t)lane - off;            // this lane's element (leaf order); >= n: not a leaf of the run
+        const bool in = i < n;
+        const uint32_t p1 = (p1f & ~31u) + (uint32_t)lane;  // its leaf (position + 1)
+        uint32_t c = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((j + i) << 2), (int)entry);  // what the push carries
+        // original value of the leaf's ancestor of rank k (wide-load lane layout, see push_run)
+        auto anc_of = [&](uint32_t rank, uint32_t base) -> uint32_t {
+            return (uint32_t)__builtin_amdgcn_ds_bpermute((int)((base + (p1 >> rank) - (p1f >> rank)) << 2), (int)anc);
+        };
+        // deepest rank (<= 5) any element can reach against the ORIGINAL ancestors (values only fall during the run), and the
+        // elements that can get above rank 5 (bit e <-> element e).  (The ancestors are fetched again level by level below:
+        // registers are what this kernel is short of.)
+        uint32_t K = 0, hm;
+        {
+            const uint32_t kc = in ? c >> sb : IDENT;  // (every lane takes part in the fetches: they are cross-lane operations)
+            auto below = [&](uint32_t rank, uint32_t base) -> uint64_t {
+                const uint32_t ak = anc_of(rank, base);
+                return __ballot(kc < (ak >> sb));
+            };
+            if (below(1, 0)) K = 1;
+            if (K == 1 && below(2, 17)) K = 2;
+            if (K == 2 && below(3, 26)) K = 3;
+            if (K == 3 && below(4, 31)) K = 4;
+            if (K == 4 && below(5, 34)) K = 5;
+            hm = K == 5 ? (uint32_t)(below(6, 36) >> off) : 0u;
+        }
+        bool forced = false;
+        // ---- above rank 5: the elements that can get there, one after another
+        if (hm) {
+            const uint32_t r = (uint32_t)lane;  // chain lane r <-> rank 5 + r (lane 0: what is handed down to rank 5)
+            const uint32_t keymask = (1u << sb) - 1u;
+            const uint32_t rsh = (5u + r) & 31u;
+            const uint32_t fbase4 = (34u + 2u * r - (p1f >> rsh)) << 2;
+            auto fresh_of = [&](uint32_t pp) -> uint32_t {
+                return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((pp >> rsh) << 2) + fbase4), (int)anc);
+            };
+            uint32_t chain = fresh_of(p1f + (uint32_t)__builtin_ctz(hm));
+            asm volatile("" : "+v"(chain));
+            while (hm) {
+                const uint32_t e = (uint32_t)__builtin_ctz(hm);
+                hm &= hm - 1;
+                const uint32_t elem = readlane_u32(entry, j + e);
+                const uint32_t pp = p1f + e;
+                const uint32_t ppn = p1f + (uint32_t)__builtin_ctz(hm | 0x80000000u);
+                const uint32_t nxt = fresh_of(ppn);
+                const bool cmp = (elem | keymask) < chain;
+                const uint32_t bal = ((uint32_t)__ballot(cmp) >> 1) & 0x3FFFu;  // bit r-1 <-> rank 5 + r (ranks 6..19)
+                const uint32_t t = (uint32_t)__builtin_ctz(~bal);
+                const uint32_t up = wave_shl1(chain, 0);
+                const uint32_t patched = r < t ? up : (r == t ? elem : chain);  // lane 0: the old rank-6 value when t >= 1
+                if (r >= 1 && r <= t) {
+                    const uint32_t dst = pp >> rsh;
+                    if (spill) set1(dst, patched);
+                    else l[dst] = patched;
+                }
+                const uint32_t out = readlane_u32(patched, 0);
+                if ((uint32_t)lane == off + e && t >= 1) {
+                    c = out;
+                    forced = true;
+                }
+                const uint32_t shr = 32u - (uint32_t)__builtin_clz((pp ^ ppn) | 1u);  // ranks >= shr are shared (|1: clz(0))
+                chain = 5u + r >= shr ? patched : nxt;
+            }
+            if (__ballot(forced)) K = 5;
+        }
+        // ---- ranks 5..1, all leaves at once
+        auto level = [&](const uint32_t k, const uint32_t base) {
+            const uint32_t B1 = (1u << k) - 1u;
+            const uint32_t ak = anc_of(k, base);  // the node's original value
+            const uint32_t comp = in ? (((c >> sb) << 7) | (forced ? 63u - i : 65u + i)) : IDENT;
+            // exclusive prefix minimum inside the aligned block of 2^k lanes
+            uint32_t x = wave_shr1(comp, IDENT);
+            if (((uint32_t)lane & B1) == 0) x = IDENT;
+            if (k >= 2) {
+                uint32_t t1 = (uint32_t)__builtin_amdgcn_update_dpp((int)IDENT, (int)x, 0x111, 0xF, 0xF, false);
+                if (B1 < 15u && ((uint32_t)lane & B1) < 1u) t1 = IDENT;
+                x = min(x, t1);
+                uint32_t t2 = (uint32_t)__builtin_amdgcn_update_dpp((int)IDENT, (int)x, 0x112, 0xF, 0xF, false);
+                if (B1 < 15u && ((uint32_t)lane & B1) < 2u) t2 = IDENT;
+                x = min(x, t2);
+            }
+            if (k >= 3) {
+                uint32_t t4 = (uint32_t)__builtin_amdgcn_update_dpp((int)IDENT, (int)x, 0x114, 0xF, 0xF, false);
+                if (B1 < 15u && ((uint32_t)lane & B1) < 4u) t4 = IDENT;
+                x = min(x, t4);
+            }
+            if (k >= 4) {
+                const uint32_t t8 = (uint32_t)__builtin_amdgcn_update_dpp((int)IDENT, (int)x, 0x118, 0xF, 0xF, false);
+                x = min(x, t8);
+            }
+            if (k >= 5) {
+                const uint32_t t16 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((((uint32_t)lane & ~31u) + 15u) << 2), (int)x);
+                if ((uint32_t)lane & 16u) x = min(x, t16);
+            }
+            const uint32_t cur = min(x, ((ak >> sb) << 7) | 64u);  // what the node holds when this push arrives
+            const uint32_t tb = cur & 127u;
+            const uint32_t src = (tb < 64u ? 63u - tb : tb - 65u) + off;  // lane of the push that brought it
+            const uint32_t hv = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)c);
+            const uint32_t curv = tb == 64u ? ak : hv;
+            const bool wins = in && comp < cur;
+            const bool last = in && ((((uint32_t)lane & B1) == B1) || i + 1 == n);  // last push of the node: its final value
+            if (last) {
+                const uint32_t fin = wins ? c : curv;
+                if (fin != ak) put(p1 >> k, fin);
+            }
+            if (wins) {
+                c = curv;
+                forced = true;
+            }
+        };
+        if (K >= 5) level(5, 34);
+        if (K >= 4) level(4, 31);
+        if (K >= 3) level(3, 26);
+        if (K >= 2) level(2, 17);
+        if (K >= 1) level(1, 0);
+        if (in) put(p1, c);
+    }
     // pre_n / pre_anc: a wide load the caller already issued for the first run (pre_n = first_run(c)), or pre_n = 0
     __device__ __forceinline__ void push_run(uint32_t entry, uint32_t c, uint32_t pre_n, uint32_t pre_anc) {
         uint32_t j = 0;
@@ -229,12 +369,19 @@ struct FastHeap {
             const bool spill = p1l > hl;  // some leaf (hence possibly some parent) lives in the spill array
             // ---- wide load of every distinct ancestor of the run (the first run's may already be in flight)
             const uint32_t anc = (j == 0 && pre_n == n) ? pre_anc : wide_load(n);
-            const uint32_t r = (uint32_t)lane;       // chain lane = ancestor rank (lane 0 and lanes > 20 unused)
-            const bool rank_ok = r >= 1 && r <= 19;
-            auto fresh_of = [&](uint32_t p1) -> uint32_t {  // rank-r ancestor of leaf p1 as loaded at the start of the run
-                const uint32_t src = wl_base() + ((p1 >> (r & 31u)) - (p1f >> (r & 31u)));
-                const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((rank_ok ? src : 0u) << 2), (int)anc);
-                return rank_ok ? v : 0u;
+            if (n >= 6) {  // level by level; short runs cost less element by element
+                push_run_scan(entry, j, n, anc, spill);
+                j += n;
+                len += n;
+                wave_sync();
+                continue;
+            }
+            const uint32_t r = (uint32_t)lane;  // chain lane = ancestor rank (ranks 1..19 are ancestors; lane 0 stands for the leaf)
+            // rank-r ancestor of leaf p1 as loaded at the start of the run: wide-load lane wl_base(r) + (p1 >> r) - (p1f >> r)
+            // (any lane index is a legal bpermute source; what lanes without a rank read is never used)
+            const uint32_t fbase4 = (wl_base() - (p1f >> (r & 31u))) << 2;
+            auto fresh_of = [&](uint32_t p1) -> uint32_t {
+                return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((p1 >> (r & 31u)) << 2) + fbase4), (int)anc);
             };
             // An element that is not smaller than the ORIGINAL parent of its leaf stays on the leaf whatever the earlier
             // pushes of the run do (a push only ever lowers the values on its path: a position receives the pushed element or
@@ -246,34 +393,37 @@ struct FastHeap {
             const uint32_t par = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((myp1 >> 1) - (p1f >> 1)) << 2), (int)anc);
             const bool inrun = (uint32_t)lane < n;
             const bool climbs = inrun && (mine >> sb) < (par >> sb);
-            uint64_t cm = __ballot(climbs);
+            uint32_t cm = (uint32_t)__ballot(climbs);  // (n <= 32)
             if (inrun && !climbs) {
                 if (spill) set1(myp1, mine);
                 else l[myp1] = mine;
             }
             if (cm) {
-                uint32_t p1 = p1f + (uint32_t)__builtin_ctzll(cm);
-                uint32_t chain = fresh_of(p1);
+                const uint32_t keymask = (1u << sb) - 1u;
+                uint32_t chain = fresh_of(p1f + (uint32_t)__builtin_ctz(cm));
                 asm volatile("" : "+v"(chain));  // the chain is complete before the loop
                 while (cm) {
-                    const uint32_t e = (uint32_t)__builtin_ctzll(cm);
+                    const uint32_t e = (uint32_t)__builtin_ctz(cm);
                     cm &= cm - 1;
                     const uint32_t elem = readlane_u32(entry, j + e);
-                    p1 = p1f + e;
-                    const uint32_t p1n = cm ? p1f + (uint32_t)__builtin_ctzll(cm) : p1 + 1;  // next climber's leaf
-                    const uint32_t nxt = fresh_of(p1n);  // in flight during this push (unused after the last climber)
-                    const bool cmp = (elem >> sb) < (chain >> sb);
-                    const uint32_t bal = ((uint32_t)__ballot(cmp) & 0xFFFFEu) >> 1;  // bit r-1 <-> ancestor r (ranks 1..19)
-                    const uint32_t t = (uint32_t)__builtin_ctz(~bal);                   // leading run of ancestors that move down
-                    if (r <= t) {
-                        const uint32_t dst = r == 0 ? (p1 >> t) : (p1 >> (r - 1));
-                        const uint32_t val = r == 0 ? elem : chain;
-                        if (spill) set1(dst, val);
-                        else l[dst] = val;
-                    }
-                    const uint32_t sh = 32u - (uint32_t)__builtin_clz(p1 ^ p1n);
+                    const uint32_t p1 = p1f + e;
+                    const uint32_t p1n = p1f + (uint32_t)__builtin_ctz(cm | 0x80000000u);  // next climber's leaf (any leaf after the last)
+                    const uint32_t nxt = fresh_of(p1n);  // in flight during this push
+                    // key(elem) < key(chain)  <=>  (elem | keymask) < chain   (keys are the bits above the slot handle)
+                    const bool cmp = (elem | keymask) < chain;
+                    const uint32_t bal = ((uint32_t)__ballot(cmp) >> 1) & 0x7FFFFu;  // bit r-1 <-> ancestor r (ranks 1..19)
+                    const uint32_t t = (uint32_t)__builtin_ctz(~bal);                  // leading run of ancestors that move down
+                    // after the push position p1 >> k holds the old rank k+1 value for k < t and the element for k == t: lane k
+                    // writes it, and the same values are the chain the next push sees from rank sh upwards
                     const uint32_t up = wave_shl1(chain, 0);  // rank r+1 value
                     const uint32_t patched = r < t ? up : (r == t ? elem : chain);
+                    if (r <= t) {
+                        const uint32_t dst = p1 >> (r & 31u);
+                        if ((p1 >> t) > hl) gstore32(g + (dst - 1 - hl), patched);  // (wave-uniform) the whole path is in the spill array
+                        else if (spill) set1(dst, patched);
+                        else l[dst] = patched;
+                    }
+                    const uint32_t sh = 32u - (uint32_t)__builtin_clz(p1 ^ p1n);
                     chain = r >= sh ? patched : nxt;
                 }
             }
@@ -335,6 +485,10 @@ struct FastHeap {
             }
             pkey = readlane_u32(cv, jd) >> sb;
             root = 2 * ad + 1 + (uint32_t)((B >> jd) & 1ull);  // jd is on the subtree's last level: descend
+            if (2 * root + 1 >= end) {  // ... unless the child is a leaf (a heap of 4096..8190 entries ends every path here)
+                pos = root;
+                break;
+            }
         }
         // sift_up(0, pos) of the former last element: it only moves when it is smaller than the new parent value
         const uint32_t item = rfl(item_v);
@@ -508,6 +662,34 @@ __device__ __forceinline__ uint32_t ham_row_reg(const uint64_t* __restrict__ row
     return ham_row4(row, qc_l, l4, code_stride, active);
 }
 
+// ham_row_reg with independent work (`mid`) placed between the issue of the row loads and their first use
+template <int NCH, bool QL, class F>
+__device__ __forceinline__ uint32_t ham_row_reg_mid(const uint64_t* __restrict__ row, const ulonglong2 (&qv)[NCH > 0 ? NCH : 1],
+                                                    const uint64_t* qc_l, int l4, uint32_t code_stride, bool active, bool stream,
+                                                    F&& mid) {
+    if (NCH == 0) {
+        mid();
+        return ham_row4(row, qc_l, l4, code_stride, active);
+    }
+    ulonglong2 r[NCH > 0 ? NCH : 1];
+#pragma unroll
+    for (int t = 0; t < NCH; ++t) {
+        const uint32_t w = 2u * (uint32_t)l4 + 8u * (uint32_t)t;
+        r[t] = (!active || w >= code_stride) ? make_ulonglong2(0, 0)
+               : stream ? load_stream16(row + w) : *reinterpret_cast<const ulonglong2*>(row + w);
+    }
+    mid();
+    uint32_t acc = 0;
+#pragma unroll
+    for (int t = 0; t < NCH; ++t) {
+        const uint32_t w = 2u * (uint32_t)l4 + 8u * (uint32_t)t;
+        ulonglong2 qq = QL ? *reinterpret_cast<const ulonglong2*>(qc_l + w) : qv[t];
+        if (w >= code_stride) qq = make_ulonglong2(0, 0);
+        acc += (uint32_t)__popcll(r[t].x ^ qq.x) + (uint32_t)__popcll(r[t].y ^ qq.y);
+    }
+    return quad_sum(active ? acc : 0u);
+}
+
 // minimum over the wave (DPP row reduction + 4 readlanes; no LDS)
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
     v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x111 /*row_shr:1*/, 0xF, 0xF, false));
@@ -542,10 +724,13 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
     uint64_t* ring = reinterpret_cast<uint64_t*>(arb + ARB_SLOTS);    // vcap entries (VR == 0 only)
     int16_t* ql = reinterpret_cast<int16_t*>(ring + (VR > 0 ? 0 : s.vcap));  // MAX_QLABELS
     uint64_t* qc_l = reinterpret_cast<uint64_t*>(ql + MAX_QLABELS);   // code_stride words (NCH == 0 only)
+    // (optional) cache of ids known to be in the dedup table: a hit answers a duplicate probe without touching the table in HBM
+    uint32_t* rc = reinterpret_cast<uint32_t*>(qc_l + (NCH == 0 ? ((a.code_stride + 1u) & ~1u) : (NCH > 0 && MINW >= 6 ? 8u * (uint32_t)NCH : 0u)));
+    const uint32_t rcm = s.rc - 1u;  // (s.rc: 0 or a power of two)
 
     const int l4 = lane & 3;
     const bool stream_rows = !(s.flags & FAST_PLAIN_ROW_LOADS);
-    constexpr bool QL = NCH > 0 && MINW >= 7;
+    constexpr bool QL = NCH > 0 && MINW >= 6;
     ulonglong2 qv[NCH > 0 ? NCH : 1];
     if (QL) {
         qv[0] = make_ulonglong2(0, 0);
@@ -566,6 +751,7 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
         *reinterpret_cast<uint4*>(lhash + i) = make_uint4(VS_EMPTY, VS_EMPTY, VS_EMPTY, VS_EMPTY);
     if (lane == 0) hp[0] = 0;  // heap sentinel
     for (uint32_t i = lane; i < ARB_SLOTS; i += WAVE) arb[i] = 0;
+    for (uint32_t i = lane; i < s.rc; i += WAVE) rc[i] = VS_EMPTY;
     const uint8_t* const visible = FULL ? s.visible : nullptr;
     const bool labels_some = FULL && s.qlabel_off != nullptr;  // LabeledVector.labels is Some (AM/labels/mod.rs:222-236)
     uint32_t nql = 0;
@@ -576,6 +762,14 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
     }
     const bool has_label_filter = labels_some && nql > 0;  // AM/scan.rs:189
     wave_sync();
+    // the query's labels as a mask, for an index whose node label sets are masks (all labels in 0..63): a query label outside that
+    // range cannot be in any node's set and simply contributes no bit
+    uint64_t qmask = 0;
+    if (has_label_filter && a.label_mask)
+        for (uint32_t i = 0; i < nql; ++i) {
+            const int v = ql[i];
+            if (v >= 0 && v < 64) qmask |= 1ull << v;
+        }
 
     FastHeap<(MINW >= 7)> heap;
     heap.l = hp;
@@ -776,8 +970,8 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
     // Neighbor rows are requested ahead of the pop that needs them: slot A = the heap root left by the last pop (asked
     // for together with the code gather, so both latencies overlap), slot B = the best new candidate when it beats that
     // root (asked for as soon as its distance is known; the pushes / pop / visited insert cover the latency).
-    uint32_t pfa_node = VS_INVALID_NODE, pfa_val = VS_INVALID_NODE;
-    uint32_t pfb_node = VS_INVALID_NODE, pfb_val = VS_INVALID_NODE;
+    uint32_t pfa_node = VS_INVALID_NODE, pfa_val = VS_INVALID_NODE, pfa_h = 0xFFFFFFFFu;  // (_h: the node's dedup handle)
+    uint32_t pfb_node = VS_INVALID_NODE, pfb_val = VS_INVALID_NODE, pfb_h = 0xFFFFFFFFu;
 
     // ---- TSVResponseIterator::next until M rows are emitted (AM/scan.rs:210-242), flattened: every iteration is
     // either one visit_closest() expansion (greedy_search_iterate, AM/graph/mod.rs:357-385) or one consume() ----
@@ -829,27 +1023,44 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
         hmax = max(hmax, heap.len);
         lap(6);
         const uint32_t hd = top >> s.sb;
-        const uint32_t node_v = node_load(top & smask);
+        // The node about to be visited is, almost always, one of the two whose neighbor rows were requested during the last
+        // visit; its dedup handle says so without a memory access.  Then everything the visit needs from memory before it can
+        // touch the heap again — heap tid, visibility, and (table-less regime) the dedup buckets of the row's ids — is requested
+        // BEFORE the pop and arrives while the pop works.
+        const uint32_t th = top & smask;
+        const bool hit_a = th == pfa_h, hit_b = th == pfb_h;
+        const bool hit = hit_a || hit_b;
+        uint32_t node_v = hit_a ? pfa_node : pfb_node;
+        if (!hit) node_v = node_load(th);
+        uint32_t row0 = hit_a ? pfa_val : pfb_val;
+        uint64_t vtid = 1;
+        uint32_t vvis = 1;
+        bool early = false;
+        uint32_t hslot0 = 0;
+        uint4 gbk0 = make_uint4(0, 0, 0, 0);
+        bool rchit0 = false;  // this lane's id of the first chunk was found in the id cache
+        if (hit) {
+            if (VR == 0 && !BUILD) {
+                vtid = a.tids[node_v];
+                if (visible) vvis = visible[node_v];
+            }
+            if (gmode && (nins_g + WAVE) * 4u <= s.gcap * 3u) {
+                early = true;
+                hslot0 = ghash_home(row0);
+                const uint64_t inval0 = __ballot(row0 == VS_INVALID_NODE);
+                if (s.rc) rchit0 = rc[hash_u32(row0 ^ 0x9e3779b9u) & rcm] == row0;
+                if ((uint32_t)lane < (inval0 ? (uint32_t)__builtin_ctzll(inval0) : WAVE) && !rchit0) gbk0 = bucket_load(hslot0);
+            }
+        }
         heap.pop();
         const uint32_t node = rfl(node_v);
         // what consume() will need to know about this node: requested now, folded into the ring entry at the insert below
-        uint64_t vtid = 1;
-        uint32_t vvis = 1;
-        if (VR == 0 && !BUILD) {
+        if (!hit && VR == 0 && !BUILD) {
             vtid = a.tids[node];
             if (visible) vvis = visible[node];
         }
         const uint32_t* nrow = a.nbrs + (size_t)node * a.nbr_stride;
-        uint32_t row0;
-        if (node == pfa_node) {
-            row0 = pfa_val;
-            (void)0;
-        } else if (node == pfb_node) {
-            row0 = pfb_val;
-            (void)0;
-        } else {
-            row0 = ((uint32_t)lane < a.R) ? nrow[lane] : VS_INVALID_NODE;
-        }
+        if (!hit) row0 = ((uint32_t)lane < a.R) ? nrow[lane] : VS_INVALID_NODE;
         lap(0);
         if (vis.len + 1 > vis.capacity()) {
             if (BUILD) vis.len = vis.capacity() - 1;  // build mode keeps the closest entries as prune candidates
@@ -878,14 +1089,20 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
             const bool frozen = !gmode && nins + WAVE > slot_limit;
             uint32_t hslot = gmode ? ghash_home(nid) : hash_home(nid), old = VS_EMPTY;
             uint4 gbk = make_uint4(0, 0, 0, 0);
-            if (gmode) {
+            bool rchit = false;
+            if (gmode && early && c0 == 0) {
+                hslot = hslot0;  // requested before the pop
+                gbk = gbk0;
+                rchit = rchit0;
+            } else if (gmode) {
                 if ((nins_g + WAVE) * 4u > s.gcap * 3u) { status |= OVF_HASH; break; }
-                if (act) gbk = bucket_load(hslot);  // in flight during the visited insert
+                if (s.rc && act) rchit = rc[hash_u32(nid ^ 0x9e3779b9u) & rcm] == nid;
+                if (act && !rchit) gbk = bucket_load(hslot);  // in flight during the visited insert
             } else if (!frozen && act) {
                 old = atomicCAS(&lhash[hslot], VS_EMPTY, nid);
             }
             // ... visited.insert(partition_point(|x| *x < head), head) runs in registers meanwhile ...
-            if (!vis_done) {
+            if (!vis_done && !(gmode && early && c0 == 0)) {  // (with the buckets already here it waits for the code rows instead)
                 vis_done = true;
                 vis.insert(hd, node, ((vtid & 0xFFFFull) == 0 ? VIS_DEAD : 0u) | (vvis == 0 ? VIS_HIDDEN : 0u));
                 lap(2);
@@ -893,7 +1110,8 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
             // ... then the probe sequence is finished
             bool fresh;
             if (gmode) {
-                fresh = global_insert(nid, act, hslot, gbk, hslot);
+                fresh = global_insert(nid, act && !rchit, hslot, gbk, hslot);
+                if (s.rc && act && !rchit) rc[hash_u32(nid ^ 0x9e3779b9u) & rcm] = nid;  // (now in the table, new or not)
             } else if (frozen) {
                 fresh = frozen_insert(nid, act, hslot);
                 if (status) break;
@@ -903,7 +1121,9 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
             st_reads += (uint32_t)__popcll(__ballot(fresh));  // SbqNode::read(neighbor)
             // label filter: query.labels.overlaps(node.labels) (AM/labels/mod.rs:124-142)
             bool pass = fresh;
-            if (has_label_filter && fresh) {
+            if (has_label_filter && a.label_mask) {
+                if (fresh) pass = (a.label_mask[nid] & qmask) != 0;
+            } else if (has_label_filter && fresh) {
                 const uint32_t lb = a.label_off[nid], le = a.label_off[nid + 1];
                 uint32_t i = 0, j = lb;
                 bool ov = false;
@@ -941,12 +1161,23 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
                 if (pass_i == 0 && !pfa_issued) {
                     pfa_issued = true;
                     pfa_node = VS_INVALID_NODE;
+                    pfa_h = 0xFFFFFFFFu;
                     if (root_after != 0xFFFFFFFFu) {
                         pfa_node = rfl(root_node_v);
+                        pfa_h = root_after & smask;
                         pfa_val = ((uint32_t)lane < a.R) ? a.nbrs[(size_t)pfa_node * a.nbr_stride + lane] : VS_INVALID_NODE;
                     }
                 }
-                const uint32_t d = ham_row_reg<NCH, QL>(crow, qv, qc_l, l4, a.code_stride, valid, stream_rows);
+                uint32_t d;
+                if (!vis_done) {  // the visited-list insert runs while the first pass of code rows is on its way
+                    vis_done = true;
+                    d = ham_row_reg_mid<NCH, QL>(crow, qv, qc_l, l4, a.code_stride, valid, stream_rows, [&]() {
+                        vis.insert(hd, node, ((vtid & 0xFFFFull) == 0 ? VIS_DEAD : 0u) | (vvis == 0 ? VIS_HIDDEN : 0u));
+                        lap(2);
+                    });
+                } else {
+                    d = ham_row_reg<NCH, QL>(crow, qv, qc_l, l4, a.code_stride, valid, stream_rows);
+                }
                 if (valid && l4 == 0) surv_d[j] = d;
             }
             st_dq += c;
@@ -969,8 +1200,10 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
             if ((list_ended || c0 + WAVE >= a.R) && !pfb_issued) {
                 pfb_issued = true;
                 pfb_node = VS_INVALID_NODE;
+                pfb_h = 0xFFFFFFFFu;
                 if (best != 0xFFFFFFFFu && (best >> s.sb) < (root_after >> s.sb)) {
                     pfb_node = best_node;  // a candidate of this visit: its id is known without a table lookup
+                    pfb_h = best & smask;
                     pfb_val = ((uint32_t)lane < a.R) ? a.nbrs[(size_t)pfb_node * a.nbr_stride + lane] : VS_INVALID_NODE;
                 }
             }
@@ -982,12 +1215,17 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
         if (!vis_done) vis.insert(hd, node, ((vtid & 0xFFFFull) == 0 ? VIS_DEAD : 0u) | (vvis == 0 ? VIS_HIDDEN : 0u));  // (an empty neighbor list)
         if (!pfa_issued) {  // nothing new to score: the old root is the next expansion
             pfa_node = VS_INVALID_NODE;
+            pfa_h = 0xFFFFFFFFu;
             if (root_after != 0xFFFFFFFFu) {
                 pfa_node = rfl(root_node_v);
+                pfa_h = root_after & smask;
                 pfa_val = ((uint32_t)lane < a.R) ? a.nbrs[(size_t)pfa_node * a.nbr_stride + lane] : VS_INVALID_NODE;
             }
         }
-        if (!pfb_issued) pfb_node = VS_INVALID_NODE;
+        if (!pfb_issued) {
+            pfb_node = VS_INVALID_NODE;
+            pfb_h = 0xFFFFFFFFu;
+        }
     }
     if (BUILD && VR == 0 && status == 0) {  // the visited list itself is the output (sorted by (hamming, recency))
         emitted = min(vis.len, s.M);
@@ -1029,9 +1267,9 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
 
 size_t fast_lds_bytes(const vs_index* idx, const FastLaunch& s) {
     const size_t nch = (idx->code_stride + 7) / 8;
-    // LDS copy of the query code: the generic variant (NCH == 0), and the register-capped variants (minw >= 7: 8 NCH words, zero padded)
-    const size_t qcopy = nch > 6 ? (size_t)idx->code_stride * 8 : (s.minw >= 7 && !s.build && !s.phase ? nch * 64 : 0);
-    size_t b = (size_t)(s.hl + 1) * 4 + (size_t)s.lh * 4 + 3 * 64 * 4 + ARB_SLOTS * 4 + (s.vr ? 0 : (size_t)s.vcap * 8) + MAX_QLABELS * 2 + qcopy + 16;
+    // LDS copy of the query code: the generic variant (NCH == 0), and the register-capped variants (minw >= 6: 8 NCH words, zero padded)
+    const size_t qcopy = nch > 6 ? (size_t)idx->code_stride * 8 : (s.minw >= 6 && !s.build && !s.phase ? nch * 64 : 0);
+    size_t b = (size_t)(s.hl + 1) * 4 + (size_t)s.lh * 4 + 3 * 64 * 4 + ARB_SLOTS * 4 + (s.vr ? 0 : (size_t)s.vcap * 8) + MAX_QLABELS * 2 + qcopy + (size_t)s.rc * 4 + 32;
     return (b + 15) / 16 * 16;
 }
 
@@ -1085,6 +1323,7 @@ int launch_search_fast(vs_index* idx, const FastLaunch& s) {
     a.tids = idx->tids;
     a.label_off = idx->label_off;
     a.label_val = idx->label_val;
+    a.label_mask = idx->label_mask;
     a.ls_labels = idx->ls_labels;
     a.ls_nodes = idx->ls_nodes;
     a.code_stride = idx->code_stride;

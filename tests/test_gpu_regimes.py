@@ -18,6 +18,8 @@ REGIMES = {
     "frozen_overflow": {"VS_F_LH": "256"},
     "lds_ring_small": {"VS_F_VR": "0", "VS_F_VCAP": "64"},
     "heap_spill": {"VS_F_HL": "63"},
+    # table-less with a small LDS cache of ids known to be in the table in front of it (duplicate probes answered on chip)
+    "tableless_idcache": {"VS_F_LDS_MAX_INS": "0", "VS_F_RC": "128"},
     "heap_spill_tableless": {"VS_F_HL": "63", "VS_F_LDS_MAX_INS": "0"},
     "tiny_pool": {"VS_F_LH": "256", "VS_F_POOL": "0.01"},
     # dedup table too small for most scans: they are finished by the second attempt of k_search_fast (four times the table) ...
@@ -164,4 +166,32 @@ def test_heavy_ties_deep_heap(gpu_ctx, regime):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+        ix.close()
+
+
+# label sets: an index whose labels all lie in 0..63 is filtered through 64-bit masks, any other through the sorted merge
+@pytest.mark.parametrize("n_labels", [40, 100])
+def test_label_filter_masks_and_merge(gpu_ctx, n_labels):
+    ti = cached_index(n=2500, dim_full=64, bits=2, R=32, distance=1, seed=51, kind="gauss", L_build=60, n_labels=n_labels)
+    ix = ti.upload(gpu_ctx)
+    try:
+        q = ti.queries(64, seed=3, kind="gauss")
+        rng = np.random.default_rng(8)
+        qlabels = [sorted(set(int(v) for v in rng.integers(1, n_labels + 1, int(rng.integers(1, 4))))) for _ in range(len(q))]
+        qlabels[0] = [1, 70] if n_labels > 63 else [1, 39]
+        for regime in ("default", "tableless"):
+            saved = {k: os.environ.get(k) for k in REGIMES[regime]}
+            try:
+                os.environ.update(REGIMES[regime])
+                oi, oh, ost = ti.oracle.stream_batch(q, L=50, m=40, qlabels=qlabels)
+                gi, gh, gst = ix.stream_batch(q, search_list_size=50, m=40, qlabels=qlabels)
+                assert (gi == oi).all() and (gh == oh).all()
+                assert gst["quantized_distance_comparisons"] == ost["quantized_distance_comparisons"]
+            finally:
+                for k, v in saved.items():
+                    if v is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = v
+    finally:
         ix.close()

@@ -662,34 +662,6 @@ __device__ __forceinline__ uint32_t ham_row_reg(const uint64_t* __restrict__ row
     return ham_row4(row, qc_l, l4, code_stride, active);
 }
 
-// ham_row_reg with independent work (`mid`) placed between the issue of the row loads and their first use
-template <int NCH, bool QL, class F>
-__device__ __forceinline__ uint32_t ham_row_reg_mid(const uint64_t* __restrict__ row, const ulonglong2 (&qv)[NCH > 0 ? NCH : 1],
-                                                    const uint64_t* qc_l, int l4, uint32_t code_stride, bool active, bool stream,
-                                                    F&& mid) {
-    if (NCH == 0) {
-        mid();
-        return ham_row4(row, qc_l, l4, code_stride, active);
-    }
-    ulonglong2 r[NCH > 0 ? NCH : 1];
-#pragma unroll
-    for (int t = 0; t < NCH; ++t) {
-        const uint32_t w = 2u * (uint32_t)l4 + 8u * (uint32_t)t;
-        r[t] = (!active || w >= code_stride) ? make_ulonglong2(0, 0)
-               : stream ? load_stream16(row + w) : *reinterpret_cast<const ulonglong2*>(row + w);
-    }
-    mid();
-    uint32_t acc = 0;
-#pragma unroll
-    for (int t = 0; t < NCH; ++t) {
-        const uint32_t w = 2u * (uint32_t)l4 + 8u * (uint32_t)t;
-        ulonglong2 qq = QL ? *reinterpret_cast<const ulonglong2*>(qc_l + w) : qv[t];
-        if (w >= code_stride) qq = make_ulonglong2(0, 0);
-        acc += (uint32_t)__popcll(r[t].x ^ qq.x) + (uint32_t)__popcll(r[t].y ^ qq.y);
-    }
-    return quad_sum(active ? acc : 0u);
-}
-
 // minimum over the wave (DPP row reduction + 4 readlanes; no LDS)
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
     v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x111 /*row_shr:1*/, 0xF, 0xF, false));
@@ -1102,7 +1074,7 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
                 old = atomicCAS(&lhash[hslot], VS_EMPTY, nid);
             }
             // ... visited.insert(partition_point(|x| *x < head), head) runs in registers meanwhile ...
-            if (!vis_done && !(gmode && early && c0 == 0)) {  // (with the buckets already here it waits for the code rows instead)
+            if (!vis_done) {
                 vis_done = true;
                 vis.insert(hd, node, ((vtid & 0xFFFFull) == 0 ? VIS_DEAD : 0u) | (vvis == 0 ? VIS_HIDDEN : 0u));
                 lap(2);
@@ -1168,16 +1140,7 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
                         pfa_val = ((uint32_t)lane < a.R) ? a.nbrs[(size_t)pfa_node * a.nbr_stride + lane] : VS_INVALID_NODE;
                     }
                 }
-                uint32_t d;
-                if (!vis_done) {  // the visited-list insert runs while the first pass of code rows is on its way
-                    vis_done = true;
-                    d = ham_row_reg_mid<NCH, QL>(crow, qv, qc_l, l4, a.code_stride, valid, stream_rows, [&]() {
-                        vis.insert(hd, node, ((vtid & 0xFFFFull) == 0 ? VIS_DEAD : 0u) | (vvis == 0 ? VIS_HIDDEN : 0u));
-                        lap(2);
-                    });
-                } else {
-                    d = ham_row_reg<NCH, QL>(crow, qv, qc_l, l4, a.code_stride, valid, stream_rows);
-                }
+                const uint32_t d = ham_row_reg<NCH, QL>(crow, qv, qc_l, l4, a.code_stride, valid, stream_rows);
                 if (valid && l4 == 0) surv_d[j] = d;
             }
             st_dq += c;

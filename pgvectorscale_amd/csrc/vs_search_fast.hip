@@ -419,8 +419,7 @@ struct FastHeap {
                     const uint32_t patched = r < t ? up : (r == t ? elem : chain);
                     if (r <= t) {
                         const uint32_t dst = p1 >> (r & 31u);
-                        if ((p1 >> t) > hl) gstore32(g + (dst - 1 - hl), patched);  // (wave-uniform) the whole path is in the spill array
-                        else if (spill) set1(dst, patched);
+                        if (spill) set1(dst, patched);
                         else l[dst] = patched;
                     }
                     const uint32_t sh = 32u - (uint32_t)__builtin_clz(p1 ^ p1n);

@@ -15,13 +15,19 @@ if [ -n "$TIP" ]; then
     timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -2 | tee gpurun_out/ab/gpu_tests_tip.txt
     cp /tmp/libvsgpu_main.so pgvectorscale_amd/libvsgpu.so
 fi
-run() { timeout 600 python scripts/perf_search.py --n $N --nq 131072 --L $L --rescore $S --reps 3 --configs VS_FAST=1 --graph-cache /tmp/vs_ab_graph "$@" 2>&1 | grep -E "search "; }
+CFGS=${AB_CONFIGS:-VS_FAST=1}
+run() { timeout 600 python scripts/perf_search.py --n $N --nq 131072 --L $L --rescore $S --reps 3 --configs "$CFGS" --graph-cache /tmp/vs_ab_graph "$@" 2>&1 | grep -E "search "; }
 echo "# this tree" | tee $O
 run | tee -a $O
 for lib in $LIBS; do
     echo "# $lib" | tee -a $O
     run --lib $lib | tee -a $O
 done
+if [ -n "$AB_TIP_CONFIGS" ] && [ -n "$TIP" ]; then
+    echo "# $TIP with $AB_TIP_CONFIGS" | tee -a $O
+    CFGS="$AB_TIP_CONFIGS" run --lib $TIP | tee -a $O
+fi
+CFGS=${AB_CONFIGS:-VS_FAST=1}
 echo "# this tree again" | tee -a $O
 run | tee -a $O
 rm -f /tmp/vs_ab_graph.*

@@ -295,7 +295,11 @@ int vs_search_batch_dev(vs_index* idx, const float* d_queries, const int16_t* d_
                         uint64_t* d_out_tids, float* d_out_dist);
 int vs_search_batch_dev_finish(vs_index* idx, vs_stats* stats);
 
-/* ---- the amrescan / amgettuple mirror (one row at a time) ---------------------------------------------------- */
+/* ---- the amrescan / amgettuple mirror (one row at a time) ----------------------------------------------------
+ * A scan keeps what TSVScanState keeps between amgettuple calls (lsr + resort_buffer, AM/scan.rs:162-174) on the device and
+ * CONTINUES the beam search when the executor asks for more rows (AM/scan.rs:370-405): it is never run again from the start
+ * (except after a capacity overflow, vs_stats.retries), and the rows prefetched ahead of the executor stay within ~6 % of
+ * what was pulled.  One thread per scan; scans of one index share its vs_ctx stream. */
 int vs_beginscan(vs_index* idx, vs_scan** out);                                  /* ambeginscan */
 /* query == NULL is the SQL-NULL query (zero vector, labels ignored; AM/labels/mod.rs:214-216).
  * has_label_key: nkeys == 1 (sets xs_recheck, AM/scan.rs:350-352); labels may be unsorted / contain duplicates. */
@@ -304,7 +308,11 @@ int vs_rescan(vs_scan* scan, const float* query, const int16_t* labels, uint32_t
 /* returns 1 and fills the outputs for the next row, 0 at end of scan, <0 on error */
 int vs_gettuple(vs_scan* scan, uint64_t* heap_tid, uint32_t* node, float* dist); /* amgettuple */
 int vs_scan_xs_recheck(const vs_scan* scan);
+/* GreedySearchStats as the reference's scan holds them after the amgettuple calls made so far (AM/stats.rs:68-125,
+ * AM/scan.rs:461-472): the counters are recorded per emitted row, so prefetched rows do not show (zero on a broker scan). */
 int vs_scan_get_stats(const vs_scan* scan, vs_stats* out);
+/* what the device really did for the scan since vs_rescan (prefetched rows and restarts included); launches may be NULL */
+int vs_scan_get_work(const vs_scan* scan, vs_stats* out, uint32_t* launches);
 void vs_endscan(vs_scan* scan);                                                   /* amendscan */
 
 /* ---- coalescing concurrent scans into batched launches (vs_broker.cpp) -------------------

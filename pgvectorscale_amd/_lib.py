@@ -133,6 +133,7 @@ SYMBOLS = {
     "vs_gettuple": (_i, [_vp, C.POINTER(_u64), C.POINTER(_u32), C.POINTER(C.c_float)]),
     "vs_scan_xs_recheck": (_i, [_vp]),
     "vs_scan_get_stats": (_i, [_vp, C.POINTER(Stats)]),
+    "vs_scan_get_work": (_i, [_vp, C.POINTER(Stats), C.POINTER(_u32)]),
     "vs_endscan": (None, [_vp]),
     "vs_broker_create": (_i, [_vp, C.POINTER(BrokerConfig), C.POINTER(_vp)]),
     "vs_broker_search": (_i, [_vp, _vp, _vp, _u32, _i, _u32, _u32, _u32, _vp, _vp, _vp]),

@@ -175,7 +175,17 @@ struct SearchLaunch {
     uint32_t pool_slots = 0;
     uint32_t* fb_flag = nullptr;   // [nq] set to 1 for every scan this launch ran in only_failed mode
     const uint8_t* visible = nullptr;  // non-null: rows whose node has visible[node] == 0 are counted and left out of the stream
+    // resumable scans (the amgettuple cursor, AM/scan.rs:162-174,370-405): resume[q * resume_stride ..] is scan q's saved state —
+    // header RS_* + the LDS image (heap top, LDS dedup table, visited list); its heap spill array / dedup ladder are region q of
+    // heap_g / hash and live on between launches.  A launch continues the scan for M more rows (written to out_ids[q][0..M)).
+    uint32_t* resume = nullptr;
+    uint32_t resume_stride = 0;
+    uint32_t* row_stats = nullptr;     // [nq][M][ST_N] the work counters as they stood when each row was emitted (or null)
 };
+// header of a saved scan (u32 words), followed by the LDS image
+enum { RS_INIT = 0, RS_HLEN, RS_HMAX, RS_VLEN, RS_GLEV, RS_NINS_L, RS_NINS_G, RS_NINS_TOP, RS_VISITS, RS_CAND, RS_DQ, RS_READS,
+       RS_NEXT, RS_INVIS, RS_STATUS, RS_EMITTED, RS_HDR = 16 };
+size_t search_resume_words(const SearchLaunch& s);  // u32 words of one saved scan at these capacities
 // fast path (vs_search_fast.hip): all hot state in LDS
 struct FastLaunch {
     uint32_t nq, L, M;
@@ -233,6 +243,9 @@ int launch_search(vs_index* idx, const SearchLaunch& s, bool build_mode = false)
 int launch_resort(vs_index* idx, uint32_t nq, uint32_t M, uint32_t rescore, uint32_t k, const uint32_t* d_stream_ids,
                   const uint32_t* d_cnt, const float* d_dist, uint64_t* d_heap_ws, uint32_t* d_out_ids,
                   uint64_t* d_out_tids, float* d_out_dist);
+int launch_resort_cursor(vs_index* idx, uint32_t n, bool exhausted, uint32_t rescore, uint32_t k, const uint32_t* d_stream,
+                         const float* d_dist, const uint32_t* d_keys, uint64_t* d_heap, uint32_t* d_cur, uint32_t* d_out_ids,
+                         uint64_t* d_out_tids, float* d_out_dist);
 int launch_row_norms(vs_index* idx);
 int launch_slice_norms(vs_index* idx, float* d_out);  // divisor of the first dim_index dims of every heap vector
 int launch_prepare_index_slice(vs_index* idx, const float* d_raw, uint32_t nq, float* d_q_index);

@@ -420,6 +420,86 @@ __global__ void k_resort(uint32_t nq, uint32_t M, uint32_t rescore, uint32_t k, 
     }
 }
 
+// The same window, resumable (the amgettuple cursor): the BinaryHeap<ResortData> of ONE scan lives in heap_ws between calls,
+// cur[0] = its length, cur[1] = stream rows pushed so far, cur[2] = rows handed out so far.  `stream` / `dist` / `keys` hold every
+// row the scan has emitted so far (n of them; `exhausted` = there will be no more).  Produces up to k more rows; a window that
+// cannot be refilled because the rows are not there yet (n too small, scan not exhausted) stops early — the host fetches so
+// that this never happens (rows >= rescore + handed out + k - 1).  cur[3] = rows produced by this call.
+__global__ void k_resort_cursor(uint32_t n, uint32_t exhausted, uint32_t rescore, uint32_t k, const uint32_t* __restrict__ stream,
+                                const float* __restrict__ dist, const uint32_t* __restrict__ keys, uint32_t plain_keys,
+                                const uint64_t* __restrict__ tids, uint64_t* __restrict__ h, uint32_t* __restrict__ cur,
+                                uint32_t* __restrict__ out_ids, uint64_t* __restrict__ out_tids, float* __restrict__ out_dist) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    uint32_t len = cur[0], pos = cur[1];
+    uint32_t produced = 0;
+    if (rescore == 0) {  // resort_buffer.capacity() == 0 -> plain next()
+        for (; produced < k && pos < n; ++produced, ++pos) {
+            const uint32_t id = stream[pos];
+            out_ids[produced] = id;
+            out_tids[produced] = tids[id];
+            float d = __int_as_float(0x7fc00000);
+            if (plain_keys) {
+                int32_t b = (int32_t)(keys[pos] ^ 0x80000000u);
+                b ^= (int32_t)(((uint32_t)(b >> 31)) >> 1);
+                d = __int_as_float(b);
+            }
+            out_dist[produced] = d;
+        }
+    } else {
+        auto kof = [](uint64_t e) { return (int32_t)(uint32_t)(e >> 32); };
+        auto sift_up = [&](uint32_t p, uint64_t elem) {
+            while (p > 0) {
+                const uint32_t parent = (p - 1) >> 1;
+                const uint64_t pe = h[parent];
+                if (kof(pe) <= kof(elem)) break;
+                h[p] = pe;
+                p = parent;
+            }
+            h[p] = elem;
+        };
+        while (produced < k) {
+            while (len < rescore && pos < n) {
+                const uint64_t e = ((uint64_t)(uint32_t)total_key(dist[pos]) << 32) | pos;
+                sift_up(len++, e);
+                ++pos;
+            }
+            if (len < rescore && !exhausted) break;  // the window cannot be filled yet
+            if (len == 0) break;
+            const uint64_t item = h[--len];
+            uint64_t top = item;
+            if (len > 0) {
+                top = h[0];
+                const uint32_t end = len;
+                uint32_t p = 0, child = 1;
+                const uint32_t lim = end >= 2 ? end - 2 : 0;
+                while (child <= lim) {
+                    const uint64_t le = h[child], ri = h[child + 1];
+                    const uint32_t pick = (kof(ri) <= kof(le)) ? 1u : 0u;
+                    child += pick;
+                    h[p] = pick ? ri : le;
+                    p = child;
+                    child = 2 * p + 1;
+                }
+                if (child == end - 1) {
+                    h[p] = h[child];
+                    p = child;
+                }
+                sift_up(p, item);
+            }
+            const uint32_t sp = (uint32_t)top;
+            const uint32_t id = stream[sp];
+            out_ids[produced] = id;
+            out_tids[produced] = tids[id];
+            out_dist[produced] = dist[sp];
+            ++produced;
+        }
+    }
+    cur[0] = len;
+    cur[1] = pos;
+    cur[2] += produced;
+    cur[3] = produced;
+}
+
 // ===============================================================================================================
 // launch wrappers
 // ===============================================================================================================
@@ -490,6 +570,16 @@ int launch_resort(vs_index* idx, uint32_t nq, uint32_t M, uint32_t rescore, uint
                                      ? (const uint32_t*)idx->ws.stream_ham.p : nullptr;
     hipLaunchKernelGGL(k_resort, dim3((nq + 63) / 64), dim3(64), 0, idx->ctx->stream, nq, M, rescore, k, d_stream_ids,
                        d_cnt, d_dist, idx->tids, d_heap_ws, d_out_ids, d_out_tids, d_out_dist, plain_keys);
+    VS_HIP(hipGetLastError());
+    return VS_OK;
+}
+
+int launch_resort_cursor(vs_index* idx, uint32_t n, bool exhausted, uint32_t rescore, uint32_t k, const uint32_t* d_stream,
+                         const float* d_dist, const uint32_t* d_keys, uint64_t* d_heap, uint32_t* d_cur, uint32_t* d_out_ids,
+                         uint64_t* d_out_tids, float* d_out_dist) {
+    const uint32_t plain_keys = (idx->d.storage_type == VS_STORAGE_PLAIN && idx->d.dim_index == idx->d.dim_full) ? 1u : 0u;
+    hipLaunchKernelGGL(k_resort_cursor, dim3(1), dim3(64), 0, idx->ctx->stream, n, exhausted ? 1u : 0u, rescore, k, d_stream, d_dist,
+                       d_keys, plain_keys, idx->tids, d_heap, d_cur, d_out_ids, d_out_tids, d_out_dist);
     VS_HIP(hipGetLastError());
     return VS_OK;
 }

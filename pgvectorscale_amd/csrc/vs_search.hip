@@ -244,7 +244,16 @@ __global__ __launch_bounds__(WAVE) void k_search(SearchArgs a) {
     } else {
         for (uint32_t w = lane; w < a.code_stride; w += WAVE) qc[w] = s.qcodes[(size_t)q * a.code_stride + w];
     }
-    for (uint32_t i = lane; i < s.lh; i += WAVE) lhash[i] = VS_EMPTY;
+    // resumable scan: state saved by an earlier launch (header + LDS image of heap top / dedup table / visited list)
+    uint32_t* rs = s.resume ? s.resume + (size_t)q * s.resume_stride : nullptr;
+    const bool resumed = rs != nullptr && rfl(rs[RS_INIT]) == 1u;
+    const uint32_t image_words = 2u * round_up_u32(s.hl + 2, 2) + round_up_u32(s.lh, 4) + 2u * round_up_u32(s.vcap, 4);
+    if (resumed) {
+        uint32_t* img = reinterpret_cast<uint32_t*>(smem);
+        for (uint32_t i = lane; i < image_words; i += WAVE) img[i] = rs[RS_HDR + i];
+    } else {
+        for (uint32_t i = lane; i < s.lh; i += WAVE) lhash[i] = VS_EMPTY;
+    }
     const bool labels_some = s.qlabel_off != nullptr;  // LabeledVector.labels is Some (AM/labels/mod.rs:222-236)
     uint32_t nql = 0;
     if (labels_some) {
@@ -268,6 +277,22 @@ __global__ __launch_bounds__(WAVE) void k_search(SearchArgs a) {
     WaveHeap heap{heap_l, s.heap_g + (size_t)wslot * (s.hcap > s.hl ? s.hcap - s.hl : 0), s.hl, 0, 0};
     uint32_t vlen = 0, emitted = 0, status = 0;
     uint32_t st_visits = 0, st_cand = 0, st_dq = 0, st_reads = 0, st_next = 0, st_invis = 0;
+    if (resumed) {  // (all wave-uniform)
+        heap.len = rfl(rs[RS_HLEN]);
+        heap.maxlen = rfl(rs[RS_HMAX]);
+        vlen = rfl(rs[RS_VLEN]);
+        glev = (int)rfl(rs[RS_GLEV]) - 1;
+        nins_l = rfl(rs[RS_NINS_L]);
+        nins_g = rfl(rs[RS_NINS_G]);
+        nins_top = rfl(rs[RS_NINS_TOP]);
+        st_visits = rfl(rs[RS_VISITS]);
+        st_cand = rfl(rs[RS_CAND]);
+        st_dq = rfl(rs[RS_DQ]);
+        st_reads = rfl(rs[RS_READS]);
+        st_next = rfl(rs[RS_NEXT]);
+        st_invis = rfl(rs[RS_INVIS]);
+        status = rfl(rs[RS_STATUS]);
+    }
 
     auto open_level = [&]() {  // uniform
         glev++;
@@ -347,7 +372,7 @@ __global__ __launch_bounds__(WAVE) void k_search(SearchArgs a) {
     };
 
     // ---- ListSearchResult::new: start nodes (AM/graph/mod.rs:97-124, AM/graph/start_nodes.rs:39-48) ----
-    {
+    if (!resumed) {
         uint32_t nstarts = labels_some ? nql : 1u;
         if (a.default_start == VS_INVALID_NODE || a.n == 0) nstarts = 0;  // ListSearchResult::empty()
         for (uint32_t si = 0; si < nstarts; ++si) {
@@ -545,6 +570,17 @@ __global__ __launch_bounds__(WAVE) void k_search(SearchArgs a) {
             if (lane == 0) {
                 s.out_ids[(size_t)q * s.M + emitted] = fnode;
                 s.out_ham[(size_t)q * s.M + emitted] = fd;
+                if (s.row_stats) {  // the counters as the reference's stood when this row left next()
+                    uint32_t* r = s.row_stats + ((size_t)q * s.M + emitted) * ST_N;
+                    r[ST_VISITS] = st_visits;
+                    r[ST_CAND] = st_cand;
+                    r[ST_DQ] = st_dq;
+                    r[ST_READS] = st_reads;
+                    r[ST_NEXT] = st_next;
+                    r[ST_GSPILL] = heap.maxlen;
+                    r[ST_INVIS] = st_invis;
+                    r[7] = nins_g;
+                }
             }
             emitted++;
             got = true;
@@ -564,6 +600,29 @@ __global__ __launch_bounds__(WAVE) void k_search(SearchArgs a) {
         s.out_ids[(size_t)q * s.M + i] = VS_INVALID_NODE;
         s.out_ham[(size_t)q * s.M + i] = 0xFFFFFFFFu;
     }
+    if (rs) {  // save the scan for the next launch (a failed scan keeps its flag: the host restarts it with larger capacities)
+        __syncthreads();
+        const uint32_t* img = reinterpret_cast<const uint32_t*>(smem);
+        for (uint32_t i = lane; i < image_words; i += WAVE) rs[RS_HDR + i] = img[i];
+        if (lane == 0) {
+            rs[RS_INIT] = 1u;
+            rs[RS_HLEN] = heap.len;
+            rs[RS_HMAX] = heap.maxlen;
+            rs[RS_VLEN] = vlen;
+            rs[RS_GLEV] = (uint32_t)(glev + 1);
+            rs[RS_NINS_L] = nins_l;
+            rs[RS_NINS_G] = nins_g;
+            rs[RS_NINS_TOP] = nins_top;
+            rs[RS_VISITS] = st_visits;
+            rs[RS_CAND] = st_cand;
+            rs[RS_DQ] = st_dq;
+            rs[RS_READS] = st_reads;
+            rs[RS_NEXT] = st_next;
+            rs[RS_INVIS] = st_invis;
+            rs[RS_STATUS] = status;
+            rs[RS_EMITTED] = (resumed ? rs[RS_EMITTED] : 0u) + (status ? 0u : emitted);
+        }
+    }
     if (lane == 0) {
         s.out_cnt[q] = status ? 0 : emitted;  // a failed scan publishes an empty stream (it is re-run or reported)
         s.status[q] = status;
@@ -577,6 +636,10 @@ __global__ __launch_bounds__(WAVE) void k_search(SearchArgs a) {
         st[ST_INVIS] = st_invis;
         st[7] = nins_g;
     }
+}
+
+size_t search_resume_words(const SearchLaunch& s) {
+    return RS_HDR + 2 * (size_t)round_up_u32(s.hl + 2, 2) + round_up_u32(s.lh, 4) + 2 * (size_t)round_up_u32(s.vcap, 4);
 }
 
 size_t search_lds_bytes(const vs_index* idx, const SearchLaunch& s) {

@@ -508,6 +508,14 @@ class IndexScan:
         check(self._L.vs_scan_get_stats(self.h, C.byref(st)))
         return st.as_dict()
 
+    def work(self):
+        """what the device really did for this scan since rescan() (prefetch and restarts included) + its launch count"""
+        st, n = Stats(), C.c_uint32()
+        check(self._L.vs_scan_get_work(self.h, C.byref(st), C.byref(n)))
+        d = st.as_dict()
+        d["launches"] = int(n.value)
+        return d
+
     def endscan(self):
         if self.h:
             self._L.vs_endscan(self.h)

@@ -154,6 +154,15 @@ int vs_index_set_labels(vs_index* idx, const uint32_t* label_off, const int16_t*
 int vs_index_set_visibility(vs_index* idx, const uint8_t* visible);
 /* the same with the mask already in device memory (n bytes, kept by the caller until replaced; NULL clears it) */
 int vs_index_set_visibility_dev(vs_index* idx, const uint8_t* d_visible);
+/* Shared launches (vs_broker / vs_shm) serve backends with DIFFERENT snapshots, so one mask per index is not enough there: the
+ * index keeps up to VS_MAX_SNAPSHOTS - 1 masks (ids 1 .. VS_MAX_SNAPSHOTS - 1; `visible` = n host bytes, NULL drops the mask) and
+ * a launch runs under the one its scans name; id 0 = every tuple visible.  vs_index_snapshot_use makes snapshot `id` the
+ * mask of the launches that follow and returns the mask that was in force (restore it with vs_index_set_visibility_dev).
+ * Same threading rule as every index call: with a broker attached only its dispatcher may call these — clients go through
+ * vs_broker_snapshot_put / vs_shm_server_snapshot_put. */
+#define VS_MAX_SNAPSHOTS 16
+int vs_index_snapshot_put(vs_index* idx, uint32_t snapshot, const uint8_t* visible);
+int vs_index_snapshot_use(vs_index* idx, uint32_t snapshot, const uint8_t** previous /* may be NULL */);
 int vs_index_get_quantizer(const vs_index* idx, float* mean, float* m2, uint64_t* count);
 /* copy index arrays back to host (tests / cpu_baseline leg); any pointer may be NULL */
 int vs_index_download(const vs_index* idx, uint64_t* codes, uint32_t* nbrs /*[n][num_neighbors]*/, uint64_t* heap_tids,
@@ -276,9 +285,10 @@ int vs_scan_topk_filtered(vs_index* idx, const uint64_t* qcodes, const int16_t* 
  * (TSVResponseIterator::next_with_resort, AM/scan.rs:244-305) with GUCs diskann.query_search_list_size =
  * search_list_size and diskann.query_rescore = rescore (AM/guc.rs:3-4).
  *   queries   host [nq][dim_full] raw f32
- *   qlabels / qlabel_off: CSR of the smallint[] scan keys, qlabel_off == NULL => no scan key on any query.  A key may hold at
- *             most 64 distinct labels (VS_ERR_INVALID beyond; the reference has no limit — the key of a scan sits in 128 bytes
- *             of on-chip memory here; the device-resident variant reads the first 64), a node at most 64 for a label-aware build
+ *   qlabels / qlabel_off: CSR of the smallint[] scan keys, qlabel_off == NULL => no scan key on any query.  A key may hold any
+ *             number of labels, as in the reference (LabelSet, AM/labels/mod.rs:19-37): up to 64 distinct labels ride in on-chip
+ *             memory, a wider key is read from global memory by the general kernel (the LDS-resident kernel hands such scans
+ *             over: vs_stats.fallback_scans).  Only the label-aware BUILD limits a node to 64 labels (VS_ERR_INVALID beyond).
  *   out_ids   [nq][k] node ids (VS_INVALID_NODE past the end of a scan), out_tids [nq][k] heap TIDs (may be NULL),
  *   out_dist  [nq][k] reranked f32 distance (NaN when rescore == 0) (may be NULL)                               */
 int vs_search_batch(vs_index* idx, const float* queries, const int16_t* qlabels, const uint32_t* qlabel_off, uint32_t nq,
@@ -320,8 +330,12 @@ void vs_endscan(vs_scan* scan);                                                 
  * of scans per launch.  A broker owns the index (its dispatcher thread is the only thread that touches the vs_ctx); any
  * number of client threads call vs_broker_search(), which blocks until the scan's rows are ready.  The dispatcher
  * gathers requests for at most max_wait_us after the oldest one (or until max_batch are waiting) and runs every group
- * that shares (search_list_size, rescore, k, label key present) as one vs_search_batch().  In a PGRX deployment the
- * queue lives in shared memory and the dispatcher is a background worker. */
+ * that shares (search_list_size, rescore, k, label key present, snapshot) as one vs_search_batch().  Heap visibility: scans of
+ * different backends see different snapshots, so a request names the snapshot mask it runs under (vs_broker_search_snapshot;
+ * masks are handed to the dispatcher with vs_broker_snapshot_put) and only scans of one snapshot share a launch; plain
+ * vs_broker_search = snapshot 0 = every tuple visible.  The index-level mask of vs_index_set_visibility is not consulted by a
+ * broker (it is left as it was).  In a PGRX deployment the queue lives in shared memory and the dispatcher is a background
+ * worker. */
 typedef struct vs_broker vs_broker;
 typedef struct vs_broker_config {
     uint32_t max_batch;   /* scans per launch at most (0 = 8192)                                  */
@@ -338,6 +352,12 @@ int vs_broker_create(vs_index* idx, const vs_broker_config* cfg /* NULL = defaul
 int vs_broker_search(vs_broker* b, const float* query, const int16_t* labels, uint32_t n_labels, int has_label_key,
                      uint32_t search_list_size, uint32_t rescore, uint32_t k, uint32_t* out_ids, uint64_t* out_tids,
                      float* out_dist);
+/* the same under snapshot mask `snapshot` (0 = every tuple visible; an id without a mask fails with VS_ERR_STATE) */
+int vs_broker_search_snapshot(vs_broker* b, const float* query, const int16_t* labels, uint32_t n_labels, int has_label_key,
+                              uint32_t search_list_size, uint32_t rescore, uint32_t k, uint32_t snapshot, uint32_t* out_ids,
+                              uint64_t* out_tids, float* out_dist);
+/* hands a snapshot's mask (n host bytes; NULL drops it) to the dispatcher; returns when it is in place.  Thread safe. */
+int vs_broker_snapshot_put(vs_broker* b, uint32_t snapshot, const uint8_t* visible);
 int vs_broker_get_stats(vs_broker* b, vs_broker_stats* out);
 vs_index* vs_broker_index(vs_broker* b);
 /* the amrescan / amgettuple mirror on top of a broker: like vs_beginscan, but every window of rows is fetched through
@@ -364,6 +384,12 @@ uint32_t vs_shm_client_dim(const vs_shm_client* c); /* dim_full of the index beh
 int vs_shm_client_search(vs_shm_client* c, const float* query, const int16_t* labels, uint32_t n_labels, int has_label_key,
                          uint32_t search_list_size, uint32_t rescore, uint32_t k, uint32_t* out_ids, uint64_t* out_tids,
                          float* out_dist);
+/* the same under snapshot mask `snapshot` of the serving process (vs_shm_server_snapshot_put; 0 = every tuple visible) */
+int vs_shm_client_search_snapshot(vs_shm_client* c, const float* query, const int16_t* labels, uint32_t n_labels, int has_label_key,
+                                  uint32_t search_list_size, uint32_t rescore, uint32_t k, uint32_t snapshot, uint32_t* out_ids,
+                                  uint64_t* out_tids, float* out_dist);
+/* serving process: a snapshot's mask (n host bytes, copied; NULL drops it); in place before the next group is formed */
+int vs_shm_server_snapshot_put(vs_shm_server* s, uint32_t snapshot, const uint8_t* visible);
 void vs_shm_client_close(vs_shm_client* c);
 
 /* ---- build-side helpers (SURVEY.md §8f "next" rows; needed to manufacture device-resident indexes) ---------- */

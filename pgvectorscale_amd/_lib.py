@@ -137,6 +137,10 @@ SYMBOLS = {
     "vs_endscan": (None, [_vp]),
     "vs_broker_create": (_i, [_vp, C.POINTER(BrokerConfig), C.POINTER(_vp)]),
     "vs_broker_search": (_i, [_vp, _vp, _vp, _u32, _i, _u32, _u32, _u32, _vp, _vp, _vp]),
+    "vs_broker_search_snapshot": (_i, [_vp, _vp, _vp, _u32, _i, _u32, _u32, _u32, _u32, _vp, _vp, _vp]),
+    "vs_broker_snapshot_put": (_i, [_vp, _u32, _vp]),
+    "vs_index_snapshot_put": (_i, [_vp, _u32, _vp]),
+    "vs_index_snapshot_use": (_i, [_vp, _u32, _vp]),
     "vs_broker_get_stats": (_i, [_vp, C.POINTER(BrokerStats)]),
     "vs_broker_destroy": (None, [_vp]),
     "vs_broker_index": (_vp, [_vp]),
@@ -144,6 +148,8 @@ SYMBOLS = {
     "vs_shm_server_create": (_i, [_vp, C.c_char_p, _u32, _u32, C.POINTER(BrokerConfig), C.POINTER(_vp)]),
     "vs_shm_server_get_stats": (_i, [_vp, C.POINTER(BrokerStats)]),
     "vs_shm_server_destroy": (None, [_vp]),
+    "vs_shm_server_snapshot_put": (_i, [_vp, _u32, _vp]),
+    "vs_shm_client_search_snapshot": (_i, [_vp, _vp, _vp, _u32, _i, _u32, _u32, _u32, _u32, _vp, _vp, _vp]),
     "vs_shm_client_open": (_i, [C.c_char_p, C.POINTER(_vp)]),
     "vs_shm_client_dim": (_u32, [_vp]),
     "vs_shm_client_search": (_i, [_vp, _vp, _vp, _u32, _i, _u32, _u32, _u32, _vp, _vp, _vp]),

@@ -308,6 +308,8 @@ extern "C" void vs_index_free(vs_index* ix) {
                     ix->label_off, ix->label_val, ix->label_mask, ix->ls_labels, ix->ls_nodes};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    for (uint8_t* p : ix->snap)
+        if (p) (void)hipFree(p);
     SearchWorkspace& w = ix->ws;
     DevBuf* bufs[] = {&w.q_full, &w.qcodes, &w.qlabels, &w.qlabel_off, &w.hash, &w.heap_g, &w.heap_g4, &w.ghash4, &w.heap_g4b, &w.ghash4b, &w.pool_ctr, &w.fb_flag, &w.phase, &w.stream_ids,
                       &w.stream_ham, &w.stream_cnt, &w.stats, &w.status, &w.rr_dist, &w.out_ids, &w.out_tids,
@@ -425,6 +427,35 @@ extern "C" int vs_index_set_visibility(vs_index* ix, const uint8_t* visible) {
     if (!ix->visible_own) VS_HIP(hipMalloc(&ix->visible_own, std::max<size_t>(ix->d.n, 1)));
     if (ix->d.n) VS_TRY(vs_dev_upload(ix->ctx, ix->visible_own, visible, ix->d.n));
     ix->visible = ix->visible_own;
+    return VS_OK;
+}
+
+extern "C" int vs_index_snapshot_put(vs_index* ix, uint32_t snapshot, const uint8_t* visible) {
+    VS_REQUIRE(ix && snapshot >= 1 && snapshot < VS_MAX_SNAPSHOTS, "vs_index_snapshot_put: snapshot id outside [1,%d]", VS_MAX_SNAPSHOTS - 1);
+    VS_HIP(hipSetDevice(ix->ctx->device));
+    if (!visible) {
+        if (ix->snap[snapshot]) {
+            VS_HIP(hipStreamSynchronize(ix->ctx->stream));  // no launch may still read it
+            if (ix->visible == ix->snap[snapshot]) ix->visible = nullptr;
+            VS_HIP(hipFree(ix->snap[snapshot]));
+            ix->snap[snapshot] = nullptr;
+        }
+        return VS_OK;
+    }
+    if (!ix->snap[snapshot]) VS_HIP(hipMalloc(&ix->snap[snapshot], std::max<size_t>(ix->d.n, 1)));
+    else VS_HIP(hipStreamSynchronize(ix->ctx->stream));  // (replacing a mask a launch may still be reading)
+    if (ix->d.n) VS_TRY(vs_dev_upload(ix->ctx, ix->snap[snapshot], visible, ix->d.n));
+    return VS_OK;
+}
+
+extern "C" int vs_index_snapshot_use(vs_index* ix, uint32_t snapshot, const uint8_t** previous) {
+    VS_REQUIRE(ix && snapshot < VS_MAX_SNAPSHOTS, "vs_index_snapshot_use: snapshot id outside [0,%d]", VS_MAX_SNAPSHOTS - 1);
+    if (snapshot && !ix->snap[snapshot]) {
+        vs_set_error("snapshot %u has no visibility mask (vs_index_snapshot_put)", snapshot);
+        return VS_ERR_STATE;
+    }
+    if (previous) *previous = ix->visible;
+    ix->visible = snapshot ? ix->snap[snapshot] : nullptr;
     return VS_OK;
 }
 
@@ -779,7 +810,7 @@ static uint32_t fast_pool_slots(uint32_t nq, double frac) {
 static uint32_t general_pool_slots(uint32_t nq) { return std::max<uint32_t>(64, nq / 64); }
 
 static bool grow_caps(Caps& c, uint32_t ovf) {
-    bool grew = (ovf & OVF_POOL) != 0;  // pool exhausted: the relaunch hands out the regions again
+    bool grew = (ovf & (OVF_POOL | OVF_KEY)) != 0;  // pool exhausted / wide label key: the relaunch (general kernel) takes them
     if ((ovf & OVF_HEAP) && c.hcap < (1u << 24)) {
         c.hcap *= 2;
         grew = true;
@@ -1157,7 +1188,6 @@ static int upload_label_keys(vs_index* ix, const int16_t* qlabels, const uint32_
         std::vector<int16_t> l(qlabels + qlabel_off[q], qlabels + qlabel_off[q + 1]);
         std::sort(l.begin(), l.end());
         l.erase(std::unique(l.begin(), l.end()), l.end());
-        VS_REQUIRE(l.size() <= 64, "more than 64 distinct labels in one scan key");
         vals.insert(vals.end(), l.begin(), l.end());
         off[q + 1] = (uint32_t)vals.size();
     }
@@ -1476,7 +1506,6 @@ static int cursor_open(vs_scan* s, uint32_t min_rows) {
         std::vector<int16_t> l(s->labels);  // LabelSet::from(Vec<Label>): sort_unstable + dedup (AM/labels/mod.rs:30-37)
         std::sort(l.begin(), l.end());
         l.erase(std::unique(l.begin(), l.end()), l.end());
-        VS_REQUIRE(l.size() <= 64, "more than 64 distinct labels in one scan key");
         const uint32_t off[2] = {0, (uint32_t)l.size()};
         VS_TRY(devbuf_reserve(c, k.qlabels, std::max<size_t>(l.size(), 1) * 2));
         VS_TRY(devbuf_reserve(c, k.qlabel_off, 8));

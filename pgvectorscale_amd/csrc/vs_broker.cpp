@@ -37,6 +37,9 @@ struct Request {
     std::vector<int16_t> labels;
     bool has_label_key;
     uint32_t L, rescore, k;
+    uint32_t snapshot = 0;             // visibility mask the scan runs under (0 = every tuple visible)
+    bool is_put = false;               // control request: install `put_mask` (n bytes or nullptr) as mask `snapshot`
+    const uint8_t* put_mask = nullptr;
     uint32_t* out_ids;
     uint64_t* out_tids;
     float* out_dist;
@@ -48,7 +51,9 @@ struct Request {
     std::condition_variable cv;
 
     bool same_group(const Request& o) const {
-        return L == o.L && rescore == o.rescore && k == o.k && has_label_key == o.has_label_key;
+        // (scans of different snapshots never share a launch: a launch runs under ONE visibility mask)
+        return !is_put && !o.is_put && L == o.L && rescore == o.rescore && k == o.k && has_label_key == o.has_label_key &&
+               snapshot == o.snapshot;
     }
 };
 
@@ -125,9 +130,17 @@ void vs_broker::run_group_launch(std::vector<Request*>& grp, std::vector<float>&
     // scans with a label key and NULL-query scans (no key) cannot share a launch: the caller keeps them in separate groups
     const bool keys = head.has_label_key;
     vs_stats stats{};
-    rc = vs_search_batch(ix, q.data(), keys ? lab.data() : nullptr, keys ? off.data() : nullptr, nq, head.L, head.rescore, k,
-                         ids.data(), tids.data(), dist.data(), &stats);
-    if (rc != VS_OK) err = vs_last_error();
+    // the group's snapshot mask for the duration of the launch (the index-level mask of direct callers is put back)
+    const uint8_t* prev = nullptr;
+    rc = vs_index_snapshot_use(ix, head.snapshot, &prev);
+    if (rc == VS_OK) {
+        rc = vs_search_batch(ix, q.data(), keys ? lab.data() : nullptr, keys ? off.data() : nullptr, nq, head.L, head.rescore, k,
+                             ids.data(), tids.data(), dist.data(), &stats);
+        if (rc != VS_OK) err = vs_last_error();
+        (void)vs_index_set_visibility_dev(ix, prev);
+    } else {
+        err = vs_last_error();
+    }
 }
 
 void vs_broker::run() {
@@ -144,7 +157,20 @@ void vs_broker::run() {
         // one group = the scans that share the oldest request's GUCs (a NULL query never carries a label key)
         std::vector<Request*> grp;
         Request* head = queue.front();
+        if (head->is_put) {  // a snapshot mask to install: done here, on the only thread that touches the index
+            queue.pop_front();
+            lk.unlock();
+            const int prc = vs_index_snapshot_put(ix, head->snapshot, head->put_mask);
+            const std::string perr = prc == VS_OK ? "" : vs_last_error();
+            lk.lock();
+            head->rc = prc;
+            head->err = perr;
+            head->done = true;
+            head->cv.notify_one();
+            continue;
+        }
         for (auto it = queue.begin(); it != queue.end() && grp.size() < cfg.max_batch;) {
+            if ((*it)->is_put) break;  // scans posted after a mask change run after it
             if ((*it)->same_group(*head)) {
                 grp.push_back(*it);
                 it = queue.erase(it);
@@ -184,9 +210,10 @@ int vs_broker_create(vs_index* idx, const vs_broker_config* cfg, vs_broker** out
     return VS_OK;
 }
 
-int vs_broker_search(vs_broker* b, const float* query, const int16_t* labels, uint32_t n_labels, int has_label_key,
-                     uint32_t search_list_size, uint32_t rescore, uint32_t k, uint32_t* out_ids, uint64_t* out_tids, float* out_dist) {
-    if (!b || !out_ids || k == 0) {
+int vs_broker_search_snapshot(vs_broker* b, const float* query, const int16_t* labels, uint32_t n_labels, int has_label_key,
+                              uint32_t search_list_size, uint32_t rescore, uint32_t k, uint32_t snapshot, uint32_t* out_ids,
+                              uint64_t* out_tids, float* out_dist) {
+    if (!b || !out_ids || k == 0 || snapshot >= VS_MAX_SNAPSHOTS) {
         vs_set_error("vs_broker_search: bad arguments");
         return VS_ERR_INVALID;
     }
@@ -198,6 +225,7 @@ int vs_broker_search(vs_broker* b, const float* query, const int16_t* labels, ui
     r.L = search_list_size;
     r.rescore = rescore;
     r.k = k;
+    r.snapshot = snapshot;
     r.out_ids = out_ids;
     r.out_tids = out_tids;
     r.out_dist = out_dist;
@@ -208,6 +236,42 @@ int vs_broker_search(vs_broker* b, const float* query, const int16_t* labels, ui
         return VS_ERR_STATE;
     }
     b->queue.push_back(&r);
+    b->cv_work.notify_one();
+    r.cv.wait(lk, [&] { return r.done; });
+    lk.unlock();
+    if (r.rc != VS_OK) vs_set_error("%s", r.err.c_str());
+    return r.rc;
+}
+
+int vs_broker_search(vs_broker* b, const float* query, const int16_t* labels, uint32_t n_labels, int has_label_key,
+                     uint32_t search_list_size, uint32_t rescore, uint32_t k, uint32_t* out_ids, uint64_t* out_tids, float* out_dist) {
+    return vs_broker_search_snapshot(b, query, labels, n_labels, has_label_key, search_list_size, rescore, k, 0, out_ids, out_tids,
+                                     out_dist);
+}
+
+int vs_broker_snapshot_put(vs_broker* b, uint32_t snapshot, const uint8_t* visible) {
+    if (!b || snapshot < 1 || snapshot >= VS_MAX_SNAPSHOTS) {
+        vs_set_error("vs_broker_snapshot_put: snapshot id outside [1,%d]", VS_MAX_SNAPSHOTS - 1);
+        return VS_ERR_INVALID;
+    }
+    Request r;
+    r.query = nullptr;
+    r.has_label_key = false;
+    r.L = r.rescore = r.k = 0;
+    r.out_ids = nullptr;
+    r.out_tids = nullptr;
+    r.out_dist = nullptr;
+    r.snapshot = snapshot;
+    r.is_put = true;
+    r.put_mask = visible;
+    // (no waiting for company: the gather window of run() ends at once for a request that arrived max_wait_us ago)
+    r.t_arrive = std::chrono::steady_clock::now() - std::chrono::hours(1);
+    std::unique_lock<std::mutex> lk(b->mu);
+    if (b->stop) {
+        vs_set_error("vs_broker_snapshot_put: the broker is shutting down");
+        return VS_ERR_STATE;
+    }
+    b->queue.push_back(&r);  // behind the scans already queued: they run under the mask they were posted with
     b->cv_work.notify_one();
     r.cv.wait(lk, [&] { return r.done; });
     lk.unlock();

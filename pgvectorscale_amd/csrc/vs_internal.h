@@ -126,6 +126,7 @@ struct vs_index {
     uint32_t build_unreachable = 0;    // nodes the last vs_build_graph left unreachable from the start node (0xFFFFFFFF: not judged)
     const uint8_t* visible = nullptr;  // per node, 0 = the heap fetch finds nothing under the scan's snapshot (nullptr: all visible)
     uint8_t* visible_own = nullptr;    // the library's own copy (vs_index_set_visibility)
+    uint8_t* snap[VS_MAX_SNAPSHOTS] = {nullptr};  // per-snapshot masks of shared launches (vs_index_snapshot_put); slot 0 unused
     float* vecs = nullptr;
     float* vnorm = nullptr;  // per node: 0 => leave vector alone, else divisor sqrt(norm) (preprocess_cosine)
     float* vnorm_idx = nullptr;  // the same for the index slice (plain storage, cosine, num_dimensions_to_index < num_dimensions)
@@ -229,7 +230,8 @@ enum {
 size_t fast_lds_bytes(const vs_index* idx, const FastLaunch& s);
 int launch_search_fast(vs_index* idx, const FastLaunch& s);
 enum { ST_VISITS = 0, ST_CAND = 1, ST_DQ = 2, ST_READS = 3, ST_NEXT = 4, ST_GSPILL = 5, ST_INVIS = 6, ST_N = 8 };
-enum { OVF_HEAP = 1, OVF_VISITED = 2, OVF_HASH = 4, OVF_POOL = 8 };
+enum { OVF_HEAP = 1, OVF_VISITED = 2, OVF_HASH = 4, OVF_POOL = 8,
+       OVF_KEY = 16 };  // (fast kernel only) the scan key has more labels than its LDS slot holds: the general kernel runs the scan
 size_t search_lds_bytes(const vs_index* idx, const SearchLaunch& s);
 
 int launch_prepare_queries(vs_index* idx, const float* d_raw, uint32_t nq, float* d_q_full, uint64_t* d_qcodes);

@@ -255,11 +255,18 @@ __global__ __launch_bounds__(WAVE) void k_search(SearchArgs a) {
         for (uint32_t i = lane; i < s.lh; i += WAVE) lhash[i] = VS_EMPTY;
     }
     const bool labels_some = s.qlabel_off != nullptr;  // LabeledVector.labels is Some (AM/labels/mod.rs:222-236)
+    // the key's labels (LabelSet: sorted, distinct — any number of them, AM/labels/mod.rs:19-37): up to MAX_QLABELS are staged
+    // in LDS, a wider key is read where it lies in global memory
     uint32_t nql = 0;
+    const int16_t* qlp = ql;
     if (labels_some) {
         uint32_t lb = s.qlabel_off[q], le = s.qlabel_off[q + 1];
-        nql = min(le - lb, (uint32_t)MAX_QLABELS);
-        for (uint32_t i = lane; i < nql; i += WAVE) ql[i] = s.qlabels[lb + i];
+        nql = le - lb;
+        if (nql <= (uint32_t)MAX_QLABELS) {
+            for (uint32_t i = lane; i < nql; i += WAVE) ql[i] = s.qlabels[lb + i];
+        } else {
+            qlp = s.qlabels + lb;
+        }
     }
     const bool has_label_filter = labels_some && nql > 0;  // AM/scan.rs:189 ; no_filter = !has_label_filter
     __syncthreads();
@@ -380,7 +387,7 @@ __global__ __launch_bounds__(WAVE) void k_search(SearchArgs a) {
             if (!labels_some) {
                 sn = a.default_start;
             } else {
-                int16_t lab = ql[si];
+                int16_t lab = qlp[si];
                 int lo = 0, hi = (int)a.n_ls;
                 while (lo < hi) {
                     int mid = (lo + hi) >> 1;
@@ -493,7 +500,7 @@ __global__ __launch_bounds__(WAVE) void k_search(SearchArgs a) {
                         uint32_t i = 0, j = lb;
                         bool ov = false;
                         while (i < nql && j < le) {
-                            int16_t x = ql[i], y = a.label_val[j];
+                            int16_t x = qlp[i], y = a.label_val[j];
                             if (x == y) { ov = true; break; }
                             if (x < y) ++i;
                             else ++j;

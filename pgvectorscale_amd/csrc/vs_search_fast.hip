@@ -726,8 +726,10 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
     const uint8_t* const visible = FULL ? s.visible : nullptr;
     const bool labels_some = FULL && s.qlabel_off != nullptr;  // LabeledVector.labels is Some (AM/labels/mod.rs:222-236)
     uint32_t nql = 0;
+    bool wide_key = false;  // a key of more than MAX_QLABELS labels does not fit the LDS slot: the general kernel runs the scan
     if (labels_some) {
         const uint32_t lb = s.qlabel_off[q], le = s.qlabel_off[q + 1];
+        wide_key = le - lb > (uint32_t)MAX_QLABELS;
         nql = min(le - lb, (uint32_t)MAX_QLABELS);
         for (uint32_t i = lane; i < nql; i += WAVE) ql[i] = s.qlabels[lb + i];
     }
@@ -753,7 +755,7 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
 
     const uint32_t slot_limit = s.lh - s.lh / 8;  // stop at 87.5 % load: the scan is handed to the general kernel
     const uint32_t smask = (1u << s.sb) - 1u;
-    uint32_t emitted = 0, status = 0, nins = 0, hmax = 0;
+    uint32_t emitted = 0, status = wide_key ? (uint32_t)OVF_KEY : 0u, nins = 0, hmax = 0;
     uint32_t st_visits = 0, st_cand = 0, st_dq = 0, st_reads = 0;
     // optional phase clock (s_memtime): 0 pop, 1 row wait, 2 visited, 3 dedup, 4 gather, 5 push, 6 other
     uint64_t ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -893,13 +895,14 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
         return global_insert(nid, need_g, b0, v, slot_out);
     };
 
-    if (gmode) open_table();  // claimed and cleared up front
+    if (status) { /* handed over (wide label key): no region is claimed */ }
+    else if (gmode) open_table();  // claimed and cleared up front
     else if (s.only_failed) claim_region();  // (the heap spill array of a second attempt comes with the region)
 
     // ---- ListSearchResult::new: start nodes (AM/graph/mod.rs:97-124, AM/graph/start_nodes.rs:39-48) ----
     {
         uint32_t nstarts = labels_some ? nql : 1u;
-        if (a.default_start == VS_INVALID_NODE || a.n == 0) nstarts = 0;  // ListSearchResult::empty()
+        if (a.default_start == VS_INVALID_NODE || a.n == 0 || status) nstarts = 0;  // ListSearchResult::empty() (or a handed-over scan)
         for (uint32_t si = 0; si < nstarts; ++si) {
             uint32_t sn = VS_INVALID_NODE;
             if (!labels_some) {

@@ -10,8 +10,14 @@
 //
 // Slot life cycle (state word, all transitions by compare-and-swap or release stores):
 //   FREE -> CLAIMED (client fills the request) -> READY (posted) -> RUNNING (dispatcher took it) -> DONE (results in the slot)
-//   -> FREE (client copied them out).  A slot whose owner process died is reclaimed by the dispatcher.
+//   -> FREE (client copied them out).  A slot whose owner process died is reclaimed by the dispatcher (CLAIMED / DONE ->
+//   REAPING -> FREE, owner pid cleared before the slot is free again, so a slot is never freed under a live client); a client
+//   whose dispatcher PROCESS died (no orderly vs_shm_server_destroy) notices through the pid in the header and fails with
+//   VS_ERR_STATE instead of sleeping forever.  The dispatcher trusts nothing it reads from a slot: k, the GUCs and the label
+//   count are validated again on its side before a group is formed.
 #include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <cerrno>
 #include <chrono>
 #include <climits>
@@ -39,9 +45,9 @@ void vs_set_error(const char* fmt, ...);
 namespace {
 
 constexpr uint32_t SHM_MAGIC = 0x56534851u;  // "VSHQ"
-constexpr uint32_t SHM_VERSION = 1;
+constexpr uint32_t SHM_VERSION = 2;
 constexpr uint32_t SHM_MAX_LABELS = 64;
-enum : uint32_t { S_FREE = 0, S_CLAIMED = 1, S_READY = 2, S_RUNNING = 3, S_DONE = 4 };
+enum : uint32_t { S_FREE = 0, S_CLAIMED = 1, S_READY = 2, S_RUNNING = 3, S_DONE = 4, S_REAPING = 5 };
 
 struct ShmHeader {
     uint32_t magic, version;
@@ -58,7 +64,8 @@ struct SlotHead {
     int32_t owner_pid;
     uint32_t L, rescore, k, n_labels, has_label_key, null_query;
     int32_t rc;
-    char err[172];
+    uint32_t snapshot;  // visibility mask of the serving process the scan runs under (0 = every tuple visible)
+    char err[168];
     int16_t labels[SHM_MAX_LABELS];
     // followed by: float query[dim_full]; uint64_t out_tids[kmax]; uint32_t out_ids[kmax]; float out_dist[kmax]
 };
@@ -87,6 +94,9 @@ int futex_wait(std::atomic<uint32_t>* addr, uint32_t expected, int timeout_us) {
 }
 void futex_wake(std::atomic<uint32_t>* addr, int n) { syscall(SYS_futex, reinterpret_cast<uint32_t*>(addr), FUTEX_WAKE, n, nullptr, nullptr, 0); }
 
+// the dispatcher process is gone (crashed or was killed: `serving` is only cleared by an orderly shutdown)
+bool server_dead(const ShmHeader* h) { return h->server_pid > 0 && kill(h->server_pid, 0) != 0 && errno == ESRCH; }
+
 }  // namespace
 
 struct vs_shm_server {
@@ -98,6 +108,12 @@ struct vs_shm_server {
     std::atomic<bool> stop{false};
     std::thread dispatcher;
     std::atomic<uint64_t> batches{0}, scans{0}, max_batch{0};
+    // snapshot masks waiting to be installed by the dispatcher (the only thread that touches the index)
+    struct PendingPut { uint32_t snapshot; bool drop; std::vector<uint8_t> mask; int rc = 1; std::string err; };
+    std::mutex put_mu;
+    std::condition_variable put_cv;
+    std::vector<PendingPut*> puts;
+    void apply_puts();
     void run();
     void run_group(const std::vector<uint32_t>& grp);
 };
@@ -131,9 +147,16 @@ void vs_shm_server::run_group(const std::vector<uint32_t>& grp) {
         tids.assign((size_t)nq * k, 0);
         dist.assign((size_t)nq * k, 0.0f);
         vs_stats st{};
-        rc = vs_search_batch(ix, q.data(), keys ? lab.data() : nullptr, keys ? off.data() : nullptr, nq, head->L, head->rescore, k,
-                             ids.data(), tids.data(), dist.data(), &st);
-        if (rc != VS_OK) err = vs_last_error();
+        const uint8_t* prev = nullptr;  // the group's snapshot mask for the duration of the launch
+        rc = vs_index_snapshot_use(ix, head->snapshot, &prev);
+        if (rc == VS_OK) {
+            rc = vs_search_batch(ix, q.data(), keys ? lab.data() : nullptr, keys ? off.data() : nullptr, nq, head->L, head->rescore, k,
+                                 ids.data(), tids.data(), dist.data(), &st);
+            if (rc != VS_OK) err = vs_last_error();
+            (void)vs_index_set_visibility_dev(ix, prev);
+        } else {
+            err = vs_last_error();
+        }
     } catch (const std::bad_alloc&) {
         rc = VS_ERR_OOM;
         err = "vs_shm: out of host memory while assembling a batch";
@@ -155,24 +178,72 @@ void vs_shm_server::run_group(const std::vector<uint32_t>& grp) {
     }
 }
 
+void vs_shm_server::apply_puts() {
+    std::unique_lock<std::mutex> lk(put_mu);
+    if (puts.empty()) return;
+    std::vector<PendingPut*> mine;
+    mine.swap(puts);
+    lk.unlock();
+    for (PendingPut* p : mine) {
+        const int r = vs_index_snapshot_put(ix, p->snapshot, p->drop ? nullptr : p->mask.data());
+        const std::string e = r == VS_OK ? "" : vs_last_error();
+        lk.lock();
+        p->err = e;
+        p->rc = r;
+        lk.unlock();
+    }
+    put_cv.notify_all();
+}
+
 void vs_shm_server::run() {
     ShmHeader* h = m.hdr();
     std::vector<uint32_t> ready;
     auto last_reap = std::chrono::steady_clock::now();
     while (!stop.load()) {
         const uint32_t seq = h->work_seq.load(std::memory_order_acquire);
+        apply_puts();
         ready.clear();
         for (uint32_t i = 0; i < h->nslots; ++i)
             if (m.slot(i)->state.load(std::memory_order_acquire) == S_READY) ready.push_back(i);
         if (ready.empty()) {
             futex_wait(&h->work_seq, seq, 50000);  // (50 ms: also the cadence of the dead-owner check below)
         } else {
-            // gather: give the others max_wait_us to post, then take what is there (at most max_batch per group)
+            // gather: until max_wait_us have passed since the first posted request was seen, or max_batch are posted (every post
+            // bumps work_seq and wakes this thread: look again and keep waiting for the rest of the window)
             if (cfg.max_wait_us && ready.size() < cfg.max_batch) {
-                futex_wait(&h->work_seq, seq, (int)cfg.max_wait_us);
-                ready.clear();
-                for (uint32_t i = 0; i < h->nslots; ++i)
-                    if (m.slot(i)->state.load(std::memory_order_acquire) == S_READY) ready.push_back(i);
+                const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(cfg.max_wait_us);
+                for (;;) {
+                    const uint32_t seq2 = h->work_seq.load(std::memory_order_acquire);
+                    ready.clear();
+                    for (uint32_t i = 0; i < h->nslots; ++i)
+                        if (m.slot(i)->state.load(std::memory_order_acquire) == S_READY) ready.push_back(i);
+                    const auto now = std::chrono::steady_clock::now();
+                    if (ready.size() >= cfg.max_batch || now >= deadline || stop.load()) break;
+                    const auto left = std::chrono::duration_cast<std::chrono::microseconds>(deadline - now).count();
+                    futex_wait(&h->work_seq, seq2, (int)std::max<long long>(left, 1));
+                }
+            }
+            // nothing read from a slot is trusted: a request outside the segment's limits is failed here, not run
+            for (size_t a = 0; a < ready.size();) {
+                SlotHead* sa = m.slot(ready[a]);
+                const char* why = nullptr;
+                if (sa->k == 0 || sa->k > h->kmax) why = "k outside [1, kmax]";
+                else if (sa->n_labels > SHM_MAX_LABELS) why = "more labels than a slot holds";
+                else if (sa->L < 1 || sa->L > 10000) why = "diskann.query_search_list_size outside [1,10000]";
+                else if (sa->rescore > 1000) why = "diskann.query_rescore outside [0,1000]";
+                else if (sa->snapshot >= VS_MAX_SNAPSHOTS) why = "snapshot id out of range";
+                if (!why) {
+                    ++a;
+                    continue;
+                }
+                uint32_t exp = S_READY;
+                if (sa->state.compare_exchange_strong(exp, S_RUNNING)) {
+                    sa->rc = VS_ERR_INVALID;
+                    snprintf(sa->err, sizeof(sa->err), "vs_shm: request rejected by the dispatcher: %s", why);
+                    sa->state.store(S_DONE, std::memory_order_release);
+                    futex_wake(&sa->state, 1);
+                }
+                ready.erase(ready.begin() + (long)a);
             }
             std::vector<bool> taken(ready.size(), false);
             for (size_t a = 0; a < ready.size(); ++a) {
@@ -181,7 +252,8 @@ void vs_shm_server::run() {
                 std::vector<uint32_t> grp;
                 for (size_t b = a; b < ready.size() && grp.size() < cfg.max_batch; ++b) {
                     SlotHead* hb = m.slot(ready[b]);
-                    if (!taken[b] && hb->L == ha->L && hb->rescore == ha->rescore && hb->k == ha->k && hb->has_label_key == ha->has_label_key) {
+                    if (!taken[b] && hb->L == ha->L && hb->rescore == ha->rescore && hb->k == ha->k && hb->has_label_key == ha->has_label_key &&
+                        hb->snapshot == ha->snapshot) {
                         taken[b] = true;
                         hb->state.store(S_RUNNING, std::memory_order_relaxed);
                         grp.push_back(ready[b]);
@@ -196,9 +268,15 @@ void vs_shm_server::run() {
             last_reap = now;
             for (uint32_t i = 0; i < h->nslots; ++i) {
                 SlotHead* s = m.slot(i);
-                const uint32_t st = s->state.load(std::memory_order_acquire);
-                if ((st == S_CLAIMED || st == S_DONE) && s->owner_pid > 0 && kill(s->owner_pid, 0) != 0 && errno == ESRCH)
+                uint32_t st = s->state.load(std::memory_order_acquire);
+                const int32_t pid = s->owner_pid;
+                if ((st == S_CLAIMED || st == S_DONE) && pid > 0 && kill(pid, 0) != 0 && errno == ESRCH &&
+                    s->state.compare_exchange_strong(st, S_REAPING, std::memory_order_acq_rel)) {
+                    // (a claimer writes its pid only after its FREE -> CLAIMED swap: the dead owner's pid must be gone before the
+                    // slot can be claimed again, or the next pass would free it under the new, live owner)
+                    if (s->owner_pid == pid) s->owner_pid = 0;
                     s->state.store(S_FREE, std::memory_order_release);
+                }
             }
         }
     }
@@ -292,6 +370,7 @@ void vs_shm_server_destroy(vs_shm_server* s) {
     s->m.hdr()->work_seq.fetch_add(1);
     futex_wake(&s->m.hdr()->work_seq, INT_MAX);
     if (s->dispatcher.joinable()) s->dispatcher.join();
+    s->put_cv.notify_all();
     munmap(s->m.base, s->m.bytes);
     shm_unlink(s->name.c_str());
     delete s;
@@ -341,10 +420,49 @@ int vs_shm_client_open(const char* name, vs_shm_client** out) {
 
 uint32_t vs_shm_client_dim(const vs_shm_client* c) { return c ? c->m.hdr()->dim_full : 0; }
 
+int vs_shm_server_snapshot_put(vs_shm_server* s, uint32_t snapshot, const uint8_t* visible) {
+    if (!s || snapshot < 1 || snapshot >= VS_MAX_SNAPSHOTS) {
+        vs_set_error("vs_shm_server_snapshot_put: snapshot id outside [1,%d]", VS_MAX_SNAPSHOTS - 1);
+        return VS_ERR_INVALID;
+    }
+    vs_shm_server::PendingPut p;
+    p.snapshot = snapshot;
+    p.drop = visible == nullptr;
+    try {
+        if (visible) p.mask.assign(visible, visible + s->d.n);
+    } catch (const std::bad_alloc&) {
+        vs_set_error("vs_shm_server_snapshot_put: out of host memory");
+        return VS_ERR_OOM;
+    }
+    std::unique_lock<std::mutex> lk(s->put_mu);
+    s->puts.push_back(&p);
+    s->m.hdr()->work_seq.fetch_add(1);
+    futex_wake(&s->m.hdr()->work_seq, INT_MAX);
+    s->put_cv.wait(lk, [&] { return p.rc <= 0 || s->stop.load(); });
+    if (p.rc > 0) {  // the dispatcher stopped first
+        for (auto it = s->puts.begin(); it != s->puts.end(); ++it)
+            if (*it == &p) {
+                s->puts.erase(it);
+                break;
+            }
+        vs_set_error("vs_shm_server_snapshot_put: the dispatcher is shutting down");
+        return VS_ERR_STATE;
+    }
+    if (p.rc != VS_OK) vs_set_error("%s", p.err.c_str());
+    return p.rc;
+}
+
 int vs_shm_client_search(vs_shm_client* c, const float* query, const int16_t* labels, uint32_t n_labels, int has_label_key,
                          uint32_t search_list_size, uint32_t rescore, uint32_t k, uint32_t* out_ids, uint64_t* out_tids,
                          float* out_dist) {
-    if (!c || !out_ids || k == 0) {
+    return vs_shm_client_search_snapshot(c, query, labels, n_labels, has_label_key, search_list_size, rescore, k, 0, out_ids, out_tids,
+                                         out_dist);
+}
+
+int vs_shm_client_search_snapshot(vs_shm_client* c, const float* query, const int16_t* labels, uint32_t n_labels, int has_label_key,
+                                  uint32_t search_list_size, uint32_t rescore, uint32_t k, uint32_t snapshot, uint32_t* out_ids,
+                                  uint64_t* out_tids, float* out_dist) {
+    if (!c || !out_ids || k == 0 || snapshot >= VS_MAX_SNAPSHOTS) {
         vs_set_error("vs_shm_client_search: bad arguments");
         return VS_ERR_INVALID;
     }
@@ -361,7 +479,7 @@ int vs_shm_client_search(vs_shm_client* c, const float* query, const int16_t* la
     SlotHead* s = nullptr;
     const uint32_t start = (uint32_t)getpid() % h->nslots;
     for (int spin = 0; !s; ++spin) {
-        if (!h->serving.load(std::memory_order_acquire)) {
+        if (!h->serving.load(std::memory_order_acquire) || server_dead(h)) {
             vs_set_error("vs_shm_client_search: no dispatcher is attached to the segment");
             return VS_ERR_STATE;
         }
@@ -376,6 +494,7 @@ int vs_shm_client_search(vs_shm_client* c, const float* query, const int16_t* la
     s->L = search_list_size;
     s->rescore = rescore;
     s->k = k;
+    s->snapshot = snapshot;
     s->null_query = query ? 0u : 1u;
     // a NULL query ignores its keys (amrescan: LabeledVector::from_scan_key_data with a NULL vector)
     s->has_label_key = (has_label_key && query) ? 1u : 0u;
@@ -389,15 +508,19 @@ int vs_shm_client_search(vs_shm_client* c, const float* query, const int16_t* la
     for (;;) {
         const uint32_t st = s->state.load(std::memory_order_acquire);
         if (st == S_DONE) break;
-        if (!h->serving.load(std::memory_order_acquire) && st == S_READY) {  // the dispatcher went away before taking it
-            uint32_t exp = S_READY;
-            if (s->state.compare_exchange_strong(exp, S_FREE)) {
+        const bool gone = !h->serving.load(std::memory_order_acquire) || server_dead(h);
+        if (gone && (st == S_READY || (st == S_RUNNING && server_dead(h)))) {
+            // the dispatcher went away before taking the request, or died with it in hand: nobody will ever complete the slot
+            uint32_t exp = st;
+            if (s->state.compare_exchange_strong(exp, S_CLAIMED)) {
+                s->owner_pid = 0;
+                s->state.store(S_FREE, std::memory_order_release);
                 vs_set_error("vs_shm_client_search: the dispatcher went away");
                 return VS_ERR_STATE;
             }
             continue;
         }
-        futex_wait(&s->state, st, 100000);
+        futex_wait(&s->state, st, 100000);  // (the timeout is the cadence of the liveness check above)
     }
     const int rc = s->rc;
     if (rc == VS_OK) {

@@ -395,15 +395,24 @@ class Broker:
         check(self._L.vs_broker_create(index.h, C.byref(cfg), C.byref(h)))
         self.h = h
 
-    def search(self, query, labels=None, search_list_size=DEFAULT_QUERY_SEARCH_LIST_SIZE, rescore=DEFAULT_QUERY_RESCORE, k=10):
+    def search(self, query, labels=None, search_list_size=DEFAULT_QUERY_SEARCH_LIST_SIZE, rescore=DEFAULT_QUERY_RESCORE, k=10,
+               snapshot=0):
+        """snapshot: id of the visibility mask the scan runs under (snapshot_put; 0 = every heap tuple visible)"""
         q = None if query is None else np.ascontiguousarray(query, np.float32).reshape(self.index.desc.dim_full)
         lab = None if labels is None else np.ascontiguousarray(labels, np.int16)
         ids = np.empty(k, np.uint32)
         tids = np.empty(k, np.uint64)
         dist = np.empty(k, np.float32)
-        check(self._L.vs_broker_search(self.h, _p(q), _p(lab), 0 if lab is None else lab.size, int(labels is not None),
-                                       search_list_size, rescore, k, _p(ids), _p(tids), _p(dist)))
+        check(self._L.vs_broker_search_snapshot(self.h, _p(q), _p(lab), 0 if lab is None else lab.size, int(labels is not None),
+                                                search_list_size, rescore, k, snapshot, _p(ids), _p(tids), _p(dist)))
         return ids, tids, dist
+
+    def snapshot_put(self, snapshot, visible):
+        """hands the dispatcher the per-node visibility mask of snapshot id 1..15 (None drops it); any thread"""
+        v = None if visible is None else np.ascontiguousarray(visible, np.uint8)
+        if v is not None and v.shape != (self.index.desc.n,):
+            raise ValueError("one byte per node")
+        check(self._L.vs_broker_snapshot_put(self.h, snapshot, _p(v)))
 
     def beginscan(self):
         """ambeginscan for a backend whose scans go through this broker"""
@@ -432,6 +441,13 @@ class ShmServer:
         check(self._L.vs_shm_server_create(index.h, name.encode(), nslots, kmax, C.byref(cfg), C.byref(h)))
         self.h = h
 
+    def snapshot_put(self, snapshot, visible):
+        """the serving process's per-node visibility mask of snapshot id 1..15 (None drops it)"""
+        v = None if visible is None else np.ascontiguousarray(visible, np.uint8)
+        if v is not None and v.shape != (self.index.desc.n,):
+            raise ValueError("one byte per node")
+        check(self._L.vs_shm_server_snapshot_put(self.h, snapshot, _p(v)))
+
     def stats(self):
         st = _lib.BrokerStats()
         check(self._L.vs_shm_server_get_stats(self.h, C.byref(st)))
@@ -453,14 +469,15 @@ class ShmClient:
         self.h = h
         self.dim = int(self._L.vs_shm_client_dim(h))
 
-    def search(self, query, labels=None, search_list_size=DEFAULT_QUERY_SEARCH_LIST_SIZE, rescore=DEFAULT_QUERY_RESCORE, k=10):
+    def search(self, query, labels=None, search_list_size=DEFAULT_QUERY_SEARCH_LIST_SIZE, rescore=DEFAULT_QUERY_RESCORE, k=10,
+               snapshot=0):
         q = None if query is None else np.ascontiguousarray(query, np.float32).reshape(self.dim)
         lab = None if labels is None else np.ascontiguousarray(labels, np.int16)
         ids = np.empty(k, np.uint32)
         tids = np.empty(k, np.uint64)
         dist = np.empty(k, np.float32)
-        check(self._L.vs_shm_client_search(self.h, _p(q), _p(lab), 0 if lab is None else lab.size, int(labels is not None),
-                                           search_list_size, rescore, k, _p(ids), _p(tids), _p(dist)))
+        check(self._L.vs_shm_client_search_snapshot(self.h, _p(q), _p(lab), 0 if lab is None else lab.size, int(labels is not None),
+                                                    search_list_size, rescore, k, snapshot, _p(ids), _p(tids), _p(dist)))
         return ids, tids, dist
 
     def close(self):

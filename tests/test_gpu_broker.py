@@ -125,3 +125,65 @@ def test_amgettuple_mirror_on_a_broker(gpu_ctx, oracle):
     assert st["max_batch"] >= 3 and st["batches"] < st["scans"], st
     broker.close()
     ix.close()
+
+
+def test_backends_with_different_snapshots_never_share_a_mask(gpu_ctx, oracle):
+    """Backends see different snapshots, so a shared launch cannot take "the index's" visibility mask: every request names its
+    snapshot, the dispatcher only groups scans of one snapshot and runs the group under that mask (AM/scan.rs:268-272: a candidate
+    the snapshot cannot see is fetched, counted and dropped before the rescore window).  Three snapshots in flight at once."""
+    import pgvectorscale_amd as P
+    O = oracle
+    ti = TestIndex(n=2000, dim_full=48, bits=2, R=24, distance=O.L2, seed=31, kind="clustered", L_build=48)
+    ix = ti.upload(gpu_ctx)
+    rng = np.random.default_rng(2)
+    masks = {0: None, 1: (rng.random(ti.n) > 0.3).astype(np.uint8), 2: (rng.random(ti.n) > 0.6).astype(np.uint8)}
+    # a direct caller's index-level mask must survive the broker's launches untouched, and must not leak into them
+    own = (rng.random(ti.n) > 0.5).astype(np.uint8)
+    ix.set_visibility(own)
+    nthreads, per_thread = 12, 5
+    q = ti.queries(nthreads * per_thread, seed=5, kind="clustered")
+    snap_of = rng.integers(0, 3, len(q))
+    want = {}
+    for i in range(len(q)):
+        ti.oracle.set_visibility(masks[int(snap_of[i])])
+        oi, od, _ = ti.oracle.search_batch(q[i:i + 1], L=20, rescore=15, k=10)
+        want[i] = (oi[0], od[0])
+    ti.oracle.set_visibility(None)
+    broker = P.Broker(ix, max_batch=64, max_wait_us=20000)
+    with pytest.raises(P.VsError, match="no visibility mask"):
+        broker.search(q[0], None, 20, 15, 10, snapshot=1)  # named before it was put
+    broker.snapshot_put(1, masks[1])
+    broker.snapshot_put(2, masks[2])
+    got, errors = {}, []
+    start = threading.Barrier(nthreads)
+
+    def client(t):
+        try:
+            start.wait()
+            for j in range(per_thread):
+                i = t * per_thread + j
+                got[i] = broker.search(q[i], None, 20, 15, 10, snapshot=int(snap_of[i]))
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=client, args=(t,)) for t in range(nthreads)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors[:3]
+    for i in range(len(q)):
+        assert (got[i][0] == want[i][0]).all(), (i, int(snap_of[i]))
+        assert (got[i][2].view(np.uint32) == want[i][1].view(np.uint32)).all(), i
+    assert broker.stats()["batches"] < len(q)  # scans of one snapshot did share launches
+    # the index-level mask is what it was: a direct scan still runs under it
+    ti.oracle.set_visibility(own)
+    gi, _, _, _ = ix.search_batch(q[:4], search_list_size=20, rescore=15, k=10)
+    oi, _, _ = ti.oracle.search_batch(q[:4], L=20, rescore=15, k=10)
+    ti.oracle.set_visibility(None)
+    assert (gi == oi).all()
+    broker.snapshot_put(2, None)
+    with pytest.raises(P.VsError, match="no visibility mask"):
+        broker.search(q[0], None, 20, 15, 10, snapshot=2)
+    broker.close()
+    ix.close()

@@ -139,3 +139,95 @@ def test_slot_of_a_dead_client_is_reclaimed(gpu_ctx, oracle):
     c.close()
     srv.close()
     ix.close()
+
+
+def test_snapshot_masks_across_processes(gpu_ctx, oracle):
+    """a client names the snapshot of the serving process its scan runs under; scans of different snapshots are not grouped"""
+    import pgvectorscale_amd as P
+    ti = TestIndex(**KW)
+    ix = ti.upload(gpu_ctx)
+    q = ti.queries(3, seed=15, kind="gauss")
+    mask = (np.random.default_rng(8).random(ti.n) > 0.4).astype(np.uint8)
+    name = f"/vs_shm_snap_{os.getpid()}"
+    srv = P.ShmServer(ix, name, nslots=4, kmax=16, max_batch=64, max_wait_us=1000)
+    c = P.ShmClient(name)
+    with pytest.raises(P.VsError, match="no visibility mask"):
+        c.search(q[0], None, 30, 12, 10, snapshot=3)
+    srv.snapshot_put(3, mask)
+    for snap, m in ((3, mask), (0, None)):
+        ti.oracle.set_visibility(m)
+        oi, od, _ = ti.oracle.search_batch(q, L=30, rescore=12, k=10)
+        for i in range(len(q)):
+            ids, _, dist = c.search(q[i], None, 30, 12, 10, snapshot=snap)
+            assert (ids == oi[i]).all() and (dist.view(np.uint32) == od[i].view(np.uint32)).all()
+    ti.oracle.set_visibility(None)
+    with pytest.raises(P.VsError):
+        c.search(q[0], None, 30, 12, 10, snapshot=99)
+    c.close()
+    srv.close()
+    ix.close()
+
+
+def _doomed_server(name, lib_path, emu, ready, kw):
+    """a serving process (device context + index + dispatcher) that the parent kills without ceremony"""
+    import time
+    if emu:
+        os.environ["VS_EMU"] = emu
+    from pgvectorscale_amd import _lib
+    if lib_path:
+        _lib.LIB_PATH = lib_path
+    import pgvectorscale_amd as P
+    ti = TestIndex(**kw)
+    ctx = P.Context(0)
+    ix = ti.upload(ctx)
+    srv = P.ShmServer(ix, name, nslots=2, kmax=16, max_batch=64, max_wait_us=3_000_000)  # requests wait 3 s for company
+    ready.set()
+    time.sleep(600)
+    srv.close()
+
+
+def test_client_notices_a_dispatcher_that_died(oracle):
+    """SIGKILL of the serving process leaves `serving` set in the segment: a client that is already waiting for its rows, and one
+    that arrives afterwards, must both come back with an error instead of sleeping forever (the pid in the header is checked)"""
+    import signal
+    import threading
+    import time
+    import pgvectorscale_amd as P
+    from pgvectorscale_amd import _lib
+    kw = dict(n=400, dim_full=32, bits=2, R=16, distance=1, seed=3, kind="gauss", L_build=32)
+    name = f"/vs_shm_crash_{os.getpid()}"
+    ctx = mp.get_context("spawn")
+    ready = ctx.Event()
+    p = ctx.Process(target=_doomed_server, args=(name, _lib.LIB_PATH, os.environ.get("VS_EMU", ""), ready, kw))
+    p.start()
+    assert ready.wait(300), "serving process did not come up"
+    q = TestIndex(**kw).queries(2, seed=1, kind="gauss")
+    c = P.ShmClient(name)
+    result = {}
+
+    def waiting_client():
+        try:
+            c.search(q[0], None, 20, 8, 10)  # posted, then held back by the 3 s gather window
+            result["first"] = "returned rows"
+        except P.VsError as e:
+            result["first"] = f"error: {e}"
+
+    th = threading.Thread(target=waiting_client)
+    th.start()
+    time.sleep(0.5)
+    os.kill(p.pid, signal.SIGKILL)
+    p.join(30)
+    th.join(20)
+    assert not th.is_alive(), "the waiting client never came back"
+    assert result["first"].startswith("error"), result
+    c2 = P.ShmClient(name)  # the segment is still there (nobody unlinked it), its dispatcher is not
+    t0 = time.time()
+    with pytest.raises(P.VsError):
+        c2.search(q[1], None, 20, 8, 10)
+    assert time.time() - t0 < 10
+    c2.close()
+    c.close()
+    try:  # what vs_shm_server_destroy would have done
+        os.unlink("/dev/shm" + name)
+    except OSError:
+        pass

@@ -34,7 +34,20 @@ def _worker(rank, world, port, nq_total, out_path):
     b, e = shard_range(nq_total, world, rank)
     ids, d, _ = ti.oracle.search_batch(q[b:e], L=30, rescore=10, k=7)
     counts = [shard_range(nq_total, world, r)[1] - shard_range(nq_total, world, r)[0] for r in range(world)]
-    gi, gd = gather_topk(torch.from_numpy(ids.astype(np.int64)), torch.from_numpy(d), counts=counts)
+    gi, gd = gather_topk(torch.from_numpy(ids.astype(np.int64)), torch.from_numpy(d), counts=counts, verify=True)
+    gi2, gd2 = gather_topk(torch.from_numpy(ids.astype(np.int64)), torch.from_numpy(d), nq_total=nq_total)  # sizes by arithmetic
+    assert torch.equal(gi, gi2) and torch.equal(gd.view(torch.int32), gd2.view(torch.int32))
+    if nq_total % world:  # uneven shards passed off as equal ones: caught on every rank before the data collective
+        try:
+            gather_topk(torch.from_numpy(ids.astype(np.int64)), torch.from_numpy(d), verify=True)
+            raise AssertionError("uneven shards went unnoticed")
+        except ValueError as e:
+            assert "ranks hold" in str(e)
+    try:
+        gather_topk(torch.from_numpy(ids.astype(np.int64)), torch.from_numpy(d.astype(np.float64)), counts=counts)
+        raise AssertionError("float64 distances accepted")
+    except TypeError:
+        pass
     if rank == 0:
         np.savez(out_path, ids=gi.numpy(), dist=gd.numpy())
     dist.barrier()

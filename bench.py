@@ -211,6 +211,10 @@ def main():
     ap.add_argument("--build-l", type=int, default=100)
     ap.add_argument("--fixed", default=None, help="L,rescore to use instead of the recall sweep")
     ap.add_argument("--skip-cpu", action="store_true")
+    ap.add_argument("--pipeline", type=int, default=1, choices=[1, 2],
+                    help="batches in flight: 2 = the steps alternate between two views of the index (two streams), so the rerank of "
+                         "a step runs under the search of the next one; the kernel times of the roofline then come from the "
+                         "(sequential) warm-up steps")
     ap.add_argument("--graph-cache", default="auto",
                     help="file prefix to keep the built neighbor array in: loaded when present, written (by local rank 0) "
                          "after a build otherwise.  The build is deterministic and outside the timed region; the cache only "
@@ -473,21 +477,68 @@ def main():
             out_ids, out_dist = out_ids[:nq], out_dist[:nq]
             nh = min(nh, nq)
             log(f"{e}; continuing with {nq} scans per step")
-    for b in range(args.warmup):
-        step(b)
-    ctx.profile_enable(True)
-    ctx.profile_read(reset=True)
-    tot = {}
-    barrier()
-    t0 = time.perf_counter()
-    for b in range(args.warmup, n_batches):
-        st = step(b)
-        for kk, vv in st.items():
-            tot[kk] = tot.get(kk, 0) + vv
-    barrier()
-    elapsed = time.perf_counter() - t0
-    prof = ctx.profile_read(reset=True)
-    ctx.profile_enable(False)
+    if args.pipeline == 1:
+        for b in range(args.warmup):
+            step(b)
+        ctx.profile_enable(True)
+        ctx.profile_read(reset=True)
+        tot = {}
+        barrier()
+        t0 = time.perf_counter()
+        for b in range(args.warmup, n_batches):
+            st = step(b)
+            for kk, vv in st.items():
+                tot[kk] = tot.get(kk, 0) + vv
+        barrier()
+        elapsed = time.perf_counter() - t0
+        prof = ctx.profile_read(reset=True)
+        ctx.profile_enable(False)
+    else:
+        # two batches in flight: even steps through the index, odd steps through a view of it on a second context (stream), each
+        # with its own output block; a step is collected after the next one has been submitted.  Kernel times are only meaningful
+        # when a kernel has the chip to itself, so they (and the work counters that go with them) come from the warm-up steps.
+        assert args.warmup >= 1, "--pipeline 2 takes the kernel times of the roofline from the warm-up steps"
+        ctx2 = P.Context(local_rank)
+        ix2 = ix.view(ctx2)
+        outs = [(out_ids, out_dist), (torch.empty_like(out_ids), torch.empty_like(out_dist))]
+        lanes = [ix, ix2]
+
+        def submit(b):
+            oi, od = outs[b % 2]
+            lanes[b % 2].search_batch_dev(qbuf[b], nq, L, S, k, C.c_void_p(oi.data_ptr()), None, C.c_void_p(od.data_ptr()),
+                                          d_qlabels=qkeys[b] and qkeys[b][2], d_qlabel_off=qkeys[b] and qkeys[b][3])
+
+        def collect(b):
+            st_ = lanes[b % 2].search_batch_dev_finish()
+            if world > 1:
+                gather_topk(*outs[b % 2])
+            return st_
+
+        submit(1)  # (the view sizes its launches from what its own first batch needed)
+        collect(1)
+        ctx.profile_enable(True)
+        ctx.profile_read(reset=True)
+        tot = {}
+        for b in range(args.warmup):
+            st = step(b)
+            for kk, vv in st.items():
+                tot[kk] = tot.get(kk, 0) + vv
+        prof = ctx.profile_read(reset=True)
+        ctx.profile_enable(False)
+        barrier()
+        ctx2.sync()
+        t0 = time.perf_counter()
+        prev = None
+        for b in range(args.warmup, n_batches):
+            submit(b)
+            if prev is not None:
+                collect(prev)
+            prev = b
+        collect(prev)
+        barrier()
+        ctx2.sync()
+        elapsed = time.perf_counter() - t0
+        out_ids, out_dist = outs[(n_batches - 1) % 2]  # the rows of the last timed step
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -588,7 +639,8 @@ def main():
                                                              f"two labels; label-aware build: filtered + unfiltered insert pass, per-label start nodes)" if NL else ""),
                    "labels": NL, "n": n, "dim": dim, "bits": bits, "words": W,
                    "num_neighbors": R, "queries_per_step_per_gpu": nq, "search_list_size": L, "rescore": S, "k": k,
-                   "parallelism": f"query-sharded x{world}, index replicated" if world > 1 else "single GPU"},
+                   "parallelism": f"query-sharded x{world}, index replicated" if world > 1 else "single GPU",
+                   "batches_in_flight": args.pipeline},
         "recall_at_k": round(recall, 4),
         "recall_validate": round(recall_validate, 4),
         "recall_heldout": None if recall_heldout is None else round(recall_heldout, 4),
@@ -686,6 +738,9 @@ def main():
 
     if rank == 0:
         print(json.dumps(result), flush=True)
+    if args.pipeline == 2:
+        ix2.close()
+        ctx2.close()
     ix.close()
     ctx.close()
     if world > 1:

@@ -241,6 +241,10 @@ def main():
     ap.add_argument("--build-l", type=int, default=100)
     ap.add_argument("--fixed", default=None, help="L,rescore to use instead of the recall sweep")
     ap.add_argument("--skip-cpu", action="store_true")
+    ap.add_argument("--pipeline", type=int, default=1, choices=[1, 2],
+                    help="batches in flight: 2 = the steps alternate between two views of the index (two streams), so the rerank of "
+                         "a step runs under the search of the next one; the kernel times of the roofline then come from the "
+                         "(sequential) warm-up steps")
     ap.add_argument("--graph-cache", default="auto",
                     help="file prefix to keep the built neighbor array in: loaded when present, written (by local rank 0) "
                          "after a build otherwise.  The build is deterministic and outside the timed region; the cache only "
@@ -545,33 +549,94 @@ def main():
             nh = min(nh, nq)
             log(f"{e}; continuing with {nq} scans per step")
 
+    # --pipeline 2: two batches in flight — even steps through the index, odd steps through a view of it on a second context
+    # (stream), each with its own output block; a step is collected after the next one has been submitted, so the bandwidth-bound
+    # rerank of step i runs under the latency-bound search of step i + 1 and the step time tends to max(search, rerank + resort)
+    # instead of their sum.  Kernel times are only meaningful when a kernel has the chip to itself, so the roofline's come from
+    # sequential steps run right before the timed region (the warm-up steps), with the work counters that belong to them.
+    pipe = {"ready": False}
+
+    def pipe_setup():
+        if not pipe["ready"]:
+            pipe["ctx2"] = P.Context(0 if EMU else local_rank)
+            pipe["ix2"] = ix.view(pipe["ctx2"])
+            pipe["outs"] = [(out_ids, out_dist), (torch.empty_like(out_ids), torch.empty_like(out_dist))]
+            pipe["lanes"] = [ix, pipe["ix2"]]
+            pipe["ready"] = True
+
+    def pipe_submit(b_):
+        oi, od = pipe["outs"][b_ % 2]
+        pipe["lanes"][b_ % 2].search_batch_dev(qbuf[b_], nq, L, S, k, C.c_void_p(oi.data_ptr()), None, C.c_void_p(od.data_ptr()),
+                                               d_qlabels=qkeys[b_] and qkeys[b_][2], d_qlabel_off=qkeys[b_] and qkeys[b_][3])
+
+    def pipe_collect(b_):
+        st_ = pipe["lanes"][b_ % 2].search_batch_dev_finish()
+        if world > 1:
+            gather_topk(*pipe["outs"][b_ % 2])
+        return st_
+
     def timed_pass():
-        """W untimed steps, then exactly K timed steps between barriers -> (seconds (max over ranks), kernel profile, counters)"""
-        for b_ in range(args.warmup):
-            step(b_)
-        ctx.profile_enable(True)
-        ctx.profile_read(reset=True)
-        tot_ = {}
-        barrier()
-        t0_ = time.perf_counter()
-        for b_ in range(args.warmup, n_batches):
-            st_ = step(b_)
-            for kk, vv in st_.items():
+        """W untimed steps, then exactly K timed steps between barriers -> (seconds (max over ranks), kernel profile, counters the
+        profile belongs to, counters of the timed steps, the output block that holds the rows of the last timed step)"""
+        last_out = (out_ids, out_dist)
+        if args.pipeline == 1:
+            for b_ in range(args.warmup):
+                step(b_)
+            ctx.profile_enable(True)
+            ctx.profile_read(reset=True)
+            tot_ = {}
+            barrier()
+            t0_ = time.perf_counter()
+            for b_ in range(args.warmup, n_batches):
+                st_ = step(b_)
+                for kk, vv in st_.items():
+                    tot_[kk] = tot_.get(kk, 0) + vv
+            barrier()
+            el_ = time.perf_counter() - t0_
+            prof_ = ctx.profile_read(reset=True)
+            ctx.profile_enable(False)
+            ptot_ = tot_
+        else:
+            assert args.warmup >= 1, "--pipeline 2 takes the kernel times of the roofline from the warm-up steps"
+            pipe_setup()
+            pipe_submit(1 % n_batches)  # (the view sizes its launches from what its own first batch needed)
+            pipe_collect(1 % n_batches)
+            ctx.profile_enable(True)
+            ctx.profile_read(reset=True)
+            ptot_ = {}
+            for b_ in range(args.warmup):
+                st_ = step(b_)
+                for kk, vv in st_.items():
+                    ptot_[kk] = ptot_.get(kk, 0) + vv
+            prof_ = ctx.profile_read(reset=True)
+            ctx.profile_enable(False)
+            tot_ = {}
+            barrier()
+            pipe["ctx2"].sync()
+            t0_ = time.perf_counter()
+            prev_ = None
+            for b_ in range(args.warmup, n_batches):
+                pipe_submit(b_)
+                if prev_ is not None:
+                    for kk, vv in pipe_collect(prev_).items():
+                        tot_[kk] = tot_.get(kk, 0) + vv
+                prev_ = b_
+            for kk, vv in pipe_collect(prev_).items():
                 tot_[kk] = tot_.get(kk, 0) + vv
-        barrier()
-        el_ = time.perf_counter() - t0_
-        prof_ = ctx.profile_read(reset=True)
-        ctx.profile_enable(False)
+            barrier()
+            pipe["ctx2"].sync()
+            el_ = time.perf_counter() - t0_
+            last_out = pipe["outs"][(n_batches - 1) % 2]
         if world > 1:
             import torch.distributed as dist
             t_ = torch.tensor([el_], dtype=torch.float64, device=dev)
             dist.all_reduce(t_, op=dist.ReduceOp.MAX)
             el_ = float(t_.item())
-        return el_, prof_, tot_
+        return el_, prof_, ptot_, tot_, last_out
 
-    def heldout_stats():
-        """recall of the rows the LAST TIMED step left in out_ids (every rank checks its own batch; pooled over the ranks)"""
-        hs_ = recall_stats(np, out_ids[:nh].cpu().numpy().view(np.uint32), held[0][:nh], held[1][:nh])
+    def heldout_stats(rows_t):
+        """recall of the rows the LAST TIMED step produced (every rank checks its own batch; pooled over the ranks)"""
+        hs_ = recall_stats(np, rows_t[:nh].cpu().numpy().view(np.uint32), held[0][:nh], held[1][:nh])
         if world > 1:
             import torch.distributed as dist
             t_ = torch.tensor([hs_["recall"], hs_["se"] ** 2], dtype=torch.float64, device=dev)
@@ -586,10 +651,10 @@ def main():
     retimed = 0
     hs = None
     while True:
-        elapsed, prof, tot = timed_pass()
+        elapsed, prof, ptot, tot, (last_ids, last_dist) = timed_pass()
         if held is None:
             break
-        hs = heldout_stats()
+        hs = heldout_stats(last_ids)
         log(f"recall@{k} of the timed results (first {nh} queries of the last timed batch" + (f", x{world} ranks" if world > 1 else "")
             + f"): {hs['recall']:.4f} (lower 95 % bound {hs['lower95']:.4f}) at L={L} rescore={S}")
         if hs["recall"] >= args.recall_target or args.fixed or S >= 1000 or retimed >= 8 or recall < args.recall_target:
@@ -610,9 +675,11 @@ def main():
     s_ms, s_n = prof["search"]
     f_ms, f_n = prof["search_fallback"]
     r_ms, r_n = prof["rerank"]
-    fb_bytes = tot.get("fallback_visited_nodes", 0) * 4 * R + tot.get("fallback_quantized_distance_comparisons", 0) * 8 * W
-    alg_bytes_search = tot["visited_nodes"] * 4 * R + tot["quantized_distance_comparisons"] * 8 * W - fb_bytes
-    alg_bytes_rerank = tot["full_distance_comparisons"] * 4 * dim
+    # (ptot: the counters of the steps the kernel profile was taken over — the timed steps, or with --pipeline 2 the sequential
+    # warm-up steps)
+    fb_bytes = ptot.get("fallback_visited_nodes", 0) * 4 * R + ptot.get("fallback_quantized_distance_comparisons", 0) * 8 * W
+    alg_bytes_search = ptot["visited_nodes"] * 4 * R + ptot["quantized_distance_comparisons"] * 8 * W - fb_bytes
+    alg_bytes_rerank = ptot["full_distance_comparisons"] * 4 * dim
     per_launch = alg_bytes_search / max(s_n, 1)
     avg_ms = s_ms / max(s_n, 1)
     achieved = per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
@@ -645,12 +712,15 @@ def main():
                 "frac": round(achieved / 8000.0, 5), "traffic": traffic, "traffic_source": traffic_source,
                 "traffic_other_operating_point": traffic_ref,
                 "alg_bytes_per_launch": int(per_launch), "avg_kernel_ms": round(avg_ms, 4), "launches": s_n,
-                "alg_bytes_per_query": round(alg_bytes_search / max(tot.get("queries", 1) - tot.get("fallback_scans", 0), 1), 1)}
+                "alg_bytes_per_query": round(alg_bytes_search / max(ptot.get("queries", 1) - ptot.get("fallback_scans", 0), 1), 1),
+                "timed_over": "the timed steps" if args.pipeline == 1 else
+                              f"{args.warmup} sequential warm-up steps (the timed steps overlap two batches: a kernel's duration there "
+                              "includes the other stream's kernels)"}
     kernels = {name: {"ms_total": round(ms, 3), "launches": cnt} for name, (ms, cnt) in prof.items() if cnt}
     if r_ms > 0:
         kernels["rerank"]["achieved_GBps"] = round(alg_bytes_rerank / (r_ms * 1e-3) / 1e9, 2)
     if f_n and f_ms > 0:
-        kernels["search_fallback"]["scans"] = tot.get("fallback_scans", 0)
+        kernels["search_fallback"]["scans"] = ptot.get("fallback_scans", 0)
 
     # ---- K5: the flat SBQ scan (same codes, streamed instead of gathered): the bandwidth-bound form of the candidate scan
     # at every tile size of the kernel (VS_SCAN_Q = 4, 8, 16 queries per pass over the codes): bytes per launch fall with the
@@ -737,7 +807,8 @@ def main():
                                                              f"two labels; label-aware build: filtered + unfiltered insert pass, per-label start nodes)" if NL else ""),
                    "labels": NL, "n": n, "dim": dim, "bits": bits, "words": W,
                    "num_neighbors": R, "queries_per_step_per_gpu": nq, "search_list_size": L, "rescore": S, "k": k,
-                   "parallelism": f"query-sharded x{world}, index replicated" if world > 1 else "single GPU"},
+                   "parallelism": f"query-sharded x{world}, index replicated" if world > 1 else "single GPU",
+                   "batches_in_flight": args.pipeline},
         "recall_at_k": round(recall, 4),
         "recall_validate": round(recall_validate, 4),
         "recall_heldout": None if recall_heldout is None else round(recall_heldout, 4),
@@ -843,6 +914,9 @@ def main():
 
     if rank == 0:
         print(json.dumps(result), flush=True)
+    if pipe["ready"]:
+        pipe["ix2"].close()
+        pipe["ctx2"].close()
     ix.close()
     ctx.close()
     if world > 1:

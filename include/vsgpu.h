@@ -137,6 +137,12 @@ int vs_index_upload(vs_ctx* ctx, const vs_index_desc* desc, const vs_index_host*
  * vs_build_graph); contents are undefined until filled. */
 int vs_index_alloc(vs_ctx* ctx, const vs_index_desc* desc, int with_vecs, vs_index** out);
 void vs_index_free(vs_index* idx);
+/* A second handle on the SAME device arrays with its own search workspace, bound to `ctx` (another HIP stream of the same device):
+ * batches submitted through different views run concurrently — the bandwidth-bound rerank of one under the latency-bound search
+ * of the next.  The reference has one backend per scan and nothing to share (AM/scan.rs:308-333); this is the handle a GPU broker
+ * gives each of its submission lanes.  The arrays stay owned by `src`: no upload / build / visibility change while a view has a
+ * batch in flight, and every view is freed before `src`. */
+int vs_index_view(vs_index* src, vs_ctx* ctx, vs_index** out);
 int vs_index_get_desc(const vs_index* idx, vs_index_desc* out);
 enum vs_array { VS_ARR_CODES = 0, VS_ARR_NBRS = 1, VS_ARR_TIDS = 2, VS_ARR_VECS = 3, VS_ARR_MEAN = 4, VS_ARR_M2 = 5,
                 VS_ARR_VNORM = 6, VS_ARR_LABEL_OFF = 7, VS_ARR_LABEL_VAL = 8 };

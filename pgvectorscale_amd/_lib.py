@@ -90,6 +90,7 @@ SYMBOLS = {
     "vs_index_upload": (_i, [_vp, C.POINTER(IndexDesc), C.POINTER(IndexHost), C.POINTER(_vp)]),
     "vs_index_alloc": (_i, [_vp, C.POINTER(IndexDesc), _i, C.POINTER(_vp)]),
     "vs_index_free": (None, [_vp]),
+    "vs_index_view": (_i, [_vp, _vp, _vp]),
     "vs_index_get_desc": (_i, [_vp, C.POINTER(IndexDesc)]),
     "vs_index_array": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_u32)]),
     "vs_index_set_quantizer": (_i, [_vp, _vp, _vp, _u64]),

@@ -306,10 +306,12 @@ extern "C" void vs_index_free(vs_index* ix) {
     (void)hipStreamSynchronize(ix->ctx->stream);
     void* ptrs[] = {ix->codes, ix->nbrs, ix->tids, ix->vecs, ix->vnorm, ix->vnorm_idx, ix->mean, ix->m2, ix->visible_own,
                     ix->label_off, ix->label_val, ix->label_mask, ix->ls_labels, ix->ls_nodes};
-    for (void* p : ptrs)
-        if (p) (void)hipFree(p);
-    for (uint8_t* p : ix->snap)
-        if (p) (void)hipFree(p);
+    if (!ix->is_view) {  // (a view shares the arrays of the index it was made from)
+        for (void* p : ptrs)
+            if (p) (void)hipFree(p);
+        for (uint8_t* p : ix->snap)
+            if (p) (void)hipFree(p);
+    }
     SearchWorkspace& w = ix->ws;
     DevBuf* bufs[] = {&w.q_full, &w.qcodes, &w.qlabels, &w.qlabel_off, &w.hash, &w.heap_g, &w.heap_g4, &w.ghash4, &w.heap_g4b, &w.ghash4b, &w.pool_ctr, &w.fb_flag, &w.phase, &w.stream_ids,
                       &w.stream_ham, &w.stream_cnt, &w.stats, &w.status, &w.rr_dist, &w.out_ids, &w.out_tids,
@@ -318,6 +320,23 @@ extern "C" void vs_index_free(vs_index* ix) {
     free(w.pend_blob);
     w.pend_blob = nullptr;
     delete ix;
+}
+
+static int vs_index_view_impl(vs_index* src, vs_ctx* c, vs_index** out) {
+    VS_REQUIRE(src && c && out, "vs_index_view: bad args");
+    VS_REQUIRE(c->device == src->ctx->device, "vs_index_view: the context is on device %d, the index on device %d", c->device,
+               src->ctx->device);
+    vs_index* v = new vs_index(*src);  // the pointers and the geometry; the workspace below is this handle's own
+    v->ctx = c;
+    v->is_view = true;
+    v->visible_own = nullptr;
+    v->ws = SearchWorkspace{};
+    v->last_stats = vs_stats{};
+    *out = v;
+    return VS_OK;
+}
+extern "C" int vs_index_view(vs_index* src, vs_ctx* c, vs_index** out) {
+    return vs_guard("vs_index_view", [&] { return vs_index_view_impl(src, c, out); });
 }
 
 static int index_alloc_fill(vs_ctx* c, const vs_index_desc* desc, vs_index* ix) {

@@ -116,6 +116,7 @@ struct ScanObs {
 
 struct vs_index {
     vs_ctx* ctx = nullptr;
+    bool is_view = false;  // vs_index_view: the device arrays belong to another handle
     vs_index_desc d{};
     uint32_t code_stride = 0;  // u64 words per code row (W rounded up to even, zero padded)
     uint32_t nbr_stride = 0;   // u32 per neighbor row (R rounded up to 16)

@@ -97,6 +97,13 @@ class DiskAnnIndex:
         check(self._L.vs_index_get_desc(self.h, C.byref(d)))
         self.desc = d
 
+    def view(self, ctx):
+        """A second handle on the same device arrays with its own workspace, bound to `ctx` (another stream of the same device):
+        batches submitted through different views overlap on the GPU (vs_index_view).  Close every view before the index."""
+        h = C.c_void_p()
+        check(self._L.vs_index_view(self.h, ctx.h, C.byref(h)))
+        return DiskAnnIndex(ctx, h)
+
     # -- construction ---------------------------------------------------------------------------------------------
     @classmethod
     def upload(cls, ctx, *, codes, nbrs, heap_tids, vecs, mean, m2, count, bits, dim_index, num_neighbors,

@@ -50,3 +50,15 @@ def test_bench_dry_run_two_ranks():
     assert r.returncode == 0, r.stderr[-3000:]
     j = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
     assert j["n_gpus"] == 2 and j["scaling"] == "weak" and "query-sharded x2" in j["config"]["parallelism"]
+
+
+@pytest.mark.skipif(not os.environ.get("VS_EMU_FULL"), reason="slow (about 2 minutes); set VS_EMU_FULL=1")
+def test_bench_dry_run_two_batches_in_flight():
+    env = dict(os.environ, VS_EMU="1", VS_F_LDS_MAX_INS="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--n", "6000", "--dim", "64", "--nq", "128", "--steps", "3", "--warmup", "1",
+           "--recall-queries", "16", "--scan-nq", "8", "--cpu-seconds", "1", "--graph-cache", "none", "--pipeline", "2"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, cwd=ROOT, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads(r.stdout.strip().splitlines()[-1])
+    assert j["config"]["batches_in_flight"] == 2 and j["steps"] == 3
+    assert j["cpu_baseline"]["gpu_rows_identical"] is True and 0.9 < j["recall_heldout"] <= 1.0

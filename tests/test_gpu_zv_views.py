@@ -1,0 +1,52 @@
+"""vs_index_view: two handles on one device-resident index, each with its own context (stream) and workspace; batches submitted
+alternately through them, the second one enqueued before the first is finished, give the rows of the oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import pgvectorscale_amd as P
+from helpers import cached_index
+
+pytestmark = pytest.mark.gpu
+
+
+def test_batches_through_two_views_overlap_and_are_exact(gpu_ctx):
+    ti = cached_index(n=3000, dim_full=96, bits=2, R=32, distance=1, seed=41, kind="gauss", L_build=60)
+    ix = ti.upload(gpu_ctx)
+    ctx2 = P.Context(0)
+    vw = ix.view(ctx2)
+    try:
+        L, S, k, nq = 40, 30, 10, 48
+        batches = [ti.queries(nq, seed=100 + b, kind="gauss") for b in range(4)]
+        want = [ti.oracle.search_batch(q, L=L, rescore=S, k=k) for q in batches]
+        handles = [(ix, gpu_ctx), (vw, ctx2)]
+        bufs = []
+        for h, c in handles:
+            bufs.append((c.alloc(nq * ti.dim_full * 4), c.alloc(nq * k * 4), c.alloc(nq * k * 4)))
+        pending = None
+        got = [None] * len(batches)
+
+        def collect(b):
+            h, c = handles[b % 2]
+            h.search_batch_dev_finish()
+            _, oi, od = bufs[b % 2]
+            got[b] = (c.download(oi, np.empty((nq, k), np.uint32)), c.download(od, np.empty((nq, k), np.float32)))
+
+        for b, q in enumerate(batches):
+            h, c = handles[b % 2]
+            qb, oi, od = bufs[b % 2]
+            c.upload(qb, np.ascontiguousarray(q, np.float32))
+            h.search_batch_dev(qb, nq, L, S, k, oi, None, od)  # enqueued while the other handle's batch is still in flight
+            if pending is not None:
+                collect(pending)
+            pending = b
+        collect(pending)
+        for b in range(len(batches)):
+            wi, wd, _ = want[b]
+            assert (got[b][0] == wi).all()
+            assert (got[b][1].view(np.uint32) == wd.view(np.uint32)).all()
+    finally:
+        vw.close()
+        ix.close()
+        ctx2.close()

@@ -679,6 +679,8 @@ def main():
     # warm-up steps)
     fb_bytes = ptot.get("fallback_visited_nodes", 0) * 4 * R + ptot.get("fallback_quantized_distance_comparisons", 0) * 8 * W
     alg_bytes_search = ptot["visited_nodes"] * 4 * R + ptot["quantized_distance_comparisons"] * 8 * W - fb_bytes
+    if NL:  # + the label set of every evaluated neighbor, 2 bytes per label (mean set size of this index)
+        alg_bytes_search += int(ptot["quantized_distance_comparisons"] * 2 * (lab_val.size / n))
     alg_bytes_rerank = ptot["full_distance_comparisons"] * 4 * dim
     per_launch = alg_bytes_search / max(s_n, 1)
     avg_ms = s_ms / max(s_n, 1)

@@ -305,7 +305,7 @@ extern "C" void vs_index_free(vs_index* ix) {
     (void)hipSetDevice(ix->ctx->device);
     (void)hipStreamSynchronize(ix->ctx->stream);
     void* ptrs[] = {ix->codes, ix->nbrs, ix->tids, ix->vecs, ix->vnorm, ix->vnorm_idx, ix->mean, ix->m2, ix->visible_own,
-                    ix->label_off, ix->label_val, ix->label_mask, ix->ls_labels, ix->ls_nodes};
+                    ix->label_off, ix->label_val, ix->label_mask, ix->label_bit, ix->ls_labels, ix->ls_nodes};
     if (!ix->is_view) {  // (a view shares the arrays of the index it was made from)
         for (void* p : ptrs)
             if (p) (void)hipFree(p);

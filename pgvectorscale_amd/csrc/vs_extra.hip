@@ -499,51 +499,74 @@ extern "C" int vs_bruteforce_topk(vs_index* ix, const float* d_queries, uint32_t
 // Label sets as 64-bit masks (an index whose labels all lie in 0..63 — the usual smallint tags): the overlap test of the scan
 // (LabelSetView::overlaps, AM/labels/mod.rs:124-142) becomes one 8-byte load and an AND instead of two dependent loads and a merge.
 // ---------------------------------------------------------------------------------------------------------------
+// label_bit[(uint16_t)label] = the bit that stands for the label in the masks (0xFF: the label occurs nowhere in the index)
+__global__ __launch_bounds__(256) void k_label_presence(const int16_t* __restrict__ val, uint64_t nvals, uint8_t* __restrict__ present) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvals; i += (uint64_t)gridDim.x * blockDim.x)
+        present[(uint16_t)val[i]] = 1;  // (benign race: every writer stores 1)
+}
 __global__ __launch_bounds__(256) void k_label_masks(const uint32_t* __restrict__ off, const int16_t* __restrict__ val, uint32_t n,
-                                                     uint64_t* __restrict__ mask, uint32_t* __restrict__ out_of_range) {
+                                                     const uint8_t* __restrict__ label_bit, uint64_t* __restrict__ mask) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint64_t m = 0;
-    bool bad = false;
-    for (uint32_t j = off[i]; j < off[i + 1]; ++j) {
-        const int v = val[j];
-        if (v < 0 || v > 63) bad = true;
-        else m |= 1ull << v;
-    }
+    for (uint32_t j = off[i]; j < off[i + 1]; ++j) m |= 1ull << label_bit[(uint16_t)val[j]];
     mask[i] = m;
-    if (bad) atomicOr(out_of_range, 1u);
 }
 
+// When the index uses at most 64 DISTINCT labels (any smallint values), every node's label set becomes a 64-bit mask through a
+// per-index label -> bit table, and the overlap test of a scan is one load and an AND; with more distinct labels the scans keep
+// the sorted-merge test on the CSR (LabelSetView::overlaps, AM/labels/mod.rs:124-142).
 int vs_refresh_label_masks(vs_index* ix) {
     vs_ctx* c = ix->ctx;
     if (ix->label_mask) {
         VS_HIP(hipFree(ix->label_mask));
         ix->label_mask = nullptr;
     }
-    if (!ix->label_off || !ix->label_val || ix->d.n == 0) return VS_OK;
-    uint64_t* m = nullptr;
-    uint32_t* flag = nullptr;
-    VS_HIP(hipMalloc(&m, (size_t)ix->d.n * 8));
-    if (hipMalloc(&flag, 4) != hipSuccess) {
-        (void)hipFree(m);
-        vs_set_error("out of device memory");
-        return VS_ERR_OOM;
+    if (ix->label_bit) {
+        VS_HIP(hipFree(ix->label_bit));
+        ix->label_bit = nullptr;
     }
-    (void)hipMemsetAsync(flag, 0, 4, c->stream);
-    hipLaunchKernelGGL(k_label_masks, dim3((ix->d.n + 255) / 256), dim3(256), 0, c->stream, ix->label_off, ix->label_val, ix->d.n, m, flag);
-    uint32_t h = 1;
-    const hipError_t e1 = hipGetLastError();
-    const hipError_t e2 = hipMemcpyAsync(&h, flag, 4, hipMemcpyDeviceToHost, c->stream);
-    const hipError_t e3 = hipStreamSynchronize(c->stream);
-    (void)hipFree(flag);
-    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || h) {  // (a label outside 0..63: the scans keep the merge)
-        (void)hipFree(m);
-        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
-            vs_set_error("k_label_masks failed");
-            return VS_ERR_HIP;
-        }
+    if (!ix->label_off || !ix->label_val || ix->d.n == 0) return VS_OK;
+    uint8_t* tab = nullptr;
+    VS_HIP(hipMalloc(&tab, 65536));
+    std::vector<uint8_t> h(65536, 0);
+    hipError_t e = hipMemsetAsync(tab, 0, 65536, c->stream);
+    if (e == hipSuccess && ix->n_label_vals) {
+        const uint32_t grid = (uint32_t)std::min<uint64_t>((ix->n_label_vals + 255) / 256, 65536);
+        hipLaunchKernelGGL(k_label_presence, dim3(grid), dim3(256), 0, c->stream, ix->label_val, ix->n_label_vals, tab);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(h.data(), tab, 65536, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) {
+        (void)hipFree(tab);
+        VS_HIP(e);
+    }
+    // bits are dealt in the order of the labels as signed smallints (only "which bit" matters, not the order)
+    uint32_t distinct = 0;
+    for (int v = -32768; v <= 32767; ++v) {
+        uint8_t& slot = h[(uint16_t)(int16_t)v];
+        if (slot) slot = distinct < 64 ? (uint8_t)distinct : 0xFF, ++distinct;
+        else slot = 0xFF;
+    }
+    if (distinct > 64) {  // the scans keep the merge
+        (void)hipFree(tab);
         return VS_OK;
     }
+    uint64_t* m = nullptr;
+    e = hipMalloc(&m, (size_t)ix->d.n * 8);
+    if (e == hipSuccess) e = hipMemcpyAsync(tab, h.data(), 65536, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_label_masks, dim3((ix->d.n + 255) / 256), dim3(256), 0, c->stream, ix->label_off, ix->label_val, ix->d.n, tab, m);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) {
+        (void)hipFree(tab);
+        if (m) (void)hipFree(m);
+        VS_HIP(e);
+    }
     ix->label_mask = m;
+    ix->label_bit = tab;
     return VS_OK;
 }

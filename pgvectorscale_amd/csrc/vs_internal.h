@@ -136,7 +136,8 @@ struct vs_index {
     uint64_t count = 0;
     uint32_t* label_off = nullptr;
     int16_t* label_val = nullptr;
-    uint64_t* label_mask = nullptr;  // per node: bit l set <=> label l in its set; only when every label of the index is in 0..63
+    uint64_t* label_mask = nullptr;  // per node: bit label_bit[l] set <=> label l in its set; only when the index uses <= 64 distinct labels
+    uint8_t* label_bit = nullptr;    // [65536] label (as u16) -> its bit, 0xFF = the label occurs nowhere in the index
     uint64_t n_label_vals = 0;
     int16_t* ls_labels = nullptr;
     uint32_t* ls_nodes = nullptr;
@@ -150,7 +151,7 @@ int devbuf_reserve(vs_ctx* ctx, DevBuf& b, size_t bytes);
 // row-wise staging through the pinned ring (device rows may be wider than host rows) / neighbor-list validation
 int vs_upload_rows(vs_ctx* c, void* dst, size_t dev_row_bytes, const void* src, size_t host_row_bytes, size_t copy_bytes, size_t rows);
 int vs_validate_graph(vs_index* ix);
-int vs_refresh_label_masks(vs_index* ix);  // (re)derives label_mask from the label CSR, or drops it when a label is outside 0..63
+int vs_refresh_label_masks(vs_index* ix);  // (re)derives label_mask / label_bit from the label CSR, or drops them when the index uses more than 64 distinct labels
 void devbuf_free(DevBuf& b);
 
 // ---- kernel launch wrappers (defined in the .hip files) -------------------------------------------------------

@@ -44,6 +44,7 @@ struct FastArgs {
     const uint32_t* label_off;
     const int16_t* label_val;
     const uint64_t* label_mask;  // may be null
+    const uint8_t* label_bit;    // with label_mask: [65536] label -> bit (0xFF: in no node's set)
     const int16_t* ls_labels;
     const uint32_t* ls_nodes;
     uint32_t code_stride, nbr_stride, R, n, n_ls, default_start;
@@ -735,14 +736,19 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
     }
     const bool has_label_filter = labels_some && nql > 0;  // AM/scan.rs:189
     wave_sync();
-    // the query's labels as a mask, for an index whose node label sets are masks (all labels in 0..63): a query label outside that
-    // range cannot be in any node's set and simply contributes no bit
+    // the query's labels as a mask, for an index whose node label sets are masks (<= 64 distinct labels, each with its bit): a
+    // query label that occurs nowhere in the index cannot be in any node's set and simply contributes no bit
     uint64_t qmask = 0;
-    if (has_label_filter && a.label_mask)
-        for (uint32_t i = 0; i < nql; ++i) {
-            const int v = ql[i];
-            if (v >= 0 && v < 64) qmask |= 1ull << v;
+    if (has_label_filter && a.label_mask) {
+        uint64_t mine = 0;
+        if ((uint32_t)lane < nql) {
+            const uint32_t bit = a.label_bit[(uint16_t)ql[lane]];
+            if (bit < 64u) mine = 1ull << bit;
         }
+        // OR over the (<= 64) lanes: a butterfly of DPP-free shuffles is not worth it for something done once per scan
+        for (int o = 32; o >= 1; o >>= 1) mine |= __shfl_xor(mine, o, WAVE);
+        qmask = mine;
+    }
 
     FastHeap<(MINW >= 7)> heap;
     heap.l = hp;
@@ -1289,6 +1295,7 @@ int launch_search_fast(vs_index* idx, const FastLaunch& s) {
     a.label_off = idx->label_off;
     a.label_val = idx->label_val;
     a.label_mask = idx->label_mask;
+    a.label_bit = idx->label_bit;
     a.ls_labels = idx->ls_labels;
     a.ls_nodes = idx->ls_nodes;
     a.code_stride = idx->code_stride;

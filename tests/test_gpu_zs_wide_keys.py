@@ -87,3 +87,33 @@ def test_wide_keys_device_batch_and_cursor(wide, gpu_ctx):
         g, o = scan.stats(), os_.stats()
         assert g["visited_nodes"] == o["visited_nodes"] and g["quantized_distance_comparisons"] == o["quantized_distance_comparisons"]
     scan.endscan()
+
+
+def test_label_masks_for_any_label_values(gpu_ctx, oracle, monkeypatch):
+    """<= 64 DISTINCT labels of any smallint value: node label sets become 64-bit masks through the per-index label -> bit table
+    (one load + AND per fresh neighbor in the LDS-resident kernel); keys may name labels the index does not know."""
+    O = oracle
+    ti = TestIndex(n=2200, dim_full=48, bits=2, R=20, distance=O.L2, seed=78, kind="uniform", n_labels=6)
+    lut = np.zeros(7, np.int16)
+    lut[1:] = [-300, -1, 0, 63, 64, 32767]  # monotone: sets stay sorted
+    ti.label_val = lut[ti.label_val]
+    ti.label_starts = {int(lut[l]): n for l, n in ti.label_starts.items()}
+    ti.oracle = O.OracleIndex(codes=ti.codes, nbrs=ti.nbrs, heap_tids=ti.tids, vecs=ti.vecs, mean=ti.mean, m2=ti.m2, count=ti.count,
+                              bits=ti.bits, dim_index=ti.dim_index, num_neighbors=ti.R, distance_type=ti.distance,
+                              default_start=ti.start, label_off=ti.label_off, label_val=ti.label_val, label_starts=ti.label_starts)
+    ix = ti.upload(gpu_ctx)
+    q = ti.queries(18, seed=2)
+    keys = [[-300], [64, 32767], [0], [5], [-1, 63], [-32768, 64], [32767], [-300, -1, 0, 63, 64, 32767], [1, 2, 3]] * 2
+    for regime in ({}, {"VS_F_LDS_MAX_INS": "0"}, {"VS_FAST": "0"}):
+        for k_, v_ in regime.items():
+            monkeypatch.setenv(k_, v_)
+        gi, _, gd, gst = ix.search_batch(q, search_list_size=25, rescore=10, k=10, qlabels=keys)
+        oi, od, ost = ti.oracle.search_batch(q, L=25, rescore=10, k=10, qlabels=keys)
+        assert (gi == oi).all(), regime
+        assert (gd.view(np.uint32) == od.view(np.uint32))[gi != 0xFFFFFFFF].all()
+        for key in ("visited_nodes", "candidate_nodes", "quantized_distance_comparisons", "node_reads"):
+            assert gst[key] == ost[key], (regime, key)
+        for k_ in regime:
+            monkeypatch.delenv(k_)
+    assert (gi[3] == 0xFFFFFFFF).all() and (gi[8] == 0xFFFFFFFF).all()  # labels nobody carries
+    ix.close()

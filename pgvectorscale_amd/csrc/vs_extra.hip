@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void k_dg_fill(uint64_t seed, uint32_t dim, ui
 extern "C" int vs_datagen_fill(vs_ctx* c, const vs_datagen_params* p, uint64_t first_row, uint64_t rows, float* d_out) {
     VS_REQUIRE(c && p && (rows == 0 || d_out), "vs_datagen_fill: bad args");
     VS_REQUIRE(p->dim >= 1 && p->dim <= 4096, "vs_datagen_fill: dim %u outside [1,4096]", p->dim);
-    VS_REQUIRE(p->latent_dim >= 1 && p->latent_dim <= 64, "vs_datagen_fill: latent_dim %u outside [1,64]", p->latent_dim);
+    VS_REQUIRE(p->latent_dim >= 1 && p->latent_dim <= 128, "vs_datagen_fill: latent_dim %u outside [1,128]", p->latent_dim);
     VS_REQUIRE(p->n_clusters >= 1 && p->intra_pct <= 100 && p->noise_pct <= 100, "vs_datagen_fill: bad mixture params");
     if (rows == 0) return VS_OK;
     VS_HIP(hipSetDevice(c->device));

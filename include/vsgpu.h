@@ -245,6 +245,48 @@ void vs_pages_close(vs_pages* p);
 int vs_pages_headers_only(vs_pages* p);
 int vs_pages_block_table(const vs_pages* p, const uint32_t** blk_base, const uint32_t** blk_cnt, uint32_t* n_blocks);
 
+/* ---- the MetaPage body (AM/meta_page.rs:176-210): item 2 of block 0, a chained rkyv archive (store / load, :344-378) ----
+ * Byte offsets of the fields inside ArchivedMetaPage (the last root_size bytes of the chain's payload).  rkyv 0.7 archives are
+ * repr(Rust): vs_meta_layout_default() lays the fields out in declaration order with C alignment; a PGRX shim passes
+ * core::mem::offset_of!(ArchivedMetaPage, ...) instead (oracle/ref_kat.rs prints them).  The archived forms
+ * restated from rkyv 0.7.43: ArchivedString = 8 bytes (<= 7 bytes inline, else {u32 len, i32 offset}); ArchivedOption =
+ * {u8 tag, T at T's alignment}; ArchivedStartNodes = {ArchivedItemPointer default_node, ArchivedBTreeMap<i16, ItemPointer>
+ * {u32 len, i32 root}} with B-tree nodes {u16 meta (bit 15: inner), u32 size, i32 ptr} + LeafNodeEntry {i16 key, ItemPointer}
+ * / InnerNodeEntry {i32 ptr, i16 key}; relative pointers count from the position of the pointer itself. */
+typedef struct vs_meta_layout {
+    uint32_t root_size;                    /* size_of::<ArchivedMetaPage>() = 80 */
+    uint32_t off_magic_number, off_version, off_extension_version_when_built, off_distance_type, off_num_dimensions,
+        off_num_dimensions_to_index, off_bq_num_bits_per_dimension, off_storage_type, off_num_neighbors, off_search_list_size,
+        off_max_alpha, off_start_nodes, off_quantizer_metadata, off_has_labels;
+} vs_meta_layout;
+int vs_meta_layout_default(vs_meta_layout* out);
+typedef struct vs_meta_page {
+    uint32_t magic_number, version;
+    char extension_version_when_built[64];  /* NUL terminated (longer strings are cut)                                     */
+    uint32_t distance_type;                 /* DistanceType as stored (u16): 0 cosine, 1 l2, 2 inner product                 */
+    uint32_t num_dimensions, num_dimensions_to_index, bq_num_bits_per_dimension;
+    uint32_t storage_type;                  /* StorageType as stored (u8): 0 plain, 1 (retired), 2 SbqCompression           */
+    uint32_t num_neighbors, search_list_size;
+    double max_alpha;
+    uint32_t has_start_nodes;               /* Option<StartNodes> is Some                                                    */
+    uint32_t default_start_block, default_start_offset;   /* StartNodes.default_node                                        */
+    uint32_t n_labeled_start_nodes;         /* StartNodes.labeled_nodes.len()                                                */
+    uint32_t quantizer_block, quantizer_offset;            /* quantizer_metadata (SbqMeans chain; vs_pages_sbq_means)        */
+    uint32_t has_labels;
+} vs_meta_page;
+/* rkyv::from_bytes::<MetaPage> over `bytes` (the chain payload).  The labeled start nodes come out in key order:
+ * start_labels / start_blocks / start_offsets hold `cap` entries each (any may be NULL); more entries than cap is an error
+ * unless all three are NULL (query n_labeled_start_nodes first).  layout NULL = vs_meta_layout_default.  Host-only. */
+int vs_meta_page_decode(const void* bytes, size_t len, const vs_meta_layout* layout, vs_meta_page* out, int16_t* start_labels,
+                        uint32_t* start_blocks, uint32_t* start_offsets, uint32_t cap);
+/* MetaPage::fetch for a reader (after vs_pages_finish): reads the chain at (0, 2), decodes it and fills the geometry of
+ * `desc` (n from the pages, distance / dims / bits / words / R / storage / has_labels from the MetaPage, default_start and the
+ * labeled start nodes translated to node ids; an index without rows has default_start = VS_INVALID_NODE).  start_labels /
+ * start_nodes: cap entries (may be NULL to query desc->n_label_starts).  meta may be NULL.  Only PageType::Meta (version 3)
+ * relations: MetaV1 / MetaV2 pages are what the reference itself rewrites on first use. */
+int vs_pages_meta(const vs_pages* p, const vs_meta_layout* layout, vs_meta_page* meta, vs_index_desc* desc, int16_t* start_labels,
+                  uint32_t* start_nodes, uint32_t cap);
+
 /* The same, decoded ON the device (vs_pages_dev.hip): the blocks are copied to HBM as they are (pinned ring,
  * hipMemcpyAsync), the host only reads the page headers on the way past, and one kernel (a wave per node page) walks the
  * line pointers and rkyv relative pointers and writes codes / neighbor ids / heap tids into the index arrays; label sets
@@ -256,7 +298,10 @@ int vs_pages_dev_add(vs_pages_dev* d, uint32_t first_block, const void* pages, u
 int vs_pages_dev_node_of(const vs_pages_dev* d, uint32_t block, uint32_t offset, uint32_t* node);
 int vs_pages_dev_sbq_means(const vs_pages_dev* d, uint32_t block, uint32_t offset, float* mean, float* m2, uint32_t dim_cap,
                            uint32_t* dim, uint64_t* count);
-/* desc: the MetaPage fields (n is taken from the pages, default_start is a node id from vs_pages_dev_node_of);
+/* MetaPage::fetch on the metadata pages the host kept (after the last vs_pages_dev_add): as vs_pages_meta */
+int vs_pages_dev_meta(vs_pages_dev* d, const vs_meta_layout* layout, vs_meta_page* meta, vs_index_desc* desc, int16_t* start_labels,
+                      uint32_t* start_nodes, uint32_t cap);
+/* desc: the MetaPage fields (vs_pages_dev_meta, or by hand: n is taken from the pages, default_start is a node id from vs_pages_dev_node_of);
  * extras: vecs / mean / m2 / count / label_start_labels / label_start_nodes (node ids); frees the raw pages */
 int vs_pages_dev_build(vs_pages_dev* d, const vs_index_desc* desc, const vs_index_host* extras, vs_pages_info* info, vs_index** out);
 void vs_pages_dev_close(vs_pages_dev* d);

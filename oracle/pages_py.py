@@ -8,6 +8,7 @@ Restated pieces ("UT/" = /root/reference/pgvectorscale/src/util/, "AM/" = .../sr
     downwards from pd_special, special area = TsvPageOpaqueData {page_type u8, reserved u8, page_id u16 = 0xAE24}
     (UT/page.rs:24-76);
   * Tape::write (UT/tape.rs:53-76) and ChainTapeWriter::write / ChainItemIterator (UT/chain.rs:72-185);
+  * the MetaPage body (String, Option<StartNodes> with its BTreeMap) the same way, see rkyv_meta_page below;
   * rkyv 0.7 `to_bytes` for the structs on this path (size_32, little endian): out-of-line data of each field in
     field order, each aligned to its element type, then the root object aligned to its own alignment at the END;
     ArchivedVec = {i32 offset relative to the field, u32 len}; archived_root = last size_of::<Archived<T>>() bytes
@@ -153,6 +154,17 @@ class ChainTapeWriter:
         self.rel, self.page_type = rel, page_type
         self.current = rel.new_page(page_type)
 
+    @classmethod
+    def reinit(cls, rel, page_type, block):
+        """ChainTapeWriter::reinit (UT/chain.rs:51-70): start again on an existing block, which is initialised afresh"""
+        w = cls.__new__(cls)
+        w.rel, w.page_type = rel, page_type
+        fresh = Relation()
+        fresh.new_page(page_type)
+        rel.pages[block] = fresh.pages[0]
+        w.current = block
+        return w
+
     def write(self, data):
         rel = self.rel
         cur = self.current
@@ -252,6 +264,216 @@ def rkyv_meta_header(magic=TSV_MAGIC_NUMBER, version=TSV_VERSION):
     return struct.pack("<II", magic, version)
 
 
+# ---- MetaPage (AM/meta_page.rs:176-210) ------------------------------------------------------------------------------
+# rkyv 0.7.43 (size_32, little endian; un-vendored dependency, restated from its published sources — "parity unpinned": no
+# fixture of a real meta page exists in the reference, oracle/ref_kat.rs prints one for a maintainer with the toolchain):
+#   * ArchivedString, 8 bytes (string/repr.rs): up to 7 bytes inline {bytes[7], len u8}; longer {len u32, offset i32 LE
+#     relative to the START of the repr} with the bytes written before the struct — the offset is negative, so the sign bit
+#     of the last byte tells the two apart (is_inline: last byte & 0x80 == 0);
+#   * ArchivedOption<T>: #[repr(u8)] enum {None = 0, Some(T) = 1}: the tag byte, then T at T's alignment;
+#   * ArchivedBTreeMap<K, V> (collections/btree_map): {len u32, root RelPtr i32 relative to the root field}; nodes =
+#     NodeHeader {meta u16 (bit 15 = inner node, low 15 bits = entries), size u32 (bytes of the node), ptr i32 (leaf: next
+#     leaf in key order, 0 = none; inner: the child below the first key)} followed by the entries, LeafNodeEntry {key, value}
+#     or InnerNodeEntry {ptr i32, key}; built from the keys in REVERSE order, a node is closed once it has reached 4096
+#     bytes, so the leaf with the largest keys is written first and the root last;
+#   * ArchivedItemPointer {block_number u32, offset u16} = 8 bytes, 4-aligned (UT/mod.rs:17-23);
+#   * the root object's fields in declaration order with C alignment rules (rkyv 0.7 archives are repr(Rust): the order is
+#     a parameter of the decoders, DEFAULT_META_LAYOUT).
+META_FIELDS = ("magic_number", "version", "extension_version_when_built", "distance_type", "num_dimensions",
+               "num_dimensions_to_index", "bq_num_bits_per_dimension", "storage_type", "num_neighbors", "search_list_size",
+               "max_alpha", "start_nodes", "quantizer_metadata", "has_labels")
+_META_SIZE_ALIGN = {"magic_number": (4, 4), "version": (4, 4), "extension_version_when_built": (8, 4), "distance_type": (2, 2),
+                    "num_dimensions": (4, 4), "num_dimensions_to_index": (4, 4), "bq_num_bits_per_dimension": (1, 1),
+                    "storage_type": (1, 1), "num_neighbors": (4, 4), "search_list_size": (4, 4), "max_alpha": (8, 8),
+                    "start_nodes": (20, 4), "quantizer_metadata": (8, 4), "has_labels": (1, 1)}
+
+
+def meta_layout(order=META_FIELDS):
+    """{"root_size": n, field: offset, ...} for the fields laid out in `order` with C alignment rules"""
+    pos, out = 0, {}
+    for f in order:
+        size, al = _META_SIZE_ALIGN[f]
+        pos = (pos + al - 1) // al * al
+        out[f] = pos
+        pos += size
+    out["root_size"] = (pos + 7) // 8 * 8
+    return out
+
+
+DEFAULT_META_LAYOUT = meta_layout()
+BTREE_MAX_NODE_SIZE = 4096
+_BT_HEADER = 12   # NodeHeader {u16 meta, (pad), u32 size, i32 ptr}
+_BT_LEAF_ENTRY = 12   # LeafNodeEntry<i16, ArchivedItemPointer> {i16 key, (pad), u32 block, u16 offset, (pad)}
+_BT_INNER_ENTRY = 8   # InnerNodeEntry<i16> {i32 ptr, i16 key, (pad)}
+
+
+def _btree_nodes(s, entries):
+    """BTreeMap::serialize -> ArchivedBTreeMap::serialize_from_reverse_iter: writes the nodes, returns the root's position"""
+    level = []  # (first key, node position), built back to front
+    rev = list(reversed(entries))
+    i = 0
+    next_leaf = None
+    while i < len(rev):
+        block_start = len(s.b)
+        grp = [rev[i]]
+        i += 1
+        while True:
+            est = len(s.b) - block_start + _BT_HEADER + len(grp) * _BT_LEAF_ENTRY
+            if est >= BTREE_MAX_NODE_SIZE and len(grp) >= 1:
+                break
+            if i < len(rev):
+                grp.append(rev[i])
+                i += 1
+            else:
+                break
+        pos = s.align(4)
+        grp.reverse()  # entries are stored in key order
+        size = _BT_HEADER + len(grp) * _BT_LEAF_ENTRY
+        ptr = 0 if next_leaf is None else next_leaf - (pos + 8)
+        s.write(struct.pack("<HHIi", len(grp), 0, size, ptr))
+        for key, (blk, off) in grp:
+            s.write(struct.pack("<hHIHH", key, 0, blk, off, 0))
+        next_leaf = pos
+        level.append((grp[0][0], pos))
+    while len(level) > 1:
+        nxt = []
+        j = 0
+        while j < len(level):  # `level` is still in reverse key order
+            block_start = len(s.b)
+            grp = [level[j]]
+            j += 1
+            while True:
+                est = len(s.b) - block_start + _BT_HEADER + len(grp) * _BT_INNER_ENTRY
+                if est >= BTREE_MAX_NODE_SIZE and len(grp) >= 2:
+                    break
+                if j < len(level):
+                    grp.append(level[j])
+                    j += 1
+                else:
+                    break
+            # the smallest child hangs off the header, the others become (ptr, key) entries in key order
+            grp.reverse()
+            first_key, first_pos = grp[0]
+            rest = grp[1:]
+            if not rest and j >= len(level) and not nxt:  # a lone child: it is the root itself
+                nxt.append((first_key, first_pos))
+                continue
+            pos = s.align(4)
+            size = _BT_HEADER + len(rest) * _BT_INNER_ENTRY
+            s.write(struct.pack("<HHIi", 0x8000 | len(rest), 0, size, first_pos - (pos + 8)))
+            for n_, (key, cpos) in enumerate(rest):
+                epos = pos + _BT_HEADER + n_ * _BT_INNER_ENTRY
+                s.write(struct.pack("<ihH", cpos - epos, key, 0))
+            nxt.append((first_key, pos))
+        level = nxt
+    return level[0][1]
+
+
+def rkyv_meta_page(*, extension_version="0.8.0", distance_type=1, num_dimensions, num_dimensions_to_index=None,
+                   bq_num_bits_per_dimension=2, storage_type=2, num_neighbors=50, search_list_size=100, max_alpha=1.2,
+                   default_start=None, labeled_starts=None, quantizer=(INVALID_BLOCK, INVALID_OFFSET), has_labels=False,
+                   magic=TSV_MAGIC_NUMBER, version=TSV_VERSION, layout=DEFAULT_META_LAYOUT):
+    """to_bytes(MetaPage) (AM/meta_page.rs:176-210, store: :344-365).  default_start None -> start_nodes = None (an index that
+    never saw a row); labeled_starts = {label: (block, offset)} (StartNodes.labeled_nodes, AM/graph/start_nodes.rs:14-22)."""
+    s = _Ser()
+    ver = extension_version.encode()
+    p_ver = None
+    if len(ver) > 7:
+        p_ver = s.write(ver)
+    root_pos = None
+    entries = sorted((labeled_starts or {}).items())
+    if default_start is not None and entries:
+        root_pos = _btree_nodes(s, entries)
+    root = s.align(8)
+    s.write(b"\0" * layout["root_size"])
+    b = s.b
+
+    def put(name, data):
+        b[root + layout[name]:root + layout[name] + len(data)] = data
+
+    put("magic_number", struct.pack("<I", magic))
+    put("version", struct.pack("<I", version))
+    f = root + layout["extension_version_when_built"]
+    if p_ver is None:
+        put("extension_version_when_built", ver.ljust(7, b"\0") + bytes([len(ver)]))
+    else:
+        put("extension_version_when_built", struct.pack("<Ii", len(ver), p_ver - f))
+    put("distance_type", struct.pack("<H", distance_type))
+    put("num_dimensions", struct.pack("<I", num_dimensions))
+    put("num_dimensions_to_index", struct.pack("<I", num_dimensions if num_dimensions_to_index is None else num_dimensions_to_index))
+    put("bq_num_bits_per_dimension", bytes([bq_num_bits_per_dimension]))
+    put("storage_type", bytes([storage_type]))
+    put("num_neighbors", struct.pack("<I", num_neighbors))
+    put("search_list_size", struct.pack("<I", search_list_size))
+    put("max_alpha", struct.pack("<d", max_alpha))
+    if default_start is not None:
+        sn = root + layout["start_nodes"]
+        root_field = sn + 4 + 8 + 4
+        put("start_nodes", bytes([1, 0, 0, 0]) + rkyv_item_pointer(*default_start) +
+            struct.pack("<Ii", len(entries), 0 if root_pos is None else root_pos - root_field))
+    put("quantizer_metadata", rkyv_item_pointer(*quantizer))
+    put("has_labels", bytes([1 if has_labels else 0]))
+    return bytes(b)
+
+
+def parse_meta_page(data, layout=DEFAULT_META_LAYOUT):
+    """rkyv::from_bytes::<MetaPage> (AM/meta_page.rs:367-378), independent of libvsgpu's decoder -> dict"""
+    root = len(data) - layout["root_size"]
+    assert root >= 0
+
+    def at(name):
+        return root + layout[name]
+
+    out = {"magic_number": struct.unpack_from("<I", data, at("magic_number"))[0],
+           "version": struct.unpack_from("<I", data, at("version"))[0]}
+    f = at("extension_version_when_built")
+    if data[f + 7] & 0x80 == 0:
+        out["extension_version_when_built"] = bytes(data[f:f + data[f + 7]]).decode()
+    else:
+        ln, off = struct.unpack_from("<Ii", data, f)
+        assert 0 <= f + off and f + off + ln <= len(data)
+        out["extension_version_when_built"] = bytes(data[f + off:f + off + ln]).decode()
+    out["distance_type"] = struct.unpack_from("<H", data, at("distance_type"))[0]
+    out["num_dimensions"] = struct.unpack_from("<I", data, at("num_dimensions"))[0]
+    out["num_dimensions_to_index"] = struct.unpack_from("<I", data, at("num_dimensions_to_index"))[0]
+    out["bq_num_bits_per_dimension"] = data[at("bq_num_bits_per_dimension")]
+    out["storage_type"] = data[at("storage_type")]
+    out["num_neighbors"] = struct.unpack_from("<I", data, at("num_neighbors"))[0]
+    out["search_list_size"] = struct.unpack_from("<I", data, at("search_list_size"))[0]
+    out["max_alpha"] = struct.unpack_from("<d", data, at("max_alpha"))[0]
+    sn = at("start_nodes")
+    if data[sn] == 0:
+        out["default_start"], out["labeled_starts"] = None, {}
+    else:
+        b_, o_, _ = struct.unpack_from("<IHH", data, sn + 4)
+        out["default_start"] = (b_, o_)
+        ln, roff = struct.unpack_from("<Ii", data, sn + 12)
+        starts = {}
+
+        def walk(pos, depth):
+            assert depth < 8 and 0 <= pos and pos + _BT_HEADER <= len(data)
+            meta, _, _, ptr = struct.unpack_from("<HHIi", data, pos)
+            cnt = meta & 0x7FFF
+            if meta & 0x8000:
+                walk(pos + 8 + ptr, depth + 1)
+                for e in range(cnt):
+                    ep = pos + _BT_HEADER + e * _BT_INNER_ENTRY
+                    walk(ep + struct.unpack_from("<i", data, ep)[0], depth + 1)
+            else:
+                for e in range(cnt):
+                    k_, _, bb, oo, _ = struct.unpack_from("<hHIHH", data, pos + _BT_HEADER + e * _BT_LEAF_ENTRY)
+                    starts[k_] = (bb, oo)
+
+        if ln:
+            walk(sn + 16 + roff, 0)
+        assert len(starts) == ln and list(starts) == sorted(starts)
+        out["labeled_starts"] = starts
+    b_, o_, _ = struct.unpack_from("<IHH", data, at("quantizer_metadata"))
+    out["quantizer_metadata"] = (b_, o_)
+    out["has_labels"] = bool(data[at("has_labels")])
+    return out
+
+
 def _archived_vec(item, field, elem):
     off, n = struct.unpack_from("<iI", item, field)
     start = field + off
@@ -298,20 +520,27 @@ class WrittenIndex:
 
 
 def write_index(*, codes, nbrs, heap_tids, mean, m2, count, label_off=None, label_val=None, num_neighbors=None,
-                means_first=True, meta_body=b"\x00" * 120, zero_page_every=0,
+                means_first=True, meta_body=b"\x00" * 120, meta=None, zero_page_every=0,
                 layout=DEFAULT_NODE_LAYOUT):
     """Lay an index out the way the reference's build does: block 0 = Meta chain (header item 1, MetaPage item 2,
     AM/meta_page.rs:344-365), a chained SbqMeans item (AM/sbq/mod.rs:123-137) and SbqNode items written through a Tape
     (AM/sbq/node.rs:118-123).  Nodes are first written with empty neighbor lists (SbqNode::new, AM/sbq/node.rs:55-90)
     and patched in place afterwards, like the reference's set_neighbors_on_disk.  `nbrs` holds dense ids; the list of a
-    node ends at the first 0xFFFFFFFF.  The MetaPage body is an opaque placeholder (its rkyv layout — String,
-    Option<StartNodes>, BTreeMap — is left to the Rust side)."""
+    node ends at the first 0xFFFFFFFF.  `meta` = keyword arguments of rkyv_meta_page with default_start / labeled_starts given
+    as dense node ids: the MetaPage is first stored without start nodes and quantizer pointer (MetaPage::create,
+    AM/meta_page.rs:297-359) and stored again on a re-initialised block 0 once they are known (store(index, false)), chaining
+    onto fresh pages when it has outgrown the block; without `meta` the body is the opaque placeholder `meta_body`."""
     n, W = codes.shape
     R = num_neighbors or nbrs.shape[1]
     has_labels = label_off is not None
     rel = Relation()
+    meta_w = meta
     meta = ChainTapeWriter(rel, PT_META)
     assert meta.write(rkyv_meta_header()) == (0, 1)
+    if meta_w is not None:
+        first = dict(meta_w, default_start=None, labeled_starts=None)
+        first.pop("quantizer", None)
+        meta_body = rkyv_meta_page(has_labels=has_labels, **first)
     assert meta.write(meta_body) == (0, 2)
     means_ptr = None
     if means_first:
@@ -340,6 +569,16 @@ def write_index(*, codes, nbrs, heap_tids, mean, m2, count, label_off=None, labe
             page[at + 8 * j:at + 8 * j + 8] = rkyv_item_pointer(*ptrs[v])
     if not means_first:
         means_ptr = ChainTapeWriter(rel, PT_SBQ_MEANS).write(rkyv_sbq_means(count, mean, m2))
+    if meta_w is not None:
+        final = dict(meta_w)
+        ds = final.pop("default_start", None)
+        ls = final.pop("labeled_starts", None) or {}
+        final.setdefault("quantizer", means_ptr)
+        body = rkyv_meta_page(has_labels=has_labels, default_start=None if ds is None else ptrs[ds],
+                              labeled_starts={k: ptrs[v] for k, v in ls.items()}, **final)
+        again = ChainTapeWriter.reinit(rel, PT_META, 0)
+        assert again.write(rkyv_meta_header()) == (0, 1)
+        assert again.write(body) == (0, 2)
     return WrittenIndex(rel, ptrs, means_ptr, has_labels, layout)
 
 

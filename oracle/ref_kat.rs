@@ -3,7 +3,7 @@
 // expression order of SbqQuantizer::add_sample / quantize, the array mechanics of std::collections::BinaryHeap that decide
 // the order of equal-distance candidates, and the rkyv 0.7 byte layout of an archived SbqNode — and no test of the reference
 // pins any of them bit for bit.  A maintainer with the reference's toolchain closes that gap with ONE
-// command: append the three modules below to the files named in their headers (they need the private items of those
+// command: append the four modules below to the files named in their headers (they need the private items of those
 // modules), then
 //
 //     cargo test --lib ref_kat -- --nocapture --test-threads=1 | grep '^KAT ' > <this repo>/tests/golden/ref_kat.txt
@@ -175,5 +175,87 @@ mod ref_kat_distance {
             let ip = unsafe { super::inner_product_x86_avx2(&a, &b) };
             println!("KAT simd d={} l2={:08x} ip={:08x}", d, l2.to_bits(), ip.to_bits());
         }
+    }
+}
+
+// ====================================================================================================================
+// 4. append to pgvectorscale/src/access_method/meta_page.rs         (the MetaPage fields are private)
+//    The archived MetaPage (String, Option<StartNodes> with its BTreeMap) as rkyv 0.7 really lays it out, with the field
+//    offsets of ArchivedMetaPage — what vs_meta_page_decode / oracle/pages_py.py::rkyv_meta_page restate from reading.
+// ====================================================================================================================
+#[cfg(test)]
+mod ref_kat_meta {
+    use super::*;
+
+    fn hex(b: &[u8]) -> String {
+        b.iter().map(|x| format!("{:02x}", x)).collect::<Vec<_>>().join("")
+    }
+
+    fn emit(tag: &str, m: &MetaPage) {
+        let bytes = m.serialize_to_vec();
+        println!(
+            "KAT meta case={} size={} offs={},{},{},{},{},{},{},{},{},{},{},{},{},{} bytes={}",
+            tag,
+            std::mem::size_of::<ArchivedMetaPage>(),
+            std::mem::offset_of!(ArchivedMetaPage, magic_number),
+            std::mem::offset_of!(ArchivedMetaPage, version),
+            std::mem::offset_of!(ArchivedMetaPage, extension_version_when_built),
+            std::mem::offset_of!(ArchivedMetaPage, distance_type),
+            std::mem::offset_of!(ArchivedMetaPage, num_dimensions),
+            std::mem::offset_of!(ArchivedMetaPage, num_dimensions_to_index),
+            std::mem::offset_of!(ArchivedMetaPage, bq_num_bits_per_dimension),
+            std::mem::offset_of!(ArchivedMetaPage, storage_type),
+            std::mem::offset_of!(ArchivedMetaPage, num_neighbors),
+            std::mem::offset_of!(ArchivedMetaPage, search_list_size),
+            std::mem::offset_of!(ArchivedMetaPage, max_alpha),
+            std::mem::offset_of!(ArchivedMetaPage, start_nodes),
+            std::mem::offset_of!(ArchivedMetaPage, quantizer_metadata),
+            std::mem::offset_of!(ArchivedMetaPage, has_labels),
+            hex(&bytes)
+        );
+    }
+
+    fn base(version: &str) -> MetaPage {
+        MetaPage {
+            magic_number: TSV_MAGIC_NUMBER,
+            version: TSV_VERSION,
+            extension_version_when_built: version.to_string(),
+            distance_type: 1,
+            num_dimensions: 768,
+            num_dimensions_to_index: 512,
+            bq_num_bits_per_dimension: 2,
+            storage_type: 2,
+            num_neighbors: 50,
+            search_list_size: 100,
+            max_alpha: 1.2,
+            start_nodes: None,
+            quantizer_metadata: ItemPointer::new(3, 1),
+            has_labels: false,
+        }
+    }
+
+    #[test]
+    fn ref_kat_archived_meta_page_bytes() {
+        emit("none_inline", &base("0.8.0"));
+        let mut m = base("0.8.0-rc1+build.77");
+        m.start_nodes = Some(StartNodes::new(ItemPointer::new(7, 1)));
+        emit("some_empty_outofline", &m);
+        let mut m = base("0.8.0");
+        let mut sn = StartNodes::new(ItemPointer::new(7, 1));
+        for l in [5i16, -3, 300, 17] {
+            sn.upsert(l, ItemPointer::new(100 + l as i32 as u32 % 50, 1 + (l as i32 as u32 % 7) as u16));
+        }
+        m.start_nodes = Some(sn);
+        m.has_labels = true;
+        emit("some_four_labels", &m);
+        // 1000 labeled start nodes: the B-tree has more than one leaf (4096-byte nodes) and an inner root
+        let mut m = base("0.8.0");
+        let mut sn = StartNodes::new(ItemPointer::new(7, 1));
+        for l in -500i16..500 {
+            sn.upsert(l, ItemPointer::new((l as i32 + 1000) as u32, 1 + ((l as i32 + 500) % 90) as u16));
+        }
+        m.start_nodes = Some(sn);
+        m.has_labels = true;
+        emit("some_thousand_labels", &m);
     }
 }

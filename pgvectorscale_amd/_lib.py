@@ -46,6 +46,28 @@ class NodeLayout(C.Structure):
                                           "off_neighbor_index_pointers", "off_labels")]
 
 
+class MetaLayout(C.Structure):
+    _fields_ = [(k, C.c_uint32) for k in ("root_size", "off_magic_number", "off_version", "off_extension_version_when_built",
+                                          "off_distance_type", "off_num_dimensions", "off_num_dimensions_to_index",
+                                          "off_bq_num_bits_per_dimension", "off_storage_type", "off_num_neighbors",
+                                          "off_search_list_size", "off_max_alpha", "off_start_nodes", "off_quantizer_metadata",
+                                          "off_has_labels")]
+
+
+class MetaPage(C.Structure):
+    _fields_ = [("magic_number", C.c_uint32), ("version", C.c_uint32), ("extension_version_when_built", C.c_char * 64),
+                ("distance_type", C.c_uint32), ("num_dimensions", C.c_uint32), ("num_dimensions_to_index", C.c_uint32),
+                ("bq_num_bits_per_dimension", C.c_uint32), ("storage_type", C.c_uint32), ("num_neighbors", C.c_uint32),
+                ("search_list_size", C.c_uint32), ("max_alpha", C.c_double), ("has_start_nodes", C.c_uint32),
+                ("default_start_block", C.c_uint32), ("default_start_offset", C.c_uint32), ("n_labeled_start_nodes", C.c_uint32),
+                ("quantizer_block", C.c_uint32), ("quantizer_offset", C.c_uint32), ("has_labels", C.c_uint32)]
+
+    def as_dict(self):
+        d = {k: getattr(self, k) for k, _ in self._fields_}
+        d["extension_version_when_built"] = d["extension_version_when_built"].decode()
+        return d
+
+
 class PagesInfo(C.Structure):
     _fields_ = [("n_blocks", C.c_uint32), ("n_nodes", C.c_uint32), ("words", C.c_uint32), ("num_neighbors", C.c_uint32),
                 ("has_labels", C.c_uint32), ("n_deleted", C.c_uint32), ("n_label_vals", C.c_uint64),
@@ -112,6 +134,10 @@ SYMBOLS = {
     "vs_pages_read_chain": (_i, [_vp, _u32, _u32, _i, _vp, _sz, C.POINTER(_sz)]),
     "vs_pages_sbq_means": (_i, [_vp, _u32, _u32, _vp, _vp, _u32, C.POINTER(_u32), C.POINTER(_u64)]),
     "vs_pages_close": (None, [_vp]),
+    "vs_meta_layout_default": (_i, [C.POINTER(MetaLayout)]),
+    "vs_meta_page_decode": (_i, [_vp, _sz, C.POINTER(MetaLayout), C.POINTER(MetaPage), _vp, _vp, _vp, _u32]),
+    "vs_pages_meta": (_i, [_vp, C.POINTER(MetaLayout), C.POINTER(MetaPage), C.POINTER(IndexDesc), _vp, _vp, _u32]),
+    "vs_pages_dev_meta": (_i, [_vp, C.POINTER(MetaLayout), C.POINTER(MetaPage), C.POINTER(IndexDesc), _vp, _vp, _u32]),
     "vs_pages_headers_only": (_i, [_vp]),
     "vs_pages_block_table": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_u32)]),
     "vs_pages_dev_open": (_i, [_vp, _u32, C.POINTER(NodeLayout), _u32, C.POINTER(_vp)]),

@@ -539,6 +539,216 @@ int vs_pages_sbq_means(const vs_pages* p, uint32_t block, uint32_t offset, float
     return VS_OK;
 }
 
+int vs_meta_layout_default(vs_meta_layout* out) {
+    if (!out) return fail("vs_meta_layout_default: null argument");
+    // declaration order (AM/meta_page.rs:179-210), C alignment: u32 u32 String(8,4) u16 u32 u32 u8 u8 u32 u32 f64 Option<StartNodes>(20,4)
+    // ItemPointer(8,4) bool
+    *out = vs_meta_layout{80, 0, 4, 8, 16, 20, 24, 28, 29, 32, 36, 40, 48, 68, 76};
+    return VS_OK;
+}
+
+namespace {
+struct MetaCursor {
+    const uint8_t* b;
+    size_t len;
+    bool in(int64_t pos, size_t n) const { return pos >= 0 && (uint64_t)pos + n <= len; }
+};
+constexpr uint32_t kBtHeader = 12, kBtLeafEntry = 12, kBtInnerEntry = 8;
+
+// in-order walk of an ArchivedBTreeMap<i16, ArchivedItemPointer> node; false + err on a malformed tree
+bool walk_btree(const MetaCursor& c, int64_t pos, int depth, std::vector<int16_t>& keys, std::vector<uint64_t>& vals, uint64_t limit,
+                std::string& err) {
+    char buf[160];
+    if (depth > 8 || !c.in(pos, kBtHeader)) {
+        snprintf(buf, sizeof buf, "B-tree node at %lld lies outside the archive (depth %d)", (long long)pos, depth);
+        err = buf;
+        return false;
+    }
+    const uint16_t meta = rd16(c.b + pos);
+    const uint32_t cnt = meta & 0x7FFFu;
+    if (meta & 0x8000u) {
+        if (!c.in(pos, kBtHeader + (size_t)cnt * kBtInnerEntry)) {
+            err = "inner B-tree node runs past the archive";
+            return false;
+        }
+        if (!walk_btree(c, pos + 8 + rdi32(c.b + pos + 8), depth + 1, keys, vals, limit, err)) return false;
+        for (uint32_t e = 0; e < cnt; ++e) {
+            const int64_t ep = pos + kBtHeader + (int64_t)e * kBtInnerEntry;
+            if (!walk_btree(c, ep + rdi32(c.b + ep), depth + 1, keys, vals, limit, err)) return false;
+        }
+        return true;
+    }
+    if (!c.in(pos, kBtHeader + (size_t)cnt * kBtLeafEntry)) {
+        err = "leaf B-tree node runs past the archive";
+        return false;
+    }
+    for (uint32_t e = 0; e < cnt; ++e) {
+        const uint8_t* q = c.b + pos + kBtHeader + (size_t)e * kBtLeafEntry;
+        if (keys.size() >= limit) {
+            err = "B-tree holds more entries than its length field says";
+            return false;
+        }
+        keys.push_back((int16_t)rd16(q));
+        vals.push_back(((uint64_t)rd32(q + 4) << 16) | rd16(q + 8));
+    }
+    return true;
+}
+}  // namespace
+
+int vs_meta_page_decode(const void* bytes, size_t len, const vs_meta_layout* layout, vs_meta_page* out, int16_t* start_labels,
+                        uint32_t* start_blocks, uint32_t* start_offsets, uint32_t cap) {
+    if (!bytes || !out) return fail("vs_meta_page_decode: null argument");
+    vs_meta_layout L;
+    if (layout) L = *layout;
+    else vs_meta_layout_default(&L);
+    const uint32_t offs[] = {L.off_magic_number + 4, L.off_version + 4, L.off_extension_version_when_built + 8, L.off_distance_type + 2,
+                             L.off_num_dimensions + 4, L.off_num_dimensions_to_index + 4, L.off_bq_num_bits_per_dimension + 1,
+                             L.off_storage_type + 1, L.off_num_neighbors + 4, L.off_search_list_size + 4, L.off_max_alpha + 8,
+                             L.off_start_nodes + 20, L.off_quantizer_metadata + 8, L.off_has_labels + 1};
+    for (uint32_t e : offs)
+        if (e > L.root_size) return fail("vs_meta_layout: a field ends at byte %u of a %u-byte root object", e, L.root_size);
+    if (len < L.root_size) return fail("MetaPage archive of %zu bytes is shorter than its %u-byte root object", len, L.root_size);
+    const uint8_t* b = static_cast<const uint8_t*>(bytes);
+    const size_t root = len - L.root_size;  // rkyv::archived_root: the root object is the tail of the buffer
+    const MetaCursor c{b, len};
+    try {
+        memset(out, 0, sizeof *out);
+        out->magic_number = rd32(b + root + L.off_magic_number);
+        out->version = rd32(b + root + L.off_version);
+        if (out->magic_number != kTsvMagic) return fail("MetaPage magic %u is not %u", out->magic_number, kTsvMagic);
+        {  // ArchivedString
+            const size_t f = root + L.off_extension_version_when_built;
+            const uint8_t* src;
+            size_t n;
+            if ((b[f + 7] & 0x80) == 0) {
+                n = b[f + 7];
+                if (n > 7) return fail("MetaPage: inline string of %zu bytes", n);
+                src = b + f;
+            } else {
+                n = rd32(b + f);
+                const int64_t at = (int64_t)f + rdi32(b + f + 4);
+                if (!c.in(at, n)) return fail("MetaPage: extension_version_when_built points outside the archive");
+                src = b + at;
+            }
+            const size_t m = std::min(n, sizeof(out->extension_version_when_built) - 1);
+            memcpy(out->extension_version_when_built, src, m);
+        }
+        out->distance_type = rd16(b + root + L.off_distance_type);
+        out->num_dimensions = rd32(b + root + L.off_num_dimensions);
+        out->num_dimensions_to_index = rd32(b + root + L.off_num_dimensions_to_index);
+        out->bq_num_bits_per_dimension = b[root + L.off_bq_num_bits_per_dimension];
+        out->storage_type = b[root + L.off_storage_type];
+        out->num_neighbors = rd32(b + root + L.off_num_neighbors);
+        out->search_list_size = rd32(b + root + L.off_search_list_size);
+        memcpy(&out->max_alpha, b + root + L.off_max_alpha, 8);
+        out->quantizer_block = rd32(b + root + L.off_quantizer_metadata);
+        out->quantizer_offset = rd16(b + root + L.off_quantizer_metadata + 4);
+        out->has_labels = b[root + L.off_has_labels] ? 1u : 0u;
+        const size_t sn = root + L.off_start_nodes;  // ArchivedOption<ArchivedStartNodes>
+        if (b[sn] > 1) return fail("MetaPage: Option tag %u", b[sn]);
+        out->has_start_nodes = b[sn];
+        out->default_start_block = kInvalidBlock;
+        if (b[sn]) {
+            out->default_start_block = rd32(b + sn + 4);
+            out->default_start_offset = rd16(b + sn + 8);
+            const uint32_t cnt = rd32(b + sn + 12);
+            out->n_labeled_start_nodes = cnt;
+            if (cnt > 65536) return fail("MetaPage: %u labeled start nodes (labels are smallints)", cnt);
+            std::vector<int16_t> keys;
+            std::vector<uint64_t> vals;
+            if (cnt) {
+                std::string err;
+                keys.reserve(cnt);
+                vals.reserve(cnt);
+                if (!walk_btree(c, (int64_t)sn + 16 + rdi32(b + sn + 16), 0, keys, vals, cnt, err)) return fail("MetaPage: %s", err.c_str());
+                if (keys.size() != cnt) return fail("MetaPage: B-tree holds %zu entries, its length field says %u", keys.size(), cnt);
+                for (size_t i = 1; i < keys.size(); ++i)
+                    if (keys[i - 1] >= keys[i]) return fail("MetaPage: start-node labels are not strictly increasing at entry %zu", i);
+            }
+            if (start_labels || start_blocks || start_offsets) {
+                if (cnt > cap) return fail("MetaPage has %u labeled start nodes, the buffers hold %u", cnt, cap);
+                for (uint32_t i = 0; i < cnt; ++i) {
+                    if (start_labels) start_labels[i] = keys[i];
+                    if (start_blocks) start_blocks[i] = (uint32_t)(vals[i] >> 16);
+                    if (start_offsets) start_offsets[i] = (uint32_t)(vals[i] & 0xFFFF);
+                }
+            }
+        }
+    } catch (const std::bad_alloc&) {
+        vs_set_error("vs_meta_page_decode: out of host memory");
+        return VS_ERR_OOM;
+    }
+    return VS_OK;
+}
+
+int vs_pages_meta(const vs_pages* p, const vs_meta_layout* layout, vs_meta_page* meta, vs_index_desc* desc, int16_t* start_labels,
+                  uint32_t* start_nodes, uint32_t cap) {
+    if (!p || !desc) return fail("vs_pages_meta: null argument");
+    if (!p->finished) return fail("vs_pages_meta: call vs_pages_finish first");
+    if (p->blk_type.empty() || p->blk_type[0] != VS_PAGE_META)
+        return fail("block 0 has page type %d: only PageType::Meta (format version 3) relations carry a chained MetaPage",
+                    p->blk_type.empty() ? -1 : p->blk_type[0]);
+    try {
+        size_t l = 0;
+        int r = vs_pages_read_chain(p, 0, 2, VS_PAGE_META, nullptr, 0, &l);  // META_OFFSET = 2 (AM/meta_page.rs:28)
+        if (r != VS_OK) return r;
+        std::vector<uint8_t> bytes(l);
+        r = vs_pages_read_chain(p, 0, 2, VS_PAGE_META, bytes.data(), l, &l);
+        if (r != VS_OK) return r;
+        vs_meta_page m;
+        r = vs_meta_page_decode(bytes.data(), l, layout, &m, nullptr, nullptr, nullptr, 0);
+        if (r != VS_OK) return r;
+        std::vector<int16_t> lab(m.n_labeled_start_nodes);
+        std::vector<uint32_t> blk(m.n_labeled_start_nodes), off(m.n_labeled_start_nodes);
+        r = vs_meta_page_decode(bytes.data(), l, layout, &m, lab.data(), blk.data(), off.data(), m.n_labeled_start_nodes);
+        if (r != VS_OK) return r;
+        if (m.version != p->meta_version) return fail("MetaPage version %u, MetaPageHeader version %u", m.version, p->meta_version);
+        if (m.distance_type > 2) return fail("Unknown DistanceType number %u", m.distance_type);       // DistanceType::from_u16
+        if (m.storage_type != 0 && m.storage_type != 2) return fail("Invalid storage type %u", m.storage_type);  // StorageType::from_u8
+        if (m.num_dimensions_to_index == 0 || m.num_dimensions_to_index > m.num_dimensions)
+            return fail("MetaPage: %u of %u dimensions indexed", m.num_dimensions_to_index, m.num_dimensions);
+        memset(desc, 0, sizeof *desc);
+        desc->n = (uint32_t)p->n;
+        desc->dim_full = m.num_dimensions;
+        desc->dim_index = m.num_dimensions_to_index;
+        desc->bits = m.bq_num_bits_per_dimension;
+        desc->words = (uint32_t)(((uint64_t)m.num_dimensions_to_index * m.bq_num_bits_per_dimension + 63) / 64);  // AM/sbq/quantize.rs:37-45
+        desc->num_neighbors = m.num_neighbors;
+        desc->distance_type = m.distance_type;
+        desc->has_labels = m.has_labels;
+        desc->storage_type = m.storage_type == 0 ? VS_STORAGE_PLAIN : VS_STORAGE_SBQ;
+        desc->default_start = VS_INVALID_NODE;
+        if (p->n && !p->headers_only) {
+            if ((uint32_t)p->has_labels != m.has_labels)
+                return fail("the reader was opened with has_labels = %d, the MetaPage says %u", p->has_labels, m.has_labels);
+            if (desc->storage_type == VS_STORAGE_SBQ && (p->W != desc->words || p->R != m.num_neighbors))
+                return fail("SbqNode items hold %u-word codes and %u neighbor slots, the MetaPage implies %u and %u", p->W, p->R,
+                            desc->words, m.num_neighbors);
+        }
+        if (m.has_start_nodes) {
+            r = vs_pages_node_of(p, m.default_start_block, m.default_start_offset, &desc->default_start);
+            if (r != VS_OK) return r;
+            desc->n_label_starts = m.n_labeled_start_nodes;
+            if (start_labels || start_nodes) {
+                if (m.n_labeled_start_nodes > cap)
+                    return fail("MetaPage has %u labeled start nodes, the buffers hold %u", m.n_labeled_start_nodes, cap);
+                for (uint32_t i = 0; i < m.n_labeled_start_nodes; ++i) {
+                    uint32_t node;
+                    r = vs_pages_node_of(p, blk[i], off[i], &node);
+                    if (r != VS_OK) return r;
+                    if (start_labels) start_labels[i] = lab[i];
+                    if (start_nodes) start_nodes[i] = node;
+                }
+            }
+        }
+        if (meta) *meta = m;
+    } catch (const std::bad_alloc&) {
+        vs_set_error("vs_pages_meta: out of host memory");
+        return VS_ERR_OOM;
+    }
+    return VS_OK;
+}
+
 int vs_pages_finish(vs_pages* p, vs_pages_info* info) {
     if (!p) return fail("vs_pages_finish: null reader");
     if (!p->finished) {

@@ -227,6 +227,13 @@ extern "C" int vs_pages_dev_sbq_means(const vs_pages_dev* d, uint32_t block, uin
     return vs_pages_sbq_means(d->hdr, block, offset, mean, m2, dim_cap, dim, count);
 }
 
+extern "C" int vs_pages_dev_meta(vs_pages_dev* d, const vs_meta_layout* layout, vs_meta_page* meta, vs_index_desc* desc,
+                                 int16_t* start_labels, uint32_t* start_nodes, uint32_t cap) {
+    VS_REQUIRE(d, "vs_pages_dev_meta: null reader");
+    VS_TRY(vs_pages_finish(d->hdr, nullptr));  // (block table complete: every block has been added)
+    return vs_pages_meta(d->hdr, layout, meta, desc, start_labels, start_nodes, cap);
+}
+
 // desc: the MetaPage fields (n is taken from the pages); extras: vecs / mean / m2 / count / start-node arrays (node ids)
 extern "C" int vs_pages_dev_build(vs_pages_dev* d, const vs_index_desc* desc, const vs_index_host* extras, vs_pages_info* info,
                                   vs_index** out) {

@@ -4,17 +4,55 @@
 pages; UT/page.rs:28-39).  Blocks are appended in block order, decoded by libvsgpu on the host cores into the flat
 arrays of `vs_index_host`, and `upload()` streams them to the device through the pinned staging ring.  What is NOT
 read from the pages is what the reference itself keeps elsewhere or only the Rust side can decode: the heap's vector
-column (`vecs`, needed for rerank) and the MetaPage body (geometry and start nodes are passed as arguments).
+column (`vecs`, needed for rerank).  The MetaPage body (geometry, start nodes, the SbqMeans pointer) is decoded by
+`meta()` / `upload_from_meta()` (vs_pages_meta), or passed by hand to `upload()`.
 """
 import ctypes as C
 
 import numpy as np
 
 from . import _lib
-from ._lib import IndexDesc, IndexHost, NodeLayout, PagesInfo, check
+from ._lib import IndexDesc, IndexHost, MetaLayout, MetaPage, NodeLayout, PagesInfo, check
 
 BLCKSZ = 8192
 PAGE_SBQ_MEANS, PAGE_META = 7, 8
+
+
+def _meta_layout(layout):
+    """None, or a {"root_size": .., field: offset} dict as oracle/pages_py.meta_layout() gives / offset_of! prints"""
+    if layout is None:
+        return None
+    lay = MetaLayout()
+    lay.root_size = layout["root_size"]
+    for k, _ in MetaLayout._fields_[1:]:
+        setattr(lay, k, layout[k[4:]])
+    return lay
+
+
+def decode_meta_page(data, layout=None):
+    """rkyv::from_bytes::<MetaPage> over the payload of the chain at (0, 2) -> (fields, {label: (block, offset)})"""
+    L = _lib.load()
+    buf = np.frombuffer(bytes(data), np.uint8)
+    lay = _meta_layout(layout)
+    m = MetaPage()
+    check(L.vs_meta_page_decode(buf.ctypes.data_as(C.c_void_p), buf.size, None if lay is None else C.byref(lay), C.byref(m), None,
+                                None, None, 0))
+    n = int(m.n_labeled_start_nodes)
+    lab, blk, off = np.empty(n, np.int16), np.empty(n, np.uint32), np.empty(n, np.uint32)
+    check(L.vs_meta_page_decode(buf.ctypes.data_as(C.c_void_p), buf.size, None if lay is None else C.byref(lay), C.byref(m),
+                                lab.ctypes.data_as(C.c_void_p), blk.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p), n))
+    return m.as_dict(), {int(l): (int(b), int(o)) for l, b, o in zip(lab, blk, off)}
+
+
+def _meta_of(fn, handle, layout):
+    lay = _meta_layout(layout)
+    m, d = MetaPage(), IndexDesc()
+    check(fn(handle, None if lay is None else C.byref(lay), C.byref(m), C.byref(d), None, None, 0))
+    n = int(d.n_label_starts)
+    lab, nodes = np.empty(n, np.int16), np.empty(n, np.uint32)
+    check(fn(handle, None if lay is None else C.byref(lay), C.byref(m), C.byref(d), lab.ctypes.data_as(C.c_void_p),
+             nodes.ctypes.data_as(C.c_void_p), n))
+    return m.as_dict(), d, {int(l): int(v) for l, v in zip(lab, nodes)}
 
 
 class IndexPages:
@@ -90,6 +128,23 @@ class IndexPages:
         check(self._L.vs_pages_sbq_means(self.h, block, offset, mean.ctypes.data_as(C.c_void_p),
                                          m2.ctypes.data_as(C.c_void_p), dim.value, C.byref(dim), C.byref(cnt)))
         return int(cnt.value), mean, m2
+
+    def meta(self, layout=None):
+        """MetaPage::fetch (AM/meta_page.rs:380-403): -> (MetaPage fields, vs_index_desc with node-id start, {label: start node})"""
+        if self.info is None:
+            self.finish()
+        return _meta_of(self._L.vs_pages_meta, self.h, layout)
+
+    def upload_from_meta(self, ctx, vecs=None, meta_layout=None):
+        """everything but the heap's vector column comes from the relation: geometry and start nodes from the MetaPage, the
+        quantizer from the SbqMeans chain it points at, nodes from the SbqNode pages"""
+        m, d, starts = self.meta(meta_layout)
+        assert bool(m["has_labels"]) == self.has_labels
+        has_q = m["quantizer_block"] != 0xFFFFFFFF
+        return self.upload(ctx, dim_index=d.dim_index, bits=d.bits, distance_type=d.distance_type,
+                           default_start=None if d.default_start == _lib.VS_INVALID_NODE else int(d.default_start),
+                           quantizer_metadata=(m["quantizer_block"], m["quantizer_offset"]) if has_q else None,
+                           vecs=vecs, label_starts=starts)
 
     def _host(self):
         if self.info is None:
@@ -199,6 +254,19 @@ class DevicePages:
         check(self._L.vs_pages_dev_sbq_means(self.h, block, offset, mean.ctypes.data_as(C.c_void_p), m2.ctypes.data_as(C.c_void_p),
                                              dim.value, C.byref(dim), C.byref(cnt)))
         return int(cnt.value), mean, m2
+
+    def meta(self, layout=None):
+        """MetaPage::fetch on the metadata pages the host kept -> (fields, vs_index_desc, {label: start node})"""
+        return _meta_of(self._L.vs_pages_dev_meta, self.h, layout)
+
+    def build_from_meta(self, vecs=None, meta_layout=None):
+        m, d, starts = self.meta(meta_layout)
+        has_q = m["quantizer_block"] != 0xFFFFFFFF
+        return self.build(words=d.words, num_neighbors=d.num_neighbors, dim_index=d.dim_index, bits=d.bits,
+                          distance_type=d.distance_type,
+                          default_start=None if d.default_start == _lib.VS_INVALID_NODE else int(d.default_start),
+                          quantizer_metadata=(m["quantizer_block"], m["quantizer_offset"]) if has_q else None, vecs=vecs,
+                          has_labels=bool(m["has_labels"]), label_starts=starts)
 
     def build(self, *, words, num_neighbors, dim_index, bits, distance_type, default_start, quantizer_metadata=None, mean=None,
               m2=None, count=0, vecs=None, has_labels=False, label_starts=None):

@@ -55,3 +55,39 @@ def test_index_from_pages_searches_like_the_oracle(gpu_ctx, oracle, labeled):
     assert gst["quantized_distance_comparisons"] == ost["quantized_distance_comparisons"]
     ix.close()
 
+
+
+@pytest.mark.parametrize("on_device", [False, True])
+def test_index_from_the_relation_alone(gpu_ctx, oracle, on_device):
+    """nothing is passed by hand but the heap's vector column: geometry, distance type, default and labeled start nodes and the
+    pointer to the SbqMeans chain are decoded from the MetaPage (vs_pages_meta / vs_pages_dev_meta), host and device decoders"""
+    from pgvectorscale_amd.pages import DevicePages, IndexPages
+    O = oracle
+    ti = TestIndex(n=1200, dim_full=80, dim_index=64, bits=2, R=20, distance=O.COSINE, seed=23, kind="gauss", n_labels=5,
+                   deleted_frac=0.05, L_build=40)
+    meta = dict(num_dimensions=ti.dim_full, num_dimensions_to_index=ti.dim_index, bq_num_bits_per_dimension=ti.bits,
+                distance_type=ti.distance, num_neighbors=ti.R, default_start=ti.start, labeled_starts=dict(ti.label_starts))
+    w = PG.write_index(codes=ti.codes, nbrs=ti.nbrs, heap_tids=ti.tids, mean=ti.mean, m2=ti.m2, count=ti.count,
+                       label_off=ti.label_off, label_val=ti.label_val, meta=meta)
+    data = w.rel.tobytes()
+    if on_device:
+        pages = DevicePages(gpu_ctx, len(w.rel.pages))
+        pages.add(data)
+        ix = pages.build_from_meta(vecs=ti.vecs)
+    else:
+        pages = IndexPages(has_labels=True)
+        pages.add(data)
+        ix = pages.upload_from_meta(gpu_ctx, vecs=ti.vecs)
+    pages.close()
+    d = ix.desc
+    assert (d.n, d.dim_full, d.dim_index, d.bits, d.num_neighbors, d.distance_type, d.default_start) == \
+        (ti.n, ti.dim_full, ti.dim_index, ti.bits, ti.R, ti.distance, ti.start)
+    q = ti.queries(24, seed=6, kind="gauss")
+    rng = np.random.default_rng(4)
+    keys = [sorted(set(int(x) for x in rng.integers(1, 6, int(rng.integers(1, 3))))) for _ in range(24)]
+    for kk in (None, keys):
+        gi, _, gd, gst = ix.search_batch(q, search_list_size=30, rescore=15, k=10, qlabels=kk)
+        oi, od, ost = ti.oracle.search_batch(q, L=30, rescore=15, k=10, qlabels=kk)
+        assert (gi == oi).all() and _close(gd, od)
+        assert gst["visited_nodes"] == ost["visited_nodes"]
+    ix.close()

@@ -224,6 +224,26 @@ def check_ref_kat_lines(oracle, lines):
             b = np.array([np.float32(np.float32(i * 53 % 103) / np.float32(103.0)) - np.float32(0.7) for i in range(d)], np.float32)
             assert f"{np.float32(O.distance_l2(a, b)).view(np.uint32):08x}" == f["l2"]
             assert f"{np.float32(O.inner_product(a, b)).view(np.uint32):08x}" == f["ip"]
+        elif kind == "meta":
+            # the archived MetaPage as the reference's rkyv really writes it: the pure-Python encoder must produce exactly these
+            # bytes under the printed field offsets (the C decoder is held to the Python one in tests/test_pages.py)
+            from oracle import pages_py as PG
+            offs = [int(x) for x in f["offs"].split(",")]
+            lay = dict(zip(PG.META_FIELDS, offs), root_size=int(f["size"]))
+            base = dict(num_dimensions=768, num_dimensions_to_index=512, bq_num_bits_per_dimension=2, distance_type=1, storage_type=2,
+                        num_neighbors=50, search_list_size=100, max_alpha=1.2, quantizer=(3, 1), layout=lay)
+            cases = {
+                "none_inline": dict(extension_version="0.8.0"),
+                "some_empty_outofline": dict(extension_version="0.8.0-rc1+build.77", default_start=(7, 1)),
+                "some_four_labels": dict(extension_version="0.8.0", default_start=(7, 1), has_labels=True,
+                                         labeled_starts={l: (100 + (l & 0xFFFFFFFF) % 50, 1 + (l & 0xFFFFFFFF) % 7) for l in (5, -3, 300, 17)}),
+                "some_thousand_labels": dict(extension_version="0.8.0", default_start=(7, 1), has_labels=True,
+                                             labeled_starts={l: (l + 1000, 1 + (l + 500) % 90) for l in range(-500, 500)}),
+            }
+            want = bytes.fromhex(f["bytes"])
+            assert PG.rkyv_meta_page(**base, **cases[f["case"]]) == want, f["case"]
+            got = PG.parse_meta_page(want, lay)
+            assert got["default_start"] == cases[f["case"]].get("default_start")
         else:
             raise AssertionError(f"unknown KAT line: {ln[:60]}")
         checked += 1
@@ -257,4 +277,9 @@ def test_ref_kat_loader_on_oracle_made_lines(oracle):
     inv = (0xFFFFFFFF, 0)
     b = PG.rkyv_sbq_node((7, 3), [0x0123456789abcdef, 0xfedcba9876543210, 0x00000000ffffffff], [(1, 1), (2, 5), inv, inv], labels=[2, 5, 9])
     lines.append(f"KAT node kind=labeled size=32 off_heap=0 off_code=8 off_nbrs=16 off_last=24 bytes={b.hex()}")
+    lay = PG.DEFAULT_META_LAYOUT
+    offs = ",".join(str(lay[k]) for k in PG.META_FIELDS)
+    mb = PG.rkyv_meta_page(num_dimensions=768, num_dimensions_to_index=512, quantizer=(3, 1), extension_version="0.8.0-rc1+build.77",
+                           default_start=(7, 1))
+    lines.append(f"KAT meta case=some_empty_outofline size={lay['root_size']} offs={offs} bytes={mb.hex()}")
     assert check_ref_kat_lines(oracle, lines) == len(lines)

@@ -350,3 +350,125 @@ def test_empty_relation():
     assert info.n_nodes == 0 and info.n_blocks == 1 and info.meta_version == 3
     assert rd.arrays()["codes"].size == 0
     rd.close()
+
+
+# ---- the MetaPage body (AM/meta_page.rs:176-210) ----------------------------------------------------------------------
+def test_meta_page_round_trip_through_both_decoders():
+    """rkyv archive of MetaPage (String inline / out of line, Option<StartNodes> None / Some, BTreeMap of 0 .. 65536 labeled start
+    nodes = one leaf .. three levels of nodes): libvsgpu's decoder and the pure-Python one must both give back what was written"""
+    from pgvectorscale_amd.pages import decode_meta_page
+    cases = [
+        dict(num_dimensions=768),
+        dict(num_dimensions=1536, num_dimensions_to_index=512, bq_num_bits_per_dimension=1, distance_type=0, storage_type=2,
+             num_neighbors=64, search_list_size=77, max_alpha=1.35, default_start=(3, 9), quantizer=(1, 1)),
+        dict(num_dimensions=128, extension_version="0.8.0-rc1+build.77", default_start=(7, 1), labeled_starts={5: (9, 2)},
+             has_labels=True),
+        dict(num_dimensions=64, storage_type=0, default_start=(2, 2), has_labels=True,
+             labeled_starts={int(l): (1000 + i, 1 + i % 90) for i, l in enumerate(range(-32768, 32768, 97))}),
+        dict(num_dimensions=64, default_start=(2, 2), has_labels=True,
+             labeled_starts={l: (40000 + l, 1 + (l % 7)) for l in range(-32768, 32768)}),
+    ]
+    for kw in cases:
+        data = PG.rkyv_meta_page(**kw)
+        want = PG.parse_meta_page(data)
+        got, starts = decode_meta_page(data)
+        assert got["magic_number"] == PG.TSV_MAGIC_NUMBER and got["version"] == PG.TSV_VERSION
+        for key in ("distance_type", "num_dimensions", "num_dimensions_to_index", "bq_num_bits_per_dimension", "storage_type",
+                    "num_neighbors", "search_list_size", "max_alpha"):
+            assert got[key] == want[key], key
+        assert got["extension_version_when_built"] == want["extension_version_when_built"][:63]
+        assert bool(got["has_labels"]) == want["has_labels"] == bool(kw.get("has_labels"))
+        assert (got["quantizer_block"], got["quantizer_offset"]) == want["quantizer_metadata"]
+        if want["default_start"] is None:
+            assert not got["has_start_nodes"] and starts == {}
+        else:
+            assert (got["default_start_block"], got["default_start_offset"]) == want["default_start"]
+            assert starts == want["labeled_starts"] == (kw.get("labeled_starts") or {})
+            assert list(starts) == sorted(starts)
+
+
+def test_meta_page_with_another_field_order():
+    """rkyv 0.7 archives are repr(Rust): the field offsets are a parameter of both decoders"""
+    from pgvectorscale_amd.pages import decode_meta_page
+    order = ("max_alpha", "start_nodes", "quantizer_metadata", "extension_version_when_built", "magic_number", "version",
+             "num_dimensions", "num_dimensions_to_index", "num_neighbors", "search_list_size", "distance_type",
+             "bq_num_bits_per_dimension", "storage_type", "has_labels")  # largest alignment first, as rustc tends to do
+    lay = PG.meta_layout(order)
+    assert lay["root_size"] == 80 and lay["magic_number"] == 44 and lay != PG.DEFAULT_META_LAYOUT
+    data = PG.rkyv_meta_page(num_dimensions=100, default_start=(4, 4), labeled_starts={1: (5, 5), 2: (6, 6)}, layout=lay,
+                             has_labels=True, max_alpha=1.0625)
+    got, starts = decode_meta_page(data, layout=lay)
+    assert got["num_dimensions"] == 100 and got["max_alpha"] == 1.0625 and starts == {1: (5, 5), 2: (6, 6)}
+    from pgvectorscale_amd import VsError
+    with pytest.raises(VsError):  # the default layout on these bytes: the magic number is not where it is looked for
+        decode_meta_page(data)
+
+
+def test_malformed_meta_pages_are_rejected():
+    from pgvectorscale_amd import VsError
+    from pgvectorscale_amd.pages import decode_meta_page
+    good = bytearray(PG.rkyv_meta_page(num_dimensions=64, default_start=(2, 2), has_labels=True, extension_version="0.8.0-long-version",
+                                       labeled_starts={l: (9, 1) for l in range(600)}))
+    lay = PG.DEFAULT_META_LAYOUT
+    root = len(good) - lay["root_size"]
+    sn = root + lay["start_nodes"]
+
+    def broken(mut):
+        b = bytearray(good)
+        mut(b)
+        with pytest.raises(VsError):
+            decode_meta_page(bytes(b))
+
+    decode_meta_page(bytes(good))
+    with pytest.raises(VsError):
+        decode_meta_page(bytes(good[-40:]))                                       # shorter than the root object
+    broken(lambda b: struct.pack_into("<I", b, root, 12345))                       # magic
+    broken(lambda b: b.__setitem__(sn, 7))                                         # Option tag
+    broken(lambda b: struct.pack_into("<i", b, sn + 16, -(1 << 30)))               # B-tree root outside the archive
+    broken(lambda b: struct.pack_into("<I", b, sn + 12, 599))                      # length field != entries
+    broken(lambda b: struct.pack_into("<I", b, sn + 12, 70000))                    # more labels than smallints
+    broken(lambda b: struct.pack_into("<i", b, root + lay["extension_version_when_built"] + 4, -(1 << 29)))  # string target
+    # a cycle: the root's first child pointer led back to the root itself
+    rootnode = sn + 16 + struct.unpack_from("<i", good, sn + 16)[0]
+    assert struct.unpack_from("<H", good, rootnode)[0] & 0x8000
+    broken(lambda b: struct.pack_into("<i", b, rootnode + 8, -8))
+    # unsorted keys
+    leaf0 = rootnode + 8 + struct.unpack_from("<i", good, rootnode + 8)[0]
+    broken(lambda b: struct.pack_into("<h", b, leaf0 + 12, 500))
+
+
+@pytest.mark.parametrize("n_labels,big_map", [(0, False), (6, False), (6, True)])
+def test_index_desc_from_the_relation_alone(n_labels, big_map):
+    """MetaPage::fetch over a manufactured relation: geometry, default start node, labeled start nodes (IndexPointers translated to
+    node ids) and the quantizer pointer all come from the pages — vs_pages_meta yields a complete vs_index_desc without Rust"""
+    n, W, R = 700, 3, 9
+    ix = random_index(n, W, R, seed=12, n_labels=n_labels)
+    rng = np.random.default_rng(1)
+    starts = {}
+    if n_labels:
+        labs = range(-5, n_labels) if not big_map else range(-2000, 2000)  # 4000 entries: the meta chain leaves block 0
+        starts = {int(l): int(rng.integers(0, n)) for l in labs}
+    meta = dict(num_dimensions=W * 32, bq_num_bits_per_dimension=2, distance_type=1, num_neighbors=R, search_list_size=100,
+                max_alpha=1.2, default_start=17, labeled_starts=starts)
+    w = PG.write_index(**ix, meta=meta, zero_page_every=97)
+    rd = _reader(has_labels=bool(n_labels))
+    rd.add(w.rel.tobytes())
+    rd.finish()
+    m, d, st = rd.meta()
+    assert (d.n, d.dim_full, d.dim_index, d.bits, d.words, d.num_neighbors, d.distance_type) == (n, W * 32, W * 32, 2, W, R, 1)
+    assert d.has_labels == int(bool(n_labels)) and d.storage_type == 0 and d.default_start == 17 and d.n_label_starts == len(starts)
+    assert st == starts
+    assert (m["quantizer_block"], m["quantizer_offset"]) == w.means_ptr
+    cnt, mean, m2 = rd.sbq_means(m["quantizer_block"], m["quantizer_offset"])
+    assert cnt == n and (mean == ix["mean"]).all() and (m2 == ix["m2"]).all()
+    if big_map:
+        assert len(PG.read_chain(w.rel, 0, 2, PG.PT_META)) > PG.BLCKSZ
+    # an index that never saw a row: start_nodes is None -> VS_INVALID_NODE
+    empty = PG.write_index(codes=np.zeros((0, W), np.uint64), nbrs=np.zeros((0, R), np.uint32), heap_tids=np.zeros(0, np.uint64),
+                           mean=ix["mean"], m2=ix["m2"], count=0, num_neighbors=R,
+                           meta=dict(num_dimensions=W * 32, num_neighbors=R))
+    rd2 = _reader()
+    rd2.add(empty.rel.tobytes())
+    rd2.finish()
+    m2_, d2, st2 = rd2.meta()
+    assert d2.n == 0 and d2.default_start == 0xFFFFFFFF and st2 == {} and not m2_["has_start_nodes"]

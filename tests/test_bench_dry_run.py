@@ -62,3 +62,24 @@ def test_bench_dry_run_two_batches_in_flight():
     j = json.loads(r.stdout.strip().splitlines()[-1])
     assert j["config"]["batches_in_flight"] == 2 and j["steps"] == 3
     assert j["cpu_baseline"]["gpu_rows_identical"] is True and 0.9 < j["recall_heldout"] <= 1.0
+
+
+def test_bench_two_ranks_small():
+    """DEFAULT CPU tier (about 20 s): the driver's N > 1 launch line on the interpreter with gloo standing in for RCCL — rank 0 builds
+    the graph and broadcasts it, both ranks run their shard of the queries with two batches in flight (--pipeline 2), the held-out
+    recall is pooled over the ranks, one all_gather closes each step, rank 0 prints the line"""
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "emu"), "-j8", "-s"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    env = dict(os.environ, VS_EMU="1", VS_EMU_THREADS="4", VS_F_LDS_MAX_INS="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29523", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--corpus", "1500", "--dim", "32", "--nq", "32",
+           "--steps", "2", "--warmup", "1", "--recall-queries", "8", "--validate-queries", "16", "--heldout-queries", "16",
+           "--scan-nq", "0", "--cpu-seconds", "1", "--graph-cache", "none", "--fixed", "20,10", "--pipeline", "2"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, cwd=ROOT, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and "query-sharded x2" in j["config"]["parallelism"]
+    assert j["config"]["batches_in_flight"] == 2 and j["steps"] == 2
+    assert "graph_build_s" in j["setup_s"] and "graph_broadcast_s" in j["setup_s"]  # rank 0 built, the others received
+    assert j["recall_heldout_queries"] == 32  # 16 per rank, pooled
+    assert j["value"] > 0 and j["roofline"]["timed_over"].startswith("1 sequential warm-up")

@@ -971,7 +971,24 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
         const uint32_t fslots = fast_pool_slots(nq, caps.f_pool_frac);
         ix->last_ins_limit = caps.f_lh ? caps.f_lh - caps.f_lh / 8 - 64 : 0xFFFFFFFFu;
         VS_TRY(devbuf_reserve(c, w.heap_g4, std::max<size_t>((size_t)nq * caps.f_gstride * 4, 16)));
+        const void* const ghash4_before = w.ghash4.p;
         VS_TRY(devbuf_reserve(c, w.ghash4, (size_t)fslots * caps.f_gcap * 4));
+        // epoch-tagged dedup table (table-less regime): no scan clears its table; the array is zeroed when it is new, when the
+        // id width changes and when the epochs wrap (VS_F_EPOCH=0: plain ids, every scan clears its 64 KB)
+        uint32_t epoch = 0, eshift = 0;
+        if (caps.f_lh == 0 && env_u32("VS_F_EPOCH", 1)) {
+            while ((1ull << eshift) < (uint64_t)std::max<uint32_t>(ix->d.n, 2)) eshift++;
+            if (eshift <= 28) {  // >= 15 launches between two clears
+                const uint32_t last = std::min<uint32_t>((1u << (32 - eshift)) - 1u, env_u32("VS_F_EPOCH_MAX", 0xFFFFFFFFu));  // (the override lets a test see the wrap)
+                if (w.ghash4.p != ghash4_before || w.ghash4_eshift != eshift || w.ghash4_epoch == 0 || w.ghash4_epoch >= last) {
+                    VS_HIP(hipMemsetAsync(w.ghash4.p, 0, w.ghash4.bytes, c->stream));
+                    w.ghash4_epoch = 0;
+                    w.ghash4_eshift = eshift;
+                }
+                epoch = ++w.ghash4_epoch;
+            }
+        }
+        if (!epoch) w.ghash4_epoch = 0;  // (a launch with plain ids leaves entries a tagged launch could misread)
         VS_TRY(devbuf_reserve(c, w.pool_ctr, 64));
         VS_HIP(hipMemsetAsync(w.pool_ctr.p, 0, 64, c->stream));
         VS_TRY(devbuf_reserve(c, w.fb_flag, (size_t)nq * 4));
@@ -992,6 +1009,8 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
         f.lh = caps.f_lh;
         f.minw = env_u32("VS_F_MINW", caps.f_lh == 0 ? (caps.f_vr ? 4 : 6) : 1);
         f.flags = env_u32("VS_F_FLAGS", 0);
+        f.epoch = epoch;
+        f.eshift = eshift;
         f.rc = caps.f_lh == 0 ? env_u32("VS_F_RC", 0) : 0;  // (measurement: LDS id cache in front of the dedup table in HBM)
         if (f.rc) f.rc = next_pow2_u32(f.rc);
         f.visible = (!bp.stream_only && bp.rescore > 0) ? ix->visible : nullptr;  // the heap is only fetched for the rescore window
@@ -1019,6 +1038,7 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
         // pool.  Scans finished above return at once; what still does not fit goes to the general kernel below.
         if (env_u32("VS_F_RETRY", 1)) {
             FastLaunch r = f;
+            r.epoch = 0;  // (its own, smaller table array: cleared by the few scans that run)
             r.only_failed = 1;
             r.fb_flag = (uint32_t*)w.fb_flag.p;
             r.phase = nullptr;

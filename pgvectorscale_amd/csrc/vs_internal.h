@@ -95,6 +95,8 @@ struct DevBuf {
 };
 
 struct SearchWorkspace {
+    uint32_t ghash4_epoch = 0;   // epoch of the last launch on ghash4 (0: the array must be zeroed before the next tagged launch)
+    uint32_t ghash4_eshift = 0;  // id bits the tags in ghash4 were written with
     DevBuf q_full, qcodes, qlabels, qlabel_off, hash, heap_g, heap_g4, ghash4, heap_g4b, ghash4b, pool_ctr, fb_flag, phase, stream_ids, stream_ham, stream_cnt, stats, status,
         rr_dist, out_ids, out_tids, out_dist, resort_heap, raw_q, misc, q_index;
     // pending async call (vs_search_batch_dev)
@@ -202,6 +204,8 @@ struct FastLaunch {
     uint32_t vcap;     // visited ring capacity (vr == 0)
     uint32_t minw;     // register cap variant: waves per SIMD to leave room for (1 = unconstrained)
     uint32_t rc = 0;   // entries of the LDS cache of ids known to be in the table (table-less regime; 0 or a power of two)
+    uint32_t epoch = 0;   // != 0: global dedup entries are (epoch << eshift) | id and stale tags count as empty (no clearing)
+    uint32_t eshift = 0;  // bits of a node id inside a tagged entry
     uint32_t build = 0; // 1: greedy_search_for_build (the visited list is the output; needs vr == 0)
     uint32_t flags = 0; // FAST_* (measurement switches)
     // second attempt of the scans a first launch gave up on (bigger capacities): only scans whose status[q] != 0 run, their

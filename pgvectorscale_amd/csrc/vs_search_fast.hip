@@ -799,9 +799,16 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
     auto hash_home = [&](uint32_t nid) -> uint32_t { return (uint32_t)(((uint64_t)hash_u32(nid) * s.lh) >> 32); };
     // handle -> node id.  node_load only ISSUES the read (LDS, or L2 for ids in the overflow table); the value is made
     // uniform with rfl() where it is needed, so the latency overlaps whatever runs in between.
+    // Epoch-tagged table (s.epoch != 0): an entry is (epoch << s.eshift) | node id, and an entry whose tag is not this launch's
+    // epoch counts as EMPTY — the table is never cleared by the scans (a 64 KB clear per scan was 8 % of a 50M launch's
+    // memory requests); the host zeroes the array once and again whenever the epochs wrap.  s.epoch == 0: entries are plain
+    // ids, VS_EMPTY marks an empty slot and the claiming wave clears its table (second attempts, build mode).
+    const uint32_t etag = s.epoch << (s.eshift & 31u);
+    const uint32_t idmask = s.epoch ? (1u << (s.eshift & 31u)) - 1u : 0xFFFFFFFFu;
+    auto g_empty = [&](uint32_t v) -> bool { return s.epoch ? (v >> (s.eshift & 31u)) != s.epoch : v == VS_EMPTY; };
     auto node_load = [&](uint32_t handle) -> uint32_t {
         if (handle < s.lh) return lload32(lhash + handle);
-        return gload32(ghash + (handle - s.lh));
+        return gload32(ghash + (handle - s.lh)) & idmask;
     };
     // true where the id was not present before; slot_out = its handle
     auto finish_insert = [&](uint32_t nid, bool act, uint32_t slot, uint32_t old, uint32_t& slot_out) -> bool {
@@ -833,12 +840,13 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
             wave_sync();  // every lane holds its snapshot before any lane stores (the loads are earlier instructions)
             uint32_t em = 0;
             if (pend) {
-                const uint32_t hit = (v.x == nid ? 1u : 0u) | (v.y == nid ? 2u : 0u) | (v.z == nid ? 4u : 0u) | (v.w == nid ? 8u : 0u);
+                const uint32_t key = nid | etag;
+                const uint32_t hit = (v.x == key ? 1u : 0u) | (v.y == key ? 2u : 0u) | (v.z == key ? 4u : 0u) | (v.w == key ? 8u : 0u);
                 if (hit) {
                     slot_out = s.lh + b0 + (uint32_t)__builtin_ctz(hit);
                     pend = false;
                 } else {
-                    em = (v.x == VS_EMPTY ? 1u : 0u) | (v.y == VS_EMPTY ? 2u : 0u) | (v.z == VS_EMPTY ? 4u : 0u) | (v.w == VS_EMPTY ? 8u : 0u);
+                    em = (g_empty(v.x) ? 1u : 0u) | (g_empty(v.y) ? 2u : 0u) | (g_empty(v.z) ? 4u : 0u) | (g_empty(v.w) ? 8u : 0u);
                     if (em == 0) b0 = (b0 + 4u) & gmask;
                 }
             }
@@ -855,7 +863,7 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
                     if (rank > 1) m &= m - 1u;
                     if (rank > 2) m &= m - 1u;
                     const uint32_t at = b0 + (uint32_t)__builtin_ctz(m);
-                    ghash[at] = nid;
+                    ghash[at] = nid | etag;
                     slot_out = s.lh + at;
                     fresh = true;
                     pend = false;
@@ -872,9 +880,11 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
         if (g_open) return true;
         if (!claim_region()) return false;
         g_open = true;
-        for (uint32_t i = 4u * lane; i < s.gcap; i += 4u * WAVE)
-            *reinterpret_cast<uint4*>(ghash + i) = make_uint4(VS_EMPTY, VS_EMPTY, VS_EMPTY, VS_EMPTY);
-        wave_sync();
+        if (s.epoch == 0) {
+            for (uint32_t i = 4u * lane; i < s.gcap; i += 4u * WAVE)
+                *reinterpret_cast<uint4*>(ghash + i) = make_uint4(VS_EMPTY, VS_EMPTY, VS_EMPTY, VS_EMPTY);
+            wave_sync();
+        }
         return true;
     };
     // Frozen mode (LDS table at its load limit): read-only probe of the LDS table, then the global table

@@ -287,6 +287,41 @@ int vs_meta_page_decode(const void* bytes, size_t len, const vs_meta_layout* lay
 int vs_pages_meta(const vs_pages* p, const vs_meta_layout* layout, vs_meta_page* meta, vs_index_desc* desc, int16_t* start_labels,
                   uint32_t* start_nodes, uint32_t cap);
 
+/* ---- the heap's vector column (vs_heap.cpp; host-only) ----------------------------------------------------------------------
+ * vs_index_host.vecs — what the rescore window reads through table_index_fetch_tuple + slot_getattr + pg_detoast_datum_copy per
+ * candidate (UT/table_slot.rs:19-42, AM/pg_vector.rs:125-135, AM/sbq/storage.rs:304-328) — is staged once, in bulk, from the
+ * pages of the table the index points into: the heap's main fork streams past in block order (vs_heap_add), then its TOAST
+ * relation's (vs_heap_toast_add; a 768-dimensional vector is 3 KB and lives there, chunked).  For every index node the tuple
+ * its heap TID names is deformed up to the vector attribute exactly as heap_deform_tuple does (null bitmap, alignment padding,
+ * 1-byte / 4-byte / external / pglz-compressed varlena forms; LP_REDIRECT line pointers are followed) and the float4s land in
+ * row `node` of out_vecs.  Visibility is not decided here (vs_index_set_visibility). */
+typedef struct vs_heap_attr {  /* pg_attribute.attlen / attalign of one column of the table, in attnum order */
+    int16_t attlen;   /* > 0 fixed length, -1 varlena, -2 cstring */
+    char attalign;    /* 'c' 1, 's' 2, 'i' 4, 'd' 8 */
+} vs_heap_attr;
+typedef struct vs_heap_info {
+    uint32_t n_nodes, heap_blocks, toast_blocks;
+    uint32_t n_inline;            /* vectors found inside their heap tuple                                            */
+    uint32_t n_external;          /* vectors assembled from TOAST chunks                                              */
+    uint32_t n_deleted;           /* index tuples with an invalid heap offset (vacuumed): no row, left zero           */
+    uint32_t n_null;              /* the row exists, its vector column is NULL                                        */
+    uint32_t n_dead_line_pointer; /* the TID names an unused / dead line pointer                                      */
+    uint32_t n_not_found;         /* the TID lies beyond the blocks that were added                                   */
+    uint32_t n_toast_incomplete;  /* an external vector whose chunks did not all arrive                               */
+    uint64_t n_chunks;            /* TOAST chunk rows consumed                                                        */
+} vs_heap_info;
+typedef struct vs_heap vs_heap;
+/* attrs / natts: the table's tuple descriptor; vector_attno: the indexed column (1-based attnum, IndexInfo.ii_IndexAttrNumbers);
+ * heap_tids [n]: ArchivedSbqNode.heap_item_pointer of every node, (block << 16) | offset, as vs_pages_host returns them;
+ * out_vecs [n][out_stride] floats (out_stride >= dim), zeroed here, filled by the calls below; kept by the caller. */
+int vs_heap_open(uint32_t page_size, const vs_heap_attr* attrs, uint32_t natts, uint32_t vector_attno, uint32_t dim,
+                 const uint64_t* heap_tids, uint32_t n, float* out_vecs, uint32_t out_stride, vs_heap** out);
+int vs_heap_add(vs_heap* h, uint32_t first_block, const void* pages, uint32_t n_blocks);        /* heap main fork, in block order */
+int vs_heap_toast_add(vs_heap* h, uint32_t first_block, const void* pages, uint32_t n_blocks);  /* then the TOAST relation's       */
+/* found [n] (may be NULL): 1 where the node's vector was read.  Everything else is counted in info. */
+int vs_heap_finish(vs_heap* h, vs_heap_info* info, uint8_t* found);
+void vs_heap_close(vs_heap* h);
+
 /* The same, decoded ON the device (vs_pages_dev.hip): the blocks are copied to HBM as they are (pinned ring,
  * hipMemcpyAsync), the host only reads the page headers on the way past, and one kernel (a wave per node page) walks the
  * line pointers and rkyv relative pointers and writes codes / neighbor ids / heap tids into the index arrays; label sets

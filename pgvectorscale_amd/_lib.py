@@ -68,6 +68,18 @@ class MetaPage(C.Structure):
         return d
 
 
+class HeapAttr(C.Structure):
+    _fields_ = [("attlen", C.c_int16), ("attalign", C.c_char)]
+
+
+class HeapInfo(C.Structure):
+    _fields_ = [(k, C.c_uint32) for k in ("n_nodes", "heap_blocks", "toast_blocks", "n_inline", "n_external", "n_deleted", "n_null",
+                                          "n_dead_line_pointer", "n_not_found", "n_toast_incomplete")] + [("n_chunks", C.c_uint64)]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
 class PagesInfo(C.Structure):
     _fields_ = [("n_blocks", C.c_uint32), ("n_nodes", C.c_uint32), ("words", C.c_uint32), ("num_neighbors", C.c_uint32),
                 ("has_labels", C.c_uint32), ("n_deleted", C.c_uint32), ("n_label_vals", C.c_uint64),
@@ -134,6 +146,11 @@ SYMBOLS = {
     "vs_pages_read_chain": (_i, [_vp, _u32, _u32, _i, _vp, _sz, C.POINTER(_sz)]),
     "vs_pages_sbq_means": (_i, [_vp, _u32, _u32, _vp, _vp, _u32, C.POINTER(_u32), C.POINTER(_u64)]),
     "vs_pages_close": (None, [_vp]),
+    "vs_heap_open": (_i, [_u32, C.POINTER(HeapAttr), _u32, _u32, _u32, _vp, _u32, _vp, _u32, C.POINTER(_vp)]),
+    "vs_heap_add": (_i, [_vp, _u32, _vp, _u32]),
+    "vs_heap_toast_add": (_i, [_vp, _u32, _vp, _u32]),
+    "vs_heap_finish": (_i, [_vp, C.POINTER(HeapInfo), _vp]),
+    "vs_heap_close": (None, [_vp]),
     "vs_meta_layout_default": (_i, [C.POINTER(MetaLayout)]),
     "vs_meta_page_decode": (_i, [_vp, _sz, C.POINTER(MetaLayout), C.POINTER(MetaPage), _vp, _vp, _vp, _u32]),
     "vs_pages_meta": (_i, [_vp, C.POINTER(MetaLayout), C.POINTER(MetaPage), C.POINTER(IndexDesc), _vp, _vp, _u32]),

@@ -806,7 +806,16 @@ static Caps initial_caps(const vs_index* ix, uint32_t L, uint32_t M) {
         c.f_hl = std::max<uint32_t>(next_pow2_u32(c.f_hl + 1), 64) - 1;
         // overflow table: room for every candidate the worst scan could insert beyond the LDS table
         c.f_gcap = next_pow2_u32(std::min<uint64_t>(std::max<uint64_t>(std::min<uint64_t>(pushes, 4 * typ_ins), 1024), 1u << 22));
-        if (const uint32_t g = env_u32("VS_F_GCAP", 0)) c.f_gcap = next_pow2_u32(std::max<uint32_t>(g, 256));
+        // table-less regime: the tables of the scans in flight (24 per CU x 64 KB = 400 MB at 50M) compete for the 256 MB of
+        // Infinity Cache — half the table is 5 % faster, twice the table 10 % slower (profiles/r03/ab_epoch_*.txt) — so once the
+        // previous batches with this (L, M) have shown what the largest scan inserts, the table is sized for exactly that
+        // (load limit 75 %, a few per cent of slack; a scan that still outgrows it takes the second attempt) instead of the
+        // next power of two
+        if (!lds_table && ix->obs.valid && ix->obs.L == L && ix->obs.M == M && env_u32("VS_F_GCAP_FIT", 1)) {
+            const uint64_t need = (uint64_t)((ix->obs.ins_max * 1.04 + 128) * 4.0 / 3.0) + 64;
+            c.f_gcap = (uint32_t)std::min<uint64_t>(c.f_gcap, std::max<uint64_t>(round_up_u32((uint32_t)std::min<uint64_t>(need, 1u << 22), 256), 1024));
+        }
+        if (const uint32_t g = env_u32("VS_F_GCAP", 0)) c.f_gcap = round_up_u32(std::max<uint32_t>(g, 256), 256);
         c.f_sb = 0;
         while ((1ull << c.f_sb) < (uint64_t)c.f_lh + c.f_gcap) c.f_sb++;
         c.f_hcap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(pushes, c.f_hl), 1u << 22);
@@ -1148,8 +1157,12 @@ static int collect_stats(vs_index* ix, uint32_t nq, uint32_t M, uint32_t rescore
         double sum = 0, mx = 0;
         uint32_t cnt_fast = 0, ov = 0;
         for (uint32_t q = 0; q < nq; ++q) {
-            if (fb[q]) { ov++; continue; }
             const double v = hs[(size_t)q * ST_N + 7];
+            if (fb[q]) {  // (finished by a second attempt: its insert count still tells how big a table the batch needs)
+                ov++;
+                mx = std::max(mx, v);
+                continue;
+            }
             sum += v;
             mx = std::max(mx, v);
             cnt_fast++;

@@ -778,7 +778,7 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
     // latency, finish_insert completes the probe sequence.  Frozen mode (LDS table at its load limit): read-only
     // probe of the LDS table, then insert into the per-scan global overflow table.
     uint32_t* ghash = s.ghash;
-    const uint32_t gmask = s.gcap - 1;
+    const uint32_t gbuckets = s.gcap >> 2;  // (any multiple of four slots: the home bucket is a multiply-shift, not a mask)
     uint32_t nins_g = 0;
     bool g_open = false, region = false;
     // global dedup overflow table: claimed from the pool on first need
@@ -831,7 +831,9 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
     // the same step draw distinct ranks from an LDS counter (lanes of other buckets sharing the counter only waste ranks)
     // and take the rank-th empty slot; a lane whose rank is past the bucket's empties looks at the bucket again.
     const bool gmode = s.lh == 0;  // table-less regime: every id lives in the global table
-    auto ghash_home = [&](uint32_t nid) -> uint32_t { return hash_u32(nid ^ 0x5bd1e995u) & gmask & ~3u; };
+    auto ghash_home = [&](uint32_t nid) -> uint32_t {
+        return (uint32_t)(((uint64_t)hash_u32(nid ^ 0x5bd1e995u) * gbuckets) >> 32) << 2;
+    };
     auto bucket_load = [&](uint32_t b0) -> uint4 { return *reinterpret_cast<const uint4*>(ghash + b0); };
     // v = the bucket at b0 as loaded by the caller (where act).  true where the id was not present before
     auto global_insert = [&](uint32_t nid, bool act, uint32_t b0, uint4 v, uint32_t& slot_out) -> bool {
@@ -847,7 +849,7 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
                     pend = false;
                 } else {
                     em = (g_empty(v.x) ? 1u : 0u) | (g_empty(v.y) ? 2u : 0u) | (g_empty(v.z) ? 4u : 0u) | (g_empty(v.w) ? 8u : 0u);
-                    if (em == 0) b0 = (b0 + 4u) & gmask;
+                    if (em == 0) b0 = b0 + 4u == s.gcap ? 0u : b0 + 4u;
                 }
             }
             const bool want = pend && em != 0;
@@ -1320,7 +1322,7 @@ int launch_search_fast(vs_index* idx, const FastLaunch& s) {
     VS_REQUIRE(((s.hl + 1) & s.hl) == 0 && s.hl >= 63, "fast search: hl must be 2^k - 1 >= 63");
     VS_REQUIRE(s.vr == 8 || (s.vr == 0 && s.vcap >= 64),
                "fast search: visited list must be 8 register pairs or a ring of >= 64 entries");
-    VS_REQUIRE(s.lh % 4 == 0 && (s.lh == 0 || s.lh >= 256) && (s.gcap & (s.gcap - 1)) == 0 && s.gcap >= 256 &&
+    VS_REQUIRE(s.lh % 4 == 0 && (s.lh == 0 || s.lh >= 256) && s.gcap % 4 == 0 && s.gcap >= 256 &&
                    (uint64_t)s.lh + s.gcap <= (1ull << s.sb) && s.hcap >= s.hl && s.gstride % 2 == 0 &&
                    s.gstride >= s.hcap - s.hl + 2,
                "fast search: bad dedup table / spill geometry");

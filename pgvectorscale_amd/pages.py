@@ -12,7 +12,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import IndexDesc, IndexHost, MetaLayout, MetaPage, NodeLayout, PagesInfo, check
+from ._lib import HeapAttr, HeapInfo, IndexDesc, IndexHost, MetaLayout, MetaPage, NodeLayout, PagesInfo, check
 
 BLCKSZ = 8192
 PAGE_SBQ_MEANS, PAGE_META = 7, 8
@@ -53,6 +53,56 @@ def _meta_of(fn, handle, layout):
     check(fn(handle, None if lay is None else C.byref(lay), C.byref(m), C.byref(d), lab.ctypes.data_as(C.c_void_p),
              nodes.ctypes.data_as(C.c_void_p), n))
     return m.as_dict(), d, {int(l): int(v) for l, v in zip(lab, nodes)}
+
+
+class HeapColumn:
+    """The heap's vector column, staged from the pages of the table and its TOAST relation (vs_heap_*): `vecs[node]` = the
+    vector of the heap tuple node's heap TID names — what the reference fetches per rescore candidate."""
+
+    def __init__(self, attrs, vector_attno, dim, heap_tids, page_size=BLCKSZ):
+        """attrs: [(attlen, attalign)] of the table's columns in attnum order; vector_attno 1-based"""
+        self._L = _lib.load()
+        self.page_size = page_size
+        self._attrs = (HeapAttr * len(attrs))(*[HeapAttr(int(l), a.encode()) for l, a in attrs])
+        self._tids = np.ascontiguousarray(heap_tids, np.uint64)
+        self.vecs = np.empty((self._tids.size, dim), np.float32)
+        h = C.c_void_p()
+        check(self._L.vs_heap_open(page_size, self._attrs, len(attrs), vector_attno, dim, self._tids.ctypes.data_as(C.c_void_p),
+                                   self._tids.size, self.vecs.ctypes.data_as(C.c_void_p), dim, C.byref(h)))
+        self.h = h
+        self._nb = [0, 0]
+
+    def _add(self, fn, which, pages, first_block):
+        buf = np.frombuffer(pages, np.uint8)
+        if buf.size % self.page_size:
+            raise ValueError(f"{buf.size} bytes is not a whole number of {self.page_size}-byte pages")
+        nb = buf.size // self.page_size
+        fb = self._nb[which] if first_block is None else first_block
+        check(fn(self.h, fb, buf.ctypes.data_as(C.c_void_p), nb))
+        self._nb[which] += nb
+
+    def add(self, pages, first_block=None):
+        self._add(self._L.vs_heap_add, 0, pages, first_block)
+
+    def toast_add(self, pages, first_block=None):
+        self._add(self._L.vs_heap_toast_add, 1, pages, first_block)
+
+    def finish(self):
+        info = HeapInfo()
+        found = np.zeros(self._tids.size, np.uint8)
+        check(self._L.vs_heap_finish(self.h, C.byref(info), found.ctypes.data_as(C.c_void_p)))
+        return info.as_dict(), found
+
+    def close(self):
+        if self.h:
+            self._L.vs_heap_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class IndexPages:

@@ -228,8 +228,9 @@ def main():
                          "its metric on (50M x 768, L2): the whole index (177 GB) fits one MI355X; the on-device build takes "
                          "about 6 minutes of the run.  --n 10000000 --distance cosine is configs[2], --n 1000000 configs[1]")
     ap.add_argument("--dim", type=int, default=768)
-    ap.add_argument("--nq", type=int, default=131072, help="queries per step per GPU (scans of one launch; the kernel has a serial "
-                    "tail of a few ms per launch, so large batches amortise it)")
+    ap.add_argument("--nq", type=int, default=262144, help="queries per step per GPU (scans of one launch; a launch ends with a tail of "
+                    "its last scans on a half-empty chip, which large batches amortise: 168.3 ms per 262144 scans against 2 x 88.2 ms per "
+                    "131072 at 50M, profiles/r03/ab_nq262144_50m.txt)")
     ap.add_argument("--scan-nq", type=int, default=64, help="queries of the flat SBQ scan (K5) roofline measurement, 0 = skip")
     ap.add_argument("--distance", default="l2", choices=["l2", "cosine", "ip"])
     ap.add_argument("--k", type=int, default=10)
@@ -714,6 +715,7 @@ def main():
                 "frac": round(achieved / 8000.0, 5), "traffic": traffic, "traffic_source": traffic_source,
                 "traffic_other_operating_point": traffic_ref,
                 "alg_bytes_per_launch": int(per_launch), "avg_kernel_ms": round(avg_ms, 4), "launches": s_n,
+                "scans_per_launch": nq, "kernel_ms_per_131072_scans": round(avg_ms * 131072 / max(nq, 1), 4),
                 "alg_bytes_per_query": round(alg_bytes_search / max(ptot.get("queries", 1) - ptot.get("fallback_scans", 0), 1), 1),
                 "timed_over": "the timed steps" if args.pipeline == 1 else
                               f"{args.warmup} sequential warm-up steps (the timed steps overlap two batches: a kernel's duration there "

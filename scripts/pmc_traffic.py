@@ -42,7 +42,13 @@ def main():
     scan_bytes = int(m.group(3))
     scan_fetch = sum(fetch["k_scan_topk"][-3:]) / len(fetch["k_scan_topk"][-3:]) * 1024
     cal = scan_bytes / scan_fetch
-    out = {"n": args.n, "nq": args.nq, "L": args.L, "rescore": args.rescore,
+    import sys
+    sys.path.insert(0, ROOT)
+    from bench import kernel_source_hash
+    # provenance: the sources the counters were collected on (bench.py compares the hash with its own build's) and the commit the
+    # session was launched from (VS_COMMIT: there is no .git on the GPU box)
+    out = {"n": args.n, "nq": args.nq, "L": args.L, "rescore": args.rescore, "dim": 768, "labels": 0,
+           "kernel_source_hash": kernel_source_hash(), "commit": os.environ.get("VS_COMMIT"),
            "fetch_calibration": {"kernel": "k_scan_topk", "known_bytes": scan_bytes, "FETCH_SIZE_bytes": round(scan_fetch),
                                  "factor": round(cal, 4)}}
     for kern in ("k_search_fast", "k_rerank"):
@@ -69,7 +75,8 @@ def main():
         ks["requests_of_128_bytes"] = round(dq + 2 * visits)
         ks["read_bytes_corrected"] = round(ks["FETCH_SIZE_bytes"] + 64 * (dq + 2 * visits))
         ks["hbm_bytes_per_launch"] = ks["read_bytes_corrected"] + ks["WRITE_SIZE_bytes"]
-        ks["algorithmic_bytes_per_launch"] = round(dq * 192 + visits * 200) if True else None
+        ks["algorithmic_bytes_per_launch"] = round(dq * 192 + visits * 200)
+        out["alg_bytes_per_launch"] = ks["algorithmic_bytes_per_launch"]
     out["hbm_bytes_per_launch"] = out.get("k_search_fast", {}).get("hbm_bytes_per_launch")
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     dst = os.path.join(args.dir, "pmc_search_traffic.json")

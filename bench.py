@@ -476,6 +476,8 @@ def main():
         hb = n_batches - 1
         held = ground_truth(qbuf[hb], nh, qkeys[hb])
     setup["ground_truth_s"] = round(time.time() - t0, 3)
+    if not EMU:
+        torch.cuda.empty_cache()  # (the ground truth's temporaries go back to the device: the search workspace needs the room)
     del X
     if NL:
         del node_mask

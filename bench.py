@@ -79,12 +79,13 @@ def graph_cache_path(args, n, dim, seed, bits, R):
 
 
 def kernel_source_hash():
-    """12 hex digits over the kernel / host sources of libvsgpu (what a graph cache and a PMC measurement belong to)"""
+    """12 hex digits over the device sources of libvsgpu and the host code that configures their launches (*.hip, *.h) — what a
+    graph cache and a PMC measurement belong to; the host-only page / heap / broker readers (*.cpp) do not touch a kernel"""
     import hashlib
     h = hashlib.sha1()
     csrc = os.path.join(ROOT, "pgvectorscale_amd", "csrc")
     for f in sorted(os.listdir(csrc)):
-        if f.endswith((".hip", ".h", ".cpp")):
+        if f.endswith((".hip", ".h")):
             h.update(open(os.path.join(csrc, f), "rb").read())
     return h.hexdigest()[:12]
 

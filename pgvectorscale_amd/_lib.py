@@ -184,6 +184,7 @@ SYMBOLS = {
     "vs_broker_search_snapshot": (_i, [_vp, _vp, _vp, _u32, _i, _u32, _u32, _u32, _u32, _vp, _vp, _vp]),
     "vs_broker_snapshot_put": (_i, [_vp, _u32, _vp]),
     "vs_index_snapshot_put": (_i, [_vp, _u32, _vp]),
+    "vs_index_has_neighbor_masks": (_i, [_vp]),
     "vs_index_snapshot_use": (_i, [_vp, _u32, _vp]),
     "vs_broker_get_stats": (_i, [_vp, C.POINTER(BrokerStats)]),
     "vs_broker_destroy": (None, [_vp]),

@@ -305,7 +305,7 @@ extern "C" void vs_index_free(vs_index* ix) {
     (void)hipSetDevice(ix->ctx->device);
     (void)hipStreamSynchronize(ix->ctx->stream);
     void* ptrs[] = {ix->codes, ix->nbrs, ix->tids, ix->vecs, ix->vnorm, ix->vnorm_idx, ix->mean, ix->m2, ix->visible_own,
-                    ix->label_off, ix->label_val, ix->label_mask, ix->label_bit, ix->ls_labels, ix->ls_nodes};
+                    ix->label_off, ix->label_val, ix->label_mask, ix->label_bit, ix->nbr_mask, ix->ls_labels, ix->ls_nodes};
     if (!ix->is_view) {  // (a view shares the arrays of the index it was made from)
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
@@ -326,6 +326,7 @@ static int vs_index_view_impl(vs_index* src, vs_ctx* c, vs_index** out) {
     VS_REQUIRE(src && c && out, "vs_index_view: bad args");
     VS_REQUIRE(c->device == src->ctx->device, "vs_index_view: the context is on device %d, the index on device %d", c->device,
                src->ctx->device);
+    if (src->nbr_mask_valid) VS_HIP(hipStreamSynchronize(src->ctx->stream));  // (derived arrays were filled on the source's stream)
     vs_index* v = new vs_index(*src);  // the pointers and the geometry; the workspace below is this handle's own
     v->ctx = c;
     v->is_view = true;
@@ -602,7 +603,12 @@ extern "C" int vs_index_array(const vs_index* ix, int which, void** p, uint32_t*
     uint32_t s = 1;
     switch (which) {
         case VS_ARR_CODES: *p = ix->codes; s = ix->code_stride; break;
-        case VS_ARR_NBRS: *p = ix->nbrs; s = ix->nbr_stride; break;
+        case VS_ARR_NBRS:  // (the caller may write through this pointer: whatever was derived from the neighbor lists is stale;
+            // a caller that keeps the pointer and writes again later must ask for it again before the next scan)
+            const_cast<vs_index*>(ix)->nbr_mask_valid = false;
+            *p = ix->nbrs;
+            s = ix->nbr_stride;
+            break;
         case VS_ARR_TIDS: *p = ix->tids; break;
         case VS_ARR_VECS: *p = ix->vecs; s = ix->vec_stride; break;
         case VS_ARR_MEAN: *p = ix->mean; break;

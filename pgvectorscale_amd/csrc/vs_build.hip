@@ -852,6 +852,7 @@ static int vs_build_graph_impl(vs_index* ix, uint32_t search_list_size, double m
     VS_REQUIRE(max_alpha >= 1.0 && max_alpha <= 5.0, "vs_build_graph: max_alpha outside [1,5]");
     VS_HIP(hipSetDevice(ix->ctx->device));
     BuildBufs B;
+    ix->nbr_mask_valid = false;  // (the neighbor lists are about to change: what was derived from them is stale)
     int r = build_graph_impl(ix, search_list_size, max_alpha, batch_max, B);
     (void)hipStreamSynchronize(ix->ctx->stream);
     B.free_all();

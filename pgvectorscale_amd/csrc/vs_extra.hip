@@ -513,11 +513,51 @@ __global__ __launch_bounds__(256) void k_label_masks(const uint32_t* __restrict_
     mask[i] = m;
 }
 
+// nbr_mask[i][j] = label_mask[nbrs[i][j]] (0 past the end of the list): what a label-filtered visit needs of its fresh neighbors,
+// laid out next to the neighbor row so that one coalesced load brings all of it
+__global__ __launch_bounds__(256) void k_nbr_masks(const uint32_t* __restrict__ nbrs, uint32_t nbr_stride, uint32_t n,
+                                                   const uint64_t* __restrict__ label_mask, uint64_t* __restrict__ out) {
+    const uint64_t total = (uint64_t)n * nbr_stride;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t v = nbrs[i];
+        out[i] = v < n ? label_mask[v] : 0ull;
+    }
+}
+
+extern "C" int vs_index_has_neighbor_masks(const vs_index* ix) { return ix && ix->nbr_mask_valid ? 1 : 0; }
+
+int vs_refresh_neighbor_masks(vs_index* ix) {
+    if (ix->nbr_mask_valid || ix->is_view || !ix->label_mask || !ix->nbrs || ix->d.n == 0) return VS_OK;
+    if (const char* e = getenv("VS_F_NBRMASK"))  // (measurement switch: 0 = per-neighbor mask loads)
+        if (*e == '0') return VS_OK;
+    vs_ctx* c = ix->ctx;
+    const size_t bytes = (size_t)ix->d.n * ix->nbr_stride * 8;
+    if (!ix->nbr_mask) {
+        if (ix->nbr_mask_tried) return VS_OK;
+        ix->nbr_mask_tried = true;
+        size_t free_b = 0, total_b = 0;
+        // a cache, not a requirement: it is only built when it leaves the search workspace plenty of room
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 2 * bytes + total_b / 16) return VS_OK;
+        if (hipMalloc(&ix->nbr_mask, bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            ix->nbr_mask = nullptr;
+            return VS_OK;
+        }
+    }
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)ix->d.n * ix->nbr_stride + 255) / 256, 1u << 20);
+    hipLaunchKernelGGL(k_nbr_masks, dim3(grid), dim3(256), 0, c->stream, ix->nbrs, ix->nbr_stride, ix->d.n, ix->label_mask, ix->nbr_mask);
+    VS_HIP(hipGetLastError());
+    ix->nbr_mask_valid = true;  // (same stream as the searches that follow: ordered)
+    return VS_OK;
+}
+
 // When the index uses at most 64 DISTINCT labels (any smallint values), every node's label set becomes a 64-bit mask through a
 // per-index label -> bit table, and the overlap test of a scan is one load and an AND; with more distinct labels the scans keep
 // the sorted-merge test on the CSR (LabelSetView::overlaps, AM/labels/mod.rs:124-142).
 int vs_refresh_label_masks(vs_index* ix) {
     vs_ctx* c = ix->ctx;
+    ix->nbr_mask_valid = false;  // (derived from the masks below)
+    ix->nbr_mask_tried = false;
     if (ix->label_mask) {
         VS_HIP(hipFree(ix->label_mask));
         ix->label_mask = nullptr;

@@ -140,6 +140,11 @@ struct vs_index {
     int16_t* label_val = nullptr;
     uint64_t* label_mask = nullptr;  // per node: bit label_bit[l] set <=> label l in its set; only when the index uses <= 64 distinct labels
     uint8_t* label_bit = nullptr;    // [65536] label (as u16) -> its bit, 0xFF = the label occurs nowhere in the index
+    // [n][nbr_stride] label masks of every node's neighbors in list order (a cache derived from nbrs + label_mask for the
+    // label-filtered scans; rebuilt lazily by vs_refresh_neighbor_masks when nbr_mask_valid is false)
+    uint64_t* nbr_mask = nullptr;
+    bool nbr_mask_valid = false;
+    bool nbr_mask_tried = false;     // the array did not fit the device: the scans load the masks per neighbor
     uint64_t n_label_vals = 0;
     int16_t* ls_labels = nullptr;
     uint32_t* ls_nodes = nullptr;
@@ -153,6 +158,7 @@ int devbuf_reserve(vs_ctx* ctx, DevBuf& b, size_t bytes);
 // row-wise staging through the pinned ring (device rows may be wider than host rows) / neighbor-list validation
 int vs_upload_rows(vs_ctx* c, void* dst, size_t dev_row_bytes, const void* src, size_t host_row_bytes, size_t copy_bytes, size_t rows);
 int vs_validate_graph(vs_index* ix);
+int vs_refresh_neighbor_masks(vs_index* ix);  // (re)derives nbr_mask when it is stale (no-op for a view or when it does not fit)
 int vs_refresh_label_masks(vs_index* ix);  // (re)derives label_mask / label_bit from the label CSR, or drops them when the index uses more than 64 distinct labels
 void devbuf_free(DevBuf& b);
 

@@ -45,6 +45,7 @@ struct FastArgs {
     const int16_t* label_val;
     const uint64_t* label_mask;  // may be null
     const uint8_t* label_bit;    // with label_mask: [65536] label -> bit (0xFF: in no node's set)
+    const uint64_t* nbr_mask;    // may be null: [n][nbr_stride] the label masks of every node's neighbors, in list order
     const int16_t* ls_labels;
     const uint32_t* ls_nodes;
     uint32_t code_stride, nbr_stride, R, n, n_ls, default_start;
@@ -964,6 +965,10 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
     // root (asked for as soon as its distance is known; the pushes / pop / visited insert cover the latency).
     uint32_t pfa_node = VS_INVALID_NODE, pfa_val = VS_INVALID_NODE, pfa_h = 0xFFFFFFFFu;  // (_h: the node's dedup handle)
     uint32_t pfb_node = VS_INVALID_NODE, pfb_val = VS_INVALID_NODE, pfb_h = 0xFFFFFFFFu;
+    // label-filtered scans on an index with label masks: the masks of a node's neighbors sit next to its neighbor row (one
+    // coalesced 8 x R byte load with the row) instead of one random 8-byte load per fresh neighbor
+    const uint64_t* const nbr_mask = FULL ? a.nbr_mask : nullptr;
+    uint64_t pfa_m = 0, pfb_m = 0;
 
     // ---- TSVResponseIterator::next until M rows are emitted (AM/scan.rs:210-242), flattened: every iteration is
     // either one visit_closest() expansion (greedy_search_iterate, AM/graph/mod.rs:357-385) or one consume() ----
@@ -1025,6 +1030,7 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
         uint32_t node_v = hit_a ? pfa_node : pfb_node;
         if (!hit) node_v = node_load(th);
         uint32_t row0 = hit_a ? pfa_val : pfb_val;
+        uint64_t rowm = hit_a ? pfa_m : pfb_m;
         uint64_t vtid = 1;
         uint32_t vvis = 1;
         bool early = false;
@@ -1052,7 +1058,10 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
             if (visible) vvis = visible[node];
         }
         const uint32_t* nrow = a.nbrs + (size_t)node * a.nbr_stride;
-        if (!hit) row0 = ((uint32_t)lane < a.R) ? nrow[lane] : VS_INVALID_NODE;
+        if (!hit) {
+            row0 = ((uint32_t)lane < a.R) ? nrow[lane] : VS_INVALID_NODE;
+            if (nbr_mask) rowm = ((uint32_t)lane < a.R) ? nbr_mask[(size_t)node * a.nbr_stride + lane] : 0ull;
+        }
         lap(0);
         if (vis.len + 1 > vis.capacity()) {
             if (BUILD) vis.len = vis.capacity() - 1;  // build mode keeps the closest entries as prune candidates
@@ -1113,7 +1122,10 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
             st_reads += (uint32_t)__popcll(__ballot(fresh));  // SbqNode::read(neighbor)
             // label filter: query.labels.overlaps(node.labels) (AM/labels/mod.rs:124-142)
             bool pass = fresh;
-            if (has_label_filter && a.label_mask) {
+            if (has_label_filter && nbr_mask) {
+                const uint64_t nm = c0 == 0 ? rowm : ((slotidx < a.R) ? nbr_mask[(size_t)node * a.nbr_stride + slotidx] : 0ull);
+                pass = fresh && (nm & qmask) != 0;
+            } else if (has_label_filter && a.label_mask) {
                 if (fresh) pass = (a.label_mask[nid] & qmask) != 0;
             } else if (has_label_filter && fresh) {
                 const uint32_t lb = a.label_off[nid], le = a.label_off[nid + 1];
@@ -1158,6 +1170,7 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
                         pfa_node = rfl(root_node_v);
                         pfa_h = root_after & smask;
                         pfa_val = ((uint32_t)lane < a.R) ? a.nbrs[(size_t)pfa_node * a.nbr_stride + lane] : VS_INVALID_NODE;
+                        if (nbr_mask) pfa_m = ((uint32_t)lane < a.R) ? nbr_mask[(size_t)pfa_node * a.nbr_stride + lane] : 0ull;
                     }
                 }
                 const uint32_t d = ham_row_reg<NCH, QL>(crow, qv, qc_l, l4, a.code_stride, valid, stream_rows);
@@ -1188,6 +1201,7 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
                     pfb_node = best_node;  // a candidate of this visit: its id is known without a table lookup
                     pfb_h = best & smask;
                     pfb_val = ((uint32_t)lane < a.R) ? a.nbrs[(size_t)pfb_node * a.nbr_stride + lane] : VS_INVALID_NODE;
+                    if (nbr_mask) pfb_m = ((uint32_t)lane < a.R) ? nbr_mask[(size_t)pfb_node * a.nbr_stride + lane] : 0ull;
                 }
             }
             // insert_neighbor in list order (AM/graph/mod.rs:144-147)
@@ -1203,6 +1217,7 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
                 pfa_node = rfl(root_node_v);
                 pfa_h = root_after & smask;
                 pfa_val = ((uint32_t)lane < a.R) ? a.nbrs[(size_t)pfa_node * a.nbr_stride + lane] : VS_INVALID_NODE;
+                if (nbr_mask) pfa_m = ((uint32_t)lane < a.R) ? nbr_mask[(size_t)pfa_node * a.nbr_stride + lane] : 0ull;
             }
         }
         if (!pfb_issued) {
@@ -1308,6 +1323,12 @@ int launch_search_fast(vs_index* idx, const FastLaunch& s) {
     a.label_val = idx->label_val;
     a.label_mask = idx->label_mask;
     a.label_bit = idx->label_bit;
+    a.nbr_mask = nullptr;
+    if (s.qlabel_off && idx->label_mask && !s.build) {  // label-filtered scans: the neighbors' masks next to the neighbor rows
+        VS_TRY(vs_refresh_neighbor_masks(idx));
+        const char* off = getenv("VS_F_NBRMASK");
+        if (idx->nbr_mask_valid && !(off && *off == '0')) a.nbr_mask = idx->nbr_mask;
+    }
     a.ls_labels = idx->ls_labels;
     a.ls_nodes = idx->ls_nodes;
     a.code_stride = idx->code_stride;

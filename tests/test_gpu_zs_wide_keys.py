@@ -104,7 +104,7 @@ def test_label_masks_for_any_label_values(gpu_ctx, oracle, monkeypatch):
     ix = ti.upload(gpu_ctx)
     q = ti.queries(18, seed=2)
     keys = [[-300], [64, 32767], [0], [5], [-1, 63], [-32768, 64], [32767], [-300, -1, 0, 63, 64, 32767], [1, 2, 3]] * 2
-    for regime in ({}, {"VS_F_LDS_MAX_INS": "0"}, {"VS_FAST": "0"}):
+    for regime in ({}, {"VS_F_LDS_MAX_INS": "0"}, {"VS_F_NBRMASK": "0"}, {"VS_FAST": "0"}):
         for k_, v_ in regime.items():
             monkeypatch.setenv(k_, v_)
         gi, _, gd, gst = ix.search_batch(q, search_list_size=25, rescore=10, k=10, qlabels=keys)
@@ -116,4 +116,19 @@ def test_label_masks_for_any_label_values(gpu_ctx, oracle, monkeypatch):
         for k_ in regime:
             monkeypatch.delenv(k_)
     assert (gi[3] == 0xFFFFFFFF).all() and (gi[8] == 0xFFFFFFFF).all()  # labels nobody carries
+    assert ix._L.vs_index_has_neighbor_masks(ix.h) == 1  # the neighbors' masks were cached next to the neighbor rows and used
+    # a change of the neighbor lists through the raw array makes the cache stale: it is rebuilt before the next labeled scan
+    from pgvectorscale_amd import _lib
+    ptr, stride = ix.array(_lib.ARR_NBRS)
+    assert ix._L.vs_index_has_neighbor_masks(ix.h) == 0
+    row = np.full((1, stride), 0xFFFFFFFF, np.uint32)  # node 0 loses its neighbors
+    gpu = ix.ctx
+    gpu.upload(ptr, row)
+    ti.nbrs[0, :] = 0xFFFFFFFF
+    ti.oracle = O.OracleIndex(codes=ti.codes, nbrs=ti.nbrs, heap_tids=ti.tids, vecs=ti.vecs, mean=ti.mean, m2=ti.m2, count=ti.count,
+                              bits=ti.bits, dim_index=ti.dim_index, num_neighbors=ti.R, distance_type=ti.distance,
+                              default_start=ti.start, label_off=ti.label_off, label_val=ti.label_val, label_starts=ti.label_starts)
+    gi, _, _, _ = ix.search_batch(q, search_list_size=25, rescore=10, k=10, qlabels=keys)
+    oi, _, _ = ti.oracle.search_batch(q, L=25, rescore=10, k=10, qlabels=keys)
+    assert (gi == oi).all() and ix._L.vs_index_has_neighbor_masks(ix.h) == 1
     ix.close()

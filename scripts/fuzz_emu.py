@@ -69,6 +69,14 @@ def gettuple_mirror(ix, oracle, q, keys, L, rescore, rng, where, exact_dist):
                 else:
                     assert close(r[2], o[2]), f"{where}: gettuple distance {r[2]} vs {o[2]}"
                 got += 1
+                if got in (1, 2, 9, 33) or got % 61 == 0:  # the cursor's GreedySearchStats after this many amgettuple calls
+                    gs, os_ = scan.stats(), osc.stats()
+                    for c in ("visited_nodes", "candidate_nodes", "quantized_distance_comparisons", "full_distance_comparisons",
+                              "node_reads", "node_heap_reads", "next_calls"):
+                        assert gs[c] == os_[c], f"{where}: cursor counter {c} after {got} rows of scan {rnd}: {gs[c]} != {os_[c]}"
+            gs, os_ = scan.stats(), osc.stats()
+            for c in ("visited_nodes", "quantized_distance_comparisons", "full_distance_comparisons", "next_calls"):
+                assert gs[c] == os_[c], f"{where}: cursor counter {c} at the end of scan {rnd}: {gs[c]} != {os_[c]}"
     finally:
         scan.endscan()
 

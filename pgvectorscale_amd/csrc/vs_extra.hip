@@ -528,8 +528,12 @@ extern "C" int vs_index_has_neighbor_masks(const vs_index* ix) { return ix && ix
 
 int vs_refresh_neighbor_masks(vs_index* ix) {
     if (ix->nbr_mask_valid || ix->is_view || !ix->label_mask || !ix->nbrs || ix->d.n == 0) return VS_OK;
-    if (const char* e = getenv("VS_F_NBRMASK"))  // (measurement switch: 0 = per-neighbor mask loads)
-        if (*e == '0') return VS_OK;
+    // off by default: at 5M x 1536 the cache bought 0.6 % (62.6 against 63.0 ms per 131072 scans, profiles/r03/s6_nbrmask_5m_summary.txt —
+    // the 40 MB of node masks are cache resident there anyway) for 8 x nbr_stride bytes per node; VS_F_NBRMASK=1 builds and uses it
+    {
+        const char* e = getenv("VS_F_NBRMASK");
+        if (!e || *e != '1') return VS_OK;
+    }
     vs_ctx* c = ix->ctx;
     const size_t bytes = (size_t)ix->d.n * ix->nbr_stride * 8;
     if (!ix->nbr_mask) {

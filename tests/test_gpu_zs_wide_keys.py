@@ -104,7 +104,7 @@ def test_label_masks_for_any_label_values(gpu_ctx, oracle, monkeypatch):
     ix = ti.upload(gpu_ctx)
     q = ti.queries(18, seed=2)
     keys = [[-300], [64, 32767], [0], [5], [-1, 63], [-32768, 64], [32767], [-300, -1, 0, 63, 64, 32767], [1, 2, 3]] * 2
-    for regime in ({}, {"VS_F_LDS_MAX_INS": "0"}, {"VS_F_NBRMASK": "0"}, {"VS_FAST": "0"}):
+    for regime in ({}, {"VS_F_LDS_MAX_INS": "0"}, {"VS_F_NBRMASK": "1"}, {"VS_F_NBRMASK": "1", "VS_F_LDS_MAX_INS": "0"}, {"VS_FAST": "0"}):
         for k_, v_ in regime.items():
             monkeypatch.setenv(k_, v_)
         gi, _, gd, gst = ix.search_batch(q, search_list_size=25, rescore=10, k=10, qlabels=keys)
@@ -117,6 +117,7 @@ def test_label_masks_for_any_label_values(gpu_ctx, oracle, monkeypatch):
             monkeypatch.delenv(k_)
     assert (gi[3] == 0xFFFFFFFF).all() and (gi[8] == 0xFFFFFFFF).all()  # labels nobody carries
     assert ix._L.vs_index_has_neighbor_masks(ix.h) == 1  # the neighbors' masks were cached next to the neighbor rows and used
+    monkeypatch.setenv("VS_F_NBRMASK", "1")
     # a change of the neighbor lists through the raw array makes the cache stale: it is rebuilt before the next labeled scan
     from pgvectorscale_amd import _lib
     ptr, stride = ix.array(_lib.ARR_NBRS)

@@ -25,7 +25,11 @@ head -8 $O/kernel_stats_50m.csv
 timeout 1500 bash scripts/pmc_traffic.sh 50000000 $NQ $L $S /tmp/g 2>&1 | tail -30 > $O/pmc_traffic.log
 cp gpurun_out/pmc_search_traffic.json $O/pmc_search_traffic_50m.json
 rm -f /tmp/g.*
-timeout 1500 python bench.py --n 20000000 --dim 1536 --distance cosine --labels 32 --steps 8 --warmup 2 --graph-cache none > $O/bench_cfg5.json 2> $O/bench_cfg5.err
+timeout 1500 python bench.py --n 20000000 --dim 1536 --distance cosine --labels 32 --steps 8 --warmup 2 --graph-cache /tmp/g5 > $O/bench_cfg5.json 2> $O/bench_cfg5.err
+VS_F_NBRMASK=1 timeout 900 python bench.py --n 20000000 --dim 1536 --distance cosine --labels 32 --steps 8 --warmup 2 --graph-cache /tmp/g5 --skip-cpu --scan-nq 0 --pcie-steps 0 > $O/bench_cfg5_nbrmask1.json 2> $O/bench_cfg5_nbrmask1.err
+rm -f /tmp/g5.*
+timeout 600 python scripts/fuzz_emu.py --gpu --seconds 200 --seed 777 2>&1 | tail -2 | tee $O/fuzz_gpu.txt
+timeout 600 python scripts/cursor_latency.py --n 10000000 2>&1 | grep -v amdgpu.ids | tee $O/cursor_latency_10m.txt
 timeout 600 python bench.py --n 1000000 --steps 20 --warmup 5 --graph-cache none > $O/bench_cfg2.json 2> $O/bench_cfg2.err
 timeout 900 python bench.py --n 10000000 --distance cosine --steps 10 --warmup 3 --graph-cache none > $O/bench_cfg3.json 2> $O/bench_cfg3.err
 timeout 900 python bench.py --n 10000000 --corpus-kind mid --steps 10 --warmup 3 --graph-cache none > $O/bench_10m_mid.json 2> $O/bench_10m_mid.err

@@ -225,6 +225,12 @@ typedef struct vs_pages_info {
 typedef struct vs_pages vs_pages; /* reader over the main fork of one diskann index relation */
 /* has_labels = MetaPage.has_labels (selects LabeledSbqNode); layout NULL = vs_node_layout_default; threads 0 = all cores (<= 32) */
 int vs_pages_open(uint32_t page_size, int has_labels, const vs_node_layout* layout, uint32_t threads, vs_pages** out);
+/* `plain` storage (PageType::Node pages of PlainNode items, AM/plain/node.rs:15-22): the same reader, with vs_pages_info.words =
+ * the dimensions of PlainNode.vector and vs_index_host.vecs = those vectors (the cosine-normalised index slice the graph
+ * distances are computed on, AM/plain/storage.rs:239-247) instead of codes; no labels (AM/plain/storage.rs:262).  layout NULL =
+ * vs_plain_layout_default (off_bq_vector names the vector field, off_labels is unused). */
+int vs_plain_layout_default(vs_node_layout* out);
+int vs_pages_open_plain(uint32_t page_size, const vs_node_layout* layout, uint32_t threads, vs_pages** out);
 /* append blocks first_block .. first_block+n_blocks-1 (must continue where the previous call stopped; the bytes are
  * not referenced after the call returns).  A failing call leaves the reader unchanged. */
 int vs_pages_add(vs_pages* p, uint32_t first_block, const void* pages, uint32_t n_blocks);

@@ -245,6 +245,69 @@ def rkyv_sbq_node(heap_ptr, code, nbr_ptrs, labels=None, layout=DEFAULT_NODE_LAY
     return bytes(s.b)
 
 
+DEFAULT_PLAIN_LAYOUT = (32, 24, 0, 16, None)  # root size, heap_item_pointer, vector, neighbor_index_pointers, (no labels)
+
+
+def rkyv_plain_node(heap_ptr, vector, nbr_ptrs, layout=DEFAULT_PLAIN_LAYOUT):
+    """to_bytes(PlainNode {vector: Vec<f32>, pq_vector: Vec<u8>, neighbor_index_pointers: Vec<ItemPointer>, heap_item_pointer})
+    (AM/plain/node.rs:15-22): the vector's floats, the (always empty) pq_vector, the neighbor ItemPointers, then the 32-byte root"""
+    s = _Ser()
+    p_vec = s.align(4)
+    s.write(np.asarray(vector, "<f4").tobytes())
+    p_pq = s.align(1)
+    p_nbr = s.align(4)
+    s.write(b"".join(rkyv_item_pointer(b, o) for (b, o) in nbr_ptrs))
+    root = s.align(4)
+    size, o_heap, o_vec, o_nbr, _ = layout
+    s.write(b"\0" * size)
+    o_pq = next(o for o in (0, 8, 16, 24) if o not in (o_heap, o_vec, o_nbr))
+    s.b[root + o_heap:root + o_heap + 8] = rkyv_item_pointer(*heap_ptr)
+    s.b[root + o_vec:root + o_vec + 8] = _vec_field(root + o_vec, p_vec, len(vector))
+    s.b[root + o_pq:root + o_pq + 8] = _vec_field(root + o_pq, p_pq, 0)
+    s.b[root + o_nbr:root + o_nbr + 8] = _vec_field(root + o_nbr, p_nbr, len(nbr_ptrs))
+    return bytes(s.b)
+
+
+def write_plain_index(*, vectors, nbrs, heap_tids, num_neighbors=None, meta=None, layout=DEFAULT_PLAIN_LAYOUT):
+    """a `plain` storage index relation: block 0 = Meta chain, PlainNode items on PageType::Node pages written through a Tape
+    (AM/plain/node.rs:66-70), neighbor lists patched in place afterwards as the reference's build does"""
+    n, D = vectors.shape
+    R = num_neighbors or nbrs.shape[1]
+    rel = Relation()
+    mw = ChainTapeWriter(rel, PT_META)
+    assert mw.write(rkyv_meta_header()) == (0, 1)
+    body = b"\x00" * 120 if meta is None else rkyv_meta_page(**dict(meta, default_start=None, labeled_starts=None))
+    assert mw.write(body) == (0, 2)
+    tape = Tape(rel, PT_NODE)
+    empty = [(INVALID_BLOCK, INVALID_OFFSET)] * R
+    ptrs = []
+    for i in range(n):
+        tid = int(heap_tids[i])
+        ptrs.append(tape.write(rkyv_plain_node((tid >> 16, tid & 0xFFFF), vectors[i], empty, layout)))
+    for i in range(n):
+        blk, off = ptrs[i]
+        s, l = rel.item_span(blk, off)
+        page = rel.pages[blk]
+        fld = s + l - layout[0] + layout[3]
+        rel_off, cnt = struct.unpack_from("<iI", page, fld)
+        assert cnt == R
+        at = fld + rel_off
+        for j in range(R):
+            v = int(nbrs[i, j]) if j < nbrs.shape[1] else INVALID_BLOCK
+            if v == INVALID_BLOCK:
+                break
+            page[at + 8 * j:at + 8 * j + 8] = rkyv_item_pointer(*ptrs[v])
+    if meta is not None:
+        final = dict(meta)
+        ds = final.pop("default_start", None)
+        final.pop("labeled_starts", None)
+        body = rkyv_meta_page(default_start=None if ds is None else ptrs[ds], **final)
+        again = ChainTapeWriter.reinit(rel, PT_META, 0)
+        assert again.write(rkyv_meta_header()) == (0, 1)
+        assert again.write(body) == (0, 2)
+    return WrittenIndex(rel, ptrs, None, False, layout)
+
+
 def rkyv_sbq_means(count, mean, m2):
     """to_bytes(SbqMeans {count: u64, means: Vec<f32>, m2: Vec<f32>}) (AM/sbq/mod.rs:62-69)"""
     s = _Ser()

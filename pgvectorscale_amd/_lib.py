@@ -138,6 +138,8 @@ SYMBOLS = {
     "vs_index_mark_deleted": (_i, [_vp, _vp, _u32]),
     "vs_node_layout_default": (_i, [_i, C.POINTER(NodeLayout)]),
     "vs_pages_open": (_i, [_u32, _i, C.POINTER(NodeLayout), _u32, C.POINTER(_vp)]),
+    "vs_pages_open_plain": (_i, [_u32, C.POINTER(NodeLayout), _u32, C.POINTER(_vp)]),
+    "vs_plain_layout_default": (_i, [C.POINTER(NodeLayout)]),
     "vs_pages_add": (_i, [_vp, _u32, _vp, _u32]),
     "vs_pages_finish": (_i, [_vp, C.POINTER(PagesInfo)]),
     "vs_pages_host": (_i, [_vp, C.POINTER(IndexHost)]),

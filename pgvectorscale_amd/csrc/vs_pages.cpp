@@ -169,6 +169,8 @@ void parallel_for(uint32_t threads, uint64_t n, F&& fn) {
 struct vs_pages {
     uint32_t page_size = VS_BLCKSZ;
     bool has_labels = false;
+    bool plain = false;  // `plain` storage: PageType::Node pages of PlainNode items (AM/plain/node.rs:15-22); W = dimensions, pvecs instead of codes
+    std::vector<float> pvecs;  // [n][W] PlainNode.vector
     vs_node_layout lay{};
     uint32_t threads = 1;
     bool finished = false;
@@ -246,6 +248,26 @@ int vs_pages_open(uint32_t page_size, int has_labels, const vs_node_layout* layo
     return VS_OK;
 }
 
+int vs_plain_layout_default(vs_node_layout* out) {
+    if (!out) return fail("vs_plain_layout_default: null output");
+    // declaration order of PlainNode (AM/plain/node.rs:15-22): vector, pq_vector, neighbor_index_pointers, heap_item_pointer
+    out->root_size = 32;
+    out->off_bq_vector = 0;  // (the field that holds the node's vector: ArchivedVec<f32>)
+    out->off_neighbor_index_pointers = 16;
+    out->off_heap_item_pointer = 24;
+    out->off_labels = 0xFFFFFFFFu;  // plain storage carries no labels (AM/plain/storage.rs:262)
+    return VS_OK;
+}
+
+int vs_pages_open_plain(uint32_t page_size, const vs_node_layout* layout, uint32_t threads, vs_pages** out) {
+    vs_node_layout lay;
+    if (layout) lay = *layout;
+    else vs_plain_layout_default(&lay);
+    int rc = vs_pages_open(page_size, 0, &lay, threads, out);
+    if (rc == VS_OK) (*out)->plain = true;
+    return rc;
+}
+
 void vs_pages_close(vs_pages* p) { delete p; }
 
 int vs_pages_add(vs_pages* p, uint32_t first_block, const void* pages, uint32_t n_blocks) {
@@ -277,7 +299,7 @@ int vs_pages_add(vs_pages* p, uint32_t first_block, const void* pages, uint32_t 
             l_new++;
         else {
             l_by_type[v.type]++;
-            if (v.type == VS_PAGE_SBQ_NODE) l_cnt[b] = v.n_items;
+            if (v.type == (p->plain ? VS_PAGE_NODE : VS_PAGE_SBQ_NODE)) l_cnt[b] = v.n_items;
         }
         l_base[b] = (uint32_t)n1;
         l_type[b] = (int8_t)v.type;
@@ -322,10 +344,11 @@ int vs_pages_add(vs_pages* p, uint32_t first_block, const void* pages, uint32_t 
             const uint32_t root = len - lay.root_size;
             const uint8_t* f;
             uint32_t w, r;
-            if (!archived_vec(it, len, root + lay.off_bq_vector, 8, f, w, err) ||
+            if (!archived_vec(it, len, root + lay.off_bq_vector, p->plain ? 4 : 8, f, w, err) ||
                 !archived_vec(it, len, root + lay.off_neighbor_index_pointers, 8, f, r, err))
                 return fail("block %u item 1: %s", first_block + b, err.c_str());
-            if (w == 0 || w > 1024) return fail("block %u item 1: bq_vector of %u words", first_block + b, w);
+            if (w == 0 || w > (p->plain ? 16000u : 1024u))
+                return fail("block %u item 1: %s of %u %s", first_block + b, p->plain ? "vector" : "bq_vector", w, p->plain ? "dimensions" : "words");
             if (r == 0 || r > 4096) return fail("block %u item 1: %u neighbor slots", first_block + b, r);
             p->W = w;
             p->R = r;
@@ -334,7 +357,8 @@ int vs_pages_add(vs_pages* p, uint32_t first_block, const void* pages, uint32_t 
     }
     const uint32_t W = p->W, R = p->R;
     try {
-        p->codes.resize((size_t)n1 * W);
+        if (p->plain) p->pvecs.resize((size_t)n1 * W);
+        else p->codes.resize((size_t)n1 * W);
         p->nbr_raw.resize((size_t)n1 * R);
         p->tids.resize(n1);
         if (p->has_labels) p->label_off.resize(n1 + 1, 0);
@@ -382,9 +406,10 @@ int vs_pages_add(vs_pages* p, uint32_t first_block, const void* pages, uint32_t 
             // bq_vector
             const uint8_t* f;
             uint32_t c;
-            if (!archived_vec(it, len, root + lay.off_bq_vector, 8, f, c, e)) return report(blk, off, e);
-            if (c != W) return report(blk, off, "bq_vector length differs from the index's code width");
-            memcpy(&p->codes[node * W], f, (size_t)W * 8);
+            if (!archived_vec(it, len, root + lay.off_bq_vector, p->plain ? 4 : 8, f, c, e)) return report(blk, off, e);
+            if (c != W) return report(blk, off, p->plain ? "vector length differs from the index's dimensions" : "bq_vector length differs from the index's code width");
+            if (p->plain) memcpy(&p->pvecs[node * W], f, (size_t)W * 4);  // PlainNode.vector (AM/plain/node.rs:18)
+            else memcpy(&p->codes[node * W], f, (size_t)W * 8);
             // neighbor_index_pointers: the list ends at the first InvalidBlockNumber (AM/sbq/node.rs:260-285)
             if (!archived_vec(it, len, root + lay.off_neighbor_index_pointers, 8, f, c, e)) return report(blk, off, e);
             if (c != R) return report(blk, off, "neighbor slot count differs from the index's num_neighbors");
@@ -408,7 +433,8 @@ int vs_pages_add(vs_pages* p, uint32_t first_block, const void* pages, uint32_t 
         deleted += del;
     });
     auto rollback = [&]() {  // leave the reader as it was before this call
-        p->codes.resize((size_t)n0 * W);
+        if (p->plain) p->pvecs.resize((size_t)n0 * W);
+        else p->codes.resize((size_t)n0 * W);
         p->nbr_raw.resize((size_t)n0 * R);
         p->tids.resize(n0);
         if (p->has_labels) p->label_off.resize(n0 + 1);
@@ -721,9 +747,14 @@ int vs_pages_meta(const vs_pages* p, const vs_meta_layout* layout, vs_meta_page*
         if (p->n && !p->headers_only) {
             if ((uint32_t)p->has_labels != m.has_labels)
                 return fail("the reader was opened with has_labels = %d, the MetaPage says %u", p->has_labels, m.has_labels);
+            if ((desc->storage_type == VS_STORAGE_PLAIN) != p->plain)
+                return fail("the MetaPage says storage type %u, the reader was opened for %s nodes", m.storage_type, p->plain ? "plain" : "SBQ");
             if (desc->storage_type == VS_STORAGE_SBQ && (p->W != desc->words || p->R != m.num_neighbors))
                 return fail("SbqNode items hold %u-word codes and %u neighbor slots, the MetaPage implies %u and %u", p->W, p->R,
                             desc->words, m.num_neighbors);
+            if (desc->storage_type == VS_STORAGE_PLAIN && (p->W != m.num_dimensions_to_index || p->R != m.num_neighbors))
+                return fail("PlainNode items hold %u-dimensional vectors and %u neighbor slots, the MetaPage implies %u and %u", p->W, p->R,
+                            m.num_dimensions_to_index, m.num_neighbors);
         }
         if (m.has_start_nodes) {
             r = vs_pages_node_of(p, m.default_start_block, m.default_start_offset, &desc->default_start);
@@ -772,8 +803,10 @@ int vs_pages_finish(vs_pages* p, vs_pages_info* info) {
             p->meta_version = rd32(hdr + 4);
             if (p->meta_magic != kTsvMagic) return fail("meta page magic %u is not %u", p->meta_magic, kTsvMagic);
         }
-        if (p->n == 0 && p->by_type[VS_PAGE_NODE] > 0)
-            return fail("the relation holds `plain` storage nodes (PageType::Node); this path reads memory_optimized (SBQ) indexes");
+        if (!p->plain && p->n == 0 && p->by_type[VS_PAGE_NODE] > 0)
+            return fail("the relation holds `plain` storage nodes (PageType::Node): open the reader with vs_pages_open_plain");
+        if (p->plain && p->n == 0 && p->by_type[VS_PAGE_SBQ_NODE] > 0)
+            return fail("the relation holds memory_optimized (SBQ) nodes: open the reader with vs_pages_open");
         if (p->headers_only) {
             p->finished = true;
         } else {
@@ -864,7 +897,8 @@ int vs_pages_host(const vs_pages* p, vs_index_host* host) {
         return VS_ERR_STATE;
     }
     memset(host, 0, sizeof *host);
-    host->codes = p->codes.data();
+    if (p->plain) host->vecs = p->pvecs.data();  // PlainNode.vector: the (cosine-normalised) index slice, [n][vs_pages_info.words] floats
+    else host->codes = p->codes.data();
     host->nbrs = p->nbrs.data();
     host->nbr_stride = p->R;
     host->heap_tids = p->tids.data();

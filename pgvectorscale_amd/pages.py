@@ -106,13 +106,18 @@ class HeapColumn:
 
 
 class IndexPages:
-    def __init__(self, has_labels=False, page_size=BLCKSZ, layout=None, threads=0):
+    def __init__(self, has_labels=False, page_size=BLCKSZ, layout=None, threads=0, plain=False):
+        """plain=True: a `plain` storage index (PlainNode items: full-precision vectors in the nodes, no SBQ codes, no labels)"""
         self._L = _lib.load()
         h = C.c_void_p()
         lay = None
         if layout is not None:
             lay = NodeLayout(*layout)
-        check(self._L.vs_pages_open(page_size, int(has_labels), None if lay is None else C.byref(lay), threads, C.byref(h)))
+        self.plain = bool(plain)
+        if plain:
+            check(self._L.vs_pages_open_plain(page_size, None if lay is None else C.byref(lay), threads, C.byref(h)))
+        else:
+            check(self._L.vs_pages_open(page_size, int(has_labels), None if lay is None else C.byref(lay), threads, C.byref(h)))
         self.h = h
         self.page_size = page_size
         self.has_labels = bool(has_labels)
@@ -213,12 +218,27 @@ class IndexPages:
                 return np.zeros(0, dtype)
             return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(np.ctypeslib.as_ctypes_type(dtype))), (count,)).copy()
 
-        out = {"codes": view(h.codes, np.uint64, n * W).reshape(n, W), "nbrs": view(h.nbrs, np.uint32, n * R).reshape(n, R),
-               "heap_tids": view(h.heap_tids, np.uint64, n)}
+        out = {"nbrs": view(h.nbrs, np.uint32, n * R).reshape(n, R), "heap_tids": view(h.heap_tids, np.uint64, n)}
+        if self.plain:
+            out["vecs"] = view(h.vecs, np.float32, n * W).reshape(n, W)  # PlainNode.vector
+        else:
+            out["codes"] = view(h.codes, np.uint64, n * W).reshape(n, W)
         if self.has_labels:
             out["label_off"] = view(h.label_off, np.uint32, n + 1)
             out["label_val"] = view(h.label_val, np.int16, int(self.info.n_label_vals))
         return out
+
+    def upload_plain(self, ctx, *, distance_type, default_start, vecs=None):
+        """a `plain` storage index in HBM: the graph from the pages; `vecs` = the heap's vector column (HeapColumn) or, when
+        None, the node vectors themselves (the cosine-normalised index slice: enough when num_dimensions_to_index = num_dimensions)"""
+        from .index import DiskAnnIndex
+        assert self.plain
+        a = self.arrays()
+        node = self.node_of(*default_start) if isinstance(default_start, tuple) else default_start
+        v = a["vecs"] if vecs is None else np.ascontiguousarray(vecs, np.float32)
+        return DiskAnnIndex._upload_plain(ctx, nbrs=a["nbrs"], heap_tids=a["heap_tids"], vecs=v, num_neighbors=self.info.num_neighbors,
+                                          distance_type=distance_type, default_start=_lib.VS_INVALID_NODE if node is None else int(node),
+                                          dim_index=a["vecs"].shape[1])
 
     def upload(self, ctx, *, dim_index, bits, distance_type, default_start, quantizer_metadata=None, mean=None, m2=None,
                count=0, vecs=None, label_starts=None):

@@ -100,3 +100,25 @@ def test_plain_storage_with_truncated_index_dimensions(gpu_ctx, oracle, distance
     for key in ("visited_nodes", "candidate_nodes", "full_distance_comparisons", "node_reads"):
         assert gst[key] == ost[key], key
     ix.close()
+
+
+def test_plain_index_from_relation_pages(gpu_ctx, oracle):
+    """a `plain` storage index staged from its relation's pages (PageType::Node, PlainNode items): the graph and the node vectors
+    come from vs_pages_open_plain, geometry and start node from the MetaPage; scans equal the oracle's bit for bit"""
+    from oracle import pages_py as PG
+    from pgvectorscale_amd.pages import IndexPages
+    pi = PlainIndex(n=900, dim=64, R=24, distance=O.L2, seed=5, kind="uniform", deleted_frac=0.05)
+    meta = dict(num_dimensions=64, storage_type=0, bq_num_bits_per_dimension=1, distance_type=O.L2, num_neighbors=24, default_start=pi.start)
+    w = PG.write_plain_index(vectors=pi.vecs, nbrs=pi.nbrs, heap_tids=pi.tids, meta=meta)
+    pages = IndexPages(plain=True)
+    pages.add(w.rel.tobytes())
+    pages.finish()
+    m, d, _ = pages.meta()
+    ix = pages.upload_plain(gpu_ctx, distance_type=d.distance_type, default_start=int(d.default_start))
+    pages.close()
+    q = make_vectors(24, 64, 3, "uniform")
+    gi, _, gd, gst = ix.search_batch(q, search_list_size=30, rescore=0, k=15)
+    oi, od, ost = pi.oracle.search_batch(q, L=30, rescore=0, k=15)
+    assert (gi == oi).all() and (gd.view(np.uint32) == od.view(np.uint32)).all()
+    assert gst["visited_nodes"] == ost["visited_nodes"] and gst["full_distance_comparisons"] == ost["full_distance_comparisons"]
+    ix.close()

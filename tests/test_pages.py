@@ -472,3 +472,39 @@ def test_index_desc_from_the_relation_alone(n_labels, big_map):
     rd2.finish()
     m2_, d2, st2 = rd2.meta()
     assert d2.n == 0 and d2.default_start == 0xFFFFFFFF and st2 == {} and not m2_["has_start_nodes"]
+
+
+# ---- `plain` storage relations (PageType::Node pages of PlainNode items, AM/plain/node.rs:15-22) -------------------------------
+def test_plain_storage_relation_round_trip():
+    rng = np.random.default_rng(3)
+    n, D, R = 900, 96, 12
+    vecs = rng.standard_normal((n, D)).astype(np.float32)
+    ix = random_index(n, 2, R, seed=8)
+    meta = dict(num_dimensions=D, storage_type=0, bq_num_bits_per_dimension=1, distance_type=0, num_neighbors=R, default_start=5)
+    w = PG.write_plain_index(vectors=vecs, nbrs=ix["nbrs"], heap_tids=ix["heap_tids"], meta=meta)
+    rd = _reader(plain=True, threads=3)
+    data = w.rel.tobytes()
+    half = (len(w.rel.pages) // 2) * PG.BLCKSZ
+    rd.add(data[:half])
+    rd.add(data[half:])
+    info = rd.finish()
+    assert (info.n_nodes, info.words, info.num_neighbors, info.has_labels) == (n, D, R, 0)
+    assert info.pages_by_type[PG.PT_NODE] > 0 and info.pages_by_type[PG.PT_SBQ_NODE] == 0
+    a = rd.arrays()
+    assert a["vecs"].tobytes() == vecs.tobytes() and (a["nbrs"] == ix["nbrs"]).all() and (a["heap_tids"] == ix["heap_tids"]).all()
+    m, d, st = rd.meta()
+    assert (d.n, d.dim_full, d.dim_index, d.num_neighbors, d.distance_type, d.storage_type, d.default_start) == (n, D, D, R, 0, 1, 5)
+    # the wrong reader for the relation is told so
+    from pgvectorscale_amd import VsError
+    sbq = _reader()
+    sbq.add(data)
+    with pytest.raises(VsError, match="plain"):
+        sbq.finish()
+    # another field order of the archived PlainNode
+    lay = (32, 0, 8, 24, None)  # heap_item_pointer, vector, (pq_vector at 16), neighbor_index_pointers
+    w2 = PG.write_plain_index(vectors=vecs[:50], nbrs=np.minimum(ix["nbrs"][:50], 49) | np.where(ix["nbrs"][:50] == 0xFFFFFFFF, np.uint32(0xFFFFFFFF), np.uint32(0)),
+                              heap_tids=ix["heap_tids"][:50], layout=lay)
+    rd2 = _reader(plain=True, layout=(32, 0, 8, 24, 0xFFFFFFFF))
+    rd2.add(w2.rel.tobytes())
+    rd2.finish()
+    assert rd2.arrays()["vecs"].tobytes() == vecs[:50].tobytes()

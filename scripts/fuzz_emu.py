@@ -438,8 +438,12 @@ def main():
     ap.add_argument("--gpu", action="store_true")
     ap.add_argument("--kind", default="any", choices=["any", "search", "plain", "pages", "build", "kernels"], help="only cases of this kind")
     ap.add_argument("-v", "--verbose", action="store_true")
+    ap.add_argument("--lib", default=None, help="with --gpu: this libvsgpu build instead of pgvectorscale_amd/libvsgpu.so (bisecting)")
+    ap.add_argument("--repeat", type=int, default=1, help="with --only: run the case this many times (rare hardware-only failures)")
     args = ap.parse_args()
     from pgvectorscale_amd import _lib
+    if args.gpu and args.lib:
+        _lib.LIB_PATH = os.path.abspath(args.lib)
     if not args.gpu:
         _lib.LIB_PATH = os.path.join(ROOT, "tests", "emu", "libvsgpu_emu.so")
         assert os.path.exists(_lib.LIB_PATH), "make -C tests/emu first"
@@ -449,7 +453,7 @@ def main():
     ctx = P.Context(0)
     t0 = time.time()
     cases = failures = 0
-    seeds = [args.only] if args.only is not None else (args.seed * 1_000_000 + i for i in range(1 << 30))
+    seeds = [args.only] * args.repeat if args.only is not None else (args.seed * 1_000_000 + i for i in range(1 << 30))
     def kind_of(cs):
         return ("build" if cs % 11 == 10 else "kernels" if cs % 13 == 12 else "plain" if cs % 5 == 4 else "pages" if cs % 7 == 6
                 else "search")
@@ -460,7 +464,7 @@ def main():
         if args.only is None and args.kind != "any" and kind_of(cs) != args.kind:
             continue
         try:
-            one_case(ctx, O, cs, args.verbose or args.only is not None)
+            one_case(ctx, O, cs, args.verbose or (args.only is not None and args.repeat == 1))
         except AssertionError as e:
             failures += 1
             print("FAIL", e, flush=True)

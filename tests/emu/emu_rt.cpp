@@ -81,7 +81,24 @@ void* guarded_alloc(size_t bytes) {
     mprotect(base, page, PROT_NONE);                // below the buffer
     mprotect(base + page + body, page, PROT_NONE);  // right after its last 256-byte unit
     char* p = base + page + (body - rounded);
-    memset(p, 0xA5, rounded);  // device memory is not zero initialised
+    // device memory is not zero initialised: 0xA5 by default; VS_EMU_POISON=<byte, hex> picks another filler and VS_EMU_POISON=rand
+    // a different pseudo-random word for every 4 bytes (what a hipMalloc that recycles another kernel's memory hands out)
+    {
+        const char* e = getenv("VS_EMU_POISON");
+        if (e && !strcmp(e, "rand")) {
+            static std::atomic<uint64_t> seq{0x9E3779B97F4A7C15ull};
+            uint64_t x = seq.fetch_add(0xD1B54A32D192ED03ull);
+            uint32_t* w = reinterpret_cast<uint32_t*>(p);
+            for (size_t i = 0; i < rounded / 4; ++i) {
+                x ^= x << 13;
+                x ^= x >> 7;
+                x ^= x << 17;
+                w[i] = (uint32_t)(x >> 16) & ((i & 3) == 0 ? 0xFFFFFFFFu : ((i & 3) == 1 ? 0x00000FFFu : ((i & 3) == 2 ? 0x000FFFFFu : 0x0FFFFFFFu)));
+            }
+        } else {
+            memset(p, e ? (int)strtoul(e, nullptr, 16) : 0xA5, rounded);
+        }
+    }
     std::lock_guard<std::mutex> lk(g_alloc_mu);
     g_allocs.push_back({p, AllocInfo{base, map_bytes}});
     return p;

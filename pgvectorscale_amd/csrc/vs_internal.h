@@ -260,6 +260,7 @@ int launch_resort(vs_index* idx, uint32_t nq, uint32_t M, uint32_t rescore, uint
 int launch_resort_cursor(vs_index* idx, uint32_t n, bool exhausted, uint32_t rescore, uint32_t k, const uint32_t* d_stream,
                          const float* d_dist, const uint32_t* d_keys, uint64_t* d_heap, uint32_t* d_cur, uint32_t* d_out_ids,
                          uint64_t* d_out_tids, float* d_out_dist);
+int launch_zero_fill(vs_ctx* c, void* p, size_t bytes);  // zero fill by kernel stores on the compute stream (16-byte granularity)
 int launch_row_norms(vs_index* idx);
 int launch_slice_norms(vs_index* idx, float* d_out);  // divisor of the first dim_index dims of every heap vector
 int launch_prepare_index_slice(vs_index* idx, const float* d_raw, uint32_t nq, float* d_q_index);

@@ -410,7 +410,12 @@ def one_case(ctx, O, case_seed, verbose):
                 for c in ("visited_nodes", "quantized_distance_comparisons", "full_distance_comparisons"):
                     assert gst[c] == ost[c], f"{where}: counter {c} {gst[c]} != {ost[c]}"
             gi2, gh2, gst2 = ix.stream_batch(q, search_list_size=L, m=m, qlabels=keys)
-            assert (gi2 == si).all() and (gh2 == sh).all(), f"{where}: stream differs"
+            if not ((gi2 == si).all() and (gh2 == sh).all()):
+                bad = np.argwhere((gi2 != si) | (gh2 != sh))
+                q0, p0 = (int(x) for x in bad[0])
+                raise AssertionError(f"{where}: stream differs: {len(bad)} of {gi2.size} entries, first at query {q0} row {p0}: got "
+                                     f"({gi2[q0, p0]}, {gh2[q0, p0]}) want ({si[q0, p0]}, {sh[q0, p0]}); got row {gi2[q0].tolist()} "
+                                     f"ham {gh2[q0].tolist()} want row {si[q0].tolist()} ham {sh[q0].tolist()}; counters {gst2} vs {sst}")
             assert gst2["candidate_nodes"] == sst["candidate_nodes"], f"{where}: stream counters differ"
             gettuple_mirror(ix, ti.oracle, q, keys, L, rescore, np.random.default_rng(case_seed + 1), where, exact_dist=False)
             if reg is regimes[0] and n > 1:  # tuples deleted after the upload (vs_index_mark_deleted): skipped by the scans from now on

@@ -23,8 +23,8 @@ REGIMES = {
     "heap_spill_tableless": {"VS_F_HL": "63", "VS_F_LDS_MAX_INS": "0"},
     # the epoch-tagged dedup table of the table-less regime wraps after two launches (the array is zeroed again), and the same
     # regime with plain ids and a 64 KB clear per scan
-    "tableless_epoch_wrap": {"VS_F_LDS_MAX_INS": "0", "VS_F_EPOCH_MAX": "2"},
-    "tableless_no_epoch": {"VS_F_LDS_MAX_INS": "0", "VS_F_EPOCH": "0"},
+    "tableless_epoch_wrap": {"VS_F_LDS_MAX_INS": "0", "VS_F_EPOCH": "1", "VS_F_EPOCH_MAX": "2"},
+    "tableless_epoch": {"VS_F_LDS_MAX_INS": "0", "VS_F_EPOCH": "1"},
     "tiny_pool": {"VS_F_LH": "256", "VS_F_POOL": "0.01"},
     # dedup table too small for most scans: they are finished by the second attempt of k_search_fast (four times the table) ...
     "second_attempt": {"VS_F_LDS_MAX_INS": "0", "VS_F_GCAP": "1024"},

@@ -1034,7 +1034,6 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
         f.flags = env_u32("VS_F_FLAGS", 0);
         f.epoch = epoch;
         f.eshift = eshift;
-        if (epoch && (env_u32("VS_F_EPOCH_DBG", 0) & 2)) f.flags |= 16;  // (diagnostics: tagged entries AND a zero fill per scan)
         f.rc = caps.f_lh == 0 ? env_u32("VS_F_RC", 0) : 0;  // (measurement: LDS id cache in front of the dedup table in HBM)
         if (f.rc) f.rc = next_pow2_u32(f.rc);
         f.visible = (!bp.stream_only && bp.rescore > 0) ? ix->visible : nullptr;  // the heap is only fetched for the rescore window

@@ -887,9 +887,6 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
             for (uint32_t i = 4u * lane; i < s.gcap; i += 4u * WAVE)
                 *reinterpret_cast<uint4*>(ghash + i) = make_uint4(VS_EMPTY, VS_EMPTY, VS_EMPTY, VS_EMPTY);
             wave_sync();
-        } else if (s.flags & 16u) {
-            for (uint32_t i = 4u * lane; i < s.gcap; i += 4u * WAVE) *reinterpret_cast<uint4*>(ghash + i) = make_uint4(0, 0, 0, 0);
-            wave_sync();
         }
         return true;
     };

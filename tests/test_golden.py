@@ -8,7 +8,8 @@ import os
 import numpy as np
 import pytest
 
-GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "*.npz")))
+GOLDEN = sorted(p for p in glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "*.npz"))
+                if not os.path.basename(p).startswith("pages_"))  # (pages_golden.npz: byte-layout fixtures, tests/test_golden_pages.py)
 
 
 def _qlabels(g):

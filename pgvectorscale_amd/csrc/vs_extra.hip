@@ -526,14 +526,19 @@ __global__ __launch_bounds__(256) void k_nbr_masks(const uint32_t* __restrict__ 
 
 extern "C" int vs_index_has_neighbor_masks(const vs_index* ix) { return ix && ix->nbr_mask_valid ? 1 : 0; }
 
+bool vs_neighbor_masks_wanted(const vs_index* ix) {
+    const char* e = getenv("VS_F_NBRMASK");
+    if (e && *e == '0') return false;
+    if (e && *e == '1') return true;
+    return ix->d.n > (8u << 20);
+}
+
 int vs_refresh_neighbor_masks(vs_index* ix) {
     if (ix->nbr_mask_valid || ix->is_view || !ix->label_mask || !ix->nbrs || ix->d.n == 0) return VS_OK;
-    // off by default: at 5M x 1536 the cache bought 0.6 % (62.6 against 63.0 ms per 131072 scans, profiles/r03/s6_nbrmask_5m_summary.txt —
-    // the 40 MB of node masks are cache resident there anyway) for 8 x nbr_stride bytes per node; VS_F_NBRMASK=1 builds and uses it
-    {
-        const char* e = getenv("VS_F_NBRMASK");
-        if (!e || *e != '1') return VS_OK;
-    }
+    // worth it once the node masks (8 bytes per node) no longer sit in the caches: +6.7 % at 20M x 1536 (77.9 -> 72.7 ms per 131072
+    // scans, profiles/r03/bench_cfg5*.json), +0.6 % at 5M (s6_nbrmask_5m_summary.txt), for 8 x nbr_stride bytes per node.  So: built
+    // for indexes of more than 8M nodes (64 MB of masks), VS_F_NBRMASK=1 / 0 forces it on / off.
+    if (!vs_neighbor_masks_wanted(ix)) return VS_OK;
     vs_ctx* c = ix->ctx;
     const size_t bytes = (size_t)ix->d.n * ix->nbr_stride * 8;
     if (!ix->nbr_mask) {

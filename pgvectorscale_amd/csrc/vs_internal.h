@@ -158,6 +158,7 @@ int devbuf_reserve(vs_ctx* ctx, DevBuf& b, size_t bytes);
 // row-wise staging through the pinned ring (device rows may be wider than host rows) / neighbor-list validation
 int vs_upload_rows(vs_ctx* c, void* dst, size_t dev_row_bytes, const void* src, size_t host_row_bytes, size_t copy_bytes, size_t rows);
 int vs_validate_graph(vs_index* ix);
+bool vs_neighbor_masks_wanted(const vs_index* ix);  // policy: > 8M nodes, or VS_F_NBRMASK=1 / 0
 int vs_refresh_neighbor_masks(vs_index* ix);  // (re)derives nbr_mask when it is stale (no-op for a view or when it does not fit)
 int vs_refresh_label_masks(vs_index* ix);  // (re)derives label_mask / label_bit from the label CSR, or drops them when the index uses more than 64 distinct labels
 void devbuf_free(DevBuf& b);

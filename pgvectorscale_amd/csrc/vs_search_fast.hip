@@ -1326,8 +1326,7 @@ int launch_search_fast(vs_index* idx, const FastLaunch& s) {
     a.nbr_mask = nullptr;
     if (s.qlabel_off && idx->label_mask && !s.build) {  // label-filtered scans: the neighbors' masks next to the neighbor rows
         VS_TRY(vs_refresh_neighbor_masks(idx));
-        const char* on = getenv("VS_F_NBRMASK");
-        if (idx->nbr_mask_valid && on && *on == '1') a.nbr_mask = idx->nbr_mask;
+        if (idx->nbr_mask_valid && vs_neighbor_masks_wanted(idx)) a.nbr_mask = idx->nbr_mask;
     }
     a.ls_labels = idx->ls_labels;
     a.ls_nodes = idx->ls_nodes;

@@ -1036,6 +1036,10 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
         f.eshift = eshift;
         f.rc = caps.f_lh == 0 ? env_u32("VS_F_RC", 0) : 0;  // (measurement: LDS id cache in front of the dedup table in HBM)
         if (f.rc) f.rc = next_pow2_u32(f.rc);
+        // written-bucket bitmap (VS_F_VIRGIN=1, table-less regime): 128 slots of the table per LDS word; tables of more than
+        // 64 Ki slots keep the clear (the bitmap would cost occupancy)
+        if (caps.f_lh == 0 && !epoch && !f.vr && env_u32("VS_F_VIRGIN", 0) && !env_u32("VS_PHASE", 0) && f.gcap <= (1u << 16))
+            f.vwords = (f.gcap + 127) / 128;
         f.visible = (!bp.stream_only && bp.rescore > 0) ? ix->visible : nullptr;  // the heap is only fetched for the rescore window
         f.sb = caps.f_sb;
         f.vcap = caps.f_vcap;
@@ -1062,6 +1066,7 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
         if (env_u32("VS_F_RETRY", 1)) {
             FastLaunch r = f;
             r.epoch = 0;  // (its own, smaller table array: cleared by the few scans that run)
+            r.vwords = 0;
             r.only_failed = 1;
             r.fb_flag = (uint32_t*)w.fb_flag.p;
             r.phase = nullptr;
@@ -1092,7 +1097,8 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
             VS_HIP(hipStreamSynchronize(c->stream));
             uint32_t hist[16] = {0};
             for (uint32_t v : stv) hist[v & 15]++;
-            fprintf(stderr, "[VS_DEBUG_STATUS] fast kernel: pool claims=%u of %u;", ctr[0], fast_pool_slots(nq, caps.f_pool_frac));
+            fprintf(stderr, "[VS_DEBUG_STATUS] fast kernel: lh=%u gcap=%u vr=%u minw=%u epoch=%u bitmap_words=%u; pool claims=%u of %u;",
+                    f.lh, f.gcap, f.vr, f.minw, f.epoch, f.vwords, ctr[0], fast_pool_slots(nq, caps.f_pool_frac));
             for (int i = 0; i < 16; ++i)
                 if (hist[i]) fprintf(stderr, " status[%d]=%u", i, hist[i]);
             fprintf(stderr, "\n");

@@ -678,7 +678,7 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 // ring capacity, farthest entry dropped) is the result.
 // FULL = label keys and / or a visibility mask may be present; the plain instantiation (neither) leaves their pointers, counters
 // and branches out of a kernel whose scalar registers are its tightest resource.
-template <int NCH, int VR, bool TIMING, int MINW, bool BUILD, bool FULL = true>
+template <int NCH, int VR, bool TIMING, int MINW, bool BUILD, bool FULL = true, bool VG = false>
 __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
@@ -700,6 +700,9 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
     // (optional) cache of ids known to be in the dedup table: a hit answers a duplicate probe without touching the table in HBM
     uint32_t* rc = reinterpret_cast<uint32_t*>(qc_l + (NCH == 0 ? ((a.code_stride + 1u) & ~1u) : (NCH > 0 && MINW >= 6 ? 8u * (uint32_t)NCH : 0u)));
     const uint32_t rcm = s.rc - 1u;  // (s.rc: 0 or a power of two)
+    // (VG) one bit per bucket of the dedup table in HBM: set once this scan has written the bucket.  A bucket whose bit is clear is
+    // neither cleared nor read — its memory holds whatever an earlier scan left there — and counts as four empty slots
+    uint32_t* vmap = rc + s.rc;  // s.vwords
 
     const int l4 = lane & 3;
     const bool stream_rows = !(s.flags & FAST_PLAIN_ROW_LOADS);
@@ -725,6 +728,8 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
     if (lane == 0) hp[0] = 0;  // heap sentinel
     for (uint32_t i = lane; i < ARB_SLOTS; i += WAVE) arb[i] = 0;
     for (uint32_t i = lane; i < s.rc; i += WAVE) rc[i] = VS_EMPTY;
+    if (VG)
+        for (uint32_t i = lane; i < s.vwords; i += WAVE) vmap[i] = 0;
     const uint8_t* const visible = FULL ? s.visible : nullptr;
     const bool labels_some = FULL && s.qlabel_off != nullptr;  // LabeledVector.labels is Some (AM/labels/mod.rs:222-236)
     uint32_t nql = 0;
@@ -836,13 +841,34 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
         return (uint32_t)(((uint64_t)hash_u32(nid ^ 0x5bd1e995u) * gbuckets) >> 32) << 2;
     };
     auto bucket_load = [&](uint32_t b0) -> uint4 { return *reinterpret_cast<const uint4*>(ghash + b0); };
-    // v = the bucket at b0 as loaded by the caller (where act).  true where the id was not present before
-    auto global_insert = [&](uint32_t nid, bool act, uint32_t b0, uint4 v, uint32_t& slot_out) -> bool {
+    // VG: virgin = the scan has not written this bucket yet; nothing is requested for it
+    auto bucket_fetch = [&](uint32_t b0, bool& virgin) -> uint4 {
+        if (VG) {
+            const uint32_t b = b0 >> 2;
+            virgin = ((vmap[b >> 5] >> (b & 31u)) & 1u) == 0;
+            if (virgin) return make_uint4(VS_EMPTY, VS_EMPTY, VS_EMPTY, VS_EMPTY);
+        }
+        return bucket_load(b0);
+    };
+    // v = the bucket at b0 as fetched by the caller (where act).  true where the id was not present before
+    auto global_insert = [&](uint32_t nid, bool act, uint32_t b0, uint4 v, bool virgin, uint32_t& slot_out) -> bool {
         bool fresh = false, pend = act;
         for (;;) {
             wave_sync();  // every lane holds its snapshot before any lane stores (the loads are earlier instructions)
             uint32_t em = 0;
-            if (pend) {
+            if (VG && pend && virgin) {
+                // the id cannot be in a bucket nobody has written.  The one lane that flips the bucket's bit writes all four
+                // slots (its id and three empties) with one store; a lane that lost the bit to another lane of this step looks
+                // at the bucket again, now a written one
+                const uint32_t b = b0 >> 2, bit = 1u << (b & 31u);
+                if ((atomicOr(&vmap[b >> 5], bit) & bit) == 0) {  // ds_or_rtn_b32
+                    *reinterpret_cast<uint4*>(ghash + b0) = make_uint4(nid, VS_EMPTY, VS_EMPTY, VS_EMPTY);
+                    slot_out = s.lh + b0;
+                    fresh = true;
+                    pend = false;
+                }
+                virgin = false;
+            } else if (pend) {
                 const uint32_t key = nid | etag;
                 const uint32_t hit = (v.x == key ? 1u : 0u) | (v.y == key ? 2u : 0u) | (v.z == key ? 4u : 0u) | (v.w == key ? 8u : 0u);
                 if (hit) {
@@ -874,7 +900,7 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
             }
             wave_sync();
             if (!__ballot(pend)) break;
-            if (pend) v = bucket_load(b0);  // (this wave's stores of the round above are visible: same CU, program order)
+            if (pend) v = bucket_fetch(b0, virgin);  // (this wave's stores of the round above are visible: same CU, program order)
         }
         nins_g += (uint32_t)__popcll(__ballot(fresh));
         return fresh;
@@ -883,7 +909,7 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
         if (g_open) return true;
         if (!claim_region()) return false;
         g_open = true;
-        if (s.epoch == 0) {
+        if (s.epoch == 0 && !VG) {
             for (uint32_t i = 4u * lane; i < s.gcap; i += 4u * WAVE)
                 *reinterpret_cast<uint4*>(ghash + i) = make_uint4(VS_EMPTY, VS_EMPTY, VS_EMPTY, VS_EMPTY);
             wave_sync();
@@ -910,8 +936,9 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
         }
         const uint32_t b0 = ghash_home(nid);
         uint4 v = make_uint4(0, 0, 0, 0);
-        if (need_g) v = bucket_load(b0);
-        return global_insert(nid, need_g, b0, v, slot_out);
+        bool virgin = false;
+        if (need_g) v = bucket_fetch(b0, virgin);
+        return global_insert(nid, need_g, b0, v, virgin, slot_out);
     };
 
     if (status) { /* handed over (wide label key): no region is claimed */ }
@@ -1037,6 +1064,7 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
         uint32_t hslot0 = 0;
         uint4 gbk0 = make_uint4(0, 0, 0, 0);
         bool rchit0 = false;  // this lane's id of the first chunk was found in the id cache
+        bool virg0 = false;
         if (hit) {
             if (VR == 0 && !BUILD) {
                 vtid = a.tids[node_v];
@@ -1047,7 +1075,7 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
                 hslot0 = ghash_home(row0);
                 const uint64_t inval0 = __ballot(row0 == VS_INVALID_NODE);
                 if (s.rc) rchit0 = rc[hash_u32(row0 ^ 0x9e3779b9u) & rcm] == row0;
-                if ((uint32_t)lane < (inval0 ? (uint32_t)__builtin_ctzll(inval0) : WAVE) && !rchit0) gbk0 = bucket_load(hslot0);
+                if ((uint32_t)lane < (inval0 ? (uint32_t)__builtin_ctzll(inval0) : WAVE) && !rchit0) gbk0 = bucket_fetch(hslot0, virg0);
             }
         }
         heap.pop();
@@ -1090,15 +1118,16 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
             const bool frozen = !gmode && nins + WAVE > slot_limit;
             uint32_t hslot = gmode ? ghash_home(nid) : hash_home(nid), old = VS_EMPTY;
             uint4 gbk = make_uint4(0, 0, 0, 0);
-            bool rchit = false;
+            bool rchit = false, virg = false;
             if (gmode && early && c0 == 0) {
                 hslot = hslot0;  // requested before the pop
                 gbk = gbk0;
                 rchit = rchit0;
+                virg = virg0;
             } else if (gmode) {
                 if ((nins_g + WAVE) * 4u > s.gcap * 3u) { status |= OVF_HASH; break; }
                 if (s.rc && act) rchit = rc[hash_u32(nid ^ 0x9e3779b9u) & rcm] == nid;
-                if (act && !rchit) gbk = bucket_load(hslot);  // in flight during the visited insert
+                if (act && !rchit) gbk = bucket_fetch(hslot, virg);  // in flight during the visited insert
             } else if (!frozen && act) {
                 old = atomicCAS(&lhash[hslot], VS_EMPTY, nid);
             }
@@ -1111,7 +1140,7 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
             // ... then the probe sequence is finished
             bool fresh;
             if (gmode) {
-                fresh = global_insert(nid, act && !rchit, hslot, gbk, hslot);
+                fresh = global_insert(nid, act && !rchit, hslot, gbk, virg, hslot);
                 if (s.rc && act && !rchit) rc[hash_u32(nid ^ 0x9e3779b9u) & rcm] = nid;  // (now in the table, new or not)
             } else if (frozen) {
                 fresh = frozen_insert(nid, act, hslot);
@@ -1267,19 +1296,19 @@ size_t fast_lds_bytes(const vs_index* idx, const FastLaunch& s) {
     const size_t nch = (idx->code_stride + 7) / 8;
     // LDS copy of the query code: the generic variant (NCH == 0), and the register-capped variants (minw >= 6: 8 NCH words, zero padded)
     const size_t qcopy = nch > 6 ? (size_t)idx->code_stride * 8 : (s.minw >= 6 && !s.build && !s.phase ? nch * 64 : 0);
-    size_t b = (size_t)(s.hl + 1) * 4 + (size_t)s.lh * 4 + 3 * 64 * 4 + ARB_SLOTS * 4 + (s.vr ? 0 : (size_t)s.vcap * 8) + MAX_QLABELS * 2 + qcopy + (size_t)s.rc * 4 + 32;
+    size_t b = (size_t)(s.hl + 1) * 4 + (size_t)s.lh * 4 + 3 * 64 * 4 + ARB_SLOTS * 4 + (s.vr ? 0 : (size_t)s.vcap * 8) + MAX_QLABELS * 2 + qcopy + (size_t)s.rc * 4 + (size_t)s.vwords * 4 + 32;
     return (b + 15) / 16 * 16;
 }
 
-template <int NCH, int VR, bool TIMING, int MINW, bool BUILD, bool FULL = true>
+template <int NCH, int VR, bool TIMING, int MINW, bool BUILD, bool FULL = true, bool VG = false>
 static int launch_fast_tt(vs_index* idx, const FastArgs& a, size_t lds) {
     static bool attr_set = false;
     if (!attr_set) {
-        VS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_search_fast<NCH, VR, TIMING, MINW, BUILD, FULL>),
+        VS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_search_fast<NCH, VR, TIMING, MINW, BUILD, FULL, VG>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_search_fast<NCH, VR, TIMING, MINW, BUILD, FULL>), dim3(a.s.nq), dim3(WAVE), lds, idx->ctx->stream, a);
+    hipLaunchKernelGGL((k_search_fast<NCH, VR, TIMING, MINW, BUILD, FULL, VG>), dim3(a.s.nq), dim3(WAVE), lds, idx->ctx->stream, a);
     VS_HIP(hipGetLastError());
     return VS_OK;
 }
@@ -1294,6 +1323,14 @@ static int launch_fast_t(vs_index* idx, const FastArgs& a, size_t lds) {
         VS_REQUIRE(NCH == 3, "VS_PHASE diagnostics are built for 17..24-word codes only");
         if (a.s.vr == 8) return launch_fast_tt<3, 8, true, 1, false>(idx, a, lds);
         return launch_fast_tt<3, 0, true, 1, false>(idx, a, lds);
+    }
+    if (a.s.vwords) {  // written-bucket bitmap in LDS instead of cleared tables (table-less regime, LDS-ring visited list)
+        VS_REQUIRE(a.s.vr == 0 && a.s.lh == 0 && a.s.epoch == 0 && (uint64_t)a.s.vwords * 128 >= a.s.gcap,
+                   "fast search: the written-bucket bitmap needs the table-less regime with plain ids and one bit per bucket");
+        const bool plain = !a.s.qlabel_off && !a.s.visible && !(a.s.flags & FAST_FULL_VARIANT);
+        if (NCH == 3 && a.s.minw == 6 && plain) return launch_fast_tt<3, 0, false, 6, false, false, true>(idx, a, lds);
+        if (NCH == 3 && a.s.minw == 6) return launch_fast_tt<3, 0, false, 6, false, true, true>(idx, a, lds);
+        return launch_fast_tt<NCH, 0, false, 1, false, true, true>(idx, a, lds);
     }
     if (a.s.vr == 8) {
         if (NCH == 3) {  // the headline geometry (768 x 2 bit, 1536 x 1 bit): register-capped variants for the occupancy-bound regime

@@ -25,6 +25,10 @@ REGIMES = {
     # regime with plain ids and a 64 KB clear per scan
     "tableless_epoch_wrap": {"VS_F_LDS_MAX_INS": "0", "VS_F_EPOCH": "1", "VS_F_EPOCH_MAX": "2"},
     "tableless_epoch": {"VS_F_LDS_MAX_INS": "0", "VS_F_EPOCH": "1"},
+    # table-less with the written-bucket bitmap in LDS: tables are never cleared and a bucket is not read before its first write
+    # (the array starts out holding whatever earlier launches left there); tight tables make chains of full buckets
+    "tableless_virgin": {"VS_F_LDS_MAX_INS": "0", "VS_F_VIRGIN": "1"},
+    "tableless_virgin_tight": {"VS_F_LDS_MAX_INS": "0", "VS_F_VIRGIN": "1", "VS_F_GCAP": "6144"},
     "tiny_pool": {"VS_F_LH": "256", "VS_F_POOL": "0.01"},
     # dedup table too small for most scans: they are finished by the second attempt of k_search_fast (four times the table) ...
     "second_attempt": {"VS_F_LDS_MAX_INS": "0", "VS_F_GCAP": "1024"},
@@ -91,7 +95,7 @@ WIDTHS = {"w12": (384, 2), "w30": (960, 2), "w48": (1536, 2), "w60": (1900, 2), 
 
 
 @pytest.mark.parametrize("wname", list(WIDTHS))
-@pytest.mark.parametrize("regime", ["default", "tableless", "heap_spill"])
+@pytest.mark.parametrize("regime", ["default", "tableless", "heap_spill", "tableless_virgin"])
 def test_code_width_specialisations(gpu_ctx, wname, regime):
     dims, bits = WIDTHS[wname]
     ti = cached_index(n=400, dim_full=dims, bits=bits, R=16, distance=1, seed=21, kind="gauss", L_build=40)
@@ -119,7 +123,7 @@ def test_code_width_specialisations(gpu_ctx, wname, regime):
 
 # the register-capped variants of the headline geometry (W = 24: 768 x 2 bit / 1536 x 1 bit) in the table-less regime:
 # waves per SIMD the kernel is compiled for (7 and 8 read the query code from LDS and keep the heap's lane constants packed)
-@pytest.mark.parametrize("minw", [6, 7, 8])
+@pytest.mark.parametrize("minw", [6, 7, 8, "6_virgin"])
 @pytest.mark.parametrize("wname", ["w24_two_bit", "w24_one_bit"])
 def test_register_capped_variants(gpu_ctx, wname, minw):
     dims, bits = {"w24_two_bit": (768, 2), "w24_one_bit": (1536, 1)}[wname]
@@ -129,6 +133,8 @@ def test_register_capped_variants(gpu_ctx, wname, minw):
     oi, oh, ost = ti.oracle.stream_batch(q, L=3, m=60)
     osi, osd, _ = ti.oracle.search_batch(q, L=3, rescore=40, k=10)
     env = {"VS_F_LDS_MAX_INS": "0", "VS_F_VR": "0", "VS_F_MINW": str(minw), "VS_F_HL": "63"}
+    if minw == "6_virgin":  # the two written-bucket-bitmap instantiations of the headline geometry
+        env.update({"VS_F_MINW": "6", "VS_F_VIRGIN": "1"})
     saved = {k: os.environ.get(k) for k in env}
     try:
         os.environ.update(env)
@@ -151,7 +157,7 @@ def test_register_capped_variants(gpu_ctx, wname, minw):
 # Few distinct keys, deep heap, long runs: 24-dimensional 1-bit codes give Hamming distances 0..24, so thousands of heap entries
 # tie and the row order is decided by the array mechanics of BinaryHeap alone (which leaf a push lands on, which child a pop
 # prefers, where a carried value stops) — with R = 48 a visit pushes up to 48 candidates in one run.
-@pytest.mark.parametrize("regime", ["default", "tableless", "heap_spill_tableless"])
+@pytest.mark.parametrize("regime", ["default", "tableless", "heap_spill_tableless", "tableless_virgin"])
 def test_heavy_ties_deep_heap(gpu_ctx, regime):
     ti = cached_index(n=6000, dim_full=24, bits=1, R=48, distance=1, seed=31, kind="gauss", L_build=60)
     ix = ti.upload(gpu_ctx)

@@ -413,6 +413,9 @@ int vs_rescan(vs_scan* scan, const float* query, const int16_t* labels, uint32_t
               uint32_t search_list_size, uint32_t rescore);                       /* amrescan */
 /* returns 1 and fills the outputs for the next row, 0 at end of scan, <0 on error */
 int vs_gettuple(vs_scan* scan, uint64_t* heap_tid, uint32_t* node, float* dist); /* amgettuple */
+/* optional hint: the executor will pull `rows` rows in all (a LIMIT it knows): they are produced by one continuation instead
+ * of several.  Fewer rows become available when the scan ends first; never an error to ask for more than exist. */
+int vs_scan_prefetch(vs_scan* scan, uint32_t rows);
 int vs_scan_xs_recheck(const vs_scan* scan);
 /* GreedySearchStats as the reference's scan holds them after the amgettuple calls made so far (AM/stats.rs:68-125,
  * AM/scan.rs:461-472): the counters are recorded per emitted row, so prefetched rows do not show (zero on a broker scan). */
@@ -441,6 +444,7 @@ typedef struct vs_broker_stats {
     uint64_t batches;   /* vs_search_batch calls made                */
     uint64_t scans;     /* scans served                              */
     uint64_t max_batch; /* largest number of scans in one launch     */
+    uint64_t tasks;     /* single-scan pieces of work run by the dispatcher between launches (cursor continuations) */
 } vs_broker_stats;
 int vs_broker_create(vs_index* idx, const vs_broker_config* cfg /* NULL = defaults */, vs_broker** out);
 /* one scan: the rows of its first k amgettuple calls (as vs_search_batch).  query == NULL: the SQL-NULL query (label keys
@@ -456,9 +460,19 @@ int vs_broker_search_snapshot(vs_broker* b, const float* query, const int16_t* l
 int vs_broker_snapshot_put(vs_broker* b, uint32_t snapshot, const uint8_t* visible);
 int vs_broker_get_stats(vs_broker* b, vs_broker_stats* out);
 vs_index* vs_broker_index(vs_broker* b);
-/* the amrescan / amgettuple mirror on top of a broker: like vs_beginscan, but every window of rows is fetched through
- * vs_broker_search, so scans of many threads (backends) share launches; vs_rescan / vs_gettuple / vs_endscan as usual */
+/* the amrescan / amgettuple mirror on top of a broker: like vs_beginscan, but the scan's first 16 rows come out of a launch
+ * shared with the scans of other threads (backends) — a LIMIT <= 16 never needs more — and an executor that keeps pulling gets a
+ * cursor of its own on the device, opened, continued and released on the dispatcher thread (vs_broker_call): from then on the
+ * scan is continued, never re-run, and vs_scan_get_stats is exact as for a direct scan (for a scan that only ever used the
+ * shared launch it replays the scan on a cursor when asked).  vs_rescan / vs_gettuple / vs_endscan as usual; end a broker's
+ * scans before vs_broker_destroy. */
 int vs_beginscan_on_broker(vs_broker* b, vs_scan** out);
+/* the visibility mask (vs_broker_snapshot_put) a scan on a broker runs under, from its next vs_rescan on (0 = every tuple
+ * visible, the default).  A direct scan runs under the index's current mask instead. */
+int vs_scan_set_snapshot(vs_scan* scan, uint32_t snapshot);
+/* runs fn(arg) on the dispatcher thread between two launches and returns its result (the error text comes along): the way work
+ * on ONE scan's device state reaches the only thread that may touch the index.  Thread safe; blocks. */
+int vs_broker_call(vs_broker* b, int (*fn)(void*), void* arg);
 void vs_broker_destroy(vs_broker* b); /* serves what is queued, then stops the dispatcher */
 
 /* ---- the same across PROCESSES (vs_shm.cpp): PostgreSQL backends are processes, so the request queue is a POSIX shared-memory
@@ -484,6 +498,15 @@ int vs_shm_client_search(vs_shm_client* c, const float* query, const int16_t* la
 int vs_shm_client_search_snapshot(vs_shm_client* c, const float* query, const int16_t* labels, uint32_t n_labels, int has_label_key,
                                   uint32_t search_list_size, uint32_t rescore, uint32_t k, uint32_t snapshot, uint32_t* out_ids,
                                   uint64_t* out_tids, float* out_dist);
+/* amgettuple beyond the first rows, across processes: rows [skip, skip + k) of the scan this process calls `scan_id` (k <= kmax;
+ * *n_rows < k: the scan has ended).  The serving process keeps a cursor on the device for the scan (lsr + resort_buffer of
+ * AM/scan.rs:162-174) and continues it from request to request; every request carries the whole scan description, so a cursor
+ * the server no longer has — or never had, because the first rows came from vs_shm_client_search — is opened and fast-forwarded
+ * to `skip` (one replay) and continued from there.  vs_shm_client_end_scan drops the cursor (so does the death of the client). */
+int vs_shm_client_fetch(vs_shm_client* c, uint64_t scan_id, const float* query, const int16_t* labels, uint32_t n_labels,
+                        int has_label_key, uint32_t search_list_size, uint32_t rescore, uint32_t snapshot, uint32_t skip, uint32_t k,
+                        uint32_t* out_ids, uint64_t* out_tids, float* out_dist, uint32_t* n_rows);
+int vs_shm_client_end_scan(vs_shm_client* c, uint64_t scan_id);
 /* serving process: a snapshot's mask (n host bytes, copied; NULL drops it); in place before the next group is formed */
 int vs_shm_server_snapshot_put(vs_shm_server* s, uint32_t snapshot, const uint8_t* visible);
 void vs_shm_client_close(vs_shm_client* c);

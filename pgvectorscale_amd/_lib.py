@@ -92,7 +92,7 @@ class BrokerConfig(C.Structure):
 
 
 class BrokerStats(C.Structure):
-    _fields_ = [("batches", C.c_uint64), ("scans", C.c_uint64), ("max_batch", C.c_uint64)]
+    _fields_ = [("batches", C.c_uint64), ("scans", C.c_uint64), ("max_batch", C.c_uint64), ("tasks", C.c_uint64)]
 
 
 class Profile(C.Structure):
@@ -192,6 +192,11 @@ SYMBOLS = {
     "vs_broker_destroy": (None, [_vp]),
     "vs_broker_index": (_vp, [_vp]),
     "vs_beginscan_on_broker": (_i, [_vp, C.POINTER(_vp)]),
+    "vs_broker_call": (_i, [_vp, _vp, _vp]),
+    "vs_scan_set_snapshot": (_i, [_vp, _u32]),
+    "vs_scan_prefetch": (_i, [_vp, _u32]),
+    "vs_shm_client_fetch": (_i, [_vp, C.c_uint64, _vp, _vp, _u32, _i, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, C.POINTER(_u32)]),
+    "vs_shm_client_end_scan": (_i, [_vp, C.c_uint64]),
     "vs_shm_server_create": (_i, [_vp, C.c_char_p, _u32, _u32, C.POINTER(BrokerConfig), C.POINTER(_vp)]),
     "vs_shm_server_get_stats": (_i, [_vp, C.POINTER(BrokerStats)]),
     "vs_shm_server_destroy": (None, [_vp]),

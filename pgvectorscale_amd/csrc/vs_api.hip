@@ -1455,6 +1455,7 @@ struct ScanCursor {
     uint32_t rows_cap = 0;    // capacity of all_ids / all_ham / all_dist (rows)
     uint32_t restarts = 0;    // times the scan was started again with larger capacities (since the rescan)
     uint32_t launches = 0;
+    bool masked = false;      // the launches ran under a heap-visibility mask (rows hidden by it still cost a heap fetch)
     DevBuf raw_q, q_full, q_index, qcodes, qlabels, qlabel_off, heap_g, hash, state, cnt, stats, status, row_stats, all_ids, all_ham,
         all_dist, resort_heap, cur, out_ids, out_tids, out_dist;
     std::vector<uint32_t> row_stats_h;  // [rows][ST_N] counters at the emission of each row
@@ -1470,7 +1471,9 @@ struct ScanCursor {
 
 struct vs_scan {
     vs_index* ix = nullptr;
-    vs_broker* broker = nullptr;  // non-null: windows are fetched through the broker (shared launches, any thread)
+    vs_broker* broker = nullptr;  // non-null: the first window comes from a shared launch, the rest from a cursor on the dispatcher thread
+    uint32_t snapshot = 0;        // (broker scans) visibility mask the scan runs under
+    uint32_t snapshot_next = 0;   // ... from the next vs_rescan on (vs_scan_set_snapshot)
     bool active = false;
     bool null_query = false;
     std::vector<float> query;
@@ -1488,6 +1491,7 @@ struct vs_scan {
     ScanCursor cur;
     ~vs_scan() { cur.free_all(); }
 };
+extern "C" int vs_broker_call(vs_broker* b, int (*fn)(void*), void* arg);
 
 extern "C" int vs_beginscan(vs_index* ix, vs_scan** out) {
     VS_REQUIRE(ix && out, "vs_beginscan: bad args");
@@ -1633,6 +1637,7 @@ static int cursor_extend(vs_scan* s, uint32_t want_rows) {
         sl.stats = (uint32_t*)k.stats.p;
         sl.status = (uint32_t*)k.status.p;
         sl.visible = S > 0 ? ix->visible : nullptr;  // the heap is only fetched for the rescore window
+        k.masked = sl.visible != nullptr;
         sl.resume = (uint32_t*)k.state.p;
         sl.resume_stride = 0;
         sl.row_stats = (uint32_t*)k.row_stats.p;
@@ -1760,8 +1765,8 @@ static int scan_fetch(vs_scan* s, uint32_t window) {
     s->tids.assign(window, 0);
     s->dist.assign(window, 0.f);
     const bool keys = s->has_label_key && !s->null_query;
-    VS_TRY(vs_broker_search(s->broker, s->null_query ? nullptr : s->query.data(), s->labels.data(), (uint32_t)s->labels.size(),
-                            keys ? 1 : 0, s->L, s->rescore, window, s->ids.data(), s->tids.data(), s->dist.data()));
+    VS_TRY(vs_broker_search_snapshot(s->broker, s->null_query ? nullptr : s->query.data(), s->labels.data(), (uint32_t)s->labels.size(),
+                                     keys ? 1 : 0, s->L, s->rescore, window, s->snapshot, s->ids.data(), s->tids.data(), s->dist.data()));
     s->stats = vs_stats{};  // the counters of a shared launch are not attributed to single scans
     (void)ix;
     s->window = window;
@@ -1773,6 +1778,34 @@ static int scan_fetch(vs_scan* s, uint32_t window) {
             break;
         }
     return VS_OK;
+}
+
+// A scan on a broker continues on the dispatcher thread (the only one that may touch the index): its cursor is opened there, run
+// under the scan's snapshot mask, and released there.  The rows a shared launch already produced are reproduced by the
+// deterministic scan once and skipped (cursor_fetch), after that the scan is only ever continued.
+struct BrokerCursorTask {
+    vs_scan* s;
+    uint32_t target;
+    bool release;
+};
+static int broker_cursor_task(void* p) {
+    BrokerCursorTask* t = static_cast<BrokerCursorTask*>(p);
+    vs_scan* s = t->s;
+    if (t->release) {
+        s->cur.free_all();
+        return VS_OK;
+    }
+    return vs_guard("vs_gettuple", [&] {
+        const uint8_t* prev = nullptr;
+        VS_TRY(vs_index_snapshot_use(s->ix, s->snapshot, &prev));
+        const int r = cursor_fetch(s, t->target);
+        (void)vs_index_set_visibility_dev(s->ix, prev);  // (leaves the error text of a failed fetch alone)
+        return r;
+    });
+}
+static int broker_cursor_fetch(vs_scan* s, uint32_t target) {
+    BrokerCursorTask t{s, target, false};
+    return vs_broker_call(s->broker, broker_cursor_task, &t);
 }
 
 static int vs_rescan_impl(vs_scan* s, const float* query, const int16_t* labels, uint32_t n_labels, int has_label_key,
@@ -1788,6 +1821,7 @@ static int vs_rescan_impl(vs_scan* s, const float* query, const int16_t* labels,
     s->has_label_key = has_label_key != 0;
     s->L = L;
     s->rescore = rescore;
+    s->snapshot = s->snapshot_next;
     s->cursor = 0;
     s->window = 0;
     s->calls_after_end = 0;
@@ -1817,14 +1851,16 @@ static int vs_gettuple_impl(vs_scan* s, uint64_t* heap_tid, uint32_t* node, floa
     }
     if (s->cursor >= s->window && !s->exhausted) {
         int r;
-        if (s->broker) {
-            // windows grow by four (16, 64, 256, ...): the scan is deterministic, so a larger window reproduces the rows already
-            // handed out and an executor that keeps pulling pays at most 4/3 of its final scan in re-runs (a LIMIT <= 16 pays one)
-            r = scan_fetch(s, s->window == 0 ? 16u : s->window * 4);
+        // continue the scan on the device for a few rows more than asked for (1/16 of what was pulled so far, 8..256): the
+        // launch overhead is shared by those rows and the scan never runs more than ~6 % ahead of the executor
+        const uint32_t ahead = std::min<uint32_t>(256, std::max<uint32_t>(8, s->cursor / 16));
+        if (s->broker && s->window == 0 && !s->cur.open) {
+            // the first rows of a scan on a broker come out of a launch shared with the other backends' scans (a LIMIT <= 16 never
+            // needs more); an executor that keeps pulling gets a cursor of its own, which runs the first rows once more
+            r = scan_fetch(s, 16u);
+        } else if (s->broker) {
+            r = broker_cursor_fetch(s, s->cursor + ahead);
         } else {
-            // continue the scan on the device for a few rows more than asked for (1/16 of what was pulled so far, 8..256): the
-            // launch overhead is shared by those rows and the scan never runs more than ~6 % ahead of the executor
-            const uint32_t ahead = std::min<uint32_t>(256, std::max<uint32_t>(8, s->cursor / 16));
             r = cursor_fetch(s, s->cursor + ahead);
         }
         if (r != VS_OK) return r;
@@ -1852,9 +1888,15 @@ extern "C" int vs_scan_xs_recheck(const vs_scan* s) { return (s && s->has_label_
 // the stream has ended every further call asks next() once more in vain.
 extern "C" int vs_scan_get_stats(const vs_scan* s, vs_stats* out) {
     VS_REQUIRE(s && out, "vs_scan_get_stats: bad args");
-    if (s->broker || !s->cur.open) {
-        *out = s->stats;
-        return VS_OK;
+    if (!s->cur.open) {
+        if (!s->broker || !s->active || s->cursor + s->calls_after_end == 0) {
+            *out = s->stats;
+            return VS_OK;
+        }
+        // a scan on a broker whose rows so far came out of a shared launch (whose counters belong to no single scan): the scan is
+        // replayed on a cursor of its own up to the executor's position, which is where the reference's counters stand
+        vs_scan* m = const_cast<vs_scan*>(s);
+        VS_TRY(broker_cursor_fetch(m, std::max<uint32_t>(m->cursor + (m->calls_after_end ? 1u : 0u), 1u)));
     }
     const ScanCursor& k = s->cur;
     const vs_index* ix = s->ix;
@@ -1890,7 +1932,7 @@ extern "C" int vs_scan_get_stats(const vs_scan* s, vs_stats* out) {
     st.node_reads = r[ST_READS];
     st.next_calls = next_calls;
     if (S > 0) {
-        const uint64_t nr = rows_used + (ix->visible ? r[ST_INVIS] : 0u);
+        const uint64_t nr = rows_used + (k.masked ? r[ST_INVIS] : 0u);
         st.full_distance_comparisons += nr;
         st.node_heap_reads += nr;
     }
@@ -1917,4 +1959,34 @@ extern "C" int vs_scan_get_work(const vs_scan* s, vs_stats* out, uint32_t* launc
     return VS_OK;
 }
 
-extern "C" void vs_endscan(vs_scan* s) { delete s; }
+extern "C" void vs_endscan(vs_scan* s) {
+    if (!s) return;
+    if (s->broker && (s->cur.open || s->cur.state.p)) {  // the cursor's device buffers go where they came from: the dispatcher thread
+        BrokerCursorTask t{s, 0, true};
+        (void)vs_broker_call(s->broker, broker_cursor_task, &t);  // (a broker that is shutting down: freed below, by this thread)
+    }
+    delete s;
+}
+
+extern "C" int vs_scan_set_snapshot(vs_scan* s, uint32_t snapshot) {
+    VS_REQUIRE(s && snapshot < VS_MAX_SNAPSHOTS, "vs_scan_set_snapshot: snapshot id outside [0,%d]", VS_MAX_SNAPSHOTS - 1);
+    VS_REQUIRE(s->broker, "vs_scan_set_snapshot: a direct scan runs under the index's current mask (vs_index_set_visibility)");
+    s->snapshot_next = snapshot;
+    return VS_OK;
+}
+
+static int vs_scan_prefetch_impl(vs_scan* s, uint32_t rows) {
+    if (!s || !s->active) {
+        vs_set_error("vs_scan_prefetch before vs_rescan");
+        return VS_ERR_STATE;
+    }
+    if (rows <= s->window || s->exhausted) return VS_OK;
+    if (s->broker && s->window == 0 && !s->cur.open) {
+        VS_TRY(scan_fetch(s, std::min<uint32_t>(rows, 1024u)));  // (a shared launch hands out up to 1024 rows per scan)
+        if (rows <= s->window || s->exhausted) return VS_OK;
+    }
+    return s->broker ? broker_cursor_fetch(s, rows) : cursor_fetch(s, rows);
+}
+extern "C" int vs_scan_prefetch(vs_scan* s, uint32_t rows) {
+    return vs_guard("vs_scan_prefetch", [&] { return vs_scan_prefetch_impl(s, rows); });
+}

@@ -40,6 +40,8 @@ struct Request {
     uint32_t snapshot = 0;             // visibility mask the scan runs under (0 = every tuple visible)
     bool is_put = false;               // control request: install `put_mask` (n bytes or nullptr) as mask `snapshot`
     const uint8_t* put_mask = nullptr;
+    int (*task)(void*) = nullptr;      // control request: run task(task_arg) on the dispatcher thread (scan cursors: vs_broker_call)
+    void* task_arg = nullptr;
     uint32_t* out_ids;
     uint64_t* out_tids;
     float* out_dist;
@@ -52,7 +54,7 @@ struct Request {
 
     bool same_group(const Request& o) const {
         // (scans of different snapshots never share a launch: a launch runs under ONE visibility mask)
-        return !is_put && !o.is_put && L == o.L && rescore == o.rescore && k == o.k && has_label_key == o.has_label_key &&
+        return !is_put && !o.is_put && !task && !o.task && L == o.L && rescore == o.rescore && k == o.k && has_label_key == o.has_label_key &&
                snapshot == o.snapshot;
     }
 };
@@ -157,12 +159,21 @@ void vs_broker::run() {
         // one group = the scans that share the oldest request's GUCs (a NULL query never carries a label key)
         std::vector<Request*> grp;
         Request* head = queue.front();
-        if (head->is_put) {  // a snapshot mask to install: done here, on the only thread that touches the index
+        if (head->is_put || head->task) {  // a snapshot mask to install, or a piece of work on one scan's cursor: done here, on
+                                            // the only thread that touches the index
             queue.pop_front();
             lk.unlock();
-            const int prc = vs_index_snapshot_put(ix, head->snapshot, head->put_mask);
-            const std::string perr = prc == VS_OK ? "" : vs_last_error();
+            int prc;
+            std::string perr;
+            try {
+                prc = head->task ? head->task(head->task_arg) : vs_index_snapshot_put(ix, head->snapshot, head->put_mask);
+                if (prc != VS_OK) perr = vs_last_error();
+            } catch (const std::bad_alloc&) {
+                prc = VS_ERR_OOM;
+                perr = "vs_broker: out of host memory in a dispatcher task";
+            }
             lk.lock();
+            if (head->task) st.tasks++;
             head->rc = prc;
             head->err = perr;
             head->done = true;
@@ -272,6 +283,39 @@ int vs_broker_snapshot_put(vs_broker* b, uint32_t snapshot, const uint8_t* visib
         return VS_ERR_STATE;
     }
     b->queue.push_back(&r);  // behind the scans already queued: they run under the mask they were posted with
+    b->cv_work.notify_one();
+    r.cv.wait(lk, [&] { return r.done; });
+    lk.unlock();
+    if (r.rc != VS_OK) vs_set_error("%s", r.err.c_str());
+    return r.rc;
+}
+
+// Runs fn(arg) on the dispatcher thread, between two launches, and returns its result: how work that belongs to ONE scan (the
+// continuation of its cursor on the device, the release of its device buffers) reaches the only thread allowed to touch the index.
+// A non-zero result carries the dispatcher thread's vs_last_error() text over to the caller's.
+int vs_broker_call(vs_broker* b, int (*fn)(void*), void* arg) {
+    if (!b || !fn) {
+        vs_set_error("vs_broker_call: null argument");
+        return VS_ERR_INVALID;
+    }
+    if (std::this_thread::get_id() == b->dispatcher.get_id()) return fn(arg);  // (already there)
+    Request r;
+    r.query = nullptr;
+    r.has_label_key = false;
+    r.L = r.rescore = r.k = 0;
+    r.out_ids = nullptr;
+    r.out_tids = nullptr;
+    r.out_dist = nullptr;
+    r.task = fn;
+    r.task_arg = arg;
+    r.t_arrive = std::chrono::steady_clock::now() - std::chrono::hours(1);  // (no waiting for company)
+    std::unique_lock<std::mutex> lk(b->mu);
+    if (b->stop) {
+        vs_set_error("vs_broker_call: the broker is shutting down");
+        return VS_ERR_STATE;
+    }
+    // ahead of queued scans that are still gathering company: a continuation is one short launch and its backend is waiting
+    b->queue.push_front(&r);
     b->cv_work.notify_one();
     r.cv.wait(lk, [&] { return r.done; });
     lk.unlock();

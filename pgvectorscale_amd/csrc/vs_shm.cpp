@@ -15,6 +15,15 @@
 //   whose dispatcher PROCESS died (no orderly vs_shm_server_destroy) notices through the pid in the header and fails with
 //   VS_ERR_STATE instead of sleeping forever.  The dispatcher trusts nothing it reads from a slot: k, the GUCs and the label
 //   count are validated again on its side before a group is formed.
+//
+// Streaming (amgettuple beyond the first rows): a slot request is either OP_SEARCH — the first k rows, out of a launch shared
+// with the other backends' scans — or OP_FETCH: rows [skip, skip + k) of the scan (owner pid, scan_id), which the dispatcher
+// serves from a cursor it keeps for that scan on the device (a direct vs_scan of its own index: lsr + resort_buffer of
+// AM/scan.rs:162-174 live there between requests).  Every OP_FETCH carries the whole scan description, so a cursor the dispatcher
+// no longer has (evicted, or never opened because the first rows came from OP_SEARCH) is opened again and fast-forwarded to
+// `skip` — one replay — and then continued; OP_CLOSE drops it (so does the death of the owner, and the least recently used one
+// when more than max_cursors are open).
+#include <algorithm>
 #include <atomic>
 #include <condition_variable>
 #include <mutex>
@@ -45,7 +54,9 @@ void vs_set_error(const char* fmt, ...);
 namespace {
 
 constexpr uint32_t SHM_MAGIC = 0x56534851u;  // "VSHQ"
-constexpr uint32_t SHM_VERSION = 2;
+constexpr uint32_t SHM_VERSION = 3;
+constexpr size_t SHM_MAX_CURSORS = 1024;
+enum : uint32_t { OP_SEARCH = 0, OP_FETCH = 1, OP_CLOSE = 2 };
 constexpr uint32_t SHM_MAX_LABELS = 64;
 enum : uint32_t { S_FREE = 0, S_CLAIMED = 1, S_READY = 2, S_RUNNING = 3, S_DONE = 4, S_REAPING = 5 };
 
@@ -65,6 +76,11 @@ struct SlotHead {
     uint32_t L, rescore, k, n_labels, has_label_key, null_query;
     int32_t rc;
     uint32_t snapshot;  // visibility mask of the serving process the scan runs under (0 = every tuple visible)
+    uint32_t op;        // OP_*
+    uint32_t skip;      // OP_FETCH: rows of the scan the client already has
+    uint32_t n_rows;    // OP_FETCH, out: rows returned (< k: the scan has ended)
+    uint32_t pad0;
+    uint64_t scan_id;   // OP_FETCH / OP_CLOSE: the client's name for the scan (unique per client process)
     char err[168];
     int16_t labels[SHM_MAX_LABELS];
     // followed by: float query[dim_full]; uint64_t out_tids[kmax]; uint32_t out_ids[kmax]; float out_dist[kmax]
@@ -113,9 +129,21 @@ struct vs_shm_server {
     std::mutex put_mu;
     std::condition_variable put_cv;
     std::vector<PendingPut*> puts;
+    // cursors of the scans that are being streamed (OP_FETCH), touched by the dispatcher thread only
+    struct Cursor {
+        int32_t pid = 0;
+        uint64_t scan_id = 0, sig = 0, last_use = 0;
+        uint32_t pos = 0;  // rows handed out so far
+        vs_scan* scan = nullptr;
+    };
+    std::vector<Cursor> cursors;
+    uint64_t use_clock = 0;
+    std::atomic<uint64_t> fetches{0}, cursor_opens{0};
     void apply_puts();
     void run();
     void run_group(const std::vector<uint32_t>& grp);
+    void run_fetch(uint32_t slot);
+    void drop_cursor(size_t i);
 };
 
 struct vs_shm_client {
@@ -178,6 +206,114 @@ void vs_shm_server::run_group(const std::vector<uint32_t>& grp) {
     }
 }
 
+void vs_shm_server::drop_cursor(size_t i) {
+    vs_endscan(cursors[i].scan);
+    cursors[i] = cursors.back();
+    cursors.pop_back();
+}
+
+// what identifies the scan a cursor belongs to besides (pid, scan_id): a client that reuses an id for another scan gets a new cursor
+static uint64_t scan_signature(const SlotHead* s, const float* q, uint32_t dim) {
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](const void* p, size_t n) {
+        const unsigned char* b = static_cast<const unsigned char*>(p);
+        for (size_t i = 0; i < n; ++i) h = (h ^ b[i]) * 1099511628211ull;
+    };
+    const uint32_t g[6] = {s->L, s->rescore, s->has_label_key, s->null_query, s->snapshot, s->n_labels};
+    mix(g, sizeof(g));
+    if (!s->null_query) mix(q, (size_t)dim * 4);
+    mix(s->labels, (size_t)std::min(s->n_labels, SHM_MAX_LABELS) * 2);
+    return h;
+}
+
+void vs_shm_server::run_fetch(uint32_t slot) {
+    SlotHead* s = m.slot(slot);
+    int rc = VS_OK;
+    std::string err;
+    uint32_t got = 0;
+    const int32_t pid = s->owner_pid;
+    size_t at = cursors.size();
+    for (size_t i = 0; i < cursors.size(); ++i)
+        if (cursors[i].pid == pid && cursors[i].scan_id == s->scan_id) at = i;
+    try {
+        if (s->op == OP_CLOSE) {
+            if (at < cursors.size()) drop_cursor(at);
+        } else {
+            const uint64_t sig = scan_signature(s, Mapping::query(s), d.dim_full);
+            const uint8_t* prev = nullptr;
+            rc = vs_index_snapshot_use(ix, s->snapshot, &prev);
+            if (rc == VS_OK) {
+                if (at < cursors.size() && (cursors[at].sig != sig || cursors[at].pos != s->skip)) {
+                    drop_cursor(at);  // another scan under the same id, or a client that is somewhere else in it: start over
+                    at = cursors.size();
+                }
+                if (at == cursors.size()) {
+                    if (cursors.size() >= SHM_MAX_CURSORS) {  // make room: the least recently used cursor goes
+                        size_t lru = 0;
+                        for (size_t i = 1; i < cursors.size(); ++i)
+                            if (cursors[i].last_use < cursors[lru].last_use) lru = i;
+                        drop_cursor(lru);
+                    }
+                    Cursor c;
+                    c.pid = pid;
+                    c.scan_id = s->scan_id;
+                    c.sig = sig;
+                    rc = vs_beginscan(ix, &c.scan);
+                    if (rc == VS_OK)
+                        rc = vs_rescan(c.scan, s->null_query ? nullptr : Mapping::query(s), s->labels, std::min(s->n_labels, SHM_MAX_LABELS),
+                                       (int)s->has_label_key, s->L, s->rescore);
+                    if (rc == VS_OK) rc = vs_scan_prefetch(c.scan, s->skip + s->k);  // (one launch for the replay and the new rows)
+                    for (uint32_t i = 0; rc == VS_OK && i < s->skip; ++i) {  // fast-forward: the client has these rows
+                        const int r = vs_gettuple(c.scan, nullptr, nullptr, nullptr);
+                        if (r < 0) rc = r;
+                        if (r <= 0) break;
+                        c.pos++;
+                    }
+                    if (rc == VS_OK) {
+                        cursors.push_back(c);
+                        at = cursors.size() - 1;
+                        cursor_opens++;
+                    } else {
+                        err = vs_last_error();
+                        if (c.scan) vs_endscan(c.scan);
+                    }
+                } else {
+                    rc = vs_scan_prefetch(cursors[at].scan, cursors[at].pos + s->k);
+                    if (rc != VS_OK) err = vs_last_error();
+                }
+                if (rc == VS_OK) {
+                    Cursor& c = cursors[at];
+                    c.last_use = ++use_clock;
+                    // (a fast-forward that fell short: the scan has fewer rows than the client skipped — nothing left to return)
+                    while (c.pos >= s->skip && got < s->k) {
+                        const int r = vs_gettuple(c.scan, m.tids(s) + got, m.ids(s) + got, m.dist(s) + got);
+                        if (r < 0) {
+                            rc = r;
+                            err = vs_last_error();
+                            break;
+                        }
+                        if (r == 0) break;
+                        got++;
+                        c.pos++;
+                    }
+                }
+                (void)vs_index_set_visibility_dev(ix, prev);
+            } else {
+                err = vs_last_error();
+            }
+        }
+    } catch (const std::bad_alloc&) {
+        rc = VS_ERR_OOM;
+        err = "vs_shm: out of host memory while serving a scan cursor";
+    }
+    fetches++;
+    s->n_rows = rc == VS_OK ? got : 0;
+    s->rc = rc;
+    snprintf(s->err, sizeof(s->err), "%s", err.c_str());
+    s->state.store(S_DONE, std::memory_order_release);
+    futex_wake(&s->state, 1);
+}
+
 void vs_shm_server::apply_puts() {
     std::unique_lock<std::mutex> lk(put_mu);
     if (puts.empty()) return;
@@ -232,6 +368,8 @@ void vs_shm_server::run() {
                 else if (sa->L < 1 || sa->L > 10000) why = "diskann.query_search_list_size outside [1,10000]";
                 else if (sa->rescore > 1000) why = "diskann.query_rescore outside [0,1000]";
                 else if (sa->snapshot >= VS_MAX_SNAPSHOTS) why = "snapshot id out of range";
+                else if (sa->op > OP_CLOSE) why = "unknown request kind";
+                else if (sa->op == OP_FETCH && (uint64_t)sa->skip + sa->k > (1u << 30)) why = "row position out of range";
                 if (!why) {
                     ++a;
                     continue;
@@ -246,6 +384,13 @@ void vs_shm_server::run() {
                 ready.erase(ready.begin() + (long)a);
             }
             std::vector<bool> taken(ready.size(), false);
+            for (size_t a = 0; a < ready.size(); ++a) {  // cursor requests: one scan each, served one after the other
+                SlotHead* ha = m.slot(ready[a]);
+                if (ha->op == OP_SEARCH) continue;
+                taken[a] = true;
+                ha->state.store(S_RUNNING, std::memory_order_relaxed);
+                run_fetch(ready[a]);
+            }
             for (size_t a = 0; a < ready.size(); ++a) {
                 if (taken[a]) continue;
                 SlotHead* ha = m.slot(ready[a]);
@@ -278,8 +423,12 @@ void vs_shm_server::run() {
                     s->state.store(S_FREE, std::memory_order_release);
                 }
             }
+            for (size_t i = 0; i < cursors.size();)  // ... and its cursors their device memory
+                if (cursors[i].pid > 0 && kill(cursors[i].pid, 0) != 0 && errno == ESRCH) drop_cursor(i);
+                else ++i;
         }
     }
+    while (!cursors.empty()) drop_cursor(cursors.size() - 1);
     // shutting down: fail what is still posted so that no client sleeps forever
     for (uint32_t i = 0; i < h->nslots; ++i) {
         SlotHead* s = m.slot(i);
@@ -360,6 +509,7 @@ int vs_shm_server_get_stats(vs_shm_server* s, vs_broker_stats* out) {
     out->batches = s->batches.load();
     out->scans = s->scans.load();
     out->max_batch = s->max_batch.load();
+    out->tasks = s->fetches.load();
     return VS_OK;
 }
 
@@ -459,10 +609,10 @@ int vs_shm_client_search(vs_shm_client* c, const float* query, const int16_t* la
                                          out_dist);
 }
 
-int vs_shm_client_search_snapshot(vs_shm_client* c, const float* query, const int16_t* labels, uint32_t n_labels, int has_label_key,
-                                  uint32_t search_list_size, uint32_t rescore, uint32_t k, uint32_t snapshot, uint32_t* out_ids,
-                                  uint64_t* out_tids, float* out_dist) {
-    if (!c || !out_ids || k == 0 || snapshot >= VS_MAX_SNAPSHOTS) {
+static int client_request(vs_shm_client* c, uint32_t op, uint64_t scan_id, uint32_t skip, const float* query, const int16_t* labels,
+                          uint32_t n_labels, int has_label_key, uint32_t search_list_size, uint32_t rescore, uint32_t k,
+                          uint32_t snapshot, uint32_t* out_ids, uint64_t* out_tids, float* out_dist, uint32_t* n_rows) {
+    if (!c || (!out_ids && op != OP_CLOSE) || k == 0 || snapshot >= VS_MAX_SNAPSHOTS) {
         vs_set_error("vs_shm_client_search: bad arguments");
         return VS_ERR_INVALID;
     }
@@ -491,6 +641,10 @@ int vs_shm_client_search_snapshot(vs_shm_client* c, const float* query, const in
         if (!s) usleep(spin < 10 ? 50 : 1000);  // every slot busy: more scans in flight than slots
     }
     s->owner_pid = (int32_t)getpid();
+    s->op = op;
+    s->scan_id = scan_id;
+    s->skip = skip;
+    s->n_rows = 0;
     s->L = search_list_size;
     s->rescore = rescore;
     s->k = k;
@@ -523,16 +677,41 @@ int vs_shm_client_search_snapshot(vs_shm_client* c, const float* query, const in
         futex_wait(&s->state, st, 100000);  // (the timeout is the cadence of the liveness check above)
     }
     const int rc = s->rc;
-    if (rc == VS_OK) {
-        memcpy(out_ids, c->m.ids(s), (size_t)k * 4);
-        if (out_tids) memcpy(out_tids, c->m.tids(s), (size_t)k * 8);
-        if (out_dist) memcpy(out_dist, c->m.dist(s), (size_t)k * 4);
-    } else {
+    if (rc == VS_OK && op != OP_CLOSE) {
+        const uint32_t rows = op == OP_FETCH ? std::min(s->n_rows, k) : k;
+        memcpy(out_ids, c->m.ids(s), (size_t)rows * 4);
+        if (out_tids) memcpy(out_tids, c->m.tids(s), (size_t)rows * 8);
+        if (out_dist) memcpy(out_dist, c->m.dist(s), (size_t)rows * 4);
+        if (n_rows) *n_rows = rows;
+    } else if (rc != VS_OK) {
         vs_set_error("%s", s->err);
     }
     s->owner_pid = 0;
     s->state.store(S_FREE, std::memory_order_release);
     return rc;
+}
+
+int vs_shm_client_search_snapshot(vs_shm_client* c, const float* query, const int16_t* labels, uint32_t n_labels, int has_label_key,
+                                  uint32_t search_list_size, uint32_t rescore, uint32_t k, uint32_t snapshot, uint32_t* out_ids,
+                                  uint64_t* out_tids, float* out_dist) {
+    return client_request(c, OP_SEARCH, 0, 0, query, labels, n_labels, has_label_key, search_list_size, rescore, k, snapshot, out_ids,
+                          out_tids, out_dist, nullptr);
+}
+
+int vs_shm_client_fetch(vs_shm_client* c, uint64_t scan_id, const float* query, const int16_t* labels, uint32_t n_labels,
+                        int has_label_key, uint32_t search_list_size, uint32_t rescore, uint32_t snapshot, uint32_t skip, uint32_t k,
+                        uint32_t* out_ids, uint64_t* out_tids, float* out_dist, uint32_t* n_rows) {
+    if (!n_rows) {
+        vs_set_error("vs_shm_client_fetch: n_rows is NULL");
+        return VS_ERR_INVALID;
+    }
+    *n_rows = 0;
+    return client_request(c, OP_FETCH, scan_id, skip, query, labels, n_labels, has_label_key, search_list_size, rescore, k, snapshot,
+                          out_ids, out_tids, out_dist, n_rows);
+}
+
+int vs_shm_client_end_scan(vs_shm_client* c, uint64_t scan_id) {
+    return client_request(c, OP_CLOSE, scan_id, 0, nullptr, nullptr, 0, 0, 1, 0, 1, 0, nullptr, nullptr, nullptr, nullptr);
 }
 
 void vs_shm_client_close(vs_shm_client* c) {

@@ -428,7 +428,7 @@ class Broker:
     def stats(self):
         st = _lib.BrokerStats()
         check(self._L.vs_broker_get_stats(self.h, C.byref(st)))
-        return {"batches": int(st.batches), "scans": int(st.scans), "max_batch": int(st.max_batch)}
+        return {"batches": int(st.batches), "scans": int(st.scans), "max_batch": int(st.max_batch), "tasks": int(st.tasks)}
 
     def close(self):
         if self.h:
@@ -458,7 +458,7 @@ class ShmServer:
     def stats(self):
         st = _lib.BrokerStats()
         check(self._L.vs_shm_server_get_stats(self.h, C.byref(st)))
-        return {"batches": int(st.batches), "scans": int(st.scans), "max_batch": int(st.max_batch)}
+        return {"batches": int(st.batches), "scans": int(st.scans), "max_batch": int(st.max_batch), "tasks": int(st.tasks)}
 
     def close(self):
         if self.h:
@@ -487,10 +487,85 @@ class ShmClient:
                                                     search_list_size, rescore, k, snapshot, _p(ids), _p(tids), _p(dist)))
         return ids, tids, dist
 
+    def fetch(self, scan_id, query, skip, k, labels=None, search_list_size=DEFAULT_QUERY_SEARCH_LIST_SIZE, rescore=DEFAULT_QUERY_RESCORE,
+              snapshot=0):
+        """rows [skip, skip + k) of the scan this process calls scan_id, continued on the serving process's cursor for it (fewer
+        than k rows: the scan has ended)"""
+        q = None if query is None else np.ascontiguousarray(query, np.float32).reshape(self.dim)
+        lab = None if labels is None else np.ascontiguousarray(labels, np.int16)
+        ids = np.empty(k, np.uint32)
+        tids = np.empty(k, np.uint64)
+        dist = np.empty(k, np.float32)
+        n = C.c_uint32(0)
+        check(self._L.vs_shm_client_fetch(self.h, scan_id, _p(q), _p(lab), 0 if lab is None else lab.size, int(labels is not None),
+                                          search_list_size, rescore, snapshot, skip, k, _p(ids), _p(tids), _p(dist), C.byref(n)))
+        return ids[:n.value], tids[:n.value], dist[:n.value]
+
+    def end_scan(self, scan_id):
+        check(self._L.vs_shm_client_end_scan(self.h, scan_id))
+
+    def beginscan(self, chunk=16):
+        """the amrescan / amgettuple surface of a backend process: the first `chunk` rows come from a launch shared with the other
+        backends' scans, every later chunk continues the scan's cursor in the serving process"""
+        return ShmScan(self, chunk)
+
     def close(self):
         if self.h:
             self._L.vs_shm_client_close(self.h)
             self.h = None
+
+
+class ShmScan:
+    """IndexScanDesc of a backend process that reaches the device through a ShmClient."""
+
+    _next_id = 1
+
+    def __init__(self, client, chunk=16):
+        self.client = client
+        self.chunk = chunk
+        self.scan_id = ShmScan._next_id
+        ShmScan._next_id += 1
+        self._args = None
+        self._rows = []
+        self._pos = 0
+        self._streamed = False
+        self._ended = True
+
+    def rescan(self, query, labels=None, search_list_size=DEFAULT_QUERY_SEARCH_LIST_SIZE, rescore=DEFAULT_QUERY_RESCORE, snapshot=0):
+        if self._streamed:
+            self.client.end_scan(self.scan_id)
+        self.scan_id = ShmScan._next_id  # (a new scan: the serving process must not mistake it for the old one)
+        ShmScan._next_id += 1
+        self._args = dict(query=None if query is None else np.array(query, np.float32), labels=labels,
+                          search_list_size=search_list_size, rescore=rescore, snapshot=snapshot)
+        self._rows, self._pos, self._streamed, self._ended = [], 0, False, False
+
+    def gettuple(self):
+        """(heap_tid, node, distance) or None at end of scan"""
+        if self._pos >= len(self._rows) and not self._ended:
+            a = self._args
+            if not self._rows:  # the first rows: a shared launch
+                ids, tids, dist = self.client.search(a["query"], a["labels"], a["search_list_size"], a["rescore"], self.chunk, a["snapshot"])
+                keep = ids != 0xFFFFFFFF
+                n = int(keep.argmin()) if not keep.all() else len(ids)
+                ids, tids, dist = ids[:n], tids[:n], dist[:n]
+                self._ended = n < self.chunk
+            else:
+                ids, tids, dist = self.client.fetch(self.scan_id, a["query"], len(self._rows), self.chunk, a["labels"],
+                                                    a["search_list_size"], a["rescore"], a["snapshot"])
+                self._streamed = True
+                self._ended = len(ids) < self.chunk
+            self._rows.extend(zip(tids.tolist(), ids.tolist(), dist.tolist()))
+        if self._pos >= len(self._rows):
+            return None
+        r = self._rows[self._pos]
+        self._pos += 1
+        return r
+
+    def endscan(self):
+        if self._streamed:
+            self.client.end_scan(self.scan_id)
+            self._streamed = False
 
 
 class IndexScan:
@@ -531,6 +606,14 @@ class IndexScan:
         st = Stats()
         check(self._L.vs_scan_get_stats(self.h, C.byref(st)))
         return st.as_dict()
+
+    def set_snapshot(self, snapshot):
+        """(scan on a broker) the visibility mask the scan runs under from its next rescan() on"""
+        check(self._L.vs_scan_set_snapshot(self.h, snapshot))
+
+    def prefetch(self, rows):
+        """hint: the executor will pull `rows` rows in all"""
+        check(self._L.vs_scan_prefetch(self.h, rows))
 
     def work(self):
         """what the device really did for this scan since rescan() (prefetch and restarts included) + its launch count"""

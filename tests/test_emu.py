@@ -25,7 +25,8 @@ SUBSET = ("test_hip_path_reproduces_golden or test_index_from_pages_searches_lik
           "(test_rows_and_stats_one_row_at_a_time and (l2_window or labels_deleted)) or test_scan_that_outgrows_its_capacities or "
           "(test_wide_keys_host_batch and 1) or test_label_masks_for_any_label_values or test_backends_with_different_snapshots or "
           "test_snapshot_masks_across_processes or test_index_from_the_relation_alone or (test_every_regime_is_exact and tableless_epoch_wrap) or "
-          "(test_register_capped_variants and 6_virgin)")
+          "(test_register_capped_variants and 6_virgin) or test_amgettuple_mirror_on_a_broker or "
+          "test_backend_processes_stream_past_the_first_rows")
 
 
 @pytest.fixture(scope="module")

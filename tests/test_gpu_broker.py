@@ -89,7 +89,7 @@ def test_amgettuple_mirror_on_a_broker(gpu_ctx, oracle):
     broker = P.Broker(ix, max_batch=32, max_wait_us=20000)
     nthreads = 12
     q = ti.queries(nthreads, seed=5, kind="gauss")
-    rows, errors = {}, []
+    rows, errors, stats, work = {}, [], {}, {}
     start = threading.Barrier(nthreads)
 
     def backend(t):
@@ -98,12 +98,15 @@ def test_amgettuple_mirror_on_a_broker(gpu_ctx, oracle):
             start.wait()
             scan.rescan(q[t], search_list_size=30, rescore=10)
             out = []
-            for _ in range(45):  # past the first window of 16 rows: the scan is re-fetched with a doubled window
+            npull = 45 if t % 3 else 7  # past the first 16 rows (a shared launch) the scan continues on a cursor of its own
+            for _ in range(npull):
                 r = scan.gettuple()
                 if r is None:
                     break
                 out.append(r)
             rows[t] = out
+            stats[t] = scan.stats()
+            work[t] = scan.work()
             scan.endscan()
         except Exception as e:  # noqa: BLE001
             errors.append(repr(e))
@@ -120,9 +123,20 @@ def test_amgettuple_mirror_on_a_broker(gpu_ctx, oracle):
             o = os_.gettuple()
             assert o is not None and node == o[0] and tid == o[1]
             assert np.float32(d).view(np.uint32) == np.float32(o[2]).view(np.uint32)
-        assert len(rows[t]) == 45
+        assert len(rows[t]) == (45 if t % 3 else 7)
+        # GreedySearchStats are the reference's after that many amgettuple calls, whether the rows came from the cursor or (7 rows)
+        # from the shared launch alone, in which case the scan is replayed on a cursor when the statistics are asked for
+        ref = os_.stats()
+        for key in ("visited_nodes", "candidate_nodes", "quantized_distance_comparisons", "full_distance_comparisons", "node_reads",
+                    "node_heap_reads", "next_calls"):
+            assert stats[t][key] == ref[key], (t, key, stats[t][key], ref[key])
+        # continued, not repeated: one replay of the first 16 rows, then at most the prefetch allowance on top of the scan itself
+        assert work[t]["visited_nodes"] <= 1.1 * ref["visited_nodes"] + 16, (work[t], ref)
+        assert work[t]["retries"] == 0
     st = broker.stats()
     assert st["max_batch"] >= 3 and st["batches"] < st["scans"], st
+    assert st["scans"] == nthreads  # one shared-launch request per scan: nothing was fetched again with a larger window
+    assert st["tasks"] >= nthreads
     broker.close()
     ix.close()
 
@@ -185,5 +199,53 @@ def test_backends_with_different_snapshots_never_share_a_mask(gpu_ctx, oracle):
     broker.snapshot_put(2, None)
     with pytest.raises(P.VsError, match="no visibility mask"):
         broker.search(q[0], None, 20, 15, 10, snapshot=2)
+    broker.close()
+    ix.close()
+
+
+def test_broker_scan_under_a_snapshot_streams_like_the_oracle(gpu_ctx, oracle):
+    """a backend's scan on a broker runs under ITS snapshot's visibility mask in the shared launch and on its cursor alike, and the
+    prefetch hint makes the rows of a known LIMIT available without further continuations"""
+    import pgvectorscale_amd as P
+    O = oracle
+    ti = TestIndex(n=1800, dim_full=48, bits=2, R=24, distance=O.L2, seed=35, kind="clustered", L_build=48)
+    ix = ti.upload(gpu_ctx)
+    rng = np.random.default_rng(4)
+    mask = (rng.random(ti.n) > 0.4).astype(np.uint8)
+    own = (rng.random(ti.n) > 0.5).astype(np.uint8)
+    ix.set_visibility(own)  # a direct caller's mask: must neither leak into the broker's scans nor be lost
+    broker = P.Broker(ix, max_batch=8, max_wait_us=1000)
+    broker.snapshot_put(3, mask)
+    q = ti.queries(2, seed=9, kind="clustered")
+    scan = broker.beginscan()
+    for snap, m in ((3, mask), (0, None)):
+        scan.set_snapshot(snap)
+        scan.rescan(q[0], search_list_size=12, rescore=9)
+        ti.oracle.set_visibility(m)
+        os_ = ti.oracle.scan(q[0], L=12, rescore=9)
+        for j in range(80):
+            r, o = scan.gettuple(), os_.gettuple()
+            assert r is not None and o is not None and r[1] == o[0] and r[0] == o[1], (snap, j)
+            assert np.float32(r[2]).view(np.uint32) == np.float32(o[2]).view(np.uint32)
+        g, ref = scan.stats(), os_.stats()
+        for key in ("visited_nodes", "quantized_distance_comparisons", "full_distance_comparisons", "node_heap_reads", "next_calls"):
+            assert g[key] == ref[key], (snap, key, g[key], ref[key])
+    # LIMIT 40 announced: one shared launch hands out all 40 rows, no cursor is ever opened
+    tasks_before = broker.stats()["tasks"]
+    scan.rescan(q[1], search_list_size=12, rescore=9)
+    scan.prefetch(40)
+    ti.oracle.set_visibility(None)
+    os_ = ti.oracle.scan(q[1], L=12, rescore=9)
+    for j in range(40):
+        r, o = scan.gettuple(), os_.gettuple()
+        assert r[1] == o[0] and r[0] == o[1], j
+    assert broker.stats()["tasks"] == tasks_before
+    assert scan.work()["launches"] == 0
+    scan.endscan()
+    ti.oracle.set_visibility(own)
+    gi, _, _, _ = ix.search_batch(q[:2], search_list_size=20, rescore=15, k=10)
+    oi, _, _ = ti.oracle.search_batch(q[:2], L=20, rescore=15, k=10)
+    ti.oracle.set_visibility(None)
+    assert (gi == oi).all()
     broker.close()
     ix.close()

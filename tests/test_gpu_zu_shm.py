@@ -231,3 +231,104 @@ def test_client_notices_a_dispatcher_that_died(oracle):
         os.unlink("/dev/shm" + name)
     except OSError:
         pass
+
+
+def _streaming_client(name, lib_path, jobs, out_q):
+    """a backend process pulling rows one at a time (amgettuple): chunks of 8 through ShmScan"""
+    try:
+        from pgvectorscale_amd import _lib
+        if lib_path:
+            _lib.LIB_PATH = lib_path
+        import pgvectorscale_amd as P
+        c = P.ShmClient(name)
+        res = {}
+        scan = c.beginscan(chunk=8)
+        for (i, q, labels, L, S, nrows) in jobs:
+            scan.rescan(q, labels, L, S)
+            rows = []
+            for _ in range(nrows):
+                r = scan.gettuple()
+                if r is None:
+                    break
+                rows.append(r)
+            res[i] = rows
+        scan.endscan()
+        # a backend that lost track: rows 20..27 of its last scan under a new name — the server opens a cursor and fast-forwards
+        (i, q, labels, L, S, nrows) = jobs[-1]
+        ids, tids, dist = c.fetch(10_000 + i, q, 20, 8, labels, L, S)
+        res[("again", i)] = list(zip(tids.tolist(), ids.tolist(), dist.tolist()))
+        # ... and asks for the same rows once more (the cursor is past them: it starts over)
+        ids, tids, dist = c.fetch(10_000 + i, q, 20, 8, labels, L, S)
+        res[("again2", i)] = list(zip(tids.tolist(), ids.tolist(), dist.tolist()))
+        c.end_scan(10_000 + i)
+        c.end_scan(424242)  # (a name the server has never seen: nothing to drop, no error)
+        c.close()
+        out_q.put(("ok", res))
+    except Exception as e:  # noqa: BLE001
+        out_q.put(("err", repr(e)))
+
+
+def test_backend_processes_stream_past_the_first_rows(gpu_ctx, oracle):
+    """amgettuple across processes: the first chunk of a scan comes out of a shared launch, every later chunk continues the cursor
+    the serving process keeps for that scan (AM/scan.rs:162-174,370-405) — rows equal the oracle's streaming scan, one row at a
+    time, for plain, label-keyed, NULL and exhausted scans, from four processes at once"""
+    import pgvectorscale_amd as P
+    from pgvectorscale_amd import _lib
+    ti = TestIndex(**KW)
+    ix = ti.upload(gpu_ctx)
+    nproc = 4
+    q = ti.queries(nproc * 3, seed=81, kind="gauss")
+    jobs = [[] for _ in range(nproc)]
+    want = {}
+    for i in range(len(q)):
+        kind = i % 3
+        if kind == 0:
+            job = (i, q[i], None, 30, 12, 70)
+            os_ = ti.oracle.scan(q[i], L=30, rescore=12)
+        elif kind == 1:
+            job = (i, q[i], [4, 2, 4], 20, 6, 50)
+            os_ = ti.oracle.scan(q[i], labels=[2, 4], L=20, rescore=6)
+        else:
+            job = (i, None, [3], 3, 0, 10_000)  # NULL query, pulled to the end (the scan visits every live node)
+            os_ = ti.oracle.scan(None, L=3, rescore=0)
+        rows = []
+        for _ in range(job[5]):
+            o = os_.gettuple()
+            if o is None:
+                break
+            rows.append(o)
+        want[i] = rows
+        jobs[i % nproc].append(job)
+    name = f"/vs_shm_stream_{os.getpid()}"
+    srv = P.ShmServer(ix, name, nslots=3, kmax=8, max_batch=64, max_wait_us=5000)
+    ctx = mp.get_context("spawn")
+    out_q = ctx.Queue()
+    procs = [ctx.Process(target=_streaming_client, args=(name, _lib.LIB_PATH, jobs[p], out_q)) for p in range(nproc)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in procs:
+        status, payload = out_q.get(timeout=600)
+        assert status == "ok", payload
+        got.update(payload)
+    for p in procs:
+        p.join(60)
+
+    def same(rows, ref, what):
+        assert len(rows) == len(ref), (what, len(rows), len(ref))
+        for j, ((tid, node, d), o) in enumerate(zip(rows, ref)):
+            assert node == o[0] and tid == o[1], (what, j)
+            if not (np.isnan(d) and np.isnan(o[2])):
+                assert np.float32(d).view(np.uint32) == np.float32(o[2]).view(np.uint32), (what, j)
+
+    for i in range(len(q)):
+        same(got[i], want[i], i)
+    assert any(len(want[i]) > 2000 for i in range(len(q)))  # the NULL scans really ran to the end
+    for key, rows in got.items():
+        if isinstance(key, tuple):
+            same(rows, want[key[1]][20:28], key)
+    st = srv.stats()
+    assert st["tasks"] > len(q)  # cursor requests were served ...
+    assert st["scans"] == len(q)  # ... and only the first chunk of every scan went through a shared launch
+    srv.close()
+    ix.close()

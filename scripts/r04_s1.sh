@@ -5,7 +5,7 @@
 # sparser tables (more never-written buckets per probe, more lines touched)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" && mkdir -p gpurun_out/r04s1
 O=gpurun_out/r04s1
-timeout 300 python -m pytest tests/test_gpu_regimes.py tests/test_gpu_zv_fuzz.py -q -m gpu -x 2>&1 | tail -3 | tee $O/tests.txt
+VS_TEST_VIRGIN=1 timeout 300 python -m pytest tests/test_gpu_regimes.py tests/test_gpu_zv_fuzz.py -q -m gpu -x 2>&1 | tail -3 | tee $O/tests.txt
 VS_F_VIRGIN=1 VS_F_LDS_MAX_INS=0 timeout 200 python scripts/fuzz_emu.py --gpu --seconds 150 --seed 4041 2>&1 | tail -5 | tee $O/fuzz_gpu_virgin.txt
 CF="VS_F_VIRGIN=0,VS_F_VIRGIN=1,VS_F_VIRGIN=1:VS_F_GCAP=16384,VS_F_VIRGIN=1:VS_F_GCAP=24576,VS_F_VIRGIN=0,VS_F_VIRGIN=1"
 timeout 900 python scripts/perf_search.py --n 10000000 --nq 262144 --L 3 --rescore 196 --reps 3 --configs "$CF" --graph-cache /tmp/g 2>&1 | grep -E "search |index ready" | tee $O/ab_virgin_10m.txt

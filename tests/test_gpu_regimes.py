@@ -37,6 +37,16 @@ REGIMES = {
     "general_kernel": {"VS_FAST": "0"},
     "general_kernel_spill": {"VS_FAST": "0", "VS_HL": "64", "VS_G0": "256"},
 }
+
+
+def _hardware_unverified(regime):
+    """the written-bucket bitmap was built after the round's GPU minutes were spent: exact on the wave64 interpreter (this file under
+    VS_EMU=1, part of the CPU tier), first run on an MI355X by scripts/r04_s1.sh (VS_TEST_VIRGIN=1) — until then it is an opt-in of
+    the library and its tests are not part of the hardware tier"""
+    if "virgin" in str(regime) and not os.environ.get("VS_EMU") and not os.environ.get("VS_TEST_VIRGIN"):
+        pytest.skip("VS_F_VIRGIN has not run on hardware yet (scripts/r04_s1.sh)")
+
+
 INDEXES = {
     "l2_R50": (dict(n=4000, dim_full=128, bits=2, R=50, distance=1, seed=1, kind="uniform", L_build=100), "uniform", 100, 50),
     "labels_deleted": (dict(n=3000, dim_full=64, bits=2, R=32, distance=1, seed=11, kind="gauss", L_build=64, n_labels=6,
@@ -58,6 +68,7 @@ def regime_indexes(gpu_ctx):
 @pytest.mark.parametrize("regime", list(REGIMES))
 @pytest.mark.parametrize("iname", list(INDEXES))
 def test_every_regime_is_exact(regime_indexes, iname, regime):
+    _hardware_unverified(regime)
     ti, ix = regime_indexes[iname]
     _, qkind, L, rescore = INDEXES[iname]
     q = ti.queries(96, seed=77, kind=qkind)
@@ -97,6 +108,7 @@ WIDTHS = {"w12": (384, 2), "w30": (960, 2), "w48": (1536, 2), "w60": (1900, 2), 
 @pytest.mark.parametrize("wname", list(WIDTHS))
 @pytest.mark.parametrize("regime", ["default", "tableless", "heap_spill", "tableless_virgin"])
 def test_code_width_specialisations(gpu_ctx, wname, regime):
+    _hardware_unverified(regime)
     dims, bits = WIDTHS[wname]
     ti = cached_index(n=400, dim_full=dims, bits=bits, R=16, distance=1, seed=21, kind="gauss", L_build=40)
     ix = ti.upload(gpu_ctx)
@@ -126,6 +138,7 @@ def test_code_width_specialisations(gpu_ctx, wname, regime):
 @pytest.mark.parametrize("minw", [6, 7, 8, "6_virgin"])
 @pytest.mark.parametrize("wname", ["w24_two_bit", "w24_one_bit"])
 def test_register_capped_variants(gpu_ctx, wname, minw):
+    _hardware_unverified(minw)
     dims, bits = {"w24_two_bit": (768, 2), "w24_one_bit": (1536, 1)}[wname]
     ti = cached_index(n=500, dim_full=dims, bits=bits, R=20, distance=1, seed=23, kind="gauss", L_build=40)
     ix = ti.upload(gpu_ctx)
@@ -159,6 +172,7 @@ def test_register_capped_variants(gpu_ctx, wname, minw):
 # prefers, where a carried value stops) — with R = 48 a visit pushes up to 48 candidates in one run.
 @pytest.mark.parametrize("regime", ["default", "tableless", "heap_spill_tableless", "tableless_virgin"])
 def test_heavy_ties_deep_heap(gpu_ctx, regime):
+    _hardware_unverified(regime)
     ti = cached_index(n=6000, dim_full=24, bits=1, R=48, distance=1, seed=31, kind="gauss", L_build=60)
     ix = ti.upload(gpu_ctx)
     q = ti.queries(24, seed=9, kind="gauss")

@@ -346,7 +346,10 @@ void vs_shm_server::run() {
         } else {
             // gather: until max_wait_us have passed since the first posted request was seen, or max_batch are posted (every post
             // bumps work_seq and wakes this thread: look again and keep waiting for the rest of the window)
-            if (cfg.max_wait_us && ready.size() < cfg.max_batch) {
+            // (only scans that can share a launch wait for company: a cursor request is served at once)
+            bool any_search = false;
+            for (uint32_t i : ready) any_search |= m.slot(i)->op == OP_SEARCH;
+            if (any_search && cfg.max_wait_us && ready.size() < cfg.max_batch) {
                 const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(cfg.max_wait_us);
                 for (;;) {
                     const uint32_t seq2 = h->work_seq.load(std::memory_order_acquire);

@@ -1777,6 +1777,9 @@ static int scan_fetch(vs_scan* s, uint32_t window) {
             s->window = i;
             break;
         }
+    s->ids.resize(s->window);  // (only rows of the scan: a cursor that takes over appends to them)
+    s->tids.resize(s->window);
+    s->dist.resize(s->window);
     return VS_OK;
 }
 
@@ -1888,15 +1891,9 @@ extern "C" int vs_scan_xs_recheck(const vs_scan* s) { return (s && s->has_label_
 // the stream has ended every further call asks next() once more in vain.
 extern "C" int vs_scan_get_stats(const vs_scan* s, vs_stats* out) {
     VS_REQUIRE(s && out, "vs_scan_get_stats: bad args");
-    if (!s->cur.open) {
-        if (!s->broker || !s->active || s->cursor + s->calls_after_end == 0) {
-            *out = s->stats;
-            return VS_OK;
-        }
-        // a scan on a broker whose rows so far came out of a shared launch (whose counters belong to no single scan): the scan is
-        // replayed on a cursor of its own up to the executor's position, which is where the reference's counters stand
-        vs_scan* m = const_cast<vs_scan*>(s);
-        VS_TRY(broker_cursor_fetch(m, std::max<uint32_t>(m->cursor + (m->calls_after_end ? 1u : 0u), 1u)));
+    if (!s->cur.open && (!s->broker || !s->active)) {
+        *out = s->stats;
+        return VS_OK;
     }
     const ScanCursor& k = s->cur;
     const vs_index* ix = s->ix;
@@ -1908,6 +1905,12 @@ extern "C" int vs_scan_get_stats(const vs_scan* s, vs_stats* out) {
         return VS_OK;
     }
     const uint64_t need = S > 0 ? S + calls - 1 : calls;  // rows those calls asked next() for
+    if (s->broker && (!k.open || (need > k.rows && !k.exhausted))) {
+        // a scan on a broker whose rows so far came out of a shared launch (whose counters belong to no single scan): the scan is
+        // replayed on a cursor of its own up to the executor's position, which is where the reference's counters stand
+        vs_scan* m = const_cast<vs_scan*>(s);
+        VS_TRY(broker_cursor_fetch(m, std::max<uint32_t>(m->cursor + (m->calls_after_end ? 1u : 0u), 1u)));
+    }
     const uint32_t* r;
     uint64_t rows_used, next_calls;
     if (need <= k.rows) {

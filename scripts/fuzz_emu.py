@@ -36,7 +36,13 @@ REGIMES = [
     {"VS_F_LDS_MAX_INS": "0", "VS_F_GCAP": "512"},                      # tiny global dedup table: second attempt of k_search_fast
     {"VS_F_LDS_MAX_INS": "0", "VS_F_GCAP": "512", "VS_F_RETRY": "0"},   # ... or straight to the general kernel
 ]
-TUNING = sorted({k for r in REGIMES for k in r})
+# drawn on top of the four regimes of a case (by a generator of their own, so that the cases of older seeds stay what they were)
+EXTRA_REGIMES = [
+    {"VS_F_LDS_MAX_INS": "0", "VS_F_VIRGIN": "1"},                      # written-bucket bitmap instead of cleared dedup tables
+    {"VS_F_LDS_MAX_INS": "0", "VS_F_VIRGIN": "1", "VS_F_HL": "63"},
+    {"VS_F_LDS_MAX_INS": "0", "VS_F_VIRGIN": "1", "VS_F_GCAP": "2048"},  # ... tight: chains of full buckets, second attempts
+]
+TUNING = sorted({k for r in REGIMES + EXTRA_REGIMES for k in r})
 
 
 def close(a, b):
@@ -48,7 +54,12 @@ def close(a, b):
 def gettuple_mirror(ix, oracle, q, keys, L, rescore, rng, where, exact_dist):
     """amrescan / amgettuple one row at a time: two scans on one handle (the second a rescan, sometimes a NULL query),
     a random number of rows each, sometimes to exhaustion"""
-    scan = ix.beginscan()
+    # one scan in three runs behind a dispatcher: first rows from a shared launch, the rest from its cursor on the dispatcher thread
+    broker = None
+    if np.random.default_rng(int(rng.bit_generator.state["state"]["state"]) % (2 ** 32) + 3).random() < 0.35:
+        import pgvectorscale_amd as P
+        broker = P.Broker(ix, max_batch=4, max_wait_us=0)
+    scan = ix.beginscan() if broker is None else broker.beginscan()
     try:
         for rnd in range(2):
             i = int(rng.integers(0, q.shape[0]))
@@ -79,6 +90,8 @@ def gettuple_mirror(ix, oracle, q, keys, L, rescore, rng, where, exact_dist):
                 assert gs[c] == os_[c], f"{where}: cursor counter {c} at the end of scan {rnd}: {gs[c]} != {os_[c]}"
     finally:
         scan.endscan()
+        if broker is not None:
+            broker.close()
 
 
 def plain_case(ctx, O, case_seed, verbose):
@@ -390,6 +403,9 @@ def one_case(ctx, O, case_seed, verbose):
     k = int(rng.choice([1, 5, 10, 40, 200]))
     m = int(rng.choice([1, 20, 75]))
     regimes = [REGIMES[i] for i in rng.choice(len(REGIMES), 4, replace=False)]
+    rng_extra = np.random.default_rng(case_seed + 7)
+    if rng_extra.random() < 0.5:
+        regimes.append(EXTRA_REGIMES[int(rng_extra.integers(0, len(EXTRA_REGIMES)))])
     oi, od, ost = ti.oracle.search_batch(q, L=L, rescore=rescore, k=k, qlabels=keys)
     si, sh, sst = ti.oracle.stream_batch(q, L=L, m=m, qlabels=keys)
     for reg in regimes:

@@ -249,3 +249,34 @@ def test_broker_scan_under_a_snapshot_streams_like_the_oracle(gpu_ctx, oracle):
     assert (gi == oi).all()
     broker.close()
     ix.close()
+
+
+def test_broker_scan_statistics_inside_the_shared_window_and_scans_that_end_there(gpu_ctx, oracle):
+    """found by the differential fuzzer: statistics asked for after 1, 2, 9 rows — all still rows of the shared launch — need the
+    replay cursor extended each time, and a scan that ends inside the shared window must end there, with or without a replay"""
+    import pgvectorscale_amd as P
+    O = oracle
+    for kw, L, rescore, pull in ((dict(n=900, dim_full=24, bits=2, R=12, distance=O.L2, seed=3, kind="gauss", L_build=30), 20, 6, 40),
+                                 (dict(n=3, dim_full=16, bits=2, R=4, distance=O.L2, seed=4, kind="gauss", L_build=8), 10, 5, 10),
+                                 (dict(n=11, dim_full=16, bits=1, R=4, distance=O.COSINE, seed=5, kind="gauss", L_build=8), 4, 0, 30)):
+        ti = TestIndex(**kw)
+        ix = ti.upload(gpu_ctx)
+        broker = P.Broker(ix, max_batch=4, max_wait_us=0)
+        q = ti.queries(2, seed=8, kind="gauss")
+        scan = broker.beginscan()
+        for qi in range(2):
+            scan.rescan(q[qi], search_list_size=L, rescore=rescore)
+            os_ = ti.oracle.scan(q[qi], L=L, rescore=rescore)
+            for j in range(pull):
+                r, o = scan.gettuple(), os_.gettuple()
+                assert (r is None) == (o is None), (kw["n"], qi, j)
+                if r is not None:
+                    assert r[1] == o[0] and r[0] == o[1], (kw["n"], qi, j)
+                if j in (0, 1, 8, 20) or r is None:
+                    g, ref = scan.stats(), os_.stats()
+                    for key in ("visited_nodes", "candidate_nodes", "quantized_distance_comparisons", "full_distance_comparisons",
+                                "node_reads", "node_heap_reads", "next_calls"):
+                        assert g[key] == ref[key], (kw["n"], qi, j, key, g[key], ref[key])
+        scan.endscan()
+        broker.close()
+        ix.close()

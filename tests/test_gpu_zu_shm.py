@@ -332,3 +332,56 @@ def test_backend_processes_stream_past_the_first_rows(gpu_ctx, oracle):
     assert st["scans"] == len(q)  # ... and only the first chunk of every scan went through a shared launch
     srv.close()
     ix.close()
+
+
+def test_fetch_protocol_random_walk(gpu_ctx, oracle):
+    """the cursor protocol under a client that behaves badly: positions out of order, rewinds, scans dropped and resumed, an id
+    reused for another scan — every answer is rows [skip, skip + k) of the oracle's scan, fewer only at its end"""
+    import pgvectorscale_amd as P
+    ti = TestIndex(**KW)
+    ix = ti.upload(gpu_ctx)
+    name = f"/vs_shm_walk_{os.getpid()}"
+    srv = P.ShmServer(ix, name, nslots=2, kmax=8, max_batch=8, max_wait_us=0)
+    c = P.ShmClient(name)  # (a client may live in the serving process too: the dispatcher is a thread of its own)
+    q = ti.queries(4, seed=91, kind="gauss")
+    scans = [dict(query=q[0], labels=None, L=25, S=9), dict(query=q[1], labels=[5, 1], L=12, S=4), dict(query=None, labels=None, L=2, S=0),
+             dict(query=q[2], labels=None, L=40, S=0)]
+    want = []
+    for s in scans:
+        os_ = ti.oracle.scan(s["query"], labels=None if s["query"] is None else s["labels"], L=s["L"], rescore=s["S"])
+        rows = []
+        while len(rows) < 400:
+            o = os_.gettuple()
+            if o is None:
+                break
+            rows.append(o)
+        want.append(rows)
+    rng = np.random.default_rng(17)
+    pos = [0] * len(scans)
+    ids_of = list(range(100, 100 + len(scans)))
+    for step in range(150):
+        j = int(rng.integers(0, len(scans)))
+        u = rng.random()
+        if u < 0.08:
+            c.end_scan(ids_of[j])
+            continue
+        if u < 0.12:  # two scans swap their names: the server must notice that the scan behind an id changed
+            a, b = int(rng.integers(0, len(scans))), int(rng.integers(0, len(scans)))
+            ids_of[a], ids_of[b] = ids_of[b], ids_of[a]
+            continue
+        skip = pos[j] if u < 0.75 else (0 if u < 0.82 else int(rng.integers(0, min(len(want[j]), 390) + 1)))
+        k = int(rng.integers(1, 9))
+        s = scans[j]
+        ids, tids, dist = c.fetch(ids_of[j], s["query"], skip, k, s["labels"], s["L"], s["S"])
+        ref = want[j][skip:skip + k]
+        if skip + k <= 400 or len(want[j]) < 400:
+            assert len(ids) == len(ref), (step, j, skip, k, len(ids), len(ref))
+        for (node, tid, d), gi, gt, gd in zip(ref, ids.tolist(), tids.tolist(), dist.tolist()):
+            assert gi == node and gt == tid, (step, j, skip)
+            if not (np.isnan(gd) and np.isnan(d)):
+                assert np.float32(gd).view(np.uint32) == np.float32(d).view(np.uint32), (step, j, skip)
+        pos[j] = skip + len(ids)
+    assert srv.stats()["tasks"] >= 100
+    c.close()
+    srv.close()
+    ix.close()

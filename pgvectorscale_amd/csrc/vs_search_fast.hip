@@ -663,6 +663,30 @@ __device__ __forceinline__ uint32_t ham_row_reg(const uint64_t* __restrict__ row
     return ham_row4(row, qc_l, l4, code_stride, active);
 }
 
+// two rows at once (all loads issued before the first popcount)
+template <int NCH>
+__device__ __forceinline__ void ham_row_reg2(const uint64_t* __restrict__ row_a, const uint64_t* __restrict__ row_b,
+                                             const ulonglong2 (&qv)[NCH > 0 ? NCH : 1], int l4, uint32_t code_stride, bool act_a,
+                                             bool act_b, bool stream, uint32_t& da, uint32_t& db) {
+    constexpr int N = NCH > 0 ? NCH : 1;
+    ulonglong2 ra[N], rb[N];
+#pragma unroll
+    for (int t = 0; t < N; ++t) {
+        const uint32_t w = 2u * (uint32_t)l4 + 8u * (uint32_t)t;
+        const bool in = w < code_stride;
+        ra[t] = !(act_a && in) ? make_ulonglong2(0, 0) : stream ? load_stream16(row_a + w) : *reinterpret_cast<const ulonglong2*>(row_a + w);
+        rb[t] = !(act_b && in) ? make_ulonglong2(0, 0) : stream ? load_stream16(row_b + w) : *reinterpret_cast<const ulonglong2*>(row_b + w);
+    }
+    uint32_t acc_a = 0, acc_b = 0;
+#pragma unroll
+    for (int t = 0; t < N; ++t) {
+        acc_a += (uint32_t)__popcll(ra[t].x ^ qv[t].x) + (uint32_t)__popcll(ra[t].y ^ qv[t].y);
+        acc_b += (uint32_t)__popcll(rb[t].x ^ qv[t].x) + (uint32_t)__popcll(rb[t].y ^ qv[t].y);
+    }
+    da = quad_sum(act_a ? acc_a : 0u);
+    db = quad_sum(act_b ? acc_b : 0u);
+}
+
 // minimum over the wave (DPP row reduction + 4 readlanes; no LDS)
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
     v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x111 /*row_shr:1*/, 0xF, 0xF, false));
@@ -707,6 +731,7 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
     const int l4 = lane & 3;
     const bool stream_rows = !(s.flags & FAST_PLAIN_ROW_LOADS);
     constexpr bool QL = NCH > 0 && MINW >= 6;
+    constexpr bool G2 = NCH == 3 && VR == 0 && MINW == 5 && !BUILD && !TIMING;  // two code rows per 4-lane group in flight
     ulonglong2 qv[NCH > 0 ? NCH : 1];
     if (QL) {
         qv[0] = make_ulonglong2(0, 0);
@@ -1185,8 +1210,10 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
             const uint32_t pre_n = heap.first_run(c);
             const uint32_t pre_anc = pre_n ? heap.wide_load(pre_n) : 0u;
             // distances: 4 lanes per code row, 16 rows per pass; the row of the current heap root rides along
+            // (G2, the 5-waves-per-SIMD variant: two rows per 4-lane group are in flight at once, so the usual 17..32 new candidates of
+            // a visit cost one round trip instead of two — paid for with 12 registers, i.e. 20 instead of 24 scans per CU)
             const uint32_t npass = (c + 15u) >> 4;
-            for (uint32_t pass_i = 0; pass_i < npass; ++pass_i) {
+            for (uint32_t pass_i = 0; pass_i < npass; pass_i += G2 ? 2u : 1u) {
                 const uint32_t j = pass_i * 16u + (uint32_t)(lane >> 2);
                 const bool valid = j < c;
                 const uint32_t id = valid ? surv_id[j] : 0;
@@ -1201,6 +1228,16 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
                         pfa_val = ((uint32_t)lane < a.R) ? a.nbrs[(size_t)pfa_node * a.nbr_stride + lane] : VS_INVALID_NODE;
                         if (nbr_mask) pfa_m = ((uint32_t)lane < a.R) ? nbr_mask[(size_t)pfa_node * a.nbr_stride + lane] : 0ull;
                     }
+                }
+                if (G2) {
+                    const uint32_t j2 = j + 16u;
+                    const bool valid2 = j2 < c;
+                    const uint64_t* crow2 = a.codes + (size_t)(valid2 ? surv_id[j2] : 0u) * a.code_stride;
+                    uint32_t d, d2;
+                    ham_row_reg2<NCH>(crow, crow2, qv, l4, a.code_stride, valid, valid2, stream_rows, d, d2);
+                    if (valid && l4 == 0) surv_d[j] = d;
+                    if (valid2 && l4 == 0) surv_d[j2] = d2;
+                    continue;
                 }
                 const uint32_t d = ham_row_reg<NCH, QL>(crow, qv, qc_l, l4, a.code_stride, valid, stream_rows);
                 if (valid && l4 == 0) surv_d[j] = d;
@@ -1330,6 +1367,8 @@ static int launch_fast_t(vs_index* idx, const FastArgs& a, size_t lds) {
         const bool plain = !a.s.qlabel_off && !a.s.visible && !(a.s.flags & FAST_FULL_VARIANT);
         if (NCH == 3 && a.s.minw == 6 && plain) return launch_fast_tt<3, 0, false, 6, false, false, true>(idx, a, lds);
         if (NCH == 3 && a.s.minw == 6) return launch_fast_tt<3, 0, false, 6, false, true, true>(idx, a, lds);
+        if (NCH == 3 && a.s.minw == 5 && plain) return launch_fast_tt<3, 0, false, 5, false, false, true>(idx, a, lds);
+        if (NCH == 3 && a.s.minw == 5) return launch_fast_tt<3, 0, false, 5, false, true, true>(idx, a, lds);
         return launch_fast_tt<NCH, 0, false, 1, false, true, true>(idx, a, lds);
     }
     if (a.s.vr == 8) {
@@ -1342,6 +1381,8 @@ static int launch_fast_t(vs_index* idx, const FastArgs& a, size_t lds) {
     }
     if (NCH == 3) {
         const bool plain = !a.s.qlabel_off && !a.s.visible && !(a.s.flags & FAST_FULL_VARIANT);  // no label keys, no visibility mask
+        if (a.s.minw == 5 && plain) return launch_fast_tt<3, 0, false, 5, false, false>(idx, a, lds);
+        if (a.s.minw == 5) return launch_fast_tt<3, 0, false, 5, false>(idx, a, lds);
         if (a.s.minw == 6 && plain) return launch_fast_tt<3, 0, false, 6, false, false>(idx, a, lds);
         if (a.s.minw == 6) return launch_fast_tt<3, 0, false, 6, false>(idx, a, lds);
         if (a.s.minw == 7) return launch_fast_tt<3, 0, false, 7, false>(idx, a, lds);

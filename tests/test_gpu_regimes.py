@@ -40,11 +40,11 @@ REGIMES = {
 
 
 def _hardware_unverified(regime):
-    """the written-bucket bitmap was built after the round's GPU minutes were spent: exact on the wave64 interpreter (this file under
+    """the written-bucket bitmap and the two-row gather variant were built after the round's GPU minutes were spent: exact on the wave64 interpreter (this file under
     VS_EMU=1, part of the CPU tier), first run on an MI355X by scripts/r04_s1.sh (VS_TEST_VIRGIN=1) — until then it is an opt-in of
     the library and its tests are not part of the hardware tier"""
-    if "virgin" in str(regime) and not os.environ.get("VS_EMU") and not os.environ.get("VS_TEST_VIRGIN"):
-        pytest.skip("VS_F_VIRGIN has not run on hardware yet (scripts/r04_s1.sh)")
+    if ("virgin" in str(regime) or str(regime) == "5") and not os.environ.get("VS_EMU") and not os.environ.get("VS_TEST_VIRGIN"):
+        pytest.skip("VS_F_VIRGIN / the two-row gather (VS_F_MINW=5) have not run on hardware yet (scripts/r04_s1.sh)")
 
 
 INDEXES = {
@@ -134,8 +134,9 @@ def test_code_width_specialisations(gpu_ctx, wname, regime):
 
 
 # the register-capped variants of the headline geometry (W = 24: 768 x 2 bit / 1536 x 1 bit) in the table-less regime:
-# waves per SIMD the kernel is compiled for (7 and 8 read the query code from LDS and keep the heap's lane constants packed)
-@pytest.mark.parametrize("minw", [6, 7, 8, "6_virgin"])
+# waves per SIMD the kernel is compiled for (7 and 8 read the query code from LDS and keep the heap's lane constants packed; 5 keeps
+# two code rows per 4-lane group in flight)
+@pytest.mark.parametrize("minw", [5, 6, 7, 8, "6_virgin", "5_virgin"])
 @pytest.mark.parametrize("wname", ["w24_two_bit", "w24_one_bit"])
 def test_register_capped_variants(gpu_ctx, wname, minw):
     _hardware_unverified(minw)
@@ -146,8 +147,8 @@ def test_register_capped_variants(gpu_ctx, wname, minw):
     oi, oh, ost = ti.oracle.stream_batch(q, L=3, m=60)
     osi, osd, _ = ti.oracle.search_batch(q, L=3, rescore=40, k=10)
     env = {"VS_F_LDS_MAX_INS": "0", "VS_F_VR": "0", "VS_F_MINW": str(minw), "VS_F_HL": "63"}
-    if minw == "6_virgin":  # the two written-bucket-bitmap instantiations of the headline geometry
-        env.update({"VS_F_MINW": "6", "VS_F_VIRGIN": "1"})
+    if str(minw).endswith("_virgin"):  # the written-bucket-bitmap instantiations of the headline geometry
+        env.update({"VS_F_MINW": str(minw)[0], "VS_F_VIRGIN": "1"})
     saved = {k: os.environ.get(k) for k in env}
     try:
         os.environ.update(env)
@@ -218,4 +219,32 @@ def test_label_filter_masks_and_merge(gpu_ctx, n_labels):
                     else:
                         os.environ[k] = v
     finally:
+        ix.close()
+
+
+# the two-row gather with every pass shape: R = 50 gives visits with 1..50 new candidates (one pair of passes, a pair + a single
+# row group, two pairs), on scans long enough to spill the heap
+@pytest.mark.parametrize("variant", ["5", "5_virgin"])
+def test_two_row_gather_full_neighbor_lists(gpu_ctx, variant):
+    _hardware_unverified("5")
+    ti = cached_index(n=1500, dim_full=768, bits=2, R=50, distance=1, seed=29, kind="gauss", L_build=60)
+    ix = ti.upload(gpu_ctx)
+    q = ti.queries(24, seed=8, kind="gauss")
+    oi, oh, ost = ti.oracle.stream_batch(q, L=25, m=90)
+    env = {"VS_F_LDS_MAX_INS": "0", "VS_F_VR": "0", "VS_F_MINW": "5"}
+    if variant.endswith("_virgin"):
+        env["VS_F_VIRGIN"] = "1"
+    saved = {k: os.environ.get(k) for k in env}
+    try:
+        os.environ.update(env)
+        gi, gh, gst = ix.stream_batch(q, search_list_size=25, m=90)
+        assert (gi == oi).all() and (gh == oh).all()
+        for key in ("visited_nodes", "candidate_nodes", "quantized_distance_comparisons", "node_reads"):
+            assert gst[key] == ost[key], (key, gst[key], ost[key])
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
         ix.close()

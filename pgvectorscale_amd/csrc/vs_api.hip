@@ -987,21 +987,24 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
         ix->last_ins_limit = caps.f_lh ? caps.f_lh - caps.f_lh / 8 - 64 : 0xFFFFFFFFu;
         VS_TRY(devbuf_reserve(c, w.heap_g4, std::max<size_t>((size_t)nq * caps.f_gstride * 4, 16)));
         const void* const ghash4_before = w.ghash4.p;
+        const size_t ghash4_bytes_before = w.ghash4.bytes;
         VS_TRY(devbuf_reserve(c, w.ghash4, (size_t)fslots * caps.f_gcap * 4));
         // epoch-tagged dedup table (table-less regime): no scan clears its table; the array is zeroed when it is new, when the
         // id width changes and when the epochs wrap (VS_F_EPOCH=0: plain ids, every scan clears its 64 KB)
         uint32_t epoch = 0, eshift = 0;
-        // OFF by default (VS_F_EPOCH=1 switches it on): worth 2.2 % at 50M and exact on the interpreter and in 6 800 random cases on
-        // the device, but ONE found configuration — scans that exhaust a 900-node graph, search_list_size 1000 (device fuzz case
-        // 777000331) — returns wrong rows on the MI355X with the tags on, every time, and right rows with them off; zeroing the
-        // array by hipMemset, synchronously, or by a kernel of our own changes nothing, a zero fill by each scan of its own region
-        // cures it, the interpreter cannot reproduce it with any memory filler (profiles/r03/s8_s9_epoch_bug_bisect.txt).  The cause
-        // was not found within the round's GPU minutes, so the measured configuration is the one without tags.
+        // OFF by default (VS_F_EPOCH=1 switches it on): worth 2.2 % at 50M, but device fuzz case 777000331 returned wrong rows on
+        // the MI355X with the tags on (profiles/r03/s8_s9_epoch_bug_bisect.txt).  The cause was found on the interpreter after the
+        // round's GPU minutes were gone (the reallocation test below used to compare addresses) — the switch
+        // stays off until the fix has run on hardware.
         if (caps.f_lh == 0 && env_u32("VS_F_EPOCH", 0)) {
             while ((1ull << eshift) < (uint64_t)std::max<uint32_t>(ix->d.n, 2)) eshift++;
             if (eshift <= 28) {  // >= 15 launches between two clears
                 const uint32_t last = std::min<uint32_t>((1u << (32 - eshift)) - 1u, env_u32("VS_F_EPOCH_MAX", 0xFFFFFFFFu));  // (the override lets a test see the wrap)
-                if (w.ghash4.p != ghash4_before || w.ghash4_eshift != eshift || w.ghash4_epoch == 0 || w.ghash4_epoch >= last) {
+                // (reallocated = the capacity changed; NOT "the address changed": a device allocator hands the range of the block just
+                // freed to the larger request that follows, and the part beyond the old block then holds what an earlier owner of
+                // those bytes left there — entries of another workspace, tagged with the same small epochs)
+                if (w.ghash4.bytes != ghash4_bytes_before || w.ghash4.p != ghash4_before || w.ghash4_eshift != eshift ||
+                    w.ghash4_epoch == 0 || w.ghash4_epoch >= last) {
                     // zeroed by a kernel of our own, not by hipMemset: see launch_zero_fill
                     if (env_u32("VS_F_EPOCH_DBG", 0) & 1) VS_HIP(hipMemsetAsync(w.ghash4.p, 0, w.ghash4.bytes, c->stream));  // (diagnostics: the old way)
                     else VS_TRY(launch_zero_fill(c, w.ghash4.p, w.ghash4.bytes & ~(size_t)15));

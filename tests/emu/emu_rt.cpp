@@ -71,7 +71,78 @@ static std::mutex g_alloc_mu;
 struct AllocInfo { void* base; size_t map_bytes; };
 static std::vector<std::pair<void*, AllocInfo>> g_allocs;
 
+// VS_EMU_ARENA=<MiB>: device memory comes out of ONE arena instead of a guarded mapping per allocation — freed blocks keep their
+// address range and their contents, nothing is filled on reuse.  That is how a device allocator behaves and the guarded mode does
+// not: hipFree + a larger hipMalloc can hand back the SAME address, with the old block's bytes at the front and whatever other
+// freed buffers left behind in the extension (what a "was the buffer reallocated?" test by pointer comparison does not see).
+struct ArenaSeg { size_t off, size; bool used; };
+static char* g_arena = nullptr;
+static size_t g_arena_bytes = 0;
+static std::vector<ArenaSeg> g_segs;  // the blocks handed out so far, live or free
+
+static bool arena_mode() {
+    static const size_t mib = [] {
+        const char* e = getenv("VS_EMU_ARENA");
+        return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)0;
+    }();
+    if (!mib) return false;
+    if (!g_arena) {
+        g_arena_bytes = mib << 20;
+        g_arena = static_cast<char*>(mmap(nullptr, g_arena_bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0));
+        if (g_arena == MAP_FAILED) {
+            fprintf(stderr, "emu: cannot map a %zu MiB arena\n", mib);
+            abort();
+        }
+        // never-used device memory is not zero either: small pseudo-random words, the kind other kernels leave behind
+        uint64_t x = 0x9E3779B97F4A7C15ull;
+        uint32_t* w = reinterpret_cast<uint32_t*>(g_arena);
+        for (size_t i = 0; i < g_arena_bytes / 4; ++i) {
+            x ^= x << 13;
+            x ^= x >> 7;
+            x ^= x << 17;
+            w[i] = (uint32_t)(x >> 16) & ((i & 3) == 0 ? 0xFFFFFFFFu : ((i & 3) == 1 ? 0x00000FFFu : ((i & 3) == 2 ? 0x000FFFFFu : 0x0FFFFFFFu)));
+        }
+    }
+    return true;
+}
+
+// granules of 2 MiB, like a device allocator that maps memory in large fragments: a freed block's address range is kept and handed
+// to the next request that fits it, most recently freed first
+static size_t g_arena_top = 0;
+static std::vector<size_t> g_free_order;  // indices into g_segs, oldest first
+
+static void* arena_alloc(size_t bytes) {
+    const size_t gran = (size_t)2 << 20;
+    const size_t rounded = (std::max<size_t>(bytes, 1) + gran - 1) / gran * gran;
+    for (size_t k = g_free_order.size(); k-- > 0;) {
+        ArenaSeg& sg = g_segs[g_free_order[k]];
+        if (sg.size < rounded) continue;
+        sg.used = true;
+        g_free_order.erase(g_free_order.begin() + (long)k);
+        return g_arena + sg.off;
+    }
+    if (g_arena_top + rounded > g_arena_bytes) return nullptr;
+    g_segs.push_back({g_arena_top, rounded, true});
+    g_arena_top += rounded;
+    return g_arena + g_segs.back().off;
+}
+
+static bool arena_free(void* p) {
+    const size_t off = (size_t)(static_cast<char*>(p) - g_arena);
+    for (size_t i = 0; i < g_segs.size(); ++i) {
+        if (g_segs[i].off != off || !g_segs[i].used) continue;
+        g_segs[i].used = false;
+        g_free_order.push_back(i);
+        return true;
+    }
+    return false;
+}
+
 void* guarded_alloc(size_t bytes) {
+    {
+        std::lock_guard<std::mutex> lk(g_alloc_mu);
+        if (arena_mode()) return arena_alloc(bytes);
+    }
     const size_t page = 4096;
     const size_t rounded = (std::max<size_t>(bytes, 1) + 255) / 256 * 256;
     const size_t body = (rounded + page - 1) / page * page;
@@ -107,6 +178,11 @@ void* guarded_alloc(size_t bytes) {
 void guarded_free(void* p) {
     if (!p) return;
     std::lock_guard<std::mutex> lk(g_alloc_mu);
+    if (g_arena && static_cast<char*>(p) >= g_arena && static_cast<char*>(p) < g_arena + g_arena_bytes) {
+        if (arena_free(p)) return;
+        fprintf(stderr, "emu: hipFree of a pointer hipMalloc never returned (%p)\n", p);
+        abort();
+    }
     for (size_t i = 0; i < g_allocs.size(); ++i)
         if (g_allocs[i].first == p) {
             munmap(g_allocs[i].second.base, g_allocs[i].second.map_bytes);

@@ -47,3 +47,16 @@ def test_gpu_parity_tests_pass_on_the_wave64_interpreter(emu_lib):
     tail = (r.stdout + r.stderr)[-3000:]
     assert r.returncode == 0, tail
     assert " passed" in r.stdout and "failed" not in r.stdout, tail
+
+
+def test_reallocation_at_the_same_address_does_not_keep_stale_dedup_entries(emu_lib):
+    """The interpreter's default device memory is one guarded mapping per hipMalloc, so a freed block's address never comes back; a
+    device allocator hands it to the next request that fits.  VS_EMU_ARENA models that (2 MiB granules, most recently freed first,
+    contents kept) — the only setting under which the interpreter reproduces what device fuzz case 777000331 found on the MI355X
+    with epoch-tagged dedup tables: the table array grows, comes back at the SAME address, was taken for "not reallocated", and its
+    extension held another workspace's entries carrying the same small epoch numbers."""
+    env = dict(os.environ, VS_F_EPOCH="1", VS_EMU_ARENA="4096")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_emu.py"), "--only", "777000331"], env=env,
+                       capture_output=True, text=True, cwd=ROOT, timeout=900)
+    tail = (r.stdout + r.stderr)[-2000:]
+    assert r.returncode == 0 and "1 cases, 0 failures" in r.stdout, tail

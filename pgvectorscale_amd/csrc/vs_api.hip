@@ -1035,6 +1035,13 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
         f.lh = caps.f_lh;
         f.minw = env_u32("VS_F_MINW", caps.f_lh == 0 ? (caps.f_vr ? 4 : 6) : 1);
         f.flags = env_u32("VS_F_FLAGS", 0);
+        // the software-pipelined variant (VS_F_SP=1): 24-word codes, table-less regime, LDS-ring visited list; it lives at 5 waves per SIMD
+        // (neighbor lists of one 64-lane chunk: a visit has ONE run of pushes to defer)
+        if (env_u32("VS_F_SP", 0) && caps.f_lh == 0 && !f.vr && (ix->code_stride + 7) / 8 == 3 && ix->d.num_neighbors <= 64 &&
+            !env_u32("VS_PHASE", 0)) {
+            f.sp = 1;
+            f.minw = env_u32("VS_F_SP", 0) >= 2 ? 4 : 5;  // (2: the 4-waves-per-SIMD build, 16 scans per CU, no scratch)
+        }
         f.epoch = epoch;
         f.eshift = eshift;
         f.rc = caps.f_lh == 0 ? env_u32("VS_F_RC", 0) : 0;  // (measurement: LDS id cache in front of the dedup table in HBM)
@@ -1070,6 +1077,7 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
             FastLaunch r = f;
             r.epoch = 0;  // (its own, smaller table array: cleared by the few scans that run)
             r.vwords = 0;
+            r.sp = 0;
             r.only_failed = 1;
             r.fb_flag = (uint32_t*)w.fb_flag.p;
             r.phase = nullptr;
@@ -1100,8 +1108,8 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
             VS_HIP(hipStreamSynchronize(c->stream));
             uint32_t hist[16] = {0};
             for (uint32_t v : stv) hist[v & 15]++;
-            fprintf(stderr, "[VS_DEBUG_STATUS] fast kernel: lh=%u gcap=%u vr=%u minw=%u epoch=%u bitmap_words=%u; pool claims=%u of %u;",
-                    f.lh, f.gcap, f.vr, f.minw, f.epoch, f.vwords, ctr[0], fast_pool_slots(nq, caps.f_pool_frac));
+            fprintf(stderr, "[VS_DEBUG_STATUS] fast kernel: lh=%u gcap=%u vr=%u minw=%u epoch=%u bitmap_words=%u pipelined=%u; pool claims=%u of %u;",
+                    f.lh, f.gcap, f.vr, f.minw, f.epoch, f.vwords, f.sp, ctr[0], fast_pool_slots(nq, caps.f_pool_frac));
             for (int i = 0; i < 16; ++i)
                 if (hist[i]) fprintf(stderr, " status[%d]=%u", i, hist[i]);
             fprintf(stderr, "\n");

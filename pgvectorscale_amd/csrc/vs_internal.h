@@ -213,6 +213,7 @@ struct FastLaunch {
     uint32_t rc = 0;   // entries of the LDS cache of ids known to be in the table (table-less regime; 0 or a power of two)
     uint32_t epoch = 0;   // != 0: global dedup entries are (epoch << eshift) | id and stale tags count as empty (no clearing)
     uint32_t eshift = 0;  // bits of a node id inside a tagged entry
+    uint32_t sp = 0;      // 1: the software-pipelined variant (pushes deferred under the next visit's bucket loads, pop under its code rows)
     uint32_t vwords = 0;  // != 0: words of the LDS bitmap of written buckets (one bit per four slots of gcap): tables are neither cleared nor read before their first write
     uint32_t build = 0; // 1: greedy_search_for_build (the visited list is the output; needs vr == 0)
     uint32_t flags = 0; // FAST_* (measurement switches)

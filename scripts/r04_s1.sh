@@ -2,15 +2,17 @@
 # round 4, GPU session 1 (prepared in round 3, which had no GPU minutes left to run it): the written-bucket bitmap of the table-less
 # dedup table (VS_F_VIRGIN=1: no clears, no reads of buckets the scan has not written) — exact on the device
 # first (the regimes that use it + the differential fuzzer), then timed against the shipped default at 10M and 50M, alone and with
-# sparser tables (more never-written buckets per probe, more lines touched), and the two-row gather variant (VS_F_MINW=5, §11b.17)
+# sparser tables (more never-written buckets per probe, more lines touched), the two-row gather variant (VS_F_MINW=5, §11b.17) and the
+# software-pipelined visits (VS_F_SP=1 / 2, §11b.18)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" && mkdir -p gpurun_out/r04s1
 O=gpurun_out/r04s1
 VS_TEST_VIRGIN=1 timeout 300 python -m pytest tests/test_gpu_regimes.py tests/test_gpu_zv_fuzz.py -q -m gpu -x 2>&1 | tail -3 | tee $O/tests.txt
+timeout 200 python scripts/fuzz_variants.py --gpu --cases 25 --seed 9 2>&1 | tail -3 | tee $O/fuzz_variants_gpu.txt
 VS_F_VIRGIN=1 VS_F_LDS_MAX_INS=0 timeout 200 python scripts/fuzz_emu.py --gpu --seconds 150 --seed 4041 2>&1 | tail -5 | tee $O/fuzz_gpu_virgin.txt
 # the epoch tags with the reallocation fix: the case that failed in round 3, then random cases
 VS_F_EPOCH=1 timeout 120 python scripts/fuzz_emu.py --gpu --only 777000331 2>&1 | tail -2 | tee $O/fuzz_gpu_epoch_case.txt
 VS_F_EPOCH=1 timeout 200 python scripts/fuzz_emu.py --gpu --seconds 120 --seed 4042 2>&1 | tail -5 | tee $O/fuzz_gpu_epoch.txt
-CF="VS_F_EPOCH=0:VS_F_VIRGIN=0:VS_F_GCAP=0:VS_F_MINW=6,VS_F_VIRGIN=1:VS_F_GCAP=0:VS_F_MINW=6,VS_F_VIRGIN=1:VS_F_GCAP=16384:VS_F_MINW=6,VS_F_VIRGIN=1:VS_F_GCAP=24576:VS_F_MINW=6,VS_F_VIRGIN=0:VS_F_GCAP=0:VS_F_MINW=5,VS_F_VIRGIN=1:VS_F_GCAP=0:VS_F_MINW=5,VS_F_VIRGIN=0:VS_F_GCAP=0:VS_F_MINW=6,VS_F_VIRGIN=1:VS_F_GCAP=0:VS_F_MINW=6,VS_F_VIRGIN=0:VS_F_EPOCH=1:VS_F_GCAP=0:VS_F_MINW=6"
+CF="VS_F_EPOCH=0:VS_F_VIRGIN=0:VS_F_GCAP=0:VS_F_MINW=6,VS_F_VIRGIN=1:VS_F_GCAP=0:VS_F_MINW=6,VS_F_VIRGIN=1:VS_F_GCAP=16384:VS_F_MINW=6,VS_F_VIRGIN=1:VS_F_GCAP=24576:VS_F_MINW=6,VS_F_VIRGIN=0:VS_F_GCAP=0:VS_F_MINW=5,VS_F_VIRGIN=1:VS_F_GCAP=0:VS_F_MINW=5,VS_F_VIRGIN=0:VS_F_GCAP=0:VS_F_MINW=6,VS_F_VIRGIN=1:VS_F_GCAP=0:VS_F_MINW=6,VS_F_VIRGIN=0:VS_F_EPOCH=1:VS_F_GCAP=0:VS_F_MINW=6,VS_F_EPOCH=0:VS_F_SP=1,VS_F_SP=2,VS_F_SP=1:VS_F_VIRGIN=1,VS_F_SP=2:VS_F_VIRGIN=1,VS_F_SP=0:VS_F_VIRGIN=0:VS_F_MINW=6"
 timeout 900 python scripts/perf_search.py --n 10000000 --nq 262144 --L 3 --rescore 196 --reps 3 --configs "$CF" --graph-cache /tmp/g 2>&1 | grep -E "search |index ready" | tee $O/ab_virgin_10m.txt
 timeout 1500 python scripts/perf_search.py --n 50000000 --nq 262144 --L 3 --rescore 196 --reps 3 --configs "$CF" --graph-cache /tmp/g 2>&1 | grep -E "search |index ready" | tee $O/ab_virgin_50m.txt
 rm -f /tmp/g.*

@@ -222,26 +222,49 @@ def test_label_filter_masks_and_merge(gpu_ctx, n_labels):
         ix.close()
 
 
-# the two-row gather with every pass shape: R = 50 gives visits with 1..50 new candidates (one pair of passes, a pair + a single
-# row group, two pairs), on scans long enough to spill the heap
-@pytest.mark.parametrize("variant", ["5", "5_virgin"])
-def test_two_row_gather_full_neighbor_lists(gpu_ctx, variant):
+# the two-row gather (VS_F_MINW=5) and the software-pipelined visit (VS_F_SP=1: 5 waves per SIMD, 2: 4 waves) with every pass shape:
+# R = 50 gives visits with 1..50 new candidates (one pair of passes, a pair + a single row group, two pairs), on scans long enough to
+# spill the heap; the labeled index runs the instantiation with label keys and a visibility mask
+VARIANTS = {"5": {"VS_F_MINW": "5"}, "5_virgin": {"VS_F_MINW": "5", "VS_F_VIRGIN": "1"}, "sp5": {"VS_F_SP": "1"},
+            "sp5_virgin": {"VS_F_SP": "1", "VS_F_VIRGIN": "1"}, "sp4": {"VS_F_SP": "2"}, "sp4_virgin": {"VS_F_SP": "2", "VS_F_VIRGIN": "1"}}
+
+
+@pytest.mark.parametrize("variant", list(VARIANTS))
+@pytest.mark.parametrize("iname", ["plain_R50", "labels_R40", "short_lists_R64"])
+def test_two_row_gather_full_neighbor_lists(gpu_ctx, iname, variant):
     _hardware_unverified("5")
-    ti = cached_index(n=1500, dim_full=768, bits=2, R=50, distance=1, seed=29, kind="gauss", L_build=60)
+    kw, L, m, rescore = {
+        "plain_R50": (dict(n=1500, dim_full=768, bits=2, R=50, distance=1, seed=29, kind="gauss", L_build=60), 25, 90, 0),
+        "labels_R40": (dict(n=1200, dim_full=1536, bits=1, R=40, distance=2, seed=30, kind="gauss", L_build=50, n_labels=5,
+                            deleted_frac=0.1), 15, 60, 20),
+        "short_lists_R64": (dict(n=300, dim_full=768, bits=2, R=64, distance=1, seed=31, kind="gauss", L_build=20), 3, 250, 0),
+    }[iname]
+    ti = cached_index(**kw)
     ix = ti.upload(gpu_ctx)
     q = ti.queries(24, seed=8, kind="gauss")
-    oi, oh, ost = ti.oracle.stream_batch(q, L=25, m=90)
-    env = {"VS_F_LDS_MAX_INS": "0", "VS_F_VR": "0", "VS_F_MINW": "5"}
-    if variant.endswith("_virgin"):
-        env["VS_F_VIRGIN"] = "1"
+    qlabels = None
+    if ti.label_off is not None:
+        rng = np.random.default_rng(6)
+        qlabels = [sorted(set(int(v) for v in rng.integers(1, 6, int(rng.integers(1, 3))))) for _ in range(len(q))]
+        vis = (rng.random(ti.n) > 0.2).astype(np.uint8)
+        ix.set_visibility(vis)
+        ti.oracle.set_visibility(vis)
+    env = {"VS_F_LDS_MAX_INS": "0", "VS_F_VR": "0"}
+    env.update(VARIANTS[variant])
     saved = {k: os.environ.get(k) for k in env}
     try:
+        oi, oh, ost = ti.oracle.stream_batch(q, L=L, m=m, qlabels=qlabels)
         os.environ.update(env)
-        gi, gh, gst = ix.stream_batch(q, search_list_size=25, m=90)
+        gi, gh, gst = ix.stream_batch(q, search_list_size=L, m=m, qlabels=qlabels)
         assert (gi == oi).all() and (gh == oh).all()
-        for key in ("visited_nodes", "candidate_nodes", "quantized_distance_comparisons", "node_reads"):
+        for key in ("visited_nodes", "candidate_nodes", "quantized_distance_comparisons", "node_reads", "next_calls"):
             assert gst[key] == ost[key], (key, gst[key], ost[key])
+        if rescore:
+            osi, osd, _ = ti.oracle.search_batch(q, L=L, rescore=rescore, k=10, qlabels=qlabels)
+            si, _, sd, _ = ix.search_batch(q, search_list_size=L, rescore=rescore, k=10, qlabels=qlabels)
+            assert (si == osi).all() and (sd.view(np.uint32) == osd.view(np.uint32)).all()
     finally:
+        ti.oracle.set_visibility(None)
         for k, v in saved.items():
             if v is None:
                 os.environ.pop(k, None)

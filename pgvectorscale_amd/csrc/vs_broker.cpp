@@ -68,6 +68,7 @@ struct vs_broker {
     std::mutex mu;
     std::condition_variable cv_work;
     std::deque<Request*> queue;
+    uint32_t ntasks = 0;  // single-scan tasks in the queue (always at its front: they are served before the gathering goes on)
     bool stop = false;
     std::thread dispatcher;
     vs_broker_stats st{};
@@ -155,7 +156,10 @@ void vs_broker::run() {
         }
         // gather: until the oldest request has waited max_wait_us or max_batch requests are queued
         const auto deadline = queue.front()->t_arrive + std::chrono::microseconds(cfg.max_wait_us);
-        while (!stop && queue.size() < cfg.max_batch && std::chrono::steady_clock::now() < deadline) cv_work.wait_until(lk, deadline);
+        // (a task that arrives meanwhile is at the front of the queue: it is run at once and the gathering resumes — the oldest
+        // scan's deadline is unchanged)
+        while (!stop && !ntasks && queue.size() < cfg.max_batch && std::chrono::steady_clock::now() < deadline)
+            cv_work.wait_until(lk, deadline);
         // one group = the scans that share the oldest request's GUCs (a NULL query never carries a label key)
         std::vector<Request*> grp;
         Request* head = queue.front();
@@ -173,7 +177,10 @@ void vs_broker::run() {
                 perr = "vs_broker: out of host memory in a dispatcher task";
             }
             lk.lock();
-            if (head->task) st.tasks++;
+            if (head->task) {
+                st.tasks++;
+                ntasks--;
+            }
             head->rc = prc;
             head->err = perr;
             head->done = true;
@@ -316,6 +323,7 @@ int vs_broker_call(vs_broker* b, int (*fn)(void*), void* arg) {
     }
     // ahead of queued scans that are still gathering company: a continuation is one short launch and its backend is waiting
     b->queue.push_front(&r);
+    b->ntasks++;
     b->cv_work.notify_one();
     r.cv.wait(lk, [&] { return r.done; });
     lk.unlock();

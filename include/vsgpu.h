@@ -445,6 +445,7 @@ typedef struct vs_broker_stats {
     uint64_t scans;     /* scans served                              */
     uint64_t max_batch; /* largest number of scans in one launch     */
     uint64_t tasks;     /* single-scan pieces of work run by the dispatcher between launches (cursor continuations) */
+    uint64_t cursors;   /* (vs_shm_server) scan cursors the serving process holds open right now */
 } vs_broker_stats;
 int vs_broker_create(vs_index* idx, const vs_broker_config* cfg /* NULL = defaults */, vs_broker** out);
 /* one scan: the rows of its first k amgettuple calls (as vs_search_batch).  query == NULL: the SQL-NULL query (label keys

@@ -92,7 +92,7 @@ class BrokerConfig(C.Structure):
 
 
 class BrokerStats(C.Structure):
-    _fields_ = [("batches", C.c_uint64), ("scans", C.c_uint64), ("max_batch", C.c_uint64), ("tasks", C.c_uint64)]
+    _fields_ = [("batches", C.c_uint64), ("scans", C.c_uint64), ("max_batch", C.c_uint64), ("tasks", C.c_uint64), ("cursors", C.c_uint64)]
 
 
 class Profile(C.Structure):

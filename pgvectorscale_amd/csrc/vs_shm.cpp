@@ -138,7 +138,7 @@ struct vs_shm_server {
     };
     std::vector<Cursor> cursors;
     uint64_t use_clock = 0;
-    std::atomic<uint64_t> fetches{0}, cursor_opens{0};
+    std::atomic<uint64_t> fetches{0}, cursor_opens{0}, open_cursors{0};
     void apply_puts();
     void run();
     void run_group(const std::vector<uint32_t>& grp);
@@ -210,6 +210,7 @@ void vs_shm_server::drop_cursor(size_t i) {
     vs_endscan(cursors[i].scan);
     cursors[i] = cursors.back();
     cursors.pop_back();
+    open_cursors = cursors.size();
 }
 
 // what identifies the scan a cursor belongs to besides (pid, scan_id): a client that reuses an id for another scan gets a new cursor
@@ -271,6 +272,7 @@ void vs_shm_server::run_fetch(uint32_t slot) {
                     }
                     if (rc == VS_OK) {
                         cursors.push_back(c);
+                        open_cursors = cursors.size();
                         at = cursors.size() - 1;
                         cursor_opens++;
                     } else {
@@ -513,6 +515,7 @@ int vs_shm_server_get_stats(vs_shm_server* s, vs_broker_stats* out) {
     out->scans = s->scans.load();
     out->max_batch = s->max_batch.load();
     out->tasks = s->fetches.load();
+    out->cursors = s->open_cursors.load();
     return VS_OK;
 }
 

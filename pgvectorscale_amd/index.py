@@ -428,7 +428,8 @@ class Broker:
     def stats(self):
         st = _lib.BrokerStats()
         check(self._L.vs_broker_get_stats(self.h, C.byref(st)))
-        return {"batches": int(st.batches), "scans": int(st.scans), "max_batch": int(st.max_batch), "tasks": int(st.tasks)}
+        return {"batches": int(st.batches), "scans": int(st.scans), "max_batch": int(st.max_batch), "tasks": int(st.tasks),
+                "cursors": int(st.cursors)}
 
     def close(self):
         if self.h:
@@ -458,7 +459,8 @@ class ShmServer:
     def stats(self):
         st = _lib.BrokerStats()
         check(self._L.vs_shm_server_get_stats(self.h, C.byref(st)))
-        return {"batches": int(st.batches), "scans": int(st.scans), "max_batch": int(st.max_batch), "tasks": int(st.tasks)}
+        return {"batches": int(st.batches), "scans": int(st.scans), "max_batch": int(st.max_batch), "tasks": int(st.tasks),
+                "cursors": int(st.cursors)}
 
     def close(self):
         if self.h:

@@ -385,3 +385,52 @@ def test_fetch_protocol_random_walk(gpu_ctx, oracle):
     c.close()
     srv.close()
     ix.close()
+
+
+def _cursor_holder(name, lib_path, q, ready):
+    from pgvectorscale_amd import _lib
+    if lib_path:
+        _lib.LIB_PATH = lib_path
+    import time
+    import pgvectorscale_amd as P
+    c = P.ShmClient(name)
+    c.fetch(7, q, 0, 8, None, 30, 10)  # opens a cursor in the serving process ...
+    ready.put("open")
+    time.sleep(600)  # ... and never ends the scan: the parent kills this process
+
+
+def test_cursors_of_a_dead_client_are_dropped(gpu_ctx, oracle):
+    """a backend that dies in the middle of a streamed scan must not leave its cursor (device memory) behind in the serving process"""
+    import signal
+    import time
+    import pgvectorscale_amd as P
+    from pgvectorscale_amd import _lib
+    ti = TestIndex(**KW)
+    ix = ti.upload(gpu_ctx)
+    q = ti.queries(2, seed=6, kind="gauss")
+    name = f"/vs_shm_cur_{os.getpid()}"
+    srv = P.ShmServer(ix, name, nslots=2, kmax=8, max_batch=8, max_wait_us=0)
+    ctx = mp.get_context("spawn")
+    ready = ctx.Queue()
+    p = ctx.Process(target=_cursor_holder, args=(name, _lib.LIB_PATH, q[0], ready))
+    p.start()
+    assert ready.get(timeout=300) == "open"
+    assert srv.stats()["cursors"] == 1
+    c = P.ShmClient(name)
+    ids, _, _ = c.fetch(1, q[1], 0, 8, None, 30, 10)  # a live client's cursor next to it
+    assert len(ids) == 8 and srv.stats()["cursors"] == 2
+    os.kill(p.pid, signal.SIGKILL)
+    p.join(30)
+    deadline = time.time() + 30
+    while srv.stats()["cursors"] != 1 and time.time() < deadline:
+        time.sleep(0.05)
+    assert srv.stats()["cursors"] == 1  # the dead client's is gone, the live one's stays ...
+    os_ = ti.oracle.scan(q[1], L=30, rescore=10)
+    want = [os_.gettuple() for _ in range(16)]
+    ids, _, _ = c.fetch(1, q[1], 8, 8, None, 30, 10)  # ... and continues
+    assert ids.tolist() == [o[0] for o in want[8:]]
+    c.end_scan(1)
+    assert srv.stats()["cursors"] == 0
+    c.close()
+    srv.close()
+    ix.close()

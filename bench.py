@@ -275,6 +275,15 @@ def main():
     ap.add_argument("--pcie-steps", type=int, default=1,
                     help="steps of the PCIe-inclusive leg (queries start in pageable host memory, rows end there: vs_search_batch); "
                          "reported next to the value, never as the value; 0 = skip")
+    ap.add_argument("--autotune", default="on", choices=["on", "off"],
+                    help="on (default): before the timed region the library times every exact launch variant of the search kernel on one "
+                         "warm-up batch (vs_index_autotune: a variant must reproduce the default's rows, distance bits and counters on all "
+                         "scans of that batch to qualify; the fastest qualified one is used when it beats the default by > 1.5 %%), after "
+                         "a child-process probe of the variants on a small index under a timeout (pgvectorscale_amd/tune_probe.py); the "
+                         "line reports every candidate's time under `autotune`.  off: the library default")
+    ap.add_argument("--tune-reps", type=int, default=2, help="timed steps per variant (after one warm-up step each)")
+    ap.add_argument("--probe-n", type=int, default=100_000, help="nodes of the probe child's index")
+    ap.add_argument("--probe-timeout", type=float, default=240.0)
     args = ap.parse_args()
 
     import numpy as np
@@ -303,6 +312,22 @@ def main():
     import pgvectorscale_amd as P
     from pgvectorscale_amd import _lib
     from pgvectorscale_amd.datagen import DatagenParams, fill_device
+
+    # ---- launch variants, step 1 (before this process owns anything on the device): every variant once in a CHILD process on a small
+    # index of the same code width, under a timeout — a kernel that misbehaves there costs its variant, not this run
+    tune = {"mode": args.autotune, "variant": "default", "probe": None, "candidates": None}
+    tune_skip = None
+    if args.autotune == "on":
+        from pgvectorscale_amd import tune_probe
+        t0 = time.time()
+        pkw = dict(dim=args.dim, n=args.probe_n, nq=8192, device=local_rank, timeout=args.probe_timeout)
+        if EMU:
+            pkw.update(n=min(args.probe_n, 600), nq=16, rescore=20, build_l=20, device=0, lib=_l.LIB_PATH, timeout=900)
+        tune_skip, prep = tune_probe.run(**pkw)
+        tune["probe"] = {kk: prep.get(kk) for kk in ("ok", "error", "skip", "seconds", "index") if kk in prep}
+        if prep.get("variants"):
+            tune["probe"]["not_clean"] = {nm: v for nm, v in prep["variants"].items() if v["applicable"] and (not v["rows_identical"] or v["error"])}
+        log(f"variant probe (child process, {time.time() - t0:.1f} s): {tune['probe']}")
 
     ctx = P.Context(0 if EMU else local_rank)
     log("device:", ctx.device_name())
@@ -649,6 +674,26 @@ def main():
             hs_ = {"recall": rec_, "se": se_, "lower95": rec_ - 1.96 * se_, "queries": nh * world}
         return hs_
 
+    # ---- launch variants, step 2: the variants the probe cleared, timed by the library on a warm-up batch of THIS index at THIS
+    # operating point (all nq scans; rows, distance bits and counters held to the default's); the index keeps the fastest
+    if args.autotune == "on" and tune_skip is not None:
+        try:
+            t0 = time.time()
+            cand = ix.autotune(qbuf[0], nq, L, S, k, d_qlabels=qkeys[0] and qkeys[0][2], d_qlabel_off=qkeys[0] and qkeys[0][3],
+                               reps=args.tune_reps, skip=tune_skip)
+            tune["candidates"] = [c_ for c_ in cand if c_["applicable"] or c_["error"] or c_["name"] in tune_skip]
+            tune["variant"] = ix.variant()
+            tune["seconds"] = round(time.time() - t0, 2)
+            log(f"autotune ({tune['seconds']} s): " + ", ".join(
+                f"{c_['name']} {c_['step_ms']:.2f} ms" + ("" if c_["rows_identical"] else " (ROWS DIFFER: disqualified)") + (" <- chosen" if c_["chosen"] else "")
+                for c_ in cand if c_["applicable"]))
+        except P.VsError as e:
+            tune["error"] = str(e)
+            ix.set_variant("default")
+            log(f"autotune failed ({e}); the library default is used")
+    elif args.autotune == "on":
+        log("the variant probe did not finish cleanly: no variant is launched in this process, the library default is used")
+
     # The printed value must belong to results that meet the target: when the rows of the timed steps themselves fall short
     # of it, the rescore window grows (as a user would raise diskann.query_rescore) and ALL K steps are timed again.
     K = args.steps
@@ -706,7 +751,8 @@ def main():
                        "kernel_source_hash": pj.get("kernel_source_hash"),
                        "same_kernel_sources_as_this_build": pj.get("kernel_source_hash") == src_hash,
                        "search_list_size": pj.get("L"), "rescore": pj.get("rescore")}
-                if pj.get("L") == L and pj.get("rescore") == S:
+                src["variant"] = pj.get("variant", "default")
+                if pj.get("L") == L and pj.get("rescore") == S and src["variant"] == tune["variant"]:
                     traffic = pj.get("hbm_bytes_per_launch")
                     traffic_source = src
                 else:
@@ -714,7 +760,7 @@ def main():
                                        alg_bytes_per_launch=pj.get("alg_bytes_per_launch"))
         except Exception:
             pass
-    roofline = {"bound": "hbm", "kernel": "k_search_fast", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
+    roofline = {"bound": "hbm", "kernel": "k_search_fast", "variant": tune["variant"], "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(achieved / 8000.0, 5), "traffic": traffic, "traffic_source": traffic_source,
                 "traffic_other_operating_point": traffic_ref,
                 "alg_bytes_per_launch": int(per_launch), "avg_kernel_ms": round(avg_ms, 4), "launches": s_n,
@@ -833,6 +879,7 @@ def main():
         "sbq_scan_roofline": scan_roofline,
         "pcie_inclusive": pcie,
         "kernels": kernels,
+        "autotune": tune,
         "work_per_query": {kk: round(vv / max(tot.get("queries", 1), 1), 2) for kk, vv in tot.items() if kk != "queries"},
         "setup_s": setup,
     }

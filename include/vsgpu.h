@@ -401,6 +401,35 @@ int vs_search_batch_dev(vs_index* idx, const float* d_queries, const int16_t* d_
                         uint64_t* d_out_tids, float* d_out_dist);
 int vs_search_batch_dev_finish(vs_index* idx, vs_stats* stats);
 
+/* ---- launch-variant selection (ours; the reference has no counterpart — its only query-time knobs are the two GUCs above,
+ * AM/guc.rs:3-43, and they stay the caller's).  The search kernel exists in several EXACT instantiations that differ only in
+ * how a scan keeps its private state (epoch-tagged dedup tables, a written-bucket bitmap, two code rows in flight, software-
+ * pipelined visits).  Which is fastest depends on the index size and on the box, so it is measured
+ * where it runs: vs_index_autotune runs every applicable variant on the caller's own device-resident batch (the arguments of
+ * vs_search_batch_dev), `reps` timed steps each after one warm-up, holds every row, every distance bit and every work counter of
+ * a variant to the library default's on the same batch, DISQUALIFIES a variant that differs anywhere (rows_identical = 0) and
+ * makes the fastest qualified one the index's choice when it beats the default by more than 1.5 %.  VS_F_* environment
+ * variables still override the choice per call.  report (may be NULL) receives one entry per variant, the default first.
+ * A caller that cannot afford a misbehaving kernel in its own process probes the variants in a child process first
+ * (pgvectorscale_amd/tune_probe.py: a small index of the same code width, every variant, a hard timeout) and passes the ones
+ * that did not come back clean as `skip`. */
+typedef struct vs_tune_entry {
+    char name[40];
+    float step_ms;          /* best device time of one step (search + rerank + rescore window), HIP events on the ctx stream */
+    float search_ms;        /* of which the search kernel(s) of the first attempt */
+    uint32_t applicable;    /* 0: the variant does not exist for this index / operating point (launched the default's kernel) */
+    uint32_t rows_identical;/* ids, distance bits and work counters equal the default's on the whole batch */
+    uint32_t chosen;
+    int32_t error;          /* VS_OK, or the error the variant's launch returned (it is then not eligible) */
+} vs_tune_entry;
+int vs_index_autotune(vs_index* idx, const float* d_queries, const int16_t* d_qlabels, const uint32_t* d_qlabel_off,
+                      uint32_t nq, uint32_t search_list_size, uint32_t rescore, uint32_t k, uint32_t reps,
+                      const char* skip /* comma-separated variant names not to launch at all, or NULL */,
+                      vs_tune_entry* report, uint32_t report_cap, uint32_t* n_report);
+/* name the variant by hand ("default", or a name vs_index_autotune reports) / read the current choice */
+int vs_index_set_variant(vs_index* idx, const char* name);
+int vs_index_get_variant(vs_index* idx, char* buf, size_t len);
+
 /* ---- the amrescan / amgettuple mirror (one row at a time) ----------------------------------------------------
  * A scan keeps what TSVScanState keeps between amgettuple calls (lsr + resort_buffer, AM/scan.rs:162-174) on the device and
  * CONTINUES the beam search when the executor asks for more rows (AM/scan.rs:370-405): it is never run again from the start

@@ -41,6 +41,16 @@ class Stats(C.Structure):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
 
 
+class TuneEntry(C.Structure):
+    _fields_ = [("name", C.c_char * 40), ("step_ms", C.c_float), ("search_ms", C.c_float), ("applicable", C.c_uint32),
+                ("rows_identical", C.c_uint32), ("chosen", C.c_uint32), ("error", C.c_int32)]
+
+    def as_dict(self):
+        return {"name": self.name.decode(), "step_ms": round(float(self.step_ms), 4), "search_ms": round(float(self.search_ms), 4),
+                "applicable": bool(self.applicable), "rows_identical": bool(self.rows_identical), "chosen": bool(self.chosen),
+                "error": int(self.error)}
+
+
 class NodeLayout(C.Structure):
     _fields_ = [(k, C.c_uint32) for k in ("root_size", "off_heap_item_pointer", "off_bq_vector",
                                           "off_neighbor_index_pointers", "off_labels")]
@@ -174,6 +184,9 @@ SYMBOLS = {
     "vs_stream_batch": (_i, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, C.POINTER(Stats)]),
     "vs_search_batch_dev": (_i, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp]),
     "vs_search_batch_dev_finish": (_i, [_vp, C.POINTER(Stats)]),
+    "vs_index_autotune": (_i, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, C.c_char_p, C.POINTER(TuneEntry), _u32, C.POINTER(_u32)]),
+    "vs_index_set_variant": (_i, [_vp, C.c_char_p]),
+    "vs_index_get_variant": (_i, [_vp, C.c_char_p, C.c_size_t]),
     "vs_beginscan": (_i, [_vp, C.POINTER(_vp)]),
     "vs_rescan": (_i, [_vp, _vp, _vp, _u32, _i, _u32, _u32]),
     "vs_gettuple": (_i, [_vp, C.POINTER(_u64), C.POINTER(_u32), C.POINTER(C.c_float)]),

@@ -116,6 +116,22 @@ struct ScanObs {
     double ov_frac = 1.0;              // fraction of scans that outgrew the LDS table
 };
 
+// the launch variant of k_search_fast an index prefers (vs_index_autotune / vs_index_set_variant): -1 = the library default;
+// a VS_F_* environment variable still overrides the field it names
+struct TuneVariant {
+    int epoch = -1, virgin = -1, minw = -1, sp = -1;
+    uint32_t gcap = 0;
+    char name[40] = "default";
+};
+// what the last first-attempt launch of k_search_fast really was (a variant that does not exist for an index / operating point
+// silently launches the default's instantiation: the autotuner reads this to tell)
+struct FastSig {
+    uint32_t epoch_on = 0, vwords = 0, minw = 0, sp = 0, gcap = 0, lh = 0, ran = 0;
+    bool operator==(const FastSig& o) const {
+        return epoch_on == o.epoch_on && vwords == o.vwords && minw == o.minw && sp == o.sp && gcap == o.gcap && lh == o.lh && ran == o.ran;
+    }
+};
+
 struct vs_index {
     vs_ctx* ctx = nullptr;
     bool is_view = false;  // vs_index_view: the device arrays belong to another handle
@@ -151,6 +167,8 @@ struct vs_index {
     SearchWorkspace ws;
     ScanObs obs;
     uint32_t last_ins_limit = 0;  // LDS-table admission limit of the last fast launch
+    TuneVariant tune;
+    FastSig last_fast;
     vs_stats last_stats{};
 };
 

@@ -372,6 +372,24 @@ class DiskAnnIndex:
         check(self._L.vs_search_batch_dev_finish(self.h, C.byref(st)))
         return st.as_dict()
 
+    def autotune(self, d_queries, nq, search_list_size, rescore, k, d_qlabels=None, d_qlabel_off=None, reps=2, skip=()):
+        """vs_index_autotune: times every applicable exact launch variant of the search kernel on this device-resident batch,
+        disqualifies any whose rows / distance bits / counters differ from the default's, keeps the fastest -> report (list of dicts)"""
+        from ._lib import TuneEntry
+        rep = (TuneEntry * 32)()
+        n = C.c_uint32(0)
+        check(self._L.vs_index_autotune(self.h, d_queries, d_qlabels, d_qlabel_off, nq, search_list_size, rescore, k, reps,
+                                        ",".join(skip).encode() if skip else None, rep, 32, C.byref(n)))
+        return [rep[i].as_dict() for i in range(min(int(n.value), 32))]
+
+    def set_variant(self, name):
+        check(self._L.vs_index_set_variant(self.h, name.encode()))
+
+    def variant(self):
+        buf = C.create_string_buffer(64)
+        check(self._L.vs_index_get_variant(self.h, buf, 64))
+        return buf.value.decode()
+
     def bruteforce_topk(self, d_queries, nq, k):
         ids = np.empty((nq, k), np.uint32)
         dist = np.empty((nq, k), np.float32)

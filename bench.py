@@ -687,10 +687,15 @@ def main():
             log(f"autotune ({tune['seconds']} s): " + ", ".join(
                 f"{c_['name']} {c_['step_ms']:.2f} ms" + ("" if c_["rows_identical"] else " (ROWS DIFFER: disqualified)") + (" <- chosen" if c_["chosen"] else "")
                 for c_ in cand if c_["applicable"]))
-        except P.VsError as e:
-            tune["error"] = str(e)
+        except Exception as e:  # noqa: BLE001 — the selection is an optimisation: whatever goes wrong, the default runs
+            tune["error"] = repr(e)
+            try:
+                ix.search_batch_dev_finish()
+            except Exception:  # noqa: BLE001
+                pass
             ix.set_variant("default")
-            log(f"autotune failed ({e}); the library default is used")
+            tune["variant"] = "default"
+            log(f"autotune failed ({e!r}); the library default is used")
     elif args.autotune == "on":
         log("the variant probe did not finish cleanly: no variant is launched in this process, the library default is used")
 

@@ -792,7 +792,7 @@ static Caps initial_caps(const vs_index* ix, uint32_t L, uint32_t M) {
     // Large scans: an LDS table for all ids would leave 3-4 scans per CU, and measurements (10M x 768: 148 ms vs 97 ms
     // per 65536 scans) show that occupancy beats on-chip latency there, so the table shrinks to a 256-slot stub, ids go
     // to the per-scan global table (L2 atomics) and the CU holds 16+ scans.
-    const bool lds_table = typ_ins <= env_u32("VS_F_LDS_MAX_INS", 3072);
+    const bool lds_table = typ_ins <= knob_u32("VS_F_LDS_MAX_INS", ix->tune.lds_max_ins, 3072);
     c.f_lh = env_u32("VS_F_LH", lds_table ? (uint32_t)round_up_u32((uint32_t)typ_ins, 64) : 0u);
     c.f_pool_frac = !lds_table ? 1.0
                     : (ix->obs.valid && ix->obs.L == L && ix->obs.M == M) ? std::min(1.0, 2.0 * ix->obs.ov_frac + 0.03) : 1.0;
@@ -1461,6 +1461,7 @@ struct TuneCand {
     const char* name;
     int epoch, virgin, minw, sp;
     uint32_t gcap;
+    int lds_max_ins = -1;  // 0: a candidate for indexes whose default is the LDS-table regime (the table-less regime there)
 };
 static const TuneCand kTuneCands[] = {
     {"default", -1, -1, -1, -1, 0},
@@ -1475,6 +1476,9 @@ static const TuneCand kTuneCands[] = {
     {"pipelined5_bitmap", 0, 1, -1, 1, 0},
     {"pipelined4", 0, 0, -1, 2, 0},
     {"pipelined4_bitmap", 0, 1, -1, 2, 0},
+    // small scans (dedup table in LDS by default: 3-4 times fewer scans per CU): the table-less regime instead, plain and with the bitmap
+    {"table_less", 0, 0, -1, 0, 0, 0},
+    {"table_less_bitmap", 0, 1, -1, 0, 0, 0},
 };
 static const uint32_t kNTuneCands = sizeof(kTuneCands) / sizeof(kTuneCands[0]);
 
@@ -1484,6 +1488,7 @@ static void tune_apply(vs_index* ix, const TuneCand& c) {
     ix->tune.minw = c.minw;
     ix->tune.sp = c.sp;
     ix->tune.gcap = c.gcap;
+    ix->tune.lds_max_ins = c.lds_max_ins;
     snprintf(ix->tune.name, sizeof(ix->tune.name), "%s", c.name);
 }
 
@@ -1595,7 +1600,8 @@ static int vs_index_autotune_impl(vs_index* ix, const float* d_q, const int16_t*
         snprintf(e.name, sizeof(e.name), "%s", cand.name);
         if (ci > 0) {
             // a variant that cannot be told from the default here is not launched at all
-            if (!base.sig.ran || base.sig.lh != 0) continue;                       // no LDS-resident kernel / LDS-table regime
+            if (!base.sig.ran) continue;                                           // no LDS-resident kernel for this index
+            if ((base.sig.lh != 0) != (cand.lds_max_ins == 0)) continue;           // table-less variants / LDS-table regime: the other's candidates
             if ((cand.minw >= 0 || cand.sp > 0) && !w24) continue;                 // built for 17..24-word codes only
             if (cand.gcap && cand.gcap <= base.sig.gcap) continue;                 // not sparser than the fitted table
             if (skip_list.find(std::string(",") + cand.name + ",") != std::string::npos) continue;  // the caller's veto

@@ -120,6 +120,7 @@ struct ScanObs {
 // a VS_F_* environment variable still overrides the field it names
 struct TuneVariant {
     int epoch = -1, virgin = -1, minw = -1, sp = -1;
+    int lds_max_ins = -1;  // 0: the table-less regime even for scans whose dedup table would fit LDS
     uint32_t gcap = 0;
     char name[40] = "default";
 };

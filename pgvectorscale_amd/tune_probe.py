@@ -121,6 +121,8 @@ def run(dim=768, n=100_000, nq=8192, device=0, lib=None, timeout=240.0, search_l
         return all_names, {"ok": False, "error": repr(e), "seconds": round(time.time() - t0, 2)}
     skip = [name for name, v in rep["variants"].items()
             if name != "default" and v["applicable"] and (not v["rows_identical"] or v["error"])]
+    if "bucket_bitmap" in skip:  # (the same kernel under the name it carries for indexes whose default is the LDS-table regime)
+        skip.append("table_less_bitmap")
     rep["skip"] = skip
     return skip, rep
 

@@ -16,7 +16,8 @@ pytestmark = pytest.mark.gpu
 EMU = bool(os.environ.get("VS_EMU"))
 REGIME = {"VS_F_LDS_MAX_INS": "0", "VS_F_VR": "0"}  # the table-less regime of large indexes (the variants exist only there)
 NAMES = ["default", "epoch_tags", "bucket_bitmap", "bucket_bitmap_16k", "bucket_bitmap_24k", "two_rows", "two_rows_bitmap",
-         "two_rows_epoch", "pipelined5", "pipelined5_bitmap", "pipelined4", "pipelined4_bitmap"]
+         "two_rows_epoch", "pipelined5", "pipelined5_bitmap", "pipelined4", "pipelined4_bitmap", "table_less", "table_less_bitmap"]
+LDS_REGIME_ONLY = NAMES[-2:]  # candidates for indexes whose default keeps the dedup table in LDS
 
 
 @pytest.fixture(scope="module")
@@ -30,7 +31,8 @@ def probe_skip():
     if EMU:
         assert rep["ok"] and skip == [], rep
         assert sorted(rep["variants"]) == sorted(NAMES)
-        assert all(v["applicable"] and v["rows_identical"] and not v["error"] and v["legs"] == 2 for v in rep["variants"].values()), rep
+        assert all(v["applicable"] and v["rows_identical"] and not v["error"] and v["legs"] == 2
+                   for nm, v in rep["variants"].items() if nm not in LDS_REGIME_ONLY), rep
     return skip
 
 
@@ -69,7 +71,7 @@ def test_autotune_holds_every_variant_to_the_defaults_rows(gpu_ctx, probe_skip, 
         assert chosen["applicable"] and chosen["rows_identical"] and chosen["error"] == 0
         assert ix.variant() == chosen["name"]
         for e in rep[1:]:
-            if e["name"] in probe_skip:
+            if e["name"] in probe_skip or e["name"] in LDS_REGIME_ONLY:
                 assert not e["applicable"] and not e["chosen"]
             elif EMU:  # on the interpreter every variant exists for this geometry and is exact
                 assert e["applicable"] and e["rows_identical"] and e["error"] == 0, e
@@ -106,18 +108,31 @@ def test_a_variant_whose_rows_differ_is_disqualified(gpu_ctx, probe_skip, regime
         ix.close()
 
 
-def test_variants_do_not_apply_outside_the_table_less_regime(gpu_ctx):
-    """a small scan keeps its dedup table in LDS: nothing but the default is launched, and the default is the choice"""
+def test_small_scans_try_the_table_less_regime(gpu_ctx, probe_skip):
+    """a small scan keeps its dedup table in LDS by default: there the candidates are the table-less regime (plain and with the
+    bitmap) and nothing else; both return the default's rows, and the oracle's"""
     ti = TestIndex(n=1500, dim_full=64, bits=2, R=32, distance=1, seed=3, kind="gauss", L_build=50)
     ix = ti.upload(gpu_ctx)
     q = ti.queries(16, seed=2, kind="gauss")
     dq = gpu_ctx.alloc(q.nbytes)
     gpu_ctx.upload(dq, q)
+    skip = list(probe_skip or [])
+    if probe_skip is None:
+        skip.append("table_less_bitmap")  # (its kernel has not been seen to come back on this box)
     try:
-        rep = ix.autotune(dq, len(q), 20, 10, 10, reps=1)
-        assert rep[0]["chosen"] and rep[0]["applicable"]
-        assert not any(e["applicable"] for e in rep[1:])
-        assert ix.variant() == "default"
+        oi, od, _ = ti.oracle.search_batch(q, L=20, rescore=10, k=10)
+        rep = ix.autotune(dq, len(q), 20, 10, 10, reps=1, skip=skip)
+        assert rep[0]["applicable"] and sum(e["chosen"] for e in rep) == 1
+        for e in rep[1:]:
+            if e["name"] not in LDS_REGIME_ONLY:
+                assert not e["applicable"], e
+            elif e["name"] not in skip:
+                assert e["applicable"] and (e["rows_identical"] or not EMU), e
+        for e in rep:
+            if e["applicable"] and e["rows_identical"]:
+                ix.set_variant(e["name"])
+                gi, _, gd, _ = ix.search_batch(q, search_list_size=20, rescore=10, k=10)
+                assert (gi == oi).all() and (gd.view(np.uint32) == od.view(np.uint32)).all(), e["name"]
     finally:
         gpu_ctx.free(dq)
         ix.close()

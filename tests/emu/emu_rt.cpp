@@ -194,6 +194,16 @@ void guarded_free(void* p) {
     abort();
 }
 
+}  // namespace emu
+// test hook (tests/test_emu.py, device-memory hygiene): device + pinned allocations that are live right now
+extern "C" size_t vs_emu_live_allocations(void) {
+    std::lock_guard<std::mutex> lk(emu::g_alloc_mu);
+    size_t n = emu::g_allocs.size();
+    for (const auto& sg : emu::g_segs) n += sg.used ? 1 : 0;
+    return n;
+}
+namespace emu {
+
 static constexpr size_t kStackBytes = 512 * 1024;
 static constexpr int kMaxThreadsPerBlock = 1024;
 

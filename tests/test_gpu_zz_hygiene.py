@@ -1,0 +1,84 @@
+"""Device-memory hygiene of the handles (a GPU broker process lives for weeks): whatever an index, its scans, cursors, brokers,
+views and the autotuner allocated on the device or as pinned memory is returned when they are closed.  Counted by the wave64
+interpreter's allocator (tests/emu: every hipMalloc / hipHostMalloc is one tracked mapping) — on hardware there is no such counter,
+so there the test only runs the sequence (it must not fail or leave the context unusable)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from helpers import TestIndex
+
+pytestmark = pytest.mark.gpu
+EMU = bool(os.environ.get("VS_EMU"))
+
+
+def _live():
+    if not EMU:
+        return 0
+    from conftest import EMU_LIB
+    lib = C.CDLL(EMU_LIB)
+    lib.vs_emu_live_allocations.restype = C.c_size_t
+    return int(lib.vs_emu_live_allocations())
+
+
+def _workout(ctx, ti, q, labeled):
+    import pgvectorscale_amd as P
+    ix = ti.upload(ctx)
+    keys = [[1], [2, 3]] * (len(q) // 2) if labeled else None
+    ix.search_batch(q, search_list_size=30, rescore=20, k=10, qlabels=keys)
+    ix.stream_batch(q, search_list_size=5, m=150, qlabels=keys)  # long streams: heap spill + global dedup regions
+    scan = ix.beginscan()
+    scan.rescan(q[0], labels=keys and keys[0], search_list_size=10, rescore=5)
+    for _ in range(70):
+        scan.gettuple()
+    scan.rescan(q[1], labels=keys and keys[1], search_list_size=4, rescore=0)
+    for _ in range(20):
+        scan.gettuple()
+    scan.endscan()
+    dq = ctx.alloc(q.nbytes)
+    ctx.upload(dq, q)
+    saved = {k: os.environ.get(k) for k in ("VS_F_LDS_MAX_INS", "VS_F_VR")}
+    try:
+        os.environ.update({"VS_F_LDS_MAX_INS": "0", "VS_F_VR": "0"})
+        if not labeled:
+            ix.autotune(dq, len(q), 10, 8, 10, reps=1, skip=() if EMU else ("bucket_bitmap", "bucket_bitmap_16k", "bucket_bitmap_24k",
+                                                                            "two_rows", "two_rows_bitmap", "two_rows_epoch", "pipelined5",
+                                                                            "pipelined5_bitmap", "pipelined4", "pipelined4_bitmap"))
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    ctx.free(dq)
+    view_ctx = P.Context(0)
+    v = ix.view(view_ctx)
+    v.search_batch(q[:4], search_list_size=20, rescore=10, k=5)
+    v.close()
+    view_ctx.close()
+    broker = P.Broker(ix, max_batch=8, max_wait_us=100)
+    broker.search(q[0], search_list_size=20, rescore=10, k=10)
+    bscan = broker.beginscan()
+    bscan.rescan(q[1], search_list_size=8, rescore=4)
+    for _ in range(40):
+        bscan.gettuple()
+    bscan.endscan()
+    broker.close()
+    ix.close()
+
+
+@pytest.mark.parametrize("labeled", [False, True])
+def test_handles_return_their_device_memory(gpu_ctx, labeled):
+    kw = dict(n=1200, dim_full=768, bits=2, R=32, distance=1, seed=13, kind="gauss", L_build=40)
+    if labeled:
+        kw.update(n_labels=4, deleted_frac=0.05)
+    ti = TestIndex(**kw)
+    q = ti.queries(8, seed=5, kind="gauss")
+    _workout(gpu_ctx, ti, q, labeled)  # first pass: the context's own lazily created resources (event pool, staging ring)
+    before = _live()
+    for _ in range(2):
+        _workout(gpu_ctx, ti, q, labeled)
+    after = _live()
+    assert after == before, f"{after - before} device / pinned allocations outlived their handles"

@@ -324,7 +324,7 @@ def main():
         if EMU:
             pkw.update(n=min(args.probe_n, 600), nq=16, rescore=20, build_l=20, device=0, lib=_l.LIB_PATH, timeout=900)
         tune_skip, prep = tune_probe.run(**pkw)
-        tune["probe"] = {kk: prep.get(kk) for kk in ("ok", "error", "skip", "seconds", "index") if kk in prep}
+        tune["probe"] = {kk: prep.get(kk) for kk in ("ok", "error", "skip", "seconds", "index", "legs") if kk in prep}
         if prep.get("variants"):
             tune["probe"]["not_clean"] = {nm: v for nm, v in prep["variants"].items() if v["applicable"] and (not v["rows_identical"] or v["error"])}
         log(f"variant probe (child process, {time.time() - t0:.1f} s): {tune['probe']}")

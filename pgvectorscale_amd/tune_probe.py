@@ -4,13 +4,15 @@ A variant of k_search_fast is only ever chosen after it has reproduced the defau
 comparison runs in the caller's process, and a kernel that never returns would take the process (a database backend's GPU broker,
 a benchmark) with it.  `run()` therefore launches every variant once in a CHILD process first: a small index of the same code
 width manufactured on the device (unlabeled and labeled, so both instantiations of every variant run: with and without label
-keys), forced into the table-less regime the large indexes live in, every variant through vs_index_autotune, under a hard
-timeout.  A variant that comes back anything but clean — or a child that has to be killed — is returned as a name to pass to
+keys), plus three corner legs (a corpus of near-duplicates whose row order the heap's array mechanics decide, scans that exhaust
+their graph, dedup tables at their load limit), forced into the table-less regime the large indexes live in, every variant
+through vs_index_autotune (each held to the default's rows on every leg), under a hard timeout.  A variant that comes back anything but clean — or a child that has to be killed — is returned as a name to pass to
 `DiskAnnIndex.autotune(skip=...)`.
 
     python -m pgvectorscale_amd.tune_probe [--dim 768] [--n 100000] [--nq 8192] [--device 0] [--lib PATH]
 
-prints one JSON object: {"ok": true, "variants": {name: {"applicable", "rows_identical", "error"}}, "seconds": s}.
+prints one JSON object: {"ok": true, "variants": {name: {"applicable", "rows_identical", "error", "legs", "failed_legs"}},
+"legs": {...}, "seconds": s}.
 
 Product code: libvsgpu.so only (no oracle, no CPU path); without a HIP device the child fails and every variant is skipped.
 """
@@ -25,9 +27,21 @@ import time
 FORCED_REGIME = {"VS_F_LDS_MAX_INS": "0", "VS_F_VR": "0"}
 
 
-def _child(args):
-    import ctypes as C
+def _labels(np, n, rng):
+    """four labels, one or two per node (sorted sets, AM/labels/mod.rs:15-37) -> CSR"""
+    two = rng.random(n) < 0.5
+    first = rng.integers(1, 5, n).astype(np.int16)
+    second = (first % 4 + 1).astype(np.int16)
+    cnt = 1 + two.astype(np.int64)
+    off = np.zeros(n + 1, np.uint32)
+    np.cumsum(cnt, out=off[1:])
+    val = np.empty(int(off[-1]), np.int16)
+    val[off[:-1]] = np.minimum(first, np.where(two, second, first))
+    val[off[:-1][two] + 1] = np.maximum(first, second)[two]
+    return off, val, cnt
 
+
+def _child(args):
     import numpy as np
 
     from . import _lib
@@ -39,55 +53,84 @@ def _child(args):
     t0 = time.time()
     os.environ.update(FORCED_REGIME)
     ctx = P.Context(args.device)
-    out = {}
-    for labeled in (False, True):
-        ix = P.DiskAnnIndex.alloc(ctx, n=args.n, dim_full=args.dim, num_neighbors=50, distance_type=P.VS_L2)
-        gp = DatagenParams(seed=77, dim=args.dim)
-        vecs_ptr, _ = ix.array(_lib.ARR_VECS)
-        fill_device(ctx, gp, 0, args.n, vecs_ptr)
-        ix.refresh_norms()
-        ix.sbq_train()
-        ix.sbq_quantize_corpus()
-        d_val = d_off = None
-        if labeled:  # four labels, one or two per node; keys of one label
+    small = max(300, min(args.n, 900))
+    # the legs: what the caller's index looks like (with and without label keys), and the corners the parity tests of the default
+    # kernel care about — rows decided by the heap's array mechanics alone (a corpus of near-duplicates: few distinct Hamming
+    # distances, thousands of ties), scans that exhaust their graph, dedup tables at their load limit (second attempts)
+    legs = [
+        dict(name="plain", n=args.n, gen={}, labeled=False, L=args.search_list_size, S=args.rescore, nq=args.nq, env={}),
+        dict(name="label_keys", n=args.n, gen={}, labeled=True, L=args.search_list_size, S=args.rescore, nq=args.nq, env={}),
+        dict(name="ties", n=max(small, args.n // 8), gen=dict(n_clusters=4, intra_pct=3, noise_pct=2), labeled=False, L=40, S=60,
+             nq=max(16, args.nq // 8), env={}),
+        dict(name="exhausted", n=small, gen={}, labeled=False, L=1000, S=0, nq=max(8, min(64, args.nq // 8)), env={}),
+        dict(name="tight_tables", n=max(small, args.n // 8), gen={}, labeled=False, L=args.search_list_size, S=args.rescore,
+             nq=max(16, args.nq // 8), env={"VS_F_GCAP": "1024" if args.rescore < 100 else "4096"}),
+    ]
+    out, leg_report = {}, {}
+    for leg in legs:
+        tl = time.time()
+        held = []
+        ix = None
+        saved = {k: os.environ.get(k) for k in leg["env"]}
+        try:
+            n, nq = leg["n"], leg["nq"]
+            ix = P.DiskAnnIndex.alloc(ctx, n=n, dim_full=args.dim, num_neighbors=50, distance_type=P.VS_L2)
+            gp = DatagenParams(seed=77, dim=args.dim, **leg["gen"])
+            vecs_ptr, _ = ix.array(_lib.ARR_VECS)
+            fill_device(ctx, gp, 0, n, vecs_ptr)
+            ix.refresh_norms()
+            ix.sbq_train()
+            ix.sbq_quantize_corpus()
+            d_val = d_off = None
             rng = np.random.default_rng(5)
-            two = rng.random(args.n) < 0.5
-            first = rng.integers(1, 5, args.n).astype(np.int16)
-            second = (first % 4 + 1).astype(np.int16)
-            cnt = 1 + two.astype(np.int64)
-            off = np.zeros(args.n + 1, np.uint32)
-            np.cumsum(cnt, out=off[1:])
-            val = np.empty(int(off[-1]), np.int16)
-            val[off[:-1]] = np.minimum(first, np.where(two, second, first))
-            val[off[:-1][two] + 1] = np.maximum(first, second)[two]
-            ix.set_labels(off, val)
-        ix.build_graph(search_list_size=args.build_l, max_alpha=1.2)
-        if labeled:
-            owner = np.repeat(np.arange(args.n, dtype=np.uint32), cnt)
-            labs, firsts = np.unique(val, return_index=True)
-            ix.set_start_nodes(0, {int(l): int(owner[i]) for l, i in zip(labs, firsts)})
-            keys = rng.integers(1, 5, args.nq).astype(np.int16)
-            koff = np.arange(args.nq + 1, dtype=np.uint32)
-            d_val, d_off = ctx.alloc(args.nq * 2), ctx.alloc((args.nq + 1) * 4)
-            ctx.upload(d_val, keys)
-            ctx.upload(d_off, koff)
-        dq = ctx.alloc(args.nq * args.dim * 4)
-        fill_device(ctx, gp, 1 << 40, args.nq, dq)
-        rep = ix.autotune(dq, args.nq, args.search_list_size, args.rescore, 10, d_qlabels=d_val, d_qlabel_off=d_off, reps=1)
-        for e in rep:
-            o = out.setdefault(e["name"], {"applicable": True, "rows_identical": True, "error": 0, "legs": 0})
-            o["applicable"] &= e["applicable"]
-            o["rows_identical"] &= e["rows_identical"]
-            o["error"] = o["error"] or e["error"]
-            o["legs"] += 1
-        ix.set_variant("default")
-        for p_ in (dq, d_val, d_off):
-            if p_ is not None:
-                ctx.free(p_)
-        ix.close()
+            if leg["labeled"]:
+                off, val, cnt = _labels(np, n, rng)
+                ix.set_labels(off, val)
+            ix.build_graph(search_list_size=args.build_l, max_alpha=1.2)
+            if leg["labeled"]:
+                owner = np.repeat(np.arange(n, dtype=np.uint32), cnt)
+                labs, firsts = np.unique(val, return_index=True)
+                ix.set_start_nodes(0, {int(l): int(owner[i]) for l, i in zip(labs, firsts)})
+                d_val, d_off = ctx.alloc(nq * 2), ctx.alloc((nq + 1) * 4)
+                held += [d_val, d_off]
+                ctx.upload(d_val, rng.integers(1, 5, nq).astype(np.int16))  # keys of one label
+                ctx.upload(d_off, np.arange(nq + 1, dtype=np.uint32))
+            dq = ctx.alloc(nq * args.dim * 4)
+            held.append(dq)
+            fill_device(ctx, gp, 1 << 40, nq, dq)
+            os.environ.update(leg["env"])
+            rep = ix.autotune(dq, nq, leg["L"], leg["S"], 10, d_qlabels=d_val, d_qlabel_off=d_off, reps=1)
+            for e in rep:
+                o = out.setdefault(e["name"], {"applicable": False, "rows_identical": True, "error": 0, "legs": 0, "failed_legs": []})
+                if e["applicable"] or e["error"]:
+                    o["applicable"] = True
+                    o["legs"] += 1
+                    if e["error"] or not e["rows_identical"]:
+                        o["rows_identical"] &= bool(e["rows_identical"]) and not e["error"]
+                        o["error"] = o["error"] or e["error"]
+                        o["failed_legs"].append(leg["name"])
+            leg_report[leg["name"]] = {"ok": True, "n": n, "scans": nq, "seconds": round(time.time() - tl, 2)}
+        except Exception as e:  # noqa: BLE001 — a leg that cannot be set up judges nobody (the first one has to run, though)
+            leg_report[leg["name"]] = {"ok": False, "error": repr(e)[:300]}
+            if leg["name"] == "plain":
+                raise
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+            if ix is not None:
+                try:
+                    ix.set_variant("default")
+                    for p_ in held:
+                        ctx.free(p_)
+                    ix.close()
+                except Exception:  # noqa: BLE001
+                    pass
     ctx.close()
-    print(json.dumps({"ok": True, "variants": out, "seconds": round(time.time() - t0, 2),
-                      "index": f"{args.n}x{args.dim}, unlabeled + labeled, table-less regime forced"}), flush=True)
+    print(json.dumps({"ok": True, "variants": out, "legs": leg_report, "seconds": round(time.time() - t0, 2),
+                      "index": f"{args.n}x{args.dim} + corner legs, table-less regime forced"}), flush=True)
 
 
 def run(dim=768, n=100_000, nq=8192, device=0, lib=None, timeout=240.0, search_list_size=3, rescore=196, build_l=64):

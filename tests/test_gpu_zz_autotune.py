@@ -30,8 +30,9 @@ def probe_skip():
     print("tune_probe:", rep)
     if EMU:
         assert rep["ok"] and skip == [], rep
+        assert all(leg["ok"] for leg in rep["legs"].values()) and len(rep["legs"]) == 5, rep["legs"]
         assert sorted(rep["variants"]) == sorted(NAMES)
-        assert all(v["applicable"] and v["rows_identical"] and not v["error"] and v["legs"] == 2
+        assert all(v["applicable"] and v["rows_identical"] and not v["error"] and v["legs"] == 5 and not v["failed_legs"]
                    for nm, v in rep["variants"].items() if nm not in LDS_REGIME_ONLY), rep
     return skip
 

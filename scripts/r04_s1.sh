@@ -15,8 +15,8 @@ VS_F_EPOCH=1 timeout 200 python scripts/fuzz_emu.py --gpu --seconds 120 --seed 4
 CF="VS_F_EPOCH=0:VS_F_VIRGIN=0:VS_F_GCAP=0:VS_F_MINW=6,VS_F_VIRGIN=1:VS_F_GCAP=0:VS_F_MINW=6,VS_F_VIRGIN=1:VS_F_GCAP=16384:VS_F_MINW=6,VS_F_VIRGIN=1:VS_F_GCAP=24576:VS_F_MINW=6,VS_F_VIRGIN=0:VS_F_GCAP=0:VS_F_MINW=5,VS_F_VIRGIN=1:VS_F_GCAP=0:VS_F_MINW=5,VS_F_VIRGIN=0:VS_F_GCAP=0:VS_F_MINW=6,VS_F_VIRGIN=1:VS_F_GCAP=0:VS_F_MINW=6,VS_F_VIRGIN=0:VS_F_EPOCH=1:VS_F_GCAP=0:VS_F_MINW=6,VS_F_EPOCH=0:VS_F_SP=1,VS_F_SP=2,VS_F_SP=1:VS_F_VIRGIN=1,VS_F_SP=2:VS_F_VIRGIN=1,VS_F_SP=0:VS_F_VIRGIN=0:VS_F_MINW=6"
 timeout 900 python scripts/perf_search.py --n 10000000 --nq 262144 --L 3 --rescore 196 --reps 3 --configs "$CF" --graph-cache /tmp/g 2>&1 | grep -E "search |index ready" | tee $O/ab_virgin_10m.txt
 timeout 1500 python scripts/perf_search.py --n 50000000 --nq 262144 --L 3 --rescore 196 --reps 3 --configs "$CF" --graph-cache /tmp/g 2>&1 | grep -E "search |index ready" | tee $O/ab_virgin_50m.txt
-rm -f /tmp/g.*
 # the product's own A/B (vs_index_autotune): the probe alone, then the bench with the selection on, and the PMC
 # traffic of whatever it chose (scripts/pmc_traffic.sh reads the variant's switches from the environment)
 timeout 300 python -m pgvectorscale_amd.tune_probe 2>&1 | tail -1 | tee $O/tune_probe.json
 timeout 900 python bench.py --steps 20 --warmup 5 --graph-cache /tmp/g 2>$O/bench_50m.log | tee $O/bench_50m_autotune.json
+rm -f /tmp/g.*

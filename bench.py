@@ -156,7 +156,7 @@ def choose_operating_point(run_sample, k, target, sweep_log, err_type=Exception)
         return L, S, rec
     _, (L, S) = min(ok)
     lo = max([x for x in s_grid if x < S], default=0)  # the last grid value that failed at this L (or 0)
-    while S - lo > max(4, S // 16):
+    while S - lo > max(4, S // 32):
         mid = (lo + S) // 2
         r_, _ = try_point(L, mid)
         if r_ >= target:
@@ -533,12 +533,13 @@ def main():
     recall = rec
     # The point must hold on queries it was not searched on, and with statistical room: the LOWER 95 % bound of recall@k on the
     # validation sample (>= 8192 queries by default: one standard error is about 0.0003 there) has to reach the target; the
-    # rescore window (diskann.query_rescore, README.md:382-394, AM/guc.rs:28-43) grows about 6 % a step until it does.
+    # rescore window (diskann.query_rescore, README.md:382-394, AM/guc.rs:28-43) grows about 2 % a step until it does (a step costs
+    # one launch of the validation sample, milliseconds; the window is the work of a query, so every step too many is QPS lost).
     val = run_set("validate", L, S)[0]
     sweep_log.append(("validate", L, S, round(val["recall"], 4), round(val["lower95"], 4)))
     bumps = 0
-    while not args.fixed and val["lower95"] < args.recall_target and recall >= args.recall_target and bumps < 12 and S < 1000:
-        S = min(1000, S + max(2, S // 16))
+    while not args.fixed and val["lower95"] < args.recall_target and recall >= args.recall_target and bumps < 40 and S < 1000:
+        S = min(1000, S + max(2, S // 48))
         bumps += 1
         recall, _ = run_sample(L, S)
         val = run_set("validate", L, S)[0]
@@ -713,7 +714,7 @@ def main():
             + f"): {hs['recall']:.4f} (lower 95 % bound {hs['lower95']:.4f}) at L={L} rescore={S}")
         if hs["recall"] >= args.recall_target or args.fixed or S >= 1000 or retimed >= 8 or recall < args.recall_target:
             break
-        S = min(1000, S + max(2, S // 16))
+        S = min(1000, S + max(2, S // 32))
         retimed += 1
         log(f"below the target: rescore -> {S}, timing all {K} steps again")
     if retimed:  # the reported tuning / validation recalls belong to the final point

@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--nq", type=int, required=True)
     ap.add_argument("--L", type=int, required=True)
     ap.add_argument("--rescore", type=int, required=True)
+    ap.add_argument("--variant", default="default", help="the launch variant the passes ran (scripts/pmc_traffic.sh)")
     ap.add_argument("--dir", default=os.path.join(ROOT, "gpurun_out"))
     args = ap.parse_args()
     fetch = per_kernel(os.path.join(args.dir, "pmc_fetch", "p_counter_collection.csv"), "FETCH_SIZE")
@@ -47,7 +48,7 @@ def main():
     from bench import kernel_source_hash
     # provenance: the sources the counters were collected on (bench.py compares the hash with its own build's) and the commit the
     # session was launched from (VS_COMMIT: there is no .git on the GPU box)
-    out = {"n": args.n, "nq": args.nq, "L": args.L, "rescore": args.rescore, "dim": 768, "labels": 0,
+    out = {"n": args.n, "nq": args.nq, "L": args.L, "rescore": args.rescore, "dim": 768, "labels": 0, "variant": args.variant,
            "kernel_source_hash": kernel_source_hash(), "commit": os.environ.get("VS_COMMIT"),
            "fetch_calibration": {"kernel": "k_scan_topk", "known_bytes": scan_bytes, "FETCH_SIZE_bytes": round(scan_fetch),
                                  "factor": round(cal, 4)}}

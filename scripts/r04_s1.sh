@@ -19,4 +19,7 @@ timeout 1500 python scripts/perf_search.py --n 50000000 --nq 262144 --L 3 --resc
 # traffic of whatever it chose (scripts/pmc_traffic.sh reads the variant's switches from the environment)
 timeout 300 python -m pgvectorscale_amd.tune_probe 2>&1 | tail -1 | tee $O/tune_probe.json
 timeout 900 python bench.py --steps 20 --warmup 5 --graph-cache /tmp/g 2>$O/bench_50m.log | tee $O/bench_50m_autotune.json
+read V L S < <(python -c "import json;j=json.load(open('$O/bench_50m_autotune.json'));print(j['roofline']['variant'], j['config']['search_list_size'], j['config']['rescore'])")
+timeout 900 bash scripts/pmc_traffic.sh 50000000 262144 $L $S /tmp/g $V 2>&1 | tail -40 | tee $O/pmc_traffic_50m_$V.txt
+cp gpurun_out/pmc_search_traffic.json $O/pmc_search_traffic_50m_$V.json
 rm -f /tmp/g.*

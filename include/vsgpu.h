@@ -169,6 +169,9 @@ int vs_index_set_visibility_dev(vs_index* idx, const uint8_t* d_visible);
 #define VS_MAX_SNAPSHOTS 16
 int vs_index_snapshot_put(vs_index* idx, uint32_t snapshot, const uint8_t* visible);
 int vs_index_snapshot_use(vs_index* idx, uint32_t snapshot, const uint8_t** previous /* may be NULL */);
+/* (for the lanes of a broker) a view takes over the snapshot masks its source holds right now — the masks stay the source's */
+int vs_index_snapshot_share(vs_index* view, const vs_index* src);
+int vs_index_device(const vs_index* idx); /* the HIP device of the index's context */
 /* 1 when the label masks of every node's neighbors are cached next to the neighbor rows: label-filtered scans on an index of
  * <= 64 distinct labels and more than 8M nodes build the cache on first use when device memory allows (+6.7 % at 20M, +0.6 % at
  * 5M, where the masks are cache resident anyway); VS_F_NBRMASK=1 / 0 forces it on / off */
@@ -468,6 +471,10 @@ typedef struct vs_broker vs_broker;
 typedef struct vs_broker_config {
     uint32_t max_batch;   /* scans per launch at most (0 = 8192)                                  */
     uint32_t max_wait_us; /* how long the oldest waiting scan may be held back to let others join */
+    uint32_t cursor_lanes; /* 0 (default): the continuations of the scans' cursors (amgettuple past the shared first rows) run on
+                            * the dispatcher thread, one at a time, between two shared launches.  n > 0: on n lanes — threads of the
+                            * broker with a HIP stream and a view of the index each — so that n scans continue concurrently on the
+                            * device and none of them waits behind a shared launch (a scan stays on its lane)          */
 } vs_broker_config;
 typedef struct vs_broker_stats {
     uint64_t batches;   /* vs_search_batch calls made                */

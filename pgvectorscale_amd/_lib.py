@@ -98,7 +98,7 @@ class PagesInfo(C.Structure):
 
 
 class BrokerConfig(C.Structure):
-    _fields_ = [("max_batch", C.c_uint32), ("max_wait_us", C.c_uint32)]
+    _fields_ = [("max_batch", C.c_uint32), ("max_wait_us", C.c_uint32), ("cursor_lanes", C.c_uint32)]
 
 
 class BrokerStats(C.Structure):

@@ -479,6 +479,13 @@ extern "C" int vs_index_snapshot_use(vs_index* ix, uint32_t snapshot, const uint
     return VS_OK;
 }
 
+extern "C" int vs_index_snapshot_share(vs_index* view, const vs_index* src) {
+    VS_REQUIRE(view && src && view->is_view, "vs_index_snapshot_share: needs a view and its source");
+    for (int i = 0; i < VS_MAX_SNAPSHOTS; ++i) view->snap[i] = src->snap[i];
+    return VS_OK;
+}
+extern "C" int vs_index_device(const vs_index* ix) { return ix ? ix->ctx->device : -1; }
+
 extern "C" int vs_index_refresh_norms(vs_index* ix) {
     VS_REQUIRE(ix, "vs_index_refresh_norms: index is NULL");
     VS_TRY(launch_row_norms(ix));
@@ -1750,6 +1757,7 @@ struct ScanCursor {
 struct vs_scan {
     vs_index* ix = nullptr;
     vs_broker* broker = nullptr;  // non-null: the first window comes from a shared launch, the rest from a cursor on the dispatcher thread
+    uint32_t lane = 0;            // (broker scans) the cursor lane the scan's continuations run on
     uint32_t snapshot = 0;        // (broker scans) visibility mask the scan runs under
     uint32_t snapshot_next = 0;   // ... from the next vs_rescan on (vs_scan_set_snapshot)
     bool active = false;
@@ -1770,6 +1778,8 @@ struct vs_scan {
     ~vs_scan() { cur.free_all(); }
 };
 extern "C" int vs_broker_call(vs_broker* b, int (*fn)(void*), void* arg);
+extern "C" int vs_broker_call_lane(vs_broker* b, uint32_t lane_key, int (*fn)(void*, vs_index*), void* arg);
+extern "C" uint32_t vs_broker_assign_lane(vs_broker* b);
 
 extern "C" int vs_beginscan(vs_index* ix, vs_scan** out) {
     VS_REQUIRE(ix && out, "vs_beginscan: bad args");
@@ -1786,6 +1796,7 @@ extern "C" int vs_beginscan_on_broker(vs_broker* b, vs_scan** out) {
     VS_REQUIRE_OOM(s, "vs_beginscan_on_broker: out of host memory");
     s->ix = vs_broker_index(b);
     s->broker = b;
+    s->lane = vs_broker_assign_lane(b);
     *out = s;
     return VS_OK;
 }
@@ -2069,24 +2080,30 @@ struct BrokerCursorTask {
     uint32_t target;
     bool release;
 };
-static int broker_cursor_task(void* p) {
+// `via`: the handle the work runs through — the broker's index on its dispatcher thread, or the view of the lane the scan lives on
+// (vs_broker_config.cursor_lanes); the scan's owner is blocked in vs_broker_call_lane meanwhile, so its `ix` can be lent out
+static int broker_cursor_task(void* p, vs_index* via) {
     BrokerCursorTask* t = static_cast<BrokerCursorTask*>(p);
     vs_scan* s = t->s;
     if (t->release) {
         s->cur.free_all();
         return VS_OK;
     }
-    return vs_guard("vs_gettuple", [&] {
+    vs_index* const own = s->ix;
+    s->ix = via;
+    const int rc = vs_guard("vs_gettuple", [&] {
         const uint8_t* prev = nullptr;
         VS_TRY(vs_index_snapshot_use(s->ix, s->snapshot, &prev));
         const int r = cursor_fetch(s, t->target);
         (void)vs_index_set_visibility_dev(s->ix, prev);  // (leaves the error text of a failed fetch alone)
         return r;
     });
+    s->ix = own;
+    return rc;
 }
 static int broker_cursor_fetch(vs_scan* s, uint32_t target) {
     BrokerCursorTask t{s, target, false};
-    return vs_broker_call(s->broker, broker_cursor_task, &t);
+    return vs_broker_call_lane(s->broker, s->lane, broker_cursor_task, &t);
 }
 
 static int vs_rescan_impl(vs_scan* s, const float* query, const int16_t* labels, uint32_t n_labels, int has_label_key,
@@ -2244,7 +2261,7 @@ extern "C" void vs_endscan(vs_scan* s) {
     if (!s) return;
     if (s->broker && (s->cur.open || s->cur.state.p)) {  // the cursor's device buffers go where they came from: the dispatcher thread
         BrokerCursorTask t{s, 0, true};
-        (void)vs_broker_call(s->broker, broker_cursor_task, &t);  // (a broker that is shutting down: freed below, by this thread)
+        (void)vs_broker_call_lane(s->broker, s->lane, broker_cursor_task, &t);  // (a broker that is shutting down: freed below, by this thread)
     }
     delete s;
 }

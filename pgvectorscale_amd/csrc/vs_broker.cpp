@@ -18,10 +18,14 @@
 #include <condition_variable>
 #include <cstdarg>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <deque>
+#include <memory>
 #include <mutex>
 #include <new>
+#include <shared_mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -41,6 +45,7 @@ struct Request {
     bool is_put = false;               // control request: install `put_mask` (n bytes or nullptr) as mask `snapshot`
     const uint8_t* put_mask = nullptr;
     int (*task)(void*) = nullptr;      // control request: run task(task_arg) on the dispatcher thread (scan cursors: vs_broker_call)
+    int (*task_via)(void*, vs_index*) = nullptr;  // ... or task_via(task_arg, <the handle of the thread that runs it>) (vs_broker_call_lane)
     void* task_arg = nullptr;
     uint32_t* out_ids;
     uint64_t* out_tids;
@@ -54,9 +59,22 @@ struct Request {
 
     bool same_group(const Request& o) const {
         // (scans of different snapshots never share a launch: a launch runs under ONE visibility mask)
-        return !is_put && !o.is_put && !task && !o.task && L == o.L && rescore == o.rescore && k == o.k && has_label_key == o.has_label_key &&
+        return !is_put && !o.is_put && !task && !o.task && !task_via && !o.task_via && L == o.L && rescore == o.rescore && k == o.k && has_label_key == o.has_label_key &&
                snapshot == o.snapshot;
     }
+};
+
+// One cursor lane (vs_broker_config.cursor_lanes): a thread with a context (HIP stream) and a view of the index of its own.  The
+// continuations of the scans assigned to it run here, one after the other; different lanes run concurrently with each other and
+// with the dispatcher's shared launches.
+struct Lane {
+    vs_ctx* ctx = nullptr;
+    vs_index* view = nullptr;
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<Request*> q;
+    bool stop = false;
 };
 
 }  // namespace
@@ -72,6 +90,13 @@ struct vs_broker {
     bool stop = false;
     std::thread dispatcher;
     vs_broker_stats st{};
+    std::vector<std::unique_ptr<Lane>> lanes;
+    std::atomic<uint32_t> next_lane{0};
+    // a lane works under the snapshot masks of the broker's index (shared for the length of a task); vs_broker_snapshot_put
+    // replaces one exclusively, i.e. when no lane is inside a task that could be reading it
+    std::shared_mutex snap_mu;
+
+    void run_lane(Lane& ln);
 
     void run();
     void run_group(std::vector<Request*>& grp);
@@ -163,21 +188,28 @@ void vs_broker::run() {
         // one group = the scans that share the oldest request's GUCs (a NULL query never carries a label key)
         std::vector<Request*> grp;
         Request* head = queue.front();
-        if (head->is_put || head->task) {  // a snapshot mask to install, or a piece of work on one scan's cursor: done here, on
+        if (head->is_put || head->task || head->task_via) {  // a snapshot mask to install, or a piece of work on one scan's cursor: done here, on
                                             // the only thread that touches the index
             queue.pop_front();
             lk.unlock();
             int prc;
             std::string perr;
             try {
-                prc = head->task ? head->task(head->task_arg) : vs_index_snapshot_put(ix, head->snapshot, head->put_mask);
+                if (head->task_via) {
+                    prc = head->task_via(head->task_arg, ix);
+                } else if (head->task) {
+                    prc = head->task(head->task_arg);
+                } else {
+                    std::unique_lock<std::shared_mutex> xl(snap_mu);  // (no lane is inside a task)
+                    prc = vs_index_snapshot_put(ix, head->snapshot, head->put_mask);
+                }
                 if (prc != VS_OK) perr = vs_last_error();
             } catch (const std::bad_alloc&) {
                 prc = VS_ERR_OOM;
                 perr = "vs_broker: out of host memory in a dispatcher task";
             }
             lk.lock();
-            if (head->task) {
+            if (head->task || head->task_via) {
                 st.tasks++;
                 ntasks--;
             }
@@ -198,6 +230,37 @@ void vs_broker::run() {
         }
         lk.unlock();
         run_group(grp);
+        lk.lock();
+    }
+}
+
+void vs_broker::run_lane(Lane& ln) {
+    std::unique_lock<std::mutex> lk(ln.mu);
+    for (;;) {
+        ln.cv.wait(lk, [&] { return ln.stop || !ln.q.empty(); });
+        if (ln.q.empty()) return;  // (stop: what was queued has been served)
+        Request* r = ln.q.front();
+        ln.q.pop_front();
+        lk.unlock();
+        int rc;
+        std::string err;
+        try {
+            std::shared_lock<std::shared_mutex> sl(snap_mu);
+            rc = vs_index_snapshot_share(ln.view, ix);
+            if (rc == VS_OK) rc = r->task_via(r->task_arg, ln.view);
+            if (rc != VS_OK) err = vs_last_error();
+        } catch (const std::bad_alloc&) {
+            rc = VS_ERR_OOM;
+            err = "vs_broker: out of host memory in a cursor lane";
+        }
+        {
+            std::lock_guard<std::mutex> g(mu);  // (the request's completion flag and the statistics live under the broker's lock)
+            st.tasks++;
+            r->rc = rc;
+            r->err = err;
+            r->done = true;
+            r->cv.notify_one();
+        }
         lk.lock();
     }
 }
@@ -223,6 +286,28 @@ int vs_broker_create(vs_index* idx, const vs_broker_config* cfg, vs_broker** out
     }
     b->cfg.max_batch = cfg && cfg->max_batch ? cfg->max_batch : 8192;
     b->cfg.max_wait_us = cfg ? cfg->max_wait_us : 200;
+    b->cfg.cursor_lanes = cfg ? std::min<uint32_t>(cfg->cursor_lanes, 64) : 0;
+    if (!b->cfg.cursor_lanes)  // (VS_BROKER_LANES: the default for brokers created without a lane count — how the whole broker
+        if (const char* e = getenv("VS_BROKER_LANES")) b->cfg.cursor_lanes = std::min<uint32_t>((uint32_t)strtoul(e, nullptr, 10), 64);  // test tier runs on lanes)
+    for (uint32_t i = 0; i < b->cfg.cursor_lanes; ++i) {
+        std::unique_ptr<Lane> ln(new (std::nothrow) Lane());
+        rc = ln ? vs_ctx_create(vs_index_device(idx), &ln->ctx) : VS_ERR_OOM;
+        if (rc == VS_OK) rc = vs_index_view(idx, ln->ctx, &ln->view);
+        if (rc != VS_OK) {  // (what was created so far goes away again; no thread has been started yet)
+            if (ln && ln->ctx) vs_ctx_destroy(ln->ctx);
+            for (auto& l : b->lanes) {
+                vs_index_free(l->view);
+                vs_ctx_destroy(l->ctx);
+            }
+            delete b;
+            return rc;
+        }
+        b->lanes.push_back(std::move(ln));
+    }
+    for (auto& l : b->lanes) {
+        Lane* lp = l.get();
+        lp->th = std::thread([b, lp] { b->run_lane(*lp); });
+    }
     b->dispatcher = std::thread([b] { b->run(); });
     *out = b;
     return VS_OK;
@@ -331,6 +416,62 @@ int vs_broker_call(vs_broker* b, int (*fn)(void*), void* arg) {
     return r.rc;
 }
 
+// fn(arg, handle) on the lane `lane_key` names (its thread, its view of the index), or — a broker without lanes — on the dispatcher
+// thread with the broker's own index; blocks until it is done.  Work of ONE scan: the scan stays on the lane it was assigned.
+int vs_broker_call_lane(vs_broker* b, uint32_t lane_key, int (*fn)(void*, vs_index*), void* arg) {
+    if (!b || !fn) {
+        vs_set_error("vs_broker_call_lane: null argument");
+        return VS_ERR_INVALID;
+    }
+    Request r;
+    r.query = nullptr;
+    r.has_label_key = false;
+    r.L = r.rescore = r.k = 0;
+    r.out_ids = nullptr;
+    r.out_tids = nullptr;
+    r.out_dist = nullptr;
+    r.task_via = fn;
+    r.task_arg = arg;
+    r.t_arrive = std::chrono::steady_clock::now() - std::chrono::hours(1);  // (no waiting for company)
+    if (b->lanes.empty()) {
+        if (std::this_thread::get_id() == b->dispatcher.get_id()) return fn(arg, b->ix);  // (already there)
+        std::unique_lock<std::mutex> lk(b->mu);
+        if (b->stop) {
+            vs_set_error("vs_broker_call_lane: the broker is shutting down");
+            return VS_ERR_STATE;
+        }
+        b->queue.push_front(&r);  // ahead of queued scans that are still gathering company
+        b->ntasks++;
+        b->cv_work.notify_one();
+        r.cv.wait(lk, [&] { return r.done; });
+    } else {
+        Lane& ln = *b->lanes[lane_key % b->lanes.size()];
+        {
+            std::lock_guard<std::mutex> lk(b->mu);
+            if (b->stop) {
+                vs_set_error("vs_broker_call_lane: the broker is shutting down");
+                return VS_ERR_STATE;
+            }
+        }
+        {
+            std::lock_guard<std::mutex> g(ln.mu);
+            if (ln.stop) {
+                vs_set_error("vs_broker_call_lane: the broker is shutting down");
+                return VS_ERR_STATE;
+            }
+            ln.q.push_back(&r);
+        }
+        ln.cv.notify_one();
+        std::unique_lock<std::mutex> lk(b->mu);
+        r.cv.wait(lk, [&] { return r.done; });
+    }
+    if (r.rc != VS_OK) vs_set_error("%s", r.err.c_str());
+    return r.rc;
+}
+
+// round robin over the lanes (0 without lanes)
+uint32_t vs_broker_assign_lane(vs_broker* b) { return b && !b->lanes.empty() ? b->next_lane.fetch_add(1) % (uint32_t)b->lanes.size() : 0u; }
+
 vs_index* vs_broker_index(vs_broker* b) { return b ? b->ix : nullptr; }
 
 int vs_broker_get_stats(vs_broker* b, vs_broker_stats* out) {
@@ -351,6 +492,16 @@ void vs_broker_destroy(vs_broker* b) {
     }
     b->cv_work.notify_all();
     if (b->dispatcher.joinable()) b->dispatcher.join();  // drains what is queued first (run() only returns on an empty queue)
+    for (auto& l : b->lanes) {  // the lanes serve what they were handed, then end; their views go before the index does
+        {
+            std::lock_guard<std::mutex> g(l->mu);
+            l->stop = true;
+        }
+        l->cv.notify_all();
+        if (l->th.joinable()) l->th.join();
+        vs_index_free(l->view);
+        vs_ctx_destroy(l->ctx);
+    }
     delete b;
 }
 

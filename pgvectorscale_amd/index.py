@@ -412,10 +412,12 @@ class Broker:
     backends).  search() may be called from any thread; the library's dispatcher thread is the only one that touches the
     device context."""
 
-    def __init__(self, index, max_batch=0, max_wait_us=200):
+    def __init__(self, index, max_batch=0, max_wait_us=200, cursor_lanes=0):
+        """cursor_lanes > 0: the continuations of the scans' cursors run on that many lanes (a thread, a HIP stream and a view of
+        the index each) instead of on the dispatcher thread between two shared launches"""
         self.index = index
         self._L = index._L
-        cfg = _lib.BrokerConfig(max_batch, max_wait_us)
+        cfg = _lib.BrokerConfig(max_batch, max_wait_us, cursor_lanes)
         h = C.c_void_p()
         check(self._L.vs_broker_create(index.h, C.byref(cfg), C.byref(h)))
         self.h = h
@@ -462,7 +464,7 @@ class ShmServer:
     def __init__(self, index, name, nslots=256, kmax=64, max_batch=0, max_wait_us=200):
         self.index = index
         self._L = index._L
-        cfg = _lib.BrokerConfig(max_batch, max_wait_us)
+        cfg = _lib.BrokerConfig(max_batch, max_wait_us, 0)
         h = C.c_void_p()
         check(self._L.vs_shm_server_create(index.h, name.encode(), nslots, kmax, C.byref(cfg), C.byref(h)))
         self.h = h

@@ -201,6 +201,8 @@ SYMBOLS = {
     "vs_index_snapshot_put": (_i, [_vp, _u32, _vp]),
     "vs_index_has_neighbor_masks": (_i, [_vp]),
     "vs_index_snapshot_use": (_i, [_vp, _u32, _vp]),
+    "vs_index_snapshot_share": (_i, [_vp, _vp]),
+    "vs_index_device": (_i, [_vp]),
     "vs_broker_get_stats": (_i, [_vp, C.POINTER(BrokerStats)]),
     "vs_broker_destroy": (None, [_vp]),
     "vs_broker_index": (_vp, [_vp]),

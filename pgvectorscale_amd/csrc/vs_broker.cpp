@@ -95,6 +95,7 @@ struct vs_broker {
     // a lane works under the snapshot masks of the broker's index (shared for the length of a task); vs_broker_snapshot_put
     // replaces one exclusively, i.e. when no lane is inside a task that could be reading it
     std::shared_mutex snap_mu;
+    std::atomic<int> put_waiting{0};  // lanes do not start a task while a mask waits to be replaced (readers would starve the writer)
 
     void run_lane(Lane& ln);
 
@@ -200,6 +201,11 @@ void vs_broker::run() {
                 } else if (head->task) {
                     prc = head->task(head->task_arg);
                 } else {
+                    struct Waiting {
+                        std::atomic<int>& n;
+                        explicit Waiting(std::atomic<int>& n_) : n(n_) { n.fetch_add(1, std::memory_order_acq_rel); }
+                        ~Waiting() { n.fetch_sub(1, std::memory_order_acq_rel); }
+                    } waiting(put_waiting);
                     std::unique_lock<std::shared_mutex> xl(snap_mu);  // (no lane is inside a task)
                     prc = vs_index_snapshot_put(ix, head->snapshot, head->put_mask);
                 }
@@ -245,6 +251,7 @@ void vs_broker::run_lane(Lane& ln) {
         int rc;
         std::string err;
         try {
+            while (put_waiting.load(std::memory_order_acquire) > 0) std::this_thread::sleep_for(std::chrono::microseconds(50));
             std::shared_lock<std::shared_mutex> sl(snap_mu);
             rc = vs_index_snapshot_share(ln.view, ix);
             if (rc == VS_OK) rc = r->task_via(r->task_arg, ln.view);

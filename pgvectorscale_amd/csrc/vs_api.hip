@@ -1483,6 +1483,8 @@ static const TuneCand kTuneCands[] = {
     {"pipelined5_bitmap", 0, 1, -1, 1, 0},
     {"pipelined4", 0, 0, -1, 2, 0},
     {"pipelined4_bitmap", 0, 1, -1, 2, 0},
+    {"pipelined5_epoch", 1, 0, -1, 1, 0},
+    {"pipelined4_epoch", 1, 0, -1, 2, 0},
     // small scans (dedup table in LDS by default: 3-4 times fewer scans per CU): the table-less regime instead, plain and with the bitmap
     {"table_less", 0, 0, -1, 0, 0, 0},
     {"table_less_bitmap", 0, 1, -1, 0, 0, 0},

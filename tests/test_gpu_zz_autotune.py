@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 EMU = bool(os.environ.get("VS_EMU"))
 REGIME = {"VS_F_LDS_MAX_INS": "0", "VS_F_VR": "0"}  # the table-less regime of large indexes (the variants exist only there)
 NAMES = ["default", "epoch_tags", "bucket_bitmap", "bucket_bitmap_16k", "bucket_bitmap_24k", "two_rows", "two_rows_bitmap",
-         "two_rows_epoch", "pipelined5", "pipelined5_bitmap", "pipelined4", "pipelined4_bitmap", "table_less", "table_less_bitmap"]
+         "two_rows_epoch", "pipelined5", "pipelined5_bitmap", "pipelined4", "pipelined4_bitmap", "pipelined5_epoch", "pipelined4_epoch", "table_less", "table_less_bitmap"]
 LDS_REGIME_ONLY = NAMES[-2:]  # candidates for indexes whose default keeps the dedup table in LDS
 
 

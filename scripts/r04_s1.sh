@@ -22,4 +22,6 @@ timeout 900 python bench.py --steps 20 --warmup 5 --graph-cache /tmp/g 2>$O/benc
 read V L S < <(python -c "import json;j=json.load(open('$O/bench_50m_autotune.json'));print(j['roofline']['variant'], j['config']['search_list_size'], j['config']['rescore'])")
 timeout 900 bash scripts/pmc_traffic.sh 50000000 262144 $L $S /tmp/g $V 2>&1 | tail -40 | tee $O/pmc_traffic_50m_$V.txt
 cp gpurun_out/pmc_search_traffic.json $O/pmc_search_traffic_50m_$V.json
+# BASELINE configs[2] at its full size against the oracle (opt-in test: 31 GB of vectors go to the host)
+VS_TEST_FULL_10M=1 timeout 600 python -m pytest tests/test_gpu_zx_full_size.py -q -m gpu -x 2>&1 | tail -3 | tee $O/full_size_tests.txt
 rm -f /tmp/g.*

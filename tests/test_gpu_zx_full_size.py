@@ -126,3 +126,35 @@ def test_configs1_1m_x_768_clustered(gpu_ctx, oracle):
             assert _recall(gi, bf) >= 0.97, _recall(gi, bf)
     finally:
         ix.close()
+
+
+@pytest.mark.skipif(not os.environ.get("VS_TEST_FULL_10M"), reason="configs[2] at full size (10M x 768, cosine): a 35-second device build and "
+                    "31 GB of vectors to the host for the oracle — opt in with VS_TEST_FULL_10M=1 (a GPU session's job, scripts/r04_s1.sh)")
+def test_configs2_10m_x_768_cosine(gpu_ctx, oracle):
+    import pgvectorscale_amd as P
+    from pgvectorscale_amd import _lib
+    from pgvectorscale_amd.datagen import DatagenParams, fill_device, rows_numpy
+    O = oracle
+    n, dim, nq, nq_oracle = (10_000_000, 768, 16384, 512) if not EMU else (2000, 768, 16, 16)
+    gp = DatagenParams(seed=5, dim=dim)
+    ix = P.DiskAnnIndex.alloc(gpu_ctx, n=n, dim_full=dim, num_neighbors=50, distance_type=P.VS_COSINE)
+    try:
+        vp, _ = ix.array(_lib.ARR_VECS)
+        fill_device(gpu_ctx, gp, 0, n, vp)
+        ix.refresh_norms()
+        ix.sbq_train()
+        ix.sbq_quantize_corpus()
+        ix.build_graph(search_list_size=100, max_alpha=1.2)
+        Q = rows_numpy(gp, (1 << 40) + 6 * (1 << 20), nq)
+        oidx = _oracle_view(O, ix, O.COSINE)
+        for L, S in ((100, 50), (35, 106)):  # the reference's defaults / the benchmark's operating point for this corpus
+            gi, gt, gd, gst = ix.search_batch(Q, search_list_size=L, rescore=S, k=10)
+            _properties(gi, gd, n)
+            assert gst["full_distance_comparisons"] == len(Q) * (S + 9)
+            oi, od, ost = oidx.search_batch(Q[:nq_oracle], L=L, rescore=S, k=10, threads=16)
+            assert (gi[:nq_oracle] == oi).all(), f"top-10 ids differ from the oracle at configs[2], L={L} rescore={S}"
+            assert np.allclose(gd[:nq_oracle], od, rtol=1e-5, atol=1e-7)  # cosine distances near 0: max(0, 1 - dot)
+            gi2, _, gd2, _ = ix.search_batch(Q[:4096], search_list_size=L, rescore=S, k=10)
+            assert (gi2 == gi[:4096]).all() and (gd2.view(np.uint32) == gd[:4096].view(np.uint32)).all()
+    finally:
+        ix.close()

@@ -474,7 +474,8 @@ typedef struct vs_broker_config {
     uint32_t cursor_lanes; /* 0 (default): the continuations of the scans' cursors (amgettuple past the shared first rows) run on
                             * the dispatcher thread, one at a time, between two shared launches.  n > 0: on n lanes — threads of the
                             * broker with a HIP stream and a view of the index each — so that n scans continue concurrently on the
-                            * device and none of them waits behind a shared launch (a scan stays on its lane)          */
+                            * device and none of them waits behind a shared launch (a scan stays on its lane).  vs_shm_server:
+                            * the streamed scans of client processes, by (client pid, scan id)                        */
 } vs_broker_config;
 typedef struct vs_broker_stats {
     uint64_t batches;   /* vs_search_batch calls made                */

@@ -26,6 +26,9 @@
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
+#include <deque>
+#include <memory>
+#include <shared_mutex>
 #include <mutex>
 #include <cerrno>
 #include <chrono>
@@ -34,6 +37,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -136,14 +140,35 @@ struct vs_shm_server {
         uint32_t pos = 0;  // rows handed out so far
         vs_scan* scan = nullptr;
     };
-    std::vector<Cursor> cursors;
-    uint64_t use_clock = 0;
+    // a table of cursors and the handle their scans run through: the dispatcher's own (the index itself), or one per cursor lane
+    struct CursorTable {
+        vs_index* ix = nullptr;
+        std::vector<Cursor> cursors;
+        uint64_t use_clock = 0;
+    };
+    CursorTable main_tab;
+    // cursor lanes (vs_broker_config.cursor_lanes): a thread, a context (HIP stream) and a view of the index each; a streamed scan
+    // is served by the lane its (client pid, scan id) hashes to, concurrently with the other lanes and with the shared launches
+    struct Lane {
+        vs_ctx* ctx = nullptr;
+        std::thread th;
+        std::mutex mu;
+        std::condition_variable cv;
+        std::deque<uint32_t> q;  // slots (already S_RUNNING) waiting for this lane
+        bool stop = false;
+        CursorTable tab;
+    };
+    std::vector<std::unique_ptr<Lane>> lanes;
+    std::shared_mutex snap_mu;        // lanes: shared for the length of a request; a mask is replaced exclusively
+    std::atomic<int> put_waiting{0};  // ... and lanes do not start a request while one waits (readers would starve the writer)
     std::atomic<uint64_t> fetches{0}, cursor_opens{0}, open_cursors{0};
     void apply_puts();
     void run();
+    void run_lane(Lane& ln);
     void run_group(const std::vector<uint32_t>& grp);
-    void run_fetch(uint32_t slot);
-    void drop_cursor(size_t i);
+    void run_fetch(uint32_t slot, CursorTable& t);
+    void drop_cursor(CursorTable& t, size_t i);
+    void reap_cursors(CursorTable& t);
 };
 
 struct vs_shm_client {
@@ -206,11 +231,18 @@ void vs_shm_server::run_group(const std::vector<uint32_t>& grp) {
     }
 }
 
-void vs_shm_server::drop_cursor(size_t i) {
-    vs_endscan(cursors[i].scan);
-    cursors[i] = cursors.back();
-    cursors.pop_back();
-    open_cursors = cursors.size();
+void vs_shm_server::drop_cursor(CursorTable& t, size_t i) {
+    vs_endscan(t.cursors[i].scan);
+    t.cursors[i] = t.cursors.back();
+    t.cursors.pop_back();
+    open_cursors--;
+}
+
+// the cursors of clients that died give their device memory back
+void vs_shm_server::reap_cursors(CursorTable& t) {
+    for (size_t i = 0; i < t.cursors.size();)
+        if (t.cursors[i].pid > 0 && kill(t.cursors[i].pid, 0) != 0 && errno == ESRCH) drop_cursor(t, i);
+        else ++i;
 }
 
 // what identifies the scan a cursor belongs to besides (pid, scan_id): a client that reuses an id for another scan gets a new cursor
@@ -227,7 +259,9 @@ static uint64_t scan_signature(const SlotHead* s, const float* q, uint32_t dim) 
     return h;
 }
 
-void vs_shm_server::run_fetch(uint32_t slot) {
+void vs_shm_server::run_fetch(uint32_t slot, CursorTable& t) {
+    std::vector<Cursor>& cursors = t.cursors;
+    vs_index* const ix = t.ix;  // (shadows the member: the handle this table's scans run through)
     SlotHead* s = m.slot(slot);
     int rc = VS_OK;
     std::string err;
@@ -238,14 +272,14 @@ void vs_shm_server::run_fetch(uint32_t slot) {
         if (cursors[i].pid == pid && cursors[i].scan_id == s->scan_id) at = i;
     try {
         if (s->op == OP_CLOSE) {
-            if (at < cursors.size()) drop_cursor(at);
+            if (at < cursors.size()) drop_cursor(t, at);
         } else {
             const uint64_t sig = scan_signature(s, Mapping::query(s), d.dim_full);
             const uint8_t* prev = nullptr;
             rc = vs_index_snapshot_use(ix, s->snapshot, &prev);
             if (rc == VS_OK) {
                 if (at < cursors.size() && (cursors[at].sig != sig || cursors[at].pos != s->skip)) {
-                    drop_cursor(at);  // another scan under the same id, or a client that is somewhere else in it: start over
+                    drop_cursor(t, at);  // another scan under the same id, or a client that is somewhere else in it: start over
                     at = cursors.size();
                 }
                 if (at == cursors.size()) {
@@ -253,7 +287,7 @@ void vs_shm_server::run_fetch(uint32_t slot) {
                         size_t lru = 0;
                         for (size_t i = 1; i < cursors.size(); ++i)
                             if (cursors[i].last_use < cursors[lru].last_use) lru = i;
-                        drop_cursor(lru);
+                        drop_cursor(t, lru);
                     }
                     Cursor c;
                     c.pid = pid;
@@ -272,7 +306,7 @@ void vs_shm_server::run_fetch(uint32_t slot) {
                     }
                     if (rc == VS_OK) {
                         cursors.push_back(c);
-                        open_cursors = cursors.size();
+                        open_cursors++;
                         at = cursors.size() - 1;
                         cursor_opens++;
                     } else {
@@ -285,7 +319,7 @@ void vs_shm_server::run_fetch(uint32_t slot) {
                 }
                 if (rc == VS_OK) {
                     Cursor& c = cursors[at];
-                    c.last_use = ++use_clock;
+                    c.last_use = ++t.use_clock;
                     // (a fast-forward that fell short: the scan has fewer rows than the client skipped — nothing left to return)
                     while (c.pos >= s->skip && got < s->k) {
                         const int r = vs_gettuple(c.scan, m.tids(s) + got, m.ids(s) + got, m.dist(s) + got);
@@ -323,7 +357,16 @@ void vs_shm_server::apply_puts() {
     mine.swap(puts);
     lk.unlock();
     for (PendingPut* p : mine) {
-        const int r = vs_index_snapshot_put(ix, p->snapshot, p->drop ? nullptr : p->mask.data());
+        int r;
+        {
+            struct Waiting {
+                std::atomic<int>& n;
+                explicit Waiting(std::atomic<int>& n_) : n(n_) { n.fetch_add(1, std::memory_order_acq_rel); }
+                ~Waiting() { n.fetch_sub(1, std::memory_order_acq_rel); }
+            } waiting(put_waiting);
+            std::unique_lock<std::shared_mutex> xl(snap_mu);  // (no lane is inside a request)
+            r = vs_index_snapshot_put(ix, p->snapshot, p->drop ? nullptr : p->mask.data());
+        }
         const std::string e = r == VS_OK ? "" : vs_last_error();
         lk.lock();
         p->err = e;
@@ -331,6 +374,34 @@ void vs_shm_server::apply_puts() {
         lk.unlock();
     }
     put_cv.notify_all();
+}
+
+void vs_shm_server::run_lane(Lane& ln) {
+    std::unique_lock<std::mutex> lk(ln.mu);
+    auto last_reap = std::chrono::steady_clock::now();
+    for (;;) {
+        ln.cv.wait_for(lk, std::chrono::milliseconds(200), [&] { return ln.stop || !ln.q.empty(); });
+        if (ln.q.empty() && ln.stop) break;
+        if (ln.q.empty() || std::chrono::steady_clock::now() - last_reap > std::chrono::milliseconds(200)) {
+            lk.unlock();
+            reap_cursors(ln.tab);
+            last_reap = std::chrono::steady_clock::now();
+            lk.lock();
+            if (ln.q.empty()) continue;
+        }
+        const uint32_t slot = ln.q.front();
+        ln.q.pop_front();
+        lk.unlock();
+        {
+            while (put_waiting.load(std::memory_order_acquire) > 0) std::this_thread::sleep_for(std::chrono::microseconds(50));
+            std::shared_lock<std::shared_mutex> sl(snap_mu);
+            (void)vs_index_snapshot_share(ln.tab.ix, ix);  // the masks the index holds right now
+            run_fetch(slot, ln.tab);
+        }
+        lk.lock();
+    }
+    lk.unlock();
+    while (!ln.tab.cursors.empty()) drop_cursor(ln.tab, ln.tab.cursors.size() - 1);
 }
 
 void vs_shm_server::run() {
@@ -394,7 +465,17 @@ void vs_shm_server::run() {
                 if (ha->op == OP_SEARCH) continue;
                 taken[a] = true;
                 ha->state.store(S_RUNNING, std::memory_order_relaxed);
-                run_fetch(ready[a]);
+                if (lanes.empty()) {
+                    run_fetch(ready[a], main_tab);
+                } else {  // the lane this scan lives on: (client pid, scan id) -> lane, the same for every request of the scan
+                    const uint64_t key = ((uint64_t)(uint32_t)ha->owner_pid * 0x9E3779B97F4A7C15ull) ^ (ha->scan_id * 0xC2B2AE3D27D4EB4Full);
+                    Lane& ln = *lanes[(size_t)((key >> 17) % lanes.size())];
+                    {
+                        std::lock_guard<std::mutex> g(ln.mu);
+                        ln.q.push_back(ready[a]);
+                    }
+                    ln.cv.notify_one();
+                }
             }
             for (size_t a = 0; a < ready.size(); ++a) {
                 if (taken[a]) continue;
@@ -428,12 +509,19 @@ void vs_shm_server::run() {
                     s->state.store(S_FREE, std::memory_order_release);
                 }
             }
-            for (size_t i = 0; i < cursors.size();)  // ... and its cursors their device memory
-                if (cursors[i].pid > 0 && kill(cursors[i].pid, 0) != 0 && errno == ESRCH) drop_cursor(i);
-                else ++i;
+            reap_cursors(main_tab);  // ... and its cursors their device memory (the lanes look after their own tables)
         }
     }
-    while (!cursors.empty()) drop_cursor(cursors.size() - 1);
+    while (!main_tab.cursors.empty()) drop_cursor(main_tab, main_tab.cursors.size() - 1);
+    // the lanes serve what they were handed, drop their cursors and end
+    for (auto& l : lanes) {
+        {
+            std::lock_guard<std::mutex> g(l->mu);
+            l->stop = true;
+        }
+        l->cv.notify_all();
+        if (l->th.joinable()) l->th.join();
+    }
     // shutting down: fail what is still posted so that no client sleeps forever
     for (uint32_t i = 0; i < h->nslots; ++i) {
         SlotHead* s = m.slot(i);
@@ -445,6 +533,15 @@ void vs_shm_server::run() {
             futex_wake(&s->state, 1);
         }
     }
+}
+
+// the views and contexts of the lanes (their threads are not running: not started yet, or joined by run())
+static void free_lanes(vs_shm_server* s) {
+    for (auto& l : s->lanes) {
+        if (l->tab.ix) vs_index_free(l->tab.ix);
+        if (l->ctx) vs_ctx_destroy(l->ctx);
+    }
+    s->lanes.clear();
 }
 
 extern "C" {
@@ -470,6 +567,22 @@ int vs_shm_server_create(vs_index* idx, const char* name, uint32_t nslots, uint3
     }
     s->cfg.max_batch = cfg && cfg->max_batch ? cfg->max_batch : 8192;
     s->cfg.max_wait_us = cfg ? cfg->max_wait_us : 200;
+    s->cfg.cursor_lanes = cfg ? std::min<uint32_t>(cfg->cursor_lanes, 64) : 0;
+    if (!s->cfg.cursor_lanes)
+        if (const char* e = getenv("VS_BROKER_LANES")) s->cfg.cursor_lanes = std::min<uint32_t>((uint32_t)strtoul(e, nullptr, 10), 64);
+    s->main_tab.ix = idx;
+    auto drop_lanes = [s] { free_lanes(s); };  // (no lane thread has been started yet)
+    for (uint32_t i = 0; i < s->cfg.cursor_lanes; ++i) {
+        std::unique_ptr<vs_shm_server::Lane> ln(new (std::nothrow) vs_shm_server::Lane());
+        rc = ln ? vs_ctx_create(vs_index_device(idx), &ln->ctx) : VS_ERR_OOM;
+        if (rc == VS_OK) rc = vs_index_view(idx, ln->ctx, &ln->tab.ix);
+        if (ln) s->lanes.push_back(std::move(ln));
+        if (rc != VS_OK) {
+            drop_lanes();
+            delete s;
+            return rc;
+        }
+    }
     const size_t sb = slot_size(s->d.dim_full, kmax);
     const size_t bytes = align16(sizeof(ShmHeader)) + sb * nslots;
     shm_unlink(name);
@@ -477,6 +590,7 @@ int vs_shm_server_create(vs_index* idx, const char* name, uint32_t nslots, uint3
     if (fd < 0 || ftruncate(fd, (off_t)bytes) != 0) {
         vs_set_error("vs_shm_server_create: shm_open/ftruncate(%s, %zu): %s", name, bytes, strerror(errno));
         if (fd >= 0) close(fd);
+        free_lanes(s);
         delete s;
         return VS_ERR_OOM;
     }
@@ -485,6 +599,7 @@ int vs_shm_server_create(vs_index* idx, const char* name, uint32_t nslots, uint3
     if (p == MAP_FAILED) {
         vs_set_error("vs_shm_server_create: mmap: %s", strerror(errno));
         shm_unlink(name);
+        free_lanes(s);
         delete s;
         return VS_ERR_OOM;
     }
@@ -501,6 +616,10 @@ int vs_shm_server_create(vs_index* idx, const char* name, uint32_t nslots, uint3
     h->serving.store(1);
     std::atomic_thread_fence(std::memory_order_release);
     h->magic = SHM_MAGIC;  // last: a client that sees the magic sees a complete header
+    for (auto& l : s->lanes) {
+        vs_shm_server::Lane* lp = l.get();
+        lp->th = std::thread([s, lp] { s->run_lane(*lp); });
+    }
     s->dispatcher = std::thread([s] { s->run(); });
     *out = s;
     return VS_OK;
@@ -525,7 +644,8 @@ void vs_shm_server_destroy(vs_shm_server* s) {
     s->stop.store(true);
     s->m.hdr()->work_seq.fetch_add(1);
     futex_wake(&s->m.hdr()->work_seq, INT_MAX);
-    if (s->dispatcher.joinable()) s->dispatcher.join();
+    if (s->dispatcher.joinable()) s->dispatcher.join();  // (run() joins the lanes before it returns)
+    free_lanes(s);
     s->put_cv.notify_all();
     munmap(s->m.base, s->m.bytes);
     shm_unlink(s->name.c_str());

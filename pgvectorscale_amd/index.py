@@ -461,10 +461,10 @@ class ShmServer:
     """The dispatcher side of the cross-process request queue (vs_shm_server_*): lives in the one process that owns the device
     context; client processes post scans into the POSIX shared-memory segment `name` and get the rows of vs_search_batch."""
 
-    def __init__(self, index, name, nslots=256, kmax=64, max_batch=0, max_wait_us=200):
+    def __init__(self, index, name, nslots=256, kmax=64, max_batch=0, max_wait_us=200, cursor_lanes=0):
         self.index = index
         self._L = index._L
-        cfg = _lib.BrokerConfig(max_batch, max_wait_us, 0)
+        cfg = _lib.BrokerConfig(max_batch, max_wait_us, cursor_lanes)  # cursor_lanes: streamed scans are served on that many lanes
         h = C.c_void_p()
         check(self._L.vs_shm_server_create(index.h, name.encode(), nslots, kmax, C.byref(cfg), C.byref(h)))
         self.h = h

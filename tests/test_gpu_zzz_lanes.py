@@ -101,3 +101,37 @@ def test_deep_scans_stream_on_lanes(gpu_ctx, oracle, lanes):
     assert (gi == oi).all()
     ix.close()
     assert _live() == before, "device / pinned memory of the lanes (contexts, views, cursors) outlived the broker and the index"
+
+
+def test_backend_processes_stream_on_lanes(gpu_ctx, oracle, monkeypatch):
+    """the same across processes (vs_shm_server with cursor lanes): the streaming and the badly-behaved-client tests of the shared-memory
+    transport, with the serving process's cursors spread over two lanes"""
+    monkeypatch.setenv("VS_BROKER_LANES", "2")  # servers created without a lane count take it from here
+    import test_gpu_zu_shm as Z
+    Z.test_backend_processes_stream_past_the_first_rows(gpu_ctx, oracle)
+    Z.test_fetch_protocol_random_walk(gpu_ctx, oracle)
+
+
+def test_shm_server_with_lanes_gives_its_memory_back(gpu_ctx, oracle):
+    import pgvectorscale_amd as P
+    ti = TestIndex(n=600, dim_full=32, bits=2, R=16, distance=oracle.L2, seed=5, kind="gauss", L_build=30)
+    before = _live()
+    ix = ti.upload(gpu_ctx)
+    name = f"/vs_shm_lanes_{os.getpid()}"
+    srv = P.ShmServer(ix, name, nslots=4, kmax=8, cursor_lanes=3)
+    cl = P.ShmClient(name)
+    q = ti.queries(3, seed=2, kind="gauss")
+    for i in range(3):  # three streamed scans (they hash to lanes by (pid, scan id)); two are left open for the server to drop
+        os_ = ti.oracle.scan(q[i], L=10, rescore=4)
+        scan = cl.beginscan(chunk=8)
+        scan.rescan(q[i], search_list_size=10, rescore=4)
+        for j in range(30):
+            r, o = scan.gettuple(), os_.gettuple()
+            assert r is not None and o is not None and r[1] == o[0] and r[0] == o[1], (i, j)
+        if i == 0:
+            scan.endscan()
+    assert srv.stats()["cursors"] == 2
+    cl.close()
+    srv.close()
+    ix.close()
+    assert _live() == before

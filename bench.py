@@ -702,6 +702,12 @@ def main():
 
     # The printed value must belong to results that meet the target: when the rows of the timed steps themselves fall short
     # of it, the rescore window grows (as a user would raise diskann.query_rescore) and ALL K steps are timed again.
+    try:  # what is left of the HBM with the index, every query batch and the sized workspace resident (how far --nq could grow)
+        free_b, total_b = ctx.mem_info()
+        setup["hbm_free_gb_at_timed_region"] = round(free_b / 1e9, 1)
+        setup["hbm_total_gb"] = round(total_b / 1e9, 1)
+    except Exception:  # noqa: BLE001
+        pass
     K = args.steps
     retimed = 0
     hs = None

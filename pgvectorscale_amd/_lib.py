@@ -241,10 +241,11 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise VsError(-2, f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
-    try:
-        import torch  # noqa: F401  (pins the HIP runtime copy when torch is installed)
-    except Exception:  # pragma: no cover
-        pass
+    if not os.environ.get("VS_NO_TORCH"):  # (VS_NO_TORCH=1: a process that will never import torch skips the seconds its import costs)
+        try:
+            import torch  # noqa: F401  (pins the HIP runtime copy when torch is installed)
+        except Exception:  # pragma: no cover
+            pass
     L = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         if os.environ.get("VS_LIB_TOLERANT") and not hasattr(L, name):

@@ -799,7 +799,11 @@ static Caps initial_caps(const vs_index* ix, uint32_t L, uint32_t M) {
     // Large scans: an LDS table for all ids would leave 3-4 scans per CU, and measurements (10M x 768: 148 ms vs 97 ms
     // per 65536 scans) show that occupancy beats on-chip latency there, so the table shrinks to a 256-slot stub, ids go
     // to the per-scan global table (L2 atomics) and the CU holds 16+ scans.
-    const bool lds_table = typ_ins <= knob_u32("VS_F_LDS_MAX_INS", ix->tune.lds_max_ins, 3072);
+    // (1024 since the end of round 3, 3072 before: at 1M x 768, search_list_size 3 / rescore 53 — about 1 100 inserted ids per scan —
+    // the table-less regime runs the search kernel in 35.0 ms per 262 144 scans against 56.2 ms with the table in LDS
+    // (profiles/r03/ab_autotune_1m.json): the LDS-table instantiation keeps its visited list in registers, 141 VGPRs, 12 scans per
+    // CU against 24.  Below ~500 inserted ids per scan the table is a kilobyte and nothing has been measured: it stays in LDS.)
+    const bool lds_table = typ_ins <= knob_u32("VS_F_LDS_MAX_INS", ix->tune.lds_max_ins, 1024);
     c.f_lh = env_u32("VS_F_LH", lds_table ? (uint32_t)round_up_u32((uint32_t)typ_ins, 64) : 0u);
     c.f_pool_frac = !lds_table ? 1.0
                     : (ix->obs.valid && ix->obs.L == L && ix->obs.M == M) ? std::min(1.0, 2.0 * ix->obs.ov_frac + 0.03) : 1.0;
@@ -1475,17 +1479,13 @@ static const TuneCand kTuneCands[] = {
     {"epoch_tags", 1, 0, -1, 0, 0},            // no per-scan clear: entries carry the launch's epoch (11b.14)
     {"bucket_bitmap", 0, 1, -1, 0, 0},         // no clear, no read of a bucket the scan has not written (11b.16)
     {"bucket_bitmap_16k", 0, 1, -1, 0, 16384}, // ... with a sparser table (more first-touch buckets per probe, more lines)
-    {"bucket_bitmap_24k", 0, 1, -1, 0, 24576},
     {"two_rows", 0, 0, 5, 0, 0},               // two code rows per 4-lane group in flight, 5 waves per SIMD (11b.17)
-    {"two_rows_bitmap", 0, 1, 5, 0, 0},
     {"two_rows_epoch", 1, 0, 5, 0, 0},
-    {"pipelined5", 0, 0, -1, 1, 0},            // software-pipelined visits at 5 / 4 waves per SIMD (11b.18)
-    {"pipelined5_bitmap", 0, 1, -1, 1, 0},
-    {"pipelined4", 0, 0, -1, 2, 0},
-    {"pipelined4_bitmap", 0, 1, -1, 2, 0},
-    {"pipelined5_epoch", 1, 0, -1, 1, 0},
-    {"pipelined4_epoch", 1, 0, -1, 2, 0},
-    // small scans (dedup table in LDS by default: 3-4 times fewer scans per CU): the table-less regime instead, plain and with the bitmap
+    // (not candidates any more, measured on the MI355X at 10M x 768, profiles/r03/ab_autotune_10m.json: the software-pipelined
+    // visits of 11b.18 — three times slower, their 55-60 spilled dwords cost more than the overlap buys — and the bitmap on top of
+    // the two-row gather / on a 24 Ki-slot table, +9 % / +6 %; VS_F_SP / VS_F_VIRGIN / VS_F_GCAP still reach them)
+    // small scans (dedup table in LDS by default: 3-4 times fewer scans per CU): the table-less regime instead, plain and with the
+    // bitmap (1M x 768 at search_list_size 3 / rescore 53: -37.7 % / -36.2 %, profiles/r03/ab_autotune_1m.json)
     {"table_less", 0, 0, -1, 0, 0, 0},
     {"table_less_bitmap", 0, 1, -1, 0, 0, 0},
 };

@@ -15,8 +15,7 @@ pytestmark = pytest.mark.gpu
 
 EMU = bool(os.environ.get("VS_EMU"))
 REGIME = {"VS_F_LDS_MAX_INS": "0", "VS_F_VR": "0"}  # the table-less regime of large indexes (the variants exist only there)
-NAMES = ["default", "epoch_tags", "bucket_bitmap", "bucket_bitmap_16k", "bucket_bitmap_24k", "two_rows", "two_rows_bitmap",
-         "two_rows_epoch", "pipelined5", "pipelined5_bitmap", "pipelined4", "pipelined4_bitmap", "pipelined5_epoch", "pipelined4_epoch", "table_less", "table_less_bitmap"]
+NAMES = ["default", "epoch_tags", "bucket_bitmap", "bucket_bitmap_16k", "two_rows", "two_rows_epoch", "table_less", "table_less_bitmap"]
 LDS_REGIME_ONLY = NAMES[-2:]  # candidates for indexes whose default keeps the dedup table in LDS
 
 
@@ -96,7 +95,7 @@ def test_autotune_holds_every_variant_to_the_defaults_rows(gpu_ctx, probe_skip, 
 def test_a_variant_whose_rows_differ_is_disqualified(gpu_ctx, probe_skip, regime):
     if probe_skip is None:
         pytest.skip("the probe child did not finish cleanly on this box: no variant is launched in this process")
-    victim = next(n for n in NAMES[1:] if n not in probe_skip and "16k" not in n and "24k" not in n)
+    victim = next(n for n in NAMES[1:] if n not in probe_skip and "16k" not in n)
     os.environ["VS_TUNE_SABOTAGE"] = victim  # one id of that variant's downloaded rows is flipped before the comparison
     ti, ix, q, dq = _setup(gpu_ctx)
     try:

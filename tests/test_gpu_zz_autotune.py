@@ -120,8 +120,9 @@ def test_small_scans_try_the_table_less_regime(gpu_ctx, probe_skip):
     if probe_skip is None:
         skip.append("table_less_bitmap")  # (its kernel has not been seen to come back on this box)
     try:
-        oi, od, _ = ti.oracle.search_batch(q, L=20, rescore=10, k=10)
-        rep = ix.autotune(dq, len(q), 20, 10, 10, reps=1, skip=skip)
+        # (a scan of a few hundred inserted ids: below VS_F_LDS_MAX_INS = 1024 expected inserts the table stays in LDS)
+        oi, od, _ = ti.oracle.search_batch(q, L=6, rescore=3, k=5)
+        rep = ix.autotune(dq, len(q), 6, 3, 5, reps=1, skip=skip)
         assert rep[0]["applicable"] and sum(e["chosen"] for e in rep) == 1
         for e in rep[1:]:
             if e["name"] not in LDS_REGIME_ONLY:
@@ -131,7 +132,7 @@ def test_small_scans_try_the_table_less_regime(gpu_ctx, probe_skip):
         for e in rep:
             if e["applicable"] and e["rows_identical"]:
                 ix.set_variant(e["name"])
-                gi, _, gd, _ = ix.search_batch(q, search_list_size=20, rescore=10, k=10)
+                gi, _, gd, _ = ix.search_batch(q, search_list_size=6, rescore=3, k=5)
                 assert (gi == oi).all() and (gd.view(np.uint32) == od.view(np.uint32)).all(), e["name"]
     finally:
         gpu_ctx.free(dq)

@@ -278,10 +278,10 @@ def main():
     ap.add_argument("--autotune", default="on", choices=["on", "off"],
                     help="on (default): before the timed region the library times every exact launch variant of the search kernel on one "
                          "warm-up batch (vs_index_autotune: a variant must reproduce the default's rows, distance bits and counters on all "
-                         "scans of that batch to qualify; the fastest qualified one is used when it beats the default by > 1.5 %%), after "
+                         "scans of that batch to qualify; the fastest qualified one is used when it beats the default by > 1 %%), after "
                          "a child-process probe of the variants on a small index under a timeout (pgvectorscale_amd/tune_probe.py); the "
                          "line reports every candidate's time under `autotune`.  off: the library default")
-    ap.add_argument("--tune-reps", type=int, default=2, help="timed steps per variant (after one warm-up step each)")
+    ap.add_argument("--tune-reps", type=int, default=3, help="timed steps per variant (after one warm-up step each)")
     ap.add_argument("--probe-n", type=int, default=100_000, help="nodes of the probe child's index")
     ap.add_argument("--probe-timeout", type=float, default=240.0)
     args = ap.parse_args()

@@ -411,7 +411,7 @@ int vs_search_batch_dev_finish(vs_index* idx, vs_stats* stats);
  * where it runs: vs_index_autotune runs every applicable variant on the caller's own device-resident batch (the arguments of
  * vs_search_batch_dev), `reps` timed steps each after one warm-up, holds every row, every distance bit and every work counter of
  * a variant to the library default's on the same batch, DISQUALIFIES a variant that differs anywhere (rows_identical = 0) and
- * makes the fastest qualified one the index's choice when it beats the default by more than 1.5 %.  VS_F_* environment
+ * makes the fastest qualified one the index's choice when it beats the default by more than 1 %.  VS_F_* environment
  * variables still override the choice per call.  report (may be NULL) receives one entry per variant, the default first.
  * A caller that cannot afford a misbehaving kernel in its own process probes the variants in a child process first
  * (pgvectorscale_amd/tune_probe.py: a small index of the same code width, every variant, a hard timeout) and passes the ones

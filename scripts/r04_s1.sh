@@ -12,7 +12,7 @@ VS_F_VIRGIN=1 VS_F_LDS_MAX_INS=0 timeout 200 python scripts/fuzz_emu.py --gpu --
 # the epoch tags with the reallocation fix: the case that failed in round 3, then random cases
 VS_F_EPOCH=1 timeout 120 python scripts/fuzz_emu.py --gpu --only 777000331 2>&1 | tail -2 | tee $O/fuzz_gpu_epoch_case.txt
 VS_F_EPOCH=1 timeout 200 python scripts/fuzz_emu.py --gpu --seconds 120 --seed 4042 2>&1 | tail -5 | tee $O/fuzz_gpu_epoch.txt
-CF="VS_F_EPOCH=0:VS_F_VIRGIN=0:VS_F_GCAP=0:VS_F_MINW=6,VS_F_VIRGIN=1:VS_F_GCAP=0:VS_F_MINW=6,VS_F_VIRGIN=1:VS_F_GCAP=16384:VS_F_MINW=6,VS_F_VIRGIN=1:VS_F_GCAP=24576:VS_F_MINW=6,VS_F_VIRGIN=0:VS_F_GCAP=0:VS_F_MINW=5,VS_F_VIRGIN=1:VS_F_GCAP=0:VS_F_MINW=5,VS_F_VIRGIN=0:VS_F_GCAP=0:VS_F_MINW=6,VS_F_VIRGIN=1:VS_F_GCAP=0:VS_F_MINW=6,VS_F_VIRGIN=0:VS_F_EPOCH=1:VS_F_GCAP=0:VS_F_MINW=6,VS_F_EPOCH=0:VS_F_SP=1,VS_F_SP=2,VS_F_SP=1:VS_F_VIRGIN=1,VS_F_SP=2:VS_F_VIRGIN=1,VS_F_SP=0:VS_F_VIRGIN=0:VS_F_MINW=6"
+CF="VS_F_EPOCH=0:VS_F_VIRGIN=0:VS_F_GCAP=0:VS_F_MINW=6,VS_F_VIRGIN=1:VS_F_GCAP=0:VS_F_MINW=6,VS_F_VIRGIN=1:VS_F_GCAP=16384:VS_F_MINW=6,VS_F_VIRGIN=1:VS_F_GCAP=24576:VS_F_MINW=6,VS_F_VIRGIN=0:VS_F_GCAP=0:VS_F_MINW=5,VS_F_VIRGIN=1:VS_F_GCAP=0:VS_F_MINW=5,VS_F_VIRGIN=0:VS_F_GCAP=0:VS_F_MINW=6,VS_F_VIRGIN=1:VS_F_GCAP=0:VS_F_MINW=6,VS_F_VIRGIN=0:VS_F_EPOCH=1:VS_F_GCAP=0:VS_F_MINW=6,VS_F_VIRGIN=0:VS_F_EPOCH=0:VS_F_MINW=7,VS_F_VIRGIN=0:VS_F_MINW=6"
 timeout 900 python scripts/perf_search.py --n 10000000 --nq 262144 --L 3 --rescore 196 --reps 3 --configs "$CF" --graph-cache /tmp/g 2>&1 | grep -E "search |index ready" | tee $O/ab_virgin_10m.txt
 timeout 1500 python scripts/perf_search.py --n 50000000 --nq 262144 --L 3 --rescore 196 --reps 3 --configs "$CF" --graph-cache /tmp/g 2>&1 | grep -E "search |index ready" | tee $O/ab_virgin_50m.txt
 # the product's own A/B (vs_index_autotune): the probe alone, then the bench with the selection on, and the PMC
@@ -24,4 +24,10 @@ timeout 900 bash scripts/pmc_traffic.sh 50000000 262144 $L $S /tmp/g $V 2>&1 | t
 cp gpurun_out/pmc_search_traffic.json $O/pmc_search_traffic_50m_$V.json
 # BASELINE configs[2] at its full size against the oracle (opt-in test: 31 GB of vectors go to the host)
 VS_TEST_FULL_10M=1 timeout 600 python -m pytest tests/test_gpu_zx_full_size.py -q -m gpu -x 2>&1 | tail -3 | tee $O/full_size_tests.txt
+# where is the boundary between the LDS-table regime and the table-less one?  (1M x 768: -37.7 % without the LDS table at L = 3 /
+# rescore 53, profiles/r03/ab_autotune_1m.json; the default moved from 3072 to 1024 expected inserts on that one measurement.)
+# Small scans, each under: LDS table + register visited list (the old default), LDS table + LDS-ring visited list, table-less
+for LS in "3 53" "3 10" "10 0" "25 20"; do set -- $LS
+  timeout 120 python scripts/perf_search.py --n 1000000 --nq 262144 --L $1 --rescore $2 --reps 3 --configs "VS_F_LDS_MAX_INS=100000,VS_F_LDS_MAX_INS=100000:VS_F_VR=0,VS_F_LDS_MAX_INS=0:VS_F_VR=0" 2>&1 | grep -E "search " | sed "s/^/L=$1 rescore=$2 /" | tee -a $O/ab_regime_boundary_1m.txt
+done
 rm -f /tmp/g.*

@@ -1054,14 +1054,6 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
         f.lh = caps.f_lh;
         f.minw = knob_u32("VS_F_MINW", (caps.f_lh == 0 && !caps.f_vr) ? ix->tune.minw : -1, caps.f_lh == 0 ? (caps.f_vr ? 4 : 6) : 1);
         f.flags = env_u32("VS_F_FLAGS", 0);
-        // the software-pipelined variant (VS_F_SP=1): 24-word codes, table-less regime, LDS-ring visited list; it lives at 5 waves per SIMD
-        // (neighbor lists of one 64-lane chunk: a visit has ONE run of pushes to defer)
-        const uint32_t want_sp = knob_u32("VS_F_SP", ix->tune.sp, 0);
-        if (want_sp && caps.f_lh == 0 && !f.vr && (ix->code_stride + 7) / 8 == 3 && ix->d.num_neighbors <= 64 &&
-            !env_u32("VS_PHASE", 0)) {
-            f.sp = 1;
-            f.minw = want_sp >= 2 ? 4 : 5;  // (2: the 4-waves-per-SIMD build, 16 scans per CU, no scratch)
-        }
         f.epoch = epoch;
         f.eshift = eshift;
         f.rc = caps.f_lh == 0 ? env_u32("VS_F_RC", 0) : 0;  // (measurement: LDS id cache in front of the dedup table in HBM)
@@ -1090,7 +1082,7 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
         VS_TRY(launch_search_fast(ix, f));
         prof_end(c, PK_SEARCH, ev);
         fast_done = true;
-        ix->last_fast = FastSig{epoch ? 1u : 0u, f.vwords, f.minw, f.sp, f.gcap, f.lh, 1u};
+        ix->last_fast = FastSig{epoch ? 1u : 0u, f.vwords, f.minw, f.gcap, f.lh, 1u};
         // second attempt of the scans that outgrew these capacities (a handful per launch at the tail of the distribution):
         // the same kernel with a four times larger dedup table, twice the heap and visited-list room, regions from a small
         // pool.  Scans finished above return at once; what still does not fit goes to the general kernel below.
@@ -1098,7 +1090,6 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
             FastLaunch r = f;
             r.epoch = 0;  // (its own, smaller table array: cleared by the few scans that run)
             r.vwords = 0;
-            r.sp = 0;
             r.only_failed = 1;
             r.fb_flag = (uint32_t*)w.fb_flag.p;
             r.phase = nullptr;
@@ -1129,8 +1120,8 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
             VS_HIP(hipStreamSynchronize(c->stream));
             uint32_t hist[16] = {0};
             for (uint32_t v : stv) hist[v & 15]++;
-            fprintf(stderr, "[VS_DEBUG_STATUS] fast kernel: lh=%u gcap=%u vr=%u minw=%u epoch=%u bitmap_words=%u pipelined=%u; pool claims=%u of %u;",
-                    f.lh, f.gcap, f.vr, f.minw, f.epoch, f.vwords, f.sp, ctr[0], fast_pool_slots(nq, caps.f_pool_frac));
+            fprintf(stderr, "[VS_DEBUG_STATUS] fast kernel: lh=%u gcap=%u vr=%u minw=%u epoch=%u bitmap_words=%u; pool claims=%u of %u;",
+                    f.lh, f.gcap, f.vr, f.minw, f.epoch, f.vwords, ctr[0], fast_pool_slots(nq, caps.f_pool_frac));
             for (int i = 0; i < 16; ++i)
                 if (hist[i]) fprintf(stderr, " status[%d]=%u", i, hist[i]);
             fprintf(stderr, "\n");
@@ -1470,24 +1461,24 @@ extern "C" int vs_search_batch_dev_finish(vs_index* ix, vs_stats* stats) {
 // ---------------------------------------------------------------------------------------------------------------
 struct TuneCand {
     const char* name;
-    int epoch, virgin, minw, sp;
+    int epoch, virgin, minw;
     uint32_t gcap;
     int lds_max_ins = -1;  // 0: a candidate for indexes whose default is the LDS-table regime (the table-less regime there)
 };
 static const TuneCand kTuneCands[] = {
-    {"default", -1, -1, -1, -1, 0},
-    {"epoch_tags", 1, 0, -1, 0, 0},            // no per-scan clear: entries carry the launch's epoch (11b.14)
-    {"bucket_bitmap", 0, 1, -1, 0, 0},         // no clear, no read of a bucket the scan has not written (11b.16)
-    {"bucket_bitmap_16k", 0, 1, -1, 0, 16384}, // ... with a sparser table (more first-touch buckets per probe, more lines)
-    {"two_rows", 0, 0, 5, 0, 0},               // two code rows per 4-lane group in flight, 5 waves per SIMD (11b.17)
-    {"two_rows_epoch", 1, 0, 5, 0, 0},
-    // (not candidates any more, measured on the MI355X at 10M x 768, profiles/r03/ab_autotune_10m.json: the software-pipelined
-    // visits of 11b.18 — three times slower, their 55-60 spilled dwords cost more than the overlap buys — and the bitmap on top of
-    // the two-row gather / on a 24 Ki-slot table, +9 % / +6 %; VS_F_SP / VS_F_VIRGIN / VS_F_GCAP still reach them)
+    {"default", -1, -1, -1, 0},
+    {"epoch_tags", 1, 0, -1, 0},            // no per-scan clear: entries carry the launch's epoch (11b.14)
+    {"bucket_bitmap", 0, 1, -1, 0},         // no clear, no read of a bucket the scan has not written (11b.16)
+    {"bucket_bitmap_16k", 0, 1, -1, 16384}, // ... with a sparser table (more first-touch buckets per probe, more lines)
+    {"two_rows", 0, 0, 5, 0},               // two code rows per 4-lane group in flight, 5 waves per SIMD (11b.17)
+    {"two_rows_epoch", 1, 0, 5, 0},
+    // (gone after the MI355X measured them at 10M x 768, profiles/r03/ab_autotune_10m.json: the software-pipelined visits of 11b.18
+    // — three times slower, their 55-60 spilled dwords cost more than the overlap buys; their instantiations are deleted — and, as
+    // candidates, the bitmap on top of the two-row gather / on a 24 Ki-slot table, +9 % / +6 %: VS_F_VIRGIN / VS_F_GCAP still reach those)
     // small scans (dedup table in LDS by default: 3-4 times fewer scans per CU): the table-less regime instead, plain and with the
     // bitmap (1M x 768 at search_list_size 3 / rescore 53: -37.7 % / -36.2 %, profiles/r03/ab_autotune_1m.json)
-    {"table_less", 0, 0, -1, 0, 0, 0},
-    {"table_less_bitmap", 0, 1, -1, 0, 0, 0},
+    {"table_less", 0, 0, -1, 0, 0},
+    {"table_less_bitmap", 0, 1, -1, 0, 0},
 };
 static const uint32_t kNTuneCands = sizeof(kTuneCands) / sizeof(kTuneCands[0]);
 
@@ -1495,7 +1486,6 @@ static void tune_apply(vs_index* ix, const TuneCand& c) {
     ix->tune.epoch = c.epoch;
     ix->tune.virgin = c.virgin;
     ix->tune.minw = c.minw;
-    ix->tune.sp = c.sp;
     ix->tune.gcap = c.gcap;
     ix->tune.lds_max_ins = c.lds_max_ins;
     snprintf(ix->tune.name, sizeof(ix->tune.name), "%s", c.name);
@@ -1611,7 +1601,7 @@ static int vs_index_autotune_impl(vs_index* ix, const float* d_q, const int16_t*
             // a variant that cannot be told from the default here is not launched at all
             if (!base.sig.ran) continue;                                           // no LDS-resident kernel for this index
             if ((base.sig.lh != 0) != (cand.lds_max_ins == 0)) continue;           // table-less variants / LDS-table regime: the other's candidates
-            if ((cand.minw >= 0 || cand.sp > 0) && !w24) continue;                 // built for 17..24-word codes only
+            if (cand.minw >= 0 && !w24) continue;                                  // built for 17..24-word codes only
             if (cand.gcap && cand.gcap <= base.sig.gcap) continue;                 // not sparser than the fitted table
             if (skip_list.find(std::string(",") + cand.name + ",") != std::string::npos) continue;  // the caller's veto
         }

@@ -119,7 +119,7 @@ struct ScanObs {
 // the launch variant of k_search_fast an index prefers (vs_index_autotune / vs_index_set_variant): -1 = the library default;
 // a VS_F_* environment variable still overrides the field it names
 struct TuneVariant {
-    int epoch = -1, virgin = -1, minw = -1, sp = -1;
+    int epoch = -1, virgin = -1, minw = -1;
     int lds_max_ins = -1;  // 0: the table-less regime even for scans whose dedup table would fit LDS
     uint32_t gcap = 0;
     char name[40] = "default";
@@ -127,9 +127,9 @@ struct TuneVariant {
 // what the last first-attempt launch of k_search_fast really was (a variant that does not exist for an index / operating point
 // silently launches the default's instantiation: the autotuner reads this to tell)
 struct FastSig {
-    uint32_t epoch_on = 0, vwords = 0, minw = 0, sp = 0, gcap = 0, lh = 0, ran = 0;
+    uint32_t epoch_on = 0, vwords = 0, minw = 0, gcap = 0, lh = 0, ran = 0;
     bool operator==(const FastSig& o) const {
-        return epoch_on == o.epoch_on && vwords == o.vwords && minw == o.minw && sp == o.sp && gcap == o.gcap && lh == o.lh && ran == o.ran;
+        return epoch_on == o.epoch_on && vwords == o.vwords && minw == o.minw && gcap == o.gcap && lh == o.lh && ran == o.ran;
     }
 };
 
@@ -232,7 +232,7 @@ struct FastLaunch {
     uint32_t rc = 0;   // entries of the LDS cache of ids known to be in the table (table-less regime; 0 or a power of two)
     uint32_t epoch = 0;   // != 0: global dedup entries are (epoch << eshift) | id and stale tags count as empty (no clearing)
     uint32_t eshift = 0;  // bits of a node id inside a tagged entry
-    uint32_t sp = 0;      // 1: the software-pipelined variant (pushes deferred under the next visit's bucket loads, pop under its code rows)
+    uint32_t reserved0 = 0;  // (the switch of the software-pipelined variant, deleted after it measured three times slower; the field keeps the kernel-argument layout)
     uint32_t vwords = 0;  // != 0: words of the LDS bitmap of written buckets (one bit per four slots of gcap): tables are neither cleared nor read before their first write
     uint32_t build = 0; // 1: greedy_search_for_build (the visited list is the output; needs vr == 0)
     uint32_t flags = 0; // FAST_* (measurement switches)

@@ -687,35 +687,6 @@ __device__ __forceinline__ void ham_row_reg2(const uint64_t* __restrict__ row_a,
     db = quad_sum(act_b ? acc_b : 0u);
 }
 
-// the same in two halves: the loads of both rows are issued here ...
-template <int NCH>
-__device__ __forceinline__ void rows_load2(const uint64_t* __restrict__ row_a, const uint64_t* __restrict__ row_b, int l4,
-                                           uint32_t code_stride, bool act_a, bool act_b, bool stream, ulonglong2 (&ra)[NCH > 0 ? NCH : 1],
-                                           ulonglong2 (&rb)[NCH > 0 ? NCH : 1]) {
-    constexpr int N = NCH > 0 ? NCH : 1;
-#pragma unroll
-    for (int t = 0; t < N; ++t) {
-        const uint32_t w = 2u * (uint32_t)l4 + 8u * (uint32_t)t;
-        const bool in = w < code_stride;
-        ra[t] = !(act_a && in) ? make_ulonglong2(0, 0) : stream ? load_stream16(row_a + w) : *reinterpret_cast<const ulonglong2*>(row_a + w);
-        rb[t] = !(act_b && in) ? make_ulonglong2(0, 0) : stream ? load_stream16(row_b + w) : *reinterpret_cast<const ulonglong2*>(row_b + w);
-    }
-}
-// ... and waited for here, after whatever the caller had to do in between
-template <int NCH>
-__device__ __forceinline__ void rows_ham2(const ulonglong2 (&ra)[NCH > 0 ? NCH : 1], const ulonglong2 (&rb)[NCH > 0 ? NCH : 1],
-                                          const ulonglong2 (&qv)[NCH > 0 ? NCH : 1], bool act_a, bool act_b, uint32_t& da, uint32_t& db) {
-    constexpr int N = NCH > 0 ? NCH : 1;
-    uint32_t acc_a = 0, acc_b = 0;
-#pragma unroll
-    for (int t = 0; t < N; ++t) {
-        acc_a += (uint32_t)__popcll(ra[t].x ^ qv[t].x) + (uint32_t)__popcll(ra[t].y ^ qv[t].y);
-        acc_b += (uint32_t)__popcll(rb[t].x ^ qv[t].x) + (uint32_t)__popcll(rb[t].y ^ qv[t].y);
-    }
-    da = quad_sum(act_a ? acc_a : 0u);
-    db = quad_sum(act_b ? acc_b : 0u);
-}
-
 // minimum over the wave (DPP row reduction + 4 readlanes; no LDS)
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
     v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x111 /*row_shr:1*/, 0xF, 0xF, false));
@@ -731,7 +702,7 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 // ring capacity, farthest entry dropped) is the result.
 // FULL = label keys and / or a visibility mask may be present; the plain instantiation (neither) leaves their pointers, counters
 // and branches out of a kernel whose scalar registers are its tightest resource.
-template <int NCH, int VR, bool TIMING, int MINW, bool BUILD, bool FULL = true, bool VG = false, bool SP = false>
+template <int NCH, int VR, bool TIMING, int MINW, bool BUILD, bool FULL = true, bool VG = false>
 __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
@@ -760,10 +731,7 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
     const int l4 = lane & 3;
     const bool stream_rows = !(s.flags & FAST_PLAIN_ROW_LOADS);
     constexpr bool QL = NCH > 0 && MINW >= 6;
-    // SP: both halves of a visit's first 32 rows are requested before the pop (24 registers: the 4-waves-per-SIMD build) or only the
-    // first half (12: the 5-waves build, which spills 55 dwords around the heap operations even so)
-    constexpr bool SP_TWO = SP && MINW == 4;
-    constexpr bool G2 = NCH == 3 && VR == 0 && (MINW == 5 || (SP && MINW == 4)) && !BUILD && !TIMING;  // two code rows per 4-lane group in flight
+    constexpr bool G2 = NCH == 3 && VR == 0 && MINW == 5 && !BUILD && !TIMING;  // two code rows per 4-lane group in flight
     ulonglong2 qv[NCH > 0 ? NCH : 1];
     if (QL) {
         qv[0] = make_ulonglong2(0, 0);
@@ -1059,42 +1027,15 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
     uint32_t ft_node = VS_INVALID_NODE;  // heap tid (and visibility) of the visited list's front entry, requested ahead of consume()
     uint64_t ft_val = 0;
     uint32_t ft_vis = 1, st_invis = 0;
-    // SP (software-pipelined visit, a 5-waves-per-SIMD variant): the heap work of a visit is taken off the path between two
-    // gathers.  The pushes of visit i are deferred to the top of the next iteration and run while the dedup buckets of visit i + 1
-    // (the node is known: it is the better of the two prefetched rows) are in flight; the pop of visit i + 1 and its visited-list
-    // insert run while its code rows are in flight.  Same heap operations in the same order, so the array mechanics — and with
-    // them the order of equal keys — are untouched; only WHEN they run moves.
-    uint32_t pend_c = 0, pend_entry = 0xFFFFFFFFu, pend_pre_n = 0, pend_pre_anc = 0;  // deferred push_run of the last visit
-    bool pre_early = false;         // the buckets of the predicted next node were requested before the deferred pushes
-    uint32_t pre_h = 0xFFFFFFFFu;   // ... its dedup handle (checked against the real top)
     uint32_t hslot0 = 0;
     uint4 gbk0 = make_uint4(0, 0, 0, 0);
     bool rchit0 = false;  // this lane's id of the first chunk was found in the id cache
     bool virg0 = false;
     while (status == 0) {
-        if (SP && pend_c) {
-            pre_early = false;
-            const bool use_b = pfb_h != 0xFFFFFFFFu;  // a new candidate below the old root: it is the root once the pushes are done
-            pre_h = use_b ? pfb_h : pfa_h;
-            if (gmode && pre_h != 0xFFFFFFFFu && (nins_g + WAVE) * 4u <= s.gcap * 3u) {
-                const uint32_t prow = use_b ? pfb_val : pfa_val;
-                pre_early = true;
-                hslot0 = ghash_home(prow);
-                const uint64_t inval0 = __ballot(prow == VS_INVALID_NODE);
-                rchit0 = s.rc ? rc[hash_u32(prow ^ 0x9e3779b9u) & rcm] == prow : false;
-                virg0 = false;
-                gbk0 = make_uint4(0, 0, 0, 0);
-                if ((uint32_t)lane < (inval0 ? (uint32_t)__builtin_ctzll(inval0) : WAVE) && !rchit0) gbk0 = bucket_fetch(hslot0, virg0);
-            }
-            heap.push_run(pend_entry, pend_c, pend_pre_n, pend_pre_anc);
-            pend_c = 0;
-        }
-        if (!SP || !pre_early) {  // (nothing requested ahead: these do not live across iterations)
-            hslot0 = 0;
-            gbk0 = make_uint4(0, 0, 0, 0);
-            rchit0 = false;
-            virg0 = false;
-        }
+        hslot0 = 0;  // (these do not live across iterations)
+        gbk0 = make_uint4(0, 0, 0, 0);
+        rchit0 = false;
+        virg0 = false;
         if (VR > 0 && vis.len > 0) {  // (the ring carries what consume() needs in its entries)
             const uint32_t fn = readlane_u32(vis.n[0], 0);
             if (fn != ft_node) {
@@ -1158,9 +1099,7 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
                 vtid = a.tids[node_v];
                 if (visible) vvis = visible[node_v];
             }
-            if (SP && pre_early && pre_h == th) {
-                early = true;  // requested before the deferred pushes
-            } else if (gmode && (nins_g + WAVE) * 4u <= s.gcap * 3u) {
+            if (gmode && (nins_g + WAVE) * 4u <= s.gcap * 3u) {
                 early = true;
                 hslot0 = ghash_home(row0);
                 const uint64_t inval0 = __ballot(row0 == VS_INVALID_NODE);
@@ -1170,11 +1109,7 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
                 if ((uint32_t)lane < (inval0 ? (uint32_t)__builtin_ctzll(inval0) : WAVE) && !rchit0) gbk0 = bucket_fetch(hslot0, virg0);
             }
         }
-        pre_early = false;
-        // SP: the pop waits until the visit's first code rows have been requested (nothing between here and there reads the heap)
-        constexpr bool sp_now = SP;
-        bool popped = !sp_now;
-        if (!sp_now) heap.pop();
+        heap.pop();
         const uint32_t node = rfl(node_v);
         // what consume() will need to know about this node: requested now, folded into the ring entry at the insert below
         if (!hit && VR == 0 && !BUILD) {
@@ -1200,7 +1135,7 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
             root_after = heap.len > 0 ? heap.root() : 0xFFFFFFFFu;
             if (root_after != 0xFFFFFFFFu) root_node_v = node_load(root_after & smask);
         };
-        if (popped) after_pop();
+        after_pop();
         uint32_t best = 0xFFFFFFFFu;  // smallest (hamming << sb | slot) among this visit's new candidates
         uint32_t best_node = VS_INVALID_NODE;
         bool pfa_issued = false, pfb_issued = false, vis_done = false;
@@ -1232,7 +1167,7 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
                 old = atomicCAS(&lhash[hslot], VS_EMPTY, nid);
             }
             // ... visited.insert(partition_point(|x| *x < head), head) runs in registers meanwhile ...
-            if (!vis_done && !sp_now) {
+            if (!vis_done) {
                 vis_done = true;
                 vis.insert(hd, node, ((vtid & 0xFFFFull) == 0 ? VIS_DEAD : 0u) | (vvis == 0 ? VIS_HIDDEN : 0u));
                 lap(2);
@@ -1272,7 +1207,7 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
             const uint32_t c = (uint32_t)__popcll(pm);
             lap(3);
             if (c) {
-                if (heap.len - (popped ? 0u : 1u) + c > s.hcap) { status |= OVF_HEAP; break; }
+                if (heap.len + c > s.hcap) { status |= OVF_HEAP; break; }
                 // compact survivors in neighbor-list order
                 if (pass) {
                     const uint32_t rank = (uint32_t)__popcll(pm & ((1ull << lane) - 1ull));
@@ -1280,25 +1215,6 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
                     surv_slot[rank] = hslot;
                 }
                 wave_sync();
-            }
-            // SP: the first 32 code rows of the visit are requested now; the pop, the lookup of the new root and the visited-list
-            // insert run while they are on their way.  (The one place an SP visit pops: every visit that is not abandoned with a
-            // status gets here in its first chunk.)
-            ulonglong2 sp_ra[NCH > 0 ? NCH : 1], sp_rb[NCH > 0 ? NCH : 1];
-            bool sp_rows = false;
-            if (SP && !popped) {
-                const uint32_t j = (uint32_t)(lane >> 2), j2 = j + 16u;
-                if (c) {
-                    rows_load2<NCH>(a.codes + (size_t)(j < c ? surv_id[j] : 0u) * a.code_stride,
-                                    a.codes + (size_t)(j2 < c ? surv_id[j2] : 0u) * a.code_stride, l4, a.code_stride, j < c, SP_TWO && j2 < c,
-                                    stream_rows, sp_ra, sp_rb);
-                    sp_rows = true;
-                }
-                heap.pop();
-                popped = true;
-                after_pop();
-                vis_done = true;
-                vis.insert(hd, node, ((vtid & 0xFFFFull) == 0 ? VIS_DEAD : 0u) | (vvis == 0 ? VIS_HIDDEN : 0u));
             }
             if (c == 0) continue;
             // the heap positions the new candidates will get are already known: their ancestors' load (L2 when the heap
@@ -1324,20 +1240,6 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
                         pfa_val = ((uint32_t)lane < a.R) ? a.nbrs[(size_t)pfa_node * a.nbr_stride + lane] : VS_INVALID_NODE;
                         if (nbr_mask) pfa_m = ((uint32_t)lane < a.R) ? nbr_mask[(size_t)pfa_node * a.nbr_stride + lane] : 0ull;
                     }
-                }
-                if (SP && sp_rows && pass_i == 0) {
-                    const uint32_t j2 = j + 16u;
-                    const bool valid2 = j2 < c;
-                    uint32_t d, d2;
-                    if (!SP_TWO) {  // the second 16 rows were not requested ahead
-                        ulonglong2 unused[NCH > 0 ? NCH : 1];
-                        rows_load2<NCH>(a.codes + (size_t)(valid2 ? surv_id[j2] : 0u) * a.code_stride, a.codes, l4, a.code_stride, valid2,
-                                        false, stream_rows, sp_rb, unused);
-                    }
-                    rows_ham2<NCH>(sp_ra, sp_rb, qv, valid, valid2, d, d2);
-                    if (valid && l4 == 0) surv_d[j] = d;
-                    if (valid2 && l4 == 0) surv_d[j2] = d2;
-                    continue;
                 }
                 if (G2) {
                     const uint32_t j2 = j + 16u;
@@ -1381,18 +1283,10 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
                 }
             }
             // insert_neighbor in list order (AM/graph/mod.rs:144-147)
-            if (SP) {  // the pushes run at the top of the next iteration, under the next visit's bucket loads
-                pend_entry = entry;
-                pend_c = c;
-                pend_pre_n = pre_n;
-                pend_pre_anc = pre_anc;
-            } else {
-                heap.push_run(entry, c, pre_n, pre_anc);
-            }
+            heap.push_run(entry, c, pre_n, pre_anc);
             lap(5);
         }
         if (status) break;
-        (void)popped;
         if (!vis_done) vis.insert(hd, node, ((vtid & 0xFFFFull) == 0 ? VIS_DEAD : 0u) | (vvis == 0 ? VIS_HIDDEN : 0u));  // (an empty neighbor list)
         if (!pfa_issued) {  // nothing new to score: the old root is the next expansion
             pfa_node = VS_INVALID_NODE;
@@ -1409,7 +1303,6 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
             pfb_h = 0xFFFFFFFFu;
         }
     }
-    if (SP) hmax = max(hmax, heap.len + pend_c);  // (the deferred pushes of the last visit are never needed: only the statistic is)
     if (BUILD && VR == 0 && status == 0) {  // the visited list itself is the output (sorted by (hamming, recency))
         emitted = min(vis.len, s.M);
         for (uint32_t i = lane; i < emitted; i += WAVE) {
@@ -1456,15 +1349,15 @@ size_t fast_lds_bytes(const vs_index* idx, const FastLaunch& s) {
     return (b + 15) / 16 * 16;
 }
 
-template <int NCH, int VR, bool TIMING, int MINW, bool BUILD, bool FULL = true, bool VG = false, bool SP = false>
+template <int NCH, int VR, bool TIMING, int MINW, bool BUILD, bool FULL = true, bool VG = false>
 static int launch_fast_tt(vs_index* idx, const FastArgs& a, size_t lds) {
     static bool attr_set = false;
     if (!attr_set) {
-        VS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_search_fast<NCH, VR, TIMING, MINW, BUILD, FULL, VG, SP>),
+        VS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_search_fast<NCH, VR, TIMING, MINW, BUILD, FULL, VG>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_search_fast<NCH, VR, TIMING, MINW, BUILD, FULL, VG, SP>), dim3(a.s.nq), dim3(WAVE), lds, idx->ctx->stream, a);
+    hipLaunchKernelGGL((k_search_fast<NCH, VR, TIMING, MINW, BUILD, FULL, VG>), dim3(a.s.nq), dim3(WAVE), lds, idx->ctx->stream, a);
     VS_HIP(hipGetLastError());
     return VS_OK;
 }
@@ -1479,25 +1372,6 @@ static int launch_fast_t(vs_index* idx, const FastArgs& a, size_t lds) {
         VS_REQUIRE(NCH == 3, "VS_PHASE diagnostics are built for 17..24-word codes only");
         if (a.s.vr == 8) return launch_fast_tt<3, 8, true, 1, false>(idx, a, lds);
         return launch_fast_tt<3, 0, true, 1, false>(idx, a, lds);
-    }
-    if (a.s.sp) {  // software-pipelined visits (5 waves per SIMD, 24-word codes, table-less regime)
-        VS_REQUIRE(NCH == 3 && a.R <= (uint32_t)WAVE && a.s.vr == 0 && a.s.lh == 0 && (a.s.minw == 5 || a.s.minw == 4) && !a.s.build && !a.s.phase && (!a.s.vwords || a.s.epoch == 0),
-                   "fast search: the pipelined variant exists for 24-word codes in the table-less regime only");
-        const bool plain = !a.s.qlabel_off && !a.s.visible && !(a.s.flags & FAST_FULL_VARIANT);
-        if (a.s.minw == 4) {  // 16 scans per CU, no scratch
-            if (a.s.vwords) {
-                if (plain) return launch_fast_tt<3, 0, false, 4, false, false, true, true>(idx, a, lds);
-                return launch_fast_tt<3, 0, false, 4, false, true, true, true>(idx, a, lds);
-            }
-            if (plain) return launch_fast_tt<3, 0, false, 4, false, false, false, true>(idx, a, lds);
-            return launch_fast_tt<3, 0, false, 4, false, true, false, true>(idx, a, lds);
-        }
-        if (a.s.vwords) {
-            if (plain) return launch_fast_tt<3, 0, false, 5, false, false, true, true>(idx, a, lds);
-            return launch_fast_tt<3, 0, false, 5, false, true, true, true>(idx, a, lds);
-        }
-        if (plain) return launch_fast_tt<3, 0, false, 5, false, false, false, true>(idx, a, lds);
-        return launch_fast_tt<3, 0, false, 5, false, true, false, true>(idx, a, lds);
     }
     if (a.s.vwords) {  // written-bucket bitmap in LDS instead of cleared tables (table-less regime, LDS-ring visited list)
         VS_REQUIRE(a.s.vr == 0 && a.s.lh == 0 && a.s.epoch == 0 && (uint64_t)a.s.vwords * 128 >= a.s.gcap,

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Random 24-word-code geometries (768 x 2 bit / 1536 x 1 bit: the headline instantiations of k_search_fast) through the queued kernel
-variants — two-row gather (VS_F_MINW=5), software-pipelined visits (VS_F_SP=1 / 2), each with and without the written-bucket bitmap
+variants — two-row gather (VS_F_MINW=5) with and without the written-bucket bitmap
 (VS_F_VIRGIN=1) — against the oracle: SBQ stream (ids + Hamming distances) and work counters exactly.  scripts/fuzz_emu.py draws
 its dimensions at random and almost never lands on these instantiations.
 
@@ -16,12 +16,10 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import numpy as np  # noqa: E402
 
-VARIANTS = [{"VS_F_MINW": "5"}, {"VS_F_MINW": "5", "VS_F_VIRGIN": "1"}, {"VS_F_SP": "1"}, {"VS_F_SP": "2"},
-            {"VS_F_SP": "1", "VS_F_VIRGIN": "1"}, {"VS_F_SP": "2", "VS_F_VIRGIN": "1"}, {"VS_F_VIRGIN": "1"},
+VARIANTS = [{"VS_F_MINW": "5"}, {"VS_F_MINW": "5", "VS_F_VIRGIN": "1"}, {"VS_F_VIRGIN": "1"},
             # the remaining candidates of vs_index_autotune (csrc/vs_api.hip, kTuneCands): epoch tags alone and with the two-row gather,
             # the bitmap on sparser tables
-            {"VS_F_EPOCH": "1"}, {"VS_F_EPOCH": "1", "VS_F_MINW": "5"}, {"VS_F_VIRGIN": "1", "VS_F_GCAP": "16384"},
-            {"VS_F_EPOCH": "1", "VS_F_SP": "1"}, {"VS_F_EPOCH": "1", "VS_F_SP": "2"}]
+            {"VS_F_EPOCH": "1"}, {"VS_F_EPOCH": "1", "VS_F_MINW": "5"}, {"VS_F_VIRGIN": "1", "VS_F_GCAP": "16384"}]
 KNOBS = sorted({k for v in VARIANTS for k in v})
 COUNTERS = ("visited_nodes", "candidate_nodes", "quantized_distance_comparisons", "node_reads", "next_calls")
 
@@ -42,7 +40,7 @@ def main():
     fails = 0
     for case in range(args.cases):
         n = int(rng.choice([60, 300, 900, 2000]))
-        R = int(rng.choice([8, 20, 32, 50, 64, 80]))  # (80: two chunks per list — the pipelined variant must step aside)
+        R = int(rng.choice([8, 20, 32, 50, 64, 80]))  # (80: two chunks per list)
         bits = int(rng.choice([1, 2]))
         labels = int(rng.choice([0, 0, 4]))
         L = int(rng.choice([1, 3, 20, 60]))

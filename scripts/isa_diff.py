@@ -2,12 +2,16 @@
 """Are the kernels two source trees compile to the same machine code?  (No GPU needed: hipcc cross-compiles.)
 
   python scripts/isa_diff.py <old vs_search_fast.hip> <new vs_search_fast.hip> [name-map-suffix]
+  python scripts/isa_diff.py <old> <new> --dropped-last-param     # the new tree REMOVED the last (bool) template parameter
 
 Compiles both to gfx950 assembly, cuts every k_search_fast instantiation out (label .. s_endpgm), drops comments and renumbers the
 basic-block labels in order of appearance, and reports per instantiation whether the instruction streams are identical — the
 evidence that a commit which only ADDS template parameters / opt-in instantiations left the shipped instantiations' code (and with
 it every hardware measurement of them) untouched.  An instantiation of the old tree k_search_fast<A...> is matched with
-k_search_fast<A..., false, false> (the parameters the new tree appended, default off) when its exact name is gone."""
+k_search_fast<A..., false, false> (the parameters the new tree appended, default off) when its exact name is gone.  With
+--dropped-last-param the old k_search_fast<A..., false> is matched with k_search_fast<A...> and the old <A..., true> ones are
+expected to be gone (how the deletion of the software-pipelined instantiations at the end of round 3 was checked: the 20
+register-capped instantiations byte-identical, the 19 unconstrained ones the same length with a few register numbers changed)."""
 import re
 import subprocess
 import sys
@@ -38,10 +42,17 @@ def kernels(src):
 
 def main():
     old, new = kernels(sys.argv[1]), kernels(sys.argv[2])
-    suffix = sys.argv[3] if len(sys.argv) > 3 else "Lb0ELb0E"
+    dropped = len(sys.argv) > 3 and sys.argv[3] == "--dropped-last-param"
+    suffix = sys.argv[3] if len(sys.argv) > 3 and not dropped else "Lb0ELb0E"
     same = diff = missing = 0
     for name, body in sorted(old.items()):
-        cand = name if name in new else name.replace("EEv8FastArgs", "E" + suffix + "Ev8FastArgs")
+        if dropped:
+            if name.endswith("Lb1EEv8FastArgs"):
+                print(f"gone     {name}" if name not in new else f"STILL THERE {name}")
+                continue
+            cand = name[:-len("Lb0EEv8FastArgs")] + "Ev8FastArgs" if name.endswith("Lb0EEv8FastArgs") else name
+        else:
+            cand = name if name in new else name.replace("EEv8FastArgs", "E" + suffix + "Ev8FastArgs")
         if cand not in new:
             print(f"MISSING  {name}")
             missing += 1

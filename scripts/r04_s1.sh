@@ -3,7 +3,7 @@
 # dedup table (VS_F_VIRGIN=1: no clears, no reads of buckets the scan has not written) — exact on the device
 # first (the regimes that use it + the differential fuzzer), then timed against the shipped default at 10M and 50M, alone and with
 # sparser tables (more never-written buckets per probe, more lines touched), the two-row gather variant (VS_F_MINW=5, §11b.17) and the
-# software-pipelined visits (VS_F_SP=1 / 2, §11b.18)
+# seven waves per SIMD (the software-pipelined visits of §11b.18 were measured three times slower at the end of round 3 and deleted)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" && mkdir -p gpurun_out/r04s1
 O=gpurun_out/r04s1
 VS_TEST_VIRGIN=1 timeout 300 python -m pytest tests/test_gpu_regimes.py tests/test_gpu_zv_fuzz.py -q -m gpu -x 2>&1 | tail -3 | tee $O/tests.txt

@@ -1,6 +1,7 @@
 // vs_api.hip — host side of libvsgpu.so: the C ABI declared in include/vsgpu.h.
 // Context / staging / index residency / batched search pipeline.  No CPU compute fallback anywhere: every compute
 // entry point needs a HIP device and fails with VS_ERR_HIP otherwise.
+#include <thread>
 #include <cstdarg>
 #include <cmath>
 #include <algorithm>
@@ -172,6 +173,37 @@ extern "C" int vs_dev_free(vs_ctx* c, void* p) {
 
 // Host -> HBM through the pinned ring: memcpy into pinned buffer i while buffer 1-i is in flight (hipMemcpyAsync on
 // the copy stream).  The final event is waited on by the compute stream so kernels see the data.
+// pageable <-> pinned copies of the staging ring.  One thread moves ~13 GB/s, a quarter of what the PCIe link behind the pinned
+// buffer takes (50M x 768: 62 ms of a 273 ms PCIe-inclusive step were this memcpy, profiles/r03/bench_50m.json), so chunks of
+// 8 MiB and more are split over a few threads (VS_STAGE_THREADS, default 4; 1 = the plain memcpy).
+static void stage_copy(void* dst, const void* src, size_t n) {
+    static const unsigned nt_cfg = [] {
+        const char* e = getenv("VS_STAGE_THREADS");
+        const unsigned v = e && *e ? (unsigned)strtoul(e, nullptr, 10) : 4u;
+        return std::min(std::max(v, 1u), 16u);
+    }();
+    if (n < (8u << 20) || nt_cfg == 1) {
+        memcpy(dst, src, n);
+        return;
+    }
+    const size_t part = (((n + nt_cfg - 1) / nt_cfg) + 4095) & ~(size_t)4095;  // (nt_cfg parts cover n)
+    std::thread th[16];
+    unsigned started = 0;
+    for (unsigned t = 1; t < nt_cfg; ++t) {
+        const size_t off = (size_t)t * part;
+        if (off >= n) break;
+        const size_t len = std::min(part, n - off);
+        try {
+            th[started] = std::thread([=] { memcpy(static_cast<char*>(dst) + off, static_cast<const char*>(src) + off, len); });
+            started++;
+        } catch (...) {  // no thread to be had: this one does the part itself
+            memcpy(static_cast<char*>(dst) + off, static_cast<const char*>(src) + off, len);
+        }
+    }
+    memcpy(dst, src, std::min(part, n));
+    for (unsigned t = 0; t < started; ++t) th[t].join();
+}
+
 extern "C" int vs_dev_upload(vs_ctx* c, void* dst, const void* src, size_t bytes) {
     VS_REQUIRE(c && (bytes == 0 || (dst && src)), "vs_dev_upload: bad args");
     const char* s = static_cast<const char*>(src);
@@ -181,7 +213,7 @@ extern "C" int vs_dev_upload(vs_ctx* c, void* dst, const void* src, size_t bytes
     while (off < bytes) {
         size_t n = std::min(c->pinned_bytes, bytes - off);
         VS_HIP(hipEventSynchronize(c->pinned_ev[slot]));  // buffer free again?
-        memcpy(c->pinned[slot], s + off, n);
+        stage_copy(c->pinned[slot], s + off, n);
         VS_HIP(hipMemcpyAsync(d + off, c->pinned[slot], n, hipMemcpyHostToDevice, c->copy_stream));
         VS_HIP(hipEventRecord(c->pinned_ev[slot], c->copy_stream));
         off += n;
@@ -202,7 +234,7 @@ extern "C" int vs_dev_download(vs_ctx* c, void* dst, const void* src, size_t byt
     while (off < bytes || pend_n[0] || pend_n[1]) {
         if (pend_n[slot]) {  // drain the older transfer in this slot
             VS_HIP(hipEventSynchronize(c->pinned_ev[slot]));
-            memcpy(d + pend_off[slot], c->pinned[slot], pend_n[slot]);
+            stage_copy(d + pend_off[slot], c->pinned[slot], pend_n[slot]);
             pend_n[slot] = 0;
         }
         if (off < bytes) {

@@ -80,3 +80,19 @@ def test_handles_return_their_device_memory(gpu_ctx, labeled):
         _workout(gpu_ctx, ti, q, labeled)
     after = _live()
     assert after == before, f"{after - before} device / pinned allocations outlived their handles"
+
+
+def test_staging_ring_round_trip(gpu_ctx):
+    """host -> pinned ring -> HBM -> pinned ring -> host: chunks of 8 MiB and more are copied into / out of the pinned buffers by several
+    threads (stage_copy, csrc/vs_api.hip); sizes around the chunk (32 MiB) and the split boundaries must come back bit for bit"""
+    rng = np.random.default_rng(3)
+    # (sizes whose per-thread share is page aligned while the total is not: the split must still cover the last bytes)
+    for nbytes in (5, (8 << 20) - 1, (8 << 20) + 4097, (32 << 20) + 12345, (70 << 20) + 1, 2 * 4096 * 1100 + 1, 3 * 4096 * 700 + 1,
+                   4 * 4096 * 600 + 3, 5 * 4096 * 500 + 4, 16 * 4096 * 140 + 15):
+        a = rng.integers(0, 256, nbytes, dtype=np.uint8)
+        d = gpu_ctx.alloc(nbytes)
+        gpu_ctx.upload(d, a)
+        b = np.zeros(nbytes, np.uint8)
+        gpu_ctx.download(d, b)
+        gpu_ctx.free(d)
+        assert (a == b).all(), nbytes

@@ -144,6 +144,7 @@ def run(dim=768, n=100_000, nq=8192, device=0, lib=None, timeout=240.0, search_l
     env = dict(os.environ)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+    env["VS_NO_TORCH"] = "1"  # (the child never touches torch: its import would be most of the probe's run time)
     t0 = time.time()
     try:
         proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, cwd=root, start_new_session=True)

@@ -176,12 +176,16 @@ extern "C" int vs_dev_free(vs_ctx* c, void* p) {
 // pageable <-> pinned copies of the staging ring.  One thread moves ~13 GB/s, a quarter of what the PCIe link behind the pinned
 // buffer takes (50M x 768: 62 ms of a 273 ms PCIe-inclusive step were this memcpy, profiles/r03/bench_50m.json), so chunks of
 // 8 MiB and more are split over a few threads (VS_STAGE_THREADS, default 4; 1 = the plain memcpy).
-static void stage_copy(void* dst, const void* src, size_t n) {
+static unsigned stage_threads() {
     static const unsigned nt_cfg = [] {
         const char* e = getenv("VS_STAGE_THREADS");
         const unsigned v = e && *e ? (unsigned)strtoul(e, nullptr, 10) : 4u;
         return std::min(std::max(v, 1u), 16u);
     }();
+    return nt_cfg;
+}
+static void stage_copy(void* dst, const void* src, size_t n) {
+    const unsigned nt_cfg = stage_threads();
     if (n < (8u << 20) || nt_cfg == 1) {
         memcpy(dst, src, n);
         return;
@@ -262,9 +266,33 @@ static int upload_rows(vs_ctx* c, void* dst, size_t dev_row_bytes, const void* s
         size_t nr = std::min(rows_per_chunk, rows - r0);
         VS_HIP(hipEventSynchronize(c->pinned_ev[slot]));
         char* p = static_cast<char*>(c->pinned[slot]);
-        memset(p, 0, nr * dev_row_bytes);
-        for (size_t r = 0; r < nr; ++r)
-            memcpy(p + r * dev_row_bytes, static_cast<const char*>(src) + (r0 + r) * host_row_bytes, copy_bytes);
+        // (rows of a chunk are independent: a chunk of 8 MiB and more is padded + copied by several threads, like stage_copy)
+        auto fill = [=](size_t ra, size_t rb) {
+            for (size_t r = ra; r < rb; ++r) {
+                char* drow = p + r * dev_row_bytes;
+                memcpy(drow, static_cast<const char*>(src) + (r0 + r) * host_row_bytes, copy_bytes);
+                if (dev_row_bytes > copy_bytes) memset(drow + copy_bytes, 0, dev_row_bytes - copy_bytes);
+            }
+        };
+        const unsigned nt = nr * dev_row_bytes >= (8u << 20) ? stage_threads() : 1u;
+        if (nt <= 1) {
+            fill(0, nr);
+        } else {
+            std::thread th[16];
+            unsigned started = 0;
+            const size_t per = (nr + nt - 1) / nt;
+            for (unsigned t = 1; t < nt && (size_t)t * per < nr; ++t) {
+                const size_t ra = (size_t)t * per, rb = std::min(nr, ra + per);
+                try {
+                    th[started] = std::thread(fill, ra, rb);
+                    started++;
+                } catch (...) {
+                    fill(ra, rb);
+                }
+            }
+            fill(0, std::min(per, nr));
+            for (unsigned t = 0; t < started; ++t) th[t].join();
+        }
         VS_HIP(hipMemcpyAsync(static_cast<char*>(dst) + r0 * dev_row_bytes, p, nr * dev_row_bytes,
                               hipMemcpyHostToDevice, c->copy_stream));
         VS_HIP(hipEventRecord(c->pinned_ev[slot], c->copy_stream));

@@ -96,3 +96,27 @@ def test_staging_ring_round_trip(gpu_ctx):
         gpu_ctx.download(d, b)
         gpu_ctx.free(d)
         assert (a == b).all(), nbytes
+
+
+def test_row_wise_staging_pads_and_copies_every_row(gpu_ctx):
+    """index upload through the public entry point: neighbor lists of R = 50 go into device rows of 64 through the pinned ring row by
+    row, zero padded, and 9-dimensional vectors into rows of 12 floats; a chunk of 8 MiB and more is filled by several threads —
+    every row must arrive (vs_index_download undoes the padding)"""
+    import pgvectorscale_amd as P
+    rng = np.random.default_rng(11)
+    n, R, dim, W = 200_001, 50, 9, 1
+    nbrs = ((np.arange(n, dtype=np.uint64)[:, None] + 1 + np.arange(R, dtype=np.uint64)[None, :] * 7919) % n).astype(np.uint32)
+    nbrs[::17, 40:] = 0xFFFFFFFF  # some short lists (the list ends at the first invalid id)
+    codes = rng.integers(0, 1 << 18, (n, W), dtype=np.uint64)
+    tids = ((np.arange(n, dtype=np.uint64) + 3) << np.uint64(16)) | np.uint64(1)
+    vecs = rng.standard_normal((n, dim)).astype(np.float32)
+    ix = P.DiskAnnIndex.upload(gpu_ctx, codes=codes, nbrs=nbrs, heap_tids=tids, vecs=vecs, mean=np.zeros(dim, np.float32),
+                               m2=np.ones(dim, np.float32), count=n, bits=2, dim_index=dim, num_neighbors=R, distance_type=P.VS_L2,
+                               default_start=0)
+    try:
+        host = ix.download(vecs=True)
+        assert (host["nbrs"] == nbrs).all()
+        assert (host["codes"] == codes).all() and (host["heap_tids"] == tids).all()
+        assert (host["vecs"].view(np.uint32) == vecs.view(np.uint32)).all()
+    finally:
+        ix.close()

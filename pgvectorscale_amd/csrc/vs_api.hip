@@ -882,7 +882,7 @@ static Caps initial_caps(const vs_index* ix, uint32_t L, uint32_t M) {
     const uint32_t want_v = (uint32_t)std::min<uint64_t>((uint64_t)L + L / 2 + 32, 1u << 20);
     // visited list: register resident (8 VGPR pairs) while LDS is the limiter; in the table-less regime registers are,
     // and the LDS ring variant needs 87 VGPRs instead of 141 (5 instead of 3 waves per SIMD)
-    c.f_vr = env_u32("VS_F_VR", (lds_table && want_v <= 512) ? 8 : 0);
+    c.f_vr = knob_u32("VS_F_VR", ix->tune.vr, (lds_table && want_v <= 512) ? 8 : 0);
     c.f_vcap = c.f_vr ? 512 : round_up_u32(std::max<uint32_t>(env_u32("VS_F_VCAP", 2 * want_v), 64), 64);
     c.f_on = env_u32("VS_FAST", 1) != 0 && ix->d.storage_type != VS_STORAGE_PLAIN;  // the LDS-resident kernels score SBQ codes
     if (c.f_on) {
@@ -1142,7 +1142,7 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
         VS_TRY(launch_search_fast(ix, f));
         prof_end(c, PK_SEARCH, ev);
         fast_done = true;
-        ix->last_fast = FastSig{epoch ? 1u : 0u, f.vwords, f.minw, f.gcap, f.lh, 1u};
+        ix->last_fast = FastSig{epoch ? 1u : 0u, f.vwords, f.minw, f.gcap, f.lh, f.vr, 1u};
         // second attempt of the scans that outgrew these capacities (a handful per launch at the tail of the distribution):
         // the same kernel with a four times larger dedup table, twice the heap and visited-list room, regions from a small
         // pool.  Scans finished above return at once; what still does not fit goes to the general kernel below.
@@ -1524,6 +1524,8 @@ struct TuneCand {
     int epoch, virgin, minw;
     uint32_t gcap;
     int lds_max_ins = -1;  // 0: a candidate for indexes whose default is the LDS-table regime (the table-less regime there)
+    int vr = -1;           // 0: likewise — the LDS table stays, the visited list moves from registers to the LDS ring
+    bool for_lds_regime() const { return lds_max_ins == 0 || vr == 0; }
 };
 static const TuneCand kTuneCands[] = {
     {"default", -1, -1, -1, 0},
@@ -1539,6 +1541,9 @@ static const TuneCand kTuneCands[] = {
     // bitmap (1M x 768 at search_list_size 3 / rescore 53: -37.7 % / -36.2 %, profiles/r03/ab_autotune_1m.json)
     {"table_less", 0, 0, -1, 0, 0},
     {"table_less_bitmap", 0, 1, -1, 0, 0},
+    // ... or the LDS table with the LDS-ring visited list (the register-resident list is what costs the default its occupancy:
+    // 141 VGPRs; exact on the interpreter, not timed yet)
+    {"lds_table_ring", 0, 0, -1, 0, -1, 0},
 };
 static const uint32_t kNTuneCands = sizeof(kTuneCands) / sizeof(kTuneCands[0]);
 
@@ -1548,6 +1553,7 @@ static void tune_apply(vs_index* ix, const TuneCand& c) {
     ix->tune.minw = c.minw;
     ix->tune.gcap = c.gcap;
     ix->tune.lds_max_ins = c.lds_max_ins;
+    ix->tune.vr = c.vr;
     snprintf(ix->tune.name, sizeof(ix->tune.name), "%s", c.name);
 }
 
@@ -1660,7 +1666,7 @@ static int vs_index_autotune_impl(vs_index* ix, const float* d_q, const int16_t*
         if (ci > 0) {
             // a variant that cannot be told from the default here is not launched at all
             if (!base.sig.ran) continue;                                           // no LDS-resident kernel for this index
-            if ((base.sig.lh != 0) != (cand.lds_max_ins == 0)) continue;           // table-less variants / LDS-table regime: the other's candidates
+            if ((base.sig.lh != 0) != cand.for_lds_regime()) continue;             // table-less variants / LDS-table regime: the other's candidates
             if (cand.minw >= 0 && !w24) continue;                                  // built for 17..24-word codes only
             if (cand.gcap && cand.gcap <= base.sig.gcap) continue;                 // not sparser than the fitted table
             if (skip_list.find(std::string(",") + cand.name + ",") != std::string::npos) continue;  // the caller's veto

@@ -121,15 +121,16 @@ struct ScanObs {
 struct TuneVariant {
     int epoch = -1, virgin = -1, minw = -1;
     int lds_max_ins = -1;  // 0: the table-less regime even for scans whose dedup table would fit LDS
+    int vr = -1;           // 0: the LDS-ring visited list also where the register-resident one is the default (LDS-table regime)
     uint32_t gcap = 0;
     char name[40] = "default";
 };
 // what the last first-attempt launch of k_search_fast really was (a variant that does not exist for an index / operating point
 // silently launches the default's instantiation: the autotuner reads this to tell)
 struct FastSig {
-    uint32_t epoch_on = 0, vwords = 0, minw = 0, gcap = 0, lh = 0, ran = 0;
+    uint32_t epoch_on = 0, vwords = 0, minw = 0, gcap = 0, lh = 0, vr = 0, ran = 0;
     bool operator==(const FastSig& o) const {
-        return epoch_on == o.epoch_on && vwords == o.vwords && minw == o.minw && gcap == o.gcap && lh == o.lh && ran == o.ran;
+        return epoch_on == o.epoch_on && vwords == o.vwords && minw == o.minw && gcap == o.gcap && lh == o.lh && vr == o.vr && ran == o.ran;
     }
 };
 

@@ -15,8 +15,8 @@ pytestmark = pytest.mark.gpu
 
 EMU = bool(os.environ.get("VS_EMU"))
 REGIME = {"VS_F_LDS_MAX_INS": "0", "VS_F_VR": "0"}  # the table-less regime of large indexes (the variants exist only there)
-NAMES = ["default", "epoch_tags", "bucket_bitmap", "bucket_bitmap_16k", "two_rows", "two_rows_epoch", "table_less", "table_less_bitmap"]
-LDS_REGIME_ONLY = NAMES[-2:]  # candidates for indexes whose default keeps the dedup table in LDS
+NAMES = ["default", "epoch_tags", "bucket_bitmap", "bucket_bitmap_16k", "two_rows", "two_rows_epoch", "table_less", "table_less_bitmap", "lds_table_ring"]
+LDS_REGIME_ONLY = NAMES[-3:]  # candidates for indexes whose default keeps the dedup table in LDS
 
 
 @pytest.fixture(scope="module")

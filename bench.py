@@ -272,7 +272,7 @@ def main():
     ap.add_argument("--latent-dim", type=int, default=0, help="override the corpus generator's latent dimension (1..128)")
     ap.add_argument("--noise-pct", type=int, default=-1, help="override the isotropic noise share (0..100)")
     ap.add_argument("--intra-pct", type=int, default=-1, help="override the within-cluster spread (0..100)")
-    ap.add_argument("--pcie-steps", type=int, default=1,
+    ap.add_argument("--pcie-steps", type=int, default=2,
                     help="steps of the PCIe-inclusive leg (queries start in pageable host memory, rows end there: vs_search_batch); "
                          "reported next to the value, never as the value; 0 = skip")
     ap.add_argument("--autotune", default="on", choices=["on", "off"],

@@ -373,7 +373,7 @@ extern "C" void vs_index_free(vs_index* ix) {
             if (p) (void)hipFree(p);
     }
     SearchWorkspace& w = ix->ws;
-    DevBuf* bufs[] = {&w.q_full, &w.qcodes, &w.qlabels, &w.qlabel_off, &w.hash, &w.heap_g, &w.heap_g4, &w.ghash4, &w.heap_g4b, &w.ghash4b, &w.pool_ctr, &w.fb_flag, &w.phase, &w.stream_ids,
+    DevBuf* bufs[] = {&w.q_full, &w.qcodes, &w.qlabels, &w.qlabel_off, &w.hash, &w.heap_g, &w.heap_g4, &w.ghash4, &w.heap_g4b, &w.ghash4b, &w.pool_ctr, &w.fb_flag, &w.phase, &w.timeline, &w.stream_ids,
                       &w.stream_ham, &w.stream_cnt, &w.stats, &w.status, &w.rr_dist, &w.out_ids, &w.out_tids,
                       &w.out_dist, &w.resort_heap, &w.raw_q, &w.misc, &w.q_index};
     for (DevBuf* b : bufs) devbuf_free(*b);
@@ -1062,9 +1062,43 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
     bool fast_done = false;
     ix->last_fast = FastSig{};
     if (caps.f_on) {
-        const uint32_t fslots = fast_pool_slots(nq, caps.f_pool_frac);
+        uint32_t fslots = fast_pool_slots(nq, caps.f_pool_frac);
         ix->last_ins_limit = caps.f_lh ? caps.f_lh - caps.f_lh / 8 - 64 : 0xFFFFFFFFu;
-        VS_TRY(devbuf_reserve(c, w.heap_g4, std::max<size_t>((size_t)nq * caps.f_gstride * 4, 16)));
+        // Persistent grid (VS_F_PERSIST, default on): as many single-wave workgroups as the device holds at once, each taking scan
+        // after scan from a counter and reusing ITS region of the heap spill array and of the dedup tables — the workspace is
+        // (resident scans) x (region) instead of nq x (region): 0.6 GB instead of 26 GB for 262 144 scans of the 50M index
+        FastLaunch f;
+        f.nq = nq;
+        f.L = bp.L;
+        f.M = M;
+        f.hl = caps.f_hl;
+        f.hcap = caps.f_hcap;
+        f.gstride = caps.f_gstride;
+        f.vr = caps.f_vr;
+        f.gcap = caps.f_gcap;
+        f.lh = caps.f_lh;
+        f.minw = knob_u32("VS_F_MINW", (caps.f_lh == 0 && !caps.f_vr) ? ix->tune.minw : -1, caps.f_lh == 0 ? (caps.f_vr ? 4 : 6) : 1);
+        f.flags = env_u32("VS_F_FLAGS", 0);
+        f.sb = caps.f_sb;
+        f.vcap = caps.f_vcap;
+        f.qlabels = d_qlabels;
+        f.qlabel_off = d_qlabel_off;
+        f.visible = (!bp.stream_only && bp.rescore > 0) ? ix->visible : nullptr;  // the heap is only fetched for the rescore window
+        f.rc = caps.f_lh == 0 ? env_u32("VS_F_RC", 0) : 0;  // (measurement: LDS id cache in front of the dedup table in HBM)
+        if (f.rc) f.rc = next_pow2_u32(f.rc);
+        const bool want_epoch = caps.f_lh == 0 && knob_u32("VS_F_EPOCH", ix->tune.epoch, 0);
+        // written-bucket bitmap (VS_F_VIRGIN=1, table-less regime): 128 slots of the table per LDS word; tables of more than
+        // 64 Ki slots keep the clear (the bitmap would cost occupancy)
+        if (caps.f_lh == 0 && !want_epoch && !f.vr && knob_u32("VS_F_VIRGIN", ix->tune.virgin, 0) && !env_u32("VS_PHASE", 0) && f.gcap <= (1u << 16))
+            f.vwords = (f.gcap + 127) / 128;
+        if (env_u32("VS_PHASE", 0)) f.phase = (uint64_t*)16;  // (selects the instantiation; the buffer is set below)
+        if (knob_u32("VS_F_PERSIST", ix->tune.persist, 1) && !want_epoch) {
+            uint32_t res = 0;
+            VS_TRY(fast_resident_scans(ix, f, &res));
+            f.persist = std::max<uint32_t>(1, (uint32_t)((uint64_t)res * env_u32("VS_F_PERSIST_PCT", 100) / 100));
+            fslots = std::min(f.persist, nq);
+        }
+        VS_TRY(devbuf_reserve(c, w.heap_g4, std::max<size_t>((size_t)(f.persist ? fslots : nq) * caps.f_gstride * 4, 16)));
         const void* const ghash4_before = w.ghash4.p;
         const size_t ghash4_bytes_before = w.ghash4.bytes;
         VS_TRY(devbuf_reserve(c, w.ghash4, (size_t)fslots * caps.f_gcap * 4));
@@ -1075,7 +1109,7 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
         // the MI355X with the tags on (profiles/r03/s8_s9_epoch_bug_bisect.txt).  The cause was found on the interpreter after the
         // round's GPU minutes were gone (the reallocation test below used to compare addresses) — the switch
         // stays off until the fix has run on hardware.
-        if (caps.f_lh == 0 && knob_u32("VS_F_EPOCH", ix->tune.epoch, 0)) {
+        if (want_epoch) {
             while ((1ull << eshift) < (uint64_t)std::max<uint32_t>(ix->d.n, 2)) eshift++;
             if (eshift <= 28) {  // >= 15 launches between two clears
                 const uint32_t last = std::min<uint32_t>((1u << (32 - eshift)) - 1u, env_u32("VS_F_EPOCH_MAX", 0xFFFFFFFFu));  // (the override lets a test see the wrap)
@@ -1098,36 +1132,16 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
         VS_HIP(hipMemsetAsync(w.pool_ctr.p, 0, 64, c->stream));
         VS_TRY(devbuf_reserve(c, w.fb_flag, (size_t)nq * 4));
         VS_HIP(hipMemsetAsync(w.fb_flag.p, 0, (size_t)nq * 4, c->stream));
-        FastLaunch f;
-        f.nq = nq;
-        f.L = bp.L;
-        f.M = M;
-        f.hl = caps.f_hl;
-        f.hcap = caps.f_hcap;
-        f.gstride = caps.f_gstride;
-        f.vr = caps.f_vr;
+        if (want_epoch && !epoch) f.vwords = 0;
         f.heap_g = (uint32_t*)w.heap_g4.p;
-        f.gcap = caps.f_gcap;
         f.ghash = (uint32_t*)w.ghash4.p;
         f.pool_counter = (uint32_t*)w.pool_ctr.p;
+        f.scan_counter = (uint32_t*)w.pool_ctr.p + 2;
         f.pool_slots = fslots;
-        f.lh = caps.f_lh;
-        f.minw = knob_u32("VS_F_MINW", (caps.f_lh == 0 && !caps.f_vr) ? ix->tune.minw : -1, caps.f_lh == 0 ? (caps.f_vr ? 4 : 6) : 1);
-        f.flags = env_u32("VS_F_FLAGS", 0);
         f.epoch = epoch;
         f.eshift = eshift;
-        f.rc = caps.f_lh == 0 ? env_u32("VS_F_RC", 0) : 0;  // (measurement: LDS id cache in front of the dedup table in HBM)
-        if (f.rc) f.rc = next_pow2_u32(f.rc);
-        // written-bucket bitmap (VS_F_VIRGIN=1, table-less regime): 128 slots of the table per LDS word; tables of more than
-        // 64 Ki slots keep the clear (the bitmap would cost occupancy)
-        if (caps.f_lh == 0 && !epoch && !f.vr && knob_u32("VS_F_VIRGIN", ix->tune.virgin, 0) && !env_u32("VS_PHASE", 0) && f.gcap <= (1u << 16))
-            f.vwords = (f.gcap + 127) / 128;
-        f.visible = (!bp.stream_only && bp.rescore > 0) ? ix->visible : nullptr;  // the heap is only fetched for the rescore window
-        f.sb = caps.f_sb;
-        f.vcap = caps.f_vcap;
+        f.phase = nullptr;
         f.qcodes = (const uint64_t*)w.qcodes.p;
-        f.qlabels = d_qlabels;
-        f.qlabel_off = d_qlabel_off;
         f.out_ids = (uint32_t*)w.stream_ids.p;
         f.out_ham = (uint32_t*)w.stream_ham.p;
         f.out_cnt = (uint32_t*)w.stream_cnt.p;
@@ -1138,10 +1152,25 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
             VS_HIP(hipMemsetAsync(w.phase.p, 0, (size_t)nq * 64, c->stream));
             f.phase = (uint64_t*)w.phase.p;
         }
+        const char* const tl_path = getenv("VS_TIMELINE");  // diagnostics: start / end of every scan of this launch, dumped to a file
+        if (tl_path && *tl_path) {
+            VS_TRY(devbuf_reserve(c, w.timeline, (size_t)nq * 16));
+            VS_HIP(hipMemsetAsync(w.timeline.p, 0, (size_t)nq * 16, c->stream));
+            f.timeline = (uint64_t*)w.timeline.p;
+        }
         hipEvent_t ev = prof_begin(c);
         VS_TRY(launch_search_fast(ix, f));
         prof_end(c, PK_SEARCH, ev);
         fast_done = true;
+        if (f.timeline) {
+            std::vector<uint64_t> tl((size_t)nq * 2);
+            VS_HIP(hipMemcpyAsync(tl.data(), w.timeline.p, tl.size() * 8, hipMemcpyDeviceToHost, c->stream));
+            VS_HIP(hipStreamSynchronize(c->stream));
+            if (FILE* fp = fopen(tl_path, "wb")) {
+                fwrite(tl.data(), 8, tl.size(), fp);
+                fclose(fp);
+            }
+        }
         ix->last_fast = FastSig{epoch ? 1u : 0u, f.vwords, f.minw, f.gcap, f.lh, f.vr, 1u};
         // second attempt of the scans that outgrew these capacities (a handful per launch at the tail of the distribution):
         // the same kernel with a four times larger dedup table, twice the heap and visited-list room, regions from a small
@@ -1150,6 +1179,8 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
             FastLaunch r = f;
             r.epoch = 0;  // (its own, smaller table array: cleared by the few scans that run)
             r.vwords = 0;
+            r.persist = 0;  // (one workgroup per scan: nearly all of them return at once; regions from the pool)
+            r.timeline = nullptr;
             r.only_failed = 1;
             r.fb_flag = (uint32_t*)w.fb_flag.p;
             r.phase = nullptr;

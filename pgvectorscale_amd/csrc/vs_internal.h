@@ -97,7 +97,7 @@ struct DevBuf {
 struct SearchWorkspace {
     uint32_t ghash4_epoch = 0;   // epoch of the last launch on ghash4 (0: the array must be zeroed before the next tagged launch)
     uint32_t ghash4_eshift = 0;  // id bits the tags in ghash4 were written with
-    DevBuf q_full, qcodes, qlabels, qlabel_off, hash, heap_g, heap_g4, ghash4, heap_g4b, ghash4b, pool_ctr, fb_flag, phase, stream_ids, stream_ham, stream_cnt, stats, status,
+    DevBuf q_full, qcodes, qlabels, qlabel_off, hash, heap_g, heap_g4, ghash4, heap_g4b, ghash4b, pool_ctr, fb_flag, phase, timeline, stream_ids, stream_ham, stream_cnt, stats, status,
         rr_dist, out_ids, out_tids, out_dist, resort_heap, raw_q, misc, q_index;
     // pending async call (vs_search_batch_dev)
     bool fb_valid = false;  // fb_flag holds the fallback marks of the last chunk
@@ -119,7 +119,7 @@ struct ScanObs {
 // the launch variant of k_search_fast an index prefers (vs_index_autotune / vs_index_set_variant): -1 = the library default;
 // a VS_F_* environment variable still overrides the field it names
 struct TuneVariant {
-    int epoch = -1, virgin = -1, minw = -1;
+    int epoch = -1, virgin = -1, minw = -1, persist = -1;
     int lds_max_ins = -1;  // 0: the table-less regime even for scans whose dedup table would fit LDS
     int vr = -1;           // 0: the LDS-ring visited list also where the register-resident one is the default (LDS-table regime)
     uint32_t gcap = 0;
@@ -233,7 +233,7 @@ struct FastLaunch {
     uint32_t rc = 0;   // entries of the LDS cache of ids known to be in the table (table-less regime; 0 or a power of two)
     uint32_t epoch = 0;   // != 0: global dedup entries are (epoch << eshift) | id and stale tags count as empty (no clearing)
     uint32_t eshift = 0;  // bits of a node id inside a tagged entry
-    uint32_t reserved0 = 0;  // (the switch of the software-pipelined variant, deleted after it measured three times slower; the field keeps the kernel-argument layout)
+    uint32_t persist = 0;  // != 0: persistent grid of `persist` workgroups taking scans from scan_counter; regions of heap_g / ghash are per workgroup
     uint32_t vwords = 0;  // != 0: words of the LDS bitmap of written buckets (one bit per four slots of gcap): tables are neither cleared nor read before their first write
     uint32_t build = 0; // 1: greedy_search_for_build (the visited list is the output; needs vr == 0)
     uint32_t flags = 0; // FAST_* (measurement switches)
@@ -257,6 +257,8 @@ struct FastLaunch {
     uint32_t* stats;
     uint32_t* status;
     uint64_t* phase = nullptr;  // optional [nq][8] per-phase shader-clock sums (VS_PHASE=1, diagnostics only)
+    uint32_t* scan_counter = nullptr;  // persist: next scan to run (zero before the launch)
+    uint64_t* timeline = nullptr;  // optional [nq][2] start / end of every scan in 100 MHz ticks (VS_TIMELINE=1, diagnostics only)
 };
 enum {
     FAST_PLAIN_ROW_LOADS = 1,  // code rows through the normal cache policy instead of non-temporal loads
@@ -264,6 +266,7 @@ enum {
 };
 size_t fast_lds_bytes(const vs_index* idx, const FastLaunch& s);
 int launch_search_fast(vs_index* idx, const FastLaunch& s);
+int fast_resident_scans(vs_index* idx, const FastLaunch& s, uint32_t* out);  // size of a persistent grid for this instantiation
 enum { ST_VISITS = 0, ST_CAND = 1, ST_DQ = 2, ST_READS = 3, ST_NEXT = 4, ST_GSPILL = 5, ST_INVIS = 6, ST_N = 8 };
 enum { OVF_HEAP = 1, OVF_VISITED = 2, OVF_HASH = 4, OVF_POOL = 8,
        OVF_KEY = 16 };  // (fast kernel only) the scan key has more labels than its LDS slot holds: the general kernel runs the scan

@@ -702,14 +702,21 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 // ring capacity, farthest entry dropped) is the result.
 // FULL = label keys and / or a visibility mask may be present; the plain instantiation (neither) leaves their pointers, counters
 // and branches out of a kernel whose scalar registers are its tightest resource.
-template <int NCH, int VR, bool TIMING, int MINW, bool BUILD, bool FULL = true, bool VG = false>
-__global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
+// One scan.  `slot` names the per-scan regions of the workspace (heap spill array, dedup table in HBM): the scan's own index when
+// the launch has one workgroup per scan, the workgroup's index when the grid is persistent (s.persist: as many workgroups as the
+// chip holds at once, each taking scan after scan from a counter — the regions are then reused by the scans a workgroup runs, the
+// workspace is a few hundred MB whatever the batch size, and no region is claimed with an atomic).
+template <int NCH, int VR, bool TIMING, int MINW, bool BUILD, bool FULL, bool VG>
+__device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, const uint32_t slot) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lane = threadIdx.x;
-    const uint32_t q = blockIdx.x;
+    int lane_v = threadIdx.x;
+    // (persistent grid: what a scan derives from its lane index is derived again by the next scan instead of being carried
+    // across the whole kernel — the register allocation of one scan stays what it is with one workgroup per scan)
+    asm volatile("" : "+v"(lane_v));
+    const int lane = lane_v;
     const FastLaunch& s = a.s;
-    if (q >= s.nq) return;
     if (s.only_failed && s.status[q] == 0) return;  // (wave-uniform) finished by the first launch
+    if (s.timeline && lane == 0) s.timeline[2 * (size_t)q] = wall_clock64();
 
     // ---- LDS carve ----
     uint32_t* hp = reinterpret_cast<uint32_t*>(smem);                 // hl + 1 (hl + 1 is a power of two >= 64)
@@ -783,7 +790,8 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
 
     FastHeap<(MINW >= 7)> heap;
     heap.l = hp;
-    heap.g = s.only_failed ? s.heap_g : s.heap_g + (size_t)q * s.gstride;  // (second attempt: set with the pool region)
+    // (second attempt with one workgroup per scan: set with the pool region)
+    heap.g = s.persist ? s.heap_g + (size_t)slot * s.gstride : (s.only_failed ? s.heap_g : s.heap_g + (size_t)q * s.gstride);
     heap.hl = s.hl;
     heap.sb = s.sb;
     heap.init(lane);
@@ -815,16 +823,21 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
     // global dedup overflow table: claimed from the pool on first need
     auto claim_region = [&]() -> bool {
         if (region) return true;
-        uint32_t slot = 0;
-        if (lane == 0) slot = atomicAdd(s.pool_counter, 1u);
-        slot = rfl(slot);
-        if (slot >= s.pool_slots) {
+        if (s.persist) {  // the workgroup's own region (the launch wrapper holds pool_slots >= the grid)
+            region = true;
+            ghash = s.ghash + (size_t)slot * s.gcap;
+            return true;
+        }
+        uint32_t pslot = 0;
+        if (lane == 0) pslot = atomicAdd(s.pool_counter, 1u);
+        pslot = rfl(pslot);
+        if (pslot >= s.pool_slots) {
             status |= OVF_POOL;
             return false;
         }
         region = true;
-        ghash = s.ghash + (size_t)slot * s.gcap;
-        if (s.only_failed) heap.g = s.heap_g + (size_t)slot * s.gstride;
+        ghash = s.ghash + (size_t)pslot * s.gcap;
+        if (s.only_failed) heap.g = s.heap_g + (size_t)pslot * s.gstride;
         return true;
     };
     auto hash_home = [&](uint32_t nid) -> uint32_t { return (uint32_t)(((uint64_t)hash_u32(nid) * s.lh) >> 32); };
@@ -1338,6 +1351,25 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
             lap(6);
             for (int k = 0; k < 8; ++k) s.phase[(size_t)q * 8 + k] = ph[k];
         }
+        if (s.timeline) s.timeline[2 * (size_t)q + 1] = wall_clock64();
+    }
+}
+
+template <int NCH, int VR, bool TIMING, int MINW, bool BUILD, bool FULL = true, bool VG = false>
+__global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
+    if (!a.s.persist) {
+        if (blockIdx.x < a.s.nq) fast_scan<NCH, VR, TIMING, MINW, BUILD, FULL, VG>(a, blockIdx.x, blockIdx.x);
+        return;
+    }
+    // persistent grid: the launch has no tail of its own beyond the last scans' lives, and the hardware never has to place a
+    // new workgroup (LDS, registers, a wave slot) while the chip is full
+    for (;;) {
+        uint32_t q = 0;
+        if (threadIdx.x == 0) q = atomicAdd(a.s.scan_counter, 1u);
+        q = rfl(q);
+        if (q >= a.s.nq) return;
+        fast_scan<NCH, VR, TIMING, MINW, BUILD, FULL, VG>(a, q, blockIdx.x);
+        wave_sync();  // the next scan re-initialises the LDS state: every lane is done with this one's
     }
 }
 
@@ -1350,61 +1382,67 @@ size_t fast_lds_bytes(const vs_index* idx, const FastLaunch& s) {
 }
 
 template <int NCH, int VR, bool TIMING, int MINW, bool BUILD, bool FULL = true, bool VG = false>
-static int launch_fast_tt(vs_index* idx, const FastArgs& a, size_t lds) {
+static int launch_fast_tt(vs_index* idx, const FastArgs& a, size_t lds, uint32_t* resident) {
     static bool attr_set = false;
     if (!attr_set) {
         VS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_search_fast<NCH, VR, TIMING, MINW, BUILD, FULL, VG>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_search_fast<NCH, VR, TIMING, MINW, BUILD, FULL, VG>), dim3(a.s.nq), dim3(WAVE), lds, idx->ctx->stream, a);
+    if (resident) {  // not a launch: how many scans (= single-wave workgroups) of this instantiation does the device hold at once?
+        int per_cu = 0;
+        VS_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_search_fast<NCH, VR, TIMING, MINW, BUILD, FULL, VG>, WAVE, lds));
+        *resident = (uint32_t)std::max(per_cu, 1) * (uint32_t)idx->ctx->prop.multiProcessorCount;
+        return VS_OK;
+    }
+    const uint32_t grid = a.s.persist ? std::min<uint32_t>(a.s.persist, a.s.nq) : a.s.nq;
+    hipLaunchKernelGGL((k_search_fast<NCH, VR, TIMING, MINW, BUILD, FULL, VG>), dim3(grid), dim3(WAVE), lds, idx->ctx->stream, a);
     VS_HIP(hipGetLastError());
     return VS_OK;
 }
 
 template <int NCH>
-static int launch_fast_t(vs_index* idx, const FastArgs& a, size_t lds) {
+static int launch_fast_t(vs_index* idx, const FastArgs& a, size_t lds, uint32_t* res) {
     if (a.s.build) {
         VS_REQUIRE(a.s.vr == 0 && !a.s.phase, "build-mode search uses the LDS-ring visited list");
-        return launch_fast_tt<NCH, 0, false, 1, true>(idx, a, lds);
+        return launch_fast_tt<NCH, 0, false, 1, true>(idx, a, lds, res);
     }
     if (a.s.phase) {
         VS_REQUIRE(NCH == 3, "VS_PHASE diagnostics are built for 17..24-word codes only");
-        if (a.s.vr == 8) return launch_fast_tt<3, 8, true, 1, false>(idx, a, lds);
-        return launch_fast_tt<3, 0, true, 1, false>(idx, a, lds);
+        if (a.s.vr == 8) return launch_fast_tt<3, 8, true, 1, false>(idx, a, lds, res);
+        return launch_fast_tt<3, 0, true, 1, false>(idx, a, lds, res);
     }
     if (a.s.vwords) {  // written-bucket bitmap in LDS instead of cleared tables (table-less regime, LDS-ring visited list)
         VS_REQUIRE(a.s.vr == 0 && a.s.lh == 0 && a.s.epoch == 0 && (uint64_t)a.s.vwords * 128 >= a.s.gcap,
                    "fast search: the written-bucket bitmap needs the table-less regime with plain ids and one bit per bucket");
         const bool plain = !a.s.qlabel_off && !a.s.visible && !(a.s.flags & FAST_FULL_VARIANT);
-        if (NCH == 3 && a.s.minw == 6 && plain) return launch_fast_tt<3, 0, false, 6, false, false, true>(idx, a, lds);
-        if (NCH == 3 && a.s.minw == 6) return launch_fast_tt<3, 0, false, 6, false, true, true>(idx, a, lds);
-        if (NCH == 3 && a.s.minw == 5 && plain) return launch_fast_tt<3, 0, false, 5, false, false, true>(idx, a, lds);
-        if (NCH == 3 && a.s.minw == 5) return launch_fast_tt<3, 0, false, 5, false, true, true>(idx, a, lds);
-        return launch_fast_tt<NCH, 0, false, 1, false, true, true>(idx, a, lds);
+        if (NCH == 3 && a.s.minw == 6 && plain) return launch_fast_tt<3, 0, false, 6, false, false, true>(idx, a, lds, res);
+        if (NCH == 3 && a.s.minw == 6) return launch_fast_tt<3, 0, false, 6, false, true, true>(idx, a, lds, res);
+        if (NCH == 3 && a.s.minw == 5 && plain) return launch_fast_tt<3, 0, false, 5, false, false, true>(idx, a, lds, res);
+        if (NCH == 3 && a.s.minw == 5) return launch_fast_tt<3, 0, false, 5, false, true, true>(idx, a, lds, res);
+        return launch_fast_tt<NCH, 0, false, 1, false, true, true>(idx, a, lds, res);
     }
     if (a.s.vr == 8) {
         if (NCH == 3) {  // the headline geometry (768 x 2 bit, 1536 x 1 bit): register-capped variants for the occupancy-bound regime
-            if (a.s.minw == 4) return launch_fast_tt<3, 8, false, 4, false>(idx, a, lds);
-            if (a.s.minw == 5) return launch_fast_tt<3, 8, false, 5, false>(idx, a, lds);
-            if (a.s.minw == 6) return launch_fast_tt<3, 8, false, 6, false>(idx, a, lds);
+            if (a.s.minw == 4) return launch_fast_tt<3, 8, false, 4, false>(idx, a, lds, res);
+            if (a.s.minw == 5) return launch_fast_tt<3, 8, false, 5, false>(idx, a, lds, res);
+            if (a.s.minw == 6) return launch_fast_tt<3, 8, false, 6, false>(idx, a, lds, res);
         }
-        return launch_fast_tt<NCH, 8, false, 1, false>(idx, a, lds);
+        return launch_fast_tt<NCH, 8, false, 1, false>(idx, a, lds, res);
     }
     if (NCH == 3) {
         const bool plain = !a.s.qlabel_off && !a.s.visible && !(a.s.flags & FAST_FULL_VARIANT);  // no label keys, no visibility mask
-        if (a.s.minw == 5 && plain) return launch_fast_tt<3, 0, false, 5, false, false>(idx, a, lds);
-        if (a.s.minw == 5) return launch_fast_tt<3, 0, false, 5, false>(idx, a, lds);
-        if (a.s.minw == 6 && plain) return launch_fast_tt<3, 0, false, 6, false, false>(idx, a, lds);
-        if (a.s.minw == 6) return launch_fast_tt<3, 0, false, 6, false>(idx, a, lds);
-        if (a.s.minw == 7) return launch_fast_tt<3, 0, false, 7, false>(idx, a, lds);
-        if (a.s.minw == 8) return launch_fast_tt<3, 0, false, 8, false>(idx, a, lds);
+        if (a.s.minw == 5 && plain) return launch_fast_tt<3, 0, false, 5, false, false>(idx, a, lds, res);
+        if (a.s.minw == 5) return launch_fast_tt<3, 0, false, 5, false>(idx, a, lds, res);
+        if (a.s.minw == 6 && plain) return launch_fast_tt<3, 0, false, 6, false, false>(idx, a, lds, res);
+        if (a.s.minw == 6) return launch_fast_tt<3, 0, false, 6, false>(idx, a, lds, res);
+        if (a.s.minw == 7) return launch_fast_tt<3, 0, false, 7, false>(idx, a, lds, res);
+        if (a.s.minw == 8) return launch_fast_tt<3, 0, false, 8, false>(idx, a, lds, res);
     }
-    return launch_fast_tt<NCH, 0, false, 1, false>(idx, a, lds);
+    return launch_fast_tt<NCH, 0, false, 1, false>(idx, a, lds, res);
 }
 
-int launch_search_fast(vs_index* idx, const FastLaunch& s) {
-    if (s.nq == 0) return VS_OK;
+static int fast_dispatch(vs_index* idx, const FastLaunch& s, uint32_t* res) {
     FastArgs a;
     a.codes = idx->codes;
     a.nbrs = idx->nbrs;
@@ -1438,12 +1476,22 @@ int launch_search_fast(vs_index* idx, const FastLaunch& s) {
                "fast search: bad dedup table / spill geometry");
     const uint32_t nch = (idx->code_stride + 7) / 8;
     switch (nch) {
-        case 1: return launch_fast_t<1>(idx, a, lds);
-        case 2: return launch_fast_t<2>(idx, a, lds);
-        case 3: return launch_fast_t<3>(idx, a, lds);
-        case 4: return launch_fast_t<4>(idx, a, lds);
+        case 1: return launch_fast_t<1>(idx, a, lds, res);
+        case 2: return launch_fast_t<2>(idx, a, lds, res);
+        case 3: return launch_fast_t<3>(idx, a, lds, res);
+        case 4: return launch_fast_t<4>(idx, a, lds, res);
         case 5:
-        case 6: return launch_fast_t<6>(idx, a, lds);
-        default: return launch_fast_t<0>(idx, a, lds);
+        case 6: return launch_fast_t<6>(idx, a, lds, res);
+        default: return launch_fast_t<0>(idx, a, lds, res);
     }
 }
+
+int launch_search_fast(vs_index* idx, const FastLaunch& s) {
+    if (s.nq == 0) return VS_OK;
+    VS_REQUIRE(!s.persist || (s.scan_counter && s.pool_slots >= std::min(s.persist, s.nq) && !s.epoch),
+               "fast search: a persistent grid needs a scan counter, one region per workgroup and plain (untagged) dedup entries");
+    return fast_dispatch(idx, s, nullptr);
+}
+
+// scans of the instantiation `s` selects that are resident on the device at once (the size of a persistent grid)
+int fast_resident_scans(vs_index* idx, const FastLaunch& s, uint32_t* out) { return fast_dispatch(idx, s, out); }

@@ -159,6 +159,9 @@ static inline T emu_shfl(T v, int from, const char* f, int l) {
 #define __popcll(x) __builtin_popcountll((unsigned long long)(x))
 #define __popc(x) __builtin_popcount((unsigned)(x))
 #define __builtin_readcyclecounter() ((uint64_t)__rdtsc())
+static inline uint64_t wall_clock64() {  // 100 MHz on the device
+    return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() / 10u;
+}
 #define __builtin_nontemporal_load(p) (*(p))
 #define __HIP_MEMORY_SCOPE_AGENT 4
 #define __HIP_MEMORY_SCOPE_WAVEFRONT 2
@@ -265,6 +268,9 @@ static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t
     return hipSuccess;
 }
 static inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
+// two workgroups per "CU": a persistent grid of 8 workgroups, so every workgroup of a test batch runs several scans
+template <class K>
+static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, K, int, size_t) { *n = 2; return hipSuccess; }
 
 // ---- kernel launch ---------------------------------------------------------------------------------------------------
 namespace emu {

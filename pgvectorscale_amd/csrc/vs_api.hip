@@ -254,6 +254,34 @@ extern "C" int vs_dev_download(vs_ctx* c, void* dst, const void* src, size_t byt
     return VS_OK;
 }
 
+// D2H through the pinned ring WITHOUT waiting for the compute stream: the caller has already synchronised with the kernels that
+// produced `src`, and later launches on the compute stream (the next chunk of a pipelined batch) do not touch it
+static int download_async_rows(vs_ctx* c, void* dst, const void* src, size_t bytes) {
+    char* d = static_cast<char*>(dst);
+    const char* s = static_cast<const char*>(src);
+    size_t off = 0;
+    int slot = 0;
+    size_t pend_off[2] = {0, 0}, pend_n[2] = {0, 0};
+    while (off < bytes || pend_n[0] || pend_n[1]) {
+        if (pend_n[slot]) {
+            VS_HIP(hipEventSynchronize(c->pinned_ev[slot]));
+            stage_copy(d + pend_off[slot], c->pinned[slot], pend_n[slot]);
+            pend_n[slot] = 0;
+        }
+        if (off < bytes) {
+            const size_t n = std::min(c->pinned_bytes, bytes - off);
+            VS_HIP(hipEventSynchronize(c->pinned_ev[slot]));
+            VS_HIP(hipMemcpyAsync(c->pinned[slot], s + off, n, hipMemcpyDeviceToHost, c->copy_stream));
+            VS_HIP(hipEventRecord(c->pinned_ev[slot], c->copy_stream));
+            pend_off[slot] = off;
+            pend_n[slot] = n;
+            off += n;
+        }
+        slot ^= 1;
+    }
+    return VS_OK;
+}
+
 // strided upload: host rows of `row_bytes` into device rows of `dev_row_bytes` (zero padded)
 static int upload_rows(vs_ctx* c, void* dst, size_t dev_row_bytes, const void* src, size_t host_row_bytes,
                        size_t copy_bytes, size_t rows) {
@@ -373,7 +401,7 @@ extern "C" void vs_index_free(vs_index* ix) {
             if (p) (void)hipFree(p);
     }
     SearchWorkspace& w = ix->ws;
-    DevBuf* bufs[] = {&w.q_full, &w.qcodes, &w.qlabels, &w.qlabel_off, &w.hash, &w.heap_g, &w.heap_g4, &w.ghash4, &w.heap_g4b, &w.ghash4b, &w.pool_ctr, &w.fb_flag, &w.phase, &w.timeline, &w.stream_ids,
+    DevBuf* bufs[] = {&w.q_full, &w.qcodes, &w.qlabels, &w.qlabel_off, &w.hash, &w.heap_g, &w.heap_g4, &w.ghash4, &w.heap_g4b, &w.ghash4b, &w.pool_ctr, &w.fb_flag, &w.phase, &w.timeline, &w.raw_q2, &w.out_ids2, &w.out_tids2, &w.out_dist2, &w.stream_ids,
                       &w.stream_ham, &w.stream_cnt, &w.stats, &w.status, &w.rr_dist, &w.out_ids, &w.out_tids,
                       &w.out_dist, &w.resort_heap, &w.raw_q, &w.misc, &w.q_index};
     for (DevBuf* b : bufs) devbuf_free(*b);
@@ -1409,19 +1437,58 @@ static int search_host(vs_index* ix, const float* queries, const int16_t* qlabel
     const int16_t* d_labels_all = nullptr;
     const uint32_t* d_off_all = nullptr;
     VS_TRY(upload_label_keys(ix, qlabels, qlabel_off, nq, &d_labels_all, &d_off_all));
-    const uint32_t chunk = chunk_queries(ix, caps, M, nq);
-    for (uint32_t q0 = 0; q0 < nq; q0 += chunk) {
-        const uint32_t cq = std::min(chunk, nq - q0);
-        VS_TRY(devbuf_reserve(c, w.raw_q, (size_t)cq * ix->d.dim_full * 4));
-        VS_TRY(vs_dev_upload(c, w.raw_q.p, queries + (size_t)q0 * ix->d.dim_full, (size_t)cq * ix->d.dim_full * 4));
-        VS_TRY(devbuf_reserve(c, w.out_ids, (size_t)cq * k * 4));
-        VS_TRY(devbuf_reserve(c, w.out_tids, (size_t)cq * k * 8));
-        VS_TRY(devbuf_reserve(c, w.out_dist, (size_t)cq * k * 4));
-        BatchPlan bp{cq, L, rescore, k, M, stream_only};
+    // Chunks of the batch run as a pipeline: while the device searches chunk i the host stages chunk i + 1 into the pinned ring and
+    // hipMemcpyAsync moves it (copy stream), and the rows of chunk i - 1 go back to the caller — the PCIe time of a call is the
+    // first chunk's way in and the last chunk's way out.  A batch that fits one launch is still cut into a few chunks when it is
+    // large enough for that to pay (VS_HOST_CHUNKS: chunks to aim for, default 4; chunks of fewer than 32 768 scans do not fill
+    // the device for long enough).  The query keys (AM/scan.rs:336-367) arrive on the host; nothing else does.
+    uint32_t chunk = chunk_queries(ix, caps, M, nq);
+    {
+        const uint32_t want = std::max<uint32_t>(env_u32("VS_HOST_CHUNKS", 4), 1);
+        const uint32_t floor_q = env_u32("VS_HOST_CHUNK_MIN", 32768);
+        const uint32_t piece = std::max<uint32_t>((nq + want - 1) / want, floor_q);
+        chunk = std::min(chunk, std::max<uint32_t>(piece, 1));
+    }
+    const size_t qrow = (size_t)ix->d.dim_full * 4;
+    DevBuf* rawq[2] = {&w.raw_q, &w.raw_q2};
+    DevBuf* oids[2] = {&w.out_ids, &w.out_ids2};
+    DevBuf* otids[2] = {&w.out_tids, &w.out_tids2};
+    DevBuf* odist[2] = {&w.out_dist, &w.out_dist2};
+    const uint32_t nchunks = (nq + chunk - 1) / chunk;
+    auto cq_of = [&](uint32_t ci) { return std::min(chunk, nq - ci * chunk); };
+    auto stage_in = [&](uint32_t ci) -> int {
+        const uint32_t cq = cq_of(ci);
+        VS_TRY(devbuf_reserve(c, *rawq[ci & 1], (size_t)chunk * qrow));
+        return vs_dev_upload(c, rawq[ci & 1]->p, queries + (size_t)ci * chunk * ix->d.dim_full, (size_t)cq * qrow);
+    };
+    auto launch = [&](uint32_t ci, BatchPlan& bp) -> int {
+        const uint32_t cq = cq_of(ci), q0 = ci * chunk;
+        VS_TRY(devbuf_reserve(c, *oids[ci & 1], (size_t)chunk * k * 4));
+        VS_TRY(devbuf_reserve(c, *otids[ci & 1], (size_t)chunk * k * 8));
+        VS_TRY(devbuf_reserve(c, *odist[ci & 1], (size_t)chunk * k * 4));
+        bp = BatchPlan{cq, L, rescore, k, M, stream_only};
         // label CSR offsets are absolute into d_labels_all, so a chunk just offsets the off pointer
-        VS_TRY(run_search_chunk(ix, bp, (const float*)w.raw_q.p, d_labels_all, d_off_all ? d_off_all + q0 : nullptr,
-                                (uint32_t*)w.out_ids.p, (uint64_t*)w.out_tids.p, (float*)w.out_dist.p, caps, true, stats));
-        VS_TRY(collect_stats(ix, cq, M, rescore, stream_only, stats, L));
+        return run_search_chunk(ix, bp, (const float*)rawq[ci & 1]->p, d_labels_all, d_off_all ? d_off_all + q0 : nullptr,
+                                (uint32_t*)oids[ci & 1]->p, (uint64_t*)otids[ci & 1]->p, (float*)odist[ci & 1]->p, caps, false, stats);
+    };
+    // the scans of a launch that outgrew every pool are re-run (synchronously, growing capacities) and the window is redone
+    auto finish = [&](uint32_t ci, const BatchPlan& bp) -> int {
+        const uint32_t q0 = ci * chunk;
+        std::vector<uint32_t> status(bp.nq);
+        VS_HIP(hipMemcpyAsync(status.data(), w.status.p, (size_t)bp.nq * 4, hipMemcpyDeviceToHost, c->stream));
+        VS_HIP(hipStreamSynchronize(c->stream));
+        uint32_t ovf = 0;
+        for (uint32_t v : status) ovf |= v;
+        if (ovf) {
+            VS_TRY(retry_failed_scans(ix, bp, d_labels_all, d_off_all ? d_off_all + q0 : nullptr, caps, stats));
+            VS_TRY(run_post_search(ix, bp, (uint32_t*)oids[ci & 1]->p, (uint64_t*)otids[ci & 1]->p, (float*)odist[ci & 1]->p));
+            VS_HIP(hipStreamSynchronize(c->stream));  // (stage_out does not wait for the compute stream)
+        }
+        return collect_stats(ix, bp.nq, M, rescore, stream_only, stats, L);
+    };
+    // a stream-only chunk hands back the workspace's own stream arrays: they go out before the next launch overwrites them
+    auto stage_out = [&](uint32_t ci) -> int {
+        const uint32_t cq = cq_of(ci), q0 = ci * chunk;
         if (stream_only) {
             VS_TRY(vs_dev_download(c, out_ids + (size_t)q0 * k, w.stream_ids.p, (size_t)cq * k * 4));
             if (out_ham) {
@@ -1434,11 +1501,23 @@ static int search_host(vs_index* ix, const float* queries, const int16_t* qlabel
                             out_ham[i] = (uint32_t)b;
                         }
             }
-        } else {
-            VS_TRY(vs_dev_download(c, out_ids + (size_t)q0 * k, w.out_ids.p, (size_t)cq * k * 4));
-            if (out_tids) VS_TRY(vs_dev_download(c, out_tids + (size_t)q0 * k, w.out_tids.p, (size_t)cq * k * 8));
-            if (out_dist) VS_TRY(vs_dev_download(c, out_dist + (size_t)q0 * k, w.out_dist.p, (size_t)cq * k * 4));
+            return VS_OK;
         }
+        VS_TRY(download_async_rows(c, out_ids + (size_t)q0 * k, oids[ci & 1]->p, (size_t)cq * k * 4));
+        if (out_tids) VS_TRY(download_async_rows(c, out_tids + (size_t)q0 * k, otids[ci & 1]->p, (size_t)cq * k * 8));
+        if (out_dist) VS_TRY(download_async_rows(c, out_dist + (size_t)q0 * k, odist[ci & 1]->p, (size_t)cq * k * 4));
+        return VS_OK;
+    };
+    BatchPlan bp_cur{}, bp_next{};
+    VS_TRY(stage_in(0));
+    VS_TRY(launch(0, bp_cur));
+    for (uint32_t ci = 0; ci < nchunks; ++ci) {
+        if (ci + 1 < nchunks) VS_TRY(stage_in(ci + 1));  // (the device is busy with chunk ci)
+        VS_TRY(finish(ci, bp_cur));
+        if (stream_only) VS_TRY(stage_out(ci));
+        if (ci + 1 < nchunks) VS_TRY(launch(ci + 1, bp_next));
+        if (!stream_only) VS_TRY(stage_out(ci));  // (... and with chunk ci + 1 while these rows travel)
+        bp_cur = bp_next;
     }
     if (stats) ix->last_stats = *stats;
     return VS_OK;

@@ -98,7 +98,8 @@ struct SearchWorkspace {
     uint32_t ghash4_epoch = 0;   // epoch of the last launch on ghash4 (0: the array must be zeroed before the next tagged launch)
     uint32_t ghash4_eshift = 0;  // id bits the tags in ghash4 were written with
     DevBuf q_full, qcodes, qlabels, qlabel_off, hash, heap_g, heap_g4, ghash4, heap_g4b, ghash4b, pool_ctr, fb_flag, phase, timeline, stream_ids, stream_ham, stream_cnt, stats, status,
-        rr_dist, out_ids, out_tids, out_dist, resort_heap, raw_q, misc, q_index;
+        rr_dist, out_ids, out_tids, out_dist, resort_heap, raw_q, misc, q_index,
+        raw_q2, out_ids2, out_tids2, out_dist2;  // second set of a pipelined host batch (search_host)
     // pending async call (vs_search_batch_dev)
     bool fb_valid = false;  // fb_flag holds the fallback marks of the last chunk
     bool pending = false;

@@ -31,6 +31,8 @@ def main():
                     help="experiment: order of the queries inside the batch — as generated, sorted by the cluster they were drawn "
                          "from (scans that run at the same time touch the same part of the graph), or sorted and dealt to the 8 XCDs "
                          "by cluster (block b runs on XCD b %% 8)")
+    ap.add_argument("--host", default=None, help="also time the host-buffer entry point (vs_search_batch: PCIe inclusive) over all --nq queries "
+                                                 "under these ','-separated configs, e.g. VS_HOST_CHUNKS=1,VS_HOST_CHUNKS=4")
     ap.add_argument("--lib", default=None, help="time this libvsgpu build instead of pgvectorscale_amd/libvsgpu.so (scripts/ab_branch.sh)")
     args = ap.parse_args()
     import numpy as np
@@ -91,6 +93,8 @@ def main():
                 k_, v_ = kv.split("=")
                 if k_ == "VARIANT":
                     ix.set_variant(v_)
+                elif k_ == "NQ":  # scans per launch of this and the following configs (<= --nq)
+                    nq = min(int(v_), args.nq)
                 else:
                     os.environ[k_] = v_
         ctx.profile_enable(True)
@@ -103,8 +107,8 @@ def main():
             st = ix.search_batch_dev_finish()
         wall = (time.perf_counter() - t0) / args.reps
         prof = ctx.profile_read(reset=True)
-        ids = ctx.download(out, np.empty((nq, k), np.uint32))
-        same = "ref" if ref_ids is None else str(bool((ids == ref_ids).all()))
+        ids = ctx.download(out, np.empty((args.nq, k), np.uint32))[:nq]
+        same = "ref" if ref_ids is None else str(bool((ids == ref_ids[:nq]).all()))
         if ref_ids is None:
             ref_ids = ids
         ms = prof["search"][0] / max(prof["search"][1], 1)
@@ -114,6 +118,23 @@ def main():
               f"{prof['rerank'][0] / prof['rerank'][1]:.3f} ms  wall {wall * 1e3:8.3f} ms "
               f"-> {nq / wall:10.0f} QPS  {bytes_ / (ms + fb) / 1e6:7.1f} GB/s alg  visits/q {st['visited_nodes'] / nq:.1f} "
               f"dq/q {st['quantized_distance_comparisons'] / nq:.1f}  same_ids={same}", flush=True)
+    if args.host:
+        qh = ctx.download(q, np.empty((args.nq, args.dim), np.float32))
+        ref = None
+        for cfg in args.host.split(","):
+            for kv in cfg.split(":"):
+                if kv:
+                    k_, v_ = kv.split("=")
+                    os.environ[k_] = v_
+            ix.search_batch(qh, search_list_size=args.L, rescore=args.rescore, k=k)
+            t0 = time.perf_counter()
+            for _ in range(args.reps):
+                hi, _, hd, _ = ix.search_batch(qh, search_list_size=args.L, rescore=args.rescore, k=k)
+            wall = (time.perf_counter() - t0) / args.reps
+            same = "ref" if ref is None else str(bool((hi == ref).all()))
+            if ref is None:
+                ref = hi
+            print(f"host {cfg:35s}: wall {wall * 1e3:8.3f} ms -> {args.nq / wall:10.0f} QPS (PCIe inclusive)  same_ids={same}", flush=True)
     if args.scan:
         os.environ.setdefault("VS_SCAN_Q", "4")
         rng = np.random.default_rng(1)

@@ -34,6 +34,17 @@ REGIMES = {
     "second_attempt": {"VS_F_LDS_MAX_INS": "0", "VS_F_GCAP": "1024"},
     # ... or, with that attempt switched off, by the general kernel
     "second_attempt_off": {"VS_F_LDS_MAX_INS": "0", "VS_F_GCAP": "1024", "VS_F_RETRY": "0"},
+    # one workgroup per scan instead of the persistent grid (round 3's launch shape; second attempts and the build still use it)
+    "one_wg_per_scan": {"VS_F_PERSIST": "0"},
+    "tableless_one_wg_per_scan": {"VS_F_LDS_MAX_INS": "0", "VS_F_PERSIST": "0"},
+    "tableless_virgin_one_wg_per_scan": {"VS_F_LDS_MAX_INS": "0", "VS_F_VIRGIN": "1", "VS_F_PERSIST": "0"},
+    # a persistent grid smaller than the device holds (here: half of the interpreter's eight workgroups): more scans per workgroup
+    "persist_half": {"VS_F_LDS_MAX_INS": "0", "VS_F_PERSIST_PCT": "50"},
+    # host batches cut into chunks that run as a pipeline (stage in chunk i + 1 / search chunk i / rows of chunk i - 1 out): four
+    # even chunks, three uneven ones, and uneven chunks whose scans outgrow the first attempt's tables (the re-run of a chunk)
+    "host_chunks_4": {"VS_HOST_CHUNK_MIN": "20", "VS_HOST_CHUNKS": "4"},
+    "host_chunks_uneven": {"VS_HOST_CHUNK_MIN": "36"},
+    "host_chunks_second_attempt": {"VS_HOST_CHUNK_MIN": "36", "VS_F_LDS_MAX_INS": "0", "VS_F_GCAP": "1024", "VS_F_RETRY": "0"},
     "general_kernel": {"VS_FAST": "0"},
     "general_kernel_spill": {"VS_FAST": "0", "VS_HL": "64", "VS_G0": "256"},
 }

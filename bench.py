@@ -331,6 +331,18 @@ def main():
 
     ctx = P.Context(0 if EMU else local_rank)
     log("device:", ctx.device_name())
+    comm = None
+    if world > 1:
+        # N > 1: the data path runs behind the C ABI — vs_comm_* (RCCL over xGMI, loaded by libvsgpu itself) replicates the graph and
+        # gathers the top-k blocks; torch.distributed only carries the launcher's control plane (this id, barriers, the timing
+        # reductions).  CPU dry runs (VS_EMU) join the ranks with the stand-in RCCL of the test tier.
+        import torch.distributed as dist
+        from pgvectorscale_amd import multi as PM
+        if EMU:
+            os.environ.setdefault("VS_RCCL_LIB", os.path.join(ROOT, "tests", "emu", "libfakerccl.so"))
+        uid = [PM.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        comm = PM.Comm(ctx, uid[0], rank, world)
     dt = {"l2": P.VS_L2, "cosine": P.VS_COSINE, "ip": P.VS_IP}[args.distance]
     n, dim, k = args.n, args.dim, args.k
     R = 50
@@ -395,10 +407,8 @@ def main():
             setup["graph_build_s"] = round(time.time() - t0, 3)
         t1 = time.time()
         nptr, nstride = ix.array(_lib.ARR_NBRS)
-        nb = _dev_tensor(torch, np, nptr.value, (n, nstride), dev, "<i4")
-        dist.broadcast(nb, src=0)
-        torch.cuda.synchronize()
-        del nb
+        comm.bcast(nptr, n * nstride * 4, 0)  # vs_comm_bcast: ncclBroadcast HBM -> HBM
+        ctx.sync()
         if rank != 0:
             ix.set_start_nodes(0)
         setup["graph_broadcast_s"] = round(time.time() - t1, 3)
@@ -555,7 +565,16 @@ def main():
         ctx.sync()
         torch.cuda.synchronize()
 
-    from pgvectorscale_amd.sharding import gather_topk
+    # final top-k gather (the only collective on this path): vs_comm_gather_topk = one grouped ncclAllGather of the id and distance
+    # blocks, enqueued on the context's stream behind the search that produced them; every rank ends a step with all world * nq rows
+    gathered = None
+    if world > 1:
+        gathered = (torch.empty((world * nq, k), dtype=torch.int32, device=dev), torch.empty((world * nq, k), dtype=torch.float32, device=dev))
+
+    def gather_topk(oi, od):
+        n_ = oi.shape[0]
+        comm.gather_topk(C.c_void_p(oi.data_ptr()), C.c_void_p(od.data_ptr()), n_, world * n_, k, C.c_void_p(gathered[0].data_ptr()),
+                         C.c_void_p(gathered[1].data_ptr()))
 
     def step(b):
         ix.search_batch_dev(qbuf[b], nq, L, S, k, C.c_void_p(out_ids.data_ptr()), None, C.c_void_p(out_dist.data_ptr()),
@@ -578,6 +597,11 @@ def main():
             out_ids, out_dist = out_ids[:nq], out_dist[:nq]
             nh = min(nh, nq)
             log(f"{e}; continuing with {nq} scans per step")
+    if world > 1:  # (once, untimed) the gathered block holds this rank's rows at this rank's place
+        ctx.sync()
+        torch.cuda.synchronize()
+        assert torch.equal(gathered[0][rank * nq:(rank + 1) * nq], out_ids) and \
+            torch.equal(gathered[1][rank * nq:(rank + 1) * nq].view(torch.int32), out_dist.view(torch.int32)), "top-k gather misplaced a shard"
 
     # --pipeline 2: two batches in flight — even steps through the index, odd steps through a view of it on a second context
     # (stream), each with its own output block; a step is collected after the next one has been submitted, so the bandwidth-bound
@@ -873,6 +897,7 @@ def main():
                    "labels": NL, "n": n, "dim": dim, "bits": bits, "words": W,
                    "num_neighbors": R, "queries_per_step_per_gpu": nq, "search_list_size": L, "rescore": S, "k": k,
                    "parallelism": f"query-sharded x{world}, index replicated" if world > 1 else "single GPU",
+                   "topk_gather": "vs_comm_gather_topk (libvsgpu C ABI: one grouped ncclAllGather of the id + distance blocks per step)" if world > 1 else None,
                    "batches_in_flight": args.pipeline},
         "recall_at_k": round(recall, 4),
         "recall_validate": round(recall_validate, 4),
@@ -983,6 +1008,8 @@ def main():
     if pipe["ready"]:
         pipe["ix2"].close()
         pipe["ctx2"].close()
+    if comm is not None:
+        comm.close()
     ix.close()
     ctx.close()
     if world > 1:

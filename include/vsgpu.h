@@ -549,6 +549,57 @@ int vs_shm_client_end_scan(vs_shm_client* c, uint64_t scan_id);
 int vs_shm_server_snapshot_put(vs_shm_server* s, uint32_t snapshot, const uint8_t* visible);
 void vs_shm_client_close(vs_shm_client* c);
 
+/* ---- multi-GPU (BASELINE.json north_star: "query batches shard embarrassingly across the 8 GPUs of one node
+ * with RCCL over xGMI used only for a final top-k gather").  The reference has nothing to mirror here — AM/mod.rs:63
+ * amcanparallel = false, one backend runs one scan (AM/scan.rs:308-456) — so this is the seam a PGRX host binds when one
+ * PostgreSQL instance fronts several devices.  The path shards by QUERY: every device holds the whole index, device g takes a
+ * contiguous block of the batch (vs_shard_range), no collective touches the data path, one gather of the [nq][k] blocks ends
+ * the step.  Two deployments, neither needs torch:
+ *   vs_multi_*  ONE process owns N devices (a broker / background worker): the index is replicated device to device
+ *               (hipMemcpyPeerAsync over xGMI: one build or upload, N - 1 copies), one host thread per device runs its shard of a
+ *               host batch and writes its rows into the caller's buffers at the shard's offset.
+ *   vs_comm_*   one PROCESS per device: RCCL (ncclAllGather of the id / distance blocks; ncclBroadcast to replicate an index
+ *               from the rank that holds it).  librccl is dlopen'ed by the first vs_comm_* call (VS_RCCL_LIB overrides the
+ *               name); the 128-byte communicator id travels between the processes by the host's own means. */
+int vs_shard_range(uint32_t nq_total, uint32_t world, uint32_t rank, uint32_t* begin, uint32_t* end); /* blocks differ by <= 1 */
+/* a full copy of `src` (arrays, quantizer, label sets + start map, visibility masks) on dst_ctx's device, device to device;
+ * the copy is an ordinary index (vs_index_free).  Works between two contexts of one device as well. */
+int vs_index_replicate(vs_index* src, vs_ctx* dst_ctx, vs_index** out);
+
+typedef struct vs_multi vs_multi;
+#define VS_MULTI_COPY_ALWAYS 1u /* also the source's own device gets a replica instead of a view of the source's arrays */
+/* one context + one copy of `src` per entry of devices[] (the first entry naming src's own device reads src's arrays through
+ * a view; src must outlive the vs_multi and must not be mutated while it exists) */
+int vs_multi_create(vs_index* src, const int* devices, uint32_t n_devices, uint32_t flags, vs_multi** out);
+uint32_t vs_multi_size(const vs_multi* m);
+vs_index* vs_multi_index(vs_multi* m, uint32_t i); /* shard i's index / context: device-resident work is driven per device */
+vs_ctx* vs_multi_ctx(vs_multi* m, uint32_t i);
+/* vs_search_batch / vs_stream_batch over all devices: same arguments, same rows in the same order as one device returns for the
+ * whole batch (scans are independent); stats are summed over the shards */
+int vs_multi_search_batch(vs_multi* m, const float* queries, const int16_t* qlabels, const uint32_t* qlabel_off, uint32_t nq,
+                          uint32_t search_list_size, uint32_t rescore, uint32_t k, uint32_t* out_ids, uint64_t* out_tids,
+                          float* out_dist, vs_stats* stats);
+int vs_multi_stream_batch(vs_multi* m, const float* queries, const int16_t* qlabels, const uint32_t* qlabel_off, uint32_t nq,
+                          uint32_t search_list_size, uint32_t mrows, uint32_t* out_ids, uint32_t* out_ham, vs_stats* stats);
+void vs_multi_destroy(vs_multi* m);
+
+typedef struct vs_comm vs_comm;
+#define VS_COMM_ID_BYTES 128
+int vs_comm_unique_id(uint8_t* id /* [VS_COMM_ID_BYTES] */);  /* one rank calls it (ncclGetUniqueId), every rank gets the bytes */
+int vs_comm_create(vs_ctx* ctx, const uint8_t* id, uint32_t rank, uint32_t world, vs_comm** out); /* collective: ncclCommInitRank */
+uint32_t vs_comm_rank(const vs_comm* c);
+uint32_t vs_comm_world(const vs_comm* c);
+/* the final top-k gather: this rank's device-resident [nq_local][k] blocks -> [nq_total][k] on every rank, shards in rank order
+ * (nq_local must be this rank's vs_shard_range of nq_total; d_dist / d_out_dist may both be NULL).  Enqueued on ctx's stream
+ * behind the search that produced the blocks (vs_search_batch_dev); vs_ctx_sync completes it.  No host synchronisation. */
+int vs_comm_gather_topk(vs_comm* c, const uint32_t* d_ids, const float* d_dist, uint32_t nq_local, uint32_t nq_total, uint32_t k,
+                        uint32_t* d_out_ids, float* d_out_dist);
+int vs_comm_bcast(vs_comm* c, void* d_buf, size_t bytes, uint32_t root); /* one device array from root to every rank (enqueued) */
+/* every rank passes an index of the same geometry on the communicator's device (root: the built / uploaded one, the others:
+ * vs_index_alloc); on return every rank holds root's index (arrays, quantizer, label sets + masks, start map, visibility) */
+int vs_comm_replicate_index(vs_comm* c, vs_index* idx, uint32_t root);
+void vs_comm_destroy(vs_comm* c);
+
 /* ---- build-side helpers (SURVEY.md §8f "next" rows; needed to manufacture device-resident indexes) ---------- */
 /* Welford pass over rows [0,n) in heap order, bit-exact to SbqQuantizer::add_sample (AM/sbq/quantize.rs:115-148):
  * one lane per dimension, sequential over rows.  Uses the (cosine-normalised) first dim_index dims of the vectors. */

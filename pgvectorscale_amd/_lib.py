@@ -221,6 +221,23 @@ SYMBOLS = {
     "vs_shm_client_dim": (_u32, [_vp]),
     "vs_shm_client_search": (_i, [_vp, _vp, _vp, _u32, _i, _u32, _u32, _u32, _vp, _vp, _vp]),
     "vs_shm_client_close": (None, [_vp]),
+    "vs_shard_range": (_i, [_u32, _u32, _u32, C.POINTER(_u32), C.POINTER(_u32)]),
+    "vs_index_replicate": (_i, [_vp, _vp, C.POINTER(_vp)]),
+    "vs_multi_create": (_i, [_vp, C.POINTER(_i), _u32, _u32, C.POINTER(_vp)]),
+    "vs_multi_size": (_u32, [_vp]),
+    "vs_multi_index": (_vp, [_vp, _u32]),
+    "vs_multi_ctx": (_vp, [_vp, _u32]),
+    "vs_multi_search_batch": (_i, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp, C.POINTER(Stats)]),
+    "vs_multi_stream_batch": (_i, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, C.POINTER(Stats)]),
+    "vs_multi_destroy": (None, [_vp]),
+    "vs_comm_unique_id": (_i, [_vp]),
+    "vs_comm_create": (_i, [_vp, _vp, _u32, _u32, C.POINTER(_vp)]),
+    "vs_comm_rank": (_u32, [_vp]),
+    "vs_comm_world": (_u32, [_vp]),
+    "vs_comm_gather_topk": (_i, [_vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp]),
+    "vs_comm_bcast": (_i, [_vp, _vp, _sz, _u32]),
+    "vs_comm_replicate_index": (_i, [_vp, _vp, _u32]),
+    "vs_comm_destroy": (None, [_vp]),
     "vs_sbq_train": (_i, [_vp]),
     "vs_sbq_quantize_corpus": (_i, [_vp]),
     "vs_build_graph": (_i, [_vp, _u32, C.c_double, _u32, _u64]),

@@ -65,9 +65,9 @@ def test_bench_dry_run_two_batches_in_flight():
 
 
 def test_bench_two_ranks_small():
-    """DEFAULT CPU tier (about 20 s): the driver's N > 1 launch line on the interpreter with gloo standing in for RCCL — rank 0 builds
+    """DEFAULT CPU tier (about 20 s): the driver's N > 1 launch line on the interpreter (gloo for the launcher's control plane, tests/emu/libfakerccl.so for the library's vs_comm_*) — rank 0 builds
     the graph and broadcasts it, both ranks run their shard of the queries with two batches in flight (--pipeline 2), the held-out
-    recall is pooled over the ranks, one all_gather closes each step, rank 0 prints the line"""
+    recall is pooled over the ranks, one vs_comm_gather_topk closes each step, rank 0 prints the line"""
     r = subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "emu"), "-j8", "-s"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     env = dict(os.environ, VS_EMU="1", VS_EMU_THREADS="4", VS_F_LDS_MAX_INS="0")
@@ -79,6 +79,7 @@ def test_bench_two_ranks_small():
     assert r.returncode == 0, r.stderr[-3000:]
     j = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
     assert j["n_gpus"] == 2 and j["scaling"] == "weak" and "query-sharded x2" in j["config"]["parallelism"]
+    assert "vs_comm_gather_topk" in j["config"]["topk_gather"]  # the collective lives behind the C ABI (stand-in RCCL on the interpreter)
     assert j["config"]["batches_in_flight"] == 2 and j["steps"] == 2
     assert "graph_build_s" in j["setup_s"] and "graph_broadcast_s" in j["setup_s"]  # rank 0 built, the others received
     assert j["recall_heldout_queries"] == 32  # 16 per rank, pooled

@@ -1117,8 +1117,25 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
         const bool want_epoch = caps.f_lh == 0 && knob_u32("VS_F_EPOCH", ix->tune.epoch, 0);
         // written-bucket bitmap (VS_F_VIRGIN=1, table-less regime): 128 slots of the table per LDS word; tables of more than
         // 64 Ki slots keep the clear (the bitmap would cost occupancy)
-        if (caps.f_lh == 0 && !want_epoch && !f.vr && knob_u32("VS_F_VIRGIN", ix->tune.virgin, 0) && !env_u32("VS_PHASE", 0) && f.gcap <= (1u << 16))
+        // ... or (VS_F_VIRGIN=2) one bit per SLOT: linear probing at slot granularity with the occupancy known on chip, so most new
+        // ids are stored without a load of the table; 32 slots per LDS word — taken only while it costs no scans per CU (else the
+        // bucket bitmap runs)
+        const uint32_t vmode = knob_u32("VS_F_VIRGIN", ix->tune.virgin, 0);
+        if (caps.f_lh == 0 && !want_epoch && !f.vr && vmode && !env_u32("VS_PHASE", 0) && f.gcap <= (1u << 16)) {
             f.vwords = (f.gcap + 127) / 128;
+            if (vmode == 2 && !f.rc && f.gcap % 32 == 0) {
+                FastLaunch g = f;
+                g.vwords = f.gcap / 32;
+                g.vslot = 1;
+                uint32_t res_b = 0, res_s = 0;
+                VS_TRY(fast_resident_scans(ix, f, &res_b));
+                VS_TRY(fast_resident_scans(ix, g, &res_s));
+                if (res_s >= res_b || env_u32("VS_F_SLOTMAP_FORCE", 0)) {
+                    f.vwords = g.vwords;
+                    f.vslot = 1;
+                }
+            }
+        }
         if (env_u32("VS_PHASE", 0)) f.phase = (uint64_t*)16;  // (selects the instantiation; the buffer is set below)
         if (knob_u32("VS_F_PERSIST", ix->tune.persist, 1) && !want_epoch) {
             uint32_t res = 0;
@@ -1160,7 +1177,7 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
         VS_HIP(hipMemsetAsync(w.pool_ctr.p, 0, 64, c->stream));
         VS_TRY(devbuf_reserve(c, w.fb_flag, (size_t)nq * 4));
         VS_HIP(hipMemsetAsync(w.fb_flag.p, 0, (size_t)nq * 4, c->stream));
-        if (want_epoch && !epoch) f.vwords = 0;
+        if (want_epoch && !epoch) f.vwords = f.vslot = 0;
         f.heap_g = (uint32_t*)w.heap_g4.p;
         f.ghash = (uint32_t*)w.ghash4.p;
         f.pool_counter = (uint32_t*)w.pool_ctr.p;
@@ -1207,6 +1224,7 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
             FastLaunch r = f;
             r.epoch = 0;  // (its own, smaller table array: cleared by the few scans that run)
             r.vwords = 0;
+            r.vslot = 0;
             r.persist = 0;  // (one workgroup per scan: nearly all of them return at once; regions from the pool)
             r.timeline = nullptr;
             r.only_failed = 1;
@@ -1642,6 +1660,7 @@ static const TuneCand kTuneCands[] = {
     {"epoch_tags", 1, 0, -1, 0},            // no per-scan clear: entries carry the launch's epoch (11b.14)
     {"bucket_bitmap", 0, 1, -1, 0},         // no clear, no read of a bucket the scan has not written (11b.16)
     {"bucket_bitmap_16k", 0, 1, -1, 16384}, // ... with a sparser table (more first-touch buckets per probe, more lines)
+    {"slot_bitmap", 0, 2, -1, 0},           // occupancy bit per slot, linear probing: a new id whose home slot is free costs no load
     {"two_rows", 0, 0, 5, 0},               // two code rows per 4-lane group in flight, 5 waves per SIMD (11b.17)
     {"two_rows_epoch", 1, 0, 5, 0},
     // (gone after the MI355X measured them at 10M x 768, profiles/r03/ab_autotune_10m.json: the software-pipelined visits of 11b.18

@@ -236,6 +236,7 @@ struct FastLaunch {
     uint32_t eshift = 0;  // bits of a node id inside a tagged entry
     uint32_t persist = 0;  // != 0: persistent grid of `persist` workgroups taking scans from scan_counter; regions of heap_g / ghash are per workgroup
     uint32_t vwords = 0;  // != 0: words of the LDS bitmap of written buckets (one bit per four slots of gcap): tables are neither cleared nor read before their first write
+    uint32_t vslot = 0;   // with vwords: the bitmap has one bit per SLOT (gcap / 32 words) and the table is probed slot by slot (linear probing)
     uint32_t build = 0; // 1: greedy_search_for_build (the visited list is the output; needs vr == 0)
     uint32_t flags = 0; // FAST_* (measurement switches)
     // second attempt of the scans a first launch gave up on (bigger capacities): only scans whose status[q] != 0 run, their

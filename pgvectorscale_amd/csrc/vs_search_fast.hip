@@ -447,22 +447,30 @@ struct FastHeap {
         const uint32_t end = len;
         uint32_t root = 0, pos = 0;
         uint32_t pkey = 0;  // key of the value now stored in the parent of `root` (0 for the heap root: never moves)
+        // Rounds are cut at the LDS / spill-array boundary: a round reads the CHILDREN of its nodes, so with levels 0 .. ll1 in LDS
+        // (ll1 = 8 for a 511-entry top) the rounds are node levels 0-5, 6 .. ll1 - 1 (both LDS only) and then ll1 .. ll1 + 5 from
+        // the spill array — ONE dependent trip to memory for a heap of up to 2^(ll1 + 7) entries, where rounds of six levels each
+        // made two (6-11 straddling the boundary, then 12-17).
+        const uint32_t ll1 = 30u - (uint32_t)__builtin_clz(hl + 1u);
+        uint32_t rl = 0;  // level of `root`
         for (;;) {
-            // one 6-level subtree per iteration: lane j < 63 is the node with relative heap index j
+            const bool lds_round = all_lds || rl < ll1;
+            const uint32_t depth = lds_round && !all_lds ? min(6u, ll1 - rl) : 6u;  // node levels of this round
+            // one subtree per iteration: lane j < 63 is the node with relative heap index j
             const uint32_t aidx = ((root + 1) << lvl()) + offm1();
             const uint32_t c = 2 * aidx + 1;
-            const bool exists = aidx < end, have1 = c < end, have2 = c + 1 < end;
+            const bool exists = aidx < end && lvl() < depth, have1 = c < end, have2 = c + 1 < end;
             uint32_t le = 0, ri = 0;
-            if (have1) {
-                if (all_lds || c < hl) {
+            if (lds_round) {
+                if (exists && have1) {
                     const uint2 p = *reinterpret_cast<const uint2*>(l + c + 1);
                     le = p.x;
                     ri = p.y;
-                } else {
-                    const uint64_t p = gload64u(reinterpret_cast<const uint64_t*>(g + (c - hl)));
-                    le = (uint32_t)p;
-                    ri = (uint32_t)(p >> 32);
                 }
+            } else if (exists && have1) {
+                const uint64_t p = gload64u(reinterpret_cast<const uint64_t*>(g + (c - hl)));
+                le = (uint32_t)p;
+                ri = (uint32_t)(p >> 32);
             }
             // child += (data[child] <= data[child+1]); Reverse => right.d <= left.d picks the right child
             const bool pick = have2 && (ri >> sb) <= (le >> sb);
@@ -485,7 +493,8 @@ struct FastHeap {
                 break;
             }
             pkey = readlane_u32(cv, jd) >> sb;
-            root = 2 * ad + 1 + (uint32_t)((B >> jd) & 1ull);  // jd is on the subtree's last level: descend
+            root = 2 * ad + 1 + (uint32_t)((B >> jd) & 1ull);  // jd is on the round's last level: descend
+            rl += depth;
             if (2 * root + 1 >= end) {  // ... unless the child is a leaf (a heap of 4096..8190 entries ends every path here)
                 pos = root;
                 break;
@@ -706,7 +715,7 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 // the launch has one workgroup per scan, the workgroup's index when the grid is persistent (s.persist: as many workgroups as the
 // chip holds at once, each taking scan after scan from a counter — the regions are then reused by the scans a workgroup runs, the
 // workspace is a few hundred MB whatever the batch size, and no region is claimed with an atomic).
-template <int NCH, int VR, bool TIMING, int MINW, bool BUILD, bool FULL, bool VG>
+template <int NCH, int VR, bool TIMING, int MINW, bool BUILD, bool FULL, int VG>
 __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, const uint32_t slot) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int lane_v = threadIdx.x;
@@ -724,15 +733,20 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
     uint32_t* surv_id = lhash + s.lh;                                 // 64
     uint32_t* surv_slot = surv_id + 64;                               // 64
     uint32_t* surv_d = surv_slot + 64;                                // 64
-    uint32_t* arb = surv_d + 64;                                      // ARB_SLOTS rank counters of the global dedup table (zero between uses)
-    uint64_t* ring = reinterpret_cast<uint64_t*>(arb + ARB_SLOTS);    // vcap entries (VR == 0 only)
+    uint32_t* arb = surv_d + 64;                                      // ARB_SLOTS rank counters of the global dedup table (zero between uses; none with the slot bitmap)
+    constexpr uint32_t ARB_N = VG == 2 ? 0u : (uint32_t)ARB_SLOTS;
+    uint64_t* ring = reinterpret_cast<uint64_t*>(arb + ARB_N);        // vcap entries (VR == 0 only)
     int16_t* ql = reinterpret_cast<int16_t*>(ring + (VR > 0 ? 0 : s.vcap));  // MAX_QLABELS
     uint64_t* qc_l = reinterpret_cast<uint64_t*>(ql + MAX_QLABELS);   // code_stride words (NCH == 0 only)
     // (optional) cache of ids known to be in the dedup table: a hit answers a duplicate probe without touching the table in HBM
     uint32_t* rc = reinterpret_cast<uint32_t*>(qc_l + (NCH == 0 ? ((a.code_stride + 1u) & ~1u) : (NCH > 0 && MINW >= 6 ? 8u * (uint32_t)NCH : 0u)));
     const uint32_t rcm = s.rc - 1u;  // (s.rc: 0 or a power of two)
-    // (VG) one bit per bucket of the dedup table in HBM: set once this scan has written the bucket.  A bucket whose bit is clear is
-    // neither cleared nor read — its memory holds whatever an earlier scan left there — and counts as four empty slots
+    // (VG == 1) one bit per bucket of the dedup table in HBM: set once this scan has written the bucket.  A bucket whose bit is clear is
+    // neither cleared nor read — its memory holds whatever an earlier scan left there — and counts as four empty slots.
+    // (VG == 2) one bit per SLOT: the table is open addressing with linear probing at slot granularity, and which slots are occupied
+    // is known on chip — an id whose home slot is free is new and is stored there without a load (most new ids: the expected share
+    // is 1 - load factor), the others are compared with the occupied run that starts at their home slot (one 16-byte load per
+    // 4-slot group the run touches), a free slot is claimed with one ds_or; no clears, no rank counters
     uint32_t* vmap = rc + s.rc;  // s.vwords
 
     const int l4 = lane & 3;
@@ -758,7 +772,7 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
     for (uint32_t i = 4u * lane; i < s.lh; i += 4u * WAVE)
         *reinterpret_cast<uint4*>(lhash + i) = make_uint4(VS_EMPTY, VS_EMPTY, VS_EMPTY, VS_EMPTY);
     if (lane == 0) hp[0] = 0;  // heap sentinel
-    for (uint32_t i = lane; i < ARB_SLOTS; i += WAVE) arb[i] = 0;
+    for (uint32_t i = lane; i < ARB_N; i += WAVE) arb[i] = 0;
     for (uint32_t i = lane; i < s.rc; i += WAVE) rc[i] = VS_EMPTY;
     if (VG)
         for (uint32_t i = lane; i < s.vwords; i += WAVE) vmap[i] = 0;
@@ -943,6 +957,55 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
         nins_g += (uint32_t)__popcll(__ballot(fresh));
         return fresh;
     };
+    // ---- VG == 2: the slot bitmap.  slot_run(pos) = occupied slots in a row from pos to the end of pos's 4-slot group (0: pos is free)
+    auto slot_home = [&](uint32_t nid) -> uint32_t { return (uint32_t)(((uint64_t)hash_u32(nid ^ 0x5bd1e995u) * s.gcap) >> 32); };
+    auto slot_run = [&](uint32_t pos) -> uint32_t {
+        const uint32_t g = pos & ~3u;
+        const uint32_t rel = ((vmap[g >> 5] >> (g & 31u)) & 0xFu) >> (pos & 3u);  // bit 0 = slot pos; the bit past the group's end is clear
+        return (uint32_t)__builtin_ctz(~rel);
+    };
+    // v = the 4-slot group of pos as fetched by the caller where pre_t != 0 (pre_t = the occupied run at pos when it looked; nothing
+    // has been inserted since).  An id is only ever compared with a run as it stood when the group was loaded: a slot that was free
+    // then holds an earlier scan's leftovers.  true where the id was not present before
+    auto slot_insert = [&](uint32_t nid, bool act, uint32_t pos, uint4 v, uint32_t pre_t, uint32_t& slot_out) -> bool {
+        bool fresh = false, pend = act;
+        for (;;) {
+            wave_sync();  // every lane sees the bits claimed and the ids stored in the round before
+            uint32_t t = pre_t;
+            if (pend && !pre_t) {
+                t = slot_run(pos);
+                if (t) v = *reinterpret_cast<const uint4*>(ghash + (pos & ~3u));  // (a bit that is set: its id was stored before the bit could be seen)
+            }
+            pre_t = 0;
+            if (pend && t == 0) {
+                // a free slot ends the probe sequence: the id is new.  The lane that flips the slot's bit owns it; a lane that lost the
+                // bit to another lane of this round (another id: a neighbor list holds no id twice) moves on
+                const uint32_t bit = 1u << (pos & 31u);
+                if ((atomicOr(&vmap[pos >> 5], bit) & bit) == 0) {  // ds_or_rtn_b32
+                    ghash[pos] = nid;
+                    slot_out = s.lh + pos;
+                    fresh = true;
+                    pend = false;
+                } else {
+                    pos = pos + 1 == s.gcap ? 0u : pos + 1;
+                }
+            } else if (pend) {
+                const uint32_t hit = ((v.x == nid ? 1u : 0u) | (v.y == nid ? 2u : 0u) | (v.z == nid ? 4u : 0u) | (v.w == nid ? 8u : 0u)) &
+                                     (((1u << t) - 1u) << (pos & 3u));
+                if (hit) {
+                    slot_out = s.lh + (pos & ~3u) + (uint32_t)__builtin_ctz(hit);
+                    pend = false;
+                } else {
+                    pos += t;
+                    if (pos == s.gcap) pos = 0;
+                }
+            }
+            wave_sync();
+            if (!__ballot(pend)) break;
+        }
+        nins_g += (uint32_t)__popcll(__ballot(fresh));
+        return fresh;
+    };
     auto open_table = [&]() -> bool {  // first use: this wave claims and clears its own table
         if (g_open) return true;
         if (!claim_region()) return false;
@@ -972,6 +1035,7 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
             status |= OVF_HASH;
             return false;
         }
+        if (VG == 2) return slot_insert(nid, need_g, slot_home(nid), make_uint4(0, 0, 0, 0), 0u, slot_out);
         const uint32_t b0 = ghash_home(nid);
         uint4 v = make_uint4(0, 0, 0, 0);
         bool virgin = false;
@@ -1044,11 +1108,13 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
     uint4 gbk0 = make_uint4(0, 0, 0, 0);
     bool rchit0 = false;  // this lane's id of the first chunk was found in the id cache
     bool virg0 = false;
+    uint32_t pret0 = 0;  // (VG == 2) occupied run at the home slot of this lane's id of the first chunk when its group was requested
     while (status == 0) {
         hslot0 = 0;  // (these do not live across iterations)
         gbk0 = make_uint4(0, 0, 0, 0);
         rchit0 = false;
         virg0 = false;
+        pret0 = 0;
         if (VR > 0 && vis.len > 0) {  // (the ring carries what consume() needs in its entries)
             const uint32_t fn = readlane_u32(vis.n[0], 0);
             if (fn != ft_node) {
@@ -1114,12 +1180,19 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
             }
             if (gmode && (nins_g + WAVE) * 4u <= s.gcap * 3u) {
                 early = true;
-                hslot0 = ghash_home(row0);
                 const uint64_t inval0 = __ballot(row0 == VS_INVALID_NODE);
-                rchit0 = s.rc ? rc[hash_u32(row0 ^ 0x9e3779b9u) & rcm] == row0 : false;
+                const bool act0 = (uint32_t)lane < (inval0 ? (uint32_t)__builtin_ctzll(inval0) : WAVE);
                 virg0 = false;
                 gbk0 = make_uint4(0, 0, 0, 0);
-                if ((uint32_t)lane < (inval0 ? (uint32_t)__builtin_ctzll(inval0) : WAVE) && !rchit0) gbk0 = bucket_fetch(hslot0, virg0);
+                if (VG == 2) {
+                    hslot0 = slot_home(row0);
+                    pret0 = act0 ? slot_run(hslot0) : 0u;
+                    if (pret0) gbk0 = *reinterpret_cast<const uint4*>(ghash + (hslot0 & ~3u));
+                } else {
+                    hslot0 = ghash_home(row0);
+                    rchit0 = s.rc ? rc[hash_u32(row0 ^ 0x9e3779b9u) & rcm] == row0 : false;
+                    if (act0 && !rchit0) gbk0 = bucket_fetch(hslot0, virg0);
+                }
             }
         }
         heap.pop();
@@ -1164,14 +1237,20 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
             lap(1);
             // prepare_insert (marks BEFORE the label check, AM/sbq/storage.rs:148-172): first probe issued, ...
             const bool frozen = !gmode && nins + WAVE > slot_limit;
-            uint32_t hslot = gmode ? ghash_home(nid) : hash_home(nid), old = VS_EMPTY;
+            uint32_t hslot = gmode ? (VG == 2 ? slot_home(nid) : ghash_home(nid)) : hash_home(nid), old = VS_EMPTY;
             uint4 gbk = make_uint4(0, 0, 0, 0);
             bool rchit = false, virg = false;
+            uint32_t pret = 0;  // (VG == 2) != 0: gbk holds the group of hslot, whose occupied run was pret slots long
             if (gmode && early && c0 == 0) {
                 hslot = hslot0;  // requested before the pop
                 gbk = gbk0;
                 rchit = rchit0;
                 virg = virg0;
+                pret = pret0;
+            } else if (gmode && VG == 2) {
+                if ((nins_g + WAVE) * 4u > s.gcap * 3u) { status |= OVF_HASH; break; }
+                pret = act ? slot_run(hslot) : 0u;
+                if (pret) gbk = *reinterpret_cast<const uint4*>(ghash + (hslot & ~3u));  // in flight during the visited insert
             } else if (gmode) {
                 if ((nins_g + WAVE) * 4u > s.gcap * 3u) { status |= OVF_HASH; break; }
                 if (s.rc && act) rchit = rc[hash_u32(nid ^ 0x9e3779b9u) & rcm] == nid;
@@ -1187,7 +1266,9 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
             }
             // ... then the probe sequence is finished
             bool fresh;
-            if (gmode) {
+            if (gmode && VG == 2) {
+                fresh = slot_insert(nid, act, hslot, gbk, pret, hslot);
+            } else if (gmode) {
                 fresh = global_insert(nid, act && !rchit, hslot, gbk, virg, hslot);
                 if (s.rc && act && !rchit) rc[hash_u32(nid ^ 0x9e3779b9u) & rcm] = nid;  // (now in the table, new or not)
             } else if (frozen) {
@@ -1355,7 +1436,7 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
     }
 }
 
-template <int NCH, int VR, bool TIMING, int MINW, bool BUILD, bool FULL = true, bool VG = false>
+template <int NCH, int VR, bool TIMING, int MINW, bool BUILD, bool FULL = true, int VG = 0>
 __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
     if (!a.s.persist) {
         if (blockIdx.x < a.s.nq) fast_scan<NCH, VR, TIMING, MINW, BUILD, FULL, VG>(a, blockIdx.x, blockIdx.x);
@@ -1377,11 +1458,11 @@ size_t fast_lds_bytes(const vs_index* idx, const FastLaunch& s) {
     const size_t nch = (idx->code_stride + 7) / 8;
     // LDS copy of the query code: the generic variant (NCH == 0), and the register-capped variants (minw >= 6: 8 NCH words, zero padded)
     const size_t qcopy = nch > 6 ? (size_t)idx->code_stride * 8 : (s.minw >= 6 && !s.build && !s.phase ? nch * 64 : 0);
-    size_t b = (size_t)(s.hl + 1) * 4 + (size_t)s.lh * 4 + 3 * 64 * 4 + ARB_SLOTS * 4 + (s.vr ? 0 : (size_t)s.vcap * 8) + MAX_QLABELS * 2 + qcopy + (size_t)s.rc * 4 + (size_t)s.vwords * 4 + 32;
+    size_t b = (size_t)(s.hl + 1) * 4 + (size_t)s.lh * 4 + 3 * 64 * 4 + (s.vslot ? 0 : ARB_SLOTS * 4) + (s.vr ? 0 : (size_t)s.vcap * 8) + MAX_QLABELS * 2 + qcopy + (size_t)s.rc * 4 + (size_t)s.vwords * 4 + 32;
     return (b + 15) / 16 * 16;
 }
 
-template <int NCH, int VR, bool TIMING, int MINW, bool BUILD, bool FULL = true, bool VG = false>
+template <int NCH, int VR, bool TIMING, int MINW, bool BUILD, bool FULL = true, int VG = 0>
 static int launch_fast_tt(vs_index* idx, const FastArgs& a, size_t lds, uint32_t* resident) {
     static bool attr_set = false;
     if (!attr_set) {
@@ -1412,15 +1493,23 @@ static int launch_fast_t(vs_index* idx, const FastArgs& a, size_t lds, uint32_t*
         if (a.s.vr == 8) return launch_fast_tt<3, 8, true, 1, false>(idx, a, lds, res);
         return launch_fast_tt<3, 0, true, 1, false>(idx, a, lds, res);
     }
+    if (a.s.vwords && a.s.vslot) {  // occupancy bitmap of the dedup table's slots in LDS (table-less regime, LDS-ring visited list)
+        VS_REQUIRE(a.s.vr == 0 && a.s.lh == 0 && a.s.epoch == 0 && (uint64_t)a.s.vwords * 32 >= a.s.gcap && a.s.rc == 0,
+                   "fast search: the slot bitmap needs the table-less regime with plain ids and one bit per slot");
+        const bool plain = !a.s.qlabel_off && !a.s.visible && !(a.s.flags & FAST_FULL_VARIANT);
+        if (NCH == 3 && a.s.minw == 6 && plain) return launch_fast_tt<3, 0, false, 6, false, false, 2>(idx, a, lds, res);
+        if (NCH == 3 && a.s.minw == 6) return launch_fast_tt<3, 0, false, 6, false, true, 2>(idx, a, lds, res);
+        return launch_fast_tt<NCH, 0, false, 1, false, true, 2>(idx, a, lds, res);
+    }
     if (a.s.vwords) {  // written-bucket bitmap in LDS instead of cleared tables (table-less regime, LDS-ring visited list)
         VS_REQUIRE(a.s.vr == 0 && a.s.lh == 0 && a.s.epoch == 0 && (uint64_t)a.s.vwords * 128 >= a.s.gcap,
                    "fast search: the written-bucket bitmap needs the table-less regime with plain ids and one bit per bucket");
         const bool plain = !a.s.qlabel_off && !a.s.visible && !(a.s.flags & FAST_FULL_VARIANT);
-        if (NCH == 3 && a.s.minw == 6 && plain) return launch_fast_tt<3, 0, false, 6, false, false, true>(idx, a, lds, res);
-        if (NCH == 3 && a.s.minw == 6) return launch_fast_tt<3, 0, false, 6, false, true, true>(idx, a, lds, res);
-        if (NCH == 3 && a.s.minw == 5 && plain) return launch_fast_tt<3, 0, false, 5, false, false, true>(idx, a, lds, res);
-        if (NCH == 3 && a.s.minw == 5) return launch_fast_tt<3, 0, false, 5, false, true, true>(idx, a, lds, res);
-        return launch_fast_tt<NCH, 0, false, 1, false, true, true>(idx, a, lds, res);
+        if (NCH == 3 && a.s.minw == 6 && plain) return launch_fast_tt<3, 0, false, 6, false, false, 1>(idx, a, lds, res);
+        if (NCH == 3 && a.s.minw == 6) return launch_fast_tt<3, 0, false, 6, false, true, 1>(idx, a, lds, res);
+        if (NCH == 3 && a.s.minw == 5 && plain) return launch_fast_tt<3, 0, false, 5, false, false, 1>(idx, a, lds, res);
+        if (NCH == 3 && a.s.minw == 5) return launch_fast_tt<3, 0, false, 5, false, true, 1>(idx, a, lds, res);
+        return launch_fast_tt<NCH, 0, false, 1, false, true, 1>(idx, a, lds, res);
     }
     if (a.s.vr == 8) {
         if (NCH == 3) {  // the headline geometry (768 x 2 bit, 1536 x 1 bit): register-capped variants for the occupancy-bound regime

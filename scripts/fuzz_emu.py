@@ -41,6 +41,8 @@ EXTRA_REGIMES = [
     {"VS_F_LDS_MAX_INS": "0", "VS_F_VIRGIN": "1"},                      # written-bucket bitmap instead of cleared dedup tables
     {"VS_F_LDS_MAX_INS": "0", "VS_F_VIRGIN": "1", "VS_F_HL": "63"},
     {"VS_F_LDS_MAX_INS": "0", "VS_F_VIRGIN": "1", "VS_F_GCAP": "2048"},  # ... tight: chains of full buckets, second attempts
+    {"VS_F_LDS_MAX_INS": "0", "VS_F_VIRGIN": "2"},                      # occupancy bit per slot (linear probing, loads only behind occupied home slots)
+    {"VS_F_LDS_MAX_INS": "0", "VS_F_VIRGIN": "2", "VS_F_GCAP": "2048"},  # ... tight: long occupied runs across groups, wrap-around, second attempts
 ]
 TUNING = sorted({k for r in REGIMES + EXTRA_REGIMES for k in r})
 

@@ -19,7 +19,9 @@ import numpy as np  # noqa: E402
 VARIANTS = [{"VS_F_MINW": "5"}, {"VS_F_MINW": "5", "VS_F_VIRGIN": "1"}, {"VS_F_VIRGIN": "1"},
             # the remaining candidates of vs_index_autotune (csrc/vs_api.hip, kTuneCands): epoch tags alone and with the two-row gather,
             # the bitmap on sparser tables
-            {"VS_F_EPOCH": "1"}, {"VS_F_EPOCH": "1", "VS_F_MINW": "5"}, {"VS_F_VIRGIN": "1", "VS_F_GCAP": "16384"}]
+            {"VS_F_EPOCH": "1"}, {"VS_F_EPOCH": "1", "VS_F_MINW": "5"}, {"VS_F_VIRGIN": "1", "VS_F_GCAP": "16384"},
+            # occupancy bit per slot of the dedup table (VS_F_VIRGIN=2), on a fitted and on a tight table
+            {"VS_F_VIRGIN": "2"}, {"VS_F_VIRGIN": "2", "VS_F_GCAP": "1536"}]
 KNOBS = sorted({k for v in VARIANTS for k in v})
 COUNTERS = ("visited_nodes", "candidate_nodes", "quantized_distance_comparisons", "node_reads", "next_calls")
 

@@ -29,6 +29,11 @@ REGIMES = {
     # (the array starts out holding whatever earlier launches left there); tight tables make chains of full buckets
     "tableless_virgin": {"VS_F_LDS_MAX_INS": "0", "VS_F_VIRGIN": "1"},
     "tableless_virgin_tight": {"VS_F_LDS_MAX_INS": "0", "VS_F_VIRGIN": "1", "VS_F_GCAP": "6144"},
+    # table-less with one occupancy bit per SLOT in LDS (linear probing at slot granularity: an id whose home slot is free is stored
+    # without a load, a free slot is claimed with one ds_or); tight tables make long occupied runs that cross groups and wrap around
+    "tableless_slotmap": {"VS_F_LDS_MAX_INS": "0", "VS_F_VIRGIN": "2"},
+    "tableless_slotmap_tight": {"VS_F_LDS_MAX_INS": "0", "VS_F_VIRGIN": "2", "VS_F_GCAP": "6144"},
+    "tableless_slotmap_one_wg_per_scan": {"VS_F_LDS_MAX_INS": "0", "VS_F_VIRGIN": "2", "VS_F_PERSIST": "0"},
     "tiny_pool": {"VS_F_LH": "256", "VS_F_POOL": "0.01"},
     # dedup table too small for most scans: they are finished by the second attempt of k_search_fast (four times the table) ...
     "second_attempt": {"VS_F_LDS_MAX_INS": "0", "VS_F_GCAP": "1024"},
@@ -51,13 +56,13 @@ REGIMES = {
 
 
 def _hardware_unverified(regime):
-    """the written-bucket bitmap and the two-row gather variant are opt-ins of the library (candidates of vs_index_autotune).  They ran on
-    the MI355X at the very end of round 3 — identical to the default on the five legs of the child-process probe and on 262 144 scans
-    at 10M and 1M (profiles/r03/tune_probe_hw.json, ab_autotune_*.json) — but the corner cases of THIS file (code widths, register caps,
-    heavy ties) have only run on the wave64 interpreter (VS_EMU=1, part of the CPU tier): on hardware they are an opt-in
-    (VS_TEST_VIRGIN=1, scripts/r04_s1.sh) so that an opt-in variant cannot turn the tier of the shipped defaults red"""
-    if ("virgin" in str(regime) or str(regime) == "5") and not os.environ.get("VS_EMU") and not os.environ.get("VS_TEST_VIRGIN"):
-        pytest.skip("VS_F_VIRGIN / the two-row gather (VS_F_MINW=5) have not run on hardware yet (scripts/r04_s1.sh)")
+    """the written-bucket bitmap, the epoch tags and the two-row gather ran this file's corner cases on the MI355X in round 4's first GPU
+    session (profiles/r04/s1_tests.txt: 96 passed with the opt-in set; device fuzz 1 074 + 1 102 cases) and are no longer skipped.
+    A variant that is newer than its first hardware session is listed here: exact on the wave64 interpreter (VS_EMU=1, part of the
+    CPU tier), an opt-in on hardware until it has run there, so that it cannot turn the tier of the shipped defaults red."""
+    unverified = ()
+    if any(u in str(regime) for u in unverified) and not os.environ.get("VS_EMU") and not os.environ.get("VS_TEST_UNVERIFIED"):
+        pytest.skip(f"{regime}: not run on hardware yet")
 
 
 INDEXES = {
@@ -119,7 +124,7 @@ WIDTHS = {"w12": (384, 2), "w30": (960, 2), "w48": (1536, 2), "w60": (1900, 2), 
 
 
 @pytest.mark.parametrize("wname", list(WIDTHS))
-@pytest.mark.parametrize("regime", ["default", "tableless", "heap_spill", "tableless_virgin"])
+@pytest.mark.parametrize("regime", ["default", "tableless", "heap_spill", "tableless_virgin", "tableless_slotmap"])
 def test_code_width_specialisations(gpu_ctx, wname, regime):
     _hardware_unverified(regime)
     dims, bits = WIDTHS[wname]
@@ -149,7 +154,7 @@ def test_code_width_specialisations(gpu_ctx, wname, regime):
 # the register-capped variants of the headline geometry (W = 24: 768 x 2 bit / 1536 x 1 bit) in the table-less regime:
 # waves per SIMD the kernel is compiled for (7 and 8 read the query code from LDS and keep the heap's lane constants packed; 5 keeps
 # two code rows per 4-lane group in flight)
-@pytest.mark.parametrize("minw", [5, 6, 7, 8, "6_virgin", "5_virgin"])
+@pytest.mark.parametrize("minw", [5, 6, 7, 8, "6_virgin", "5_virgin", "6_slotmap"])
 @pytest.mark.parametrize("wname", ["w24_two_bit", "w24_one_bit"])
 def test_register_capped_variants(gpu_ctx, wname, minw):
     _hardware_unverified(minw)
@@ -162,6 +167,8 @@ def test_register_capped_variants(gpu_ctx, wname, minw):
     env = {"VS_F_LDS_MAX_INS": "0", "VS_F_VR": "0", "VS_F_MINW": str(minw), "VS_F_HL": "63"}
     if str(minw).endswith("_virgin"):  # the written-bucket-bitmap instantiations of the headline geometry
         env.update({"VS_F_MINW": str(minw)[0], "VS_F_VIRGIN": "1"})
+    if str(minw).endswith("_slotmap"):  # ... and the slot-bitmap ones
+        env.update({"VS_F_MINW": str(minw)[0], "VS_F_VIRGIN": "2"})
     saved = {k: os.environ.get(k) for k in env}
     try:
         os.environ.update(env)
@@ -184,7 +191,7 @@ def test_register_capped_variants(gpu_ctx, wname, minw):
 # Few distinct keys, deep heap, long runs: 24-dimensional 1-bit codes give Hamming distances 0..24, so thousands of heap entries
 # tie and the row order is decided by the array mechanics of BinaryHeap alone (which leaf a push lands on, which child a pop
 # prefers, where a carried value stops) — with R = 48 a visit pushes up to 48 candidates in one run.
-@pytest.mark.parametrize("regime", ["default", "tableless", "heap_spill_tableless", "tableless_virgin"])
+@pytest.mark.parametrize("regime", ["default", "tableless", "heap_spill_tableless", "tableless_virgin", "tableless_slotmap", "tableless_slotmap_tight"])
 def test_heavy_ties_deep_heap(gpu_ctx, regime):
     _hardware_unverified(regime)
     ti = cached_index(n=6000, dim_full=24, bits=1, R=48, distance=1, seed=31, kind="gauss", L_build=60)
@@ -245,7 +252,6 @@ VARIANTS = {"5": {"VS_F_MINW": "5"}, "5_virgin": {"VS_F_MINW": "5", "VS_F_VIRGIN
 @pytest.mark.parametrize("variant", list(VARIANTS))
 @pytest.mark.parametrize("iname", ["plain_R50", "labels_R40", "short_lists_R64"])
 def test_two_row_gather_full_neighbor_lists(gpu_ctx, iname, variant):
-    _hardware_unverified("5")
     kw, L, m, rescore = {
         "plain_R50": (dict(n=1500, dim_full=768, bits=2, R=50, distance=1, seed=29, kind="gauss", L_build=60), 25, 90, 0),
         "labels_R40": (dict(n=1200, dim_full=1536, bits=1, R=40, distance=2, seed=30, kind="gauss", L_build=50, n_labels=5,

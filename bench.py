@@ -275,12 +275,13 @@ def main():
     ap.add_argument("--pcie-steps", type=int, default=2,
                     help="steps of the PCIe-inclusive leg (queries start in pageable host memory, rows end there: vs_search_batch); "
                          "reported next to the value, never as the value; 0 = skip")
-    ap.add_argument("--autotune", default="on", choices=["on", "off"],
-                    help="on (default): before the timed region the library times every exact launch variant of the search kernel on one "
+    ap.add_argument("--autotune", default="off", choices=["on", "off"],
+                    help="off (default): the library's default launch variant — the one the committed rocprofv3 / PMC summaries under profiles/ "
+                         "were taken on.  on: before the timed region the library times every exact launch variant of the search kernel on one "
                          "warm-up batch (vs_index_autotune: a variant must reproduce the default's rows, distance bits and counters on all "
-                         "scans of that batch to qualify; the fastest qualified one is used when it beats the default by > 1 %%), after "
+                         "scans of that batch to qualify; the fastest qualified one is used when it beats the default by >= 3 %% twice), after "
                          "a child-process probe of the variants on a small index under a timeout (pgvectorscale_amd/tune_probe.py); the "
-                         "line reports every candidate's time under `autotune`.  off: the library default")
+                         "line reports every candidate's time under `autotune`")
     ap.add_argument("--tune-reps", type=int, default=3, help="timed steps per variant (after one warm-up step each)")
     ap.add_argument("--probe-n", type=int, default=100_000, help="nodes of the probe child's index")
     ap.add_argument("--probe-timeout", type=float, default=240.0)
@@ -742,7 +743,9 @@ def main():
         hs = heldout_stats(last_ids)
         log(f"recall@{k} of the timed results (first {nh} queries of the last timed batch" + (f", x{world} ranks" if world > 1 else "")
             + f"): {hs['recall']:.4f} (lower 95 % bound {hs['lower95']:.4f}) at L={L} rescore={S}")
-        if hs["recall"] >= args.recall_target or args.fixed or S >= 1000 or retimed >= 8 or recall < args.recall_target:
+        # (accepted on the LOWER 95 % bound of the timed rows, like the validation set: a point estimate 0.0004 above the target
+        # is not a met target)
+        if hs["lower95"] >= args.recall_target or args.fixed or S >= 1000 or retimed >= 12 or recall < args.recall_target:
             break
         S = min(1000, S + max(2, S // 32))
         retimed += 1
@@ -910,7 +913,7 @@ def main():
         "retimed_after_heldout_check": retimed,
         # met = the timed rows themselves reach the target, and so do the tuning sample and the LOWER 95 % bound of the
         # validation sample
-        "recall_target_met": bool(min(recall, val["lower95"], 1.0 if recall_heldout is None else recall_heldout) >= args.recall_target),
+        "recall_target_met": bool(min(recall, val["lower95"], 1.0 if hs is None else hs["lower95"]) >= args.recall_target),
         "recall_sweep": sweep_log,
         "roofline": roofline,
         "sbq_scan_roofline": scan_roofline,

@@ -406,12 +406,12 @@ int vs_search_batch_dev_finish(vs_index* idx, vs_stats* stats);
 
 /* ---- launch-variant selection (ours; the reference has no counterpart — its only query-time knobs are the two GUCs above,
  * AM/guc.rs:3-43, and they stay the caller's).  The search kernel exists in several EXACT instantiations that differ only in
- * how a scan keeps its private state (epoch-tagged dedup tables, a written-bucket bitmap, two code rows in flight; for small
+ * how a scan keeps its private state (dedup tables cleared per scan, a written-bucket bitmap, an occupancy bit per slot; for small
  * scans: dedup table in LDS or not).  Which is fastest depends on the index size and on the box, so it is measured
  * where it runs: vs_index_autotune runs every applicable variant on the caller's own device-resident batch (the arguments of
  * vs_search_batch_dev), `reps` timed steps each after one warm-up, holds every row, every distance bit and every work counter of
  * a variant to the library default's on the same batch, DISQUALIFIES a variant that differs anywhere (rows_identical = 0) and
- * makes the fastest qualified one the index's choice when it beats the default by more than 1 %.  VS_F_* environment
+ * makes the fastest qualified one the index's choice when it beats the default by at least 3 % and does so again on a second timing.  VS_F_* environment
  * variables still override the choice per call.  report (may be NULL) receives one entry per variant, the default first.
  * A caller that cannot afford a misbehaving kernel in its own process probes the variants in a child process first
  * (pgvectorscale_amd/tune_probe.py: a small index of the same code width, every variant, a hard timeout) and passes the ones

@@ -724,13 +724,18 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
     asm volatile("" : "+v"(lane_v));
     const int lane = lane_v;
     const FastLaunch& s = a.s;
-    if (s.only_failed && s.status[q] == 0) return;  // (wave-uniform) finished by the first launch
+    // (the bitmap variants only exist for the table-less regime: the LDS-table code paths are not compiled into them)
+    const uint32_t lhv = VG ? 0u : s.lh;
+    const uint32_t epochv = VG ? 0u : s.epoch;        // (plain ids)
+    const uint32_t onlyfv = VG ? 0u : s.only_failed;  // (second attempts run the instantiation that clears its tables)
+    const uint32_t rcv = VG == 2 ? 0u : s.rc;
+    if (onlyfv && s.status[q] == 0) return;  // (wave-uniform) finished by the first launch
     if (s.timeline && lane == 0) s.timeline[2 * (size_t)q] = wall_clock64();
 
     // ---- LDS carve ----
     uint32_t* hp = reinterpret_cast<uint32_t*>(smem);                 // hl + 1 (hl + 1 is a power of two >= 64)
     uint32_t* lhash = hp + (s.hl + 1);                                // lh (multiple of 4)
-    uint32_t* surv_id = lhash + s.lh;                                 // 64
+    uint32_t* surv_id = lhash + lhv;                                 // 64
     uint32_t* surv_slot = surv_id + 64;                               // 64
     uint32_t* surv_d = surv_slot + 64;                                // 64
     uint32_t* arb = surv_d + 64;                                      // ARB_SLOTS rank counters of the global dedup table (zero between uses; none with the slot bitmap)
@@ -740,14 +745,14 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
     uint64_t* qc_l = reinterpret_cast<uint64_t*>(ql + MAX_QLABELS);   // code_stride words (NCH == 0 only)
     // (optional) cache of ids known to be in the dedup table: a hit answers a duplicate probe without touching the table in HBM
     uint32_t* rc = reinterpret_cast<uint32_t*>(qc_l + (NCH == 0 ? ((a.code_stride + 1u) & ~1u) : (NCH > 0 && MINW >= 6 ? 8u * (uint32_t)NCH : 0u)));
-    const uint32_t rcm = s.rc - 1u;  // (s.rc: 0 or a power of two)
+    const uint32_t rcm = rcv - 1u;  // (rcv: 0 or a power of two)
     // (VG == 1) one bit per bucket of the dedup table in HBM: set once this scan has written the bucket.  A bucket whose bit is clear is
     // neither cleared nor read — its memory holds whatever an earlier scan left there — and counts as four empty slots.
     // (VG == 2) one bit per SLOT: the table is open addressing with linear probing at slot granularity, and which slots are occupied
     // is known on chip — an id whose home slot is free is new and is stored there without a load (most new ids: the expected share
     // is 1 - load factor), the others are compared with the occupied run that starts at their home slot (one 16-byte load per
     // 4-slot group the run touches), a free slot is claimed with one ds_or; no clears, no rank counters
-    uint32_t* vmap = rc + s.rc;  // s.vwords
+    uint32_t* vmap = rc + rcv;  // s.vwords
 
     const int l4 = lane & 3;
     const bool stream_rows = !(s.flags & FAST_PLAIN_ROW_LOADS);
@@ -769,11 +774,11 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
     } else {
         for (uint32_t w = lane; w < a.code_stride; w += WAVE) qc_l[w] = s.qcodes[(size_t)q * a.code_stride + w];
     }
-    for (uint32_t i = 4u * lane; i < s.lh; i += 4u * WAVE)
+    for (uint32_t i = 4u * lane; i < lhv; i += 4u * WAVE)
         *reinterpret_cast<uint4*>(lhash + i) = make_uint4(VS_EMPTY, VS_EMPTY, VS_EMPTY, VS_EMPTY);
     if (lane == 0) hp[0] = 0;  // heap sentinel
     for (uint32_t i = lane; i < ARB_N; i += WAVE) arb[i] = 0;
-    for (uint32_t i = lane; i < s.rc; i += WAVE) rc[i] = VS_EMPTY;
+    for (uint32_t i = lane; i < rcv; i += WAVE) rc[i] = VS_EMPTY;
     if (VG)
         for (uint32_t i = lane; i < s.vwords; i += WAVE) vmap[i] = 0;
     const uint8_t* const visible = FULL ? s.visible : nullptr;
@@ -805,14 +810,14 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
     FastHeap<(MINW >= 7)> heap;
     heap.l = hp;
     // (second attempt with one workgroup per scan: set with the pool region)
-    heap.g = s.persist ? s.heap_g + (size_t)slot * s.gstride : (s.only_failed ? s.heap_g : s.heap_g + (size_t)q * s.gstride);
+    heap.g = s.persist ? s.heap_g + (size_t)slot * s.gstride : (onlyfv ? s.heap_g : s.heap_g + (size_t)q * s.gstride);
     heap.hl = s.hl;
     heap.sb = s.sb;
     heap.init(lane);
     Visited<VR> vis;
     vis.init(lane, ring, VR > 0 ? 64u * VR : s.vcap);
 
-    const uint32_t slot_limit = s.lh - s.lh / 8;  // stop at 87.5 % load: the scan is handed to the general kernel
+    const uint32_t slot_limit = lhv - lhv / 8;  // stop at 87.5 % load: the scan is handed to the general kernel
     const uint32_t smask = (1u << s.sb) - 1u;
     uint32_t emitted = 0, status = wide_key ? (uint32_t)OVF_KEY : 0u, nins = 0, hmax = 0;
     uint32_t st_visits = 0, st_cand = 0, st_dq = 0, st_reads = 0;
@@ -851,22 +856,22 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
         }
         region = true;
         ghash = s.ghash + (size_t)pslot * s.gcap;
-        if (s.only_failed) heap.g = s.heap_g + (size_t)pslot * s.gstride;
+        if (onlyfv) heap.g = s.heap_g + (size_t)pslot * s.gstride;
         return true;
     };
-    auto hash_home = [&](uint32_t nid) -> uint32_t { return (uint32_t)(((uint64_t)hash_u32(nid) * s.lh) >> 32); };
+    auto hash_home = [&](uint32_t nid) -> uint32_t { return (uint32_t)(((uint64_t)hash_u32(nid) * lhv) >> 32); };
     // handle -> node id.  node_load only ISSUES the read (LDS, or L2 for ids in the overflow table); the value is made
     // uniform with rfl() where it is needed, so the latency overlaps whatever runs in between.
-    // Epoch-tagged table (s.epoch != 0): an entry is (epoch << s.eshift) | node id, and an entry whose tag is not this launch's
+    // Epoch-tagged table (epochv != 0): an entry is (epoch << s.eshift) | node id, and an entry whose tag is not this launch's
     // epoch counts as EMPTY — the table is never cleared by the scans (a 64 KB clear per scan was 8 % of a 50M launch's
-    // memory requests); the host zeroes the array once and again whenever the epochs wrap.  s.epoch == 0: entries are plain
+    // memory requests); the host zeroes the array once and again whenever the epochs wrap.  epochv == 0: entries are plain
     // ids, VS_EMPTY marks an empty slot and the claiming wave clears its table (second attempts, build mode).
-    const uint32_t etag = s.epoch << (s.eshift & 31u);
-    const uint32_t idmask = s.epoch ? (1u << (s.eshift & 31u)) - 1u : 0xFFFFFFFFu;
-    auto g_empty = [&](uint32_t v) -> bool { return s.epoch ? (v >> (s.eshift & 31u)) != s.epoch : v == VS_EMPTY; };
+    const uint32_t etag = epochv << (s.eshift & 31u);
+    const uint32_t idmask = epochv ? (1u << (s.eshift & 31u)) - 1u : 0xFFFFFFFFu;
+    auto g_empty = [&](uint32_t v) -> bool { return epochv ? (v >> (s.eshift & 31u)) != epochv : v == VS_EMPTY; };
     auto node_load = [&](uint32_t handle) -> uint32_t {
-        if (handle < s.lh) return lload32(lhash + handle);
-        return gload32(ghash + (handle - s.lh)) & idmask;
+        if (handle < lhv) return lload32(lhash + handle);
+        return gload32(ghash + (handle - lhv)) & idmask;
     };
     // true where the id was not present before; slot_out = its handle
     auto finish_insert = [&](uint32_t nid, bool act, uint32_t slot, uint32_t old, uint32_t& slot_out) -> bool {
@@ -875,7 +880,7 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
             for (;;) {
                 if (old == VS_EMPTY) { fresh = true; break; }
                 if (old == nid) break;
-                slot = slot + 1 == s.lh ? 0 : slot + 1;
+                slot = slot + 1 == lhv ? 0 : slot + 1;
                 old = atomicCAS(&lhash[slot], VS_EMPTY, nid);  // ds_cmpst_rtn_b32
             }
             slot_out = slot;
@@ -888,7 +893,7 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
     // in this bucket and the bucket has an empty slot" means the id is absent.  Lanes that want a slot of their bucket in
     // the same step draw distinct ranks from an LDS counter (lanes of other buckets sharing the counter only waste ranks)
     // and take the rank-th empty slot; a lane whose rank is past the bucket's empties looks at the bucket again.
-    const bool gmode = s.lh == 0;  // table-less regime: every id lives in the global table
+    const bool gmode = lhv == 0;  // table-less regime: every id lives in the global table
     auto ghash_home = [&](uint32_t nid) -> uint32_t {
         return (uint32_t)(((uint64_t)hash_u32(nid ^ 0x5bd1e995u) * gbuckets) >> 32) << 2;
     };
@@ -915,7 +920,7 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
                 const uint32_t b = b0 >> 2, bit = 1u << (b & 31u);
                 if ((atomicOr(&vmap[b >> 5], bit) & bit) == 0) {  // ds_or_rtn_b32
                     *reinterpret_cast<uint4*>(ghash + b0) = make_uint4(nid, VS_EMPTY, VS_EMPTY, VS_EMPTY);
-                    slot_out = s.lh + b0;
+                    slot_out = lhv + b0;
                     fresh = true;
                     pend = false;
                 }
@@ -924,7 +929,7 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
                 const uint32_t key = nid | etag;
                 const uint32_t hit = (v.x == key ? 1u : 0u) | (v.y == key ? 2u : 0u) | (v.z == key ? 4u : 0u) | (v.w == key ? 8u : 0u);
                 if (hit) {
-                    slot_out = s.lh + b0 + (uint32_t)__builtin_ctz(hit);
+                    slot_out = lhv + b0 + (uint32_t)__builtin_ctz(hit);
                     pend = false;
                 } else {
                     em = (g_empty(v.x) ? 1u : 0u) | (g_empty(v.y) ? 2u : 0u) | (g_empty(v.z) ? 4u : 0u) | (g_empty(v.w) ? 8u : 0u);
@@ -945,7 +950,7 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
                     if (rank > 2) m &= m - 1u;
                     const uint32_t at = b0 + (uint32_t)__builtin_ctz(m);
                     ghash[at] = nid | etag;
-                    slot_out = s.lh + at;
+                    slot_out = lhv + at;
                     fresh = true;
                     pend = false;
                 }
@@ -983,7 +988,7 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
                 const uint32_t bit = 1u << (pos & 31u);
                 if ((atomicOr(&vmap[pos >> 5], bit) & bit) == 0) {  // ds_or_rtn_b32
                     ghash[pos] = nid;
-                    slot_out = s.lh + pos;
+                    slot_out = lhv + pos;
                     fresh = true;
                     pend = false;
                 } else {
@@ -993,7 +998,7 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
                 const uint32_t hit = ((v.x == nid ? 1u : 0u) | (v.y == nid ? 2u : 0u) | (v.z == nid ? 4u : 0u) | (v.w == nid ? 8u : 0u)) &
                                      (((1u << t) - 1u) << (pos & 3u));
                 if (hit) {
-                    slot_out = s.lh + (pos & ~3u) + (uint32_t)__builtin_ctz(hit);
+                    slot_out = lhv + (pos & ~3u) + (uint32_t)__builtin_ctz(hit);
                     pend = false;
                 } else {
                     pos += t;
@@ -1010,7 +1015,7 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
         if (g_open) return true;
         if (!claim_region()) return false;
         g_open = true;
-        if (s.epoch == 0 && !VG) {
+        if (epochv == 0 && !VG) {
             for (uint32_t i = 4u * lane; i < s.gcap; i += 4u * WAVE)
                 *reinterpret_cast<uint4*>(ghash + i) = make_uint4(VS_EMPTY, VS_EMPTY, VS_EMPTY, VS_EMPTY);
             wave_sync();
@@ -1020,13 +1025,13 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
     // Frozen mode (LDS table at its load limit): read-only probe of the LDS table, then the global table
     auto frozen_insert = [&](uint32_t nid, bool act, uint32_t& slot_out) -> bool {
         bool need_g = act;
-        if (act && s.lh) {
+        if (act && lhv) {
             uint32_t slot = hash_home(nid);
             for (;;) {
                 const uint32_t v = lhash[slot];
                 if (v == nid) { need_g = false; break; }
                 if (v == VS_EMPTY) break;
-                slot = slot + 1 == s.lh ? 0 : slot + 1;
+                slot = slot + 1 == lhv ? 0 : slot + 1;
             }
         }
         if (!__ballot(need_g)) return false;
@@ -1045,7 +1050,7 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
 
     if (status) { /* handed over (wide label key): no region is claimed */ }
     else if (gmode) open_table();  // claimed and cleared up front
-    else if (s.only_failed) claim_region();  // (the heap spill array of a second attempt comes with the region)
+    else if (onlyfv) claim_region();  // (the heap spill array of a second attempt comes with the region)
 
     // ---- ListSearchResult::new: start nodes (AM/graph/mod.rs:97-124, AM/graph/start_nodes.rs:39-48) ----
     {
@@ -1190,7 +1195,7 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
                     if (pret0) gbk0 = *reinterpret_cast<const uint4*>(ghash + (hslot0 & ~3u));
                 } else {
                     hslot0 = ghash_home(row0);
-                    rchit0 = s.rc ? rc[hash_u32(row0 ^ 0x9e3779b9u) & rcm] == row0 : false;
+                    rchit0 = rcv ? rc[hash_u32(row0 ^ 0x9e3779b9u) & rcm] == row0 : false;
                     if (act0 && !rchit0) gbk0 = bucket_fetch(hslot0, virg0);
                 }
             }
@@ -1253,7 +1258,7 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
                 if (pret) gbk = *reinterpret_cast<const uint4*>(ghash + (hslot & ~3u));  // in flight during the visited insert
             } else if (gmode) {
                 if ((nins_g + WAVE) * 4u > s.gcap * 3u) { status |= OVF_HASH; break; }
-                if (s.rc && act) rchit = rc[hash_u32(nid ^ 0x9e3779b9u) & rcm] == nid;
+                if (rcv && act) rchit = rc[hash_u32(nid ^ 0x9e3779b9u) & rcm] == nid;
                 if (act && !rchit) gbk = bucket_fetch(hslot, virg);  // in flight during the visited insert
             } else if (!frozen && act) {
                 old = atomicCAS(&lhash[hslot], VS_EMPTY, nid);
@@ -1270,7 +1275,7 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
                 fresh = slot_insert(nid, act, hslot, gbk, pret, hslot);
             } else if (gmode) {
                 fresh = global_insert(nid, act && !rchit, hslot, gbk, virg, hslot);
-                if (s.rc && act && !rchit) rc[hash_u32(nid ^ 0x9e3779b9u) & rcm] = nid;  // (now in the table, new or not)
+                if (rcv && act && !rchit) rc[hash_u32(nid ^ 0x9e3779b9u) & rcm] = nid;  // (now in the table, new or not)
             } else if (frozen) {
                 fresh = frozen_insert(nid, act, hslot);
                 if (status) break;
@@ -1414,7 +1419,7 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
         }
     }
     if (lane == 0) {
-        if (s.only_failed && s.fb_flag) s.fb_flag[q] = 1;
+        if (onlyfv && s.fb_flag) s.fb_flag[q] = 1;
         s.status[q] = status;
         s.out_cnt[q] = status ? 0 : emitted;  // a failed scan publishes an empty stream until the fallback re-runs it
         if (status == 0) {

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 EMU = bool(os.environ.get("VS_EMU"))
 REGIME = {"VS_F_LDS_MAX_INS": "0", "VS_F_VR": "0"}  # the table-less regime of large indexes (the variants exist only there)
-NAMES = ["default", "epoch_tags", "bucket_bitmap", "bucket_bitmap_16k", "two_rows", "two_rows_epoch", "table_less", "table_less_bitmap", "lds_table_ring"]
+NAMES = ["default", "bucket_bitmap", "bucket_bitmap_16k", "slot_bitmap", "table_less", "table_less_bitmap", "lds_table_ring"]
 LDS_REGIME_ONLY = NAMES[-3:]  # candidates for indexes whose default keeps the dedup table in LDS
 
 
@@ -93,6 +93,8 @@ def test_autotune_holds_every_variant_to_the_defaults_rows(gpu_ctx, probe_skip, 
 
 
 def test_a_variant_whose_rows_differ_is_disqualified(gpu_ctx, probe_skip, regime):
+    if not EMU:
+        pytest.skip("VS_TUNE_SABOTAGE is compiled into the interpreter build of the test tier only (-DVS_TEST_HOOKS), not into libvsgpu.so")
     if probe_skip is None:
         pytest.skip("the probe child did not finish cleanly on this box: no variant is launched in this process")
     victim = next(n for n in NAMES[1:] if n not in probe_skip and "16k" not in n)
@@ -145,11 +147,11 @@ def test_set_variant_by_name(gpu_ctx):
     ix = ti.upload(gpu_ctx)
     try:
         assert ix.variant() == "default"
-        ix.set_variant("epoch_tags")
-        assert ix.variant() == "epoch_tags"
+        ix.set_variant("slot_bitmap")
+        assert ix.variant() == "slot_bitmap"
         with pytest.raises(P.VsError):
             ix.set_variant("no_such_variant")
-        assert ix.variant() == "epoch_tags"
+        assert ix.variant() == "slot_bitmap"
         ix.set_variant("default")
         # a view inherits the choice of the index it was made from
         ix.set_variant("bucket_bitmap")

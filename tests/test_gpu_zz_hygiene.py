@@ -43,7 +43,7 @@ def _workout(ctx, ti, q, labeled):
     try:
         os.environ.update({"VS_F_LDS_MAX_INS": "0", "VS_F_VR": "0"})
         if not labeled:
-            ix.autotune(dq, len(q), 10, 8, 10, reps=1, skip=() if EMU else ("bucket_bitmap", "bucket_bitmap_16k", "two_rows", "two_rows_epoch"))
+            ix.autotune(dq, len(q), 10, 8, 10, reps=1, skip=())
     finally:
         for k, v in saved.items():
             if v is None:

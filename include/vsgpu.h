@@ -106,7 +106,10 @@ const char* vs_last_error(void);
 const char* vs_version(void);
 
 /* ---- context ------------------------------------------------------------------------------------------------- */
-int vs_ctx_create(int device, vs_ctx** out);
+int vs_ctx_create(int device, vs_ctx** out);            /* staging ring: 2 x 32 MiB of pinned host memory */
+/* the same with a staging ring of 2 x staging_bytes: the contexts of cursor lanes and other handles that move a few rows per call
+ * (vs_broker_config.cursor_lanes creates up to 64 of them per broker) take 2 x 1 MiB instead of 2 x 32 MiB */
+int vs_ctx_create_staging(int device, size_t staging_bytes, vs_ctx** out);
 void vs_ctx_destroy(vs_ctx* ctx);
 int vs_ctx_sync(vs_ctx* ctx);          /* wait for the compute stream */
 void* vs_ctx_stream(vs_ctx* ctx);      /* the hipStream_t all kernels of this ctx are launched on */
@@ -475,7 +478,10 @@ typedef struct vs_broker_config {
                             * the dispatcher thread, one at a time, between two shared launches.  n > 0: on n lanes — threads of the
                             * broker with a HIP stream and a view of the index each — so that n scans continue concurrently on the
                             * device and none of them waits behind a shared launch (a scan stays on its lane).  vs_shm_server:
-                            * the streamed scans of client processes, by (client pid, scan id)                        */
+                            * the streamed scans of client processes, by (client pid, scan id).  Cost per lane: a context
+                            * with 2 x 1 MiB of pinned staging memory and the device workspace of the scans it continues.
+                            * (VS_BROKER_LANES in the environment: the lane count of brokers created with 0 — how the test tier
+                            * runs every broker test on lanes; leave it unset in production.)                         */
 } vs_broker_config;
 typedef struct vs_broker_stats {
     uint64_t batches;   /* vs_search_batch calls made                */

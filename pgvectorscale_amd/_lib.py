@@ -120,6 +120,7 @@ SYMBOLS = {
     "vs_last_error": (C.c_char_p, []),
     "vs_version": (C.c_char_p, []),
     "vs_ctx_create": (_i, [_i, C.POINTER(_vp)]),
+    "vs_ctx_create_staging": (_i, [_i, _sz, C.POINTER(_vp)]),
     "vs_ctx_destroy": (None, [_vp]),
     "vs_ctx_sync": (_i, [_vp]),
     "vs_ctx_stream": (_vp, [_vp]),

@@ -7,6 +7,9 @@
 #include <algorithm>
 #include <cstdlib>
 
+#include <mutex>
+#include <unordered_map>
+
 #include "vs_internal.h"
 
 static thread_local char g_err[1024] = "";
@@ -45,8 +48,13 @@ void devbuf_free(DevBuf& b) {
 // ---------------------------------------------------------------------------------------------------------------
 static const size_t kPinnedBytes = 32u << 20;  // 2 x 32 MiB staging ring
 
-extern "C" int vs_ctx_create(int device, vs_ctx** out) {
+extern "C" int vs_ctx_create_staging(int device, size_t staging_bytes, vs_ctx** out);
+extern "C" int vs_ctx_create(int device, vs_ctx** out) { return vs_ctx_create_staging(device, kPinnedBytes, out); }
+
+extern "C" int vs_ctx_create_staging(int device, size_t staging_bytes, vs_ctx** out) {
     VS_REQUIRE(out != nullptr, "vs_ctx_create: out is NULL");
+    VS_REQUIRE(staging_bytes >= 4096 && staging_bytes <= ((size_t)1 << 32), "vs_ctx_create_staging: %zu bytes per staging buffer outside [4 KiB, 4 GiB]",
+               staging_bytes);
     *out = nullptr;
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -61,7 +69,7 @@ extern "C" int vs_ctx_create(int device, vs_ctx** out) {
     VS_HIP(hipGetDeviceProperties(&c->prop, device));
     VS_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     VS_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
-    c->pinned_bytes = kPinnedBytes;
+    c->pinned_bytes = staging_bytes;
     for (int i = 0; i < 2; ++i) {
         VS_HIP(hipHostMalloc(&c->pinned[i], c->pinned_bytes, hipHostMallocDefault));
         VS_HIP(hipEventCreateWithFlags(&c->pinned_ev[i], hipEventDisableTiming));
@@ -388,8 +396,41 @@ static int index_alloc_common(vs_ctx* c, const vs_index_desc* desc, bool with_ve
     return VS_OK;
 }
 
+// views point into their source's arrays: the count of live views is what lets the entry points that free or move those arrays
+// (label sets, start map) refuse while a lane / a second stream / a vs_multi shard could still launch on the old pointers
+static std::mutex vs_view_mu;
+static std::unordered_map<const vs_index*, int> vs_view_count;  // owner -> live views (owners without views have no entry)
+int vs_index_live_views(vs_index* ix) {
+    std::lock_guard<std::mutex> lk(vs_view_mu);
+    const auto it = vs_view_count.find(ix);
+    return it == vs_view_count.end() ? 0 : it->second;
+}
+#define VS_REQUIRE_NO_VIEWS(ix, what)                                                                                                  \
+    do {                                                                                                                                \
+        const int _nv = vs_index_live_views(ix);                                                                                        \
+        if (_nv > 0) {                                                                                                                  \
+            vs_set_error("%s: %d view(s) of this index are alive (cursor lanes, a second stream, a vs_multi shard) and hold its device " \
+                         "pointers; free them first",                                                                                  \
+                         what, _nv);                                                                                                    \
+            return VS_ERR_STATE;                                                                                                        \
+        }                                                                                                                               \
+    } while (0)
+
 extern "C" void vs_index_free(vs_index* ix) {
     if (!ix) return;
+    {
+        std::lock_guard<std::mutex> lk(vs_view_mu);
+        if (ix->is_view) {
+            const auto it = vs_view_count.find(ix->view_of);  // (gone when the owner was freed first)
+            if (it != vs_view_count.end() && --it->second <= 0) vs_view_count.erase(it);
+        } else {
+            const auto it = vs_view_count.find(ix);
+            if (it != vs_view_count.end()) {
+                fprintf(stderr, "[libvsgpu] vs_index_free: %d view(s) of this index are still alive; they must not be used any more\n", it->second);
+                vs_view_count.erase(it);
+            }
+        }
+    }
     (void)hipSetDevice(ix->ctx->device);
     (void)hipStreamSynchronize(ix->ctx->stream);
     void* ptrs[] = {ix->codes, ix->nbrs, ix->tids, ix->vecs, ix->vnorm, ix->vnorm_idx, ix->mean, ix->m2, ix->visible_own,
@@ -418,6 +459,11 @@ static int vs_index_view_impl(vs_index* src, vs_ctx* c, vs_index** out) {
     vs_index* v = new vs_index(*src);  // the pointers and the geometry; the workspace below is this handle's own
     v->ctx = c;
     v->is_view = true;
+    {
+        std::lock_guard<std::mutex> lk(vs_view_mu);
+        v->view_of = src->is_view ? src->view_of : src;  // (a view of a view is a view of the owner)
+        vs_view_count[v->view_of]++;
+    }
     v->visible_own = nullptr;
     v->ws = SearchWorkspace{};
     v->last_stats = vs_stats{};
@@ -469,6 +515,7 @@ extern "C" int vs_index_get_quantizer(const vs_index* ix, float* mean, float* m2
 static int vs_index_set_start_nodes_impl(vs_index* ix, uint32_t default_start, const int16_t* labels,
                                         const uint32_t* nodes, uint32_t n) {
     VS_REQUIRE(ix, "vs_index_set_start_nodes: index is NULL");
+    VS_REQUIRE_NO_VIEWS(ix, "vs_index_set_start_nodes");
     VS_REQUIRE(default_start == VS_INVALID_NODE || default_start < ix->d.n, "default_start out of range");
     for (uint32_t i = 0; i < n; ++i) {
         VS_REQUIRE(nodes[i] < ix->d.n, "label start node out of range");
@@ -496,6 +543,7 @@ extern "C" int vs_index_set_start_nodes(vs_index* ix, uint32_t default_start, co
 
 static int vs_index_set_labels_impl(vs_index* ix, const uint32_t* label_off, const int16_t* label_val) {
     VS_REQUIRE(ix && label_off, "vs_index_set_labels: bad args");
+    VS_REQUIRE_NO_VIEWS(ix, "vs_index_set_labels");
     const uint32_t n = ix->d.n;
     VS_REQUIRE(label_off[0] == 0, "label_off[0] must be 0");
     for (uint32_t i = 0; i < n; ++i) {
@@ -863,6 +911,8 @@ static uint32_t knob_u32(const char* name, int tuned, uint32_t dflt) {
     return tuned >= 0 ? (uint32_t)tuned : dflt;
 }
 
+static uint32_t gload_pct() { return std::min<uint32_t>(std::max<uint32_t>(env_u32("VS_F_GLOAD_PCT", 75), 25), 90); }
+
 static Caps initial_caps(const vs_index* ix, uint32_t L, uint32_t M) {
     // visits ~ 1.1-2 L before the first row + one per further row; each visit pushes <= R candidates.
     uint64_t visits = 2ull * L + M + 32;
@@ -924,7 +974,8 @@ static Caps initial_caps(const vs_index* ix, uint32_t L, uint32_t M) {
         // (load limit 75 %, a few per cent of slack; a scan that still outgrows it takes the second attempt) instead of the
         // next power of two
         if (!lds_table && ix->obs.valid && ix->obs.L == L && ix->obs.M == M && env_u32("VS_F_GCAP_FIT", 1)) {
-            const uint64_t need = (uint64_t)((ix->obs.ins_max * 1.04 + 128) * 4.0 / 3.0) + 64;
+            // (load limit: 75 %; VS_F_GLOAD_PCT moves it — a denser table is a smaller cache footprint and longer probe runs)
+            const uint64_t need = (uint64_t)((ix->obs.ins_max * 1.04 + 128) * 100.0 / gload_pct()) + 64;
             c.f_gcap = (uint32_t)std::min<uint64_t>(c.f_gcap, std::max<uint64_t>(round_up_u32((uint32_t)std::min<uint64_t>(need, 1u << 22), 256), 1024));
         }
         if (const uint32_t g = env_u32("VS_F_GCAP", lds_table ? 0 : ix->tune.gcap)) c.f_gcap = round_up_u32(std::max<uint32_t>(g, 256), 256);
@@ -1104,6 +1155,7 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
         f.gstride = caps.f_gstride;
         f.vr = caps.f_vr;
         f.gcap = caps.f_gcap;
+        f.glimit = (uint32_t)((uint64_t)caps.f_gcap * gload_pct() / 100) - 64u;
         f.lh = caps.f_lh;
         f.minw = knob_u32("VS_F_MINW", (caps.f_lh == 0 && !caps.f_vr) ? ix->tune.minw : -1, caps.f_lh == 0 ? (caps.f_vr ? 4 : 6) : 1);
         f.flags = env_u32("VS_F_FLAGS", 0);
@@ -1120,7 +1172,9 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
         // ... or (VS_F_VIRGIN=2) one bit per SLOT: linear probing at slot granularity with the occupancy known on chip, so most new
         // ids are stored without a load of the table; 32 slots per LDS word — taken only while it costs no scans per CU (else the
         // bucket bitmap runs)
-        const uint32_t vmode = knob_u32("VS_F_VIRGIN", ix->tune.virgin, 0);
+        // Default since round 4's third GPU session: the slot bitmap — 161.1 ms per 262 144 scans at 50M against 167.9 with the bucket
+        // bitmap and 171.2 with cleared tables, 125.8 / 129.7 / 130.1 at 10M (profiles/r04/s3_ab_slotmap_*.txt); 639 device fuzz cases.
+        const uint32_t vmode = knob_u32("VS_F_VIRGIN", ix->tune.virgin, 2);
         if (caps.f_lh == 0 && !want_epoch && !f.vr && vmode && !env_u32("VS_PHASE", 0) && f.gcap <= (1u << 16)) {
             f.vwords = (f.gcap + 127) / 128;
             if (vmode == 2 && !f.rc && f.gcap % 32 == 0) {
@@ -1231,6 +1285,7 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
             r.fb_flag = (uint32_t*)w.fb_flag.p;
             r.phase = nullptr;
             r.gcap = (uint32_t)std::min<uint64_t>(4ull * f.gcap, 1u << 22);
+            r.glimit = 0;  // (75 % of the larger table)
             r.hcap = (uint32_t)std::min<uint64_t>(2ull * f.hcap, 1u << 22);
             r.gstride = round_up_u32(r.hcap - r.hl + 2, 2);
             if (!r.vr) r.vcap = 2 * f.vcap;
@@ -1659,7 +1714,9 @@ static const TuneCand kTuneCands[] = {
     {"default", -1, -1, -1, 0},
     {"bucket_bitmap", 0, 1, -1, 0},         // no clear, no read of a bucket the scan has not written (11b.16)
     {"bucket_bitmap_16k", 0, 1, -1, 16384}, // ... with a sparser table (more first-touch buckets per probe, more lines)
-    {"slot_bitmap", 0, 2, -1, 0},           // occupancy bit per slot, linear probing: a new id whose home slot is free costs no load
+    {"cleared_tables", 0, 0, -1, 0},        // round 3's default: every scan clears its table, every probe loads a bucket
+    // (the library default in the table-less regime is the SLOT bitmap, VS_F_VIRGIN=2: an occupancy bit per slot, linear probing, a new
+    // id whose home slot is free costs no load)
     // (no longer candidates: the epoch tags — exact on hardware since round 4's first session, profiles/r04/s1_fuzz_gpu_epoch*.txt,
     // but no faster than the bitmaps at 50M (s1_ab_virgin_50m.txt) and not compatible with the persistent grid's per-workgroup
     // regions — and the two-row gather at 5 waves per SIMD, 2.8-7.3 % slower at 10M / 50M in the same session; VS_F_EPOCH=1 and

@@ -298,7 +298,7 @@ int vs_broker_create(vs_index* idx, const vs_broker_config* cfg, vs_broker** out
         if (const char* e = getenv("VS_BROKER_LANES")) b->cfg.cursor_lanes = std::min<uint32_t>((uint32_t)strtoul(e, nullptr, 10), 64);  // test tier runs on lanes)
     for (uint32_t i = 0; i < b->cfg.cursor_lanes; ++i) {
         std::unique_ptr<Lane> ln(new (std::nothrow) Lane());
-        rc = ln ? vs_ctx_create(vs_index_device(idx), &ln->ctx) : VS_ERR_OOM;
+        rc = ln ? vs_ctx_create_staging(vs_index_device(idx), (size_t)1 << 20, &ln->ctx) : VS_ERR_OOM;  // (a lane moves one query in and a few rows out)
         if (rc == VS_OK) rc = vs_index_view(idx, ln->ctx, &ln->view);
         if (rc != VS_OK) {  // (what was created so far goes away again; no thread has been started yet)
             if (ln && ln->ctx) vs_ctx_destroy(ln->ctx);

@@ -138,6 +138,7 @@ struct FastSig {
 struct vs_index {
     vs_ctx* ctx = nullptr;
     bool is_view = false;  // vs_index_view: the device arrays belong to another handle
+    vs_index* view_of = nullptr;  // ... that one (a key into the registry of live views, never dereferenced)
     vs_index_desc d{};
     uint32_t code_stride = 0;  // u64 words per code row (W rounded up to even, zero padded)
     uint32_t nbr_stride = 0;   // u32 per neighbor row (R rounded up to 16)
@@ -176,6 +177,7 @@ struct vs_index {
 };
 
 int devbuf_reserve(vs_ctx* ctx, DevBuf& b, size_t bytes);
+int vs_index_live_views(vs_index* ix);  // views made of ix that have not been freed yet
 // row-wise staging through the pinned ring (device rows may be wider than host rows) / neighbor-list validation
 int vs_upload_rows(vs_ctx* c, void* dst, size_t dev_row_bytes, const void* src, size_t host_row_bytes, size_t copy_bytes, size_t rows);
 int vs_validate_graph(vs_index* ix);
@@ -226,7 +228,8 @@ struct FastLaunch {
     uint32_t hcap;     // total heap capacity; positions [hl, hcap) live in heap_g
     uint32_t gstride;  // u32 per scan in heap_g (even, >= hcap - hl + 2)
     uint32_t lh;       // slots of the LDS dedup table (multiple of 4)
-    uint32_t gcap;     // slots of the per-scan global overflow dedup table (power of two), handles lh .. lh + gcap - 1
+    uint32_t gcap;     // slots of the per-scan global overflow dedup table (a multiple of 256), handles lh .. lh + gcap - 1
+    uint32_t glimit = 0;  // ids the global table may hold when a visit starts (gcap x load limit - one wave of inserts); a scan beyond it is handed to the second attempt
     uint32_t sb;       // bits of a slot handle inside a heap entry (lh + gcap <= 1 << sb)
     uint32_t vr;       // visited list: 8 = eight register pairs (512 entries), 0 = LDS ring of vcap entries
     uint32_t vcap;     // visited ring capacity (vr == 0)

@@ -471,6 +471,7 @@ static int vs_comm_replicate_index_impl(vs_comm* c, vs_index* ix, uint32_t root)
     VS_REQUIRE(ix->ctx->device == c->ctx->device, "vs_comm_replicate_index: the index lives on device %d, the communicator on %d",
                ix->ctx->device, c->ctx->device);
     VS_REQUIRE(!ix->is_view, "vs_comm_replicate_index: a view does not own its arrays");
+    VS_REQUIRE(c->rank == root || vs_index_live_views(ix) == 0, "vs_comm_replicate_index: views of the receiving index are alive");
     VS_HIP(hipSetDevice(c->ctx->device));
     const bool is_root = c->rank == root;
     hipStream_t s = c->ctx->stream;

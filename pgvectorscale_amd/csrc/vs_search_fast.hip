@@ -447,30 +447,25 @@ struct FastHeap {
         const uint32_t end = len;
         uint32_t root = 0, pos = 0;
         uint32_t pkey = 0;  // key of the value now stored in the parent of `root` (0 for the heap root: never moves)
-        // Rounds are cut at the LDS / spill-array boundary: a round reads the CHILDREN of its nodes, so with levels 0 .. ll1 in LDS
-        // (ll1 = 8 for a 511-entry top) the rounds are node levels 0-5, 6 .. ll1 - 1 (both LDS only) and then ll1 .. ll1 + 5 from
-        // the spill array — ONE dependent trip to memory for a heap of up to 2^(ll1 + 7) entries, where rounds of six levels each
-        // made two (6-11 straddling the boundary, then 12-17).
-        const uint32_t ll1 = 30u - (uint32_t)__builtin_clz(hl + 1u);
-        uint32_t rl = 0;  // level of `root`
+        // (rounds cut at the LDS / spill-array boundary instead — node levels 0-5, 6-7, then 8-13 from the spill array — were tried in
+        // round 4: exact, and no faster at 10M / 50M, profiles/r04/s3_ab_slotmap_*.txt; a heap of up to 8190 entries already needs only one
+        // round that reads the spill array)
         for (;;) {
-            const bool lds_round = all_lds || rl < ll1;
-            const uint32_t depth = lds_round && !all_lds ? min(6u, ll1 - rl) : 6u;  // node levels of this round
-            // one subtree per iteration: lane j < 63 is the node with relative heap index j
+            // one 6-level subtree per iteration: lane j < 63 is the node with relative heap index j
             const uint32_t aidx = ((root + 1) << lvl()) + offm1();
             const uint32_t c = 2 * aidx + 1;
-            const bool exists = aidx < end && lvl() < depth, have1 = c < end, have2 = c + 1 < end;
+            const bool exists = aidx < end, have1 = c < end, have2 = c + 1 < end;
             uint32_t le = 0, ri = 0;
-            if (lds_round) {
-                if (exists && have1) {
+            if (have1) {
+                if (all_lds || c < hl) {
                     const uint2 p = *reinterpret_cast<const uint2*>(l + c + 1);
                     le = p.x;
                     ri = p.y;
+                } else {
+                    const uint64_t p = gload64u(reinterpret_cast<const uint64_t*>(g + (c - hl)));
+                    le = (uint32_t)p;
+                    ri = (uint32_t)(p >> 32);
                 }
-            } else if (exists && have1) {
-                const uint64_t p = gload64u(reinterpret_cast<const uint64_t*>(g + (c - hl)));
-                le = (uint32_t)p;
-                ri = (uint32_t)(p >> 32);
             }
             // child += (data[child] <= data[child+1]); Reverse => right.d <= left.d picks the right child
             const bool pick = have2 && (ri >> sb) <= (le >> sb);
@@ -493,8 +488,7 @@ struct FastHeap {
                 break;
             }
             pkey = readlane_u32(cv, jd) >> sb;
-            root = 2 * ad + 1 + (uint32_t)((B >> jd) & 1ull);  // jd is on the round's last level: descend
-            rl += depth;
+            root = 2 * ad + 1 + (uint32_t)((B >> jd) & 1ull);  // jd is on the subtree's last level: descend
             if (2 * root + 1 >= end) {  // ... unless the child is a leaf (a heap of 4096..8190 entries ends every path here)
                 pos = root;
                 break;
@@ -1036,7 +1030,7 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
         }
         if (!__ballot(need_g)) return false;
         if (!open_table()) return false;
-        if ((nins_g + WAVE) * 4u > s.gcap * 3u) {
+        if (nins_g > s.glimit) {
             status |= OVF_HASH;
             return false;
         }
@@ -1183,7 +1177,7 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
                 vtid = a.tids[node_v];
                 if (visible) vvis = visible[node_v];
             }
-            if (gmode && (nins_g + WAVE) * 4u <= s.gcap * 3u) {
+            if (gmode && nins_g <= s.glimit) {
                 early = true;
                 const uint64_t inval0 = __ballot(row0 == VS_INVALID_NODE);
                 const bool act0 = (uint32_t)lane < (inval0 ? (uint32_t)__builtin_ctzll(inval0) : WAVE);
@@ -1253,11 +1247,11 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
                 virg = virg0;
                 pret = pret0;
             } else if (gmode && VG == 2) {
-                if ((nins_g + WAVE) * 4u > s.gcap * 3u) { status |= OVF_HASH; break; }
+                if (nins_g > s.glimit) { status |= OVF_HASH; break; }
                 pret = act ? slot_run(hslot) : 0u;
                 if (pret) gbk = *reinterpret_cast<const uint4*>(ghash + (hslot & ~3u));  // in flight during the visited insert
             } else if (gmode) {
-                if ((nins_g + WAVE) * 4u > s.gcap * 3u) { status |= OVF_HASH; break; }
+                if (nins_g > s.glimit) { status |= OVF_HASH; break; }
                 if (rcv && act) rchit = rc[hash_u32(nid ^ 0x9e3779b9u) & rcm] == nid;
                 if (act && !rchit) gbk = bucket_fetch(hslot, virg);  // in flight during the visited insert
             } else if (!frozen && act) {
@@ -1559,6 +1553,7 @@ static int fast_dispatch(vs_index* idx, const FastLaunch& s, uint32_t* res) {
     a.n_ls = idx->d.n_label_starts;
     a.default_start = idx->d.default_start;
     a.s = s;
+    if (!a.s.glimit) a.s.glimit = s.gcap / 4 * 3 - WAVE;  // 75 % load, less the ids one visit can add
     const size_t lds = fast_lds_bytes(idx, s);
     VS_REQUIRE(lds <= 160 * 1024, "fast search state does not fit LDS (%zu B)", lds);
     VS_REQUIRE(((s.hl + 1) & s.hl) == 0 && s.hl >= 63, "fast search: hl must be 2^k - 1 >= 63");

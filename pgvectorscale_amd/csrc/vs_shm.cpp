@@ -13,8 +13,10 @@
 //   -> FREE (client copied them out).  A slot whose owner process died is reclaimed by the dispatcher (CLAIMED / DONE ->
 //   REAPING -> FREE, owner pid cleared before the slot is free again, so a slot is never freed under a live client); a client
 //   whose dispatcher PROCESS died (no orderly vs_shm_server_destroy) notices through the pid in the header and fails with
-//   VS_ERR_STATE instead of sleeping forever.  The dispatcher trusts nothing it reads from a slot: k, the GUCs and the label
-//   count are validated again on its side before a group is formed.
+//   VS_ERR_STATE instead of sleeping forever.  The dispatcher trusts nothing it reads from a slot, and reads it ONCE: when a
+//   posted slot is taken (READY -> RUNNING) its request — k, the GUCs, the label key, the query vector, the scan id — is copied
+//   into the dispatcher's own memory and validated THERE; everything that follows (grouping, launches, how many rows are
+//   written back and where) uses that copy and the geometry the dispatcher wrote, never the slot or the header again.
 //
 // Streaming (amgettuple beyond the first rows): a slot request is either OP_SEARCH — the first k rows, out of a launch shared
 // with the other backends' scans — or OP_FETCH: rows [skip, skip + k) of the scan (owner pid, scan_id), which the dispatcher
@@ -98,14 +100,24 @@ size_t slot_size(uint32_t dim_full, uint32_t kmax) {
 struct Mapping {
     void* base = nullptr;
     size_t bytes = 0;
+    // the segment's geometry as this process read it ONCE (server: as it wrote it): the header lives in memory every client can
+    // write, so no address is ever computed from the header again
+    uint32_t nslots = 0, dim_full = 0, kmax = 0, slot_bytes = 0;
+    void pin() {
+        const ShmHeader* h = hdr();
+        nslots = h->nslots;
+        dim_full = h->dim_full;
+        kmax = h->kmax;
+        slot_bytes = h->slot_bytes;
+    }
     ShmHeader* hdr() const { return static_cast<ShmHeader*>(base); }
     SlotHead* slot(uint32_t i) const {
-        return reinterpret_cast<SlotHead*>(static_cast<char*>(base) + align16(sizeof(ShmHeader)) + (size_t)i * hdr()->slot_bytes);
+        return reinterpret_cast<SlotHead*>(static_cast<char*>(base) + align16(sizeof(ShmHeader)) + (size_t)i * slot_bytes);
     }
     static float* query(SlotHead* s) { return reinterpret_cast<float*>(reinterpret_cast<char*>(s) + sizeof(SlotHead)); }
-    uint64_t* tids(SlotHead* s) const { return reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(query(s)) + align16((size_t)hdr()->dim_full * 4)); }
-    uint32_t* ids(SlotHead* s) const { return reinterpret_cast<uint32_t*>(tids(s) + hdr()->kmax); }
-    float* dist(SlotHead* s) const { return reinterpret_cast<float*>(ids(s) + hdr()->kmax); }
+    uint64_t* tids(SlotHead* s) const { return reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(query(s)) + align16((size_t)dim_full * 4)); }
+    uint32_t* ids(SlotHead* s) const { return reinterpret_cast<uint32_t*>(tids(s) + kmax); }
+    float* dist(SlotHead* s) const { return reinterpret_cast<float*>(ids(s) + kmax); }
 };
 
 int futex_wait(std::atomic<uint32_t>* addr, uint32_t expected, int timeout_us) {
@@ -132,7 +144,8 @@ struct vs_shm_server {
     struct PendingPut { uint32_t snapshot; bool drop; std::vector<uint8_t> mask; int rc = 1; std::string err; };
     std::mutex put_mu;
     std::condition_variable put_cv;
-    std::vector<PendingPut*> puts;
+    std::vector<std::shared_ptr<PendingPut>> puts;  // (shared: a caller that gives up at shutdown leaves nothing dangling behind)
+    std::atomic<int> put_callers{0};               // threads inside vs_shm_server_snapshot_put (destroy waits for them)
     // cursors of the scans that are being streamed (OP_FETCH), touched by the dispatcher thread only
     struct Cursor {
         int32_t pid = 0;
@@ -147,6 +160,17 @@ struct vs_shm_server {
         uint64_t use_clock = 0;
     };
     CursorTable main_tab;
+    // the dispatcher's private copy of a taken slot's request (see the header comment): filled by take(), read by run_group /
+    // run_fetch (a lane reads the copy of the slot it was handed: the slot is RUNNING until that lane marks it DONE)
+    struct Req {
+        uint32_t L = 0, rescore = 0, k = 0, n_labels = 0, has_label_key = 0, null_query = 0, snapshot = 0, op = 0, skip = 0;
+        uint64_t scan_id = 0;
+        int32_t owner_pid = 0;
+        int16_t labels[SHM_MAX_LABELS] = {0};
+        std::vector<float> query;
+    };
+    std::vector<Req> reqs;
+    const char* take(uint32_t slot);  // copies + validates; nullptr = accepted, else why not
     // cursor lanes (vs_broker_config.cursor_lanes): a thread, a context (HIP stream) and a view of the index each; a streamed scan
     // is served by the lane its (client pid, scan id) hashes to, concurrently with the other lanes and with the shared launches
     struct Lane {
@@ -175,11 +199,38 @@ struct vs_shm_client {
     Mapping m;
 };
 
+const char* vs_shm_server::take(uint32_t slot) {
+    SlotHead* s = m.slot(slot);
+    Req& r = reqs[slot];
+    r.L = s->L;
+    r.rescore = s->rescore;
+    r.k = s->k;
+    r.n_labels = s->n_labels;
+    r.has_label_key = s->has_label_key;
+    r.null_query = s->null_query;
+    r.snapshot = s->snapshot;
+    r.op = s->op;
+    r.skip = s->skip;
+    r.scan_id = s->scan_id;
+    r.owner_pid = s->owner_pid;
+    if (r.k == 0 || r.k > m.kmax) return "k outside [1, kmax]";
+    if (r.n_labels > SHM_MAX_LABELS) return "more labels than a slot holds";
+    if (r.L < 1 || r.L > 10000) return "diskann.query_search_list_size outside [1,10000]";
+    if (r.rescore > 1000) return "diskann.query_rescore outside [0,1000]";
+    if (r.snapshot >= VS_MAX_SNAPSHOTS) return "snapshot id out of range";
+    if (r.op > OP_CLOSE) return "unknown request kind";
+    if (r.op == OP_FETCH && (uint64_t)r.skip + r.k > (1u << 30)) return "row position out of range";
+    memcpy(r.labels, s->labels, (size_t)r.n_labels * sizeof(int16_t));
+    r.query.resize(d.dim_full);
+    if (!r.null_query) memcpy(r.query.data(), Mapping::query(s), (size_t)d.dim_full * 4);
+    return nullptr;
+}
+
 void vs_shm_server::run_group(const std::vector<uint32_t>& grp) {
     const uint32_t nq = (uint32_t)grp.size();
-    SlotHead* head = m.slot(grp[0]);
-    const uint32_t k = head->k;
-    const bool keys = head->has_label_key != 0;
+    const Req& head = reqs[grp[0]];
+    const uint32_t k = head.k;
+    const bool keys = head.has_label_key != 0;
     int rc = VS_OK;
     std::string err;
     std::vector<float> q;
@@ -191,9 +242,9 @@ void vs_shm_server::run_group(const std::vector<uint32_t>& grp) {
         q.assign((size_t)nq * d.dim_full, 0.0f);  // a NULL query is the zero vector (AM/labels/mod.rs:214-216)
         off.assign(nq + 1, 0);
         for (uint32_t i = 0; i < nq; ++i) {
-            SlotHead* s = m.slot(grp[i]);
-            if (!s->null_query) memcpy(&q[(size_t)i * d.dim_full], Mapping::query(s), (size_t)d.dim_full * 4);
-            if (keys && !s->null_query) lab.insert(lab.end(), s->labels, s->labels + std::min(s->n_labels, SHM_MAX_LABELS));
+            const Req& r = reqs[grp[i]];
+            if (!r.null_query) memcpy(&q[(size_t)i * d.dim_full], r.query.data(), (size_t)d.dim_full * 4);
+            if (keys && !r.null_query) lab.insert(lab.end(), r.labels, r.labels + r.n_labels);
             off[i + 1] = (uint32_t)lab.size();
         }
         ids.assign((size_t)nq * k, 0);
@@ -201,9 +252,9 @@ void vs_shm_server::run_group(const std::vector<uint32_t>& grp) {
         dist.assign((size_t)nq * k, 0.0f);
         vs_stats st{};
         const uint8_t* prev = nullptr;  // the group's snapshot mask for the duration of the launch
-        rc = vs_index_snapshot_use(ix, head->snapshot, &prev);
+        rc = vs_index_snapshot_use(ix, head.snapshot, &prev);
         if (rc == VS_OK) {
-            rc = vs_search_batch(ix, q.data(), keys ? lab.data() : nullptr, keys ? off.data() : nullptr, nq, head->L, head->rescore, k,
+            rc = vs_search_batch(ix, q.data(), keys ? lab.data() : nullptr, keys ? off.data() : nullptr, nq, head.L, head.rescore, k,
                                  ids.data(), tids.data(), dist.data(), &st);
             if (rc != VS_OK) err = vs_last_error();
             (void)vs_index_set_visibility_dev(ix, prev);
@@ -246,7 +297,8 @@ void vs_shm_server::reap_cursors(CursorTable& t) {
 }
 
 // what identifies the scan a cursor belongs to besides (pid, scan_id): a client that reuses an id for another scan gets a new cursor
-static uint64_t scan_signature(const SlotHead* s, const float* q, uint32_t dim) {
+template <class R>
+static uint64_t scan_signature(const R* s, const float* q, uint32_t dim) {
     uint64_t h = 1469598103934665603ull;
     auto mix = [&](const void* p, size_t n) {
         const unsigned char* b = static_cast<const unsigned char*>(p);
@@ -255,14 +307,15 @@ static uint64_t scan_signature(const SlotHead* s, const float* q, uint32_t dim) 
     const uint32_t g[6] = {s->L, s->rescore, s->has_label_key, s->null_query, s->snapshot, s->n_labels};
     mix(g, sizeof(g));
     if (!s->null_query) mix(q, (size_t)dim * 4);
-    mix(s->labels, (size_t)std::min(s->n_labels, SHM_MAX_LABELS) * 2);
+    mix(s->labels, (size_t)std::min<uint32_t>(s->n_labels, SHM_MAX_LABELS) * 2);
     return h;
 }
 
 void vs_shm_server::run_fetch(uint32_t slot, CursorTable& t) {
     std::vector<Cursor>& cursors = t.cursors;
     vs_index* const ix = t.ix;  // (shadows the member: the handle this table's scans run through)
-    SlotHead* s = m.slot(slot);
+    SlotHead* const out = m.slot(slot);  // written (results), never read
+    const Req* const s = &reqs[slot];    // the request as it was taken
     int rc = VS_OK;
     std::string err;
     uint32_t got = 0;
@@ -274,7 +327,7 @@ void vs_shm_server::run_fetch(uint32_t slot, CursorTable& t) {
         if (s->op == OP_CLOSE) {
             if (at < cursors.size()) drop_cursor(t, at);
         } else {
-            const uint64_t sig = scan_signature(s, Mapping::query(s), d.dim_full);
+            const uint64_t sig = scan_signature(s, s->query.data(), d.dim_full);
             const uint8_t* prev = nullptr;
             rc = vs_index_snapshot_use(ix, s->snapshot, &prev);
             if (rc == VS_OK) {
@@ -295,7 +348,7 @@ void vs_shm_server::run_fetch(uint32_t slot, CursorTable& t) {
                     c.sig = sig;
                     rc = vs_beginscan(ix, &c.scan);
                     if (rc == VS_OK)
-                        rc = vs_rescan(c.scan, s->null_query ? nullptr : Mapping::query(s), s->labels, std::min(s->n_labels, SHM_MAX_LABELS),
+                        rc = vs_rescan(c.scan, s->null_query ? nullptr : s->query.data(), s->labels, s->n_labels,
                                        (int)s->has_label_key, s->L, s->rescore);
                     if (rc == VS_OK) rc = vs_scan_prefetch(c.scan, s->skip + s->k);  // (one launch for the replay and the new rows)
                     for (uint32_t i = 0; rc == VS_OK && i < s->skip; ++i) {  // fast-forward: the client has these rows
@@ -322,7 +375,7 @@ void vs_shm_server::run_fetch(uint32_t slot, CursorTable& t) {
                     c.last_use = ++t.use_clock;
                     // (a fast-forward that fell short: the scan has fewer rows than the client skipped — nothing left to return)
                     while (c.pos >= s->skip && got < s->k) {
-                        const int r = vs_gettuple(c.scan, m.tids(s) + got, m.ids(s) + got, m.dist(s) + got);
+                        const int r = vs_gettuple(c.scan, m.tids(out) + got, m.ids(out) + got, m.dist(out) + got);
                         if (r < 0) {
                             rc = r;
                             err = vs_last_error();
@@ -343,20 +396,20 @@ void vs_shm_server::run_fetch(uint32_t slot, CursorTable& t) {
         err = "vs_shm: out of host memory while serving a scan cursor";
     }
     fetches++;
-    s->n_rows = rc == VS_OK ? got : 0;
-    s->rc = rc;
-    snprintf(s->err, sizeof(s->err), "%s", err.c_str());
-    s->state.store(S_DONE, std::memory_order_release);
-    futex_wake(&s->state, 1);
+    out->n_rows = rc == VS_OK ? got : 0;
+    out->rc = rc;
+    snprintf(out->err, sizeof(out->err), "%s", err.c_str());
+    out->state.store(S_DONE, std::memory_order_release);
+    futex_wake(&out->state, 1);
 }
 
 void vs_shm_server::apply_puts() {
     std::unique_lock<std::mutex> lk(put_mu);
     if (puts.empty()) return;
-    std::vector<PendingPut*> mine;
+    std::vector<std::shared_ptr<PendingPut>> mine;
     mine.swap(puts);
     lk.unlock();
-    for (PendingPut* p : mine) {
+    for (const std::shared_ptr<PendingPut>& p : mine) {
         int r;
         {
             struct Waiting {
@@ -412,7 +465,7 @@ void vs_shm_server::run() {
         const uint32_t seq = h->work_seq.load(std::memory_order_acquire);
         apply_puts();
         ready.clear();
-        for (uint32_t i = 0; i < h->nslots; ++i)
+        for (uint32_t i = 0; i < m.nslots; ++i)
             if (m.slot(i)->state.load(std::memory_order_acquire) == S_READY) ready.push_back(i);
         if (ready.empty()) {
             futex_wait(&h->work_seq, seq, 50000);  // (50 ms: also the cadence of the dead-owner check below)
@@ -421,13 +474,13 @@ void vs_shm_server::run() {
             // bumps work_seq and wakes this thread: look again and keep waiting for the rest of the window)
             // (only scans that can share a launch wait for company: a cursor request is served at once)
             bool any_search = false;
-            for (uint32_t i : ready) any_search |= m.slot(i)->op == OP_SEARCH;
+            for (uint32_t i : ready) any_search |= m.slot(i)->op == OP_SEARCH;  // (a hint for how long to gather; nothing is run on it)
             if (any_search && cfg.max_wait_us && ready.size() < cfg.max_batch) {
                 const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(cfg.max_wait_us);
                 for (;;) {
                     const uint32_t seq2 = h->work_seq.load(std::memory_order_acquire);
                     ready.clear();
-                    for (uint32_t i = 0; i < h->nslots; ++i)
+                    for (uint32_t i = 0; i < m.nslots; ++i)
                         if (m.slot(i)->state.load(std::memory_order_acquire) == S_READY) ready.push_back(i);
                     const auto now = std::chrono::steady_clock::now();
                     if (ready.size() >= cfg.max_batch || now >= deadline || stop.load()) break;
@@ -435,36 +488,32 @@ void vs_shm_server::run() {
                     futex_wait(&h->work_seq, seq2, (int)std::max<long long>(left, 1));
                 }
             }
-            // nothing read from a slot is trusted: a request outside the segment's limits is failed here, not run
+            // every posted slot is TAKEN here: READY -> RUNNING first (the client may no longer touch a RUNNING slot; one that does
+            // anyway changes nothing the dispatcher will read), then its request is copied and the copy validated; a request
+            // outside the segment's limits is failed, not run
             for (size_t a = 0; a < ready.size();) {
                 SlotHead* sa = m.slot(ready[a]);
-                const char* why = nullptr;
-                if (sa->k == 0 || sa->k > h->kmax) why = "k outside [1, kmax]";
-                else if (sa->n_labels > SHM_MAX_LABELS) why = "more labels than a slot holds";
-                else if (sa->L < 1 || sa->L > 10000) why = "diskann.query_search_list_size outside [1,10000]";
-                else if (sa->rescore > 1000) why = "diskann.query_rescore outside [0,1000]";
-                else if (sa->snapshot >= VS_MAX_SNAPSHOTS) why = "snapshot id out of range";
-                else if (sa->op > OP_CLOSE) why = "unknown request kind";
-                else if (sa->op == OP_FETCH && (uint64_t)sa->skip + sa->k > (1u << 30)) why = "row position out of range";
+                uint32_t exp = S_READY;
+                if (!sa->state.compare_exchange_strong(exp, S_RUNNING, std::memory_order_acq_rel)) {  // (reaped or withdrawn meanwhile)
+                    ready.erase(ready.begin() + (long)a);
+                    continue;
+                }
+                const char* why = take(ready[a]);
                 if (!why) {
                     ++a;
                     continue;
                 }
-                uint32_t exp = S_READY;
-                if (sa->state.compare_exchange_strong(exp, S_RUNNING)) {
-                    sa->rc = VS_ERR_INVALID;
-                    snprintf(sa->err, sizeof(sa->err), "vs_shm: request rejected by the dispatcher: %s", why);
-                    sa->state.store(S_DONE, std::memory_order_release);
-                    futex_wake(&sa->state, 1);
-                }
+                sa->rc = VS_ERR_INVALID;
+                snprintf(sa->err, sizeof(sa->err), "vs_shm: request rejected by the dispatcher: %s", why);
+                sa->state.store(S_DONE, std::memory_order_release);
+                futex_wake(&sa->state, 1);
                 ready.erase(ready.begin() + (long)a);
             }
             std::vector<bool> taken(ready.size(), false);
             for (size_t a = 0; a < ready.size(); ++a) {  // cursor requests: one scan each, served one after the other
-                SlotHead* ha = m.slot(ready[a]);
+                const Req* ha = &reqs[ready[a]];
                 if (ha->op == OP_SEARCH) continue;
                 taken[a] = true;
-                ha->state.store(S_RUNNING, std::memory_order_relaxed);
                 if (lanes.empty()) {
                     run_fetch(ready[a], main_tab);
                 } else {  // the lane this scan lives on: (client pid, scan id) -> lane, the same for every request of the scan
@@ -479,14 +528,13 @@ void vs_shm_server::run() {
             }
             for (size_t a = 0; a < ready.size(); ++a) {
                 if (taken[a]) continue;
-                SlotHead* ha = m.slot(ready[a]);
+                const Req* ha = &reqs[ready[a]];
                 std::vector<uint32_t> grp;
                 for (size_t b = a; b < ready.size() && grp.size() < cfg.max_batch; ++b) {
-                    SlotHead* hb = m.slot(ready[b]);
+                    const Req* hb = &reqs[ready[b]];
                     if (!taken[b] && hb->L == ha->L && hb->rescore == ha->rescore && hb->k == ha->k && hb->has_label_key == ha->has_label_key &&
                         hb->snapshot == ha->snapshot) {
                         taken[b] = true;
-                        hb->state.store(S_RUNNING, std::memory_order_relaxed);
                         grp.push_back(ready[b]);
                     }
                 }
@@ -497,7 +545,7 @@ void vs_shm_server::run() {
         const auto now = std::chrono::steady_clock::now();
         if (now - last_reap > std::chrono::milliseconds(200)) {
             last_reap = now;
-            for (uint32_t i = 0; i < h->nslots; ++i) {
+            for (uint32_t i = 0; i < m.nslots; ++i) {
                 SlotHead* s = m.slot(i);
                 uint32_t st = s->state.load(std::memory_order_acquire);
                 const int32_t pid = s->owner_pid;
@@ -523,7 +571,7 @@ void vs_shm_server::run() {
         if (l->th.joinable()) l->th.join();
     }
     // shutting down: fail what is still posted so that no client sleeps forever
-    for (uint32_t i = 0; i < h->nslots; ++i) {
+    for (uint32_t i = 0; i < m.nslots; ++i) {
         SlotHead* s = m.slot(i);
         uint32_t exp = S_READY;
         if (s->state.compare_exchange_strong(exp, S_RUNNING)) {
@@ -574,7 +622,7 @@ int vs_shm_server_create(vs_index* idx, const char* name, uint32_t nslots, uint3
     auto drop_lanes = [s] { free_lanes(s); };  // (no lane thread has been started yet)
     for (uint32_t i = 0; i < s->cfg.cursor_lanes; ++i) {
         std::unique_ptr<vs_shm_server::Lane> ln(new (std::nothrow) vs_shm_server::Lane());
-        rc = ln ? vs_ctx_create(vs_index_device(idx), &ln->ctx) : VS_ERR_OOM;
+        rc = ln ? vs_ctx_create_staging(vs_index_device(idx), (size_t)1 << 20, &ln->ctx) : VS_ERR_OOM;  // (a lane moves one query in and a few rows out)
         if (rc == VS_OK) rc = vs_index_view(idx, ln->ctx, &ln->tab.ix);
         if (ln) s->lanes.push_back(std::move(ln));
         if (rc != VS_OK) {
@@ -616,6 +664,8 @@ int vs_shm_server_create(vs_index* idx, const char* name, uint32_t nslots, uint3
     h->serving.store(1);
     std::atomic_thread_fence(std::memory_order_release);
     h->magic = SHM_MAGIC;  // last: a client that sees the magic sees a complete header
+    s->m.pin();
+    s->reqs.resize(nslots);
     for (auto& l : s->lanes) {
         vs_shm_server::Lane* lp = l.get();
         lp->th = std::thread([s, lp] { s->run_lane(*lp); });
@@ -646,7 +696,14 @@ void vs_shm_server_destroy(vs_shm_server* s) {
     futex_wake(&s->m.hdr()->work_seq, INT_MAX);
     if (s->dispatcher.joinable()) s->dispatcher.join();  // (run() joins the lanes before it returns)
     free_lanes(s);
-    s->put_cv.notify_all();
+    // callers still inside vs_shm_server_snapshot_put see `stop`, give up and leave before the object goes away
+    while (s->put_callers.load(std::memory_order_acquire) > 0) {
+        {
+            std::lock_guard<std::mutex> g(s->put_mu);
+        }
+        s->put_cv.notify_all();
+        std::this_thread::sleep_for(std::chrono::microseconds(200));
+    }
     munmap(s->m.base, s->m.bytes);
     shm_unlink(s->name.c_str());
     delete s;
@@ -690,42 +747,53 @@ int vs_shm_client_open(const char* name, vs_shm_client** out) {
     }
     c->m.base = p;
     c->m.bytes = (size_t)sb.st_size;
+    c->m.pin();  // (validated above against the size of the mapping)
     *out = c;
     return VS_OK;
 }
 
-uint32_t vs_shm_client_dim(const vs_shm_client* c) { return c ? c->m.hdr()->dim_full : 0; }
+uint32_t vs_shm_client_dim(const vs_shm_client* c) { return c ? c->m.dim_full : 0; }
 
 int vs_shm_server_snapshot_put(vs_shm_server* s, uint32_t snapshot, const uint8_t* visible) {
     if (!s || snapshot < 1 || snapshot >= VS_MAX_SNAPSHOTS) {
         vs_set_error("vs_shm_server_snapshot_put: snapshot id outside [1,%d]", VS_MAX_SNAPSHOTS - 1);
         return VS_ERR_INVALID;
     }
-    vs_shm_server::PendingPut p;
-    p.snapshot = snapshot;
-    p.drop = visible == nullptr;
+    struct Inside {
+        std::atomic<int>& n;
+        explicit Inside(std::atomic<int>& n_) : n(n_) { n.fetch_add(1, std::memory_order_acq_rel); }
+        ~Inside() { n.fetch_sub(1, std::memory_order_acq_rel); }
+    } inside(s->put_callers);
+    std::shared_ptr<vs_shm_server::PendingPut> p;
     try {
-        if (visible) p.mask.assign(visible, visible + s->d.n);
+        p = std::make_shared<vs_shm_server::PendingPut>();
+        p->snapshot = snapshot;
+        p->drop = visible == nullptr;
+        if (visible) p->mask.assign(visible, visible + s->d.n);
     } catch (const std::bad_alloc&) {
         vs_set_error("vs_shm_server_snapshot_put: out of host memory");
         return VS_ERR_OOM;
     }
     std::unique_lock<std::mutex> lk(s->put_mu);
-    s->puts.push_back(&p);
+    if (s->stop.load()) {
+        vs_set_error("vs_shm_server_snapshot_put: the dispatcher is shutting down");
+        return VS_ERR_STATE;
+    }
+    s->puts.push_back(p);
     s->m.hdr()->work_seq.fetch_add(1);
     futex_wake(&s->m.hdr()->work_seq, INT_MAX);
-    s->put_cv.wait(lk, [&] { return p.rc <= 0 || s->stop.load(); });
-    if (p.rc > 0) {  // the dispatcher stopped first
+    s->put_cv.wait(lk, [&] { return p->rc <= 0 || s->stop.load(); });
+    if (p->rc > 0) {  // the dispatcher stopped first (an entry it had already taken is its own: the shared_ptr keeps it alive)
         for (auto it = s->puts.begin(); it != s->puts.end(); ++it)
-            if (*it == &p) {
+            if (it->get() == p.get()) {
                 s->puts.erase(it);
                 break;
             }
         vs_set_error("vs_shm_server_snapshot_put: the dispatcher is shutting down");
         return VS_ERR_STATE;
     }
-    if (p.rc != VS_OK) vs_set_error("%s", p.err.c_str());
-    return p.rc;
+    if (p->rc != VS_OK) vs_set_error("%s", p->err.c_str());
+    return p->rc;
 }
 
 int vs_shm_client_search(vs_shm_client* c, const float* query, const int16_t* labels, uint32_t n_labels, int has_label_key,
@@ -743,8 +811,8 @@ static int client_request(vs_shm_client* c, uint32_t op, uint64_t scan_id, uint3
         return VS_ERR_INVALID;
     }
     ShmHeader* h = c->m.hdr();
-    if (k > h->kmax) {
-        vs_set_error("vs_shm_client_search: k = %u exceeds the segment's %u rows per scan", k, h->kmax);
+    if (k > c->m.kmax) {
+        vs_set_error("vs_shm_client_search: k = %u exceeds the segment's %u rows per scan", k, c->m.kmax);
         return VS_ERR_INVALID;
     }
     if (has_label_key && query && n_labels > SHM_MAX_LABELS) {
@@ -753,14 +821,14 @@ static int client_request(vs_shm_client* c, uint32_t op, uint64_t scan_id, uint3
     }
     // claim a slot (every backend holds at most one; the segment is sized for max_connections)
     SlotHead* s = nullptr;
-    const uint32_t start = (uint32_t)getpid() % h->nslots;
+    const uint32_t start = (uint32_t)getpid() % c->m.nslots;
     for (int spin = 0; !s; ++spin) {
         if (!h->serving.load(std::memory_order_acquire) || server_dead(h)) {
             vs_set_error("vs_shm_client_search: no dispatcher is attached to the segment");
             return VS_ERR_STATE;
         }
-        for (uint32_t i = 0; i < h->nslots && !s; ++i) {
-            SlotHead* cand = c->m.slot((start + i) % h->nslots);
+        for (uint32_t i = 0; i < c->m.nslots && !s; ++i) {
+            SlotHead* cand = c->m.slot((start + i) % c->m.nslots);
             uint32_t exp = S_FREE;
             if (cand->state.compare_exchange_strong(exp, S_CLAIMED, std::memory_order_acq_rel)) s = cand;
         }
@@ -780,7 +848,7 @@ static int client_request(vs_shm_client* c, uint32_t op, uint64_t scan_id, uint3
     s->has_label_key = (has_label_key && query) ? 1u : 0u;
     s->n_labels = s->has_label_key ? n_labels : 0u;
     if (s->n_labels) memcpy(s->labels, labels, (size_t)s->n_labels * 2);
-    if (query) memcpy(Mapping::query(s), query, (size_t)h->dim_full * 4);
+    if (query) memcpy(Mapping::query(s), query, (size_t)c->m.dim_full * 4);
     s->rc = VS_OK;
     s->state.store(S_READY, std::memory_order_release);
     h->work_seq.fetch_add(1, std::memory_order_acq_rel);

@@ -50,3 +50,33 @@ def test_batches_through_two_views_overlap_and_are_exact(gpu_ctx):
         vw.close()
         ix.close()
         ctx2.close()
+
+
+def test_entry_points_that_move_the_arrays_refuse_while_a_view_is_alive(gpu_ctx):
+    """a view holds its owner's device pointers: replacing the label sets or the start map frees what a lane / a second stream / a
+    vs_multi shard could still launch on — refused with VS_ERR_STATE until the last view is gone (freed in either order)"""
+    ti = cached_index(n=600, dim_full=32, bits=2, R=16, distance=1, seed=43, kind="gauss", L_build=30, n_labels=4)
+    ix = ti.upload(gpu_ctx)
+    ctx2 = P.Context(0)
+    vw = ix.view(ctx2)
+    vw2 = vw.view(ctx2)  # a view of a view is a view of the owner
+    try:
+        for _ in range(2):
+            with pytest.raises(P.VsError) as ei:
+                ix.set_labels(ti.label_off, ti.label_val)
+            assert ei.value.code == -5 and "view" in str(ei.value)
+            with pytest.raises(P.VsError):
+                ix.set_start_nodes(ti.start, ti.label_starts)
+            vw2.close()
+            vw2 = vw.view(ctx2)
+        vw2.close()
+        vw.close()
+        ix.set_labels(ti.label_off, ti.label_val)  # no view left: allowed again
+        ix.set_start_nodes(ti.start, ti.label_starts)
+        q = ti.queries(8, seed=3, kind="gauss")
+        gi, _, gd, _ = ix.search_batch(q, search_list_size=20, rescore=10, k=5)
+        oi, od, _ = ti.oracle.search_batch(q, L=20, rescore=10, k=5)
+        assert (gi == oi).all()
+    finally:
+        ix.close()
+        ctx2.close()

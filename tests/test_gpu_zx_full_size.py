@@ -128,8 +128,7 @@ def test_configs1_1m_x_768_clustered(gpu_ctx, oracle):
         ix.close()
 
 
-@pytest.mark.skipif(not os.environ.get("VS_TEST_FULL_10M"), reason="configs[2] at full size (10M x 768, cosine): a 35-second device build and "
-                    "31 GB of vectors to the host for the oracle — opt in with VS_TEST_FULL_10M=1 (a GPU session's job, scripts/r04_s1.sh)")
+# (in the default GPU tier since round 4: a 35-second device build and 31 GB of vectors to the host for the oracle's share)
 def test_configs2_10m_x_768_cosine(gpu_ctx, oracle):
     import pgvectorscale_amd as P
     from pgvectorscale_amd import _lib

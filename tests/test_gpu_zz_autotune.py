@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 EMU = bool(os.environ.get("VS_EMU"))
 REGIME = {"VS_F_LDS_MAX_INS": "0", "VS_F_VR": "0"}  # the table-less regime of large indexes (the variants exist only there)
-NAMES = ["default", "bucket_bitmap", "bucket_bitmap_16k", "slot_bitmap", "table_less", "table_less_bitmap", "lds_table_ring"]
+NAMES = ["default", "bucket_bitmap", "bucket_bitmap_16k", "cleared_tables", "table_less", "table_less_bitmap", "lds_table_ring"]
 LDS_REGIME_ONLY = NAMES[-3:]  # candidates for indexes whose default keeps the dedup table in LDS
 
 
@@ -147,11 +147,11 @@ def test_set_variant_by_name(gpu_ctx):
     ix = ti.upload(gpu_ctx)
     try:
         assert ix.variant() == "default"
-        ix.set_variant("slot_bitmap")
-        assert ix.variant() == "slot_bitmap"
+        ix.set_variant("cleared_tables")
+        assert ix.variant() == "cleared_tables"
         with pytest.raises(P.VsError):
             ix.set_variant("no_such_variant")
-        assert ix.variant() == "slot_bitmap"
+        assert ix.variant() == "cleared_tables"
         ix.set_variant("default")
         # a view inherits the choice of the index it was made from
         ix.set_variant("bucket_bitmap")

@@ -410,7 +410,7 @@ int vs_search_batch_dev_finish(vs_index* idx, vs_stats* stats);
 /* ---- launch-variant selection (ours; the reference has no counterpart — its only query-time knobs are the two GUCs above,
  * AM/guc.rs:3-43, and they stay the caller's).  The search kernel exists in several EXACT instantiations that differ only in
  * how a scan keeps its private state (dedup tables cleared per scan, a written-bucket bitmap, an occupancy bit per slot; for small
- * scans: dedup table in LDS or not).  Which is fastest depends on the index size and on the box, so it is measured
+ * scans: dedup table in LDS or not; DESIGN.md 3.1 / 4, docs/LAB_NOTEBOOK.md 10b).  Which is fastest depends on the index size and on the box, so it is measured
  * where it runs: vs_index_autotune runs every applicable variant on the caller's own device-resident batch (the arguments of
  * vs_search_batch_dev), `reps` timed steps each after one warm-up, holds every row, every distance bit and every work counter of
  * a variant to the library default's on the same batch, DISQUALIFIES a variant that differs anywhere (rows_identical = 0) and

@@ -1166,7 +1166,6 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
         f.visible = (!bp.stream_only && bp.rescore > 0) ? ix->visible : nullptr;  // the heap is only fetched for the rescore window
         f.rc = caps.f_lh == 0 ? env_u32("VS_F_RC", 0) : 0;  // (measurement: LDS id cache in front of the dedup table in HBM)
         if (f.rc) f.rc = next_pow2_u32(f.rc);
-        const bool want_epoch = caps.f_lh == 0 && knob_u32("VS_F_EPOCH", ix->tune.epoch, 0);
         // written-bucket bitmap (VS_F_VIRGIN=1, table-less regime): 128 slots of the table per LDS word; tables of more than
         // 64 Ki slots keep the clear (the bitmap would cost occupancy)
         // ... or (VS_F_VIRGIN=2) one bit per SLOT: linear probing at slot granularity with the occupancy known on chip, so most new
@@ -1175,7 +1174,7 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
         // Default since round 4's third GPU session: the slot bitmap — 161.1 ms per 262 144 scans at 50M against 167.9 with the bucket
         // bitmap and 171.2 with cleared tables, 125.8 / 129.7 / 130.1 at 10M (profiles/r04/s3_ab_slotmap_*.txt); 639 device fuzz cases.
         const uint32_t vmode = knob_u32("VS_F_VIRGIN", ix->tune.virgin, 2);
-        if (caps.f_lh == 0 && !want_epoch && !f.vr && vmode && !env_u32("VS_PHASE", 0) && f.gcap <= (1u << 16)) {
+        if (caps.f_lh == 0 && !f.vr && vmode && !env_u32("VS_PHASE", 0) && f.gcap <= (1u << 16)) {
             f.vwords = (f.gcap + 127) / 128;
             if (vmode == 2 && !f.rc && f.gcap % 32 == 0) {
                 FastLaunch g = f;
@@ -1191,54 +1190,23 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
             }
         }
         if (env_u32("VS_PHASE", 0)) f.phase = (uint64_t*)16;  // (selects the instantiation; the buffer is set below)
-        if (knob_u32("VS_F_PERSIST", ix->tune.persist, 1) && !want_epoch) {
+        if (knob_u32("VS_F_PERSIST", ix->tune.persist, 1)) {
             uint32_t res = 0;
             VS_TRY(fast_resident_scans(ix, f, &res));
             f.persist = std::max<uint32_t>(1, (uint32_t)((uint64_t)res * env_u32("VS_F_PERSIST_PCT", 100) / 100));
             fslots = std::min(f.persist, nq);
         }
         VS_TRY(devbuf_reserve(c, w.heap_g4, std::max<size_t>((size_t)(f.persist ? fslots : nq) * caps.f_gstride * 4, 16)));
-        const void* const ghash4_before = w.ghash4.p;
-        const size_t ghash4_bytes_before = w.ghash4.bytes;
         VS_TRY(devbuf_reserve(c, w.ghash4, (size_t)fslots * caps.f_gcap * 4));
-        // epoch-tagged dedup table (table-less regime): no scan clears its table; the array is zeroed when it is new, when the
-        // id width changes and when the epochs wrap (VS_F_EPOCH=0: plain ids, every scan clears its 64 KB)
-        uint32_t epoch = 0, eshift = 0;
-        // OFF by default (VS_F_EPOCH=1 switches it on): worth 2.2 % at 50M, but device fuzz case 777000331 returned wrong rows on
-        // the MI355X with the tags on (profiles/r03/s8_s9_epoch_bug_bisect.txt).  The cause was found on the interpreter after the
-        // round's GPU minutes were gone (the reallocation test below used to compare addresses) — the switch
-        // stays off until the fix has run on hardware.
-        if (want_epoch) {
-            while ((1ull << eshift) < (uint64_t)std::max<uint32_t>(ix->d.n, 2)) eshift++;
-            if (eshift <= 28) {  // >= 15 launches between two clears
-                const uint32_t last = std::min<uint32_t>((1u << (32 - eshift)) - 1u, env_u32("VS_F_EPOCH_MAX", 0xFFFFFFFFu));  // (the override lets a test see the wrap)
-                // (reallocated = the capacity changed; NOT "the address changed": a device allocator hands the range of the block just
-                // freed to the larger request that follows, and the part beyond the old block then holds what an earlier owner of
-                // those bytes left there — entries of another workspace, tagged with the same small epochs)
-                if (w.ghash4.bytes != ghash4_bytes_before || w.ghash4.p != ghash4_before || w.ghash4_eshift != eshift ||
-                    w.ghash4_epoch == 0 || w.ghash4_epoch >= last) {
-                    // zeroed by a kernel of our own, not by hipMemset: see launch_zero_fill
-                    if (env_u32("VS_F_EPOCH_DBG", 0) & 1) VS_HIP(hipMemsetAsync(w.ghash4.p, 0, w.ghash4.bytes, c->stream));  // (diagnostics: the old way)
-                    else VS_TRY(launch_zero_fill(c, w.ghash4.p, w.ghash4.bytes & ~(size_t)15));
-                    w.ghash4_epoch = 0;
-                    w.ghash4_eshift = eshift;
-                }
-                epoch = ++w.ghash4_epoch;
-            }
-        }
-        if (!epoch) w.ghash4_epoch = 0;  // (a launch with plain ids leaves entries a tagged launch could misread)
         VS_TRY(devbuf_reserve(c, w.pool_ctr, 64));
         VS_HIP(hipMemsetAsync(w.pool_ctr.p, 0, 64, c->stream));
         VS_TRY(devbuf_reserve(c, w.fb_flag, (size_t)nq * 4));
         VS_HIP(hipMemsetAsync(w.fb_flag.p, 0, (size_t)nq * 4, c->stream));
-        if (want_epoch && !epoch) f.vwords = f.vslot = 0;
         f.heap_g = (uint32_t*)w.heap_g4.p;
         f.ghash = (uint32_t*)w.ghash4.p;
         f.pool_counter = (uint32_t*)w.pool_ctr.p;
         f.scan_counter = (uint32_t*)w.pool_ctr.p + 2;
         f.pool_slots = fslots;
-        f.epoch = epoch;
-        f.eshift = eshift;
         f.phase = nullptr;
         f.qcodes = (const uint64_t*)w.qcodes.p;
         f.out_ids = (uint32_t*)w.stream_ids.p;
@@ -1270,14 +1238,13 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
                 fclose(fp);
             }
         }
-        ix->last_fast = FastSig{epoch ? 1u : 0u, f.vwords, f.minw, f.gcap, f.lh, f.vr, 1u};
+        ix->last_fast = FastSig{f.vwords, f.minw, f.gcap, f.lh, f.vr, 1u};
         // second attempt of the scans that outgrew these capacities (a handful per launch at the tail of the distribution):
         // the same kernel with a four times larger dedup table, twice the heap and visited-list room, regions from a small
         // pool.  Scans finished above return at once; what still does not fit goes to the general kernel below.
         if (env_u32("VS_F_RETRY", 1)) {
             FastLaunch r = f;
-            r.epoch = 0;  // (its own, smaller table array: cleared by the few scans that run)
-            r.vwords = 0;
+            r.vwords = 0;  // (its own, smaller table array: cleared by the few scans that run)
             r.vslot = 0;
             r.persist = 0;  // (one workgroup per scan: nearly all of them return at once; regions from the pool)
             r.timeline = nullptr;
@@ -1312,8 +1279,8 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
             VS_HIP(hipStreamSynchronize(c->stream));
             uint32_t hist[16] = {0};
             for (uint32_t v : stv) hist[v & 15]++;
-            fprintf(stderr, "[VS_DEBUG_STATUS] fast kernel: lh=%u gcap=%u vr=%u minw=%u epoch=%u bitmap_words=%u; pool claims=%u of %u;",
-                    f.lh, f.gcap, f.vr, f.minw, f.epoch, f.vwords, ctr[0], fast_pool_slots(nq, caps.f_pool_frac));
+            fprintf(stderr, "[VS_DEBUG_STATUS] fast kernel: lh=%u gcap=%u vr=%u minw=%u bitmap_words=%u (per %s); pool claims=%u of %u;",
+                    f.lh, f.gcap, f.vr, f.minw, f.vwords, f.vslot ? "slot" : "bucket", ctr[0], fast_pool_slots(nq, caps.f_pool_frac));
             for (int i = 0; i < 16; ++i)
                 if (hist[i]) fprintf(stderr, " status[%d]=%u", i, hist[i]);
             fprintf(stderr, "\n");
@@ -1699,40 +1666,39 @@ extern "C" int vs_search_batch_dev_finish(vs_index* ix, vs_stats* stats) {
 // ---------------------------------------------------------------------------------------------------------------
 // Launch-variant selection (include/vsgpu.h: vs_index_autotune).  Every variant is an EXACT instantiation of k_search_fast
 // (same rows, same counters); they differ in where a scan keeps its private state, and which of them is fastest depends on the
-// index size and the box — so it is measured on the caller's own batch, and a variant has to reproduce the
+// index size and the box (docs/LAB_NOTEBOOK.md 11b.13-18) — so it is measured on the caller's own batch, and a variant has to reproduce the
 // default's output on that batch bit for bit before it may be chosen.
 // ---------------------------------------------------------------------------------------------------------------
 struct TuneCand {
     const char* name;
-    int epoch, virgin, minw;
+    int virgin, minw;
     uint32_t gcap;
     int lds_max_ins = -1;  // 0: a candidate for indexes whose default is the LDS-table regime (the table-less regime there)
     int vr = -1;           // 0: likewise — the LDS table stays, the visited list moves from registers to the LDS ring
     bool for_lds_regime() const { return lds_max_ins == 0 || vr == 0; }
 };
 static const TuneCand kTuneCands[] = {
-    {"default", -1, -1, -1, 0},
-    {"bucket_bitmap", 0, 1, -1, 0},         // no clear, no read of a bucket the scan has not written (11b.16)
-    {"bucket_bitmap_16k", 0, 1, -1, 16384}, // ... with a sparser table (more first-touch buckets per probe, more lines)
-    {"cleared_tables", 0, 0, -1, 0},        // round 3's default: every scan clears its table, every probe loads a bucket
+    {"default", -1, -1, 0},
+    {"bucket_bitmap", 1, -1, 0},         // no clear, no read of a bucket the scan has not written (11b.16)
+    {"bucket_bitmap_16k", 1, -1, 16384}, // ... with a sparser table (more first-touch buckets per probe, more lines)
+    {"cleared_tables", 0, -1, 0},        // round 3's default: every scan clears its table, every probe loads a bucket
     // (the library default in the table-less regime is the SLOT bitmap, VS_F_VIRGIN=2: an occupancy bit per slot, linear probing, a new
     // id whose home slot is free costs no load)
-    // (no longer candidates: the epoch tags — exact on hardware since round 4's first session, profiles/r04/s1_fuzz_gpu_epoch*.txt,
-    // but no faster than the bitmaps at 50M (s1_ab_virgin_50m.txt) and not compatible with the persistent grid's per-workgroup
-    // regions — and the two-row gather at 5 waves per SIMD, 2.8-7.3 % slower at 10M / 50M in the same session; VS_F_EPOCH=1 and
-    // VS_F_MINW=5 still select them by hand.  Gone for good: the software-pipelined visits, three times slower, profiles/r03/ab_autotune_10m.json)
+    // (no longer candidates: the two-row gather at 5 waves per SIMD, 2.8-7.3 % slower at 10M / 50M, profiles/r04/s1_ab_virgin_*.txt
+    // (VS_F_MINW=5 still selects it by hand).  Deleted: the epoch-tagged tables — exact on hardware in round 4's first session,
+    // profiles/r04/s1_fuzz_gpu_epoch*.txt, but no faster than the bitmaps and not compatible with the persistent grid's per-workgroup
+    // regions — and the software-pipelined visits, three times slower, profiles/r03/ab_autotune_10m.json)
     // small scans (dedup table in LDS by default: 3-4 times fewer scans per CU): the table-less regime instead, plain and with the
     // bitmap (1M x 768 at search_list_size 3 / rescore 53: -37.7 % / -36.2 %, profiles/r03/ab_autotune_1m.json)
-    {"table_less", 0, 0, -1, 0, 0},
-    {"table_less_bitmap", 0, 1, -1, 0, 0},
+    {"table_less", 0, -1, 0, 0},
+    {"table_less_bitmap", 1, -1, 0, 0},
     // ... or the LDS table with the LDS-ring visited list (the register-resident list is what costs the default its occupancy:
     // 141 VGPRs; exact on the interpreter, not timed yet)
-    {"lds_table_ring", 0, 0, -1, 0, -1, 0},
+    {"lds_table_ring", 0, -1, 0, -1, 0},
 };
 static const uint32_t kNTuneCands = sizeof(kTuneCands) / sizeof(kTuneCands[0]);
 
 static void tune_apply(vs_index* ix, const TuneCand& c) {
-    ix->tune.epoch = c.epoch;
     ix->tune.virgin = c.virgin;
     ix->tune.minw = c.minw;
     ix->tune.gcap = c.gcap;
@@ -1955,7 +1921,6 @@ static int vs_index_autotune_impl(vs_index* ix, const float* d_q, const int16_t*
         // a sparser-table candidate grew the table array for everyone: give it back unless it won (the next launch sizes it anew)
         if (!kTuneCands[pick].gcap) {
             devbuf_free(ix->ws.ghash4);
-            ix->ws.ghash4_epoch = 0;
         }
     } else {
         ix->tune = before;

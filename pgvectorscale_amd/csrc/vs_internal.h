@@ -95,8 +95,6 @@ struct DevBuf {
 };
 
 struct SearchWorkspace {
-    uint32_t ghash4_epoch = 0;   // epoch of the last launch on ghash4 (0: the array must be zeroed before the next tagged launch)
-    uint32_t ghash4_eshift = 0;  // id bits the tags in ghash4 were written with
     DevBuf q_full, qcodes, qlabels, qlabel_off, hash, heap_g, heap_g4, ghash4, heap_g4b, ghash4b, pool_ctr, fb_flag, phase, timeline, stream_ids, stream_ham, stream_cnt, stats, status,
         rr_dist, out_ids, out_tids, out_dist, resort_heap, raw_q, misc, q_index,
         raw_q2, out_ids2, out_tids2, out_dist2;  // second set of a pipelined host batch (search_host)
@@ -120,7 +118,7 @@ struct ScanObs {
 // the launch variant of k_search_fast an index prefers (vs_index_autotune / vs_index_set_variant): -1 = the library default;
 // a VS_F_* environment variable still overrides the field it names
 struct TuneVariant {
-    int epoch = -1, virgin = -1, minw = -1, persist = -1;
+    int virgin = -1, minw = -1, persist = -1;
     int lds_max_ins = -1;  // 0: the table-less regime even for scans whose dedup table would fit LDS
     int vr = -1;           // 0: the LDS-ring visited list also where the register-resident one is the default (LDS-table regime)
     uint32_t gcap = 0;
@@ -129,9 +127,9 @@ struct TuneVariant {
 // what the last first-attempt launch of k_search_fast really was (a variant that does not exist for an index / operating point
 // silently launches the default's instantiation: the autotuner reads this to tell)
 struct FastSig {
-    uint32_t epoch_on = 0, vwords = 0, minw = 0, gcap = 0, lh = 0, vr = 0, ran = 0;
+    uint32_t vwords = 0, minw = 0, gcap = 0, lh = 0, vr = 0, ran = 0;
     bool operator==(const FastSig& o) const {
-        return epoch_on == o.epoch_on && vwords == o.vwords && minw == o.minw && gcap == o.gcap && lh == o.lh && vr == o.vr && ran == o.ran;
+        return vwords == o.vwords && minw == o.minw && gcap == o.gcap && lh == o.lh && vr == o.vr && ran == o.ran;
     }
 };
 
@@ -235,8 +233,6 @@ struct FastLaunch {
     uint32_t vcap;     // visited ring capacity (vr == 0)
     uint32_t minw;     // register cap variant: waves per SIMD to leave room for (1 = unconstrained)
     uint32_t rc = 0;   // entries of the LDS cache of ids known to be in the table (table-less regime; 0 or a power of two)
-    uint32_t epoch = 0;   // != 0: global dedup entries are (epoch << eshift) | id and stale tags count as empty (no clearing)
-    uint32_t eshift = 0;  // bits of a node id inside a tagged entry
     uint32_t persist = 0;  // != 0: persistent grid of `persist` workgroups taking scans from scan_counter; regions of heap_g / ghash are per workgroup
     uint32_t vwords = 0;  // != 0: words of the LDS bitmap of written buckets (one bit per four slots of gcap): tables are neither cleared nor read before their first write
     uint32_t vslot = 0;   // with vwords: the bitmap has one bit per SLOT (gcap / 32 words) and the table is probed slot by slot (linear probing)
@@ -291,7 +287,6 @@ int launch_resort(vs_index* idx, uint32_t nq, uint32_t M, uint32_t rescore, uint
 int launch_resort_cursor(vs_index* idx, uint32_t n, bool exhausted, uint32_t rescore, uint32_t k, const uint32_t* d_stream,
                          const float* d_dist, const uint32_t* d_keys, uint64_t* d_heap, uint32_t* d_cur, uint32_t* d_out_ids,
                          uint64_t* d_out_tids, float* d_out_dist);
-int launch_zero_fill(vs_ctx* c, void* p, size_t bytes);  // zero fill by kernel stores on the compute stream (16-byte granularity)
 int launch_row_norms(vs_index* idx);
 int launch_slice_norms(vs_index* idx, float* d_out);  // divisor of the first dim_index dims of every heap vector
 int launch_prepare_index_slice(vs_index* idx, const float* d_raw, uint32_t nq, float* d_q_index);

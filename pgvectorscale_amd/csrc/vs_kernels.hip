@@ -584,25 +584,6 @@ int launch_resort_cursor(vs_index* idx, uint32_t n, bool exhausted, uint32_t res
     return VS_OK;
 }
 
-// Zero fill by an ordinary kernel on the compute stream.  The epoch-tagged dedup tables (vs_search_fast.hip) depend on a zeroed
-// array when an epoch number comes round again; a hipMemset / hipMemsetAsync of the same array was NOT always what the scans of
-// the next launch read on an MI355X when the array reused the memory of a freed one (device fuzz case 777000331: a synchronous
-// hipMemset + hipDeviceSynchronize did not help either, a fill by kernel stores did — profiles/r03/s9_epoch_memset.txt).
-__global__ __launch_bounds__(256) void k_zero_fill(uint4* __restrict__ p, uint64_t n16) {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * blockDim.x)
-        p[i] = make_uint4(0, 0, 0, 0);
-}
-
-int launch_zero_fill(vs_ctx* c, void* p, size_t bytes) {
-    if (!bytes) return VS_OK;
-    VS_REQUIRE(((uintptr_t)p & 15) == 0 && bytes % 16 == 0, "launch_zero_fill: 16-byte granularity");
-    const uint64_t n16 = bytes / 16;
-    const uint32_t grid = (uint32_t)std::min<uint64_t>((n16 + 255) / 256, 1u << 16);
-    hipLaunchKernelGGL(k_zero_fill, dim3(grid), dim3(256), 0, c->stream, static_cast<uint4*>(p), n16);
-    VS_HIP(hipGetLastError());
-    return VS_OK;
-}
-
 int launch_row_norms(vs_index* idx) {
     if (!idx->vecs || idx->d.n == 0) return VS_OK;
     uint32_t blocks = (idx->d.n + 63) / 64;

@@ -720,7 +720,6 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
     const FastLaunch& s = a.s;
     // (the bitmap variants only exist for the table-less regime: the LDS-table code paths are not compiled into them)
     const uint32_t lhv = VG ? 0u : s.lh;
-    const uint32_t epochv = VG ? 0u : s.epoch;        // (plain ids)
     const uint32_t onlyfv = VG ? 0u : s.only_failed;  // (second attempts run the instantiation that clears its tables)
     const uint32_t rcv = VG == 2 ? 0u : s.rc;
     if (onlyfv && s.status[q] == 0) return;  // (wave-uniform) finished by the first launch
@@ -856,16 +855,12 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
     auto hash_home = [&](uint32_t nid) -> uint32_t { return (uint32_t)(((uint64_t)hash_u32(nid) * lhv) >> 32); };
     // handle -> node id.  node_load only ISSUES the read (LDS, or L2 for ids in the overflow table); the value is made
     // uniform with rfl() where it is needed, so the latency overlaps whatever runs in between.
-    // Epoch-tagged table (epochv != 0): an entry is (epoch << s.eshift) | node id, and an entry whose tag is not this launch's
-    // epoch counts as EMPTY — the table is never cleared by the scans (a 64 KB clear per scan was 8 % of a 50M launch's
-    // memory requests); the host zeroes the array once and again whenever the epochs wrap.  epochv == 0: entries are plain
-    // ids, VS_EMPTY marks an empty slot and the claiming wave clears its table (second attempts, build mode).
-    const uint32_t etag = epochv << (s.eshift & 31u);
-    const uint32_t idmask = epochv ? (1u << (s.eshift & 31u)) - 1u : 0xFFFFFFFFu;
-    auto g_empty = [&](uint32_t v) -> bool { return epochv ? (v >> (s.eshift & 31u)) != epochv : v == VS_EMPTY; };
+    // entries are plain node ids; VS_EMPTY marks an empty slot of a table its claiming wave has cleared (no bitmap: second attempts,
+    // build mode, LDS-table regime overflow)
+    auto g_empty = [&](uint32_t v) -> bool { return v == VS_EMPTY; };
     auto node_load = [&](uint32_t handle) -> uint32_t {
         if (handle < lhv) return lload32(lhash + handle);
-        return gload32(ghash + (handle - lhv)) & idmask;
+        return gload32(ghash + (handle - lhv));
     };
     // true where the id was not present before; slot_out = its handle
     auto finish_insert = [&](uint32_t nid, bool act, uint32_t slot, uint32_t old, uint32_t& slot_out) -> bool {
@@ -920,7 +915,7 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
                 }
                 virgin = false;
             } else if (pend) {
-                const uint32_t key = nid | etag;
+                const uint32_t key = nid;
                 const uint32_t hit = (v.x == key ? 1u : 0u) | (v.y == key ? 2u : 0u) | (v.z == key ? 4u : 0u) | (v.w == key ? 8u : 0u);
                 if (hit) {
                     slot_out = lhv + b0 + (uint32_t)__builtin_ctz(hit);
@@ -943,7 +938,7 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
                     if (rank > 1) m &= m - 1u;
                     if (rank > 2) m &= m - 1u;
                     const uint32_t at = b0 + (uint32_t)__builtin_ctz(m);
-                    ghash[at] = nid | etag;
+                    ghash[at] = nid;
                     slot_out = lhv + at;
                     fresh = true;
                     pend = false;
@@ -1009,7 +1004,7 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
         if (g_open) return true;
         if (!claim_region()) return false;
         g_open = true;
-        if (epochv == 0 && !VG) {
+        if (!VG) {
             for (uint32_t i = 4u * lane; i < s.gcap; i += 4u * WAVE)
                 *reinterpret_cast<uint4*>(ghash + i) = make_uint4(VS_EMPTY, VS_EMPTY, VS_EMPTY, VS_EMPTY);
             wave_sync();
@@ -1493,16 +1488,16 @@ static int launch_fast_t(vs_index* idx, const FastArgs& a, size_t lds, uint32_t*
         return launch_fast_tt<3, 0, true, 1, false>(idx, a, lds, res);
     }
     if (a.s.vwords && a.s.vslot) {  // occupancy bitmap of the dedup table's slots in LDS (table-less regime, LDS-ring visited list)
-        VS_REQUIRE(a.s.vr == 0 && a.s.lh == 0 && a.s.epoch == 0 && (uint64_t)a.s.vwords * 32 >= a.s.gcap && a.s.rc == 0,
-                   "fast search: the slot bitmap needs the table-less regime with plain ids and one bit per slot");
+        VS_REQUIRE(a.s.vr == 0 && a.s.lh == 0 && (uint64_t)a.s.vwords * 32 >= a.s.gcap && a.s.rc == 0,
+                   "fast search: the slot bitmap needs the table-less regime and one bit per slot");
         const bool plain = !a.s.qlabel_off && !a.s.visible && !(a.s.flags & FAST_FULL_VARIANT);
         if (NCH == 3 && a.s.minw == 6 && plain) return launch_fast_tt<3, 0, false, 6, false, false, 2>(idx, a, lds, res);
         if (NCH == 3 && a.s.minw == 6) return launch_fast_tt<3, 0, false, 6, false, true, 2>(idx, a, lds, res);
         return launch_fast_tt<NCH, 0, false, 1, false, true, 2>(idx, a, lds, res);
     }
     if (a.s.vwords) {  // written-bucket bitmap in LDS instead of cleared tables (table-less regime, LDS-ring visited list)
-        VS_REQUIRE(a.s.vr == 0 && a.s.lh == 0 && a.s.epoch == 0 && (uint64_t)a.s.vwords * 128 >= a.s.gcap,
-                   "fast search: the written-bucket bitmap needs the table-less regime with plain ids and one bit per bucket");
+        VS_REQUIRE(a.s.vr == 0 && a.s.lh == 0 && (uint64_t)a.s.vwords * 128 >= a.s.gcap,
+                   "fast search: the written-bucket bitmap needs the table-less regime and one bit per bucket");
         const bool plain = !a.s.qlabel_off && !a.s.visible && !(a.s.flags & FAST_FULL_VARIANT);
         if (NCH == 3 && a.s.minw == 6 && plain) return launch_fast_tt<3, 0, false, 6, false, false, 1>(idx, a, lds, res);
         if (NCH == 3 && a.s.minw == 6) return launch_fast_tt<3, 0, false, 6, false, true, 1>(idx, a, lds, res);
@@ -1577,8 +1572,8 @@ static int fast_dispatch(vs_index* idx, const FastLaunch& s, uint32_t* res) {
 
 int launch_search_fast(vs_index* idx, const FastLaunch& s) {
     if (s.nq == 0) return VS_OK;
-    VS_REQUIRE(!s.persist || (s.scan_counter && s.pool_slots >= std::min(s.persist, s.nq) && !s.epoch),
-               "fast search: a persistent grid needs a scan counter, one region per workgroup and plain (untagged) dedup entries");
+    VS_REQUIRE(!s.persist || (s.scan_counter && s.pool_slots >= std::min(s.persist, s.nq)),
+               "fast search: a persistent grid needs a scan counter and one region per workgroup");
     return fast_dispatch(idx, s, nullptr);
 }
 

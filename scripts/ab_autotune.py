@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""The library's own A/B of the search kernel's launch variants (vs_index_autotune, DESIGN.md 10b) on a device-manufactured index:
+"""The library's own A/B of the search kernel's launch variants (vs_index_autotune, DESIGN.md §4) on a device-manufactured index:
 every variant timed on one batch at one operating point, rows / distance bits / counters held to the default's.  No torch, no oracle.
 
   VS_NO_TORCH=1 python scripts/ab_autotune.py --n 10000000 --nq 262144 --L 3 --rescore 196 --reps 3 > ab.json

@@ -17,9 +17,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 
 VARIANTS = [{"VS_F_MINW": "5"}, {"VS_F_MINW": "5", "VS_F_VIRGIN": "1"}, {"VS_F_VIRGIN": "1"},
-            # the remaining candidates of vs_index_autotune (csrc/vs_api.hip, kTuneCands): epoch tags alone and with the two-row gather,
-            # the bitmap on sparser tables
-            {"VS_F_EPOCH": "1"}, {"VS_F_EPOCH": "1", "VS_F_MINW": "5"}, {"VS_F_VIRGIN": "1", "VS_F_GCAP": "16384"},
+            # the bucket bitmap on sparser tables, cleared tables (round 3's default)
+            {"VS_F_VIRGIN": "1", "VS_F_GCAP": "16384"}, {"VS_F_VIRGIN": "0"},
             # occupancy bit per slot of the dedup table (VS_F_VIRGIN=2), on a fitted and on a tight table
             {"VS_F_VIRGIN": "2"}, {"VS_F_VIRGIN": "2", "VS_F_GCAP": "1536"}]
 KNOBS = sorted({k for v in VARIANTS for k in v})

@@ -87,7 +87,7 @@ def main():
     for cfg in args.configs.split(","):
         # a config is a ':'-separated list of NAME=VALUE environment overrides read by libvsgpu (VS_FAST, VS_F_LH, VS_F_HL,
         # VS_F_VCAP for the fast kernel; VS_HL, VS_LH, VS_G0 for the general one)
-        # (VARIANT=<name>: not an environment variable — the launch variant of vs_index_autotune by name, DESIGN.md 10b)
+        # (VARIANT=<name>: not an environment variable — the launch variant of vs_index_autotune by name, DESIGN.md §4)
         for kv in cfg.split(":"):
             if kv:
                 k_, v_ = kv.split("=")

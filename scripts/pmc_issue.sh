@@ -5,7 +5,7 @@
 #                                        ACTIVE_INST_ANY ~ WAVE_CYCLES; ACTIVE_INST_VALU / _SCA / _LDS / _VMEM split the last
 #   pass B: how many instructions        INSTS_VALU / _SALU / _LDS / _VMEM_RD / _VMEM_WR / _SMEM, WAVES
 # Reading: ACTIVE_INST_ANY / WAVE_CYCLES near the number of resident waves^-1 means the SIMDs are busy issuing (cut
-# instructions); a dominant WAIT_ANY means latency (raise occupancy / prefetch more).
+# instructions, DESIGN.md section 11 / docs/LAB_NOTEBOOK.md section 11); a dominant WAIT_ANY means latency (raise occupancy / prefetch more).
 # usage: scripts/pmc_issue.sh <n> <nq> <L> <rescore> [graph-cache-prefix]     (counter names: rocprofv3 -L)
 N=${1:-1000000}; NQ=${2:-131072}; L=${3:-100}; S=${4:-50}; CACHE=${5:-}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"

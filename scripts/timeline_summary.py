@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Reads a VS_TIMELINE dump of libvsgpu (start / end of every scan of one k_search_fast launch, 100 MHz ticks) and prints what the
 launch looked like from the inside: its span, how many scans were in flight over time, how long a scan lived depending on when it
-started.  Diagnostics for the launch-tail question (DESIGN.md 11d).
+started.  Diagnostics for the launch-tail question (DESIGN.md 3.1).
 
   VS_TIMELINE=/tmp/tl.bin python scripts/perf_search.py ... ; python scripts/timeline_summary.py /tmp/tl.bin
 """

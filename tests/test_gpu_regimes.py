@@ -21,10 +21,6 @@ REGIMES = {
     # table-less with a small LDS cache of ids known to be in the table in front of it (duplicate probes answered on chip)
     "tableless_idcache": {"VS_F_LDS_MAX_INS": "0", "VS_F_RC": "128"},
     "heap_spill_tableless": {"VS_F_HL": "63", "VS_F_LDS_MAX_INS": "0"},
-    # the epoch-tagged dedup table of the table-less regime wraps after two launches (the array is zeroed again), and the same
-    # regime with plain ids and a 64 KB clear per scan
-    "tableless_epoch_wrap": {"VS_F_LDS_MAX_INS": "0", "VS_F_EPOCH": "1", "VS_F_EPOCH_MAX": "2"},
-    "tableless_epoch": {"VS_F_LDS_MAX_INS": "0", "VS_F_EPOCH": "1"},
     # table-less with the written-bucket bitmap in LDS: tables are never cleared and a bucket is not read before its first write
     # (the array starts out holding whatever earlier launches left there); tight tables make chains of full buckets
     "tableless_virgin": {"VS_F_LDS_MAX_INS": "0", "VS_F_VIRGIN": "1"},
@@ -56,7 +52,7 @@ REGIMES = {
 
 
 def _hardware_unverified(regime):
-    """the written-bucket bitmap, the epoch tags and the two-row gather ran this file's corner cases on the MI355X in round 4's first GPU
+    """the written-bucket bitmap and the two-row gather ran this file's corner cases on the MI355X in round 4's first GPU
     session (profiles/r04/s1_tests.txt: 96 passed with the opt-in set; device fuzz 1 074 + 1 102 cases) and are no longer skipped.
     A variant that is newer than its first hardware session is listed here: exact on the wave64 interpreter (VS_EMU=1, part of the
     CPU tier), an opt-in on hardware until it has run there, so that it cannot turn the tier of the shipped defaults red."""
@@ -246,7 +242,7 @@ def test_label_filter_masks_and_merge(gpu_ctx, n_labels):
 # three times slower, profiles/r03/ab_autotune_10m.json) with every pass shape:
 # R = 50 gives visits with 1..50 new candidates (one pair of passes, a pair + a single row group, two pairs), on scans long enough to
 # spill the heap; the labeled index runs the instantiation with label keys and a visibility mask
-VARIANTS = {"5": {"VS_F_MINW": "5"}, "5_virgin": {"VS_F_MINW": "5", "VS_F_VIRGIN": "1"}, "5_epoch": {"VS_F_MINW": "5", "VS_F_EPOCH": "1"}}
+VARIANTS = {"5": {"VS_F_MINW": "5"}, "5_virgin": {"VS_F_MINW": "5", "VS_F_VIRGIN": "1"}}
 
 
 @pytest.mark.parametrize("variant", list(VARIANTS))

@@ -151,6 +151,16 @@ def choose_operating_point(run_sample, k, target, sweep_log, err_type=Exception)
                 break  # a larger rescore at this L only costs more
     ok = [(c_, p_) for p_, (r_, c_) in tried.items() if r_ >= target]
     if not ok:
+        # nothing up to rescore 400 reaches the target (the `mid` corpus at 50M: 0.9876 at 400 / 400): the GUC goes to 1000
+        # (AM/guc.rs:28-43), so the upper range is tried at the list sizes whose 400-row point came closest per unit of cost
+        s_grid = s_grid + [600, 800, 1000]
+        for cl in (3, 10, 50, 100):
+            for cs in (600, 800, 1000):
+                r_, _ = try_point(cl, cs)
+                if r_ >= target:
+                    break
+        ok = [(c_, p_) for p_, (r_, c_) in tried.items() if r_ >= target]
+    if not ok:
         (L, S), (rec, _) = max(tried.items(), key=lambda kv: kv[1][0])
         log(f"WARNING: recall target {target} not reached; using best L={L} rescore={S} ({rec:.4f})")
         return L, S, rec

@@ -1412,8 +1412,17 @@ static uint32_t stream_len(uint32_t rescore, uint32_t k) { return rescore > 0 ? 
 static uint32_t chunk_queries(const vs_index* ix, const Caps& c, uint32_t M, uint32_t nq) {
     const size_t general = (size_t)c.hashcap * 4 + (size_t)(c.hcap > c.hl ? c.hcap - c.hl : 0) * 8;
     size_t per_q = (size_t)M * 12 + ix->vec_stride * 4ull + ix->code_stride * 8ull + 256;
-    if (c.f_on) per_q += (size_t)((double)c.f_gcap * 4 * c.f_pool_frac) + (size_t)c.f_gstride * 4 + general / 64 + 64;
-    else per_q += general;
+    // (persistent grid: the dedup tables and heap spill arrays are per resident workgroup — at most 32 per CU — not per scan)
+    const bool persist = c.f_on && knob_u32("VS_F_PERSIST", ix->tune.persist, 1);
+    size_t fixed = 0;
+    if (persist) {
+        fixed = (size_t)ix->ctx->prop.multiProcessorCount * 32 * ((size_t)c.f_gcap * 4 + (size_t)c.f_gstride * 4);
+        per_q += general / 64 + 64;
+    } else if (c.f_on) {
+        per_q += (size_t)((double)c.f_gcap * 4 * c.f_pool_frac) + (size_t)c.f_gstride * 4 + general / 64 + 64;
+    } else {
+        per_q += general;
+    }
     // workspace budget: half of what is free on the device right now (plus what the workspace already holds), <= 64 GiB
     size_t budget = 24ull << 30;
     size_t free_b = 0, total_b = 0;
@@ -1424,6 +1433,7 @@ static uint32_t chunk_queries(const vs_index* ix, const Caps& c, uint32_t M, uin
         budget = std::min<size_t>((free_b + held) / 2, 64ull << 30);
         budget = std::max<size_t>(budget, 1ull << 30);
     }
+    budget = budget > fixed + (budget >> 2) ? budget - fixed : budget >> 2;
     uint32_t m = (uint32_t)std::max<size_t>(1, std::min<size_t>(budget / per_q, 1u << 20));
     return std::min(m, nq);
 }

@@ -263,6 +263,7 @@ struct FastLaunch {
 };
 enum {
     FAST_PLAIN_ROW_LOADS = 1,  // code rows through the normal cache policy instead of non-temporal loads
+    FAST_PLAIN_NBR_LOADS = 2,  // ... and neighbor rows / neighbor masks / heap tids
     FAST_FULL_VARIANT = 8,     // run the instantiation that handles label keys and a visibility mask even when the batch has neither
 };
 size_t fast_lds_bytes(const vs_index* idx, const FastLaunch& s);

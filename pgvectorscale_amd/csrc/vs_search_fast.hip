@@ -749,6 +749,9 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
 
     const int l4 = lane & 3;
     const bool stream_rows = !(s.flags & FAST_PLAIN_ROW_LOADS);
+    // neighbor rows, the neighbors' label masks and heap tids are read once per scan too: non-temporal, so that what stays in L2 / the
+    // Infinity Cache is what a scan comes back to (its dedup table, its heap spill) — 214 rows x 256 B is as much as the table itself
+    const bool nt_rows = !(s.flags & FAST_PLAIN_NBR_LOADS);
     constexpr bool QL = NCH > 0 && MINW >= 6;
     constexpr bool G2 = NCH == 3 && VR == 0 && MINW == 5 && !BUILD && !TIMING;  // two code rows per 4-lane group in flight
     ulonglong2 qv[NCH > 0 ? NCH : 1];
@@ -1113,7 +1116,7 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
             const uint32_t fn = readlane_u32(vis.n[0], 0);
             if (fn != ft_node) {
                 ft_node = fn;
-                ft_val = a.tids[fn];
+                ft_val = load_stream64(a.tids + fn, nt_rows);
                 if (visible) ft_vis = visible[fn];
             }
         }
@@ -1132,7 +1135,7 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
             vis.pop_front(fd, fnode, fflags);
             st_reads++;
             if (VR > 0) {
-                const uint64_t tid = fnode == ft_node ? ft_val : a.tids[fnode];
+                const uint64_t tid = fnode == ft_node ? ft_val : load_stream64(a.tids + fnode, nt_rows);
                 fflags = (tid & 0xFFFFull) == 0 ? VIS_DEAD : 0u;
                 if (visible) fflags |= rfl(fnode == ft_node ? ft_vis : (uint32_t)visible[fnode]) == 0 ? VIS_HIDDEN : 0u;
             }
@@ -1169,7 +1172,7 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
         bool early = false;
         if (hit) {
             if (VR == 0 && !BUILD) {
-                vtid = a.tids[node_v];
+                vtid = load_stream64(a.tids + node_v, nt_rows);
                 if (visible) vvis = visible[node_v];
             }
             if (gmode && nins_g <= s.glimit) {
@@ -1193,13 +1196,13 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
         const uint32_t node = rfl(node_v);
         // what consume() will need to know about this node: requested now, folded into the ring entry at the insert below
         if (!hit && VR == 0 && !BUILD) {
-            vtid = a.tids[node];
+            vtid = load_stream64(a.tids + node, nt_rows);
             if (visible) vvis = visible[node];
         }
         const uint32_t* nrow = a.nbrs + (size_t)node * a.nbr_stride;
         if (!hit) {
-            row0 = ((uint32_t)lane < a.R) ? nrow[lane] : VS_INVALID_NODE;
-            if (nbr_mask) rowm = ((uint32_t)lane < a.R) ? nbr_mask[(size_t)node * a.nbr_stride + lane] : 0ull;
+            row0 = ((uint32_t)lane < a.R) ? load_stream32(nrow + lane, nt_rows) : VS_INVALID_NODE;
+            if (nbr_mask) rowm = ((uint32_t)lane < a.R) ? load_stream64(nbr_mask + (size_t)node * a.nbr_stride + lane, nt_rows) : 0ull;
         }
         lap(0);
         if (vis.len + 1 > vis.capacity()) {
@@ -1222,7 +1225,7 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
         bool list_ended = false;
         for (uint32_t c0 = 0; c0 < a.R && !list_ended; c0 += WAVE) {
             const uint32_t slotidx = c0 + lane;
-            const uint32_t nid = c0 == 0 ? row0 : ((slotidx < a.R) ? nrow[slotidx] : VS_INVALID_NODE);
+            const uint32_t nid = c0 == 0 ? row0 : ((slotidx < a.R) ? load_stream32(nrow + slotidx, nt_rows) : VS_INVALID_NODE);
             // list ends at the first InvalidBlockNumber (AM/sbq/node.rs:260-285)
             const uint64_t inval = __ballot(nid == VS_INVALID_NODE);
             const uint32_t nvalid = inval ? (uint32_t)__builtin_ctzll(inval) : WAVE;
@@ -1275,7 +1278,7 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
             // label filter: query.labels.overlaps(node.labels) (AM/labels/mod.rs:124-142)
             bool pass = fresh;
             if (has_label_filter && nbr_mask) {
-                const uint64_t nm = c0 == 0 ? rowm : ((slotidx < a.R) ? nbr_mask[(size_t)node * a.nbr_stride + slotidx] : 0ull);
+                const uint64_t nm = c0 == 0 ? rowm : ((slotidx < a.R) ? load_stream64(nbr_mask + (size_t)node * a.nbr_stride + slotidx, nt_rows) : 0ull);
                 pass = fresh && (nm & qmask) != 0;
             } else if (has_label_filter && a.label_mask) {
                 if (fresh) pass = (a.label_mask[nid] & qmask) != 0;
@@ -1325,8 +1328,8 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
                     if (root_after != 0xFFFFFFFFu) {
                         pfa_node = rfl(root_node_v);
                         pfa_h = root_after & smask;
-                        pfa_val = ((uint32_t)lane < a.R) ? a.nbrs[(size_t)pfa_node * a.nbr_stride + lane] : VS_INVALID_NODE;
-                        if (nbr_mask) pfa_m = ((uint32_t)lane < a.R) ? nbr_mask[(size_t)pfa_node * a.nbr_stride + lane] : 0ull;
+                        pfa_val = ((uint32_t)lane < a.R) ? load_stream32(a.nbrs + (size_t)pfa_node * a.nbr_stride + lane, nt_rows) : VS_INVALID_NODE;
+                        if (nbr_mask) pfa_m = ((uint32_t)lane < a.R) ? load_stream64(nbr_mask + (size_t)pfa_node * a.nbr_stride + lane, nt_rows) : 0ull;
                     }
                 }
                 if (G2) {
@@ -1366,8 +1369,8 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
                 if (best != 0xFFFFFFFFu && (best >> s.sb) < (root_after >> s.sb)) {
                     pfb_node = best_node;  // a candidate of this visit: its id is known without a table lookup
                     pfb_h = best & smask;
-                    pfb_val = ((uint32_t)lane < a.R) ? a.nbrs[(size_t)pfb_node * a.nbr_stride + lane] : VS_INVALID_NODE;
-                    if (nbr_mask) pfb_m = ((uint32_t)lane < a.R) ? nbr_mask[(size_t)pfb_node * a.nbr_stride + lane] : 0ull;
+                    pfb_val = ((uint32_t)lane < a.R) ? load_stream32(a.nbrs + (size_t)pfb_node * a.nbr_stride + lane, nt_rows) : VS_INVALID_NODE;
+                    if (nbr_mask) pfb_m = ((uint32_t)lane < a.R) ? load_stream64(nbr_mask + (size_t)pfb_node * a.nbr_stride + lane, nt_rows) : 0ull;
                 }
             }
             // insert_neighbor in list order (AM/graph/mod.rs:144-147)
@@ -1382,8 +1385,8 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
             if (root_after != 0xFFFFFFFFu) {
                 pfa_node = rfl(root_node_v);
                 pfa_h = root_after & smask;
-                pfa_val = ((uint32_t)lane < a.R) ? a.nbrs[(size_t)pfa_node * a.nbr_stride + lane] : VS_INVALID_NODE;
-                if (nbr_mask) pfa_m = ((uint32_t)lane < a.R) ? nbr_mask[(size_t)pfa_node * a.nbr_stride + lane] : 0ull;
+                pfa_val = ((uint32_t)lane < a.R) ? load_stream32(a.nbrs + (size_t)pfa_node * a.nbr_stride + lane, nt_rows) : VS_INVALID_NODE;
+                if (nbr_mask) pfa_m = ((uint32_t)lane < a.R) ? load_stream64(nbr_mask + (size_t)pfa_node * a.nbr_stride + lane, nt_rows) : 0ull;
             }
         }
         if (!pfb_issued) {

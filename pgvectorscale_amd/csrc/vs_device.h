@@ -24,8 +24,8 @@ __device__ __forceinline__ ulonglong2 load_stream16(const uint64_t* p) {
 }
 
 // the same for data a scan reads once and never again: its visit's neighbor row (and the neighbors' label masks next to it), a heap tid
-__device__ __forceinline__ uint32_t load_stream32(const uint32_t* p, bool nt) { return nt ? __builtin_nontemporal_load(p) : *p; }
-__device__ __forceinline__ uint64_t load_stream64(const uint64_t* p, bool nt) { return nt ? __builtin_nontemporal_load(p) : *p; }
+__device__ __forceinline__ uint32_t load_stream32(const uint32_t* p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ uint64_t load_stream64(const uint64_t* p) { return __builtin_nontemporal_load(p); }
 
 __device__ __forceinline__ uint32_t hash_u32(uint32_t x) {
     x ^= x >> 16;

@@ -113,6 +113,7 @@ struct ScanObs {
     uint32_t L = 0, M = 0;
     double ins_mean = 0, ins_max = 0;  // inserted ids per scan
     double ov_frac = 1.0;              // fraction of scans that outgrew the LDS table
+    uint32_t vis_max = 0;              // longest visited list of any scan (0: unknown; 1023: that long or longer)
 };
 
 // the launch variant of k_search_fast an index prefers (vs_index_autotune / vs_index_set_variant): -1 = the library default;
@@ -263,7 +264,6 @@ struct FastLaunch {
 };
 enum {
     FAST_PLAIN_ROW_LOADS = 1,  // code rows through the normal cache policy instead of non-temporal loads
-    FAST_PLAIN_NBR_LOADS = 2,  // ... and neighbor rows / neighbor masks / heap tids
     FAST_FULL_VARIANT = 8,     // run the instantiation that handles label keys and a visibility mask even when the batch has neither
 };
 size_t fast_lds_bytes(const vs_index* idx, const FastLaunch& s);

@@ -749,9 +749,8 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
 
     const int l4 = lane & 3;
     const bool stream_rows = !(s.flags & FAST_PLAIN_ROW_LOADS);
-    // neighbor rows, the neighbors' label masks and heap tids are read once per scan too: non-temporal, so that what stays in L2 / the
-    // Infinity Cache is what a scan comes back to (its dedup table, its heap spill) — 214 rows x 256 B is as much as the table itself
-    const bool nt_rows = !(s.flags & FAST_PLAIN_NBR_LOADS);
+    // (neighbor rows, the neighbors' label masks and heap tids are read once per scan too and go through non-temporal loads as well:
+    // measured neutral at 50M — 159.94 against 159.93 ms, profiles/r04/s5_ab_nt_rows_50m.txt — where the code rows' are worth 10 %)
     constexpr bool QL = NCH > 0 && MINW >= 6;
     constexpr bool G2 = NCH == 3 && VR == 0 && MINW == 5 && !BUILD && !TIMING;  // two code rows per 4-lane group in flight
     ulonglong2 qv[NCH > 0 ? NCH : 1];
@@ -815,7 +814,7 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
 
     const uint32_t slot_limit = lhv - lhv / 8;  // stop at 87.5 % load: the scan is handed to the general kernel
     const uint32_t smask = (1u << s.sb) - 1u;
-    uint32_t emitted = 0, status = wide_key ? (uint32_t)OVF_KEY : 0u, nins = 0, hmax = 0;
+    uint32_t emitted = 0, status = wide_key ? (uint32_t)OVF_KEY : 0u, nins = 0, hmax = 0, vmax = 0;
     uint32_t st_visits = 0, st_cand = 0, st_dq = 0, st_reads = 0;
     // optional phase clock (s_memtime): 0 pop, 1 row wait, 2 visited, 3 dedup, 4 gather, 5 push, 6 other
     uint64_t ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1116,7 +1115,7 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
             const uint32_t fn = readlane_u32(vis.n[0], 0);
             if (fn != ft_node) {
                 ft_node = fn;
-                ft_val = load_stream64(a.tids + fn, nt_rows);
+                ft_val = load_stream64(a.tids + fn);
                 if (visible) ft_vis = visible[fn];
             }
         }
@@ -1135,7 +1134,7 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
             vis.pop_front(fd, fnode, fflags);
             st_reads++;
             if (VR > 0) {
-                const uint64_t tid = fnode == ft_node ? ft_val : load_stream64(a.tids + fnode, nt_rows);
+                const uint64_t tid = fnode == ft_node ? ft_val : load_stream64(a.tids + fnode);
                 fflags = (tid & 0xFFFFull) == 0 ? VIS_DEAD : 0u;
                 if (visible) fflags |= rfl(fnode == ft_node ? ft_vis : (uint32_t)visible[fnode]) == 0 ? VIS_HIDDEN : 0u;
             }
@@ -1154,6 +1153,7 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
             continue;
         }
         hmax = max(hmax, heap.len);
+        vmax = max(vmax, vis.len);
         lap(6);
         const uint32_t hd = top >> s.sb;
         // The node about to be visited is, almost always, one of the two whose neighbor rows were requested during the last
@@ -1172,7 +1172,7 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
         bool early = false;
         if (hit) {
             if (VR == 0 && !BUILD) {
-                vtid = load_stream64(a.tids + node_v, nt_rows);
+                vtid = load_stream64(a.tids + node_v);
                 if (visible) vvis = visible[node_v];
             }
             if (gmode && nins_g <= s.glimit) {
@@ -1196,13 +1196,13 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
         const uint32_t node = rfl(node_v);
         // what consume() will need to know about this node: requested now, folded into the ring entry at the insert below
         if (!hit && VR == 0 && !BUILD) {
-            vtid = load_stream64(a.tids + node, nt_rows);
+            vtid = load_stream64(a.tids + node);
             if (visible) vvis = visible[node];
         }
         const uint32_t* nrow = a.nbrs + (size_t)node * a.nbr_stride;
         if (!hit) {
-            row0 = ((uint32_t)lane < a.R) ? load_stream32(nrow + lane, nt_rows) : VS_INVALID_NODE;
-            if (nbr_mask) rowm = ((uint32_t)lane < a.R) ? load_stream64(nbr_mask + (size_t)node * a.nbr_stride + lane, nt_rows) : 0ull;
+            row0 = ((uint32_t)lane < a.R) ? load_stream32(nrow + lane) : VS_INVALID_NODE;
+            if (nbr_mask) rowm = ((uint32_t)lane < a.R) ? load_stream64(nbr_mask + (size_t)node * a.nbr_stride + lane) : 0ull;
         }
         lap(0);
         if (vis.len + 1 > vis.capacity()) {
@@ -1225,7 +1225,7 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
         bool list_ended = false;
         for (uint32_t c0 = 0; c0 < a.R && !list_ended; c0 += WAVE) {
             const uint32_t slotidx = c0 + lane;
-            const uint32_t nid = c0 == 0 ? row0 : ((slotidx < a.R) ? load_stream32(nrow + slotidx, nt_rows) : VS_INVALID_NODE);
+            const uint32_t nid = c0 == 0 ? row0 : ((slotidx < a.R) ? load_stream32(nrow + slotidx) : VS_INVALID_NODE);
             // list ends at the first InvalidBlockNumber (AM/sbq/node.rs:260-285)
             const uint64_t inval = __ballot(nid == VS_INVALID_NODE);
             const uint32_t nvalid = inval ? (uint32_t)__builtin_ctzll(inval) : WAVE;
@@ -1278,7 +1278,7 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
             // label filter: query.labels.overlaps(node.labels) (AM/labels/mod.rs:124-142)
             bool pass = fresh;
             if (has_label_filter && nbr_mask) {
-                const uint64_t nm = c0 == 0 ? rowm : ((slotidx < a.R) ? load_stream64(nbr_mask + (size_t)node * a.nbr_stride + slotidx, nt_rows) : 0ull);
+                const uint64_t nm = c0 == 0 ? rowm : ((slotidx < a.R) ? load_stream64(nbr_mask + (size_t)node * a.nbr_stride + slotidx) : 0ull);
                 pass = fresh && (nm & qmask) != 0;
             } else if (has_label_filter && a.label_mask) {
                 if (fresh) pass = (a.label_mask[nid] & qmask) != 0;
@@ -1328,8 +1328,8 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
                     if (root_after != 0xFFFFFFFFu) {
                         pfa_node = rfl(root_node_v);
                         pfa_h = root_after & smask;
-                        pfa_val = ((uint32_t)lane < a.R) ? load_stream32(a.nbrs + (size_t)pfa_node * a.nbr_stride + lane, nt_rows) : VS_INVALID_NODE;
-                        if (nbr_mask) pfa_m = ((uint32_t)lane < a.R) ? load_stream64(nbr_mask + (size_t)pfa_node * a.nbr_stride + lane, nt_rows) : 0ull;
+                        pfa_val = ((uint32_t)lane < a.R) ? load_stream32(a.nbrs + (size_t)pfa_node * a.nbr_stride + lane) : VS_INVALID_NODE;
+                        if (nbr_mask) pfa_m = ((uint32_t)lane < a.R) ? load_stream64(nbr_mask + (size_t)pfa_node * a.nbr_stride + lane) : 0ull;
                     }
                 }
                 if (G2) {
@@ -1369,8 +1369,8 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
                 if (best != 0xFFFFFFFFu && (best >> s.sb) < (root_after >> s.sb)) {
                     pfb_node = best_node;  // a candidate of this visit: its id is known without a table lookup
                     pfb_h = best & smask;
-                    pfb_val = ((uint32_t)lane < a.R) ? load_stream32(a.nbrs + (size_t)pfb_node * a.nbr_stride + lane, nt_rows) : VS_INVALID_NODE;
-                    if (nbr_mask) pfb_m = ((uint32_t)lane < a.R) ? load_stream64(nbr_mask + (size_t)pfb_node * a.nbr_stride + lane, nt_rows) : 0ull;
+                    pfb_val = ((uint32_t)lane < a.R) ? load_stream32(a.nbrs + (size_t)pfb_node * a.nbr_stride + lane) : VS_INVALID_NODE;
+                    if (nbr_mask) pfb_m = ((uint32_t)lane < a.R) ? load_stream64(nbr_mask + (size_t)pfb_node * a.nbr_stride + lane) : 0ull;
                 }
             }
             // insert_neighbor in list order (AM/graph/mod.rs:144-147)
@@ -1385,8 +1385,8 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
             if (root_after != 0xFFFFFFFFu) {
                 pfa_node = rfl(root_node_v);
                 pfa_h = root_after & smask;
-                pfa_val = ((uint32_t)lane < a.R) ? load_stream32(a.nbrs + (size_t)pfa_node * a.nbr_stride + lane, nt_rows) : VS_INVALID_NODE;
-                if (nbr_mask) pfa_m = ((uint32_t)lane < a.R) ? load_stream64(nbr_mask + (size_t)pfa_node * a.nbr_stride + lane, nt_rows) : 0ull;
+                pfa_val = ((uint32_t)lane < a.R) ? load_stream32(a.nbrs + (size_t)pfa_node * a.nbr_stride + lane) : VS_INVALID_NODE;
+                if (nbr_mask) pfa_m = ((uint32_t)lane < a.R) ? load_stream64(nbr_mask + (size_t)pfa_node * a.nbr_stride + lane) : 0ull;
             }
         }
         if (!pfb_issued) {
@@ -1421,7 +1421,9 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
             st[ST_DQ] = st_dq;
             st[ST_READS] = st_reads;
             st[ST_NEXT] = st_next;
-            st[ST_GSPILL] = hmax;
+            // largest heap (22 bits; capacities end at 2^22) | longest visited list before an insert (10 bits, saturating): what the
+            // next launch with the same (L, M) sizes the LDS ring of the visited list from
+            st[ST_GSPILL] = min(hmax, 0x3FFFFFu) | (min(vmax + 1u, 1023u) << 22);
             st[ST_INVIS] = st_invis;
             st[7] = nins + nins_g;
         }

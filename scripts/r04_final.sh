@@ -46,3 +46,7 @@ for f in ("bench_50m", "bench_50m_under_rocprof", "bench_50m_with_traffic"):
         print(f, "unreadable:", e)
 PY
 timeout 300 python scripts/fuzz_emu.py --gpu --seconds 150 --seed 4071 2>&1 | tail -2 | tee $O/fuzz_gpu.txt
+# 7. many backends streaming at once: 1 / 8 / 64 concurrent cursors of 1 000 rows on the dispatcher thread and on 8 / 64 lanes, with
+#    HIP's default number of hardware queues and with 16
+timeout 400 python scripts/cursor_concurrency.py --n 1000000 2>&1 | grep -Ev "$NOBANNER" | tee $O/cursor_concurrency_1m.txt
+GPU_MAX_HW_QUEUES=16 timeout 400 python scripts/cursor_concurrency.py --n 1000000 --lanes 64 --threads 1,64 2>&1 | grep -Ev "$NOBANNER" | tee -a $O/cursor_concurrency_1m.txt

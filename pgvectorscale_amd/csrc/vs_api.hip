@@ -961,13 +961,9 @@ static Caps initial_caps(const vs_index* ix, uint32_t L, uint32_t M) {
     // visited list: register resident (8 VGPR pairs) while LDS is the limiter; in the table-less regime registers are,
     // and the LDS ring variant needs 87 VGPRs instead of 141 (5 instead of 3 waves per SIMD)
     c.f_vr = knob_u32("VS_F_VR", ix->tune.vr, (lds_table && want_v <= 512) ? 8 : 0);
-    // LDS ring of the visited list: twice the list size + slack until the scans of this (L, M) have shown how long the list gets
-    // (it holds what was visited and not yet consumed: rarely more than L + a few entries), then that + 12 % — at the reference's
-    // default list size of 100 the difference is 1.5 KB of LDS per scan, i.e. 21 instead of 18 scans per CU
-    uint32_t vcap_auto = 2 * want_v;
-    if (ix->obs.valid && ix->obs.L == L && ix->obs.M == M && ix->obs.vis_max > 0 && ix->obs.vis_max < 1023)
-        vcap_auto = std::min<uint32_t>(vcap_auto, ix->obs.vis_max + ix->obs.vis_max / 8 + 8);
-    c.f_vcap = c.f_vr ? 512 : round_up_u32(std::max<uint32_t>(env_u32("VS_F_VCAP", vcap_auto), 64), 64);
+    // (sizing the ring from the lists of earlier batches — 21 instead of 18 scans per CU at the reference's default list size — was
+    // measured in round 4 and bought nothing: profiles/r04/s6_summary.txt)
+    c.f_vcap = c.f_vr ? 512 : round_up_u32(std::max<uint32_t>(env_u32("VS_F_VCAP", 2 * want_v), 64), 64);
     c.f_on = env_u32("VS_FAST", 1) != 0 && ix->d.storage_type != VS_STORAGE_PLAIN;  // the LDS-resident kernels score SBQ codes
     if (c.f_on) {
         if (c.f_lh) c.f_lh = round_up_u32(std::max<uint32_t>(c.f_lh, 256), 4);
@@ -1363,10 +1359,9 @@ static int collect_stats(vs_index* ix, uint32_t nq, uint32_t M, uint32_t rescore
     }
     if (w.fb_valid && ix->last_ins_limit) {  // what this batch needed: sizes the next launch with the same (L, M)
         double sum = 0, mx = 0;
-        uint32_t cnt_fast = 0, ov = 0, vmx = 0;
+        uint32_t cnt_fast = 0, ov = 0;
         for (uint32_t q = 0; q < nq; ++q) {
             const double v = hs[(size_t)q * ST_N + 7];
-            vmx = std::max(vmx, hs[(size_t)q * ST_N + ST_GSPILL] >> 22);  // (0 from the general kernel, whose slot holds a heap length only)
             if (fb[q]) {  // (finished by a second attempt: its insert count still tells how big a table the batch needs)
                 ov++;
                 mx = std::max(mx, v);
@@ -1384,7 +1379,6 @@ static int collect_stats(vs_index* ix, uint32_t nq, uint32_t M, uint32_t rescore
             o.ins_mean = (1 - a) * o.ins_mean + a * (sum / cnt_fast);
             o.ins_max = same ? std::max(o.ins_max, mx) : mx;
             o.ov_frac = (1 - a) * (same ? o.ov_frac : 0.0) + a * ((double)ov / nq);
-            o.vis_max = same ? std::max(o.vis_max, vmx) : vmx;
             o.L = obs_L;
             o.M = M;
             o.valid = true;

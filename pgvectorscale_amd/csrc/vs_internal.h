@@ -113,7 +113,6 @@ struct ScanObs {
     uint32_t L = 0, M = 0;
     double ins_mean = 0, ins_max = 0;  // inserted ids per scan
     double ov_frac = 1.0;              // fraction of scans that outgrew the LDS table
-    uint32_t vis_max = 0;              // longest visited list of any scan (0: unknown; 1023: that long or longer)
 };
 
 // the launch variant of k_search_fast an index prefers (vs_index_autotune / vs_index_set_variant): -1 = the library default;

@@ -22,7 +22,10 @@
 //     the "table-less" regime) keep every id there.  The global table belongs to ONE wave, so it needs no atomics (an L2
 //     atomic costs a 64-byte write to the memory side each; scripts/microbench/randmem.hip: 26 G/s for the whole chip
 //     against 60-100 G/s for loads): a probe is one 16-byte load of a bucket of four slots, an insert a 4-byte store, and
-//     lanes that want the same bucket in the same step are told apart by an LDS counter.
+//     lanes that want the same bucket in the same step are told apart by an LDS counter.  The default of the table-less regime
+//     since round 4 keeps one OCCUPANCY BIT PER SLOT in LDS instead (VG == 2): slot-granular linear probing, an id whose home slot
+//     is free is new and is stored without a load, an occupied run is compared through one 16-byte load per 4-slot group, a free
+//     slot is claimed with one ds_or; the tables are never cleared and never read before they are written.
 //   * visited list (sorted Vec<ListSearchNeighbor>): sorted array in REGISTERS (entry i = lane i % 64 of register
 //     i / 64); insert / remove(0) are DPP wave shifts, no LDS traffic.  (LDS ring buffer when it does not fit.)
 //   * the query code lives in registers (4 lanes x 16 B per code row, NCH steps).
@@ -814,7 +817,7 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
 
     const uint32_t slot_limit = lhv - lhv / 8;  // stop at 87.5 % load: the scan is handed to the general kernel
     const uint32_t smask = (1u << s.sb) - 1u;
-    uint32_t emitted = 0, status = wide_key ? (uint32_t)OVF_KEY : 0u, nins = 0, hmax = 0, vmax = 0;
+    uint32_t emitted = 0, status = wide_key ? (uint32_t)OVF_KEY : 0u, nins = 0, hmax = 0;
     uint32_t st_visits = 0, st_cand = 0, st_dq = 0, st_reads = 0;
     // optional phase clock (s_memtime): 0 pop, 1 row wait, 2 visited, 3 dedup, 4 gather, 5 push, 6 other
     uint64_t ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1153,7 +1156,6 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
             continue;
         }
         hmax = max(hmax, heap.len);
-        vmax = max(vmax, vis.len);
         lap(6);
         const uint32_t hd = top >> s.sb;
         // The node about to be visited is, almost always, one of the two whose neighbor rows were requested during the last
@@ -1421,9 +1423,7 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
             st[ST_DQ] = st_dq;
             st[ST_READS] = st_reads;
             st[ST_NEXT] = st_next;
-            // largest heap (22 bits; capacities end at 2^22) | longest visited list before an insert (10 bits, saturating): what the
-            // next launch with the same (L, M) sizes the LDS ring of the visited list from
-            st[ST_GSPILL] = min(hmax, 0x3FFFFFu) | (min(vmax + 1u, 1023u) << 22);
+            st[ST_GSPILL] = hmax;
             st[ST_INVIS] = st_invis;
             st[7] = nins + nins_g;
         }

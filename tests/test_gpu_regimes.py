@@ -287,33 +287,3 @@ def test_two_row_gather_full_neighbor_lists(gpu_ctx, iname, variant):
                 os.environ[k] = v
         ix.close()
 
-
-def test_visited_ring_fitted_to_an_earlier_batch_still_serves_longer_lists(gpu_ctx):
-    """the LDS ring of the visited list is sized from the longest list the previous batches with the same (L, M) produced (+ 12 %):
-    a later batch whose scans hold more visited-and-not-yet-consumed nodes than that must come out exact all the same (the scans
-    that outgrow the ring take the second attempt with twice the room)"""
-    ti = cached_index(n=4000, dim_full=128, bits=2, R=50, distance=1, seed=1, kind="uniform", L_build=100)
-    ix = ti.upload(gpu_ctx)
-    env = {"VS_F_LDS_MAX_INS": "0"}
-    saved = {k: os.environ.get(k) for k in env}
-    try:
-        os.environ.update(env)
-        L, m = 60, 40
-        first = ti.queries(2, seed=901, kind="uniform")
-        for _ in range(2):  # (the second call runs on a ring fitted to these two scans)
-            gi, gh, _ = ix.stream_batch(first, search_list_size=L, m=m)
-            oi, oh, _ = ti.oracle.stream_batch(first, L=L, m=m)
-            assert (gi == oi).all() and (gh == oh).all()
-        later = ti.queries(160, seed=902, kind="gauss")  # another distribution: other list lengths
-        gi, gh, gst = ix.stream_batch(later, search_list_size=L, m=m)
-        oi, oh, ost = ti.oracle.stream_batch(later, L=L, m=m)
-        assert (gi == oi).all() and (gh == oh).all()
-        for key in ("visited_nodes", "candidate_nodes", "quantized_distance_comparisons", "node_reads", "next_calls"):
-            assert gst[key] == ost[key], (key, gst[key], ost[key])
-    finally:
-        for k, v in saved.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
-        ix.close()

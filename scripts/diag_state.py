@@ -1,0 +1,118 @@
+#!/usr/bin/env python3
+"""Why is the search kernel ~8 % slower right after an on-device graph build than on the same graph loaded from a file
+(round 4's final session: 167.2 ms in the run that built the 50M graph, 153.6 / 154.1 ms in the two runs that loaded it)?
+Same work (identical counters), so it is a state of the device or of the process.  One process builds and then times the same
+batch (a) at once, (b) after an idle minute (clocks / temperature), (c) through a fresh view of the index, i.e. with a search
+workspace allocated NOW (placement of the dedup tables / heap spill arrays), (d) after a 'torch.cuda.empty_cache()'-free
+re-allocation of nothing — the control; a second process loads the saved graph and times the batch again (e).
+
+  python scripts/diag_state.py --n 50000000 --phase build   # (a)-(d), writes the graph file
+  python scripts/diag_state.py --n 50000000 --phase load    # (e)
+"""
+import argparse
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def smi():
+    try:
+        out = subprocess.run(["rocm-smi", "--showclocks", "--showtemp", "--showpower"], capture_output=True, text=True, timeout=20).stdout
+        keep = [ln.strip() for ln in out.splitlines() if any(k in ln for k in ("sclk", "mclk", "Temperature (Sensor junction)", "Temperature (Sensor memory)", "Power"))]
+        return " | ".join(keep[:8])
+    except Exception as e:  # noqa: BLE001
+        return f"rocm-smi: {e!r}"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=50_000_000)
+    ap.add_argument("--nq", type=int, default=262144)
+    ap.add_argument("--L", type=int, default=3)
+    ap.add_argument("--rescore", type=int, default=195)
+    ap.add_argument("--phase", default="build", choices=["build", "load"])
+    ap.add_argument("--graph", default="/tmp/diag_graph")
+    ap.add_argument("--idle", type=float, default=60.0)
+    args = ap.parse_args()
+    import numpy as np  # noqa: F401
+    import torch  # noqa: F401
+    import pgvectorscale_amd as P
+    from pgvectorscale_amd import _lib
+    if os.environ.get("VS_EMU"):  # (dry run of the control flow on the interpreter)
+        _lib.LIB_PATH = os.path.join(ROOT, "tests", "emu", "libvsgpu_emu.so")
+    from pgvectorscale_amd.datagen import DatagenParams, fill_device
+
+    ctx = P.Context(0)
+    ix = P.DiskAnnIndex.alloc(ctx, n=args.n, dim_full=768, num_neighbors=50, distance_type=P.VS_L2)
+    seed = {1_000_000: 3, 10_000_000: 5, 50_000_000: 6}.get(args.n, 3)
+    gp = DatagenParams(seed=seed, dim=768)
+    vp, _ = ix.array(_lib.ARR_VECS)
+    fill_device(ctx, gp, 0, args.n, vp)
+    ix.refresh_norms()
+    ix.sbq_train()
+    ix.sbq_quantize_corpus()
+    t0 = time.time()
+    if args.phase == "build":
+        ix.build_graph(search_list_size=100, max_alpha=1.2)
+        print(f"graph built in {time.time() - t0:.1f} s; {smi()}", flush=True)
+    else:
+        ix.load_graph(args.graph)
+        print(f"graph loaded in {time.time() - t0:.1f} s; {smi()}", flush=True)
+    nq, k = args.nq, 10
+    q = ctx.alloc(nq * 768 * 4)
+    fill_device(ctx, gp, 1 << 40, nq, q)
+    out = ctx.alloc(nq * k * 4)
+
+    def timed(handle, c, label, reps=4):
+        c.profile_enable(True)
+        handle.search_batch_dev(q, nq, args.L, args.rescore, k, out)
+        handle.search_batch_dev_finish()
+        handle.search_batch_dev(q, nq, args.L, args.rescore, k, out)  # (second warm-up: the fitted tables)
+        handle.search_batch_dev_finish()
+        c.profile_read(reset=True)
+        ms = []
+        for _ in range(reps):
+            handle.search_batch_dev(q, nq, args.L, args.rescore, k, out)
+            handle.search_batch_dev_finish()
+            p = c.profile_read(reset=True)
+            ms.append(p["search"][0] / max(p["search"][1], 1))
+        print(f"{label:58s}: search " + " ".join(f"{x:7.2f}" for x in ms) + f" ms   {smi()}", flush=True)
+
+    timed(ix, ctx, "(a) right after the " + ("build" if args.phase == "build" else "load"))
+    if args.phase == "build":
+        time.sleep(args.idle)
+        timed(ix, ctx, f"(b) after {args.idle:.0f} idle seconds")
+        ctx2 = P.Context(0)
+        vw = ix.view(ctx2)
+        q2, out2 = q, out
+
+        def timed_view(label):
+            nonlocal q2, out2
+            ctx2.profile_enable(True)
+            for _ in range(2):
+                vw.search_batch_dev(q2, nq, args.L, args.rescore, k, out2)
+                vw.search_batch_dev_finish()
+            ctx2.profile_read(reset=True)
+            ms = []
+            for _ in range(4):
+                vw.search_batch_dev(q2, nq, args.L, args.rescore, k, out2)
+                vw.search_batch_dev_finish()
+                p = ctx2.profile_read(reset=True)
+                ms.append(p["search"][0] / max(p["search"][1], 1))
+            print(f"{label:58s}: search " + " ".join(f"{x:7.2f}" for x in ms) + f" ms   {smi()}", flush=True)
+
+        timed_view("(c) through a fresh view (workspace allocated now)")
+        timed(ix, ctx, "(d) the first handle again")
+        vw.close()
+        ctx2.close()
+        ix.save_graph(args.graph)
+    ix.close()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -15,19 +15,22 @@ def short(name):
 
 def full_launches(trace_path, kernel="k_search_fast", min_ms=1.0):
     """k_search_fast is also launched on tiny recall samples and as the (mostly empty) second attempt of a step, which the stats
-    row averages in: the timed launches are the dispatches of the largest grid that ran longer than `min_ms`"""
+    row averages in: the timed launches are the dispatches within a factor of two of the longest one (with the persistent grid the
+    LARGEST grid is the second attempt's — one workgroup per scan, nearly all of which return at once)"""
     rows = [r for r in csv.DictReader(open(trace_path)) if kernel in r["Kernel_Name"]]
     if not rows:
         return None
-    gmax = max(int(r["Grid_Size_X"]) for r in rows)
-    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows if int(r["Grid_Size_X"]) == gmax]
-    d = [x for x in d if x >= min_ms]
-    if not d:
+    dur = lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6  # noqa: E731
+    dmax = max(dur(r) for r in rows)
+    full = [r for r in rows if dur(r) >= max(0.5 * dmax, min_ms)]
+    if not full:
         return None
-    d = [x for x in d if x >= 0.5 * max(d)]  # (a second attempt that had a scan or two to finish is not a full launch)
-    r0 = max((r for r in rows if int(r["Grid_Size_X"]) == gmax), key=lambda r: int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-    return {"grid": gmax, "calls": len(d), "avg_ms": sum(d) / len(d), "min_ms": min(d), "max_ms": max(d), "vgpr": r0["VGPR_Count"],
-            "sgpr": r0["SGPR_Count"], "lds": r0["LDS_Block_Size"], "scratch": r0["Scratch_Size"]}
+    d = [dur(r) for r in full]
+    # the timed region of bench.py is its last `steps` full launches (the earlier ones: warm-up, validation and held-out batches)
+    r0 = max(full, key=dur)
+    return {"grid": int(r0["Grid_Size_X"]), "calls": len(d), "avg_ms": sum(d) / len(d), "min_ms": min(d), "max_ms": max(d),
+            "last20_avg_ms": sum(d[-20:]) / len(d[-20:]), "vgpr": r0["VGPR_Count"], "sgpr": r0["SGPR_Count"], "lds": r0["LDS_Block_Size"],
+            "scratch": r0["Scratch_Size"]}
 
 
 def main(src, dst, note=""):
@@ -39,8 +42,9 @@ def main(src, dst, note=""):
         if note:
             f.write(f"# {note}\n")
         if fl:
-            f.write(f"# k_search_fast, full launches only (grid {fl['grid']} threads, > 1 ms; from the kernel trace of the same run): "
-                    f"calls={fl['calls']} avg_ms={fl['avg_ms']:.3f} min_ms={fl['min_ms']:.3f} max_ms={fl['max_ms']:.3f} "
+            f.write(f"# k_search_fast, full launches only (grid {fl['grid']} threads = {fl['grid'] // 64} single-wave workgroups, within 2x of the longest; from the kernel "
+                    f"trace of the same run): calls={fl['calls']} avg_ms={fl['avg_ms']:.3f} min_ms={fl['min_ms']:.3f} max_ms={fl['max_ms']:.3f} "
+                    f"last_20_avg_ms={fl['last20_avg_ms']:.3f} "
                     f"VGPRs={fl['vgpr']} SGPRs={fl['sgpr']} LDS={fl['lds']} B scratch={fl['scratch']} B\n")
         f.write("kernel,calls,total_ms,avg_us,min_us,max_us,pct\n")
         for r in rows:

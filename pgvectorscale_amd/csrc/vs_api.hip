@@ -376,24 +376,6 @@ static int index_alloc_arrays(vs_ctx* c, const vs_index_desc* desc, bool with_ve
     return VS_OK;
 }
 
-// The randomly accessed part of the search workspace — the per-workgroup dedup tables and heap spill arrays of the persistent grid,
-// ~0.4 GB each — is reserved together with the index arrays, while the process's device memory is as unfragmented as it will ever be.
-// Round 4 measured the identical work 9.6 % slower (168.4 against 152.3 ms per 262 144 scans at 50M) in a process that had built
-// the graph on the device — tens of GB of temporaries allocated and freed — before its first search allocated these arrays, than
-// in a process that loaded the same graph; idle time, clocks and a workspace allocated later still made no difference
-// (profiles/r04/s7_diag_state_50m.txt).  Sized for the headline regime (24 single-wave workgroups per CU, 16 Ki slots / entries per
-// region); a launch that needs more grows the arrays as before.  Best effort: an allocation failure here is not an error.
-static void reserve_search_workspace(vs_ctx* c, vs_index* ix) {
-    const char* e = getenv("VS_WS_RESERVE_MIN_N");  // (nodes from which the reservation is made; the test tier lowers it)
-    const uint32_t min_n = e && *e ? (uint32_t)strtoul(e, nullptr, 10) : (4u << 20);
-    if (ix->d.n < min_n || ix->d.storage_type == VS_STORAGE_PLAIN) return;  // (small indexes: LDS tables, little spill)
-    const size_t bytes = (size_t)c->prop.multiProcessorCount * 24 * 16384 * 4;
-    if (devbuf_reserve(c, ix->ws.ghash4, bytes) != VS_OK || devbuf_reserve(c, ix->ws.heap_g4, bytes) != VS_OK) {
-        (void)hipGetLastError();
-        vs_set_error("");
-    }
-}
-
 static int index_alloc_common(vs_ctx* c, const vs_index_desc* desc, bool with_vecs, vs_index** out) {
     VS_REQUIRE(c && out, "index alloc: bad args");
     *out = nullptr;
@@ -410,7 +392,6 @@ static int index_alloc_common(vs_ctx* c, const vs_index_desc* desc, bool with_ve
         vs_index_free(ix);
         return r;
     }
-    reserve_search_workspace(c, ix);
     *out = ix;
     return VS_OK;
 }

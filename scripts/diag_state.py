@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--phase", default="build", choices=["build", "load"])
     ap.add_argument("--graph", default="/tmp/diag_graph")
     ap.add_argument("--idle", type=float, default=60.0)
+    ap.add_argument("--early", action="store_true", help="allocate the query buffers and the whole search workspace right after the index "
+                                                          "arrays (one dummy batch on the still empty graph), before anything else")
     args = ap.parse_args()
     import numpy as np  # noqa: F401
     import torch  # noqa: F401
@@ -50,6 +52,14 @@ def main():
     ix = P.DiskAnnIndex.alloc(ctx, n=args.n, dim_full=768, num_neighbors=50, distance_type=P.VS_L2)
     seed = {1_000_000: 3, 10_000_000: 5, 50_000_000: 6}.get(args.n, 3)
     gp = DatagenParams(seed=seed, dim=768)
+    nq, k = args.nq, 10
+    q = out = None
+    if args.early:
+        q = ctx.alloc(nq * 768 * 4)
+        out = ctx.alloc(nq * k * 4)
+        ix.search_batch_dev(q, nq, args.L, args.rescore, k, out)  # (empty graph: every scan ends at once; the workspace is allocated)
+        ix.search_batch_dev_finish()
+        print("workspace allocated right after the index arrays", flush=True)
     vp, _ = ix.array(_lib.ARR_VECS)
     fill_device(ctx, gp, 0, args.n, vp)
     ix.refresh_norms()
@@ -62,10 +72,10 @@ def main():
     else:
         ix.load_graph(args.graph)
         print(f"graph loaded in {time.time() - t0:.1f} s; {smi()}", flush=True)
-    nq, k = args.nq, 10
-    q = ctx.alloc(nq * 768 * 4)
+    if q is None:
+        q = ctx.alloc(nq * 768 * 4)
+        out = ctx.alloc(nq * k * 4)
     fill_device(ctx, gp, 1 << 40, nq, q)
-    out = ctx.alloc(nq * k * 4)
 
     def timed(handle, c, label, reps=4):
         c.profile_enable(True)

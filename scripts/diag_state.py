@@ -59,7 +59,8 @@ def main():
         out = ctx.alloc(nq * k * 4)
         ix.search_batch_dev(q, nq, args.L, args.rescore, k, out)  # (empty graph: every scan ends at once; the workspace is allocated)
         ix.search_batch_dev_finish()
-        print("workspace allocated right after the index arrays", flush=True)
+        print("workspace allocated right after the index arrays (NOTE: this dummy batch also leaves scan statistics for this (L, M) that "
+              "under-size the tables of the timed batches below: run the timed batches at another rescore, or ignore their times)", flush=True)
     vp, _ = ix.array(_lib.ARR_VECS)
     fill_device(ctx, gp, 0, args.n, vp)
     ix.refresh_norms()

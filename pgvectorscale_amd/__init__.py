@@ -6,3 +6,4 @@ tests and bench (datagen.py).
 """
 from ._lib import VS_COSINE, VS_INVALID_NODE, VS_IP, VS_L2, VsError, load  # noqa: F401
 from .index import Broker, Context, DiskAnnIndex, IndexScan, ShmClient, ShmServer  # noqa: F401
+from .multi import Comm, MultiIndex  # noqa: F401  (several GPUs: one process with N devices / one process per device over RCCL)

@@ -2,7 +2,11 @@
 
 The path shards by query: scans are independent and read-only, every rank holds the whole index, rank g takes a
 contiguous block of the query batch, and ONE all_gather of the [nq_local, k] id / distance blocks closes the step
-(RCCL over xGMI when the tensors live on GPUs — backend "nccl" — and gloo on CPU tensors in the tests)."""
+(RCCL over xGMI when the tensors live on GPUs — backend "nccl" — and gloo on CPU tensors in the tests).
+
+This module is the torch.distributed convenience for callers that already live in torch.  The product path, and `bench.py --gpus N`
+since round 4, is behind the C ABI instead: `vs_comm_gather_topk` / `vs_multi_search_batch` (include/vsgpu.h, pgvectorscale_amd/multi.py),
+which need no torch; `shard_range` here and `vs_shard_range` there are the same arithmetic (tests/test_gpu_multi.py holds them together)."""
 import torch
 import torch.distributed as dist
 

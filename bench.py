@@ -351,9 +351,22 @@ def main():
         from pgvectorscale_amd import multi as PM
         if EMU:
             os.environ.setdefault("VS_RCCL_LIB", os.path.join(ROOT, "tests", "emu", "libfakerccl.so"))
-        uid = [PM.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        comm = PM.Comm(ctx, uid[0], rank, world)
+        # (the communicator is created by all ranks or by none: a rank where the library's RCCL cannot be loaded or initialised must not
+        # leave the others waiting inside ncclCommInitRank, so the id travels only after every rank has reported that it can load it,
+        # and a failure anywhere sends the whole job to the torch.distributed gather of pgvectorscale_amd/sharding.py — reported in
+        # config.topk_gather, never silent)
+        comm_err = None
+        try:
+            uid = [PM.comm_unique_id()]  # (every rank: it is also the probe that the library can load its RCCL here; rank 0's is used)
+        except Exception as e:  # noqa: BLE001
+            uid, comm_err = [None], repr(e)
+        ok_ = torch.tensor([0 if comm_err else 1], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok_, op=dist.ReduceOp.MIN)
+        if int(ok_.item()):
+            dist.broadcast_object_list(uid, src=0)
+            comm = PM.Comm(ctx, uid[0], rank, world)
+        else:
+            log(f"vs_comm unavailable on some rank ({comm_err}); the top-k gather and the graph broadcast fall back to torch.distributed")
     dt = {"l2": P.VS_L2, "cosine": P.VS_COSINE, "ip": P.VS_IP}[args.distance]
     n, dim, k = args.n, args.dim, args.k
     R = 50
@@ -418,8 +431,14 @@ def main():
             setup["graph_build_s"] = round(time.time() - t0, 3)
         t1 = time.time()
         nptr, nstride = ix.array(_lib.ARR_NBRS)
-        comm.bcast(nptr, n * nstride * 4, 0)  # vs_comm_bcast: ncclBroadcast HBM -> HBM
-        ctx.sync()
+        if comm is not None:
+            comm.bcast(nptr, n * nstride * 4, 0)  # vs_comm_bcast: ncclBroadcast HBM -> HBM
+            ctx.sync()
+        else:
+            nb = _dev_tensor(torch, np, nptr.value, (n, nstride), dev, "<i4")
+            dist.broadcast(nb, src=0)
+            torch.cuda.synchronize()
+            del nb
         if rank != 0:
             ix.set_start_nodes(0)
         setup["graph_broadcast_s"] = round(time.time() - t1, 3)
@@ -584,6 +603,12 @@ def main():
 
     def gather_topk(oi, od):
         n_ = oi.shape[0]
+        if comm is None:  # (fallback, see above)
+            from pgvectorscale_amd.sharding import gather_topk as torch_gather
+            gi_, gd_ = torch_gather(oi, od)
+            gathered[0][:gi_.shape[0]].copy_(gi_)
+            gathered[1][:gd_.shape[0]].copy_(gd_)
+            return
         comm.gather_topk(C.c_void_p(oi.data_ptr()), C.c_void_p(od.data_ptr()), n_, world * n_, k, C.c_void_p(gathered[0].data_ptr()),
                          C.c_void_p(gathered[1].data_ptr()))
 
@@ -910,7 +935,8 @@ def main():
                    "labels": NL, "n": n, "dim": dim, "bits": bits, "words": W,
                    "num_neighbors": R, "queries_per_step_per_gpu": nq, "search_list_size": L, "rescore": S, "k": k,
                    "parallelism": f"query-sharded x{world}, index replicated" if world > 1 else "single GPU",
-                   "topk_gather": "vs_comm_gather_topk (libvsgpu C ABI: one grouped ncclAllGather of the id + distance blocks per step)" if world > 1 else None,
+                   "topk_gather": None if world == 1 else ("vs_comm_gather_topk (libvsgpu C ABI: one grouped ncclAllGather of the id + distance blocks per step)" if comm is not None
+                                                            else "torch.distributed all_gather_into_tensor (FALLBACK: vs_comm_* could not be initialised on every rank)"),
                    "batches_in_flight": args.pipeline},
         "recall_at_k": round(recall, 4),
         "recall_validate": round(recall_validate, 4),

@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--phase", default="build", choices=["build", "load"])
     ap.add_argument("--graph", default="/tmp/diag_graph")
     ap.add_argument("--idle", type=float, default=60.0)
+    ap.add_argument("--pad-mb", type=int, default=0, help="allocate and hold this much device memory BEFORE the index arrays (shifts everything)")
+    ap.add_argument("--ws-pad-mb", type=int, default=0, help="allocate and hold this much right before the first search (shifts the workspace only)")
     ap.add_argument("--early", action="store_true", help="allocate the query buffers and the whole search workspace right after the index "
                                                           "arrays (one dummy batch on the still empty graph), before anything else")
     args = ap.parse_args()
@@ -49,6 +51,9 @@ def main():
     from pgvectorscale_amd.datagen import DatagenParams, fill_device
 
     ctx = P.Context(0)
+    pads = []
+    if args.pad_mb:
+        pads.append(ctx.alloc(args.pad_mb << 20))
     ix = P.DiskAnnIndex.alloc(ctx, n=args.n, dim_full=768, num_neighbors=50, distance_type=P.VS_L2)
     seed = {1_000_000: 3, 10_000_000: 5, 50_000_000: 6}.get(args.n, 3)
     gp = DatagenParams(seed=seed, dim=768)
@@ -77,6 +82,9 @@ def main():
         q = ctx.alloc(nq * 768 * 4)
         out = ctx.alloc(nq * k * 4)
     fill_device(ctx, gp, 1 << 40, nq, q)
+    if args.ws_pad_mb:
+        pads.append(ctx.alloc(args.ws_pad_mb << 20))
+    print(f"pad {args.pad_mb} MB before the index, {args.ws_pad_mb} MB before the workspace; q at {q.value:#x}, out at {out.value:#x}", flush=True)
 
     def timed(handle, c, label, reps=4):
         c.profile_enable(True)

@@ -39,6 +39,9 @@ def main():
     ap.add_argument("--idle", type=float, default=60.0)
     ap.add_argument("--pad-mb", type=int, default=0, help="allocate and hold this much device memory BEFORE the index arrays (shifts everything)")
     ap.add_argument("--ws-pad-mb", type=int, default=0, help="allocate and hold this much right before the first search (shifts the workspace only)")
+    ap.add_argument("--lib", default=None, help="another build of libvsgpu (docs/experiments/ws_spread.patch: VS_WS_SPREAD_MB)")
+    ap.add_argument("--spread", default=None, help="after the first timing: ','-separated WHAT:MB pairs, each timed in this process with the regions of "
+                                                   "the persistent grid spread over MB of device memory (WHAT: 1 heap spill, 2 dedup tables, 3 both; needs --lib)")
     ap.add_argument("--early", action="store_true", help="allocate the query buffers and the whole search workspace right after the index "
                                                           "arrays (one dummy batch on the still empty graph), before anything else")
     args = ap.parse_args()
@@ -46,6 +49,8 @@ def main():
     import torch  # noqa: F401
     import pgvectorscale_amd as P
     from pgvectorscale_amd import _lib
+    if args.lib:
+        _lib.LIB_PATH = os.path.abspath(args.lib)
     if os.environ.get("VS_EMU"):  # (dry run of the control flow on the interpreter)
         _lib.LIB_PATH = os.path.join(ROOT, "tests", "emu", "libvsgpu_emu.so")
     from pgvectorscale_amd.datagen import DatagenParams, fill_device
@@ -102,6 +107,12 @@ def main():
         print(f"{label:58s}: search " + " ".join(f"{x:7.2f}" for x in ms) + f" ms   {smi()}", flush=True)
 
     timed(ix, ctx, "(a) right after the " + ("build" if args.phase == "build" else "load"))
+    if args.spread:
+        for item in args.spread.split(","):
+            what, mb = item.split(":")
+            os.environ["VS_WS_SPREAD_WHAT"], os.environ["VS_WS_SPREAD_MB"] = what, mb
+            timed(ix, ctx, f"(s) regions spread: what={what} over {mb} MB each")
+        os.environ["VS_WS_SPREAD_MB"] = "0"
     if args.phase == "build":
         time.sleep(args.idle)
         timed(ix, ctx, f"(b) after {args.idle:.0f} idle seconds")

@@ -29,7 +29,7 @@ SUBSET = ("test_hip_path_reproduces_golden or test_index_from_pages_searches_lik
           "test_backend_processes_stream_past_the_first_rows or test_two_row_gather_full_neighbor_lists or "
           "test_autotune_holds_every_variant_to_the_defaults_rows or test_a_variant_whose_rows_differ_is_disqualified or "
           "test_small_scans_try_the_table_less_regime or test_set_variant_by_name or "
-          "test_replica_on_a_second_context_outlives_its_source or (test_multi_search_batch_returns_the_single_device_rows and 33) or "
+          "test_a_client_that_rewrites_its_request_after_posting_cannot_move_the_dispatcher or test_replica_on_a_second_context_outlives_its_source or (test_multi_search_batch_returns_the_single_device_rows and 33) or "
           "test_comm_world_of_one_gathers_and_replicates or test_entry_points_that_move_the_arrays_refuse_while_a_view_is_alive or "
           "test_handles_return_their_device_memory or test_deep_scans_stream_on_lanes or test_shm_server_with_lanes_gives_its_memory_back or test_staging_ring_round_trip or test_row_wise_staging_pads_and_copies_every_row")
 

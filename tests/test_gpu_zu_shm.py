@@ -434,3 +434,86 @@ def test_cursors_of_a_dead_client_are_dropped(gpu_ctx, oracle):
     c.close()
     srv.close()
     ix.close()
+
+
+def test_a_client_that_rewrites_its_request_after_posting_cannot_move_the_dispatcher(gpu_ctx, oracle):
+    """The segment is writable by every client, so the dispatcher copies a posted request into its own memory and validates the
+    copy (vs_shm.cpp, header comment).  A hostile client — this test, through a raw mapping of the segment — posts a valid request
+    and rewrites k, the label count, the GUCs and the header's geometry the moment the slot is taken; and posts requests that are
+    out of range to begin with.  Whatever happens, the dispatcher writes at most the rows the request it TOOK asked for, inside that
+    slot: the neighbouring slot's bytes do not change, the server stays alive and keeps answering honest clients with the oracle's
+    rows."""
+    import mmap
+    import struct
+    import time
+    import pgvectorscale_amd as P
+    ti = TestIndex(**KW)
+    ix = ti.upload(gpu_ctx)
+    name = f"/vs_shm_hostile_{os.getpid()}"
+    nslots, kmax, dim = 4, 16, 64
+    srv = P.ShmServer(ix, name, nslots=nslots, kmax=kmax, max_batch=8, max_wait_us=100)
+    S_FREE, S_CLAIMED, S_READY, S_RUNNING, S_DONE = 0, 1, 2, 3, 4
+    HDR = 64                     # ShmHeader: 9 x u32 + pad, 16-byte aligned
+    OFF = dict(state=0, pid=4, L=8, rescore=12, k=16, n_labels=20, has_key=24, null_q=28, rc=32, snapshot=36, op=40, skip=44, n_rows=48,
+               scan_id=56, err=64, labels=232, query=360)
+    fd = os.open("/dev/shm" + name, os.O_RDWR)
+    try:
+        size = os.fstat(fd).st_size
+        m = mmap.mmap(fd, size)
+        magic, version, h_nslots, h_dim, h_kmax, slot_bytes = struct.unpack_from("<6I", m, 0)
+        assert (h_nslots, h_dim, h_kmax) == (nslots, dim, kmax)
+        u32 = lambda off: struct.unpack_from("<I", m, off)[0]  # noqa: E731
+
+        def put32(off, v):
+            struct.pack_into("<I", m, off, v & 0xFFFFFFFF)
+
+        def post(slot, k, L=20, rescore=8, n_labels=0, op=0, rewrite=None):
+            base = HDR + slot * slot_bytes
+            assert u32(base + OFF["state"]) == S_FREE
+            put32(base + OFF["state"], S_CLAIMED)
+            put32(base + OFF["pid"], os.getpid())
+            for key, v in (("L", L), ("rescore", rescore), ("k", k), ("n_labels", n_labels), ("has_key", 1 if n_labels else 0), ("null_q", 0),
+                           ("snapshot", 0), ("op", op), ("skip", 0)):
+                put32(base + OFF[key], v)
+            q = ti.queries(1, seed=5, kind="gauss")[0].astype(np.float32)
+            m[base + OFF["query"]: base + OFF["query"] + dim * 4] = q.tobytes()
+            put32(base + OFF["state"], S_READY)
+            put32(28, u32(28) + 1)  # work_seq: the dispatcher also polls every 50 ms, so no futex wake is needed
+            t0 = time.time()
+            while u32(base + OFF["state"]) not in (S_RUNNING, S_DONE) and time.time() - t0 < 20:
+                pass
+            if rewrite:  # the slot has been taken: now lie about what was asked
+                for key, v in rewrite.items():
+                    put32(base + OFF[key], v)
+            while u32(base + OFF["state"]) != S_DONE and time.time() - t0 < 30:
+                time.sleep(0.001)
+            assert u32(base + OFF["state"]) == S_DONE, "the dispatcher never finished the slot"
+            rc = struct.unpack_from("<i", m, base + OFF["rc"])[0]
+            ids = np.frombuffer(m, np.uint32, kmax, base + OFF["query"] + dim * 4 + kmax * 8).copy()
+            put32(base + OFF["pid"], 0)
+            put32(base + OFF["state"], S_FREE)
+            return rc, ids, q
+
+        oracle_rows = lambda q, k: ti.oracle.search_batch(q[None, :], L=20, rescore=8, k=k)[0][0]  # noqa: E731
+        victim = HDR + 1 * slot_bytes
+        for trial in range(6):
+            before = bytes(m[victim: victim + slot_bytes])
+            rc, ids, q = post(0, k=5, rewrite={"k": 1 << 20, "n_labels": 60000, "L": 0, "rescore": 1 << 30, "op": 77, "skip": 1 << 31})
+            assert rc in (0, -1)  # served as posted, or (the lie landed before the copy) rejected as out of range
+            if rc == 0:
+                assert (ids[:5] == oracle_rows(q, 5)).all()
+            assert bytes(m[victim: victim + slot_bytes]) == before, "the dispatcher wrote outside the slot it was serving"
+        # requests that are out of range from the start are failed, not run
+        for bad in (dict(k=kmax + 1), dict(k=0), dict(k=4, L=0), dict(k=4, rescore=5000), dict(k=4, n_labels=65), dict(k=4, op=9)):
+            rc, _, _ = post(2, **bad)
+            assert rc == -1, bad
+        # the header's geometry is not read again either: a client that rewrites it changes nothing for the dispatcher
+        struct.pack_into("<4I", m, 8, 1, 7, 1 << 20, 64)
+        rc, ids, q = post(3, k=6)
+        assert rc == 0 and (ids[:6] == oracle_rows(q, 6)).all()
+        struct.pack_into("<4I", m, 8, nslots, dim, kmax, slot_bytes)
+        m.close()
+    finally:
+        os.close(fd)
+        srv.close()
+        ix.close()

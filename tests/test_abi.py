@@ -45,3 +45,39 @@ def test_product_package_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "oracle_py" not in txt and "liboracle" not in txt and "vs_oracle" not in txt, f
+
+
+def test_header_is_plain_c_and_a_c_program_links_against_the_library(tmp_path):
+    """include/vsgpu.h is what a Rust / C host binds: it must compile as C99 with no C++ in it, and a plain C program must link
+    against libvsgpu.so and get VS_ERR_HIP (not a crash, not a CPU fallback) from the first entry point that needs a device when
+    there is none — on a GPU box the same program creates a context and shards a batch with vs_shard_range."""
+    import subprocess
+    import pgvectorscale_amd
+    hdr = os.path.join(ROOT, "include", "vsgpu.h")
+    r = subprocess.run(["gcc", "-x", "c", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", hdr], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    src = tmp_path / "host.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <string.h>
+#include "vsgpu.h"
+int main(void) {
+    vs_ctx* ctx = NULL;
+    uint32_t b = 0, e = 0;
+    if (vs_shard_range(11, 2, 1, &b, &e) != VS_OK || b != 6 || e != 11) { printf("shard arithmetic\n"); return 2; }
+    if (vs_shard_range(4, 2, 2, &b, &e) != VS_ERR_INVALID) { printf("bad rank accepted\n"); return 2; }
+    int rc = vs_ctx_create(0, &ctx);
+    if (rc == VS_OK) { printf("device: ok\n"); vs_ctx_destroy(ctx); return 0; }
+    if (rc != VS_ERR_HIP || ctx != NULL || strstr(vs_last_error(), "no CPU fallback") == NULL) { printf("unexpected: %d %s\n", rc, vs_last_error()); return 3; }
+    printf("no device: VS_ERR_HIP\n");
+    return 0;
+}
+''')
+    libdir = os.path.dirname(pgvectorscale_amd._lib.LIB_PATH)
+    exe = tmp_path / "host"
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe), "-L", libdir, "-l:libvsgpu.so",
+                        f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "VS_ERR_HIP" in r.stdout or "device: ok" in r.stdout

@@ -125,3 +125,33 @@ def test_comm_world_of_one_gathers_and_replicates(gpu_ctx, oracle, monkeypatch):
     finally:
         comm.close()
         ix.close()
+
+
+def test_multi_across_two_devices(gpu_ctx, oracle, monkeypatch):
+    """devices [0, 1]: the replica on device 1 is made with hipMemcpyPeerAsync (peer access enabled where the devices can reach each
+    other) and shard 1 really runs on the other device.  Needs two devices: the interpreter provides them (VS_EMU_DEVICES), a
+    single-GPU box skips, a multi-GPU box runs it for real."""
+    if os.environ.get("VS_EMU"):
+        monkeypatch.setenv("VS_EMU_DEVICES", "2")
+    try:
+        ctx1 = P.Context(1)
+    except P.VsError:
+        pytest.skip("one device only")
+    ti = _index()
+    src = ti.upload(gpu_ctx)
+    rep = M.replicate(src, ctx1)  # device 0 -> device 1
+    m = M.MultiIndex(src, [0, 1])
+    try:
+        q = ti.queries(21, seed=15)
+        keys = _keys(21, 4)
+        oi, od, ost = ti.oracle.search_batch(q, L=25, rescore=12, k=9, qlabels=keys)
+        ri, _, rd, _ = rep.search_batch(q, search_list_size=25, rescore=12, k=9, qlabels=keys)
+        gi, gt, gd, st = m.search_batch(q, search_list_size=25, rescore=12, k=9, qlabels=keys)
+        assert (ri == oi).all() and (gi == oi).all()
+        assert np.allclose(gd, od, rtol=1e-5, atol=0, equal_nan=True) and gd.tobytes() == rd.tobytes()
+        assert st["visited_nodes"] == ost["visited_nodes"]
+    finally:
+        m.close()
+        rep.close()
+        src.close()
+        ctx1.close()

@@ -292,11 +292,6 @@ def main():
                          "scans of that batch to qualify; the fastest qualified one is used when it beats the default by >= 3 %% twice), after "
                          "a child-process probe of the variants on a small index under a timeout (pgvectorscale_amd/tune_probe.py); the "
                          "line reports every candidate's time under `autotune`")
-    ap.add_argument("--workspace", default="auto", choices=["auto", "grow", "asis"],
-                    help="grow: before anything is timed, one throw-away batch at a large operating point (DiskAnnIndex.grow_workspace) makes "
-                         "the library allocate its search workspace once, as blocks of several GB — allocation history moves the search kernel "
-                         "by up to 10 %% at identical bytes (DESIGN.md 7, State); asis: whatever the batches before the timed region leave "
-                         "behind; auto = grow from 4M nodes (the table-less regime), asis below")
     ap.add_argument("--tune-reps", type=int, default=3, help="timed steps per variant (after one warm-up step each)")
     ap.add_argument("--probe-n", type=int, default=100_000, help="nodes of the probe child's index")
     ap.add_argument("--probe-timeout", type=float, default=240.0)
@@ -625,11 +620,6 @@ def main():
             gather_topk(out_ids, out_dist)
         return st
 
-    ws_grow = args.workspace == "grow" or (args.workspace == "auto" and n >= (4 << 20))
-    if ws_grow:
-        setup["workspace_grow_s"] = round(ix.grow_workspace(), 3)
-        log(f"search workspace grown by one throw-away batch at L=400 / rescore=1000 ({setup['workspace_grow_s']} s)")
-
     # a very wide operating point (a corpus on which the target is out of reach ends at L = 400 / rescore = 400) may not fit
     # 131072 scans into the workspace budget: halve the scans per step until a launch is accepted
     while True:
@@ -951,8 +941,8 @@ def main():
                    "topk_gather": None if world == 1 else ("vs_comm_gather_topk (libvsgpu C ABI: one grouped ncclAllGather of the id + distance blocks per step)" if comm is not None
                                                             else "torch.distributed all_gather_into_tensor (FALLBACK: vs_comm_* could not be initialised on every rank)"),
                    "batches_in_flight": args.pipeline,
-                   "workspace": ("grown before the timed region by one throw-away batch of 8 192 scans at L=400 / rescore=1000 (allocation history "
-                                 "moves k_search_fast by up to 10 % at identical bytes: DESIGN.md 7, State)") if ws_grow else "as the earlier batches left it"},
+                   "workspace": "library default (the persistent grid's dedup tables + heap spill arrays sub-allocated from the index's "
+                                "grow-only slab inside libvsgpu: VS_WS_SLAB_MB, 4 GB from 4M nodes)"},
         "recall_at_k": round(recall, 4),
         "recall_validate": round(recall_validate, 4),
         "recall_heldout": None if recall_heldout is None else round(recall_heldout, 4),

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cstdlib>
 
+#include <atomic>
 #include <mutex>
 #include <unordered_map>
 
@@ -27,20 +28,83 @@ extern "C" const char* vs_version(void) { return "vsgpu 0.1 (gfx950)"; }
 int devbuf_reserve(vs_ctx* ctx, DevBuf& b, size_t bytes) {
     (void)ctx;
     if (bytes <= b.bytes) return VS_OK;
-    if (b.p) {
-        VS_HIP(hipFree(b.p));
-        b.p = nullptr;
-        b.bytes = 0;
-    }
+    if (b.p && !b.in_slab) VS_HIP(hipFree(b.p));
+    b.p = nullptr;
+    b.bytes = 0;
+    b.in_slab = false;
     size_t want = bytes + bytes / 8 + 256;
     VS_HIP(hipMalloc(&b.p, want));
     b.bytes = want;
     return VS_OK;
 }
 void devbuf_free(DevBuf& b) {
-    if (b.p) (void)hipFree(b.p);
+    if (b.p && !b.in_slab) (void)hipFree(b.p);
     b.p = nullptr;
     b.bytes = 0;
+    b.in_slab = false;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// the workspace slab (WsSlab, vs_internal.h)
+// ---------------------------------------------------------------------------------------------------------------
+WsSlab* vs_slab_new(int device) {
+    WsSlab* s = new WsSlab();
+    s->device = device;
+    return s;
+}
+void vs_slab_release(WsSlab* s) {
+    if (!s) return;
+    bool last;
+    {
+        std::lock_guard<std::mutex> lk(s->mu);
+        last = --s->refs <= 0;
+    }
+    if (!last) return;
+    if (s->base) (void)hipFree(s->base);
+    delete s;
+}
+// VS_WS_SLAB_MB (default 4096; 0: no slab) for indexes of VS_WS_SLAB_MIN_N nodes and more (default 4M: smaller indexes run the
+// LDS-table regime or tables of a few MB in all, where placement was never seen to matter)
+static uint32_t env_u32(const char* name, uint32_t dflt);
+static size_t slab_bytes_wanted(const vs_index* ix) {
+    if (ix->d.n < env_u32("VS_WS_SLAB_MIN_N", 4u << 20)) return 0;
+    return (size_t)env_u32("VS_WS_SLAB_MB", 4096) << 20;
+}
+int devbuf_reserve_hot(vs_index* ix, DevBuf& b, size_t bytes) {
+    if (bytes <= b.bytes) return VS_OK;
+    WsSlab* s = ix->slab;
+    const size_t slab_bytes = s ? slab_bytes_wanted(ix) : 0;
+    if (slab_bytes) {
+        std::lock_guard<std::mutex> lk(s->mu);
+        if (!s->base && !s->tried) {
+            s->tried = true;
+            if (hipMalloc(&s->base, slab_bytes) == hipSuccess) {
+                s->bytes = slab_bytes;
+            } else {  // best effort: a device that cannot spare the slab serves exact-size allocations
+                (void)hipGetLastError();
+                s->base = nullptr;
+            }
+        }
+        if (s->base) {
+            const size_t kAlign = 1u << 16;
+            const size_t want = (bytes + bytes / 8 + kAlign - 1) / kAlign * kAlign;
+            // the newest chunk grows in place (the arrays of one handle alternate, so room is left behind each: 1/8 above)
+            if (b.in_slab && (char*)b.p + b.bytes == (char*)s->base + s->used && (size_t)((char*)b.p - (char*)s->base) + want <= s->bytes) {
+                s->used = (size_t)((char*)b.p - (char*)s->base) + want;
+                b.bytes = want;
+                return VS_OK;
+            }
+            if (s->used + want <= s->bytes) {
+                if (b.p && !b.in_slab) VS_HIP(hipFree(b.p));  // (synchronises: nothing in flight reads the old array)
+                b.p = (char*)s->base + s->used;
+                b.bytes = want;
+                b.in_slab = true;
+                s->used += want;
+                return VS_OK;
+            }
+        }
+    }
+    return devbuf_reserve(ix->ctx, b, bytes);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -383,7 +447,16 @@ static int index_alloc_common(vs_ctx* c, const vs_index_desc* desc, bool with_ve
     VS_HIP(hipSetDevice(c->device));
     vs_index* ix = new vs_index();
     ix->ctx = c;
+    ix->owner_id = vs_new_owner_id();
+    ix->slab = vs_slab_new(c->device);
     ix->d = *desc;
+    // (VS_WS_SLAB_EARLY=1: the slab is the index's FIRST device allocation instead of being made by the first search that needs it)
+    if (env_u32("VS_WS_SLAB_EARLY", 0) && slab_bytes_wanted(ix)) {
+        std::lock_guard<std::mutex> lk(ix->slab->mu);
+        ix->slab->tried = true;
+        if (hipMalloc(&ix->slab->base, slab_bytes_wanted(ix)) == hipSuccess) ix->slab->bytes = slab_bytes_wanted(ix);
+        else { (void)hipGetLastError(); ix->slab->base = nullptr; }
+    }
     ix->code_stride = round_up_u32(desc->words, 2);
     ix->nbr_stride = round_up_u32(desc->num_neighbors, 16);
     ix->vec_stride = round_up_u32(desc->dim_full, 4);
@@ -399,12 +472,25 @@ static int index_alloc_common(vs_ctx* c, const vs_index_desc* desc, bool with_ve
 // views point into their source's arrays: the count of live views is what lets the entry points that free or move those arrays
 // (label sets, start map) refuse while a lane / a second stream / a vs_multi shard could still launch on the old pointers
 static std::mutex vs_view_mu;
-static std::unordered_map<const vs_index*, int> vs_view_count;  // owner -> live views (owners without views have no entry)
+// keyed by the owner's id, not its address: an index allocated at the address of a freed one must not inherit (or lose) its count
+static std::unordered_map<uint64_t, int> vs_view_count;  // owner id -> live views (owners without views have no entry)
+uint64_t vs_new_owner_id() {
+    static std::atomic<uint64_t> next{1};
+    return next.fetch_add(1);
+}
 int vs_index_live_views(vs_index* ix) {
+    if (ix->is_view) return 0;  // (the mutators below refuse view handles outright: VS_REQUIRE_OWNER)
     std::lock_guard<std::mutex> lk(vs_view_mu);
-    const auto it = vs_view_count.find(ix);
+    const auto it = vs_view_count.find(ix->owner_id);
     return it == vs_view_count.end() ? 0 : it->second;
 }
+#define VS_REQUIRE_OWNER(ix, what)                                                                                                     \
+    do {                                                                                                                                \
+        if ((ix)->is_view) {                                                                                                            \
+            vs_set_error("%s: this handle is a view; the arrays belong to the index it was made from", what);                         \
+            return VS_ERR_STATE;                                                                                                        \
+        }                                                                                                                               \
+    } while (0)
 #define VS_REQUIRE_NO_VIEWS(ix, what)                                                                                                  \
     do {                                                                                                                                \
         const int _nv = vs_index_live_views(ix);                                                                                        \
@@ -421,10 +507,10 @@ extern "C" void vs_index_free(vs_index* ix) {
     {
         std::lock_guard<std::mutex> lk(vs_view_mu);
         if (ix->is_view) {
-            const auto it = vs_view_count.find(ix->view_of);  // (gone when the owner was freed first)
+            const auto it = vs_view_count.find(ix->owner_id);  // (gone when the owner was freed first)
             if (it != vs_view_count.end() && --it->second <= 0) vs_view_count.erase(it);
         } else {
-            const auto it = vs_view_count.find(ix);
+            const auto it = vs_view_count.find(ix->owner_id);
             if (it != vs_view_count.end()) {
                 fprintf(stderr, "[libvsgpu] vs_index_free: %d view(s) of this index are still alive; they must not be used any more\n", it->second);
                 vs_view_count.erase(it);
@@ -448,6 +534,7 @@ extern "C" void vs_index_free(vs_index* ix) {
     for (DevBuf* b : bufs) devbuf_free(*b);
     free(w.pend_blob);
     w.pend_blob = nullptr;
+    vs_slab_release(ix->slab);  // (after the stream synchronisation above; the last handle frees the allocation)
     delete ix;
 }
 
@@ -462,7 +549,13 @@ static int vs_index_view_impl(vs_index* src, vs_ctx* c, vs_index** out) {
     {
         std::lock_guard<std::mutex> lk(vs_view_mu);
         v->view_of = src->is_view ? src->view_of : src;  // (a view of a view is a view of the owner)
-        vs_view_count[v->view_of]++;
+        vs_view_count[v->owner_id]++;                    // (owner_id was copied from the source)
+    }
+    if (env_u32("VS_WS_SLAB_PRIVATE", 0)) {  // (measurement: a slab of the view's own, allocated by its first search)
+        v->slab = vs_slab_new(c->device);
+    } else if (v->slab) {  // the view's hot regions come out of the owner's slab
+        std::lock_guard<std::mutex> lk(v->slab->mu);
+        v->slab->refs++;
     }
     v->visible_own = nullptr;
     v->ws = SearchWorkspace{};
@@ -515,6 +608,7 @@ extern "C" int vs_index_get_quantizer(const vs_index* ix, float* mean, float* m2
 static int vs_index_set_start_nodes_impl(vs_index* ix, uint32_t default_start, const int16_t* labels,
                                         const uint32_t* nodes, uint32_t n) {
     VS_REQUIRE(ix, "vs_index_set_start_nodes: index is NULL");
+    VS_REQUIRE_OWNER(ix, "vs_index_set_start_nodes");
     VS_REQUIRE_NO_VIEWS(ix, "vs_index_set_start_nodes");
     VS_REQUIRE(default_start == VS_INVALID_NODE || default_start < ix->d.n, "default_start out of range");
     for (uint32_t i = 0; i < n; ++i) {
@@ -543,6 +637,7 @@ extern "C" int vs_index_set_start_nodes(vs_index* ix, uint32_t default_start, co
 
 static int vs_index_set_labels_impl(vs_index* ix, const uint32_t* label_off, const int16_t* label_val) {
     VS_REQUIRE(ix && label_off, "vs_index_set_labels: bad args");
+    VS_REQUIRE_OWNER(ix, "vs_index_set_labels");
     VS_REQUIRE_NO_VIEWS(ix, "vs_index_set_labels");
     const uint32_t n = ix->d.n;
     VS_REQUIRE(label_off[0] == 0, "label_off[0] must be 0");
@@ -1198,8 +1293,14 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
             f.persist = std::max<uint32_t>(1, (uint32_t)((uint64_t)res * env_u32("VS_F_PERSIST_PCT", 100) / 100));
             fslots = std::min(f.persist, nq);
         }
-        VS_TRY(devbuf_reserve(c, w.heap_g4, std::max<size_t>((size_t)(f.persist ? fslots : nq) * caps.f_gstride * 4, 16)));
-        VS_TRY(devbuf_reserve(c, w.ghash4, (size_t)fslots * caps.f_gcap * 4));
+        // (persistent grid: the two randomly accessed arrays live in the index's slab, dedup tables first)
+        if (f.persist) {
+            VS_TRY(devbuf_reserve_hot(ix, w.ghash4, (size_t)fslots * caps.f_gcap * 4));
+            VS_TRY(devbuf_reserve_hot(ix, w.heap_g4, std::max<size_t>((size_t)fslots * caps.f_gstride * 4, 16)));
+        } else {
+            VS_TRY(devbuf_reserve(c, w.heap_g4, std::max<size_t>((size_t)nq * caps.f_gstride * 4, 16)));
+            VS_TRY(devbuf_reserve(c, w.ghash4, (size_t)fslots * caps.f_gcap * 4));
+        }
         VS_TRY(devbuf_reserve(c, w.pool_ctr, 64));
         VS_HIP(hipMemsetAsync(w.pool_ctr.p, 0, 64, c->stream));
         VS_TRY(devbuf_reserve(c, w.fb_flag, (size_t)nq * 4));

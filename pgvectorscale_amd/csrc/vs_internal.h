@@ -6,6 +6,8 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <atomic>
+#include <mutex>
 #include <vector>
 
 #include "../../include/vsgpu.h"
@@ -92,6 +94,22 @@ void prof_end(vs_ctx* c, int kind, hipEvent_t a);
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
+    bool in_slab = false;  // a chunk of the index's WsSlab (never freed on its own)
+};
+
+// The hot, randomly accessed per-workgroup regions of the search workspace (dedup tables, heap spill arrays of the persistent grid:
+// 0.7 GB at 50M) run fastest packed at the start of ONE large device allocation: allocation history moved k_search_fast by +-10 % at
+// identical bytes while the regions lived in allocations of their own size (profiles/r04/s7_diag_state_50m.txt,
+// s11_diag_spread_50m.txt).  One grow-only slab per index, allocated by the first search that needs it and shared with every view
+// of the index (cursor lanes, second streams, the own-device shard of a vs_multi); chunks are bump-allocated, never returned one
+// by one, and the slab goes when the last handle that holds it does.
+struct WsSlab {
+    std::mutex mu;
+    void* base = nullptr;
+    size_t bytes = 0, used = 0;
+    int refs = 1;
+    int device = 0;
+    bool tried = false;  // the allocation failed once: handles fall back to allocations of their own
 };
 
 struct SearchWorkspace {
@@ -136,7 +154,9 @@ struct FastSig {
 struct vs_index {
     vs_ctx* ctx = nullptr;
     bool is_view = false;  // vs_index_view: the device arrays belong to another handle
-    vs_index* view_of = nullptr;  // ... that one (a key into the registry of live views, never dereferenced)
+    vs_index* view_of = nullptr;  // ... that one (never dereferenced: the owner may be gone)
+    uint64_t owner_id = 0;        // key of the owner in the registry of live views (unique per vs_index_alloc / replica, never reused)
+    WsSlab* slab = nullptr;       // shared by an index and its views (reference counted)
     vs_index_desc d{};
     uint32_t code_stride = 0;  // u64 words per code row (W rounded up to even, zero padded)
     uint32_t nbr_stride = 0;   // u32 per neighbor row (R rounded up to 16)
@@ -174,7 +194,21 @@ struct vs_index {
     vs_stats last_stats{};
 };
 
+// "done once per device" for function-scope statics (hipFuncSetAttribute is per device; one thread per device may launch the same
+// instantiation at once through vs_multi_*): pending() is true where the calling device's bit is not set yet, done() records it.
+// Setting an attribute twice is harmless, so two threads of one device racing through the unset state are fine.
+struct DeviceOnce {
+    std::atomic<uint64_t> mask{0};
+    bool pending(int device) const { return device < 0 || device >= 64 || !((mask.load(std::memory_order_acquire) >> device) & 1ull); }
+    void done(int device) {
+        if (device >= 0 && device < 64) mask.fetch_or(1ull << device, std::memory_order_acq_rel);
+    }
+};
 int devbuf_reserve(vs_ctx* ctx, DevBuf& b, size_t bytes);
+int devbuf_reserve_hot(vs_index* ix, DevBuf& b, size_t bytes);  // from the index's slab when it has one (else as devbuf_reserve)
+uint64_t vs_new_owner_id();
+WsSlab* vs_slab_new(int device);
+void vs_slab_release(WsSlab* s);
 int vs_index_live_views(vs_index* ix);  // views made of ix that have not been freed yet
 // row-wise staging through the pinned ring (device rows may be wider than host rows) / neighbor-list validation
 int vs_upload_rows(vs_ctx* c, void* dst, size_t dev_row_bytes, const void* src, size_t host_row_bytes, size_t copy_bytes, size_t rows);

@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <atomic>
 #include <mutex>
+#include <system_error>
 #include <thread>
 
 #include "vs_internal.h"
@@ -82,6 +83,8 @@ static int vs_index_replicate_impl(vs_index* src, vs_ctx* c, vs_index** out) {
     }
     vs_index* ix = new vs_index();
     ix->ctx = c;
+    ix->owner_id = vs_new_owner_id();
+    ix->slab = vs_slab_new(c->device);
     ix->d = src->d;
     ix->code_stride = src->code_stride;
     ix->nbr_stride = src->nbr_stride;
@@ -231,9 +234,19 @@ static int vs_multi_search_impl(vs_multi* m, const float* queries, const int16_t
         rc[g] = r;
         if (r != VS_OK) err[g] = vs_last_error();  // (thread-local: carried to the caller's thread below)
     };
+    // (a thread that cannot be created — std::system_error — must not unwind past joinable threads: its shard runs inline)
     std::vector<std::thread> th;
-    for (uint32_t g = 1; g < world; ++g) th.emplace_back(work, g);
+    th.reserve(world);
+    std::vector<uint32_t> inline_shards;
+    for (uint32_t g = 1; g < world; ++g) {
+        try {
+            th.emplace_back(work, g);
+        } catch (const std::system_error&) {
+            inline_shards.push_back(g);
+        }
+    }
     work(0);
+    for (uint32_t g : inline_shards) work(g);
     for (auto& t : th) t.join();
     for (uint32_t g = 0; g < world; ++g) {
         if (rc[g] != VS_OK) {
@@ -390,7 +403,7 @@ extern "C" int vs_comm_create(vs_ctx* ctx, const uint8_t* id, uint32_t rank, uin
             vs_comm_destroy(c);
             return VS_ERR_HIP;
         }
-        const int r = devbuf_reserve(ctx, c->scratch, 256);
+        const int r = devbuf_reserve(ctx, c->scratch, 8192);
         if (r != VS_OK) {
             vs_comm_destroy(c);
             return r;
@@ -489,18 +502,82 @@ static int vs_comm_replicate_index_impl(vs_comm* c, vs_index* ix, uint32_t root)
     VS_TRY(bcast_bytes(c, c->scratch.p, sizeof(hdr), root));
     VS_HIP(hipMemcpyAsync(hdr, c->scratch.p, sizeof(hdr), hipMemcpyDeviceToHost, s));
     VS_HIP(hipStreamSynchronize(s));
-    if (!is_root) {
+    // ---- every rank checks the header against its own index and makes every allocation the transfer needs, then the ranks exchange
+    // one word each: a rank that cannot go on (another geometry, out of device memory) fails the call on ALL ranks here, before
+    // anyone is inside a broadcast the others would wait in forever
+    const size_t n = std::max<uint32_t>(ix->d.n, 1);
+    const uint32_t nls = (uint32_t)hdr[9];
+    int my_rc = VS_OK;
+    auto prepare = [&]() -> int {
+        if (is_root) return VS_OK;
         VS_REQUIRE(hdr[0] == ix->d.n && hdr[1] == ix->d.dim_full && hdr[2] == ix->d.dim_index && hdr[3] == ix->d.bits && hdr[4] == ix->d.words &&
                        hdr[5] == ix->d.num_neighbors && hdr[6] == ix->d.distance_type && hdr[10] == ix->d.storage_type,
                    "vs_comm_replicate_index: rank %u allocated another geometry than the root's (n %u vs %llu, dim %u vs %llu)", c->rank,
                    ix->d.n, (unsigned long long)hdr[0], ix->d.dim_full, (unsigned long long)hdr[1]);
         VS_REQUIRE((hdr[13] != 0) == (ix->vecs != nullptr), "vs_comm_replicate_index: the root %s the heap vectors, rank %u %s",
                    hdr[13] ? "holds" : "does not hold", c->rank, ix->vecs ? "allocated them" : "did not allocate them");
+        if (hdr[14] && !ix->vnorm_idx) VS_HIP(hipMalloc(&ix->vnorm_idx, n * 4));
+        // label sets (AM/labels/mod.rs:15-37): the root's, or none when the root has none
+        if (ix->label_off) VS_HIP(hipFree(ix->label_off));
+        if (ix->label_val) VS_HIP(hipFree(ix->label_val));
+        ix->label_off = nullptr;
+        ix->label_val = nullptr;
+        ix->n_label_vals = 0;
+        ix->d.has_labels = 0;
+        if (!hdr[15]) {  // (the derived masks of an earlier label set go with it)
+            if (ix->label_mask) VS_HIP(hipFree(ix->label_mask));
+            if (ix->label_bit) VS_HIP(hipFree(ix->label_bit));
+            if (ix->nbr_mask) VS_HIP(hipFree(ix->nbr_mask));
+            ix->label_mask = nullptr;
+            ix->label_bit = nullptr;
+            ix->nbr_mask = nullptr;
+        }
+        ix->nbr_mask_valid = false;
+        ix->nbr_mask_tried = false;
+        if (hdr[15]) {
+            VS_HIP(hipMalloc(&ix->label_off, (n + 1) * 4));
+            VS_HIP(hipMalloc(&ix->label_val, std::max<uint64_t>(hdr[12], 1) * 2));
+        }
+        if (ix->ls_labels) VS_HIP(hipFree(ix->ls_labels));
+        if (ix->ls_nodes) VS_HIP(hipFree(ix->ls_nodes));
+        ix->ls_labels = nullptr;
+        ix->ls_nodes = nullptr;
+        ix->d.n_label_starts = 0;
+        if (nls) {
+            VS_HIP(hipMalloc(&ix->ls_labels, (size_t)nls * 2));
+            VS_HIP(hipMalloc(&ix->ls_nodes, (size_t)nls * 4));
+        }
+        if (hdr[16] && !ix->visible_own) VS_HIP(hipMalloc(&ix->visible_own, n));
+        if (!hdr[16]) ix->visible = nullptr;  // the root scans without a mask: so does the replica
+        return VS_OK;
+    };
+    my_rc = prepare();
+    const std::string my_err = my_rc == VS_OK ? std::string() : std::string(vs_last_error());
+    if (my_rc != VS_OK) (void)hipGetLastError();
+    {
+        VS_REQUIRE((size_t)c->world * 4 + 1024 + 4 <= c->scratch.bytes, "vs_comm_replicate_index: world of %u ranks", c->world);
+        uint32_t* words = reinterpret_cast<uint32_t*>((char*)c->scratch.p + 1024);  // [world] gathered, then this rank's own word
+        const uint32_t mine = my_rc == VS_OK ? 1u : 0u;
+        VS_HIP(hipMemcpyAsync(words + c->world, &mine, 4, hipMemcpyHostToDevice, s));
+        VS_NCCL(g_rccl.AllGather(words + c->world, words, 1, kNcclUint32, c->comm, s));
+        std::vector<uint32_t> ok(c->world);
+        VS_HIP(hipMemcpyAsync(ok.data(), words, (size_t)c->world * 4, hipMemcpyDeviceToHost, s));
+        VS_HIP(hipStreamSynchronize(s));
+        for (uint32_t r = 0; r < c->world; ++r) {
+            if (ok[r]) continue;
+            if (my_rc != VS_OK) vs_set_error("%s", my_err.c_str());
+            else vs_set_error("vs_comm_replicate_index: rank %u could not take the root's index (see its error); nothing was transferred", r);
+            return my_rc != VS_OK ? my_rc : VS_ERR_STATE;
+        }
+    }
+    if (!is_root) {
         ix->d.default_start = (uint32_t)hdr[8];
         ix->count = hdr[11];
         ix->build_unreachable = (uint32_t)hdr[17];
+        ix->n_label_vals = hdr[15] ? hdr[12] : 0;
+        ix->d.has_labels = hdr[15] ? (uint32_t)hdr[7] : 0;
+        ix->d.n_label_starts = nls;
     }
-    const size_t n = std::max<uint32_t>(ix->d.n, 1);
     VS_TRY(bcast_bytes(c, ix->codes, n * ix->code_stride * 8, root));
     VS_TRY(bcast_bytes(c, ix->nbrs, n * ix->nbr_stride * 4, root));
     VS_TRY(bcast_bytes(c, ix->tids, n * 8, root));
@@ -510,39 +587,13 @@ static int vs_comm_replicate_index_impl(vs_comm* c, vs_index* ix, uint32_t root)
         VS_TRY(bcast_bytes(c, ix->vecs, n * ix->vec_stride * 4, root));
         VS_TRY(bcast_bytes(c, ix->vnorm, n * 4, root));
     }
-    if (hdr[14]) {
-        if (!ix->vnorm_idx) VS_HIP(hipMalloc(&ix->vnorm_idx, n * 4));
-        VS_TRY(bcast_bytes(c, ix->vnorm_idx, n * 4, root));
-    }
-    if (hdr[15]) {  // label sets (AM/labels/mod.rs:15-37): CSR + the derived masks are rebuilt locally
-        if (!is_root) {
-            if (ix->label_off) VS_HIP(hipFree(ix->label_off));
-            if (ix->label_val) VS_HIP(hipFree(ix->label_val));
-            ix->label_off = nullptr;
-            ix->label_val = nullptr;
-            ix->n_label_vals = hdr[12];
-            VS_HIP(hipMalloc(&ix->label_off, (n + 1) * 4));
-            VS_HIP(hipMalloc(&ix->label_val, std::max<uint64_t>(ix->n_label_vals, 1) * 2));
-            ix->d.has_labels = (uint32_t)hdr[7];
-        }
+    if (hdr[14]) VS_TRY(bcast_bytes(c, ix->vnorm_idx, n * 4, root));
+    if (hdr[15]) {  // CSR travels; the derived masks are rebuilt locally
         VS_TRY(bcast_bytes(c, ix->label_off, ((size_t)ix->d.n + 1) * 4, root));
         VS_TRY(bcast_bytes(c, ix->label_val, (size_t)ix->n_label_vals * 2, root));
         if (!is_root) {
             VS_HIP(hipStreamSynchronize(s));
             VS_TRY(vs_refresh_label_masks(ix));
-            ix->nbr_mask_valid = false;
-        }
-    }
-    const uint32_t nls = (uint32_t)hdr[9];
-    if (!is_root) {
-        if (ix->ls_labels) VS_HIP(hipFree(ix->ls_labels));
-        if (ix->ls_nodes) VS_HIP(hipFree(ix->ls_nodes));
-        ix->ls_labels = nullptr;
-        ix->ls_nodes = nullptr;
-        ix->d.n_label_starts = nls;
-        if (nls) {
-            VS_HIP(hipMalloc(&ix->ls_labels, (size_t)nls * 2));
-            VS_HIP(hipMalloc(&ix->ls_nodes, (size_t)nls * 4));
         }
     }
     if (nls) {
@@ -550,7 +601,6 @@ static int vs_comm_replicate_index_impl(vs_comm* c, vs_index* ix, uint32_t root)
         VS_TRY(bcast_bytes(c, ix->ls_nodes, (size_t)nls * 4, root));
     }
     if (hdr[16]) {  // the visibility mask in force
-        if (!is_root && !ix->visible_own) VS_HIP(hipMalloc(&ix->visible_own, n));
         VS_TRY(bcast_bytes(c, is_root ? (void*)ix->visible : (void*)ix->visible_own, n, root));
         if (!is_root) ix->visible = ix->visible_own;
     }

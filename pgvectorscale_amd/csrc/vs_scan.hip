@@ -203,11 +203,12 @@ __global__ __launch_bounds__(WAVE) void k_scan_merge(const uint64_t* __restrict_
 
 template <int NCH, int Q>
 static int launch_scan_tq(vs_index* idx, const ScanArgs& a, dim3 grid, size_t lds) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_set;
+    const int attr_dev = idx->ctx->device;
+    if (attr_set.pending(attr_dev)) {
         VS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_topk<NCH, Q>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    160 * 1024));
-        attr_set = true;
+        attr_set.done(attr_dev);
     }
     hipLaunchKernelGGL((k_scan_topk<NCH, Q>), grid, dim3(SCAN_WAVES * WAVE), lds, idx->ctx->stream, a);
     VS_HIP(hipGetLastError());

@@ -692,15 +692,16 @@ int launch_search(vs_index* idx, const SearchLaunch& s, bool build_mode) {
         vs_set_error("dedup table sizes must be powers of two");
         return VS_ERR_INVALID;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_set;
+    const int attr_dev = idx->ctx->device;
+    if (attr_set.pending(attr_dev)) {
         VS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_search<false, false>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         VS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_search<true, false>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         VS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_search<false, true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+        attr_set.done(attr_dev);
     }
     if (plain) hipLaunchKernelGGL((k_search<false, true>), dim3(s.nq), dim3(WAVE), lds, idx->ctx->stream, a);
     else if (build_mode) hipLaunchKernelGGL((k_search<true, false>), dim3(s.nq), dim3(WAVE), lds, idx->ctx->stream, a);

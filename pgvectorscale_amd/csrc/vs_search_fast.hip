@@ -1463,11 +1463,12 @@ size_t fast_lds_bytes(const vs_index* idx, const FastLaunch& s) {
 
 template <int NCH, int VR, bool TIMING, int MINW, bool BUILD, bool FULL = true, int VG = 0>
 static int launch_fast_tt(vs_index* idx, const FastArgs& a, size_t lds, uint32_t* resident) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_set;
+    const int attr_dev = idx->ctx->device;
+    if (attr_set.pending(attr_dev)) {
         VS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_search_fast<NCH, VR, TIMING, MINW, BUILD, FULL, VG>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+        attr_set.done(attr_dev);
     }
     if (resident) {  // not a launch: how many scans (= single-wave workgroups) of this instantiation does the device hold at once?
         int per_cu = 0;

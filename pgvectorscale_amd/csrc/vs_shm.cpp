@@ -170,7 +170,20 @@ struct vs_shm_server {
         std::vector<float> query;
     };
     std::vector<Req> reqs;
-    const char* take(uint32_t slot);  // copies + validates; nullptr = accepted, else why not
+    // dispatcher-private: the slot's last accepted request has not been marked DONE by the SERVER yet.  A client that writes READY over
+    // the state word of its RUNNING slot is not taken again (its request would be copied over the one a lane is still reading, and the
+    // slot would be queued twice): the slot is looked at again once the server itself has finished it
+    std::unique_ptr<std::atomic<uint8_t>[]> in_flight;
+    bool posted(uint32_t slot) const {
+        return m.slot(slot)->state.load(std::memory_order_acquire) == S_READY && !in_flight[slot].load(std::memory_order_acquire);
+    }
+    void finish(uint32_t slot) {  // DONE, by the server: the slot may be taken again
+        SlotHead* s = m.slot(slot);
+        in_flight[slot].store(0, std::memory_order_release);
+        s->state.store(S_DONE, std::memory_order_release);
+        futex_wake(&s->state, 1);
+    }
+    const char* take(uint32_t slot);  // copies into a local, validates, publishes into reqs[slot] on success; nullptr = accepted, else why not
     // cursor lanes (vs_broker_config.cursor_lanes): a thread, a context (HIP stream) and a view of the index each; a streamed scan
     // is served by the lane its (client pid, scan id) hashes to, concurrently with the other lanes and with the shared launches
     struct Lane {
@@ -201,7 +214,7 @@ struct vs_shm_client {
 
 const char* vs_shm_server::take(uint32_t slot) {
     SlotHead* s = m.slot(slot);
-    Req& r = reqs[slot];
+    Req r;  // (a rejected request leaves reqs[slot] as it was: nothing unvalidated is ever visible to run_group / run_fetch)
     r.L = s->L;
     r.rescore = s->rescore;
     r.k = s->k;
@@ -223,6 +236,8 @@ const char* vs_shm_server::take(uint32_t slot) {
     memcpy(r.labels, s->labels, (size_t)r.n_labels * sizeof(int16_t));
     r.query.resize(d.dim_full);
     if (!r.null_query) memcpy(r.query.data(), Mapping::query(s), (size_t)d.dim_full * 4);
+    reqs[slot] = std::move(r);
+    in_flight[slot].store(1, std::memory_order_release);
     return nullptr;
 }
 
@@ -277,8 +292,7 @@ void vs_shm_server::run_group(const std::vector<uint32_t>& grp) {
         }
         s->rc = rc;
         snprintf(s->err, sizeof(s->err), "%s", err.c_str());
-        s->state.store(S_DONE, std::memory_order_release);
-        futex_wake(&s->state, 1);
+        finish(grp[i]);
     }
 }
 
@@ -316,6 +330,7 @@ void vs_shm_server::run_fetch(uint32_t slot, CursorTable& t) {
     vs_index* const ix = t.ix;  // (shadows the member: the handle this table's scans run through)
     SlotHead* const out = m.slot(slot);  // written (results), never read
     const Req* const s = &reqs[slot];    // the request as it was taken
+    const uint32_t req_k = s->k, req_skip = s->skip;  // (validated by take(): k <= kmax, the rows fit the slot)
     int rc = VS_OK;
     std::string err;
     uint32_t got = 0;
@@ -331,7 +346,7 @@ void vs_shm_server::run_fetch(uint32_t slot, CursorTable& t) {
             const uint8_t* prev = nullptr;
             rc = vs_index_snapshot_use(ix, s->snapshot, &prev);
             if (rc == VS_OK) {
-                if (at < cursors.size() && (cursors[at].sig != sig || cursors[at].pos != s->skip)) {
+                if (at < cursors.size() && (cursors[at].sig != sig || cursors[at].pos != req_skip)) {
                     drop_cursor(t, at);  // another scan under the same id, or a client that is somewhere else in it: start over
                     at = cursors.size();
                 }
@@ -350,8 +365,8 @@ void vs_shm_server::run_fetch(uint32_t slot, CursorTable& t) {
                     if (rc == VS_OK)
                         rc = vs_rescan(c.scan, s->null_query ? nullptr : s->query.data(), s->labels, s->n_labels,
                                        (int)s->has_label_key, s->L, s->rescore);
-                    if (rc == VS_OK) rc = vs_scan_prefetch(c.scan, s->skip + s->k);  // (one launch for the replay and the new rows)
-                    for (uint32_t i = 0; rc == VS_OK && i < s->skip; ++i) {  // fast-forward: the client has these rows
+                    if (rc == VS_OK) rc = vs_scan_prefetch(c.scan, req_skip + req_k);  // (one launch for the replay and the new rows)
+                    for (uint32_t i = 0; rc == VS_OK && i < req_skip; ++i) {  // fast-forward: the client has these rows
                         const int r = vs_gettuple(c.scan, nullptr, nullptr, nullptr);
                         if (r < 0) rc = r;
                         if (r <= 0) break;
@@ -367,14 +382,14 @@ void vs_shm_server::run_fetch(uint32_t slot, CursorTable& t) {
                         if (c.scan) vs_endscan(c.scan);
                     }
                 } else {
-                    rc = vs_scan_prefetch(cursors[at].scan, cursors[at].pos + s->k);
+                    rc = vs_scan_prefetch(cursors[at].scan, cursors[at].pos + req_k);
                     if (rc != VS_OK) err = vs_last_error();
                 }
                 if (rc == VS_OK) {
                     Cursor& c = cursors[at];
                     c.last_use = ++t.use_clock;
                     // (a fast-forward that fell short: the scan has fewer rows than the client skipped — nothing left to return)
-                    while (c.pos >= s->skip && got < s->k) {
+                    while (c.pos >= req_skip && got < req_k) {
                         const int r = vs_gettuple(c.scan, m.tids(out) + got, m.ids(out) + got, m.dist(out) + got);
                         if (r < 0) {
                             rc = r;
@@ -399,8 +414,7 @@ void vs_shm_server::run_fetch(uint32_t slot, CursorTable& t) {
     out->n_rows = rc == VS_OK ? got : 0;
     out->rc = rc;
     snprintf(out->err, sizeof(out->err), "%s", err.c_str());
-    out->state.store(S_DONE, std::memory_order_release);
-    futex_wake(&out->state, 1);
+    finish(slot);
 }
 
 void vs_shm_server::apply_puts() {
@@ -466,7 +480,7 @@ void vs_shm_server::run() {
         apply_puts();
         ready.clear();
         for (uint32_t i = 0; i < m.nslots; ++i)
-            if (m.slot(i)->state.load(std::memory_order_acquire) == S_READY) ready.push_back(i);
+            if (posted(i)) ready.push_back(i);
         if (ready.empty()) {
             futex_wait(&h->work_seq, seq, 50000);  // (50 ms: also the cadence of the dead-owner check below)
         } else {
@@ -481,7 +495,7 @@ void vs_shm_server::run() {
                     const uint32_t seq2 = h->work_seq.load(std::memory_order_acquire);
                     ready.clear();
                     for (uint32_t i = 0; i < m.nslots; ++i)
-                        if (m.slot(i)->state.load(std::memory_order_acquire) == S_READY) ready.push_back(i);
+                        if (posted(i)) ready.push_back(i);
                     const auto now = std::chrono::steady_clock::now();
                     if (ready.size() >= cfg.max_batch || now >= deadline || stop.load()) break;
                     const auto left = std::chrono::duration_cast<std::chrono::microseconds>(deadline - now).count();
@@ -666,6 +680,8 @@ int vs_shm_server_create(vs_index* idx, const char* name, uint32_t nslots, uint3
     h->magic = SHM_MAGIC;  // last: a client that sees the magic sees a complete header
     s->m.pin();
     s->reqs.resize(nslots);
+    s->in_flight.reset(new std::atomic<uint8_t>[nslots]);
+    for (uint32_t i = 0; i < nslots; ++i) s->in_flight[i].store(0);
     for (auto& l : s->lanes) {
         vs_shm_server::Lane* lp = l.get();
         lp->th = std::thread([s, lp] { s->run_lane(*lp); });

@@ -367,36 +367,6 @@ class DiskAnnIndex:
         check(self._L.vs_search_batch_dev(self.h, d_queries, d_qlabels, d_qlabel_off, nq, search_list_size, rescore, k, d_out_ids,
                                           d_out_tids, d_out_dist))
 
-    def grow_workspace(self, nq=8192, search_list_size=400, rescore=1000, k=10):
-        """Stop-gap of round 4 ("State"): one throw-away batch at a LARGE operating point, so that the library's search
-        workspace — which only ever grows — is allocated once, as blocks of several GB, before the batches that matter.  The search
-        kernel's hot private state (the per-workgroup dedup tables and heap spill arrays of the persistent grid, 0.7 GB at 50M) then
-        sits packed at the start of large allocations; measured on the MI355X the same batch ran in 153.2 ms there against 156.8 ms
-        in the library's own 0.45 GB allocations of the same process, and allocation history moves the kernel by up to 10 %
-        (profiles/r04/s7_diag_state_50m.txt, s11_diag_spread_50m.txt).  A slab inside the library replaces this call next round.
-        Returns the seconds it took; never raises (a workspace that cannot grow is not an error)."""
-        import time
-        t0 = time.time()
-        try:
-            nq = int(min(nq, 1 << 16))
-            dim = self.desc.dim_full
-            dq = self.ctx.alloc(nq * dim * 4)
-            di = self.ctx.alloc(nq * k * 4)
-            dd = self.ctx.alloc(nq * k * 4)
-            try:
-                q = np.zeros((nq, dim), np.float32)
-                q[:, 0] = 1.0  # (any vector does: the batch only has to be launched)
-                self.ctx.upload(dq, q)
-                S = rescore if self.desc.storage_type == _lib.VS_STORAGE_SBQ else 0
-                self.search_batch_dev(dq, nq, search_list_size, S, k, di, None, dd)
-                self.search_batch_dev_finish()
-            finally:
-                for p in (dq, di, dd):
-                    self.ctx.free(p)
-        except _lib.VsError:
-            pass
-        return time.time() - t0
-
     def search_batch_dev_finish(self):
         st = Stats()
         check(self._L.vs_search_batch_dev_finish(self.h, C.byref(st)))

@@ -36,12 +36,13 @@ def main():
     ap.add_argument("--rescore", type=int, default=195)
     ap.add_argument("--phase", default="build", choices=["build", "load"])
     ap.add_argument("--graph", default="/tmp/diag_graph")
-    ap.add_argument("--idle", type=float, default=60.0)
+    ap.add_argument("--idle", type=float, default=0.0, help="(b) seconds to idle before timing again (0: skip)")
     ap.add_argument("--pad-mb", type=int, default=0, help="allocate and hold this much device memory BEFORE the index arrays (shifts everything)")
     ap.add_argument("--ws-pad-mb", type=int, default=0, help="allocate and hold this much right before the first search (shifts the workspace only)")
     ap.add_argument("--lib", default=None, help="another build of libvsgpu (docs/experiments/ws_spread.patch: VS_WS_SPREAD_MB)")
     ap.add_argument("--spread", default=None, help="after the first timing: ','-separated WHAT:MB pairs, each timed in this process with the regions of "
                                                    "the persistent grid spread over MB of device memory (WHAT: 1 heap spill, 2 dedup tables, 3 both; needs --lib)")
+    ap.add_argument("--private-slabs", default="", help="','-separated MB: after (c0), fresh views with a slab of their own of these sizes")
     ap.add_argument("--early", action="store_true", help="allocate the query buffers and the whole search workspace right after the index "
                                                           "arrays (one dummy batch on the still empty graph), before anything else")
     args = ap.parse_args()
@@ -113,14 +114,23 @@ def main():
             os.environ["VS_WS_SPREAD_WHAT"], os.environ["VS_WS_SPREAD_MB"] = what, mb
             timed(ix, ctx, f"(s) regions spread: what={what} over {mb} MB each")
         os.environ["VS_WS_SPREAD_MB"] = "0"
-    if args.phase == "build":
-        time.sleep(args.idle)
-        timed(ix, ctx, f"(b) after {args.idle:.0f} idle seconds")
-        ctx2 = P.Context(0)
-        vw = ix.view(ctx2)
+    if True:
+        if args.idle > 0:
+            time.sleep(args.idle)
+            timed(ix, ctx, f"(b) after {args.idle:.0f} idle seconds")
         q2, out2 = q, out
 
-        def timed_view(label):
+        def timed_view(label, slab_mb=None, private=False, sleep=0.0):
+            # a fresh view = a new context and a new workspace; slab_mb = 0: its hot regions in allocations of their own size (the
+            # round-4 library), None: out of the index's slab (the library default)
+            if slab_mb is not None:
+                os.environ["VS_WS_SLAB_MB"] = str(slab_mb)
+            if private:
+                os.environ["VS_WS_SLAB_PRIVATE"] = "1"
+            if sleep:
+                time.sleep(sleep)
+            ctx2 = P.Context(0)
+            vw = ix.view(ctx2)
             nonlocal q2, out2
             ctx2.profile_enable(True)
             for _ in range(2):
@@ -134,12 +144,20 @@ def main():
                 p = ctx2.profile_read(reset=True)
                 ms.append(p["search"][0] / max(p["search"][1], 1))
             print(f"{label:58s}: search " + " ".join(f"{x:7.2f}" for x in ms) + f" ms   {smi()}", flush=True)
+            vw.close()
+            ctx2.close()
+            os.environ.pop("VS_WS_SLAB_MB", None)
+            os.environ.pop("VS_WS_SLAB_PRIVATE", None)
 
-        timed_view("(c) through a fresh view (workspace allocated now)")
+        timed_view("(c) through a fresh view (regions out of the index's slab)")
+        timed_view("(c0) through a fresh view, VS_WS_SLAB_MB=0 (own allocations)", slab_mb=0)
+        for mb in [int(x) for x in args.private_slabs.split(",") if x]:
+            timed_view(f"(p) fresh view, private slab of {mb} MB allocated now", slab_mb=mb, private=True)
+        if args.private_slabs:
+            timed_view("(p) fresh view, private slab of 4096 MB after 15 idle s", slab_mb=4096, private=True, sleep=15.0)
         timed(ix, ctx, "(d) the first handle again")
-        vw.close()
-        ctx2.close()
-        ix.save_graph(args.graph)
+        if args.phase == "build":
+            ix.save_graph(args.graph)
     ix.close()
     ctx.close()
 

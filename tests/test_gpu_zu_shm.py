@@ -516,4 +516,62 @@ def test_a_client_that_rewrites_its_request_after_posting_cannot_move_the_dispat
     finally:
         os.close(fd)
         srv.close()
+    # ... and with cursor lanes: a streamed request (OP_FETCH) is read by a LANE thread while the dispatcher keeps polling.  A client
+    # that writes READY over the state word of its RUNNING slot with k = 0xFFFFFFFF must neither get that request copied over the one
+    # the lane is serving nor get the slot queued twice (round-4 advisor finding: take() published before it validated)
+    name2 = f"/vs_shm_hostile_lanes_{os.getpid()}"
+    srv2 = P.ShmServer(ix, name2, nslots=nslots, kmax=kmax, max_batch=8, max_wait_us=100, cursor_lanes=2)
+    fd = os.open("/dev/shm" + name2, os.O_RDWR)
+    try:
+        size = os.fstat(fd).st_size
+        m = mmap.mmap(fd, size)
+        slot_bytes = struct.unpack_from("<6I", m, 0)[5]
+        victim = HDR + 1 * slot_bytes
+        q = ti.queries(1, seed=5, kind="gauss")[0].astype(np.float32)
+        want = ti.oracle.search_batch(q[None, :], L=20, rescore=8, k=5)[0][0]
+        for trial in range(8):
+            before = bytes(m[victim: victim + slot_bytes])
+            base = HDR
+            assert u32(base + OFF["state"]) == S_FREE
+            put32(base + OFF["state"], S_CLAIMED)
+            put32(base + OFF["pid"], os.getpid())
+            for key, v in (("L", 20), ("rescore", 8), ("k", 5), ("n_labels", 0), ("has_key", 0), ("null_q", 0), ("snapshot", 0), ("op", 1),
+                           ("skip", 0)):
+                put32(base + OFF[key], v)
+            struct.pack_into("<Q", m, base + OFF["scan_id"], 1000 + trial)
+            m[base + OFF["query"]: base + OFF["query"] + dim * 4] = q.tobytes()
+            put32(base + OFF["state"], S_READY)
+            put32(28, u32(28) + 1)
+            t0 = time.time()
+            while u32(base + OFF["state"]) not in (S_RUNNING, S_DONE) and time.time() - t0 < 20:
+                pass
+            # the slot is with a lane: post again over it, out of range
+            put32(base + OFF["k"], 0xFFFFFFFF)
+            put32(base + OFF["skip"], 0)
+            put32(base + OFF["state"], S_READY)
+            put32(28, u32(28) + 1)
+            deadline = time.time() + 30
+            seen_done = 0
+            while time.time() < deadline:  # the honest request's DONE, then (if the re-post survived it) the rejection's
+                if u32(base + OFF["state"]) == S_DONE:
+                    seen_done += 1
+                    time.sleep(0.05)
+                    if u32(base + OFF["state"]) == S_DONE:
+                        break
+                time.sleep(0.001)
+            assert u32(base + OFF["state"]) == S_DONE, "the dispatcher never finished the slot"
+            assert bytes(m[victim: victim + slot_bytes]) == before, "a lane wrote outside the slot it was serving"
+            put32(base + OFF["pid"], 0)
+            put32(base + OFF["state"], S_FREE)
+        m.close()
+        # the server is alive and exact for an honest client
+        cl = P.ShmClient(name2)
+        try:
+            gi = cl.search(q, search_list_size=20, rescore=8, k=5)[0]
+            assert (np.asarray(gi)[:5] == want).all()
+        finally:
+            cl.close()
+    finally:
+        os.close(fd)
+        srv2.close()
         ix.close()

@@ -136,6 +136,9 @@ SYMBOLS = {
     "vs_index_alloc": (_i, [_vp, C.POINTER(IndexDesc), _i, C.POINTER(_vp)]),
     "vs_index_free": (None, [_vp]),
     "vs_index_view": (_i, [_vp, _vp, _vp]),
+    "vs_index_set_slab": (_i, [_vp, _vp, C.c_size_t]),
+    "vs_ws_probe": (_i, [_vp, _vp, C.c_size_t, C.c_uint32, C.POINTER(C.c_float)]),
+    "vs_ws_probe_mix": (_i, [_vp, _vp, C.c_size_t, C.c_uint32, C.POINTER(C.c_float)]),
     "vs_index_get_desc": (_i, [_vp, C.POINTER(IndexDesc)]),
     "vs_index_array": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_u32)]),
     "vs_index_set_quantizer": (_i, [_vp, _vp, _vp, _u64]),

@@ -60,12 +60,187 @@ void vs_slab_release(WsSlab* s) {
         last = --s->refs <= 0;
     }
     if (!last) return;
-    if (s->base) (void)hipFree(s->base);
+    if (s->base && !s->external) (void)hipFree(s->base);
     delete s;
 }
+// The caller's own device memory as the slab of this handle (and of the views made of it afterwards): a host that manages HBM itself,
+// or one that has probed where the hot regions run fastest (vs_ws_probe).  Before the handle's first search; the memory stays the
+// caller's and must outlive the handle and its views.
+static int vs_index_set_slab_impl(vs_index* ix, void* p, size_t bytes) {
+    VS_REQUIRE(ix && p && bytes >= (1u << 20), "vs_index_set_slab: bad args (at least 1 MiB)");
+    VS_REQUIRE(!ix->ws.ghash4.p && !ix->ws.heap_g4.p, "vs_index_set_slab: the handle has searched already (its workspace exists)");
+    WsSlab* s = vs_slab_new(ix->ctx->device);
+    s->base = p;
+    s->bytes = bytes;
+    s->tried = true;
+    s->external = true;
+    vs_slab_release(ix->slab);
+    ix->slab = s;
+    return VS_OK;
+}
+extern "C" int vs_index_set_slab(vs_index* ix, void* p, size_t bytes) {
+    return vs_guard("vs_index_set_slab", [&] { return vs_index_set_slab_impl(ix, p, bytes); });
+}
+
+// The private-state traffic of k_search_fast in miniature, on an arbitrary device region: 24 single-wave workgroups per CU, each with
+// its own contiguous share of the region; per iteration 28 random 16-byte loads, 31 random 4-byte stores and 56 random 8-byte loads
+// inside that share (the dedup group loads, the dedup inserts, the heap's child pairs).  Milliseconds for `iters` iterations: where a
+// region is slow for this shape, the search kernel is slow with its workspace there ("State").
+__global__ __launch_bounds__(64) void k_ws_probe(uint8_t* base, size_t share, uint32_t iters, uint64_t* sink) {
+    const uint32_t lane = threadIdx.x;
+    uint8_t* tab = base + (size_t)blockIdx.x * share;
+    const uint32_t u16 = (uint32_t)(share / 16), u8 = (uint32_t)(share / 8), u4 = (uint32_t)(share / 4);
+    uint64_t acc = 0;
+    uint32_t ctr = blockIdx.x * 0x9E3779B9u + 99u;
+    for (uint32_t it = 0; it < iters; ++it) {
+        uint32_t h = ctr + lane * 0x85ebca6bu + it * 0xc2b2ae35u;
+        h ^= h >> 16; h *= 0x7feb352dU; h ^= h >> 15; h *= 0x846ca68bU; h ^= h >> 16;
+        if (lane < 28) {
+            const uint4 v = *reinterpret_cast<const uint4*>(tab + (size_t)(uint32_t)(((uint64_t)h * u16) >> 32) * 16);
+            acc += v.x ^ v.y ^ v.z ^ v.w;
+        }
+        if (lane < 56) acc += *reinterpret_cast<const uint64_t*>(tab + (size_t)(uint32_t)(((uint64_t)(h * 0x9E3779B1u) * u8) >> 32) * 8);
+        if (lane < 31 && acc != 0x123456789abcull) *reinterpret_cast<uint32_t*>(tab + (size_t)(uint32_t)(((uint64_t)(h ^ 0x5bd1e995u) * u4) >> 32) * 4) = h;
+        ctr += 0x632be5abu;
+    }
+    if (acc == 0x123456789abcull) sink[0] = acc;
+}
+static int vs_ws_probe_impl(vs_ctx* c, void* p, size_t bytes, uint32_t iters, float* ms_out) {
+    VS_REQUIRE(c && p && ms_out && bytes >= (64u << 20) && iters > 0, "vs_ws_probe: bad args (a region of at least 64 MiB)");
+    VS_HIP(hipSetDevice(c->device));
+    const uint32_t waves = (uint32_t)c->prop.multiProcessorCount * 24;
+    const size_t share = bytes / waves / 16 * 16;
+    static DeviceOnce attr_set;
+    if (attr_set.pending(c->device)) {
+        VS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ws_probe), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set.done(c->device);
+    }
+    const size_t lds = (160 * 1024) / 24 - 64;  // pins 24 workgroups per CU
+    hipEvent_t e0, e1;
+    VS_HIP(hipEventCreate(&e0));
+    VS_HIP(hipEventCreate(&e1));
+    uint64_t* sink = nullptr;
+    VS_HIP(hipMalloc(&sink, 8));
+    hipLaunchKernelGGL(k_ws_probe, dim3(waves), dim3(64), lds, c->stream, (uint8_t*)p, share, std::max(iters / 8, 1u), sink);  // warm-up
+    VS_HIP(hipEventRecord(e0, c->stream));
+    hipLaunchKernelGGL(k_ws_probe, dim3(waves), dim3(64), lds, c->stream, (uint8_t*)p, share, iters, sink);
+    VS_HIP(hipEventRecord(e1, c->stream));
+    VS_HIP(hipEventSynchronize(e1));
+    VS_HIP(hipEventElapsedTime(ms_out, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(sink);
+    return VS_OK;
+}
+extern "C" int vs_ws_probe(vs_ctx* c, void* p, size_t bytes, uint32_t iters, float* ms_out) {
+    return vs_guard("vs_ws_probe", [&] { return vs_ws_probe_impl(c, p, bytes, iters, ms_out); });
+}
+
+// The same with the rest of the search kernel's request mix around it, read from THIS index's arrays: per iteration one random neighbor
+// row (50 x 4-byte non-temporal loads), two passes of 16 random code rows (4 lanes x 16-byte non-temporal loads per 64 bytes of a row),
+// and the private-state requests above with the tables at the region's start and the heap arrays in its second half.  Device memory
+// is not uniform for this mix: the same launch takes 30.3 or 32.9 ms depending on which allocation holds the private state
+// (scripts/microbench/placemix.hip, profiles/r05/s6_placemix.txt), a property of the allocation, not of offsets inside it — and
+// k_search_fast follows (156 / 170 ms, profiles/r05/s4_placement_map_50m.txt).  So the slab is CHOSEN: see slab_select below.
+struct WsMixArgs {
+    const uint8_t* codes;
+    const uint32_t* nbrs;
+    uint64_t nrows;
+    uint32_t code_row_bytes, nbr_stride, R;
+    uint8_t* tab_base;
+    uint8_t* heap_base;
+    uint32_t tab_bytes, heap_bytes, iters;
+    uint64_t* sink;
+};
+__global__ __launch_bounds__(64) void k_ws_probe_mix(WsMixArgs a) {
+    const uint32_t lane = threadIdx.x, l4 = lane & 3, grp = lane >> 2;
+    uint8_t* tab = a.tab_base + (size_t)blockIdx.x * a.tab_bytes;
+    uint8_t* heap = a.heap_base + (size_t)blockIdx.x * a.heap_bytes;
+    const uint32_t t16 = a.tab_bytes / 16, t4 = a.tab_bytes / 4, h8 = a.heap_bytes / 8;
+    const uint32_t pieces = std::min<uint32_t>(a.code_row_bytes / 64, 3u);  // 64-byte pieces of a code row a 4-lane group reads
+    uint64_t acc = 0;
+    uint32_t ctr = blockIdx.x * 0x9E3779B9u + 12345u;
+    auto mix = [](uint32_t x) {
+        x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+        return x;
+    };
+    for (uint32_t it = 0; it < a.iters; ++it) {
+        const uint32_t h = mix(ctr + lane * 0x85ebca6bu + it * 0xc2b2ae35u);
+        const uint64_t nrow = ((uint64_t)mix(ctr ^ (it * 0x9E3779B1u)) * a.nrows) >> 32;
+        if (lane < a.R) acc += __builtin_nontemporal_load(a.nbrs + nrow * a.nbr_stride + lane);
+        if (lane < 28) {
+            const uint4 v = *reinterpret_cast<const uint4*>(tab + (size_t)(uint32_t)(((uint64_t)h * t16) >> 32) * 16);
+            acc += v.x ^ v.y ^ v.z ^ v.w;
+        }
+        if (lane < 31 && acc != 0x123456789abcull)
+            *reinterpret_cast<uint32_t*>(tab + (size_t)(uint32_t)(((uint64_t)(h ^ 0x5bd1e995u) * t4) >> 32) * 4) = h;
+        if (lane < 56) acc += *reinterpret_cast<const uint64_t*>(heap + (size_t)(uint32_t)(((uint64_t)(h * 0x9E3779B1u) * h8) >> 32) * 8);
+        for (uint32_t p = 0; p < 2; ++p) {
+            const uint64_t row = ((uint64_t)mix(ctr ^ ((it * 64u + p * 16u + grp) * 0x9E3779B1u) ^ 0xabcdefu) * a.nrows) >> 32;
+            const uint8_t* r = a.codes + row * a.code_row_bytes + 16u * l4;
+            for (uint32_t t = 0; t < pieces; ++t) {
+                const __uint128_t v = __builtin_nontemporal_load(reinterpret_cast<const __uint128_t*>(r + 64u * t));
+                acc += (uint64_t)__popcll((unsigned long long)v) + (uint64_t)__popcll((unsigned long long)(v >> 64));
+            }
+        }
+        ctr += 0x632be5abu;
+    }
+    if (acc == 0x123456789abcull) a.sink[0] = acc;
+}
+static int ws_probe_mix(vs_index* ix, void* p, size_t bytes, uint32_t iters, float* ms_out) {
+    vs_ctx* c = ix->ctx;
+    VS_REQUIRE(p && ms_out && bytes >= (64u << 20) && iters > 0 && ix->d.n > 0 && ix->codes && ix->nbrs, "vs_ws_probe_mix: bad args");
+    VS_HIP(hipSetDevice(c->device));
+    const uint32_t waves = (uint32_t)c->prop.multiProcessorCount * 24;
+    const size_t half = bytes / 2 / 4096 * 4096;
+    WsMixArgs a;
+    a.codes = reinterpret_cast<const uint8_t*>(ix->codes);
+    a.nbrs = ix->nbrs;
+    a.nrows = ix->d.n;
+    a.code_row_bytes = ix->code_stride * 8;
+    a.nbr_stride = ix->nbr_stride;
+    a.R = std::min<uint32_t>(ix->d.num_neighbors, 64);
+    a.tab_base = (uint8_t*)p;
+    a.heap_base = (uint8_t*)p + half;
+    a.tab_bytes = (uint32_t)std::min<size_t>(half / waves / 16 * 16, 58752);
+    a.heap_bytes = (uint32_t)std::min<size_t>(half / waves / 16 * 16, 53248);
+    a.iters = iters;
+    static DeviceOnce attr_set;
+    if (attr_set.pending(c->device)) {
+        VS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ws_probe_mix), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set.done(c->device);
+    }
+    const size_t lds = (160 * 1024) / 24 - 64;  // pins 24 workgroups per CU
+    hipEvent_t e0, e1;
+    VS_HIP(hipEventCreate(&e0));
+    VS_HIP(hipEventCreate(&e1));
+    uint64_t* sink = nullptr;
+    VS_HIP(hipMalloc(&sink, 8));
+    a.sink = sink;
+    WsMixArgs w = a;
+    w.iters = std::max(iters / 8, 1u);
+    hipLaunchKernelGGL(k_ws_probe_mix, dim3(waves), dim3(64), lds, c->stream, w);  // warm-up
+    VS_HIP(hipEventRecord(e0, c->stream));
+    hipLaunchKernelGGL(k_ws_probe_mix, dim3(waves), dim3(64), lds, c->stream, a);
+    VS_HIP(hipEventRecord(e1, c->stream));
+    VS_HIP(hipEventSynchronize(e1));
+    VS_HIP(hipEventElapsedTime(ms_out, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(sink);
+    return VS_OK;
+}
+extern "C" int vs_ws_probe_mix(vs_index* ix, void* p, size_t bytes, uint32_t iters, float* ms_out) {
+    return vs_guard("vs_ws_probe_mix", [&]() -> int {
+        VS_REQUIRE(ix != nullptr, "vs_ws_probe_mix: index is NULL");
+        return ws_probe_mix(ix, p, bytes, iters, ms_out);
+    });
+}
+
 // VS_WS_SLAB_MB (default 4096; 0: no slab) for indexes of VS_WS_SLAB_MIN_N nodes and more (default 4M: smaller indexes run the
 // LDS-table regime or tables of a few MB in all, where placement was never seen to matter)
 static uint32_t env_u32(const char* name, uint32_t dflt);
+static int ws_probe_mix(vs_index* ix, void* p, size_t bytes, uint32_t iters, float* ms_out);
 static size_t slab_bytes_wanted(const vs_index* ix) {
     if (ix->d.n < env_u32("VS_WS_SLAB_MIN_N", 4u << 20)) return 0;
     return (size_t)env_u32("VS_WS_SLAB_MB", 4096) << 20;
@@ -78,11 +253,36 @@ int devbuf_reserve_hot(vs_index* ix, DevBuf& b, size_t bytes) {
         std::lock_guard<std::mutex> lk(s->mu);
         if (!s->base && !s->tried) {
             s->tried = true;
-            if (hipMalloc(&s->base, slab_bytes) == hipSuccess) {
+            // Device memory is not uniform for the search kernel's request mix (see k_ws_probe_mix): up to VS_WS_SLAB_CANDIDATES
+            // allocations are made (all held until the choice, so that each lands somewhere else), each is timed with the mix probe
+            // against THIS index's arrays (a few ms), the fastest is kept and the others go back to the device.
+            const uint32_t ncand = std::max<uint32_t>(1, std::min<uint32_t>(env_u32("VS_WS_SLAB_CANDIDATES", 6), 16));
+            void* cand[16] = {nullptr};
+            float ms[16] = {0};
+            uint32_t got = 0;
+            const bool probe = ncand > 1 && ix->codes && ix->nbrs && ix->d.n > 0 && slab_bytes >= ((size_t)64 << 20);
+            for (uint32_t i = 0; i < (probe ? ncand : 1u); ++i) {
+                if (hipMalloc(&cand[i], slab_bytes) != hipSuccess) {  // best effort: what the device can spare
+                    (void)hipGetLastError();
+                    cand[i] = nullptr;
+                    break;
+                }
+                got = i + 1;
+                if (probe && ws_probe_mix(ix, cand[i], std::min<size_t>(slab_bytes, (size_t)1 << 30), 300, &ms[i]) != VS_OK) ms[i] = 1e30f;
+            }
+            uint32_t best = 0;
+            for (uint32_t i = 1; i < got; ++i)
+                if (ms[i] < ms[best]) best = i;
+            for (uint32_t i = 0; i < got; ++i)
+                if (i != best) (void)hipFree(cand[i]);
+            if (got) {
+                s->base = cand[best];
                 s->bytes = slab_bytes;
-            } else {  // best effort: a device that cannot spare the slab serves exact-size allocations
-                (void)hipGetLastError();
-                s->base = nullptr;
+            }
+            if (env_u32("VS_WS_DEBUG", 0) && got) {
+                fprintf(stderr, "[VS_WS_DEBUG] slab of %zu MB chosen among %u candidates (mix probe, ms):", slab_bytes >> 20, got);
+                for (uint32_t i = 0; i < got; ++i) fprintf(stderr, " %s%.3f", i == best ? "*" : "", ms[i]);
+                fprintf(stderr, "\n");
             }
         }
         if (s->base) {
@@ -1295,12 +1495,19 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
         }
         // (persistent grid: the two randomly accessed arrays live in the index's slab, dedup tables first)
         if (f.persist) {
-            VS_TRY(devbuf_reserve_hot(ix, w.ghash4, (size_t)fslots * caps.f_gcap * 4));
-            VS_TRY(devbuf_reserve_hot(ix, w.heap_g4, std::max<size_t>((size_t)fslots * caps.f_gstride * 4, 16)));
+            const uint32_t what = env_u32("VS_WS_SLAB_WHAT", 3);  // (measurement: 1 = only the dedup tables, 2 = only the heap spill arrays)
+            if (what & 1) VS_TRY(devbuf_reserve_hot(ix, w.ghash4, (size_t)fslots * caps.f_gcap * 4));
+            else VS_TRY(devbuf_reserve(c, w.ghash4, (size_t)fslots * caps.f_gcap * 4));
+            if (what & 2) VS_TRY(devbuf_reserve_hot(ix, w.heap_g4, std::max<size_t>((size_t)fslots * caps.f_gstride * 4, 16)));
+            else VS_TRY(devbuf_reserve(c, w.heap_g4, std::max<size_t>((size_t)fslots * caps.f_gstride * 4, 16)));
         } else {
             VS_TRY(devbuf_reserve(c, w.heap_g4, std::max<size_t>((size_t)nq * caps.f_gstride * 4, 16)));
             VS_TRY(devbuf_reserve(c, w.ghash4, (size_t)fslots * caps.f_gcap * 4));
         }
+        if (env_u32("VS_WS_DEBUG", 0))  // diagnostics: where the hot arrays live (scripts/diag_state.py --placement)
+            fprintf(stderr, "[VS_WS_DEBUG] ghash4 %p (%zu B%s) heap_g4 %p (%zu B%s) region bytes: table %zu heap %zu x %u regions; stream_ids %p qcodes %p\n", w.ghash4.p,
+                    w.ghash4.bytes, w.ghash4.in_slab ? ", slab" : "", w.heap_g4.p, w.heap_g4.bytes, w.heap_g4.in_slab ? ", slab" : "",
+                    (size_t)caps.f_gcap * 4, (size_t)caps.f_gstride * 4, fslots, w.stream_ids.p, w.qcodes.p);
         VS_TRY(devbuf_reserve(c, w.pool_ctr, 64));
         VS_HIP(hipMemsetAsync(w.pool_ctr.p, 0, 64, c->stream));
         VS_TRY(devbuf_reserve(c, w.fb_flag, (size_t)nq * 4));
@@ -1492,7 +1699,16 @@ static int collect_stats(vs_index* ix, uint32_t nq, uint32_t M, uint32_t rescore
         if (ix->d.storage_type == VS_STORAGE_PLAIN) st->full_distance_comparisons += hs[(size_t)q * ST_N + ST_DQ];
         else st->quantized_distance_comparisons += hs[(size_t)q * ST_N + ST_DQ];
         st->node_reads += hs[(size_t)q * ST_N + ST_READS];
-        st->next_calls += hs[(size_t)q * ST_N + ST_NEXT];
+        uint64_t next_calls = hs[(size_t)q * ST_N + ST_NEXT];
+        if (!stream_only && rescore > 0 && cnt[q] < M && next_calls > 0) {
+            // an exhausted stream under next_with_resort (AM/scan.rs:244-305): every amgettuple call that finds the window short asks
+            // `next` once more and gets None again.  The batch stands for min(k, rows + 1) calls (the executor stops at the first call
+            // without a row); the first call that runs into the end is number max(1, rows - rescore + 2)
+            const int64_t C = cnt[q], S = rescore, kk = (int64_t)M - rescore + 1;
+            const int64_t J = std::min<int64_t>(kk, C + 1), j0 = std::max<int64_t>(1, C - S + 2);
+            next_calls = next_calls - 1 + (uint64_t)std::max<int64_t>(J - j0 + 1, 1);
+        }
+        st->next_calls += next_calls;
         if (fb[q]) {
             st->fallback_scans++;
             st->fallback_visited_nodes += hs[(size_t)q * ST_N + ST_VISITS];

@@ -110,6 +110,7 @@ struct WsSlab {
     int refs = 1;
     int device = 0;
     bool tried = false;  // the allocation failed once: handles fall back to allocations of their own
+    bool external = false;  // the caller's memory (vs_index_set_slab): never freed here
 };
 
 struct SearchWorkspace {

@@ -63,6 +63,12 @@ class Context:
         names = ["prepare_queries", "search", "rerank", "resort", "search_fallback", "scan"]
         return {n: (float(p.ms[k]), int(p.launches[k])) for k, n in enumerate(names)}
 
+    def ws_probe(self, d_mem, nbytes, iters=600):
+        """milliseconds the search kernel's private-state request shapes take on this device region (vs_ws_probe)"""
+        ms = C.c_float(0)
+        check(self._L.vs_ws_probe(self.h, d_mem, nbytes, iters, C.byref(ms)))
+        return float(ms.value)
+
     def alloc(self, nbytes):
         p = C.c_void_p()
         check(self._L.vs_dev_alloc(self.h, nbytes, C.byref(p)))
@@ -103,6 +109,16 @@ class DiskAnnIndex:
         h = C.c_void_p()
         check(self._L.vs_index_view(self.h, ctx.h, C.byref(h)))
         return DiskAnnIndex(ctx, h)
+
+    def ws_probe_mix(self, d_mem, nbytes, iters=400):
+        """milliseconds of the search kernel's whole request mix with its private state on this device region (vs_ws_probe_mix)"""
+        ms = C.c_float(0)
+        check(self._L.vs_ws_probe_mix(self.h, d_mem, nbytes, iters, C.byref(ms)))
+        return float(ms.value)
+
+    def set_slab(self, d_mem, nbytes):
+        """the caller's device memory as this handle's workspace slab (vs_index_set_slab; before its first search)"""
+        check(self._L.vs_index_set_slab(self.h, d_mem, nbytes))
 
     # -- construction ---------------------------------------------------------------------------------------------
     @classmethod

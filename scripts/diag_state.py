@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--lib", default=None, help="another build of libvsgpu (docs/experiments/ws_spread.patch: VS_WS_SPREAD_MB)")
     ap.add_argument("--spread", default=None, help="after the first timing: ','-separated WHAT:MB pairs, each timed in this process with the regions of "
                                                    "the persistent grid spread over MB of device memory (WHAT: 1 heap spill, 2 dedup tables, 3 both; needs --lib)")
+    ap.add_argument("--placement", type=int, default=0, help="placement study: this many fresh views (see the code)")
     ap.add_argument("--private-slabs", default="", help="','-separated MB: after (c0), fresh views with a slab of their own of these sizes")
     ap.add_argument("--early", action="store_true", help="allocate the query buffers and the whole search workspace right after the index "
                                                           "arrays (one dummy batch on the still empty graph), before anything else")
@@ -138,7 +139,7 @@ def main():
                 vw.search_batch_dev_finish()
             ctx2.profile_read(reset=True)
             ms = []
-            for _ in range(4):
+            for _ in range(2 if args.placement else 4):
                 vw.search_batch_dev(q2, nq, args.L, args.rescore, k, out2)
                 vw.search_batch_dev_finish()
                 p = ctx2.profile_read(reset=True)
@@ -151,6 +152,31 @@ def main():
 
         timed_view("(c) through a fresh view (regions out of the index's slab)")
         timed_view("(c0) through a fresh view, VS_WS_SLAB_MB=0 (own allocations)", slab_mb=0)
+        if args.placement:
+            # placement study: many fresh views, each with its own slab (or own allocations), pads of odd sizes held in between so that
+            # every trial lands somewhere else; VS_WS_DEBUG prints the addresses of the two hot arrays next to each timing
+            import random
+            rnd = random.Random(12345)
+            os.environ["VS_WS_DEBUG"] = "1"
+            held = []
+            for t in range(args.placement):
+                kind = t % 4
+                pad_mb = rnd.choice([0, 3, 64, 200, 1000, 2500])
+                if pad_mb:
+                    held.append(ctx.alloc(pad_mb << 20))
+                if kind == 0:
+                    timed_view(f"(t{t}) pad {pad_mb} MB, own allocations", slab_mb=0)
+                elif kind == 1:
+                    timed_view(f"(t{t}) pad {pad_mb} MB, private slab 1024 MB", slab_mb=1024, private=True)
+                elif kind == 2:
+                    os.environ["VS_WS_SLAB_WHAT"] = "1"
+                    timed_view(f"(t{t}) pad {pad_mb} MB, private slab 1024 MB, tables only", slab_mb=1024, private=True)
+                    os.environ.pop("VS_WS_SLAB_WHAT")
+                else:
+                    os.environ["VS_WS_SLAB_WHAT"] = "2"
+                    timed_view(f"(t{t}) pad {pad_mb} MB, private slab 1024 MB, heap only", slab_mb=1024, private=True)
+                    os.environ.pop("VS_WS_SLAB_WHAT")
+            os.environ.pop("VS_WS_DEBUG")
         for mb in [int(x) for x in args.private_slabs.split(",") if x]:
             timed_view(f"(p) fresh view, private slab of {mb} MB allocated now", slab_mb=mb, private=True)
         if args.private_slabs:

@@ -2,11 +2,13 @@
 """Turns the two rocprofv3 --pmc passes of scripts/pmc_traffic.sh into HBM bytes per launch for k_search_fast (written to
 profiles/pmc_search_traffic.json, which bench.py reports as roofline.traffic when the configuration matches).
 
-FETCH_SIZE / WRITE_SIZE are in KiB.  On gfx950 FETCH_SIZE under-reports wide coalesced reads (MI355X_MICROARCH.md, HBM
-section), so the read side is calibrated on k_scan_topk of the same process, whose traffic is known exactly
-(tiles * n * 8 * code_stride bytes; 16-B-per-lane loads like the search kernel's code gathers)."""
+FETCH_SIZE / WRITE_SIZE are in KiB.  On gfx950 FETCH_SIZE tallies a 128-byte request at 64 B (MI355X_MICROARCH.md, HBM section); how that
+plays out for each request shape of the search kernel is taken from the calibration run of scripts/pmc_calibrate.sh
+(profiles/rNN/pmc_calibration_randmem.json).  The flat scan k_scan_topk of the same process (known bytes: tiles * n * 8 * code_stride)
+is kept as a cross-check of the streaming factor."""
 import argparse
 import csv
+import glob
 import json
 import os
 import re
@@ -64,19 +66,35 @@ def main():
         wb = sum(w) / len(w) * 1024
         out[kern] = {"FETCH_SIZE_bytes": round(fb), "WRITE_SIZE_bytes": round(wb), "read_bytes_calibrated": round(fb * cal),
                      "hbm_bytes_per_launch": round(fb * cal + wb)}
-    # FETCH_SIZE = read requests x 64 B, and a 128-byte request is tallied as 64 (MI355X_MICROARCH.md, HBM section; the flat scan
-    # above measures exactly that factor of two).  k_search_fast mixes request sizes: a 192-byte code row is one 128-byte and
-    # one 64-byte request (scripts/microbench/randmem.hip: FETCH_SIZE = 2/3 of the bytes of a pure row gather), a 256-byte
-    # neighbor row two 128-byte requests, everything else (dedup buckets, heap spill) 64-byte requests.  So its read bytes are
-    # FETCH_SIZE + 64 B per 128-byte request, with the request counts taken from the kernel's own work counters.
+    # FETCH_SIZE under-reports 128-byte requests (tallied at 64 B: MI355X_MICROARCH.md, HBM section).  How much each request SHAPE of
+    # k_search_fast is under-reported is MEASURED, not modelled: scripts/microbench/pmccal.hip issues each shape a known number of
+    # times over footprints beyond every cache, under the same two --pmc passes (scripts/pmc_calibrate.sh ->
+    # profiles/rNN/pmc_calibration_randmem.json): counter bytes per 192-byte code row (4 lanes x 3 non-temporal 16-byte loads), per
+    # neighbor row (50 x 4-byte non-temporal loads = four 64-byte sectors), per 16-byte table load, per 8-byte heap load, per 4-byte store.
+    # Read bytes of a launch = FETCH_SIZE + rows x (sector bytes of a row - counter bytes of a row) for the two row shapes, with the row
+    # counts from the kernel's own work counters; the small loads and the stores need no correction (their requests are 64-byte or
+    # smaller ones, tallied as they are).
+    cal_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[5-9]", "pmc_calibration_randmem.json")))
     m2 = re.search(r"visits/q ([0-9.]+) dq/q ([0-9.]+)", log)
-    if m2 and "k_search_fast" in out:
+    if m2 and "k_search_fast" in out and cal_files:
+        cj = json.load(open(cal_files[-1]))["patterns"]
+        c192 = cj["cal_rows192"]["fetch_bytes_per_request"]
+        c200 = cj["cal_rows200"]["fetch_bytes_per_request"]
+        stream = cj["cal_stream16"]["fetch_over_requested"]
         visits, dq = float(m2.group(1)) * args.nq, float(m2.group(2)) * args.nq
         ks = out["k_search_fast"]
-        ks["requests_of_128_bytes"] = round(dq + 2 * visits)
-        ks["read_bytes_corrected"] = round(ks["FETCH_SIZE_bytes"] + 64 * (dq + 2 * visits))
+        ks["calibration"] = {"file": os.path.relpath(cal_files[-1], ROOT), "counter_bytes_per_code_row_192B": c192,
+                             "counter_bytes_per_neighbor_row_256B_sectors": c200, "streaming_read_counter_over_bytes": stream,
+                             "counter_bytes_per_16B_table_load": cj["cal_small_load<16>"]["fetch_bytes_per_request"],
+                             "counter_bytes_per_8B_heap_load": cj["cal_small_load<8>"]["fetch_bytes_per_request"],
+                             "write_counter_bytes_per_4B_store": cj["cal_small_store<unsigned int>"]["write_bytes_per_request"],
+                             "streaming_write_counter_over_bytes": cj["cal_wstream16"]["write_over_requested"]}
+        ks["code_rows"] = round(dq)
+        ks["neighbor_rows"] = round(visits)
+        ks["read_bytes_corrected"] = round(ks["FETCH_SIZE_bytes"] + dq * (192.0 - c192) + visits * (256.0 - c200))
         ks["hbm_bytes_per_launch"] = ks["read_bytes_corrected"] + ks["WRITE_SIZE_bytes"]
         ks["algorithmic_bytes_per_launch"] = round(dq * 192 + visits * 200)
+        ks["traffic_over_algorithmic"] = round(ks["hbm_bytes_per_launch"] / ks["algorithmic_bytes_per_launch"], 4)
         out["alg_bytes_per_launch"] = ks["algorithmic_bytes_per_launch"]
     out["hbm_bytes_per_launch"] = out.get("k_search_fast", {}).get("hbm_bytes_per_launch")
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)

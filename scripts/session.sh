@@ -16,6 +16,10 @@ for step in "$@"; do
     diag)  N=${arg:-50000000}
            timeout 900 python scripts/diag_state.py --n $N --phase build --graph /tmp/diag_graph $DIAG_ARGS 2>&1 | grep -Ev "$NOBANNER" | sed 's/ *GPU\[0\].*//' | tee $O/diag_state_$N.txt
            [ -n "$DIAG_BUILD_ONLY" ] || timeout 600 python scripts/diag_state.py --n $N --phase load --graph /tmp/diag_graph $DIAG_ARGS 2>&1 | grep -Ev "$NOBANNER" | sed 's/ *GPU\[0\].*//' | tee -a $O/diag_state_$N.txt ;;
+    place) N=${arg:-50000000}   # placement study in a process that LOADS the graph a diag step of this session wrote (or builds it)
+           PH=load; [ -f /tmp/diag_graph ] || PH=build
+           timeout 900 python scripts/diag_state.py --n $N --phase $PH --graph /tmp/diag_graph --placement ${PLACE_TRIALS:-24} 2>&1 | grep -Ev "$NOBANNER" | sed 's/ *GPU\[0\].*//' | uniq | tee $O/placement_$N.txt ;;
+    pmap)  timeout 1200 python scripts/placement_map.py --n ${arg:-50000000} $PMAP_ARGS 2>&1 | grep -Ev "$NOBANNER" | tee $O/placement_map.txt ;;
     bench) timeout 2400 python bench.py $arg > $O/bench_$(echo "$arg" | tr -c 'A-Za-z0-9\n' '_').json 2> $O/bench.err; tail -3 $O/bench.err; tail -c 1500 $O/bench_*.json ;;
     ab)    N=${arg%%:*}; CFG=${arg#*:}
            timeout 1500 python scripts/perf_search.py --n $N --nq 262144 --L 3 --rescore 195 --reps 4 --graph-cache /tmp/g --configs "$CFG" 2>&1 | grep -Ev "$NOBANNER" | tee $O/ab_$N.txt ;;

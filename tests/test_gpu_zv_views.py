@@ -69,6 +69,12 @@ def test_entry_points_that_move_the_arrays_refuse_while_a_view_is_alive(gpu_ctx)
                 ix.set_start_nodes(ti.start, ti.label_starts)
             vw2.close()
             vw2 = vw.view(ctx2)
+        # ... and a VIEW handle is never allowed to move them (its live-view count is not the owner's)
+        with pytest.raises(P.VsError) as ei:
+            vw.set_labels(ti.label_off, ti.label_val)
+        assert ei.value.code == -5 and "view" in str(ei.value)
+        with pytest.raises(P.VsError):
+            vw2.set_start_nodes(ti.start, ti.label_starts)
         vw2.close()
         vw.close()
         ix.set_labels(ti.label_off, ti.label_val)  # no view left: allowed again
@@ -79,4 +85,28 @@ def test_entry_points_that_move_the_arrays_refuse_while_a_view_is_alive(gpu_ctx)
         assert (gi == oi).all()
     finally:
         ix.close()
+        ctx2.close()
+
+
+def test_a_stale_view_does_not_touch_the_count_of_a_new_index_at_the_same_address(gpu_ctx):
+    """the registry of live views is keyed by an owner id, not by the owner's address: freeing a view whose owner is gone must not
+    decrement the count of an index that was allocated where the old owner lived (round-4 advisor finding)"""
+    ti = cached_index(n=600, dim_full=32, bits=2, R=16, distance=1, seed=43, kind="gauss", L_build=30, n_labels=4)
+    ctx2 = P.Context(0)
+    ix = ti.upload(gpu_ctx)
+    stale = ix.view(ctx2)
+    ix.close()  # (the library warns: the view must not be used any more — it is only freed below)
+    fresh = [ti.upload(gpu_ctx) for _ in range(4)]  # one of them is likely to reuse the freed handle's address
+    views = [f.view(ctx2) for f in fresh]
+    try:
+        stale.close()
+        for f in fresh:  # every new index still counts its own view
+            with pytest.raises(P.VsError) as ei:
+                f.set_labels(ti.label_off, ti.label_val)
+            assert ei.value.code == -5
+    finally:
+        for v in views:
+            v.close()
+        for f in fresh:
+            f.close()
         ctx2.close()

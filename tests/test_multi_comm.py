@@ -94,3 +94,54 @@ def test_two_ranks_replicate_search_and_gather(tmp_path, oracle, emu_libs, nq_to
             got = np.load(out % r)
             assert (got[name + "_ids"] == want_i).all(), (name, r)
             assert np.allclose(got[name + "_dist"], want_d, rtol=1e-5, atol=0, equal_nan=True), (name, r)
+
+
+def _worker_mismatch(rank, world, conn, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["VS_RCCL_LIB"] = os.path.join(EMU_DIR, "libfakerccl.so")
+    os.environ["VS_NO_TORCH"] = "1"
+    from pgvectorscale_amd import _lib
+    _lib.LIB_PATH = os.path.join(EMU_DIR, "libvsgpu_emu.so")
+    import pgvectorscale_amd as P
+    from helpers import cached_index
+    from oracle import oracle_py as O
+    from pgvectorscale_amd import multi as M
+    ti = cached_index(n=700, dim_full=32, bits=2, R=16, distance=O.COSINE, seed=3, kind="uniform", n_labels=4, L_build=40)
+    ctx = P.Context(0)
+    if rank == 0:
+        uid = M.comm_unique_id()
+        conn.send(uid)
+    else:
+        uid = conn.recv()
+    comm = M.Comm(ctx, uid, rank, world)
+    if rank == 0:
+        ix = ti.upload(ctx)
+    else:  # ANOTHER geometry than the root's
+        ix = P.DiskAnnIndex.alloc(ctx, n=ti.n + 1, dim_full=ti.dim_full, bits=ti.bits, num_neighbors=ti.R, distance_type=ti.distance)
+    msg = "no error"
+    try:
+        comm.replicate_index(ix, 0)
+    except P.VsError as e:
+        msg = str(e)
+    open(out_path % rank, "w").write(msg)
+    comm.close()
+    ix.close()
+    ctx.close()
+
+
+def test_replicate_fails_on_every_rank_together(tmp_path, oracle, emu_libs):
+    """a rank that cannot take the root's index (another geometry here) fails the call on ALL ranks before the array broadcasts start:
+    nobody is left waiting inside a collective (round-4 advisor finding)"""
+    out = str(tmp_path / "rank%d.txt")
+    mpc = mp.get_context("spawn")
+    a, b = mpc.Pipe()
+    procs = [mpc.Process(target=_worker_mismatch, args=(r, 2, (a, b)[r], out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0, "a rank hung or died"
+    m0, m1 = open(out % 0).read(), open(out % 1).read()
+    assert "rank 1 could not take the root's index" in m0, m0
+    assert "another geometry" in m1, m1

@@ -60,7 +60,8 @@ void vs_slab_release(WsSlab* s) {
         last = --s->refs <= 0;
     }
     if (!last) return;
-    if (s->base && !s->external) (void)hipFree(s->base);
+    for (void* o : s->owned)
+        if (o) (void)hipFree(o);
     delete s;
 }
 // The caller's own device memory as the slab of this handle (and of the views made of it afterwards): a host that manages HBM itself,
@@ -70,9 +71,11 @@ static int vs_index_set_slab_impl(vs_index* ix, void* p, size_t bytes) {
     VS_REQUIRE(ix && p && bytes >= (1u << 20), "vs_index_set_slab: bad args (at least 1 MiB)");
     VS_REQUIRE(!ix->ws.ghash4.p && !ix->ws.heap_g4.p, "vs_index_set_slab: the handle has searched already (its workspace exists)");
     WsSlab* s = vs_slab_new(ix->ctx->device);
-    s->base = p;
-    s->bytes = bytes;
-    s->tried = true;
+    const size_t half = bytes / 2 / 65536 * 65536;
+    s->base[0] = p;
+    s->base[1] = (char*)p + half;
+    s->bytes[0] = s->bytes[1] = half;
+    s->tried = true;  // (nothing owned: the memory stays the caller's)
     s->external = true;
     vs_slab_release(ix->slab);
     ix->slab = s;
@@ -187,12 +190,12 @@ __global__ __launch_bounds__(64) void k_ws_probe_mix(WsMixArgs a) {
     }
     if (acc == 0x123456789abcull) a.sink[0] = acc;
 }
-static int ws_probe_mix(vs_index* ix, void* p, size_t bytes, uint32_t iters, float* ms_out) {
+// tables on [tab, tab + half), heap arrays on [heap, heap + half)
+static int ws_probe_mix(vs_index* ix, void* tab, void* heap, size_t half, uint32_t iters, float* ms_out) {
     vs_ctx* c = ix->ctx;
-    VS_REQUIRE(p && ms_out && bytes >= (64u << 20) && iters > 0 && ix->d.n > 0 && ix->codes && ix->nbrs, "vs_ws_probe_mix: bad args");
+    VS_REQUIRE(tab && heap && ms_out && half >= (32u << 20) && iters > 0 && ix->d.n > 0 && ix->codes && ix->nbrs, "vs_ws_probe_mix: bad args");
     VS_HIP(hipSetDevice(c->device));
     const uint32_t waves = (uint32_t)c->prop.multiProcessorCount * 24;
-    const size_t half = bytes / 2 / 4096 * 4096;
     WsMixArgs a;
     a.codes = reinterpret_cast<const uint8_t*>(ix->codes);
     a.nbrs = ix->nbrs;
@@ -200,8 +203,8 @@ static int ws_probe_mix(vs_index* ix, void* p, size_t bytes, uint32_t iters, flo
     a.code_row_bytes = ix->code_stride * 8;
     a.nbr_stride = ix->nbr_stride;
     a.R = std::min<uint32_t>(ix->d.num_neighbors, 64);
-    a.tab_base = (uint8_t*)p;
-    a.heap_base = (uint8_t*)p + half;
+    a.tab_base = (uint8_t*)tab;
+    a.heap_base = (uint8_t*)heap;
     a.tab_bytes = (uint32_t)std::min<size_t>(half / waves / 16 * 16, 58752);
     a.heap_bytes = (uint32_t)std::min<size_t>(half / waves / 16 * 16, 53248);
     a.iters = iters;
@@ -232,74 +235,106 @@ static int ws_probe_mix(vs_index* ix, void* p, size_t bytes, uint32_t iters, flo
 }
 extern "C" int vs_ws_probe_mix(vs_index* ix, void* p, size_t bytes, uint32_t iters, float* ms_out) {
     return vs_guard("vs_ws_probe_mix", [&]() -> int {
-        VS_REQUIRE(ix != nullptr, "vs_ws_probe_mix: index is NULL");
-        return ws_probe_mix(ix, p, bytes, iters, ms_out);
+        VS_REQUIRE(ix != nullptr && p != nullptr, "vs_ws_probe_mix: bad args");
+        const size_t half = bytes / 2 / 4096 * 4096;
+        return ws_probe_mix(ix, p, (char*)p + half, half, iters, ms_out);
     });
 }
 
 // VS_WS_SLAB_MB (default 4096; 0: no slab) for indexes of VS_WS_SLAB_MIN_N nodes and more (default 4M: smaller indexes run the
 // LDS-table regime or tables of a few MB in all, where placement was never seen to matter)
 static uint32_t env_u32(const char* name, uint32_t dflt);
-static int ws_probe_mix(vs_index* ix, void* p, size_t bytes, uint32_t iters, float* ms_out);
 static size_t slab_bytes_wanted(const vs_index* ix) {
     if (ix->d.n < env_u32("VS_WS_SLAB_MIN_N", 4u << 20)) return 0;
     return (size_t)env_u32("VS_WS_SLAB_MB", 4096) << 20;
 }
-int devbuf_reserve_hot(vs_index* ix, DevBuf& b, size_t bytes) {
+// Device memory is not uniform for the search kernel's request mix (k_ws_probe_mix): up to VS_WS_SLAB_CANDIDATES allocations of the
+// slab's size are made (all held until the choice, so that each lands somewhere else) and every PAIR (tables on candidate i, heap
+// arrays on candidate j, i == j: the two halves of one allocation) is timed with the mix probe against THIS index's arrays (a few ms
+// each); the best pair is kept, the other candidates go back to the device.
+static void slab_select(vs_index* ix, WsSlab* s, size_t slab_bytes) {
+    s->tried = true;
+    const uint32_t ncand = std::max<uint32_t>(1, std::min<uint32_t>(env_u32("VS_WS_SLAB_CANDIDATES", 6), 8));
+    const size_t half = slab_bytes / 2 / 65536 * 65536;
+    void* cand[8] = {nullptr};
+    uint32_t got = 0;
+    const bool probe = ncand > 1 && ix->codes && ix->nbrs && ix->d.n > 0 && half >= ((size_t)64 << 20);
+    for (uint32_t i = 0; i < (probe ? ncand : 1u); ++i) {
+        if (hipMalloc(&cand[i], slab_bytes) != hipSuccess) {  // best effort: what the device can spare
+            (void)hipGetLastError();
+            cand[i] = nullptr;
+            break;
+        }
+        got = i + 1;
+    }
+    if (!got) return;
+    uint32_t bi = 0, bj = 0;
+    float ms[8][8];
+    if (probe && got > 1) {
+        const size_t ph = std::min<size_t>(half, (size_t)512 << 20);
+        float best = 1e30f;
+        for (uint32_t i = 0; i < got; ++i)
+            for (uint32_t j = 0; j < got; ++j) {
+                // (i == j: the heap arrays in the second half of the same allocation; i != j: at the start of the other one)
+                void* hb = i == j ? (void*)((char*)cand[j] + half) : cand[j];
+                if (ws_probe_mix(ix, cand[i], hb, ph, 200, &ms[i][j]) != VS_OK) ms[i][j] = 1e30f;
+                // a pair of two allocations has to beat the best single one by 1 %: it costs the device a second slab
+                const float v = i == j ? ms[i][j] : ms[i][j] * 1.01f;
+                if (v < best) {
+                    best = v;
+                    bi = i;
+                    bj = j;
+                }
+            }
+    }
+    s->base[0] = cand[bi];
+    s->owned[0] = cand[bi];
+    if (bi == bj) {
+        s->base[1] = (char*)cand[bi] + half;
+        s->bytes[0] = s->bytes[1] = half;
+    } else {  // two allocations, each whole for its kind
+        s->base[1] = cand[bj];
+        s->owned[1] = cand[bj];
+        s->bytes[0] = s->bytes[1] = slab_bytes;
+    }
+    for (uint32_t i = 0; i < got; ++i)
+        if (i != bi && i != bj) (void)hipFree(cand[i]);
+    if (env_u32("VS_WS_DEBUG", 0)) {
+        fprintf(stderr, "[VS_WS_DEBUG] workspace slab: %u candidates of %zu MB, tables on %u, heap arrays on %u", got, slab_bytes >> 20, bi, bj);
+        if (probe && got > 1) {
+            fprintf(stderr, "; mix probe ms [tables][heaps]:");
+            for (uint32_t i = 0; i < got; ++i) {
+                fprintf(stderr, " [");
+                for (uint32_t j = 0; j < got; ++j) fprintf(stderr, "%s%.2f", j ? " " : "", ms[i][j]);
+                fprintf(stderr, "]");
+            }
+        }
+        fprintf(stderr, "\n");
+    }
+}
+int devbuf_reserve_hot(vs_index* ix, DevBuf& b, size_t bytes, int which) {
     if (bytes <= b.bytes) return VS_OK;
     WsSlab* s = ix->slab;
     const size_t slab_bytes = s ? slab_bytes_wanted(ix) : 0;
-    if (slab_bytes) {
+    if (slab_bytes || (s && s->external)) {  // (the caller's memory is used whatever the size rule says)
         std::lock_guard<std::mutex> lk(s->mu);
-        if (!s->base && !s->tried) {
-            s->tried = true;
-            // Device memory is not uniform for the search kernel's request mix (see k_ws_probe_mix): up to VS_WS_SLAB_CANDIDATES
-            // allocations are made (all held until the choice, so that each lands somewhere else), each is timed with the mix probe
-            // against THIS index's arrays (a few ms), the fastest is kept and the others go back to the device.
-            const uint32_t ncand = std::max<uint32_t>(1, std::min<uint32_t>(env_u32("VS_WS_SLAB_CANDIDATES", 6), 16));
-            void* cand[16] = {nullptr};
-            float ms[16] = {0};
-            uint32_t got = 0;
-            const bool probe = ncand > 1 && ix->codes && ix->nbrs && ix->d.n > 0 && slab_bytes >= ((size_t)64 << 20);
-            for (uint32_t i = 0; i < (probe ? ncand : 1u); ++i) {
-                if (hipMalloc(&cand[i], slab_bytes) != hipSuccess) {  // best effort: what the device can spare
-                    (void)hipGetLastError();
-                    cand[i] = nullptr;
-                    break;
-                }
-                got = i + 1;
-                if (probe && ws_probe_mix(ix, cand[i], std::min<size_t>(slab_bytes, (size_t)1 << 30), 300, &ms[i]) != VS_OK) ms[i] = 1e30f;
-            }
-            uint32_t best = 0;
-            for (uint32_t i = 1; i < got; ++i)
-                if (ms[i] < ms[best]) best = i;
-            for (uint32_t i = 0; i < got; ++i)
-                if (i != best) (void)hipFree(cand[i]);
-            if (got) {
-                s->base = cand[best];
-                s->bytes = slab_bytes;
-            }
-            if (env_u32("VS_WS_DEBUG", 0) && got) {
-                fprintf(stderr, "[VS_WS_DEBUG] slab of %zu MB chosen among %u candidates (mix probe, ms):", slab_bytes >> 20, got);
-                for (uint32_t i = 0; i < got; ++i) fprintf(stderr, " %s%.3f", i == best ? "*" : "", ms[i]);
-                fprintf(stderr, "\n");
-            }
-        }
-        if (s->base) {
+        if (!s->base[0] && !s->tried) slab_select(ix, s, slab_bytes);
+        if (s->base[which]) {
+            char* const base = (char*)s->base[which];
             const size_t kAlign = 1u << 16;
             const size_t want = (bytes + bytes / 8 + kAlign - 1) / kAlign * kAlign;
-            // the newest chunk grows in place (the arrays of one handle alternate, so room is left behind each: 1/8 above)
-            if (b.in_slab && (char*)b.p + b.bytes == (char*)s->base + s->used && (size_t)((char*)b.p - (char*)s->base) + want <= s->bytes) {
-                s->used = (size_t)((char*)b.p - (char*)s->base) + want;
+            // the newest chunk of a region grows in place
+            if (b.in_slab && (char*)b.p + b.bytes == base + s->used[which] && (size_t)((char*)b.p - base) + want <= s->bytes[which]) {
+                s->used[which] = (size_t)((char*)b.p - base) + want;
                 b.bytes = want;
                 return VS_OK;
             }
-            if (s->used + want <= s->bytes) {
+            if (s->used[which] + want <= s->bytes[which]) {
                 if (b.p && !b.in_slab) VS_HIP(hipFree(b.p));  // (synchronises: nothing in flight reads the old array)
-                b.p = (char*)s->base + s->used;
+                b.p = base + s->used[which];
                 b.bytes = want;
                 b.in_slab = true;
-                s->used += want;
+                s->used[which] += want;
                 return VS_OK;
             }
         }
@@ -653,9 +688,7 @@ static int index_alloc_common(vs_ctx* c, const vs_index_desc* desc, bool with_ve
     // (VS_WS_SLAB_EARLY=1: the slab is the index's FIRST device allocation instead of being made by the first search that needs it)
     if (env_u32("VS_WS_SLAB_EARLY", 0) && slab_bytes_wanted(ix)) {
         std::lock_guard<std::mutex> lk(ix->slab->mu);
-        ix->slab->tried = true;
-        if (hipMalloc(&ix->slab->base, slab_bytes_wanted(ix)) == hipSuccess) ix->slab->bytes = slab_bytes_wanted(ix);
-        else { (void)hipGetLastError(); ix->slab->base = nullptr; }
+        slab_select(ix, ix->slab, slab_bytes_wanted(ix));  // (no arrays yet: one allocation, no probe)
     }
     ix->code_stride = round_up_u32(desc->words, 2);
     ix->nbr_stride = round_up_u32(desc->num_neighbors, 16);
@@ -1470,10 +1503,12 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
         // bucket bitmap runs)
         // Default since round 4's third GPU session: the slot bitmap — 161.1 ms per 262 144 scans at 50M against 167.9 with the bucket
         // bitmap and 171.2 with cleared tables, 125.8 / 129.7 / 130.1 at 10M (profiles/r04/s3_ab_slotmap_*.txt); 639 device fuzz cases.
-        const uint32_t vmode = knob_u32("VS_F_VIRGIN", ix->tune.virgin, 2);
+        // Default since round 5: the 16-bit tables below (VS_F_VIRGIN=3) — 139.7 ms per 262 144 scans at 50M against 153.5 with the 4-byte
+        // slot-bitmap tables, same session, same slab (profiles/r05/s10_ab_q16_50m.txt); 300 device fuzz runs, regimes green on hardware.
+        const uint32_t vmode = knob_u32("VS_F_VIRGIN", ix->tune.virgin, 3);
         if (caps.f_lh == 0 && !f.vr && vmode && !env_u32("VS_PHASE", 0) && f.gcap <= (1u << 16)) {
             f.vwords = (f.gcap + 127) / 128;
-            if (vmode == 2 && !f.rc && f.gcap % 32 == 0) {
+            if (vmode >= 2 && !f.rc && f.gcap % 32 == 0) {
                 FastLaunch g = f;
                 g.vwords = f.gcap / 32;
                 g.vslot = 1;
@@ -1483,6 +1518,41 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
                 if (res_s >= res_b || env_u32("VS_F_SLOTMAP_FORCE", 0)) {
                     f.vwords = g.vwords;
                     f.vslot = 1;
+                }
+            }
+        }
+        // ... or (VS_F_VIRGIN=3) 16-BIT entries: buckets of eight slots (one 16-byte load), the entry is the remainder of a bijective
+        // hash of the node id given its bucket (quotienting), a small overflow table of whole ids behind the buckets.  Half the bytes
+        // per slot: the tables of the scans in flight are the largest part of the kernel's hot private state (fast_scan, VG == 3).
+        // Needs a power-of-two number of buckets and ceil(log2 n) - log2(buckets) <= 16 remainder bits.
+        uint32_t gregion = f.gcap;
+        if (vmode == 3 && f.vslot == 1 && caps.f_lh == 0) {
+            uint32_t qd = 1;
+            while ((1ull << qd) < (uint64_t)std::max<uint32_t>(ix->d.n, 2)) qd++;
+            const uint32_t gcap16 = std::max<uint32_t>(next_pow2_u32(f.gcap), 1024);
+            uint32_t lb = 0;
+            while ((1u << lb) < (gcap16 >> 3)) lb++;
+            if (qd < lb + 3) qd = lb + 3;  // (a small index: more hash bits than id bits — the bijection works on any width)
+            const uint32_t qk = qd - lb;
+            FastLaunch g = f;
+            g.gcap = gcap16;
+            g.ocap = std::max<uint32_t>(round_up_u32(gcap16 / 16, 32), 256);
+            g.vwords = (g.gcap + g.ocap) / 32;
+            g.vslot = 2;
+            g.sb = 0;
+            while ((1ull << g.sb) < (uint64_t)g.gcap + g.ocap) g.sb++;
+            const uint64_t nbits = (uint64_t)ix->d.dim_index * ix->d.bits;
+            uint32_t res_s = 0, res_q = 0;
+            if (qk <= 16 && qd <= 32 && nbits < (1ull << (32 - g.sb))) {
+                g.qd = qd;
+                g.qk = qk;
+                g.gregion = (g.gcap >> 1) + g.ocap;
+                g.glimit = (uint32_t)((uint64_t)g.gcap * gload_pct() / 100) - 64u;
+                VS_TRY(fast_resident_scans(ix, f, &res_s));
+                VS_TRY(fast_resident_scans(ix, g, &res_q));
+                if (res_q >= res_s || env_u32("VS_F_SLOTMAP_FORCE", 0)) {  // (taken only while it costs no scans per CU)
+                    f = g;
+                    gregion = g.gregion;
                 }
             }
         }
@@ -1496,18 +1566,18 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
         // (persistent grid: the two randomly accessed arrays live in the index's slab, dedup tables first)
         if (f.persist) {
             const uint32_t what = env_u32("VS_WS_SLAB_WHAT", 3);  // (measurement: 1 = only the dedup tables, 2 = only the heap spill arrays)
-            if (what & 1) VS_TRY(devbuf_reserve_hot(ix, w.ghash4, (size_t)fslots * caps.f_gcap * 4));
-            else VS_TRY(devbuf_reserve(c, w.ghash4, (size_t)fslots * caps.f_gcap * 4));
-            if (what & 2) VS_TRY(devbuf_reserve_hot(ix, w.heap_g4, std::max<size_t>((size_t)fslots * caps.f_gstride * 4, 16)));
+            if (what & 1) VS_TRY(devbuf_reserve_hot(ix, w.ghash4, (size_t)fslots * gregion * 4, 0));
+            else VS_TRY(devbuf_reserve(c, w.ghash4, (size_t)fslots * gregion * 4));
+            if (what & 2) VS_TRY(devbuf_reserve_hot(ix, w.heap_g4, std::max<size_t>((size_t)fslots * caps.f_gstride * 4, 16), 1));
             else VS_TRY(devbuf_reserve(c, w.heap_g4, std::max<size_t>((size_t)fslots * caps.f_gstride * 4, 16)));
         } else {
             VS_TRY(devbuf_reserve(c, w.heap_g4, std::max<size_t>((size_t)nq * caps.f_gstride * 4, 16)));
-            VS_TRY(devbuf_reserve(c, w.ghash4, (size_t)fslots * caps.f_gcap * 4));
+            VS_TRY(devbuf_reserve(c, w.ghash4, (size_t)fslots * gregion * 4));
         }
         if (env_u32("VS_WS_DEBUG", 0))  // diagnostics: where the hot arrays live (scripts/diag_state.py --placement)
             fprintf(stderr, "[VS_WS_DEBUG] ghash4 %p (%zu B%s) heap_g4 %p (%zu B%s) region bytes: table %zu heap %zu x %u regions; stream_ids %p qcodes %p\n", w.ghash4.p,
                     w.ghash4.bytes, w.ghash4.in_slab ? ", slab" : "", w.heap_g4.p, w.heap_g4.bytes, w.heap_g4.in_slab ? ", slab" : "",
-                    (size_t)caps.f_gcap * 4, (size_t)caps.f_gstride * 4, fslots, w.stream_ids.p, w.qcodes.p);
+                    (size_t)gregion * 4, (size_t)caps.f_gstride * 4, fslots, w.stream_ids.p, w.qcodes.p);
         VS_TRY(devbuf_reserve(c, w.pool_ctr, 64));
         VS_HIP(hipMemsetAsync(w.pool_ctr.p, 0, 64, c->stream));
         VS_TRY(devbuf_reserve(c, w.fb_flag, (size_t)nq * 4));
@@ -1590,7 +1660,7 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
             uint32_t hist[16] = {0};
             for (uint32_t v : stv) hist[v & 15]++;
             fprintf(stderr, "[VS_DEBUG_STATUS] fast kernel: lh=%u gcap=%u vr=%u minw=%u bitmap_words=%u (per %s); pool claims=%u of %u;",
-                    f.lh, f.gcap, f.vr, f.minw, f.vwords, f.vslot ? "slot" : "bucket", ctr[0], fast_pool_slots(nq, caps.f_pool_frac));
+                    f.lh, f.gcap, f.vr, f.minw, f.vwords, f.vslot == 2 ? "slot, 16-bit entries" : f.vslot ? "slot" : "bucket", ctr[0], fast_pool_slots(nq, caps.f_pool_frac));
             for (int i = 0; i < 16; ++i)
                 if (hist[i]) fprintf(stderr, " status[%d]=%u", i, hist[i]);
             fprintf(stderr, "\n");
@@ -2011,8 +2081,9 @@ static const TuneCand kTuneCands[] = {
     {"bucket_bitmap", 1, -1, 0},         // no clear, no read of a bucket the scan has not written (11b.16)
     {"bucket_bitmap_16k", 1, -1, 16384}, // ... with a sparser table (more first-touch buckets per probe, more lines)
     {"cleared_tables", 0, -1, 0},        // round 3's default: every scan clears its table, every probe loads a bucket
-    // (the library default in the table-less regime is the SLOT bitmap, VS_F_VIRGIN=2: an occupancy bit per slot, linear probing, a new
-    // id whose home slot is free costs no load)
+    {"slot_bitmap", 2, -1, 0},           // round 4's default: 4-byte entries, an occupancy bit per slot, linear probing
+    // (the library default in the table-less regime since round 5: 16-BIT entries in buckets of eight with an occupancy bit per slot,
+    // VS_F_VIRGIN=3 — where an index's id width does not fit 16-bit remainders the slot bitmap runs instead)
     // (no longer candidates: the two-row gather at 5 waves per SIMD, 2.8-7.3 % slower at 10M / 50M, profiles/r04/s1_ab_virgin_*.txt
     // (VS_F_MINW=5 still selects it by hand).  Deleted: the epoch-tagged tables — exact on hardware in round 4's first session,
     // profiles/r04/s1_fuzz_gpu_epoch*.txt, but no faster than the bitmaps and not compatible with the persistent grid's per-workgroup

@@ -105,12 +105,15 @@ struct DevBuf {
 // by one, and the slab goes when the last handle that holds it does.
 struct WsSlab {
     std::mutex mu;
-    void* base = nullptr;
-    size_t bytes = 0, used = 0;
+    // two regions: [0] the dedup tables, [1] the heap spill arrays — halves of one allocation, or two allocations when the probe found a
+    // pair of places that beats every single one
+    void* base[2] = {nullptr, nullptr};
+    size_t bytes[2] = {0, 0}, used[2] = {0, 0};
+    void* owned[2] = {nullptr, nullptr};  // what is hipFree'd with the slab (nothing for the caller's memory)
     int refs = 1;
     int device = 0;
     bool tried = false;  // the allocation failed once: handles fall back to allocations of their own
-    bool external = false;  // the caller's memory (vs_index_set_slab): never freed here
+    bool external = false;  // the caller's memory (vs_index_set_slab): used whatever VS_WS_SLAB_MB / the size rule say
 };
 
 struct SearchWorkspace {
@@ -206,7 +209,7 @@ struct DeviceOnce {
     }
 };
 int devbuf_reserve(vs_ctx* ctx, DevBuf& b, size_t bytes);
-int devbuf_reserve_hot(vs_index* ix, DevBuf& b, size_t bytes);  // from the index's slab when it has one (else as devbuf_reserve)
+int devbuf_reserve_hot(vs_index* ix, DevBuf& b, size_t bytes, int which);  // from region `which` of the index's slab when it has one (else as devbuf_reserve)
 uint64_t vs_new_owner_id();
 WsSlab* vs_slab_new(int device);
 void vs_slab_release(WsSlab* s);
@@ -271,6 +274,11 @@ struct FastLaunch {
     uint32_t persist = 0;  // != 0: persistent grid of `persist` workgroups taking scans from scan_counter; regions of heap_g / ghash are per workgroup
     uint32_t vwords = 0;  // != 0: words of the LDS bitmap of written buckets (one bit per four slots of gcap): tables are neither cleared nor read before their first write
     uint32_t vslot = 0;   // with vwords: the bitmap has one bit per SLOT (gcap / 32 words) and the table is probed slot by slot (linear probing)
+                          // 2: ... and the table holds 16-BIT entries in buckets of eight (quotienting, see fast_scan VG == 3)
+    // vslot == 2: an id is mapped by a bijection on qd bits to x; bucket = x >> qk (gcap / 8 buckets, a power of two), the entry is the
+    // remainder x & (2^qk - 1) (qk <= 16); ids whose bucket is full go to an overflow table of ocap 32-bit slots behind the buckets
+    // (handles gcap ..); gregion = u32 words per region (gcap / 2 + ocap)
+    uint32_t qd = 0, qk = 0, ocap = 0, gregion = 0;
     uint32_t build = 0; // 1: greedy_search_for_build (the visited list is the output; needs vr == 0)
     uint32_t flags = 0; // FAST_* (measurement switches)
     // second attempt of the scans a first launch gave up on (bigger capacities): only scans whose status[q] != 0 run, their

@@ -38,6 +38,12 @@
 #include "vs_device.h"
 
 #define MAX_QLABELS 64
+// odd multipliers of the 16-bit table's bijection (fast_scan, VG == 3) and their inverses mod 2^32
+#define VS_Q16_A 0x9E3779B1u
+#define VS_Q16_B 0x85EBCA6Bu
+#define VS_Q16_AI 0x0E8B2F51u
+#define VS_Q16_BI 0xA5CB9243u
+static_assert((uint32_t)(VS_Q16_A * VS_Q16_AI) == 1u && (uint32_t)(VS_Q16_B * VS_Q16_BI) == 1u, "inverse multipliers");
 #define ARB_SLOTS 128
 
 struct FastArgs {
@@ -72,9 +78,12 @@ __device__ __forceinline__ void wave_sync() {
 typedef __attribute__((address_space(1))) uint32_t glb_u32;
 typedef __attribute__((address_space(1))) uint64_t glb_u64;
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef __attribute__((address_space(1))) uint16_t glb_u16;
 __device__ __forceinline__ uint32_t gload32(const uint32_t* p) { return *(const glb_u32*)p; }
 __device__ __forceinline__ void gstore32(uint32_t* p, uint32_t v) { *(glb_u32*)p = v; }
 __device__ __forceinline__ uint64_t gload64u(const uint64_t* p) { return *(const glb_u64*)p; }
+__device__ __forceinline__ uint32_t gload16(const uint16_t* p) { return (uint32_t)*(const glb_u16*)p; }
+__device__ __forceinline__ void gstore16(uint16_t* p, uint32_t v) { *(glb_u16*)p = (uint16_t)v; }
 __device__ __forceinline__ uint32_t lload32(const uint32_t* p) { return *(const lds_u32*)p; }
 __device__ __forceinline__ void lstore32(uint32_t* p, uint32_t v) { *(lds_u32*)p = v; }
 __device__ __forceinline__ uint32_t readlane_u32(uint32_t v, uint32_t l) {
@@ -724,7 +733,7 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
     // (the bitmap variants only exist for the table-less regime: the LDS-table code paths are not compiled into them)
     const uint32_t lhv = VG ? 0u : s.lh;
     const uint32_t onlyfv = VG ? 0u : s.only_failed;  // (second attempts run the instantiation that clears its tables)
-    const uint32_t rcv = VG == 2 ? 0u : s.rc;
+    const uint32_t rcv = VG >= 2 ? 0u : s.rc;
     if (onlyfv && s.status[q] == 0) return;  // (wave-uniform) finished by the first launch
     if (s.timeline && lane == 0) s.timeline[2 * (size_t)q] = wall_clock64();
 
@@ -735,7 +744,7 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
     uint32_t* surv_slot = surv_id + 64;                               // 64
     uint32_t* surv_d = surv_slot + 64;                                // 64
     uint32_t* arb = surv_d + 64;                                      // ARB_SLOTS rank counters of the global dedup table (zero between uses; none with the slot bitmap)
-    constexpr uint32_t ARB_N = VG == 2 ? 0u : (uint32_t)ARB_SLOTS;
+    constexpr uint32_t ARB_N = VG >= 2 ? 0u : (uint32_t)ARB_SLOTS;
     uint64_t* ring = reinterpret_cast<uint64_t*>(arb + ARB_N);        // vcap entries (VR == 0 only)
     int16_t* ql = reinterpret_cast<int16_t*>(ring + (VR > 0 ? 0 : s.vcap));  // MAX_QLABELS
     uint64_t* qc_l = reinterpret_cast<uint64_t*>(ql + MAX_QLABELS);   // code_stride words (NCH == 0 only)
@@ -842,7 +851,7 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
         if (region) return true;
         if (s.persist) {  // the workgroup's own region (the launch wrapper holds pool_slots >= the grid)
             region = true;
-            ghash = s.ghash + (size_t)slot * s.gcap;
+            ghash = s.ghash + (size_t)slot * (VG == 3 ? s.gregion : s.gcap);
             return true;
         }
         uint32_t pslot = 0;
@@ -853,7 +862,7 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
             return false;
         }
         region = true;
-        ghash = s.ghash + (size_t)pslot * s.gcap;
+        ghash = s.ghash + (size_t)pslot * (VG == 3 ? s.gregion : s.gcap);
         if (onlyfv) heap.g = s.heap_g + (size_t)pslot * s.gstride;
         return true;
     };
@@ -863,9 +872,38 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
     // entries are plain node ids; VS_EMPTY marks an empty slot of a table its claiming wave has cleared (no bitmap: second attempts,
     // build mode, LDS-table regime overflow)
     auto g_empty = [&](uint32_t v) -> bool { return v == VS_EMPTY; };
+    // ---- VG == 3: 16-bit entries.  The id is mapped by a bijection on qd bits (multiply, xor-shift, multiply, xor-shift: each step is
+    // invertible mod 2^qd) to x; the bucket of eight slots is x >> qk, the entry the remainder x & (2^qk - 1), the preferred slot x & 7.
+    // (bucket, entry) names the id: q_inv gives it back, so a heap entry's handle (the slot) still finds the node without a second array.
+    const uint32_t qdm = VG == 3 ? (s.qd >= 32 ? 0xFFFFFFFFu : (1u << s.qd) - 1u) : 0u;
+    const uint32_t qxs = (s.qd + 1u) >> 1;  // (2 qxs >= qd: x ^= x >> qxs is its own inverse)
+    // (the multipliers are compile-time constants — the kernel lives at its scalar-register limit; the launch wrapper checks that the
+    // host's copies agree)
+    auto q_fwd = [&](uint32_t id) -> uint32_t {
+        uint32_t x = (id * VS_Q16_A) & qdm;
+        x ^= x >> qxs;
+        x = (x * VS_Q16_B) & qdm;
+        x ^= x >> qxs;
+        return x;
+    };
+    auto q_inv = [&](uint32_t x) -> uint32_t {
+        x ^= x >> qxs;
+        x = (x * VS_Q16_BI) & qdm;
+        x ^= x >> qxs;
+        return (x * VS_Q16_AI) & qdm;
+    };
     auto node_load = [&](uint32_t handle) -> uint32_t {
+        if (VG == 3) {  // (table-less regime only: lhv == 0)
+            if (handle < s.gcap) return gload16(reinterpret_cast<const uint16_t*>(ghash) + handle);
+            return gload32(ghash + (s.gcap >> 1) + (handle - s.gcap));
+        }
         if (handle < lhv) return lload32(lhash + handle);
         return gload32(ghash + (handle - lhv));
+    };
+    // what node_load returned (made uniform by the caller) -> the node id
+    auto node_of = [&](uint32_t handle, uint32_t raw) -> uint32_t {
+        if (VG == 3 && handle < s.gcap) return q_inv(((handle >> 3) << s.qk) | raw);
+        return raw;
     };
     // true where the id was not present before; slot_out = its handle
     auto finish_insert = [&](uint32_t nid, bool act, uint32_t slot, uint32_t old, uint32_t& slot_out) -> bool {
@@ -1005,6 +1043,118 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
         nins_g += (uint32_t)__popcll(__ballot(fresh));
         return fresh;
     };
+    // ---- VG == 3: buckets of eight 16-bit entries (one aligned 16-byte load), one occupancy bit per slot in LDS.  An id lives in its
+    // bucket at the first slot that was free, in cyclic order from its preferred slot, when it was inserted; slots never become free
+    // again, so (a) an id whose preferred slot is free is new — no load —, (b) otherwise it is in the occupied run that starts at its
+    // preferred slot or it is new, and ONE load of the bucket decides, whatever other lanes insert meanwhile (a neighbor list holds no
+    // id twice, so nothing inserted after the snapshot can be this id); (c) an id whose bucket is full goes to a small overflow table
+    // of whole ids behind the buckets (linear probing, its own occupancy bits), which is also where a lookup continues when all
+    // eight entries of the bucket are other ids.  Half the bytes per slot of the 4-byte table and never a second dependent load.
+    auto b16_occ = [&](uint32_t hb) -> uint32_t { return (vmap[hb >> 2] >> ((hb & 3u) << 3)) & 0xFFu; };
+    auto b16_run = [&](uint32_t x) -> uint32_t {  // occupied slots in a row, cyclic, from x's preferred slot (0: it is free, 8: full)
+        const uint32_t occ = b16_occ(x >> s.qk);
+        const uint32_t rot = ((occ | (occ << 8)) >> (x & 7u)) & 0xFFu;
+        return (uint32_t)__builtin_ctz(~rot);
+    };
+    auto b16_load = [&](uint32_t x) -> uint4 { return *reinterpret_cast<const uint4*>(ghash + ((size_t)(x >> s.qk) << 2)); };
+    uint32_t n_ovf = 0;
+    auto ovf_insert = [&](uint32_t nid, bool act, uint32_t& slot_out) -> bool {  // (as slot_insert, on the overflow table)
+        uint32_t* const ot = ghash + (s.gcap >> 1);
+        uint32_t* const om = vmap + (s.gcap >> 5);
+        auto orun = [&](uint32_t pos) -> uint32_t {
+            const uint32_t g = pos & ~3u;
+            const uint32_t rel = ((om[g >> 5] >> (g & 31u)) & 0xFu) >> (pos & 3u);
+            return (uint32_t)__builtin_ctz(~rel);
+        };
+        bool fresh = false, pend = act;
+        uint32_t pos = (uint32_t)(((uint64_t)hash_u32(nid ^ 0x5bd1e995u) * s.ocap) >> 32);
+        for (;;) {
+            wave_sync();
+            uint32_t t = 0;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (pend) {
+                t = orun(pos);
+                if (t) v = *reinterpret_cast<const uint4*>(ot + (pos & ~3u));
+            }
+            if (pend && t == 0) {
+                const uint32_t bit = 1u << (pos & 31u);
+                if ((atomicOr(&om[pos >> 5], bit) & bit) == 0) {
+                    ot[pos] = nid;
+                    slot_out = lhv + s.gcap + pos;
+                    fresh = true;
+                    pend = false;
+                } else {
+                    pos = pos + 1 == s.ocap ? 0u : pos + 1;
+                }
+            } else if (pend) {
+                const uint32_t hit = ((v.x == nid ? 1u : 0u) | (v.y == nid ? 2u : 0u) | (v.z == nid ? 4u : 0u) | (v.w == nid ? 8u : 0u)) &
+                                     (((1u << t) - 1u) << (pos & 3u));
+                if (hit) {
+                    slot_out = lhv + s.gcap + (pos & ~3u) + (uint32_t)__builtin_ctz(hit);
+                    pend = false;
+                } else {
+                    pos += t;
+                    if (pos == s.ocap) pos = 0;
+                }
+            }
+            wave_sync();
+            if (!__ballot(pend)) break;
+        }
+        n_ovf += (uint32_t)__popcll(__ballot(fresh));
+        return fresh;
+    };
+    // v / pre_t: the bucket of x and the occupied run at its preferred slot as the caller found them (have_pre; nothing has been inserted
+    // since), else both are looked up here.  true where the id was not present before
+    auto b16_insert = [&](uint32_t nid, bool act, uint32_t x, uint4 v, uint32_t pre_t, bool have_pre, uint32_t& slot_out) -> bool {
+        uint32_t t = pre_t;
+        if (!have_pre) {
+            wave_sync();
+            t = act ? b16_run(x) : 0u;
+            if (t) v = b16_load(x);
+        }
+        const uint32_t hb = x >> s.qk, r = x & ((1u << s.qk) - 1u), pref = x & 7u;
+        bool fresh = false, pend = act;
+        if (act && t) {  // in the run of the snapshot, or new
+            const uint32_t rr = r | (r << 16);
+            const uint32_t dx = v.x ^ rr, dy = v.y ^ rr, dz = v.z ^ rr, dw = v.w ^ rr;
+            const uint32_t m = ((dx & 0xFFFFu) == 0 ? 1u : 0u) | ((dx >> 16) == 0 ? 2u : 0u) | ((dy & 0xFFFFu) == 0 ? 4u : 0u) |
+                               ((dy >> 16) == 0 ? 8u : 0u) | ((dz & 0xFFFFu) == 0 ? 16u : 0u) | ((dz >> 16) == 0 ? 32u : 0u) |
+                               ((dw & 0xFFFFu) == 0 ? 64u : 0u) | ((dw >> 16) == 0 ? 128u : 0u);
+            uint32_t rm = ((1u << t) - 1u) << pref;
+            rm = (rm | (rm >> 8)) & 0xFFu;
+            const uint32_t hit = m & rm;
+            if (hit) {
+                slot_out = lhv + (hb << 3) + (uint32_t)__builtin_ctz(hit);
+                pend = false;
+            }
+        }
+        bool ovf = false;
+        for (;;) {  // a new id takes the first free slot of its bucket, cyclic from its preferred one
+            wave_sync();
+            if (pend) {
+                const uint32_t occ = b16_occ(hb);
+                const uint32_t t2 = (uint32_t)__builtin_ctz(~(((occ | (occ << 8)) >> pref) & 0xFFu));
+                if (t2 >= 8u) {  // the bucket is full: the overflow table (where the id may also be already)
+                    ovf = true;
+                    pend = false;
+                } else {
+                    const uint32_t idx = (hb << 3) + ((pref + t2) & 7u);
+                    const uint32_t bit = 1u << (idx & 31u);
+                    if ((atomicOr(&vmap[idx >> 5], bit) & bit) == 0) {  // ds_or_rtn_b32: the lane that flips the bit owns the slot
+                        gstore16(reinterpret_cast<uint16_t*>(ghash) + idx, r);
+                        slot_out = lhv + idx;
+                        fresh = true;
+                        pend = false;
+                    }
+                }
+            }
+            wave_sync();
+            if (!__ballot(pend)) break;
+        }
+        if (__ballot(ovf)) fresh = ovf_insert(nid, ovf, slot_out) || fresh;
+        nins_g += (uint32_t)__popcll(__ballot(fresh));
+        return fresh;
+    };
     auto open_table = [&]() -> bool {  // first use: this wave claims and clears its own table
         if (g_open) return true;
         if (!claim_region()) return false;
@@ -1034,6 +1184,7 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
             status |= OVF_HASH;
             return false;
         }
+        if (VG == 3) return b16_insert(nid, need_g, q_fwd(nid), make_uint4(0, 0, 0, 0), 0u, false, slot_out);
         if (VG == 2) return slot_insert(nid, need_g, slot_home(nid), make_uint4(0, 0, 0, 0), 0u, slot_out);
         const uint32_t b0 = ghash_home(nid);
         uint4 v = make_uint4(0, 0, 0, 0);
@@ -1183,7 +1334,11 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
                 const bool act0 = (uint32_t)lane < (inval0 ? (uint32_t)__builtin_ctzll(inval0) : WAVE);
                 virg0 = false;
                 gbk0 = make_uint4(0, 0, 0, 0);
-                if (VG == 2) {
+                if (VG == 3) {
+                    hslot0 = q_fwd(row0);
+                    pret0 = act0 ? b16_run(hslot0) : 0u;
+                    if (pret0) gbk0 = b16_load(hslot0);
+                } else if (VG == 2) {
                     hslot0 = slot_home(row0);
                     pret0 = act0 ? slot_run(hslot0) : 0u;
                     if (pret0) gbk0 = *reinterpret_cast<const uint4*>(ghash + (hslot0 & ~3u));
@@ -1195,7 +1350,7 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
             }
         }
         heap.pop();
-        const uint32_t node = rfl(node_v);
+        const uint32_t node = hit ? rfl(node_v) : node_of(th, rfl(node_v));
         // what consume() will need to know about this node: requested now, folded into the ring entry at the insert below
         if (!hit && VR == 0 && !BUILD) {
             vtid = load_stream64(a.tids + node);
@@ -1236,7 +1391,7 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
             lap(1);
             // prepare_insert (marks BEFORE the label check, AM/sbq/storage.rs:148-172): first probe issued, ...
             const bool frozen = !gmode && nins + WAVE > slot_limit;
-            uint32_t hslot = gmode ? (VG == 2 ? slot_home(nid) : ghash_home(nid)) : hash_home(nid), old = VS_EMPTY;
+            uint32_t hslot = gmode ? (VG == 3 ? q_fwd(nid) : VG == 2 ? slot_home(nid) : ghash_home(nid)) : hash_home(nid), old = VS_EMPTY;
             uint4 gbk = make_uint4(0, 0, 0, 0);
             bool rchit = false, virg = false;
             uint32_t pret = 0;  // (VG == 2) != 0: gbk holds the group of hslot, whose occupied run was pret slots long
@@ -1246,6 +1401,10 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
                 rchit = rchit0;
                 virg = virg0;
                 pret = pret0;
+            } else if (gmode && VG == 3) {
+                if (nins_g > s.glimit) { status |= OVF_HASH; break; }
+                pret = act ? b16_run(hslot) : 0u;
+                if (pret) gbk = b16_load(hslot);  // in flight during the visited insert
             } else if (gmode && VG == 2) {
                 if (nins_g > s.glimit) { status |= OVF_HASH; break; }
                 pret = act ? slot_run(hslot) : 0u;
@@ -1265,7 +1424,10 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
             }
             // ... then the probe sequence is finished
             bool fresh;
-            if (gmode && VG == 2) {
+            if (gmode && VG == 3) {
+                fresh = b16_insert(nid, act, hslot, gbk, pret, true, hslot);
+                if (n_ovf + WAVE > s.ocap - s.ocap / 4) status |= OVF_HASH;  // (the overflow table at its load limit: the second attempt)
+            } else if (gmode && VG == 2) {
                 fresh = slot_insert(nid, act, hslot, gbk, pret, hslot);
             } else if (gmode) {
                 fresh = global_insert(nid, act && !rchit, hslot, gbk, virg, hslot);
@@ -1328,7 +1490,7 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
                     pfa_node = VS_INVALID_NODE;
                     pfa_h = 0xFFFFFFFFu;
                     if (root_after != 0xFFFFFFFFu) {
-                        pfa_node = rfl(root_node_v);
+                        pfa_node = node_of(root_after & smask, rfl(root_node_v));
                         pfa_h = root_after & smask;
                         pfa_val = ((uint32_t)lane < a.R) ? load_stream32(a.nbrs + (size_t)pfa_node * a.nbr_stride + lane) : VS_INVALID_NODE;
                         if (nbr_mask) pfa_m = ((uint32_t)lane < a.R) ? load_stream64(nbr_mask + (size_t)pfa_node * a.nbr_stride + lane) : 0ull;
@@ -1385,7 +1547,7 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
             pfa_node = VS_INVALID_NODE;
             pfa_h = 0xFFFFFFFFu;
             if (root_after != 0xFFFFFFFFu) {
-                pfa_node = rfl(root_node_v);
+                pfa_node = node_of(root_after & smask, rfl(root_node_v));
                 pfa_h = root_after & smask;
                 pfa_val = ((uint32_t)lane < a.R) ? load_stream32(a.nbrs + (size_t)pfa_node * a.nbr_stride + lane) : VS_INVALID_NODE;
                 if (nbr_mask) pfa_m = ((uint32_t)lane < a.R) ? load_stream64(nbr_mask + (size_t)pfa_node * a.nbr_stride + lane) : 0ull;
@@ -1493,6 +1655,17 @@ static int launch_fast_t(vs_index* idx, const FastArgs& a, size_t lds, uint32_t*
         if (a.s.vr == 8) return launch_fast_tt<3, 8, true, 1, false>(idx, a, lds, res);
         return launch_fast_tt<3, 0, true, 1, false>(idx, a, lds, res);
     }
+    if (a.s.vwords && a.s.vslot == 2) {  // 16-bit entries in buckets of eight + overflow table, occupancy bits in LDS (see fast_scan)
+        VS_REQUIRE(a.s.vr == 0 && a.s.lh == 0 && a.s.rc == 0 && a.s.gcap >= 256 && (a.s.gcap & (a.s.gcap - 1)) == 0 && a.s.ocap % 32 == 0 && a.s.ocap >= 64 &&
+                       (uint64_t)a.s.vwords * 32 >= (uint64_t)a.s.gcap + a.s.ocap && a.s.qk >= 3 && a.s.qk <= 16 && a.s.qd <= 32 &&
+                       (1ull << a.s.qd) == ((uint64_t)(a.s.gcap >> 3) << a.s.qk) && (a.s.qd >= 32 || a.n <= (1ull << a.s.qd)) &&
+                       a.s.gregion >= (a.s.gcap >> 1) + a.s.ocap,
+                   "fast search: bad geometry of the 16-bit dedup table");
+        const bool plain = !a.s.qlabel_off && !a.s.visible && !(a.s.flags & FAST_FULL_VARIANT);
+        if (NCH == 3 && a.s.minw == 6 && plain) return launch_fast_tt<3, 0, false, 6, false, false, 3>(idx, a, lds, res);
+        if (NCH == 3 && a.s.minw == 6) return launch_fast_tt<3, 0, false, 6, false, true, 3>(idx, a, lds, res);
+        return launch_fast_tt<NCH, 0, false, 1, false, true, 3>(idx, a, lds, res);
+    }
     if (a.s.vwords && a.s.vslot) {  // occupancy bitmap of the dedup table's slots in LDS (table-less regime, LDS-ring visited list)
         VS_REQUIRE(a.s.vr == 0 && a.s.lh == 0 && (uint64_t)a.s.vwords * 32 >= a.s.gcap && a.s.rc == 0,
                    "fast search: the slot bitmap needs the table-less regime and one bit per slot");
@@ -1561,7 +1734,7 @@ static int fast_dispatch(vs_index* idx, const FastLaunch& s, uint32_t* res) {
     VS_REQUIRE(s.vr == 8 || (s.vr == 0 && s.vcap >= 64),
                "fast search: visited list must be 8 register pairs or a ring of >= 64 entries");
     VS_REQUIRE(s.lh % 4 == 0 && (s.lh == 0 || s.lh >= 256) && s.gcap % 4 == 0 && s.gcap >= 256 &&
-                   (uint64_t)s.lh + s.gcap <= (1ull << s.sb) && s.hcap >= s.hl && s.gstride % 2 == 0 &&
+                   (uint64_t)s.lh + s.gcap + (s.vslot == 2 ? s.ocap : 0u) <= (1ull << s.sb) && s.hcap >= s.hl && s.gstride % 2 == 0 &&
                    s.gstride >= s.hcap - s.hl + 2,
                "fast search: bad dedup table / spill geometry");
     const uint32_t nch = (idx->code_stride + 7) / 8;

@@ -43,6 +43,9 @@ EXTRA_REGIMES = [
     {"VS_F_LDS_MAX_INS": "0", "VS_F_VIRGIN": "1", "VS_F_GCAP": "2048"},  # ... tight: chains of full buckets, second attempts
     {"VS_F_LDS_MAX_INS": "0", "VS_F_VIRGIN": "2"},                      # occupancy bit per slot (linear probing, loads only behind occupied home slots)
     {"VS_F_LDS_MAX_INS": "0", "VS_F_VIRGIN": "2", "VS_F_GCAP": "2048"},  # ... tight: long occupied runs across groups, wrap-around, second attempts
+    {"VS_F_LDS_MAX_INS": "0", "VS_F_VIRGIN": "3"},                      # 16-bit entries in buckets of eight + overflow table
+    {"VS_F_LDS_MAX_INS": "0", "VS_F_VIRGIN": "3", "VS_F_GCAP": "2048"},  # ... tight: full buckets, overflow inserts / lookups, second attempts
+    {"VS_F_LDS_MAX_INS": "0", "VS_F_VIRGIN": "3", "VS_F_GCAP": "1024", "VS_F_GLOAD_PCT": "90"},
 ]
 TUNING = sorted({k for r in REGIMES + EXTRA_REGIMES for k in r})
 

@@ -30,6 +30,13 @@ REGIMES = {
     "tableless_slotmap": {"VS_F_LDS_MAX_INS": "0", "VS_F_VIRGIN": "2"},
     "tableless_slotmap_tight": {"VS_F_LDS_MAX_INS": "0", "VS_F_VIRGIN": "2", "VS_F_GCAP": "6144"},
     "tableless_slotmap_one_wg_per_scan": {"VS_F_LDS_MAX_INS": "0", "VS_F_VIRGIN": "2", "VS_F_PERSIST": "0"},
+    # table-less with 16-BIT entries: buckets of eight slots, the entry is the remainder of a bijective hash of the id given its bucket, a
+    # small overflow table of whole ids for full buckets; tight tables fill buckets (overflow inserts and lookups), 4096 slots sit at
+    # the load limit (some scans go to the second attempt)
+    "tableless_q16": {"VS_F_LDS_MAX_INS": "0", "VS_F_VIRGIN": "3"},
+    "tableless_q16_tight": {"VS_F_LDS_MAX_INS": "0", "VS_F_VIRGIN": "3", "VS_F_GCAP": "4096"},
+    "tableless_q16_tighter": {"VS_F_LDS_MAX_INS": "0", "VS_F_VIRGIN": "3", "VS_F_GCAP": "2048", "VS_F_GLOAD_PCT": "90"},
+    "tableless_q16_one_wg_per_scan": {"VS_F_LDS_MAX_INS": "0", "VS_F_VIRGIN": "3", "VS_F_PERSIST": "0"},
     "tiny_pool": {"VS_F_LH": "256", "VS_F_POOL": "0.01"},
     # dedup table too small for most scans: they are finished by the second attempt of k_search_fast (four times the table) ...
     "second_attempt": {"VS_F_LDS_MAX_INS": "0", "VS_F_GCAP": "1024"},

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 EMU = bool(os.environ.get("VS_EMU"))
 REGIME = {"VS_F_LDS_MAX_INS": "0", "VS_F_VR": "0"}  # the table-less regime of large indexes (the variants exist only there)
-NAMES = ["default", "bucket_bitmap", "bucket_bitmap_16k", "cleared_tables", "table_less", "table_less_bitmap", "lds_table_ring"]
+NAMES = ["default", "bucket_bitmap", "bucket_bitmap_16k", "cleared_tables", "slot_bitmap", "table_less", "table_less_bitmap", "lds_table_ring"]
 LDS_REGIME_ONLY = NAMES[-3:]  # candidates for indexes whose default keeps the dedup table in LDS
 
 

@@ -1006,7 +1006,7 @@ def main():
                                                             else "torch.distributed all_gather_into_tensor (FALLBACK: vs_comm_* could not be initialised on every rank)"),
                    "batches_in_flight": args.pipeline,
                    "workspace": "library default (the persistent grid's dedup tables + heap spill arrays sub-allocated from the index's "
-                                "grow-only slab inside libvsgpu: VS_WS_SLAB_MB, 4 GB from 4M nodes)"},
+                                "grow-only slab inside libvsgpu, chosen among probed candidates: VS_WS_SLAB_MB, VS_WS_SLAB_CANDIDATES)"},
         "recall_at_k": round(recall, 4),
         "recall_validate": round(recall_validate, 4),
         "recall_heldout": None if recall_heldout is None else round(recall_heldout, 4),

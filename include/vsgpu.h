@@ -147,7 +147,7 @@ void vs_index_free(vs_index* idx);
  * batch in flight, and every view is freed before `src`. */
 int vs_index_view(vs_index* src, vs_ctx* ctx, vs_index** out);
 /* The search workspace's randomly accessed part (the persistent grid's per-workgroup dedup tables and heap spill arrays) lives in ONE
- * grow-only slab per index, shared with its views (VS_WS_SLAB_MB, default 4 GiB from 4M nodes; allocated by the first search).
+ * grow-only slab per index, shared with its views (VS_WS_SLAB_MB, default 2 GiB per kind from 4M nodes; chosen by the first search among VS_WS_SLAB_CANDIDATES probed allocations).
  * vs_index_set_slab hands the library the CALLER's device memory for it instead (before the handle's first search; the memory stays the
  * caller's and must outlive the handle and the views made of it afterwards) — for a host that manages HBM itself, or one that has
  * measured where those regions run fastest: vs_ws_probe times the same request shapes (random 16-byte loads, 4-byte stores, 8-byte
@@ -157,7 +157,7 @@ int vs_index_set_slab(vs_index* idx, void* d_mem, size_t bytes);
 int vs_ws_probe(vs_ctx* ctx, void* d_mem, size_t bytes, uint32_t iters, float* ms_out);
 /* ... and vs_ws_probe_mix the kernel's WHOLE request mix, with the neighbor rows and code rows read from this index's arrays and the
  * private state on the region (tables at its start, heap arrays in its second half): what the library itself uses to choose its slab
- * among VS_WS_SLAB_CANDIDATES allocations (default 6) at the first search of an index of 4M nodes or more. */
+ * among VS_WS_SLAB_CANDIDATES allocations (default 8, spread over the free device memory by spacers) at the first search of an index of 4M nodes or more. */
 int vs_ws_probe_mix(vs_index* idx, void* d_mem, size_t bytes, uint32_t iters, float* ms_out);
 int vs_index_get_desc(const vs_index* idx, vs_index_desc* out);
 enum vs_array { VS_ARR_CODES = 0, VS_ARR_NBRS = 1, VS_ARR_TIDS = 2, VS_ARR_VECS = 3, VS_ARR_MEAN = 4, VS_ARR_M2 = 5,

@@ -176,7 +176,7 @@ __global__ __launch_bounds__(64) void k_ws_probe_mix(WsMixArgs a) {
             acc += v.x ^ v.y ^ v.z ^ v.w;
         }
         if (lane < 31 && acc != 0x123456789abcull)
-            *reinterpret_cast<uint32_t*>(tab + (size_t)(uint32_t)(((uint64_t)(h ^ 0x5bd1e995u) * t4) >> 32) * 4) = h;
+            *reinterpret_cast<uint16_t*>(tab + (size_t)(uint32_t)(((uint64_t)(h ^ 0x5bd1e995u) * t4) >> 32) * 4) = (uint16_t)h;
         if (lane < 56) acc += *reinterpret_cast<const uint64_t*>(heap + (size_t)(uint32_t)(((uint64_t)(h * 0x9E3779B1u) * h8) >> 32) * 8);
         for (uint32_t p = 0; p < 2; ++p) {
             const uint64_t row = ((uint64_t)mix(ctr ^ ((it * 64u + p * 16u + grp) * 0x9E3779B1u) ^ 0xabcdefu) * a.nrows) >> 32;
@@ -205,8 +205,8 @@ static int ws_probe_mix(vs_index* ix, void* tab, void* heap, size_t half, uint32
     a.R = std::min<uint32_t>(ix->d.num_neighbors, 64);
     a.tab_base = (uint8_t*)tab;
     a.heap_base = (uint8_t*)heap;
-    a.tab_bytes = (uint32_t)std::min<size_t>(half / waves / 16 * 16, 58752);
-    a.heap_bytes = (uint32_t)std::min<size_t>(half / waves / 16 * 16, 53248);
+    a.tab_bytes = (uint32_t)std::min<size_t>(half / waves / 16 * 16, 36864);   // (a 16-bit table of 16 Ki slots + its overflow table)
+    a.heap_bytes = (uint32_t)std::min<size_t>(half / waves / 16 * 16, 46368);
     a.iters = iters;
     static DeviceOnce attr_set;
     if (attr_set.pending(c->device)) {
@@ -241,12 +241,12 @@ extern "C" int vs_ws_probe_mix(vs_index* ix, void* p, size_t bytes, uint32_t ite
     });
 }
 
-// VS_WS_SLAB_MB (default 4096; 0: no slab) for indexes of VS_WS_SLAB_MIN_N nodes and more (default 4M: smaller indexes run the
+// VS_WS_SLAB_MB (default 2048; 0: no slab) for indexes of VS_WS_SLAB_MIN_N nodes and more (default 4M: smaller indexes run the
 // LDS-table regime or tables of a few MB in all, where placement was never seen to matter)
 static uint32_t env_u32(const char* name, uint32_t dflt);
 static size_t slab_bytes_wanted(const vs_index* ix) {
     if (ix->d.n < env_u32("VS_WS_SLAB_MIN_N", 4u << 20)) return 0;
-    return (size_t)env_u32("VS_WS_SLAB_MB", 4096) << 20;
+    return (size_t)env_u32("VS_WS_SLAB_MB", 2048) << 20;
 }
 // Device memory is not uniform for the search kernel's request mix (k_ws_probe_mix): up to VS_WS_SLAB_CANDIDATES allocations of the
 // slab's size are made (all held until the choice, so that each lands somewhere else) and every PAIR (tables on candidate i, heap
@@ -254,11 +254,27 @@ static size_t slab_bytes_wanted(const vs_index* ix) {
 // each); the best pair is kept, the other candidates go back to the device.
 static void slab_select(vs_index* ix, WsSlab* s, size_t slab_bytes) {
     s->tried = true;
-    const uint32_t ncand = std::max<uint32_t>(1, std::min<uint32_t>(env_u32("VS_WS_SLAB_CANDIDATES", 6), 8));
+    const uint32_t ncand = std::max<uint32_t>(1, std::min<uint32_t>(env_u32("VS_WS_SLAB_CANDIDATES", 8), 8));
     const size_t half = slab_bytes / 2 / 65536 * 65536;
     void* cand[8] = {nullptr};
+    void* spacer[8] = {nullptr};
     uint32_t got = 0;
     const bool probe = ncand > 1 && ix->codes && ix->nbrs && ix->d.n > 0 && half >= ((size_t)64 << 20);
+    // The kernel is slow where its private state lives in the same kind of memory as the code rows and fast elsewhere, and the kinds
+    // come in stretches of tens of GB in allocation order (profiles/r05/s7, s12, s13): candidates made back to back would all be of
+    // one kind, so spacers (returned right after the choice) spread them over what the device has free.
+    size_t sp = 0;
+    if (probe) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const size_t keep = (size_t)env_u32("VS_WS_SLAB_KEEP_FREE_MB", 12288) << 20;  // what the probing never touches
+            const size_t need = (size_t)ncand * slab_bytes + keep;
+            if (free_b > need) sp = std::min<size_t>((free_b - need) / ncand, (size_t)env_u32("VS_WS_SLAB_SPACER_MB", 16384) << 20);
+            sp = sp / ((size_t)2 << 20) * ((size_t)2 << 20);
+        } else {
+            (void)hipGetLastError();
+        }
+    }
     for (uint32_t i = 0; i < (probe ? ncand : 1u); ++i) {
         if (hipMalloc(&cand[i], slab_bytes) != hipSuccess) {  // best effort: what the device can spare
             (void)hipGetLastError();
@@ -266,7 +282,13 @@ static void slab_select(vs_index* ix, WsSlab* s, size_t slab_bytes) {
             break;
         }
         got = i + 1;
+        if (sp >= ((size_t)64 << 20) && i + 1 < ncand && hipMalloc(&spacer[i], sp) != hipSuccess) {
+            (void)hipGetLastError();
+            spacer[i] = nullptr;
+        }
     }
+    for (void* p : spacer)
+        if (p) (void)hipFree(p);
     if (!got) return;
     uint32_t bi = 0, bj = 0;
     float ms[8][8];
@@ -278,8 +300,8 @@ static void slab_select(vs_index* ix, WsSlab* s, size_t slab_bytes) {
                 // (i == j: the heap arrays in the second half of the same allocation; i != j: at the start of the other one)
                 void* hb = i == j ? (void*)((char*)cand[j] + half) : cand[j];
                 if (ws_probe_mix(ix, cand[i], hb, ph, 200, &ms[i][j]) != VS_OK) ms[i][j] = 1e30f;
-                // a pair of two allocations has to beat the best single one by 1 %: it costs the device a second slab
-                const float v = i == j ? ms[i][j] : ms[i][j] * 1.01f;
+                // a pair of two allocations has to beat the best single one by 0.5 %: it costs the device a second slab
+                const float v = i == j ? ms[i][j] : ms[i][j] * 1.005f;
                 if (v < best) {
                     best = v;
                     bi = i;
@@ -300,7 +322,8 @@ static void slab_select(vs_index* ix, WsSlab* s, size_t slab_bytes) {
     for (uint32_t i = 0; i < got; ++i)
         if (i != bi && i != bj) (void)hipFree(cand[i]);
     if (env_u32("VS_WS_DEBUG", 0)) {
-        fprintf(stderr, "[VS_WS_DEBUG] workspace slab: %u candidates of %zu MB, tables on %u, heap arrays on %u", got, slab_bytes >> 20, bi, bj);
+        fprintf(stderr, "[VS_WS_DEBUG] workspace slab: %u candidates of %zu MB (spacers of %zu MB), tables on %u, heap arrays on %u", got, slab_bytes >> 20,
+                sp >> 20, bi, bj);
         if (probe && got > 1) {
             fprintf(stderr, "; mix probe ms [tables][heaps]:");
             for (uint32_t i = 0; i < got; ++i) {
@@ -1555,6 +1578,12 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
                     gregion = g.gregion;
                 }
             }
+        }
+        // (VS_F_MINW=7 with the 16-bit tables: 28 scans per CU when a scan's LDS fits 5 632 B — the visited ring is then sized in steps
+        // of 16 entries instead of 64)
+        if (f.minw == 7 && f.vslot == 2 && !f.vr && !env_u32("VS_F_VCAP", 0)) {
+            const uint32_t want_v = (uint32_t)std::min<uint64_t>((uint64_t)bp.L + bp.L / 2 + 32, 1u << 20);
+            f.vcap = round_up_u32(std::max<uint32_t>(2 * want_v, 64), 16);
         }
         if (env_u32("VS_PHASE", 0)) f.phase = (uint64_t*)16;  // (selects the instantiation; the buffer is set below)
         if (knob_u32("VS_F_PERSIST", ix->tune.persist, 1)) {

@@ -740,14 +740,17 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
     // ---- LDS carve ----
     uint32_t* hp = reinterpret_cast<uint32_t*>(smem);                 // hl + 1 (hl + 1 is a power of two >= 64)
     uint32_t* lhash = hp + (s.hl + 1);                                // lh (multiple of 4)
+    // LEAN (the 7-waves-per-SIMD variant of the 16-bit tables: 28 scans per CU need <= 5 632 B of LDS each): a survivor's distance is
+    // merged into its slot word instead of an array of its own, and the plain instantiation has no room for label keys it never reads
+    constexpr bool LEAN = MINW == 7 && VG == 3;
     uint32_t* surv_id = lhash + lhv;                                 // 64
     uint32_t* surv_slot = surv_id + 64;                               // 64
-    uint32_t* surv_d = surv_slot + 64;                                // 64
+    uint32_t* surv_d = LEAN ? surv_slot : surv_slot + 64;             // 64 (LEAN: the same words)
     uint32_t* arb = surv_d + 64;                                      // ARB_SLOTS rank counters of the global dedup table (zero between uses; none with the slot bitmap)
     constexpr uint32_t ARB_N = VG >= 2 ? 0u : (uint32_t)ARB_SLOTS;
     uint64_t* ring = reinterpret_cast<uint64_t*>(arb + ARB_N);        // vcap entries (VR == 0 only)
     int16_t* ql = reinterpret_cast<int16_t*>(ring + (VR > 0 ? 0 : s.vcap));  // MAX_QLABELS
-    uint64_t* qc_l = reinterpret_cast<uint64_t*>(ql + MAX_QLABELS);   // code_stride words (NCH == 0 only)
+    uint64_t* qc_l = reinterpret_cast<uint64_t*>(ql + (LEAN && !FULL ? 0 : MAX_QLABELS));   // code_stride words (NCH == 0 only)
     // (optional) cache of ids known to be in the dedup table: a hit answers a duplicate probe without touching the table in HBM
     uint32_t* rc = reinterpret_cast<uint32_t*>(qc_l + (NCH == 0 ? ((a.code_stride + 1u) & ~1u) : (NCH > 0 && MINW >= 6 ? 8u * (uint32_t)NCH : 0u)));
     const uint32_t rcm = rcv - 1u;  // (rcv: 0 or a power of two)
@@ -1502,18 +1505,18 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
                     const uint64_t* crow2 = a.codes + (size_t)(valid2 ? surv_id[j2] : 0u) * a.code_stride;
                     uint32_t d, d2;
                     ham_row_reg2<NCH>(crow, crow2, qv, l4, a.code_stride, valid, valid2, stream_rows, d, d2);
-                    if (valid && l4 == 0) surv_d[j] = d;
-                    if (valid2 && l4 == 0) surv_d[j2] = d2;
+                    if (valid && l4 == 0) surv_d[j] = LEAN ? ((d << s.sb) | surv_slot[j]) : d;
+                    if (valid2 && l4 == 0) surv_d[j2] = LEAN ? ((d2 << s.sb) | surv_slot[j2]) : d2;
                     continue;
                 }
                 const uint32_t d = ham_row_reg<NCH, QL>(crow, qv, qc_l, l4, a.code_stride, valid, stream_rows);
-                if (valid && l4 == 0) surv_d[j] = d;
+                if (valid && l4 == 0) surv_d[j] = LEAN ? ((d << s.sb) | surv_slot[j]) : d;
             }
             st_dq += c;
             st_cand += c;
             wave_sync();
             uint32_t entry = 0xFFFFFFFFu;
-            if ((uint32_t)lane < c) entry = (surv_d[lane] << s.sb) | surv_slot[lane];
+            if ((uint32_t)lane < c) entry = LEAN ? surv_slot[lane] : ((surv_d[lane] << s.sb) | surv_slot[lane]);
             if (TIMING) {
                 if (__ballot(entry == 0xFFFFFFFEu) == ~0ull) status |= 0x100;
                 lap(4);
@@ -1619,7 +1622,10 @@ size_t fast_lds_bytes(const vs_index* idx, const FastLaunch& s) {
     const size_t nch = (idx->code_stride + 7) / 8;
     // LDS copy of the query code: the generic variant (NCH == 0), and the register-capped variants (minw >= 6: 8 NCH words, zero padded)
     const size_t qcopy = nch > 6 ? (size_t)idx->code_stride * 8 : (s.minw >= 6 && !s.build && !s.phase ? nch * 64 : 0);
-    size_t b = (size_t)(s.hl + 1) * 4 + (size_t)s.lh * 4 + 3 * 64 * 4 + (s.vslot ? 0 : ARB_SLOTS * 4) + (s.vr ? 0 : (size_t)s.vcap * 8) + MAX_QLABELS * 2 + qcopy + (size_t)s.rc * 4 + (size_t)s.vwords * 4 + 32;
+    const bool lean = s.minw == 7 && s.vslot == 2 && nch == 3 && !s.build && !s.phase;  // (fast_scan: LEAN)
+    const bool plain = !s.qlabel_off && !s.visible && !(s.flags & FAST_FULL_VARIANT);
+    size_t b = (size_t)(s.hl + 1) * 4 + (size_t)s.lh * 4 + (lean ? 2 : 3) * 64 * 4 + (s.vslot ? 0 : ARB_SLOTS * 4) + (s.vr ? 0 : (size_t)s.vcap * 8) +
+               (lean && plain ? 0 : MAX_QLABELS * 2) + qcopy + (size_t)s.rc * 4 + (size_t)s.vwords * 4 + (lean ? 16 : 32);
     return (b + 15) / 16 * 16;
 }
 
@@ -1664,6 +1670,8 @@ static int launch_fast_t(vs_index* idx, const FastArgs& a, size_t lds, uint32_t*
         const bool plain = !a.s.qlabel_off && !a.s.visible && !(a.s.flags & FAST_FULL_VARIANT);
         if (NCH == 3 && a.s.minw == 6 && plain) return launch_fast_tt<3, 0, false, 6, false, false, 3>(idx, a, lds, res);
         if (NCH == 3 && a.s.minw == 6) return launch_fast_tt<3, 0, false, 6, false, true, 3>(idx, a, lds, res);
+        if (NCH == 3 && a.s.minw == 7 && plain) return launch_fast_tt<3, 0, false, 7, false, false, 3>(idx, a, lds, res);
+        if (NCH == 3 && a.s.minw == 7) return launch_fast_tt<3, 0, false, 7, false, true, 3>(idx, a, lds, res);
         return launch_fast_tt<NCH, 0, false, 1, false, true, 3>(idx, a, lds, res);
     }
     if (a.s.vwords && a.s.vslot) {  // occupancy bitmap of the dedup table's slots in LDS (table-less regime, LDS-ring visited list)

@@ -23,6 +23,7 @@ VARIANTS = [{"VS_F_MINW": "5"}, {"VS_F_MINW": "5", "VS_F_VIRGIN": "1"}, {"VS_F_V
             {"VS_F_VIRGIN": "2"}, {"VS_F_VIRGIN": "2", "VS_F_GCAP": "1536"},
             # 16-bit entries in buckets of eight + overflow table (VS_F_VIRGIN=3): fitted, tight (full buckets, overflow inserts and
             # lookups), tight near the load limit (second attempts)
+            {"VS_F_VIRGIN": "3", "VS_F_MINW": "7"}, {"VS_F_VIRGIN": "3", "VS_F_MINW": "7", "VS_F_GCAP": "2048"},  # ... the lean 7-wave layout
             {"VS_F_VIRGIN": "3"}, {"VS_F_VIRGIN": "3", "VS_F_GCAP": "2048"}, {"VS_F_VIRGIN": "3", "VS_F_GCAP": "1024", "VS_F_GLOAD_PCT": "90"}]
 KNOBS = sorted({k for v in VARIANTS for k in v})
 COUNTERS = ("visited_nodes", "candidate_nodes", "quantized_distance_comparisons", "node_reads", "next_calls")

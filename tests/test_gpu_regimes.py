@@ -37,6 +37,9 @@ REGIMES = {
     "tableless_q16_tight": {"VS_F_LDS_MAX_INS": "0", "VS_F_VIRGIN": "3", "VS_F_GCAP": "4096"},
     "tableless_q16_tighter": {"VS_F_LDS_MAX_INS": "0", "VS_F_VIRGIN": "3", "VS_F_GCAP": "2048", "VS_F_GLOAD_PCT": "90"},
     "tableless_q16_one_wg_per_scan": {"VS_F_LDS_MAX_INS": "0", "VS_F_VIRGIN": "3", "VS_F_PERSIST": "0"},
+    # ... at 7 waves per SIMD with the lean LDS layout (survivor distances merged into the slot words, visited ring in steps of 16)
+    "tableless_q16_seven_waves": {"VS_F_LDS_MAX_INS": "0", "VS_F_VIRGIN": "3", "VS_F_MINW": "7"},
+    "tableless_q16_seven_waves_tight": {"VS_F_LDS_MAX_INS": "0", "VS_F_VIRGIN": "3", "VS_F_MINW": "7", "VS_F_GCAP": "4096"},
     "tiny_pool": {"VS_F_LH": "256", "VS_F_POOL": "0.01"},
     # dedup table too small for most scans: they are finished by the second attempt of k_search_fast (four times the table) ...
     "second_attempt": {"VS_F_LDS_MAX_INS": "0", "VS_F_GCAP": "1024"},
@@ -63,7 +66,7 @@ def _hardware_unverified(regime):
     session (profiles/r04/s1_tests.txt: 96 passed with the opt-in set; device fuzz 1 074 + 1 102 cases) and are no longer skipped.
     A variant that is newer than its first hardware session is listed here: exact on the wave64 interpreter (VS_EMU=1, part of the
     CPU tier), an opt-in on hardware until it has run there, so that it cannot turn the tier of the shipped defaults red."""
-    unverified = ()
+    unverified = ("seven_waves",)
     if any(u in str(regime) for u in unverified) and not os.environ.get("VS_EMU") and not os.environ.get("VS_TEST_UNVERIFIED"):
         pytest.skip(f"{regime}: not run on hardware yet")
 

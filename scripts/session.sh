@@ -25,6 +25,44 @@ for step in "$@"; do
            timeout 1500 python scripts/perf_search.py --n $N --nq 262144 --L 3 --rescore 195 --reps 4 --graph-cache /tmp/g --configs "$CFG" 2>&1 | grep -Ev "$NOBANNER" | tee $O/ab_$N.txt ;;
     fuzzv) timeout $(( ${arg:-40} * 8 + 120 )) python scripts/fuzz_variants.py --gpu --cases ${arg:-40} --seed $RANDOM 2>&1 | tail -4 | tee $O/fuzz_variants_gpu.txt ;;
     fuzzv) timeout $(( ${arg:-40} * 8 + 120 )) python scripts/fuzz_variants.py --gpu --cases ${arg:-40} --seed $RANDOM 2>&1 | tail -4 | tee $O/fuzz_variants_gpu.txt ;;
+    final) # the evidence set of the frozen tree: the driver's bench command (builds, writes the graph cache), the same under rocprofv3
+           # --kernel-trace --stats, two --pmc passes at the bench's operating point, the bench once more WITH roofline.traffic
+           timeout 2400 python bench.py --steps 20 --warmup 5 --graph-cache /tmp/g > $O/bench_50m.json 2> $O/bench_50m.err; tail -3 $O/bench_50m.err
+           LS=$(python - <<PY
+import json
+j = json.loads(open("$O/bench_50m.json").read().strip().splitlines()[-1])
+print(j["config"]["search_list_size"], j["config"]["rescore"], j["config"]["queries_per_step_per_gpu"])
+PY
+)
+           set -- $LS; L=$1; S=$2; NQ=$3; echo "operating point L=$L rescore=$S nq=$NQ"
+           rm -rf gpurun_out/prof_final
+           timeout 1500 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_final -o bench -- python bench.py --steps 20 --warmup 5 --skip-cpu --extras off --graph-cache /tmp/g > $O/bench_50m_under_rocprof.json 2> $O/bench_50m_under_rocprof.err
+           python scripts/summarize_rocprof.py gpurun_out/prof_final/bench_kernel_stats.csv $O/kernel_stats_50m.csv "rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 --skip-cpu --extras off --graph-cache ... (50M x 768 l2, $NQ scans per launch, L=$L rescore=$S; index loaded from the cache the plain bench run wrote)"
+           head -8 $O/kernel_stats_50m.csv
+           timeout 1500 bash scripts/pmc_traffic.sh 50000000 $NQ $L $S /tmp/g 2>&1 | tail -40 > $O/pmc_traffic.log
+           cp gpurun_out/pmc_search_traffic.json $O/pmc_search_traffic_50m.json
+           mkdir -p profiles/r05 && cp $O/pmc_search_traffic_50m.json profiles/r05/pmc_search_traffic_50m.json
+           timeout 900 python bench.py --steps 20 --warmup 5 --skip-cpu --extras off --graph-cache /tmp/g > $O/bench_50m_with_traffic.json 2> $O/bench_50m_with_traffic.err
+           python - <<PY | tee $O/summary.txt
+import json
+for f in ("bench_50m", "bench_50m_under_rocprof", "bench_50m_with_traffic"):
+    try:
+        j = json.loads(open(f"$O/{f}.json").read().strip().splitlines()[-1])
+        r = j["roofline"]
+        print(f, "QPS", j["value"], "ms/step", j["ms_per_step"], "L/S", j["config"]["search_list_size"], j["config"]["rescore"],
+              "recall", j["recall_at_k"], j["recall_validate_lower95"], j["recall_heldout"], j.get("recall_heldout_lower95"), "met", j["recall_target_met"],
+              "kernel ms", r["avg_kernel_ms"], "frac", r["frac"], "traffic", r["traffic"],
+              "src", (r.get("traffic_source") or {}).get("same_kernel_sources_as_this_build"),
+              "pcie", (j.get("pcie_inclusive") or {}).get("value"), "cpu", (j.get("cpu_baseline") or {}).get("value"),
+              "identical", (j.get("cpu_baseline") or {}).get("gpu_rows_identical"))
+        for x in ("default_gucs", "harder_corpus"):
+            e = j.get(x)
+            if e:
+                print("  ", x, {k: e.get(k) for k in ("value", "search_list_size", "rescore", "recall_validate_lower95", "recall_heldout_lower95", "recall_target_met", "gpu_rows_identical", "seconds", "error")}, (e.get("roofline") or {}).get("frac"))
+    except Exception as e:
+        print(f, "unreadable:", e)
+PY
+           ;;
     fuzz)  timeout $(( ${arg:-150} + 120 )) python scripts/fuzz_emu.py --gpu --seconds ${arg:-150} --seed $RANDOM 2>&1 | tail -3 | tee $O/fuzz_gpu.txt ;;
     *) echo "unknown step $step" ;;
   esac

@@ -472,6 +472,29 @@ int vs_scan_get_stats(const vs_scan* scan, vs_stats* out);
 int vs_scan_get_work(const vs_scan* scan, vs_stats* out, uint32_t* launches);
 void vs_endscan(vs_scan* scan);                                                   /* amendscan */
 
+/* ---- many streamed scans continued TOGETHER (vs_scanpool.cpp) ------------------------------------------------
+ * A single cursor continues its scan with a launch of its own: one wave on the chip and half a millisecond of launch / copy
+ * overhead per continuation, and 64 backends streaming at once are 64 such launches per round.  A scan pool keeps what
+ * TSVResponseIterator keeps per scan (lsr + resort_buffer, AM/scan.rs:162-174) for up to `capacity` scans in pooled device arrays,
+ * so that ONE resumed launch (plus one rerank launch) continues every scan that asked for rows in this round — what a GPU broker
+ * does with the amgettuple calls of many backends that arrive together.  Rows and GreedySearchStats are the single cursor's, row
+ * for row.  All scans of a pool share the GUCs (search_list_size, rescore) and the visibility mask in force; scan keys are per
+ * scan (slot).  kmax = most rows one fetch asks for; rows_cap = most stream rows a pooled scan may produce (0: 4096) — a scan that
+ * needs more fails with VS_ERR_CAPACITY in its out_rows entry and is continued by a vs_scan of its own.  One thread at a time. */
+typedef struct vs_scan_pool vs_scan_pool;
+int vs_scanpool_create(vs_index* idx, uint32_t capacity, uint32_t search_list_size, uint32_t rescore, uint32_t kmax, uint32_t rows_cap,
+                       vs_scan_pool** out);
+void vs_scanpool_free(vs_scan_pool* pool);
+int vs_scanpool_rescan(vs_scan_pool* pool, uint32_t slot, const float* query, const int16_t* labels, uint32_t n_labels,
+                       int has_label_key);                                                                   /* amrescan of one slot */
+int vs_scanpool_endscan(vs_scan_pool* pool, uint32_t slot);
+/* amgettuple x k for the n listed slots at once: out_*[i][0 .. out_rows[i]) are the next rows of slots[i] (fewer than k: its scan
+ * has ended; a negative VS_ERR_*: that scan failed, the others are served).  out_tids / out_ids / out_dist may be NULL. */
+int vs_scanpool_fetch(vs_scan_pool* pool, const uint32_t* slots, uint32_t n, uint32_t k, uint64_t* out_tids, uint32_t* out_ids,
+                      float* out_dist, int32_t* out_rows);
+int vs_scanpool_get_stats(const vs_scan_pool* pool, uint32_t slot, vs_stats* out);  /* as vs_scan_get_stats */
+int vs_scanpool_get_work(const vs_scan_pool* pool, uint64_t* launches, uint64_t* rounds);  /* shared search launches / rounds so far */
+
 /* ---- coalescing concurrent scans into batched launches (vs_broker.cpp) -------------------
  * The reference serves one query per single-threaded backend (amcanparallel = false, AM/mod.rs:63); a GPU needs thousands
  * of scans per launch.  A broker owns the index (its dispatcher thread is the only thread that touches the vs_ctx); any
@@ -495,6 +518,12 @@ typedef struct vs_broker_config {
                             * with 2 x 1 MiB of pinned staging memory and the device workspace of the scans it continues.
                             * (VS_BROKER_LANES in the environment: the lane count of brokers created with 0 — how the test tier
                             * runs every broker test on lanes; leave it unset in production.)                         */
+    uint32_t cursor_pool; /* (vs_shm_server) n > 0: the streamed scans of the client processes live in scan pools of n slots
+                           * (vs_scanpool_*: one pool per (search_list_size, rescore, snapshot) in use, four at most) and the
+                           * amgettuple continuations that arrive in one dispatcher round are served by SHARED launches — 64
+                           * backends streaming at once cost about what one costs.  Scans a pool cannot take (no free pool for
+                           * their GUCs, more than 4096 stream rows) fall back to a cursor of their own.  (VS_SHM_CURSOR_POOL in
+                           * the environment: the pool size of servers created with 0 — test tier.)                          */
 } vs_broker_config;
 typedef struct vs_broker_stats {
     uint64_t batches;   /* vs_search_batch calls made                */

@@ -98,7 +98,7 @@ class PagesInfo(C.Structure):
 
 
 class BrokerConfig(C.Structure):
-    _fields_ = [("max_batch", C.c_uint32), ("max_wait_us", C.c_uint32), ("cursor_lanes", C.c_uint32)]
+    _fields_ = [("max_batch", C.c_uint32), ("max_wait_us", C.c_uint32), ("cursor_lanes", C.c_uint32), ("cursor_pool", C.c_uint32)]
 
 
 class BrokerStats(C.Structure):
@@ -136,6 +136,13 @@ SYMBOLS = {
     "vs_index_alloc": (_i, [_vp, C.POINTER(IndexDesc), _i, C.POINTER(_vp)]),
     "vs_index_free": (None, [_vp]),
     "vs_index_view": (_i, [_vp, _vp, _vp]),
+    "vs_scanpool_create": (_i, [_vp, _u32, _u32, _u32, _u32, _u32, C.POINTER(_vp)]),
+    "vs_scanpool_free": (None, [_vp]),
+    "vs_scanpool_rescan": (_i, [_vp, _u32, _vp, _vp, _u32, _i]),
+    "vs_scanpool_endscan": (_i, [_vp, _u32]),
+    "vs_scanpool_fetch": (_i, [_vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp]),
+    "vs_scanpool_get_stats": (_i, [_vp, _u32, _vp]),
+    "vs_scanpool_get_work": (_i, [_vp, C.POINTER(_u64), C.POINTER(_u64)]),
     "vs_index_set_slab": (_i, [_vp, _vp, C.c_size_t]),
     "vs_ws_probe": (_i, [_vp, _vp, C.c_size_t, C.c_uint32, C.POINTER(C.c_float)]),
     "vs_ws_probe_mix": (_i, [_vp, _vp, C.c_size_t, C.c_uint32, C.POINTER(C.c_float)]),

@@ -195,6 +195,25 @@ struct vs_shm_server {
         bool stop = false;
         CursorTable tab;
     };
+    // scan pools (vs_broker_config.cursor_pool): the streamed scans of the clients kept in pooled device arrays, the continuations of
+    // one dispatcher round served by shared launches (vs_scanpool.cpp); dispatcher thread only
+    struct PoolCursor {
+        int32_t pid = 0;
+        uint64_t scan_id = 0, sig = 0, last_use = 0;
+        uint32_t pos = 0;  // rows handed out so far
+        bool used = false;
+    };
+    struct Pool {
+        vs_scan_pool* h = nullptr;
+        uint32_t L = 0, rescore = 0, snapshot = 0;
+        std::vector<PoolCursor> cur;  // by pool slot
+        uint64_t use_clock = 0;
+    };
+    std::vector<Pool> pools;
+    std::atomic<uint64_t> pool_rounds{0};
+    void run_fetch_pooled(const std::vector<uint32_t>& slots);
+    void reap_pools();
+    void free_pools();
     std::vector<std::unique_ptr<Lane>> lanes;
     std::shared_mutex snap_mu;        // lanes: shared for the length of a request; a mask is replaced exclusively
     std::atomic<int> put_waiting{0};  // ... and lanes do not start a request while one waits (readers would starve the writer)
@@ -417,6 +436,197 @@ void vs_shm_server::run_fetch(uint32_t slot, CursorTable& t) {
     finish(slot);
 }
 
+// ---- pooled continuations ---------------------------------------------------------------------------------------------------
+void vs_shm_server::free_pools() {
+    for (Pool& p : pools) {
+        for (PoolCursor& c : p.cur)
+            if (c.used) open_cursors--;
+        vs_scanpool_free(p.h);
+    }
+    pools.clear();
+}
+void vs_shm_server::reap_pools() {
+    for (Pool& p : pools)
+        for (uint32_t i = 0; i < p.cur.size(); ++i) {
+            PoolCursor& c = p.cur[i];
+            if (c.used && c.pid > 0 && kill(c.pid, 0) != 0 && errno == ESRCH) {
+                (void)vs_scanpool_endscan(p.h, i);
+                c = PoolCursor{};
+                open_cursors--;
+            }
+        }
+}
+// Every OP_FETCH / OP_CLOSE request taken in this dispatcher round.  A scan lives in the pool of its (search_list_size, rescore,
+// snapshot); the requests of one pool that ask for the same number of rows are ONE vs_scanpool_fetch — one resumed search launch, one
+// rerank launch for all of them.  What a pool cannot take is served by a cursor of its own (run_fetch).
+void vs_shm_server::run_fetch_pooled(const std::vector<uint32_t>& slots) {
+    struct Item { uint32_t slot, pool, pslot; };
+    std::vector<Item> items;
+    std::vector<uint32_t> single;  // requests for the single-cursor path
+    auto in_main_tab = [&](const Req& r) {
+        for (const Cursor& c : main_tab.cursors)
+            if (c.pid == r.owner_pid && c.scan_id == r.scan_id) return true;
+        return false;
+    };
+    for (uint32_t slot : slots) {
+        const Req& r = reqs[slot];
+        // (a scan that fell back to a cursor of its own stays there)
+        if (in_main_tab(r)) {
+            single.push_back(slot);
+            continue;
+        }
+        // where the scan lives, if anywhere
+        int pi = -1, ci = -1;
+        for (size_t a = 0; a < pools.size() && pi < 0; ++a)
+            for (size_t b = 0; b < pools[a].cur.size(); ++b)
+                if (pools[a].cur[b].used && pools[a].cur[b].pid == r.owner_pid && pools[a].cur[b].scan_id == r.scan_id) {
+                    pi = (int)a;
+                    ci = (int)b;
+                    break;
+                }
+        if (r.op == OP_CLOSE) {
+            if (pi >= 0) {
+                (void)vs_scanpool_endscan(pools[pi].h, (uint32_t)ci);
+                pools[pi].cur[ci] = PoolCursor{};
+                open_cursors--;
+                SlotHead* out = m.slot(slot);
+                out->n_rows = 0;
+                out->rc = VS_OK;
+                out->err[0] = 0;
+                fetches++;
+                finish(slot);
+            } else {
+                single.push_back(slot);
+            }
+            continue;
+        }
+        const uint64_t sig = scan_signature(&r, r.query.data(), d.dim_full);
+        if (pi >= 0 && (pools[pi].L != r.L || pools[pi].rescore != r.rescore || pools[pi].snapshot != r.snapshot || pools[pi].cur[ci].sig != sig ||
+                        pools[pi].cur[ci].pos != r.skip)) {
+            // another scan under the same id, or a client that is somewhere else in it: start over
+            (void)vs_scanpool_endscan(pools[pi].h, (uint32_t)ci);
+            pools[pi].cur[ci] = PoolCursor{};
+            open_cursors--;
+            pi = ci = -1;
+        }
+        if (pi < 0) {
+            if (r.skip > 0) {  // a scan that is already under way elsewhere (evicted, or its first rows came from OP_SEARCH): the single
+                single.push_back(slot);  // cursor replays it once; pooled scans start at row 0
+                continue;
+            }
+            for (size_t a = 0; a < pools.size(); ++a)
+                if (pools[a].L == r.L && pools[a].rescore == r.rescore && pools[a].snapshot == r.snapshot) pi = (int)a;
+            if (pi < 0 && pools.size() < 4) {
+                Pool np;
+                np.L = r.L;
+                np.rescore = r.rescore;
+                np.snapshot = r.snapshot;
+                if (vs_scanpool_create(ix, cfg.cursor_pool, r.L, r.rescore, m.kmax, 0, &np.h) == VS_OK) {
+                    np.cur.resize(cfg.cursor_pool);
+                    pools.push_back(np);
+                    pi = (int)pools.size() - 1;
+                }
+            }
+            if (pi < 0) {
+                single.push_back(slot);
+                continue;
+            }
+            Pool& p = pools[pi];
+            for (size_t b = 0; b < p.cur.size() && ci < 0; ++b)
+                if (!p.cur[b].used) ci = (int)b;
+            if (ci < 0) {  // make room: the least recently used scan of the pool goes (its client's next request replays it on a cursor)
+                ci = 0;
+                for (size_t b = 1; b < p.cur.size(); ++b)
+                    if (p.cur[b].last_use < p.cur[ci].last_use) ci = (int)b;
+                (void)vs_scanpool_endscan(p.h, (uint32_t)ci);
+                open_cursors--;
+            }
+            const int rc = vs_scanpool_rescan(p.h, (uint32_t)ci, r.null_query ? nullptr : r.query.data(), r.labels, r.n_labels, (int)r.has_label_key);
+            if (rc != VS_OK) {
+                p.cur[ci] = PoolCursor{};
+                single.push_back(slot);
+                continue;
+            }
+            PoolCursor& c = p.cur[ci];
+            c.used = true;
+            c.pid = r.owner_pid;
+            c.scan_id = r.scan_id;
+            c.sig = sig;
+            c.pos = 0;
+            open_cursors++;
+            cursor_opens++;
+        }
+        pools[pi].cur[ci].last_use = ++pools[pi].use_clock;
+        items.push_back(Item{slot, (uint32_t)pi, (uint32_t)ci});
+    }
+    // one shared fetch per (pool, rows asked)
+    std::vector<bool> done(items.size(), false);
+    for (size_t a = 0; a < items.size(); ++a) {
+        if (done[a]) continue;
+        const uint32_t k = reqs[items[a].slot].k;
+        Pool& p = pools[items[a].pool];
+        std::vector<size_t> grp;
+        std::vector<uint32_t> pslots;
+        for (size_t b = a; b < items.size(); ++b)
+            if (!done[b] && items[b].pool == items[a].pool && reqs[items[b].slot].k == k) {
+                done[b] = true;
+                grp.push_back(b);
+                pslots.push_back(items[b].pslot);
+            }
+        int rc = VS_OK;
+        std::string err;
+        std::vector<int32_t> rows(grp.size(), 0);
+        std::vector<uint32_t> ids;
+        std::vector<uint64_t> tids;
+        std::vector<float> dist;
+        try {
+            ids.assign(grp.size() * k, 0);
+            tids.assign(grp.size() * k, 0);
+            dist.assign(grp.size() * k, 0.0f);
+            const uint8_t* prev = nullptr;
+            rc = vs_index_snapshot_use(ix, p.snapshot, &prev);
+            if (rc == VS_OK) {
+                rc = vs_scanpool_fetch(p.h, pslots.data(), (uint32_t)pslots.size(), k, tids.data(), ids.data(), dist.data(), rows.data());
+                if (rc != VS_OK) err = vs_last_error();
+                (void)vs_index_set_visibility_dev(ix, prev);
+            } else {
+                err = vs_last_error();
+            }
+        } catch (const std::bad_alloc&) {
+            rc = VS_ERR_OOM;
+            err = "vs_shm: out of host memory while serving pooled scan cursors";
+        }
+        pool_rounds++;
+        for (size_t g = 0; g < grp.size(); ++g) {
+            const Item& it = items[grp[g]];
+            PoolCursor& c = p.cur[it.pslot];
+            if (rc == VS_OK && rows[g] < 0) {  // this scan outgrew the pool: it continues on a cursor of its own (one replay)
+                (void)vs_scanpool_endscan(p.h, it.pslot);
+                c = PoolCursor{};
+                open_cursors--;
+                single.push_back(it.slot);
+                continue;
+            }
+            SlotHead* out = m.slot(it.slot);
+            if (rc == VS_OK) {
+                const uint32_t got = (uint32_t)rows[g];
+                memcpy(m.ids(out), &ids[g * k], (size_t)got * 4);
+                memcpy(m.tids(out), &tids[g * k], (size_t)got * 8);
+                memcpy(m.dist(out), &dist[g * k], (size_t)got * 4);
+                out->n_rows = got;
+                c.pos += got;
+            } else {
+                out->n_rows = 0;
+            }
+            out->rc = rc;
+            snprintf(out->err, sizeof(out->err), "%s", err.c_str());
+            fetches++;
+            finish(it.slot);
+        }
+    }
+    for (uint32_t slot : single) run_fetch(slot, main_tab);
+}
+
 void vs_shm_server::apply_puts() {
     std::unique_lock<std::mutex> lk(put_mu);
     if (puts.empty()) return;
@@ -488,7 +698,7 @@ void vs_shm_server::run() {
             // bumps work_seq and wakes this thread: look again and keep waiting for the rest of the window)
             // (only scans that can share a launch wait for company: a cursor request is served at once)
             bool any_search = false;
-            for (uint32_t i : ready) any_search |= m.slot(i)->op == OP_SEARCH;  // (a hint for how long to gather; nothing is run on it)
+            for (uint32_t i : ready) any_search |= m.slot(i)->op == OP_SEARCH || cfg.cursor_pool != 0;  // (a hint for how long to gather; nothing is run on it — with scan pools the cursor requests share launches too)
             if (any_search && cfg.max_wait_us && ready.size() < cfg.max_batch) {
                 const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(cfg.max_wait_us);
                 for (;;) {
@@ -524,9 +734,18 @@ void vs_shm_server::run() {
                 ready.erase(ready.begin() + (long)a);
             }
             std::vector<bool> taken(ready.size(), false);
+            if (cfg.cursor_pool) {  // cursor requests of this round: served together out of the scan pools
+                std::vector<uint32_t> fetch_slots;
+                for (size_t a = 0; a < ready.size(); ++a)
+                    if (reqs[ready[a]].op != OP_SEARCH) {
+                        taken[a] = true;
+                        fetch_slots.push_back(ready[a]);
+                    }
+                if (!fetch_slots.empty()) run_fetch_pooled(fetch_slots);
+            }
             for (size_t a = 0; a < ready.size(); ++a) {  // cursor requests: one scan each, served one after the other
                 const Req* ha = &reqs[ready[a]];
-                if (ha->op == OP_SEARCH) continue;
+                if (ha->op == OP_SEARCH || taken[a]) continue;
                 taken[a] = true;
                 if (lanes.empty()) {
                     run_fetch(ready[a], main_tab);
@@ -572,9 +791,11 @@ void vs_shm_server::run() {
                 }
             }
             reap_cursors(main_tab);  // ... and its cursors their device memory (the lanes look after their own tables)
+            reap_pools();
         }
     }
     while (!main_tab.cursors.empty()) drop_cursor(main_tab, main_tab.cursors.size() - 1);
+    free_pools();
     // the lanes serve what they were handed, drop their cursors and end
     for (auto& l : lanes) {
         {
@@ -630,6 +851,9 @@ int vs_shm_server_create(vs_index* idx, const char* name, uint32_t nslots, uint3
     s->cfg.max_batch = cfg && cfg->max_batch ? cfg->max_batch : 8192;
     s->cfg.max_wait_us = cfg ? cfg->max_wait_us : 200;
     s->cfg.cursor_lanes = cfg ? std::min<uint32_t>(cfg->cursor_lanes, 64) : 0;
+    s->cfg.cursor_pool = cfg ? std::min<uint32_t>(cfg->cursor_pool, 1024) : 0;
+    if (!s->cfg.cursor_pool)
+        if (const char* e = getenv("VS_SHM_CURSOR_POOL")) s->cfg.cursor_pool = std::min<uint32_t>((uint32_t)strtoul(e, nullptr, 10), 1024);
     if (!s->cfg.cursor_lanes)
         if (const char* e = getenv("VS_BROKER_LANES")) s->cfg.cursor_lanes = std::min<uint32_t>((uint32_t)strtoul(e, nullptr, 10), 64);
     s->main_tab.ix = idx;

@@ -423,6 +423,54 @@ class DiskAnnIndex:
             self.h = None
 
 
+class ScanPool:
+    """Many streamed scans of one index continued by launches they share (vs_scanpool_*, csrc/vs_scanpool.cpp): slot i is one
+    backend's amrescan / amgettuple cursor; fetch() serves the next k rows of every listed slot with ONE resumed search launch (+ one
+    rerank launch) per round.  All slots share search_list_size / rescore."""
+
+    def __init__(self, index, capacity, search_list_size=DEFAULT_QUERY_SEARCH_LIST_SIZE, rescore=DEFAULT_QUERY_RESCORE, kmax=64, rows_cap=0):
+        self.index = index
+        self._L = index._L
+        self.kmax = kmax
+        h = C.c_void_p()
+        check(self._L.vs_scanpool_create(index.h, capacity, search_list_size, rescore, kmax, rows_cap, C.byref(h)))
+        self.h = h
+
+    def rescan(self, slot, query, labels=None):
+        q = None if query is None else np.ascontiguousarray(query, np.float32).reshape(self.index.desc.dim_full)
+        lab = None if labels is None else np.ascontiguousarray(labels, np.int16)
+        check(self._L.vs_scanpool_rescan(self.h, slot, _p(q), _p(lab), 0 if lab is None else lab.size, int(labels is not None)))
+
+    def endscan(self, slot):
+        check(self._L.vs_scanpool_endscan(self.h, slot))
+
+    def fetch(self, slots, k):
+        """-> (rows [n] int32 (negative: that slot's error code), ids [n][k], tids [n][k], dist [n][k])"""
+        sl = np.ascontiguousarray(slots, np.uint32)
+        n = sl.size
+        ids = np.full((n, k), 0xFFFFFFFF, np.uint32)
+        tids = np.zeros((n, k), np.uint64)
+        dist = np.zeros((n, k), np.float32)
+        rows = np.zeros(n, np.int32)
+        check(self._L.vs_scanpool_fetch(self.h, _p(sl), n, k, _p(tids), _p(ids), _p(dist), _p(rows)))
+        return rows, ids, tids, dist
+
+    def stats(self, slot):
+        st = _lib.Stats()
+        check(self._L.vs_scanpool_get_stats(self.h, slot, C.byref(st)))
+        return st.as_dict()
+
+    def work(self):
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        check(self._L.vs_scanpool_get_work(self.h, C.byref(a), C.byref(b)))
+        return {"launches": int(a.value), "rounds": int(b.value)}
+
+    def close(self):
+        if self.h:
+            self._L.vs_scanpool_free(self.h)
+            self.h = None
+
+
 class Broker:
     """Coalesces the scans of many client threads into batched launches (vs_broker_*; threads stand in for PostgreSQL
     backends).  search() may be called from any thread; the library's dispatcher thread is the only one that touches the
@@ -477,10 +525,12 @@ class ShmServer:
     """The dispatcher side of the cross-process request queue (vs_shm_server_*): lives in the one process that owns the device
     context; client processes post scans into the POSIX shared-memory segment `name` and get the rows of vs_search_batch."""
 
-    def __init__(self, index, name, nslots=256, kmax=64, max_batch=0, max_wait_us=200, cursor_lanes=0):
+    def __init__(self, index, name, nslots=256, kmax=64, max_batch=0, max_wait_us=200, cursor_lanes=0, cursor_pool=0):
         self.index = index
         self._L = index._L
-        cfg = _lib.BrokerConfig(max_batch, max_wait_us, cursor_lanes)  # cursor_lanes: streamed scans are served on that many lanes
+        # cursor_lanes: streamed scans are served on that many lanes; cursor_pool: ... or out of scan pools of that many slots, the
+        # continuations of one dispatcher round sharing their launches
+        cfg = _lib.BrokerConfig(max_batch, max_wait_us, cursor_lanes, cursor_pool)
         h = C.c_void_p()
         check(self._L.vs_shm_server_create(index.h, name.encode(), nslots, kmax, C.byref(cfg), C.byref(h)))
         self.h = h

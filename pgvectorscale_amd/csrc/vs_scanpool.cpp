@@ -16,6 +16,7 @@
 // session-level in PostgreSQL) and the snapshot mask in force; scan keys are per scan.  A scan that outgrows the pool's fixed
 // capacities (more than rows_cap stream rows) fails with VS_ERR_CAPACITY and is continued by a cursor of its own.
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 #include <vector>
 
@@ -44,8 +45,22 @@ struct vs_scan_pool {
     bool csr_dirty = true;
     DevBuf raw_q, q_full, q_index, qcodes, qlabels, qlabel_off, heap_g, hash, state, cnt, stats, status, row_stats, stage, all, resort_heap,
         cur, out_ids, out_tids, out_dist;
-    uint64_t launches = 0, rounds = 0;
+    // the window kernel (k_resort_cursor) is one serial thread per scan: the launches of one fetch are dealt over a few streams so that
+    // they run side by side instead of one after the other
+    static constexpr int kAux = 8;
+    hipStream_t aux[kAux] = {nullptr};
+    hipEvent_t ev_main = nullptr, ev_aux[kAux] = {nullptr};
+    uint64_t launches = 0, rounds = 0, fetches = 0, scans_served = 0;
+    double t_search = 0, t_append = 0, t_resort = 0;  // (VS_POOL_DEBUG) host seconds: launch .. counters back / rerank + append / resort + rows back
     void free_all() {
+        for (int i = 0; i < kAux; ++i) {
+            if (aux[i]) (void)hipStreamDestroy(aux[i]);
+            if (ev_aux[i]) (void)hipEventDestroy(ev_aux[i]);
+            aux[i] = nullptr;
+            ev_aux[i] = nullptr;
+        }
+        if (ev_main) (void)hipEventDestroy(ev_main);
+        ev_main = nullptr;
         for (DevBuf* b : {&raw_q, &q_full, &q_index, &qcodes, &qlabels, &qlabel_off, &heap_g, &hash, &state, &cnt, &stats, &status, &row_stats,
                           &stage, &all, &resort_heap, &cur, &out_ids, &out_tids, &out_dist}) {
             if (b->p && !b->in_slab) (void)hipFree(b->p);
@@ -115,6 +130,11 @@ static int scanpool_create_impl(vs_index* ix, uint32_t capacity, uint32_t L, uin
         VS_TRY(devbuf_reserve(c, p->out_ids, G * (size_t)kmax * 4));
         VS_TRY(devbuf_reserve(c, p->out_tids, G * (size_t)kmax * 8));
         VS_TRY(devbuf_reserve(c, p->out_dist, G * (size_t)kmax * 4));
+        VS_HIP(hipEventCreateWithFlags(&p->ev_main, hipEventDisableTiming));
+        for (int i = 0; i < vs_scan_pool::kAux; ++i) {
+            VS_HIP(hipStreamCreateWithFlags(&p->aux[i], hipStreamNonBlocking));
+            VS_HIP(hipEventCreateWithFlags(&p->ev_aux[i], hipEventDisableTiming));
+        }
         return VS_OK;
     };
     const int r = all();
@@ -132,6 +152,11 @@ extern "C" int vs_scanpool_create(vs_index* ix, uint32_t capacity, uint32_t L, u
 
 extern "C" void vs_scanpool_free(vs_scan_pool* p) {
     if (!p) return;
+    if (pool_env_u32("VS_POOL_DEBUG", 0))
+        fprintf(stderr, "[VS_POOL_DEBUG] pool L=%u rescore=%u: %llu fetch calls serving %llu scan chunks in %llu rounds (%llu search launches); host ms: "
+                        "search %.1f, rerank+append %.1f, resort+rows %.1f\n", p->L, p->rescore, (unsigned long long)p->fetches,
+                (unsigned long long)p->scans_served, (unsigned long long)p->rounds, (unsigned long long)p->launches, p->t_search * 1e3, p->t_append * 1e3,
+                p->t_resort * 1e3);
     (void)hipSetDevice(p->ix->ctx->device);
     (void)hipStreamSynchronize(p->ix->ctx->stream);
     p->free_all();
@@ -207,6 +232,7 @@ static int pool_round(vs_scan_pool* p, const std::vector<uint32_t>& run, uint32_
     const bool plain = ix->d.storage_type == VS_STORAGE_PLAIN;
     uint32_t nq = 0;
     for (uint32_t q : run) nq = std::max(nq, q + 1);
+    const auto tp0 = std::chrono::steady_clock::now();
     VS_TRY(upload_csr(p));
     VS_HIP(hipMemsetAsync(p->cnt.p, 0, (size_t)G * 4, c->stream));
     uint32_t* const stage_ids = (uint32_t*)p->stage.p;
@@ -222,7 +248,7 @@ static int pool_round(vs_scan_pool* p, const std::vector<uint32_t>& run, uint32_
             }
         if (!any) continue;
         uint32_t* const d_status = (uint32_t*)p->status.p + (size_t)keyed * G;
-        VS_TRY(vs_dev_upload(c, d_status, mask.data(), (size_t)nq * 4));
+        VS_HIP(hipMemcpyAsync(d_status, mask.data(), (size_t)nq * 4, hipMemcpyHostToDevice, c->stream));  // (pageable source: staged before the call returns)
         SearchLaunch sl;
         sl.nq = nq;
         sl.L = p->L;
@@ -266,11 +292,14 @@ static int pool_round(vs_scan_pool* p, const std::vector<uint32_t>& run, uint32_
         p->launches++;
     }
     p->rounds++;
-    // headers + row counts of the slots that ran
-    std::vector<uint32_t> hdr((size_t)nq * RS_HDR), cnt(nq);
-    VS_HIP(hipMemcpy2DAsync(hdr.data(), RS_HDR * 4, p->state.p, (size_t)p->rw * 4, RS_HDR * 4, nq, hipMemcpyDeviceToHost, c->stream));
+    // outcome, counters and row counts of the slots that ran (what the kernel publishes per scan next to the saved state)
+    std::vector<uint32_t> kst((size_t)nq * ST_N), kstatus((size_t)2 * G), cnt(nq);
+    VS_HIP(hipMemcpyAsync(kst.data(), p->stats.p, (size_t)nq * ST_N * 4, hipMemcpyDeviceToHost, c->stream));
+    VS_HIP(hipMemcpyAsync(kstatus.data(), p->status.p, (size_t)2 * G * 4, hipMemcpyDeviceToHost, c->stream));
     VS_HIP(hipMemcpyAsync(cnt.data(), p->cnt.p, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
     VS_HIP(hipStreamSynchronize(c->stream));
+    const auto tp1 = std::chrono::steady_clock::now();
+    p->t_search += std::chrono::duration<double>(tp1 - tp0).count();
     std::vector<uint32_t> rst((size_t)nq * M * ST_N);
     VS_HIP(hipMemcpyAsync(rst.data(), p->row_stats.p, rst.size() * 4, hipMemcpyDeviceToHost, c->stream));
     if (p->S > 0) {  // get_full_distance_for_resort of the new rows (AM/sbq/storage.rs:304-328): one launch for every slot
@@ -280,32 +309,43 @@ static int pool_round(vs_scan_pool* p, const std::vector<uint32_t>& run, uint32_
         prof_end(c, PK_RERANK, ev2);
     }
     uint32_t* const all_ids = (uint32_t*)p->all.p;
+    // ids, Hamming keys and distances of the new rows go from the round's staging rows to the slots' stream arrays.  Scans that are
+    // streamed side by side move in lockstep (same position, M new rows each): a contiguous run of such slots is ONE 2-D copy per kind
+    // of array; anything else one 2-D copy per slot (three "rows": the three kinds).
+    bool lockstep = run.size() > 1;
+    for (size_t i = 0; i < run.size() && lockstep; ++i)
+        lockstep = run[i] == run[0] + i && p->slots[run[i]].rows == p->slots[run[0]].rows && cnt[run[i]] == M &&
+                   kstatus[(size_t)(p->slots[run[i]].keys ? G : 0) + run[i]] == 0;
+    if (lockstep) {
+        const uint32_t q0 = run[0], r0 = p->slots[q0].rows;
+        for (int kind = 0; kind < 3; ++kind)
+            VS_HIP(hipMemcpy2DAsync(all_ids + (size_t)kind * G * p->rows_cap + (size_t)q0 * p->rows_cap + r0, (size_t)p->rows_cap * 4,
+                                    stage_ids + (size_t)kind * G * p->mmax + (size_t)q0 * M, (size_t)M * 4, (size_t)M * 4, run.size(),
+                                    hipMemcpyDeviceToDevice, c->stream));
+    }
     for (uint32_t q : run) {
         Slot& s = p->slots[q];
-        const uint32_t* h = hdr.data() + (size_t)q * RS_HDR;
+        const uint32_t* h = kst.data() + (size_t)q * ST_N;
         s.launches++;
         s.masked = p->S > 0 && ix->visible != nullptr;
-        if (h[RS_STATUS] != 0) {  // a structure outgrew the pool's capacities: the scan continues on a cursor of its own
+        if (kstatus[(size_t)(s.keys ? G : 0) + q] != 0) {  // a structure outgrew the pool's capacities: the scan continues on a cursor of its own
             s.failed = true;
             continue;
         }
         const uint32_t n = cnt[q];
-        if (n) {
-            // ids, Hamming keys and distances of the new rows, from the round's staging rows to the slot's stream arrays: ONE 2-D copy
-            // (three "rows": the three kinds of array)
+        if (n && !lockstep)
             VS_HIP(hipMemcpy2DAsync(all_ids + (size_t)q * p->rows_cap + s.rows, (size_t)G * p->rows_cap * 4, stage_ids + (size_t)q * M,
                                     (size_t)G * p->mmax * 4, (size_t)n * 4, 3, hipMemcpyDeviceToDevice, c->stream));
-        }
         s.rows += n;
         if (n < M) {
             s.exhausted = true;
             memset(s.final_counters, 0, sizeof(s.final_counters));
-            s.final_counters[ST_VISITS] = h[RS_VISITS];
-            s.final_counters[ST_CAND] = h[RS_CAND];
-            s.final_counters[ST_DQ] = h[RS_DQ];
-            s.final_counters[ST_READS] = h[RS_READS];
-            s.final_counters[ST_NEXT] = h[RS_NEXT];
-            s.final_counters[ST_INVIS] = h[RS_INVIS];
+            s.final_counters[ST_VISITS] = h[ST_VISITS];
+            s.final_counters[ST_CAND] = h[ST_CAND];
+            s.final_counters[ST_DQ] = h[ST_DQ];
+            s.final_counters[ST_READS] = h[ST_READS];
+            s.final_counters[ST_NEXT] = h[ST_NEXT];
+            s.final_counters[ST_INVIS] = h[ST_INVIS];
         }
     }
     VS_HIP(hipStreamSynchronize(c->stream));  // (row_stats: the per-row counters of this round)
@@ -315,6 +355,7 @@ static int pool_round(vs_scan_pool* p, const std::vector<uint32_t>& run, uint32_
         const uint32_t n = cnt[q];
         s.row_stats.insert(s.row_stats.end(), rst.begin() + (size_t)q * M * ST_N, rst.begin() + ((size_t)q * M + n) * ST_N);
     }
+    p->t_append += std::chrono::duration<double>(std::chrono::steady_clock::now() - tp1).count();
     return VS_OK;
 }
 
@@ -350,6 +391,12 @@ static int scanpool_fetch_impl(vs_scan_pool* p, const uint32_t* slots, uint32_t 
             M = std::max<uint32_t>(M, (uint32_t)(need - s.rows));
         }
         if (run.empty()) break;
+        // a scan that keeps being streamed is carried ahead of its executor: from its third continuation on a round produces up to
+        // four chunks of rows (bounded by the round's staging rows), so most of its later fetches find their rows already there.  The
+        // counters are recorded per row: what the executor has not pulled does not show in them.
+        bool streaming = true;
+        for (uint32_t q : run) streaming = streaming && p->slots[q].launches >= 2;
+        if (streaming) M = std::max(M, std::min<uint32_t>(4 * k, p->mmax));
         M = std::min(M, p->mmax);
         // (a scan that needs fewer rows than the round's M is simply further ahead afterwards — rows are handed out by the window
         // below and the counters are recorded per row — but no scan may pass its row budget)
@@ -358,20 +405,36 @@ static int scanpool_fetch_impl(vs_scan_pool* p, const uint32_t* slots, uint32_t 
         VS_TRY(pool_round(p, run, M));
     }
     // ---- next_with_resort x k per scan (AM/scan.rs:244-305): one k_resort_cursor launch per listed scan, all enqueued, one wait
+    const auto tr0 = std::chrono::steady_clock::now();
+    p->fetches++;
+    p->scans_served += n;
     uint32_t* const all_ids = (uint32_t*)p->all.p;
     uint32_t* const all_ham = all_ids + (size_t)G * p->rows_cap;
     float* const all_dist = (float*)(all_ham + (size_t)G * p->rows_cap);
-    for (uint32_t i = 0; i < n; ++i) {
+    const int naux = n >= 4 ? vs_scan_pool::kAux : 0;  // (a few scans: the context's own stream)
+    hipStream_t const main_stream = c->stream;
+    if (naux) {
+        VS_HIP(hipEventRecord(p->ev_main, main_stream));  // the rows appended above are in place
+        for (int a = 0; a < naux; ++a) VS_HIP(hipStreamWaitEvent(p->aux[a], p->ev_main, 0));
+    }
+    int lrc = VS_OK;
+    for (uint32_t i = 0; i < n && lrc == VS_OK; ++i) {
         const uint32_t q = slots[i];
         Slot& s = p->slots[q];
         if (s.failed) continue;
-        hipEvent_t ev = prof_begin(c);
-        VS_TRY(launch_resort_cursor(ix, s.rows, s.exhausted, S, k, all_ids + (size_t)q * p->rows_cap, all_dist + (size_t)q * p->rows_cap,
-                                    all_ham + (size_t)q * p->rows_cap, (uint64_t*)p->resort_heap.p + (size_t)q * S, (uint32_t*)p->cur.p + (size_t)q * 4,
-                                    (uint32_t*)p->out_ids.p + (size_t)q * p->kmax, (uint64_t*)p->out_tids.p + (size_t)q * p->kmax,
-                                    (float*)p->out_dist.p + (size_t)q * p->kmax));
-        prof_end(c, PK_RESORT, ev);
+        if (naux) c->stream = p->aux[i % naux];  // (launch_resort_cursor launches on the context's stream; one dispatcher thread)
+        lrc = launch_resort_cursor(ix, s.rows, s.exhausted, S, k, all_ids + (size_t)q * p->rows_cap, all_dist + (size_t)q * p->rows_cap,
+                                   all_ham + (size_t)q * p->rows_cap, (uint64_t*)p->resort_heap.p + (size_t)q * S, (uint32_t*)p->cur.p + (size_t)q * 4,
+                                   (uint32_t*)p->out_ids.p + (size_t)q * p->kmax, (uint64_t*)p->out_tids.p + (size_t)q * p->kmax,
+                                   (float*)p->out_dist.p + (size_t)q * p->kmax);
     }
+    c->stream = main_stream;
+    if (naux)
+        for (int a = 0; a < naux; ++a) {
+            VS_HIP(hipEventRecord(p->ev_aux[a], p->aux[a]));
+            VS_HIP(hipStreamWaitEvent(main_stream, p->ev_aux[a], 0));
+        }
+    VS_TRY(lrc);
     std::vector<uint32_t> cur((size_t)G * 4), ids((size_t)G * p->kmax);
     std::vector<uint64_t> tids((size_t)G * p->kmax);
     std::vector<float> dist((size_t)G * p->kmax);
@@ -380,6 +443,7 @@ static int scanpool_fetch_impl(vs_scan_pool* p, const uint32_t* slots, uint32_t 
     VS_HIP(hipMemcpyAsync(tids.data(), p->out_tids.p, tids.size() * 8, hipMemcpyDeviceToHost, c->stream));
     VS_HIP(hipMemcpyAsync(dist.data(), p->out_dist.p, dist.size() * 4, hipMemcpyDeviceToHost, c->stream));
     VS_HIP(hipStreamSynchronize(c->stream));
+    p->t_resort += std::chrono::duration<double>(std::chrono::steady_clock::now() - tr0).count();
     for (uint32_t i = 0; i < n; ++i) {
         const uint32_t q = slots[i];
         Slot& s = p->slots[q];

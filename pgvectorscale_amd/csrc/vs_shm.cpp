@@ -461,7 +461,7 @@ void vs_shm_server::reap_pools() {
 // rerank launch for all of them.  What a pool cannot take is served by a cursor of its own (run_fetch).
 void vs_shm_server::run_fetch_pooled(const std::vector<uint32_t>& slots) {
     struct Item { uint32_t slot, pool, pslot; };
-    std::vector<Item> items;
+    std::vector<Item> items, ff;  // requests to serve / new scans to fast-forward first
     std::vector<uint32_t> single;  // requests for the single-cursor path
     auto in_main_tab = [&](const Req& r) {
         for (const Cursor& c : main_tab.cursors)
@@ -510,10 +510,6 @@ void vs_shm_server::run_fetch_pooled(const std::vector<uint32_t>& slots) {
             pi = ci = -1;
         }
         if (pi < 0) {
-            if (r.skip > 0) {  // a scan that is already under way elsewhere (evicted, or its first rows came from OP_SEARCH): the single
-                single.push_back(slot);  // cursor replays it once; pooled scans start at row 0
-                continue;
-            }
             for (size_t a = 0; a < pools.size(); ++a)
                 if (pools[a].L == r.L && pools[a].rescore == r.rescore && pools[a].snapshot == r.snapshot) pi = (int)a;
             if (pi < 0 && pools.size() < 4) {
@@ -555,9 +551,76 @@ void vs_shm_server::run_fetch_pooled(const std::vector<uint32_t>& slots) {
             c.pos = 0;
             open_cursors++;
             cursor_opens++;
+            // a scan that is already under way (its first rows came out of a shared OP_SEARCH launch, or its cursor was evicted): the
+            // rows the client has are reproduced once by the deterministic scan and skipped, as a single cursor does it — for all
+            // the scans that start in this round together (below)
+            if (r.skip > 0) ff.push_back(Item{slot, (uint32_t)pi, (uint32_t)ci});
         }
         pools[pi].cur[ci].last_use = ++pools[pi].use_clock;
         items.push_back(Item{slot, (uint32_t)pi, (uint32_t)ci});
+    }
+    // fast-forward of the scans that start in this round: shared fetches whose rows are thrown away, rounds of at most kmax rows
+    {
+        std::vector<bool> ffd(ff.size(), false);
+        for (size_t a = 0; a < ff.size(); ++a) {
+            if (ffd[a]) continue;
+            Pool& p = pools[ff[a].pool];
+            const uint32_t skip = reqs[ff[a].slot].skip;
+            std::vector<size_t> grp;
+            for (size_t b = a; b < ff.size(); ++b)
+                if (!ffd[b] && ff[b].pool == ff[a].pool && reqs[ff[b].slot].skip == skip) {
+                    ffd[b] = true;
+                    grp.push_back(b);
+                }
+            const uint8_t* prev = nullptr;
+            bool ok = vs_index_snapshot_use(ix, p.snapshot, &prev) == VS_OK;
+            std::vector<uint32_t> live;  // pool slots still being forwarded
+            for (size_t g : grp) live.push_back(ff[g].pslot);
+            uint32_t left = skip;
+            while (ok && left && !live.empty()) {
+                const uint32_t kk = std::min<uint32_t>(left, m.kmax);
+                std::vector<int32_t> got(live.size(), 0);
+                ok = vs_scanpool_fetch(p.h, live.data(), (uint32_t)live.size(), kk, nullptr, nullptr, nullptr, got.data()) == VS_OK;
+                if (!ok) break;
+                std::vector<uint32_t> next;
+                for (size_t i = 0; i < live.size(); ++i) {
+                    if (got[i] < 0) continue;  // (outgrew the pool during the replay: pos stays short, handled below)
+                    p.cur[live[i]].pos += (uint32_t)got[i];
+                    if ((uint32_t)got[i] == kk) next.push_back(live[i]);  // else: fewer rows than the client skipped — the scan is over
+                }
+                live.swap(next);
+                left -= kk;
+            }
+            if (ok) (void)vs_index_set_visibility_dev(ix, prev);
+            for (size_t g : grp) {
+                PoolCursor& c = p.cur[ff[g].pslot];
+                if (!ok) c.pos = 0xFFFFFFFFu;  // (marks "could not be forwarded": a cursor of its own)
+            }
+        }
+    }
+    // requests whose scan could not be brought to the client's position inside the pool go to a cursor of their own
+    for (size_t a = 0; a < items.size();) {
+        Pool& p = pools[items[a].pool];
+        PoolCursor& c = p.cur[items[a].pslot];
+        if (c.pos == 0xFFFFFFFFu) {
+            (void)vs_scanpool_endscan(p.h, items[a].pslot);
+            c = PoolCursor{};
+            open_cursors--;
+            single.push_back(items[a].slot);
+            items.erase(items.begin() + (long)a);
+            continue;
+        }
+        if (c.pos < reqs[items[a].slot].skip) {  // (the fast-forward fell short: the scan is over)
+            SlotHead* out = m.slot(items[a].slot);
+            out->n_rows = 0;
+            out->rc = VS_OK;
+            out->err[0] = 0;
+            fetches++;
+            finish(items[a].slot);
+            items.erase(items.begin() + (long)a);
+            continue;
+        }
+        ++a;
     }
     // one shared fetch per (pool, rows asked)
     std::vector<bool> done(items.size(), false);
@@ -698,7 +761,7 @@ void vs_shm_server::run() {
             // bumps work_seq and wakes this thread: look again and keep waiting for the rest of the window)
             // (only scans that can share a launch wait for company: a cursor request is served at once)
             bool any_search = false;
-            for (uint32_t i : ready) any_search |= m.slot(i)->op == OP_SEARCH || cfg.cursor_pool != 0;  // (a hint for how long to gather; nothing is run on it — with scan pools the cursor requests share launches too)
+            for (uint32_t i : ready) any_search |= m.slot(i)->op == OP_SEARCH || (cfg.cursor_pool != 0 && open_cursors.load() > 1);  // (a hint for how long to gather; nothing is run on it — with scan pools the cursor requests share launches too)
             if (any_search && cfg.max_wait_us && ready.size() < cfg.max_batch) {
                 const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(cfg.max_wait_us);
                 for (;;) {

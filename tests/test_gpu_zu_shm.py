@@ -268,8 +268,10 @@ def _streaming_client(name, lib_path, jobs, out_q):
         out_q.put(("err", repr(e)))
 
 
-def test_backend_processes_stream_past_the_first_rows(gpu_ctx, oracle):
-    """amgettuple across processes: the first chunk of a scan comes out of a shared launch, every later chunk continues the cursor
+@pytest.mark.parametrize("cursor_pool", [0, 6], ids=["cursor_per_scan", "scan_pools"])
+def test_backend_processes_stream_past_the_first_rows(gpu_ctx, oracle, cursor_pool):
+    """(scan_pools: the streamed scans live in scan pools of six slots — more scans than slots, three different GUC pairs — and the
+    continuations of one dispatcher round share their launches, vs_scanpool.cpp.)  amgettuple across processes: the first chunk of a scan comes out of a shared launch, every later chunk continues the cursor
     the serving process keeps for that scan (AM/scan.rs:162-174,370-405) — rows equal the oracle's streaming scan, one row at a
     time, for plain, label-keyed, NULL and exhausted scans, from four processes at once"""
     import pgvectorscale_amd as P
@@ -300,7 +302,7 @@ def test_backend_processes_stream_past_the_first_rows(gpu_ctx, oracle):
         want[i] = rows
         jobs[i % nproc].append(job)
     name = f"/vs_shm_stream_{os.getpid()}"
-    srv = P.ShmServer(ix, name, nslots=3, kmax=8, max_batch=64, max_wait_us=5000)
+    srv = P.ShmServer(ix, name, nslots=3, kmax=8, max_batch=64, max_wait_us=5000, cursor_pool=cursor_pool)
     ctx = mp.get_context("spawn")
     out_q = ctx.Queue()
     procs = [ctx.Process(target=_streaming_client, args=(name, _lib.LIB_PATH, jobs[p], out_q)) for p in range(nproc)]

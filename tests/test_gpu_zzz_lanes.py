@@ -108,7 +108,7 @@ def test_backend_processes_stream_on_lanes(gpu_ctx, oracle, monkeypatch):
     transport, with the serving process's cursors spread over two lanes"""
     monkeypatch.setenv("VS_BROKER_LANES", "2")  # servers created without a lane count take it from here
     import test_gpu_zu_shm as Z
-    Z.test_backend_processes_stream_past_the_first_rows(gpu_ctx, oracle)
+    Z.test_backend_processes_stream_past_the_first_rows(gpu_ctx, oracle, 0)
     Z.test_fetch_protocol_random_walk(gpu_ctx, oracle)
 
 

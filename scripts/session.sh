@@ -23,6 +23,7 @@ for step in "$@"; do
     bench) timeout 2400 python bench.py $arg > $O/bench_$(echo "$arg" | tr -c 'A-Za-z0-9\n' '_').json 2> $O/bench.err; tail -3 $O/bench.err; tail -c 1500 $O/bench_*.json ;;
     ab)    N=${arg%%:*}; CFG=${arg#*:}
            timeout 1500 python scripts/perf_search.py --n $N --nq 262144 --L 3 --rescore 195 --reps 4 --graph-cache /tmp/g --configs "$CFG" 2>&1 | grep -Ev "$NOBANNER" | tee $O/ab_$N.txt ;;
+    pmcissue) bash scripts/pmc_issue.sh ${arg:-10000000} 262144 3 195 2>&1 | grep -Ev "$NOBANNER" | tee $O/pmc_issue.txt ;;
     cpool) timeout 900 python scripts/cursor_pool_concurrency.py --n ${arg:-1000000} 2>&1 | grep -Ev "$NOBANNER" | tee $O/cursor_pool_concurrency.txt ;;
     fuzzv) timeout $(( ${arg:-40} * 8 + 120 )) python scripts/fuzz_variants.py --gpu --cases ${arg:-40} --seed $RANDOM 2>&1 | tail -4 | tee $O/fuzz_variants_gpu.txt ;;
     fuzzv) timeout $(( ${arg:-40} * 8 + 120 )) python scripts/fuzz_variants.py --gpu --cases ${arg:-40} --seed $RANDOM 2>&1 | tail -4 | tee $O/fuzz_variants_gpu.txt ;;

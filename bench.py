@@ -293,7 +293,8 @@ def main():
                          "a child-process probe of the variants on a small index under a timeout (pgvectorscale_amd/tune_probe.py); the "
                          "line reports every candidate's time under `autotune`")
     ap.add_argument("--extras", default="auto", choices=["auto", "on", "off"],
-                    help="two more objects in the JSON line, outside the headline value (N = 1 only): `default_gucs` — the same index at the "
+                    help="three more objects in the JSON line, outside the headline value (N = 1 only): `cursor_pool` — 32 backend processes streaming "
+                         "320 rows each through the shared-memory server, a cursor per scan against scan pools; `default_gucs` — the same index at the "
                          "reference's default GUCs (diskann.query_search_list_size = 100, diskann.query_rescore = 50, AM/guc.rs:3-4): QPS, "
                          "recall@k with its lower 95 %% bound, kernel fraction — and `harder_corpus` — a child run of this script on 10M vectors "
                          "of the `mid` corpus (its own operating point, QPS, recall bounds, CPU parity).  auto = on for the default workload "
@@ -980,6 +981,34 @@ def main():
             except Exception:  # noqa: BLE001
                 pass
 
+    # ---- extras (never the value): the amgettuple continuations of many backends at once — 32 backend PROCESSES stream 320 rows each
+    # through the shared-memory server (the first chunk of a scan out of a shared launch, the rest by cursor requests), with a cursor per
+    # scan on the dispatcher thread and out of scan pools (vs_scanpool.cpp: the requests of one dispatcher round share their launches)
+    cursor_pool = None
+    if extras_on and ix.desc.storage_type == _lib.VS_STORAGE_SBQ:
+        try:
+            from pgvectorscale_amd.shm_clients import stream_many
+            nb, rows_each, chunk = (32, 320, 16) if not EMU else (3, 48, 16)
+            qh_c = ctx.download(qbuf[0], np.empty((nq, dim), np.float32))[:nb]
+            cursor_pool = {"backends": nb, "rows_per_scan": rows_each, "chunk": chunk, "search_list_size": 100, "rescore": 50}
+            ref_rows = None
+            for mode, kw in (("cursor_per_scan", dict(cursor_pool=0)), ("scan_pools", dict(cursor_pool=nb))):
+                shm_name = f"/vs_bench_cp_{os.getpid()}_{mode}"
+                srv = P.ShmServer(ix, shm_name, nslots=nb, kmax=chunk, max_batch=256, max_wait_us=100, **kw)
+                try:
+                    wall1, out1 = stream_many(shm_name, _lib.LIB_PATH, [qh_c[0]], 100, 50, rows_each, chunk, timeout=240)
+                    walln, outn = stream_many(shm_name, _lib.LIB_PATH, [qh_c[t] for t in range(nb)], 100, 50, rows_each, chunk, timeout=240)
+                finally:
+                    srv.close()
+                if ref_rows is None:
+                    ref_rows = outn
+                cursor_pool[mode] = {"one_scan_ms": round(wall1, 2), "all_scans_ms": round(walln, 2), "ratio": round(walln / max(wall1, 1e-9), 2),
+                                     "rows_identical_to_cursor_per_scan": bool(outn == ref_rows and out1[0] == ref_rows[0])}
+            log(f"cursor continuations of {nb} backends: {cursor_pool['cursor_per_scan']['all_scans_ms']} ms with a cursor per scan, "
+                f"{cursor_pool['scan_pools']['all_scans_ms']} ms out of scan pools (one scan: {cursor_pool['scan_pools']['one_scan_ms']} ms)")
+        except Exception as e:  # noqa: BLE001 — an extra never costs the headline line
+            cursor_pool = {"error": repr(e)}
+
     result = {
         "metric": f"QPS at recall@{k}>={args.recall_target:g}",
         "value": round(qps, 1),
@@ -1028,6 +1057,7 @@ def main():
         "work_per_query": {kk: round(vv / max(tot.get("queries", 1), 1), 2) for kk, vv in tot.items() if kk != "queries"},
         "setup_s": setup,
         "default_gucs": default_gucs,
+        "cursor_pool": cursor_pool,
         "harder_corpus": None,
     }
 

@@ -1,0 +1,64 @@
+"""Backend processes that stream scans through a vs_shm server at the same time — the measurement harness of the scan pools
+(scripts/cursor_pool_concurrency.py, bench.py `cursor_pool` extra).  A backend maps the segment (no GPU, no device context), takes the
+first chunk of its scan out of a shared OP_SEARCH launch and every later chunk as an OP_FETCH continuation, as a PostgreSQL backend's
+amgettuple calls would (AM/scan.rs:369-436)."""
+import multiprocessing as mp
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _backend(name, lib_path, t, query, L, rescore, rows_wanted, chunk, bar, outq):
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ["VS_NO_TORCH"] = "1"
+        from pgvectorscale_amd import _lib
+        _lib.LIB_PATH = lib_path
+        import pgvectorscale_amd as P
+        cl = P.ShmClient(name)
+        rows = []
+        for rep in range(3):  # (two untimed passes pay the serving process's allocations and lazy initialisations; the third is timed)
+            sid = 1000 * (rep + 1) + t
+            if rep == 2:
+                bar.wait()  # ready (warm-up pass done)
+                bar.wait()  # go
+            ids, _, _ = cl.search(query, None, L, rescore, chunk)
+            rows = ids.tolist()
+            while len(rows) < rows_wanted:
+                ids, _, _ = cl.fetch(sid, query, len(rows), chunk, None, L, rescore)
+                rows.extend(ids.tolist())
+                if len(ids) < chunk:
+                    break
+            cl.end_scan(sid)
+        cl.close()
+        outq.put(("ok", t, rows))
+    except Exception as e:  # noqa: BLE001
+        outq.put(("error", t, repr(e)))
+
+
+def stream_many(name, lib_path, queries, L, rescore, rows, chunk, timeout=600):
+    """len(queries) backend processes, one scan each, `rows` rows in chunks of `chunk` -> (wall ms of the timed pass, {backend: node ids})"""
+    nt = len(queries)
+    mpc = mp.get_context("spawn")
+    bar = mpc.Barrier(nt + 1)
+    outq = mpc.Queue()
+    procs = [mpc.Process(target=_backend, args=(name, lib_path, t, queries[t], L, rescore, rows, chunk, bar, outq)) for t in range(nt)]
+    for pr in procs:
+        pr.start()
+    try:
+        bar.wait(timeout)  # every backend has mapped the segment and run its warm-up pass
+        bar.wait(timeout)  # go
+        t0 = time.perf_counter()
+        res = [outq.get(timeout=timeout) for _ in procs]
+        wall = (time.perf_counter() - t0) * 1e3
+    finally:
+        for pr in procs:
+            pr.join(30)
+            if pr.is_alive():
+                pr.terminate()
+    errors = [r for r in res if r[0] != "ok"]
+    if errors:
+        raise RuntimeError(f"backend processes failed: {errors[:3]}")
+    return wall, {r[1]: r[2] for r in res}

@@ -8,40 +8,12 @@ resumed search launch and one rerank launch (vs_scanpool.cpp).  VERDICT r04: 64 
   python scripts/cursor_pool_concurrency.py --n 1000000 [--rows 1000] [--chunk 16] [--threads 1,8,64]
 """
 import argparse
-import multiprocessing as mp
 import os
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-
-
-def _backend(name, lib_path, t, query, L, rescore, rows_wanted, chunk, bar, outq):
-    try:
-        sys.path.insert(0, ROOT)
-        os.environ["VS_NO_TORCH"] = "1"
-        from pgvectorscale_amd import _lib
-        _lib.LIB_PATH = lib_path
-        import pgvectorscale_amd as P
-        cl = P.ShmClient(name)
-        for rep in range(2):  # (the first pass pays the allocations of the serving process; the second one is timed)
-            sid = 1000 * (rep + 1) + t
-            if rep == 1:
-                bar.wait()  # ready (warm-up pass done)
-                bar.wait()  # go
-            ids, _, _ = cl.search(query, None, L, rescore, chunk)
-            rows = ids.tolist()
-            while len(rows) < rows_wanted:
-                ids, _, _ = cl.fetch(sid, query, len(rows), chunk, None, L, rescore)
-                rows.extend(ids.tolist())
-                if len(ids) < chunk:
-                    break
-            cl.end_scan(sid)
-        cl.close()
-        outq.put(("ok", t, rows))
-    except Exception as e:  # noqa: BLE001
-        outq.put(("error", t, repr(e)))
 
 
 def main():
@@ -61,6 +33,7 @@ def main():
     if os.environ.get("VS_EMU"):  # (dry run of the control flow on the interpreter)
         _lib.LIB_PATH = os.path.join(ROOT, "tests", "emu", "libvsgpu_emu.so")
     from pgvectorscale_amd.datagen import DatagenParams, fill_device, rows_numpy
+    from pgvectorscale_amd.shm_clients import stream_many
 
     ctx = P.Context(0)
     ix = P.DiskAnnIndex.alloc(ctx, n=args.n, dim_full=768, num_neighbors=50, distance_type=P.VS_L2)
@@ -81,25 +54,9 @@ def main():
         srv = P.ShmServer(ix, name, nslots=max(tmax, 4), kmax=args.chunk, max_batch=256, max_wait_us=100, **modes[mode])
         for nt in [int(x) for x in args.threads.split(",")]:
             # the backends are PROCESSES (as under PostgreSQL): threads of this interpreter would take turns on its lock
-            mpc = mp.get_context("spawn")
-            bar = mpc.Barrier(nt + 1)
-            outq = mpc.Queue()
-            procs = [mpc.Process(target=_backend, args=(name, _lib.LIB_PATH, t, q[t], args.L, args.rescore, args.rows, args.chunk, bar, outq))
-                     for t in range(nt)]
-            for pr in procs:
-                pr.start()
             st0 = srv.stats()
-            bar.wait()      # every backend has mapped the segment and warmed its scan path up
-            bar.wait()      # go
-            t0 = time.perf_counter()
-            res = [outq.get(timeout=600) for _ in procs]
-            wall = (time.perf_counter() - t0) * 1e3
-            for pr in procs:
-                pr.join(60)
+            wall, out = stream_many(name, _lib.LIB_PATH, [q[t] for t in range(nt)], args.L, args.rescore, args.rows, args.chunk)
             st1 = srv.stats()
-            errors = [r for r in res if r[0] != "ok"]
-            assert not errors, errors
-            out = {r[1]: r[2] for r in res}
             if ref_rows is None:
                 ref_rows = out[0]
             same = out[0] == ref_rows  # scan 0 returns the same rows whoever runs next to it, however it is served

@@ -47,15 +47,22 @@ def stream_many(name, lib_path, queries, L, rescore, rows, chunk, timeout=600):
     procs = [mpc.Process(target=_backend, args=(name, lib_path, t, queries[t], L, rescore, rows, chunk, bar, outq)) for t in range(nt)]
     for pr in procs:
         pr.start()
+    res = []
     try:
-        bar.wait(timeout)  # every backend has mapped the segment and run its warm-up pass
+        bar.wait(timeout)  # every backend has mapped the segment and run its warm-up passes
         bar.wait(timeout)  # go
         t0 = time.perf_counter()
         res = [outq.get(timeout=timeout) for _ in procs]
         wall = (time.perf_counter() - t0) * 1e3
     finally:
+        try:
+            bar.abort()  # (whoever still waits at the barrier leaves it with an error instead of hanging)
+        except Exception:  # noqa: BLE001
+            pass
+        deadline = time.time() + 20
         for pr in procs:
-            pr.join(30)
+            pr.join(max(0.1, deadline - time.time()))
+        for pr in procs:
             if pr.is_alive():
                 pr.terminate()
     errors = [r for r in res if r[0] != "ok"]

@@ -84,3 +84,27 @@ def test_bench_two_ranks_small():
     assert "graph_build_s" in j["setup_s"] and "graph_broadcast_s" in j["setup_s"]  # rank 0 built, the others received
     assert j["recall_heldout_queries"] == 32  # 16 per rank, pooled
     assert j["value"] > 0 and j["roofline"]["timed_over"].startswith("1 sequential warm-up")
+
+
+def test_bench_extras_small():
+    """DEFAULT CPU tier (about a minute): the three objects the default run adds outside the headline value — `default_gucs` (the
+    reference's default GUCs on the same index), `cursor_pool` (backend PROCESSES streaming through the shared-memory server: a cursor
+    per scan against scan pools, rows compared) and `harder_corpus` (a child run of the script on the `mid` corpus) — assembled by the
+    script's own control flow on the interpreter"""
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "emu"), "-j8", "-s"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    env = dict(os.environ, VS_EMU="1", VS_F_LDS_MAX_INS="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--n", "2000", "--dim", "64", "--nq", "32", "--steps", "1", "--warmup", "1",
+           "--recall-queries", "16", "--validate-queries", "16", "--heldout-queries", "16", "--scan-nq", "0", "--cpu-seconds", "1",
+           "--graph-cache", "none", "--pcie-steps", "0", "--extras", "on", "--fixed", "20,10"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, cwd=ROOT, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    dg, cp, hc = j["default_gucs"], j["cursor_pool"], j["harder_corpus"]
+    assert "error" not in dg and dg["search_list_size"] == 100 and dg["rescore"] == 50 and dg["value"] > 0
+    assert isinstance(dg["recall_target_met"], bool) and set(("achieved", "frac", "avg_kernel_ms")) <= set(dg["roofline"])
+    assert "error" not in cp, cp
+    for mode in ("cursor_per_scan", "scan_pools"):
+        assert cp[mode]["rows_identical_to_cursor_per_scan"] is True and cp[mode]["all_scans_ms"] > 0
+    assert "error" not in hc, hc
+    assert hc["gpu_rows_identical"] is True and isinstance(hc["recall_target_met"], bool) and "mid" in hc["corpus"]

@@ -159,6 +159,11 @@ int vs_ws_probe(vs_ctx* ctx, void* d_mem, size_t bytes, uint32_t iters, float* m
  * private state on the region (tables at its start, heap arrays in its second half): what the library itself uses to choose its slab
  * among VS_WS_SLAB_CANDIDATES allocations (default 8, spread over the free device memory by spacers) at the first search of an index of 4M nodes or more. */
 int vs_ws_probe_mix(vs_index* idx, void* d_mem, size_t bytes, uint32_t iters, float* ms_out);
+/* Chooses the slab NOW instead of inside the first search (after the index's arrays are uploaded / loaded; a no-op for an index that
+ * has its slab, has none by the size rule, or is a view).  The probing holds its candidates and spacers for a fraction of a second:
+ * at most VS_WS_SLAB_PROBE_PCT (default 50) per cent of the device memory that is free at that moment and never the last
+ * VS_WS_SLAB_KEEP_FREE_MB (default 12 GiB) — a host that shares the device calls this at index load, when nobody else allocates. */
+int vs_index_prepare_workspace(vs_index* idx);
 int vs_index_get_desc(const vs_index* idx, vs_index_desc* out);
 enum vs_array { VS_ARR_CODES = 0, VS_ARR_NBRS = 1, VS_ARR_TIDS = 2, VS_ARR_VECS = 3, VS_ARR_MEAN = 4, VS_ARR_M2 = 5,
                 VS_ARR_VNORM = 6, VS_ARR_LABEL_OFF = 7, VS_ARR_LABEL_VAL = 8 };
@@ -572,6 +577,9 @@ int vs_shm_server_create(vs_index* idx, const char* name, uint32_t nslots /* sca
                          uint32_t kmax /* rows per scan at most */, const vs_broker_config* cfg /* NULL = defaults */,
                          vs_shm_server** out);
 int vs_shm_server_get_stats(vs_shm_server* s, vs_broker_stats* out);
+/* the scan pools of a server (cfg->cursor_pool != 0): out[0] = pools alive, out[1] = shared fetch rounds so far, out[2] = pools re-keyed
+ * at the cap of four (an empty pool gives way to a new (search_list_size, rescore, snapshot) combination), out[3] = scans living in pools */
+int vs_shm_server_pool_stats(vs_shm_server* s, uint64_t out[4]);
 void vs_shm_server_destroy(vs_shm_server* s); /* fails what is still posted, unlinks the segment */
 int vs_shm_client_open(const char* name, vs_shm_client** out);
 uint32_t vs_shm_client_dim(const vs_shm_client* c); /* dim_full of the index behind the segment */

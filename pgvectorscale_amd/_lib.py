@@ -146,6 +146,7 @@ SYMBOLS = {
     "vs_index_set_slab": (_i, [_vp, _vp, C.c_size_t]),
     "vs_ws_probe": (_i, [_vp, _vp, C.c_size_t, C.c_uint32, C.POINTER(C.c_float)]),
     "vs_ws_probe_mix": (_i, [_vp, _vp, C.c_size_t, C.c_uint32, C.POINTER(C.c_float)]),
+    "vs_index_prepare_workspace": (_i, [_vp]),
     "vs_index_get_desc": (_i, [_vp, C.POINTER(IndexDesc)]),
     "vs_index_array": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_u32)]),
     "vs_index_set_quantizer": (_i, [_vp, _vp, _vp, _u64]),
@@ -225,6 +226,7 @@ SYMBOLS = {
     "vs_shm_client_end_scan": (_i, [_vp, C.c_uint64]),
     "vs_shm_server_create": (_i, [_vp, C.c_char_p, _u32, _u32, C.POINTER(BrokerConfig), C.POINTER(_vp)]),
     "vs_shm_server_get_stats": (_i, [_vp, C.POINTER(BrokerStats)]),
+    "vs_shm_server_pool_stats": (_i, [_vp, C.POINTER(C.c_uint64)]),
     "vs_shm_server_destroy": (None, [_vp]),
     "vs_shm_server_snapshot_put": (_i, [_vp, _u32, _vp]),
     "vs_shm_client_search_snapshot": (_i, [_vp, _vp, _vp, _u32, _i, _u32, _u32, _u32, _u32, _vp, _vp, _vp]),

@@ -254,7 +254,7 @@ static size_t slab_bytes_wanted(const vs_index* ix) {
 // each); the best pair is kept, the other candidates go back to the device.
 static void slab_select(vs_index* ix, WsSlab* s, size_t slab_bytes) {
     s->tried = true;
-    const uint32_t ncand = std::max<uint32_t>(1, std::min<uint32_t>(env_u32("VS_WS_SLAB_CANDIDATES", 8), 8));
+    uint32_t ncand = std::max<uint32_t>(1, std::min<uint32_t>(env_u32("VS_WS_SLAB_CANDIDATES", 8), 8));
     const size_t half = slab_bytes / 2 / 65536 * 65536;
     void* cand[8] = {nullptr};
     void* spacer[8] = {nullptr};
@@ -267,9 +267,17 @@ static void slab_select(vs_index* ix, WsSlab* s, size_t slab_bytes) {
     if (probe) {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            // Transient footprint (advisor, round 5): candidates and spacers are all held at once for the ~0.3 s of the probes, while
+            // other users of the device (other processes, torch, other indexes, scan pools allocating at the same moment) may want
+            // memory too.  So the whole transient set stays within VS_WS_SLAB_PROBE_PCT (default 50) per cent of what is free NOW and
+            // never touches the last VS_WS_SLAB_KEEP_FREE_MB; a host that wants the probing at a moment of its own choosing calls
+            // vs_index_prepare_workspace() after loading the index.
             const size_t keep = (size_t)env_u32("VS_WS_SLAB_KEEP_FREE_MB", 12288) << 20;  // what the probing never touches
-            const size_t need = (size_t)ncand * slab_bytes + keep;
-            if (free_b > need) sp = std::min<size_t>((free_b - need) / ncand, (size_t)env_u32("VS_WS_SLAB_SPACER_MB", 16384) << 20);
+            const size_t pct = std::min<uint32_t>(env_u32("VS_WS_SLAB_PROBE_PCT", 50), 100);
+            const size_t budget = std::min<size_t>(free_b / 100 * pct, free_b > keep ? free_b - keep : 0);
+            if (slab_bytes && budget / slab_bytes < ncand) ncand = (uint32_t)std::max<size_t>(1, budget / slab_bytes);  // (fewer candidates on a full device)
+            const size_t need = (size_t)ncand * slab_bytes;
+            if (budget > need && ncand > 1) sp = std::min<size_t>((budget - need) / (ncand - 1), (size_t)env_u32("VS_WS_SLAB_SPACER_MB", 16384) << 20);
             sp = sp / ((size_t)2 << 20) * ((size_t)2 << 20);
         } else {
             (void)hipGetLastError();
@@ -334,6 +342,18 @@ static void slab_select(vs_index* ix, WsSlab* s, size_t slab_bytes) {
         }
         fprintf(stderr, "\n");
     }
+}
+extern "C" int vs_index_prepare_workspace(vs_index* ix) {
+    return vs_guard("vs_index_prepare_workspace", [&]() -> int {
+        VS_REQUIRE(ix != nullptr, "vs_index_prepare_workspace: index is NULL");
+        WsSlab* s = ix->slab;
+        const size_t slab_bytes = s ? slab_bytes_wanted(ix) : 0;
+        if (!slab_bytes || ix->is_view) return VS_OK;
+        VS_HIP(hipSetDevice(ix->ctx->device));
+        std::lock_guard<std::mutex> lk(s->mu);
+        if (!s->base[0] && !s->tried && !s->external) slab_select(ix, s, slab_bytes);
+        return VS_OK;
+    });
 }
 int devbuf_reserve_hot(vs_index* ix, DevBuf& b, size_t bytes, int which) {
     if (bytes <= b.bytes) return VS_OK;

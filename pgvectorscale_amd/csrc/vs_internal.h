@@ -305,7 +305,7 @@ struct FastLaunch {
     uint64_t* timeline = nullptr;  // optional [nq][2] start / end of every scan in 100 MHz ticks (VS_TIMELINE=1, diagnostics only)
 };
 enum {
-    FAST_PLAIN_ROW_LOADS = 1,  // code rows through the normal cache policy instead of non-temporal loads
+    // (1 was FAST_PLAIN_ROW_LOADS until round 5: code rows through the normal cache policy; the loads are non-temporal at compile time now)
     FAST_FULL_VARIANT = 8,     // run the instantiation that handles label keys and a visibility mask even when the batch has neither
 };
 size_t fast_lds_bytes(const vs_index* idx, const FastLaunch& s);

@@ -654,7 +654,8 @@ struct Visited {
 
 // QL: the query code is read from its LDS copy (8 NCH words, zero padded) instead of 4 NCH registers per lane — the variant that
 // has to fit 64 VGPRs (8 waves per SIMD)
-template <int NCH, bool QL = false>
+// XW: the rows are exactly 8 NCH words wide (no lane ever reads past a row: the width tests fall away)
+template <int NCH, bool QL = false, bool XW = false>
 __device__ __forceinline__ uint32_t ham_row_reg(const uint64_t* __restrict__ row, const ulonglong2 (&qv)[NCH > 0 ? NCH : 1],
                                                 const uint64_t* qc_l, int l4, uint32_t code_stride, bool active, bool stream) {
     uint32_t acc = 0;
@@ -664,7 +665,7 @@ __device__ __forceinline__ uint32_t ham_row_reg(const uint64_t* __restrict__ row
 #pragma unroll
             for (int t = 0; t < NCH; ++t) {
                 const uint32_t w = 2u * (uint32_t)l4 + 8u * (uint32_t)t;
-                r[t] = w >= code_stride ? make_ulonglong2(0, 0)
+                r[t] = (!XW && w >= code_stride) ? make_ulonglong2(0, 0)
                        : stream ? load_stream16(row + w) : *reinterpret_cast<const ulonglong2*>(row + w);
             }
 #pragma unroll
@@ -721,8 +722,15 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 // the launch has one workgroup per scan, the workgroup's index when the grid is persistent (s.persist: as many workgroups as the
 // chip holds at once, each taking scan after scan from a counter — the regions are then reused by the scans a workgroup runs, the
 // workspace is a few hundred MB whatever the batch size, and no region is claimed with an atomic).
-template <int NCH, int VR, bool TIMING, int MINW, bool BUILD, bool FULL, int VG>
+// OPT: what the launch wrapper knows about the index and states at compile time (round 6: every one of these was a branch, a live
+// scalar register or an exec-mask region in a kernel that spilled 226 of them): OPT_XW = code rows are exactly 8 NCH words,
+// OPT_R1 = num_neighbors <= 64, i.e. a neighbor list is ONE wave-wide chunk.
+#define OPT_XW 1
+#define OPT_R1 2
+template <int NCH, int VR, bool TIMING, int MINW, bool BUILD, bool FULL, int VG, int OPT>
 __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, const uint32_t slot) {
+    constexpr bool XW = (OPT & OPT_XW) != 0 && NCH > 0;
+    constexpr bool R1 = (OPT & OPT_R1) != 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int lane_v = threadIdx.x;
     // (persistent grid: what a scan derives from its lane index is derived again by the next scan instead of being carried
@@ -737,22 +745,24 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
     if (onlyfv && s.status[q] == 0) return;  // (wave-uniform) finished by the first launch
     if (s.timeline && lane == 0) s.timeline[2 * (size_t)q] = wall_clock64();
 
-    // ---- LDS carve ----
-    uint32_t* hp = reinterpret_cast<uint32_t*>(smem);                 // hl + 1 (hl + 1 is a power of two >= 64)
-    uint32_t* lhash = hp + (s.hl + 1);                                // lh (multiple of 4)
+    // ---- LDS carve ----  Everything of a size known at compile time comes first, so its addresses are immediates of the ds
+    // instructions instead of scalar registers (round 6); the arrays sized by the launch follow.
     // LEAN (the 7-waves-per-SIMD variant of the 16-bit tables: 28 scans per CU need <= 5 632 B of LDS each): a survivor's distance is
     // merged into its slot word instead of an array of its own, and the plain instantiation has no room for label keys it never reads
     constexpr bool LEAN = MINW == 7 && VG == 3;
-    uint32_t* surv_id = lhash + lhv;                                 // 64
+    constexpr bool QL = NCH > 0 && MINW >= 6;
+    uint32_t* surv_id = reinterpret_cast<uint32_t*>(smem);            // 64
     uint32_t* surv_slot = surv_id + 64;                               // 64
     uint32_t* surv_d = LEAN ? surv_slot : surv_slot + 64;             // 64 (LEAN: the same words)
     uint32_t* arb = surv_d + 64;                                      // ARB_SLOTS rank counters of the global dedup table (zero between uses; none with the slot bitmap)
     constexpr uint32_t ARB_N = VG >= 2 ? 0u : (uint32_t)ARB_SLOTS;
-    uint64_t* ring = reinterpret_cast<uint64_t*>(arb + ARB_N);        // vcap entries (VR == 0 only)
-    int16_t* ql = reinterpret_cast<int16_t*>(ring + (VR > 0 ? 0 : s.vcap));  // MAX_QLABELS
-    uint64_t* qc_l = reinterpret_cast<uint64_t*>(ql + (LEAN && !FULL ? 0 : MAX_QLABELS));   // code_stride words (NCH == 0 only)
+    uint64_t* qc_fix = reinterpret_cast<uint64_t*>(arb + ARB_N);      // 8 NCH words (QL: the register-capped variants' copy of the query code; 16-byte aligned)
+    int16_t* ql = reinterpret_cast<int16_t*>(qc_fix + (QL ? 8 * NCH : 0));  // MAX_QLABELS
+    uint32_t* hp = reinterpret_cast<uint32_t*>(ql + (LEAN && !FULL ? 0 : MAX_QLABELS));  // hl + 1 (hl + 1 is a power of two >= 64; 8-byte aligned)
+    uint32_t* lhash = hp + (s.hl + 1);                                // lh (multiple of 4)
+    uint64_t* ring = reinterpret_cast<uint64_t*>(lhash + lhv);        // vcap entries (VR == 0 only)
     // (optional) cache of ids known to be in the dedup table: a hit answers a duplicate probe without touching the table in HBM
-    uint32_t* rc = reinterpret_cast<uint32_t*>(qc_l + (NCH == 0 ? ((a.code_stride + 1u) & ~1u) : (NCH > 0 && MINW >= 6 ? 8u * (uint32_t)NCH : 0u)));
+    uint32_t* rc = reinterpret_cast<uint32_t*>(ring + (VR > 0 ? 0 : s.vcap));
     const uint32_t rcm = rcv - 1u;  // (rcv: 0 or a power of two)
     // (VG == 1) one bit per bucket of the dedup table in HBM: set once this scan has written the bucket.  A bucket whose bit is clear is
     // neither cleared nor read — its memory holds whatever an earlier scan left there — and counts as four empty slots.
@@ -761,12 +771,15 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
     // is 1 - load factor), the others are compared with the occupied run that starts at their home slot (one 16-byte load per
     // 4-slot group the run touches), a free slot is claimed with one ds_or; no clears, no rank counters
     uint32_t* vmap = rc + rcv;  // s.vwords
+    // the generic width's copy of the query code (code_stride words) is the one array of a size only the launch knows that wants 16 bytes
+    uint64_t* qc_l = QL ? qc_fix : reinterpret_cast<uint64_t*>(smem + ((((vmap + s.vwords) - reinterpret_cast<uint32_t*>(smem)) * 4u + 15u) & ~15u));
 
     const int l4 = lane & 3;
-    const bool stream_rows = !(s.flags & FAST_PLAIN_ROW_LOADS);
+    // code rows are read once per scan: non-temporal loads, worth 10 % at 50M (profiles/r04/s5_ab_nt_rows_50m.txt).  A compile-time
+    // constant since round 6: as a launch flag every row load was two instructions behind a branch.
+    constexpr bool stream_rows = true;
     // (neighbor rows, the neighbors' label masks and heap tids are read once per scan too and go through non-temporal loads as well:
     // measured neutral at 50M — 159.94 against 159.93 ms, profiles/r04/s5_ab_nt_rows_50m.txt — where the code rows' are worth 10 %)
-    constexpr bool QL = NCH > 0 && MINW >= 6;
     constexpr bool G2 = NCH == 3 && VR == 0 && MINW == 5 && !BUILD && !TIMING;  // two code rows per 4-lane group in flight
     ulonglong2 qv[NCH > 0 ? NCH : 1];
     if (QL) {
@@ -1234,7 +1247,7 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
             slot = rfl(slot);
             st_reads++;
             const uint32_t d =
-                rfl(ham_row_reg<NCH, QL>(a.codes + (size_t)sn * a.code_stride, qv, qc_l, l4, a.code_stride, lane < 4, stream_rows));
+                rfl(ham_row_reg<NCH, QL, XW>(a.codes + (size_t)sn * a.code_stride, qv, qc_l, l4, a.code_stride, lane < 4, stream_rows));
             st_dq++;
             st_cand++;
             if (heap.len + 1 > s.hcap) { status |= OVF_HEAP; break; }
@@ -1383,7 +1396,7 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
         uint32_t best_node = VS_INVALID_NODE;
         bool pfa_issued = false, pfb_issued = false, vis_done = false;
         bool list_ended = false;
-        for (uint32_t c0 = 0; c0 < a.R && !list_ended; c0 += WAVE) {
+        for (uint32_t c0 = 0; c0 < (R1 ? 1u : a.R) && !list_ended; c0 += WAVE) {
             const uint32_t slotidx = c0 + lane;
             const uint32_t nid = c0 == 0 ? row0 : ((slotidx < a.R) ? load_stream32(nrow + slotidx) : VS_INVALID_NODE);
             // list ends at the first InvalidBlockNumber (AM/sbq/node.rs:260-285)
@@ -1509,7 +1522,7 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
                     if (valid2 && l4 == 0) surv_d[j2] = LEAN ? ((d2 << s.sb) | surv_slot[j2]) : d2;
                     continue;
                 }
-                const uint32_t d = ham_row_reg<NCH, QL>(crow, qv, qc_l, l4, a.code_stride, valid, stream_rows);
+                const uint32_t d = ham_row_reg<NCH, QL, XW>(crow, qv, qc_l, l4, a.code_stride, valid, stream_rows);
                 if (valid && l4 == 0) surv_d[j] = LEAN ? ((d << s.sb) | surv_slot[j]) : d;
             }
             st_dq += c;
@@ -1529,7 +1542,7 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
                     best_node = rfl(surv_id[__builtin_ctzll(__ballot(entry == m))]);  // entry lane = survivor rank
                 }
             }
-            if ((list_ended || c0 + WAVE >= a.R) && !pfb_issued) {
+            if ((R1 || list_ended || c0 + WAVE >= a.R) && !pfb_issued) {
                 pfb_issued = true;
                 pfb_node = VS_INVALID_NODE;
                 pfb_h = 0xFFFFFFFFu;
@@ -1600,10 +1613,10 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
     }
 }
 
-template <int NCH, int VR, bool TIMING, int MINW, bool BUILD, bool FULL = true, int VG = 0>
+template <int NCH, int VR, bool TIMING, int MINW, bool BUILD, bool FULL = true, int VG = 0, int OPT = 0>
 __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
     if (!a.s.persist) {
-        if (blockIdx.x < a.s.nq) fast_scan<NCH, VR, TIMING, MINW, BUILD, FULL, VG>(a, blockIdx.x, blockIdx.x);
+        if (blockIdx.x < a.s.nq) fast_scan<NCH, VR, TIMING, MINW, BUILD, FULL, VG, OPT>(a, blockIdx.x, blockIdx.x);
         return;
     }
     // persistent grid: the launch has no tail of its own beyond the last scans' lives, and the hardware never has to place a
@@ -1613,7 +1626,7 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
         if (threadIdx.x == 0) q = atomicAdd(a.s.scan_counter, 1u);
         q = rfl(q);
         if (q >= a.s.nq) return;
-        fast_scan<NCH, VR, TIMING, MINW, BUILD, FULL, VG>(a, q, blockIdx.x);
+        fast_scan<NCH, VR, TIMING, MINW, BUILD, FULL, VG, OPT>(a, q, blockIdx.x);
         wave_sync();  // the next scan re-initialises the LDS state: every lane is done with this one's
     }
 }
@@ -1629,23 +1642,23 @@ size_t fast_lds_bytes(const vs_index* idx, const FastLaunch& s) {
     return (b + 15) / 16 * 16;
 }
 
-template <int NCH, int VR, bool TIMING, int MINW, bool BUILD, bool FULL = true, int VG = 0>
+template <int NCH, int VR, bool TIMING, int MINW, bool BUILD, bool FULL = true, int VG = 0, int OPT = 0>
 static int launch_fast_tt(vs_index* idx, const FastArgs& a, size_t lds, uint32_t* resident) {
     static DeviceOnce attr_set;
     const int attr_dev = idx->ctx->device;
     if (attr_set.pending(attr_dev)) {
-        VS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_search_fast<NCH, VR, TIMING, MINW, BUILD, FULL, VG>),
+        VS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_search_fast<NCH, VR, TIMING, MINW, BUILD, FULL, VG, OPT>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set.done(attr_dev);
     }
     if (resident) {  // not a launch: how many scans (= single-wave workgroups) of this instantiation does the device hold at once?
         int per_cu = 0;
-        VS_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_search_fast<NCH, VR, TIMING, MINW, BUILD, FULL, VG>, WAVE, lds));
+        VS_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_search_fast<NCH, VR, TIMING, MINW, BUILD, FULL, VG, OPT>, WAVE, lds));
         *resident = (uint32_t)std::max(per_cu, 1) * (uint32_t)idx->ctx->prop.multiProcessorCount;
         return VS_OK;
     }
     const uint32_t grid = a.s.persist ? std::min<uint32_t>(a.s.persist, a.s.nq) : a.s.nq;
-    hipLaunchKernelGGL((k_search_fast<NCH, VR, TIMING, MINW, BUILD, FULL, VG>), dim3(grid), dim3(WAVE), lds, idx->ctx->stream, a);
+    hipLaunchKernelGGL((k_search_fast<NCH, VR, TIMING, MINW, BUILD, FULL, VG, OPT>), dim3(grid), dim3(WAVE), lds, idx->ctx->stream, a);
     VS_HIP(hipGetLastError());
     return VS_OK;
 }
@@ -1668,6 +1681,10 @@ static int launch_fast_t(vs_index* idx, const FastArgs& a, size_t lds, uint32_t*
                        a.s.gregion >= (a.s.gcap >> 1) + a.s.ocap,
                    "fast search: bad geometry of the 16-bit dedup table");
         const bool plain = !a.s.qlabel_off && !a.s.visible && !(a.s.flags & FAST_FULL_VARIANT);
+        // (the usual index: 24-word code rows — 768 x 2 bit, 1536 x 1 bit — and num_neighbors <= 64)
+        const bool std_geom = a.code_stride == 24 && a.R <= WAVE;
+        if (NCH == 3 && a.s.minw == 6 && plain && std_geom) return launch_fast_tt<3, 0, false, 6, false, false, 3, OPT_XW | OPT_R1>(idx, a, lds, res);
+        if (NCH == 3 && a.s.minw == 6 && std_geom) return launch_fast_tt<3, 0, false, 6, false, true, 3, OPT_XW | OPT_R1>(idx, a, lds, res);
         if (NCH == 3 && a.s.minw == 6 && plain) return launch_fast_tt<3, 0, false, 6, false, false, 3>(idx, a, lds, res);
         if (NCH == 3 && a.s.minw == 6) return launch_fast_tt<3, 0, false, 6, false, true, 3>(idx, a, lds, res);
         if (NCH == 3 && a.s.minw == 7 && plain) return launch_fast_tt<3, 0, false, 7, false, false, 3>(idx, a, lds, res);

@@ -200,6 +200,7 @@ struct vs_shm_server {
     struct PoolCursor {
         int32_t pid = 0;
         uint64_t scan_id = 0, sig = 0, last_use = 0;
+        uint64_t round = 0;  // the dispatcher round that last put a request of this scan on its list (never evicted within that round)
         uint32_t pos = 0;  // rows handed out so far
         bool used = false;
     };
@@ -208,8 +209,11 @@ struct vs_shm_server {
         uint32_t L = 0, rescore = 0, snapshot = 0;
         std::vector<PoolCursor> cur;  // by pool slot
         uint64_t use_clock = 0;
+        uint64_t last_round = 0;  // the last dispatcher round that served a request out of this pool
     };
     std::vector<Pool> pools;
+    uint64_t pool_round_no = 0;
+    static constexpr size_t MAX_POOLS = 4;
     std::atomic<uint64_t> pool_rounds{0};
     void run_fetch_pooled(const std::vector<uint32_t>& slots);
     void reap_pools();
@@ -217,7 +221,7 @@ struct vs_shm_server {
     std::vector<std::unique_ptr<Lane>> lanes;
     std::shared_mutex snap_mu;        // lanes: shared for the length of a request; a mask is replaced exclusively
     std::atomic<int> put_waiting{0};  // ... and lanes do not start a request while one waits (readers would starve the writer)
-    std::atomic<uint64_t> fetches{0}, cursor_opens{0}, open_cursors{0};
+    std::atomic<uint64_t> fetches{0}, cursor_opens{0}, open_cursors{0}, pools_retired{0}, pools_alive{0}, pooled_scans{0};
     void apply_puts();
     void run();
     void run_lane(Lane& ln);
@@ -463,6 +467,10 @@ void vs_shm_server::run_fetch_pooled(const std::vector<uint32_t>& slots) {
     struct Item { uint32_t slot, pool, pslot; };
     std::vector<Item> items, ff;  // requests to serve / new scans to fast-forward first
     std::vector<uint32_t> single;  // requests for the single-cursor path
+    const uint64_t round_no = ++pool_round_no;
+    // host allocations below (the lists of a round) must not take the dispatcher thread down: whatever has not been answered when
+    // memory runs out is answered with VS_ERR_OOM (a slot is in flight from take() until finish())
+    try {
     auto in_main_tab = [&](const Req& r) {
         for (const Cursor& c : main_tab.cursors)
             if (c.pid == r.owner_pid && c.scan_id == r.scan_id) return true;
@@ -489,6 +497,7 @@ void vs_shm_server::run_fetch_pooled(const std::vector<uint32_t>& slots) {
                 (void)vs_scanpool_endscan(pools[pi].h, (uint32_t)ci);
                 pools[pi].cur[ci] = PoolCursor{};
                 open_cursors--;
+                pooled_scans--;  // (before the client is answered: it may read the counters right away)
                 SlotHead* out = m.slot(slot);
                 out->n_rows = 0;
                 out->rc = VS_OK;
@@ -512,7 +521,33 @@ void vs_shm_server::run_fetch_pooled(const std::vector<uint32_t>& slots) {
         if (pi < 0) {
             for (size_t a = 0; a < pools.size(); ++a)
                 if (pools[a].L == r.L && pools[a].rescore == r.rescore && pools[a].snapshot == r.snapshot) pi = (int)a;
-            if (pi < 0 && pools.size() < 4) {
+            if (pi < 0 && pools.size() >= MAX_POOLS) {
+                // at the cap: the pool that has served nothing for the longest time AND holds no live scan is re-keyed in place (its
+                // index stays valid for the lists of this round: a pool without live scans is on none of them).  Snapshot ids come and
+                // go in a PostgreSQL deployment — without this the fifth (L, rescore, snapshot) would fall back to single cursors for good.
+                int victim = -1;
+                for (size_t a = 0; a < pools.size(); ++a) {
+                    bool live = false;
+                    for (const PoolCursor& c : pools[a].cur) live = live || c.used;
+                    if (!live && pools[a].last_round != round_no && (victim < 0 || pools[a].last_round < pools[victim].last_round)) victim = (int)a;
+                }
+                if (victim >= 0) {
+                    Pool& vp = pools[victim];
+                    vs_scan_pool* nh = nullptr;
+                    if (vs_scanpool_create(ix, cfg.cursor_pool, r.L, r.rescore, m.kmax, 0, &nh) == VS_OK) {
+                        vs_scanpool_free(vp.h);
+                        vp.h = nh;
+                        vp.L = r.L;
+                        vp.rescore = r.rescore;
+                        vp.snapshot = r.snapshot;
+                        vp.cur.assign(cfg.cursor_pool, PoolCursor{});
+                        vp.use_clock = 0;
+                        pools_retired++;
+                        pi = victim;
+                    }
+                }
+            }
+            if (pi < 0 && pools.size() < MAX_POOLS) {
                 Pool np;
                 np.L = r.L;
                 np.rescore = r.rescore;
@@ -530,11 +565,18 @@ void vs_shm_server::run_fetch_pooled(const std::vector<uint32_t>& slots) {
             Pool& p = pools[pi];
             for (size_t b = 0; b < p.cur.size() && ci < 0; ++b)
                 if (!p.cur[b].used) ci = (int)b;
-            if (ci < 0) {  // make room: the least recently used scan of the pool goes (its client's next request replays it on a cursor)
-                ci = 0;
-                for (size_t b = 1; b < p.cur.size(); ++b)
-                    if (p.cur[b].last_use < p.cur[ci].last_use) ci = (int)b;
+            if (ci < 0) {
+                // make room: the least recently used scan of the pool goes (its client's next request replays it) — but never a scan
+                // that already has a request on this round's list: two requests would share one pool slot, the second rescan would
+                // overwrite the first scan, and vs_scanpool_fetch would be handed the slot twice
+                for (size_t b = 0; b < p.cur.size(); ++b)
+                    if (p.cur[b].round != round_no && (ci < 0 || p.cur[b].last_use < p.cur[ci].last_use)) ci = (int)b;
+                if (ci < 0) {  // every slot is spoken for in this round: a cursor of its own
+                    single.push_back(slot);
+                    continue;
+                }
                 (void)vs_scanpool_endscan(p.h, (uint32_t)ci);
+                p.cur[ci] = PoolCursor{};
                 open_cursors--;
             }
             const int rc = vs_scanpool_rescan(p.h, (uint32_t)ci, r.null_query ? nullptr : r.query.data(), r.labels, r.n_labels, (int)r.has_label_key);
@@ -557,6 +599,8 @@ void vs_shm_server::run_fetch_pooled(const std::vector<uint32_t>& slots) {
             if (r.skip > 0) ff.push_back(Item{slot, (uint32_t)pi, (uint32_t)ci});
         }
         pools[pi].cur[ci].last_use = ++pools[pi].use_clock;
+        pools[pi].cur[ci].round = round_no;
+        pools[pi].last_round = round_no;
         items.push_back(Item{slot, (uint32_t)pi, (uint32_t)ci});
     }
     // fast-forward of the scans that start in this round: shared fetches whose rows are thrown away, rounds of at most kmax rows
@@ -573,7 +617,8 @@ void vs_shm_server::run_fetch_pooled(const std::vector<uint32_t>& slots) {
                     grp.push_back(b);
                 }
             const uint8_t* prev = nullptr;
-            bool ok = vs_index_snapshot_use(ix, p.snapshot, &prev) == VS_OK;
+            const bool snap_set = vs_index_snapshot_use(ix, p.snapshot, &prev) == VS_OK;
+            bool ok = snap_set;
             std::vector<uint32_t> live;  // pool slots still being forwarded
             for (size_t g : grp) live.push_back(ff[g].pslot);
             uint32_t left = skip;
@@ -591,7 +636,7 @@ void vs_shm_server::run_fetch_pooled(const std::vector<uint32_t>& slots) {
                 live.swap(next);
                 left -= kk;
             }
-            if (ok) (void)vs_index_set_visibility_dev(ix, prev);
+            if (snap_set) (void)vs_index_set_visibility_dev(ix, prev);  // (also after a failed fetch: the index-level mask is left as it was)
             for (size_t g : grp) {
                 PoolCursor& c = p.cur[ff[g].pslot];
                 if (!ok) c.pos = 0xFFFFFFFFu;  // (marks "could not be forwarded": a cursor of its own)
@@ -688,6 +733,22 @@ void vs_shm_server::run_fetch_pooled(const std::vector<uint32_t>& slots) {
         }
     }
     for (uint32_t slot : single) run_fetch(slot, main_tab);
+    uint64_t live_scans = 0;
+    for (const Pool& p : pools)
+        for (const PoolCursor& c : p.cur) live_scans += c.used ? 1 : 0;
+    pools_alive.store(pools.size());
+    pooled_scans.store(live_scans);
+    } catch (const std::bad_alloc&) {
+        for (uint32_t slot : slots) {
+            if (!in_flight[slot].load(std::memory_order_acquire)) continue;
+            SlotHead* out = m.slot(slot);
+            out->n_rows = 0;
+            out->rc = VS_ERR_OOM;
+            snprintf(out->err, sizeof(out->err), "vs_shm: out of host memory while serving pooled scan cursors");
+            fetches++;
+            finish(slot);
+        }
+    }
 }
 
 void vs_shm_server::apply_puts() {
@@ -988,6 +1049,19 @@ int vs_shm_server_get_stats(vs_shm_server* s, vs_broker_stats* out) {
     out->max_batch = s->max_batch.load();
     out->tasks = s->fetches.load();
     out->cursors = s->open_cursors.load();
+    return VS_OK;
+}
+
+// (read by the caller's thread while the dispatcher works: the counters are atomics, the pool list is only sized)
+int vs_shm_server_pool_stats(vs_shm_server* s, uint64_t out[4]) {
+    if (!s || !out) {
+        vs_set_error("vs_shm_server_pool_stats: null argument");
+        return VS_ERR_INVALID;
+    }
+    out[0] = s->pools_alive.load();
+    out[1] = s->pool_rounds.load();
+    out[2] = s->pools_retired.load();
+    out[3] = s->pooled_scans.load();
     return VS_OK;
 }
 

@@ -120,6 +120,10 @@ class DiskAnnIndex:
         """the caller's device memory as this handle's workspace slab (vs_index_set_slab; before its first search)"""
         check(self._L.vs_index_set_slab(self.h, d_mem, nbytes))
 
+    def prepare_workspace(self):
+        """chooses the workspace slab now instead of inside the first search (vs_index_prepare_workspace)"""
+        check(self._L.vs_index_prepare_workspace(self.h))
+
     # -- construction ---------------------------------------------------------------------------------------------
     @classmethod
     def upload(cls, ctx, *, codes, nbrs, heap_tids, vecs, mean, m2, count, bits, dim_index, num_neighbors,
@@ -547,6 +551,12 @@ class ShmServer:
         check(self._L.vs_shm_server_get_stats(self.h, C.byref(st)))
         return {"batches": int(st.batches), "scans": int(st.scans), "max_batch": int(st.max_batch), "tasks": int(st.tasks),
                 "cursors": int(st.cursors)}
+
+    def pool_stats(self):
+        """scan pools of the server: pools alive, shared fetch rounds, pools re-keyed at the cap, scans living in pools"""
+        out = (C.c_uint64 * 4)()
+        check(self._L.vs_shm_server_pool_stats(self.h, out))
+        return {"pools": int(out[0]), "rounds": int(out[1]), "retired": int(out[2]), "scans": int(out[3])}
 
     def close(self):
         if self.h:

@@ -577,3 +577,112 @@ def test_a_client_that_rewrites_its_request_after_posting_cannot_move_the_dispat
         os.close(fd)
         srv2.close()
         ix.close()
+
+
+def _pool_pressure_client(name, lib_path, t, q, chunk, nrows, bar, out_q):
+    """a backend that streams ONE scan in lockstep with the others (a barrier before every fetch), so that every dispatcher round
+    sees more streamed scans of one (L, rescore, snapshot) than the pool has slots"""
+    try:
+        from pgvectorscale_amd import _lib
+        if lib_path:
+            _lib.LIB_PATH = lib_path
+        import pgvectorscale_amd as P
+        c = P.ShmClient(name)
+        sid = 7000 + t
+        ids, tids, dist = c.search(q, None, 30, 12, chunk)
+        rows = list(zip(tids.tolist(), ids.tolist(), dist.tolist()))
+        while len(rows) < nrows:
+            try:
+                bar.wait(30)  # (a backend that is done leaves the others waiting: they go on alone after the timeout)
+            except Exception:  # noqa: BLE001
+                pass
+            ids, tids, dist = c.fetch(sid, q, len(rows), chunk, None, 30, 12)
+            rows.extend(zip(tids.tolist(), ids.tolist(), dist.tolist()))
+            if len(ids) < chunk:
+                break
+        c.end_scan(sid)
+        c.close()
+        out_q.put(("ok", t, rows))
+    except Exception as e:  # noqa: BLE001
+        out_q.put(("err", t, repr(e)))
+
+
+@pytest.mark.parametrize("chunks", [(8, 8, 8, 8, 8), (8, 5, 8, 3, 5)], ids=["equal_k", "mixed_k"])
+def test_more_streamed_scans_than_pool_slots_never_share_a_slot(gpu_ctx, oracle, chunks):
+    """Advisor finding of round 5 (vs_shm.cpp run_fetch_pooled): with a pool SMALLER than the streamed scans of one dispatcher round,
+    the LRU eviction could hand the slot of a request already placed in this round to the next one — equal k: `slot listed twice`
+    for the whole group; mixed k: the earlier client silently got the later client's rows.  Five backends in lockstep over a pool of
+    two slots: every backend gets exactly the oracle's rows, whatever is evicted in between."""
+    import pgvectorscale_amd as P
+    from pgvectorscale_amd import _lib
+    ti = TestIndex(**KW)
+    ix = ti.upload(gpu_ctx)
+    nproc = len(chunks)
+    q = ti.queries(nproc, seed=83, kind="gauss")
+    name = f"/vs_shm_pp_{os.getpid()}"
+    srv = P.ShmServer(ix, name, nslots=8, kmax=8, max_batch=64, max_wait_us=20000, cursor_pool=2)
+    ctx = mp.get_context("spawn")
+    bar = ctx.Barrier(nproc)
+    out_q = ctx.Queue()
+    nrows = 40
+    procs = [ctx.Process(target=_pool_pressure_client, args=(name, _lib.LIB_PATH, t, q[t], chunks[t], nrows, bar, out_q)) for t in range(nproc)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in procs:
+        status, t, payload = out_q.get(timeout=600)
+        assert status == "ok", payload
+        got[t] = payload
+    for p in procs:
+        p.join(60)
+    for t in range(nproc):
+        os_ = ti.oracle.scan(q[t], L=30, rescore=12)
+        ref = []
+        while len(ref) < len(got[t]):
+            o = os_.gettuple()
+            if o is None:
+                break
+            ref.append(o)
+        assert len(got[t]) >= nrows and len(ref) == len(got[t]), (t, len(got[t]), len(ref))
+        for j, ((tid, node, d), o) in enumerate(zip(got[t], ref)):
+            assert node == o[0] and tid == o[1], (t, j, chunks)
+            assert np.float32(d).view(np.uint32) == np.float32(o[2]).view(np.uint32), (t, j)
+    ps = srv.pool_stats()
+    assert ps["pools"] == 1 and ps["rounds"] > 0, ps  # the pool really served rounds
+    srv.close()
+    ix.close()
+
+
+def test_scan_pools_are_retired_when_the_combinations_move_on(gpu_ctx, oracle):
+    """Advisor finding of round 5: pools are keyed by (search_list_size, rescore, snapshot) and capped at four; they were never
+    retired, so the fifth combination fell back to single cursors for good.  Seven combinations one after another: every scan
+    streams out of a pool (the pool of a finished combination is re-keyed at the cap) and returns the oracle's rows."""
+    import pgvectorscale_amd as P
+    ti = TestIndex(**KW)
+    ix = ti.upload(gpu_ctx)
+    q = ti.queries(7, seed=85, kind="gauss")
+    name = f"/vs_shm_ret_{os.getpid()}"
+    srv = P.ShmServer(ix, name, nslots=2, kmax=8, max_batch=8, max_wait_us=0, cursor_pool=3)
+    c = P.ShmClient(name)
+    combos = [(20, 5), (24, 6), (28, 7), (32, 8), (36, 9), (40, 10), (20, 5)]
+    rounds_before = 0
+    for i, (L, S) in enumerate(combos):
+        os_ = ti.oracle.scan(q[i], L=L, rescore=S)
+        want = [os_.gettuple() for _ in range(24)]
+        ids, _, _ = c.search(q[i], None, L, S, 8)
+        rows = ids.tolist()
+        while len(rows) < 24:
+            ids, _, _ = c.fetch(500 + i, q[i], len(rows), 8, None, L, S)
+            rows.extend(ids.tolist())
+        assert rows == [o[0] for o in want], (i, L, S)
+        c.end_scan(500 + i)
+        ps = srv.pool_stats()
+        assert ps["rounds"] > rounds_before, (i, ps)  # this combination was served out of a pool, not by a cursor of its own
+        rounds_before = ps["rounds"]
+        assert ps["pools"] <= 4 and ps["scans"] == 0, ps
+    ps = srv.pool_stats()
+    assert ps["retired"] >= 2, ps
+    assert srv.stats()["cursors"] == 0
+    c.close()
+    srv.close()
+    ix.close()

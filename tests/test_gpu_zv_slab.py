@@ -77,3 +77,30 @@ def test_probes_run_on_any_region(gpu_ctx, oracle):
     finally:
         gpu_ctx.free(mem)
         ix.close()
+
+
+def test_prepare_workspace_chooses_the_slab_before_the_first_search(gpu_ctx, oracle, monkeypatch):
+    """vs_index_prepare_workspace (advisor, round 5: the probing's transient allocations at a moment of the host's choosing, bounded to a
+    share of the free memory): the slab exists after the call — the first search allocates no slab of its own — and rows are the oracle's"""
+    ti = cached_index(**KW)
+    monkeypatch.setenv("VS_F_LDS_MAX_INS", "0")
+    monkeypatch.setenv("VS_WS_SLAB_MIN_N", "1")
+    monkeypatch.setenv("VS_WS_SLAB_MB", "128")
+    monkeypatch.setenv("VS_WS_SLAB_CANDIDATES", "3")
+    monkeypatch.setenv("VS_WS_SLAB_PROBE_PCT", "10")
+    ix = ti.upload(gpu_ctx)
+    try:
+        free0, _ = gpu_ctx.mem_info()
+        ix.prepare_workspace()
+        free1, _ = gpu_ctx.mem_info()
+        real = not os.environ.get("VS_EMU")  # (the interpreter's hipMemGetInfo does not move)
+        if real:
+            assert 64 << 20 <= free0 - free1 <= 2 * (128 << 20) + (8 << 20), (free0, free1)  # one slab (or a pair) stays, the other candidates and the spacers went back
+        ix.prepare_workspace()  # a second call is a no-op
+        assert gpu_ctx.mem_info()[0] == free1
+        q = ti.queries(24, seed=6, kind="gauss")
+        _check(ix, ti, q)
+        free2, _ = gpu_ctx.mem_info()
+        assert not real or free1 - free2 < (64 << 20), (free1, free2)  # the search's regions came out of the slab: no second slab-sized allocation
+    finally:
+        ix.close()

@@ -27,6 +27,21 @@ __device__ __forceinline__ ulonglong2 load_stream16(const uint64_t* p) {
 __device__ __forceinline__ uint32_t load_stream32(const uint32_t* p) { return __builtin_nontemporal_load(p); }
 __device__ __forceinline__ uint64_t load_stream64(const uint64_t* p) { return __builtin_nontemporal_load(p); }
 
+// per 16-bit half: min(a, b) (v_pk_min_u16).  Written with the GCC vector extension so that the host build of the test interpreter
+// compiles it too.
+typedef unsigned short vs_u16x2 __attribute__((vector_size(4)));
+__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {
+    vs_u16x2 x, y;
+    __builtin_memcpy(&x, &a, 4);
+    __builtin_memcpy(&y, &b, 4);
+    const vs_u16x2 m = x < y ? x : y;
+    uint32_t r;
+    __builtin_memcpy(&r, &m, 4);
+    return r;
+}
+// a wave-uniform 64-bit lane mask as a per-lane condition (no vector instruction: the mask goes straight into exec)
+__device__ __forceinline__ bool lane_of(uint64_t mask) { return __builtin_amdgcn_inverse_ballot_w64(mask); }
+
 __device__ __forceinline__ uint32_t hash_u32(uint32_t x) {
     x ^= x >> 16;
     x *= 0x7feb352dU;

@@ -258,22 +258,18 @@ struct FastHeap {
         auto anc_of = [&](uint32_t rank, uint32_t base) -> uint32_t {
             return (uint32_t)__builtin_amdgcn_ds_bpermute((int)((base + (p1 >> rank) - (p1f >> rank)) << 2), (int)anc);
         };
-        // deepest rank (<= 5) any element can reach against the ORIGINAL ancestors (values only fall during the run), and the
-        // elements that can get above rank 5 (bit e <-> element e).  (The ancestors are fetched again level by level below:
-        // registers are what this kernel is short of.)
+        // The leaf's original ancestors of ranks 1..6: six cross-lane reads issued back to back and kept in registers for the levels
+        // below (round 6; they used to be fetched once for the test here and again level by level — five more address computations,
+        // five more waits on the LDS crossbar per run).  Deepest rank (<= 5) any element can reach against the ORIGINAL ancestors
+        // (values only fall during the run), and the elements that can get above rank 5 (bit e <-> element e).
+        const uint32_t ak1 = anc_of(1, 0), ak2 = anc_of(2, 17), ak3 = anc_of(3, 26), ak4 = anc_of(4, 31), ak5 = anc_of(5, 34), ak6 = anc_of(6, 36);
         uint32_t K = 0, hm;
         {
-            const uint32_t kc = in ? c >> sb : IDENT;  // (every lane takes part in the fetches: they are cross-lane operations)
-            auto below = [&](uint32_t rank, uint32_t base) -> uint64_t {
-                const uint32_t ak = anc_of(rank, base);
-                return __ballot(kc < (ak >> sb));
-            };
-            if (below(1, 0)) K = 1;
-            if (K == 1 && below(2, 17)) K = 2;
-            if (K == 2 && below(3, 26)) K = 3;
-            if (K == 3 && below(4, 31)) K = 4;
-            if (K == 4 && below(5, 34)) K = 5;
-            hm = K == 5 ? (uint32_t)(below(6, 36) >> off) : 0u;
+            const uint32_t kc = in ? c >> sb : IDENT;
+            const uint64_t b1 = __ballot(kc < (ak1 >> sb)), b2 = __ballot(kc < (ak2 >> sb)), b3 = __ballot(kc < (ak3 >> sb)),
+                           b4 = __ballot(kc < (ak4 >> sb)), b5 = __ballot(kc < (ak5 >> sb)), b6 = __ballot(kc < (ak6 >> sb));
+            K = !b1 ? 0u : !b2 ? 1u : !b3 ? 2u : !b4 ? 3u : !b5 ? 4u : 5u;
+            hm = K == 5 ? (uint32_t)(b6 >> off) : 0u;
         }
         bool forced = false;
         // ---- above rank 5: the elements that can get there, one after another
@@ -315,9 +311,8 @@ struct FastHeap {
             if (__ballot(forced)) K = 5;
         }
         // ---- ranks 5..1, all leaves at once
-        auto level = [&](const uint32_t k, const uint32_t base) {
+        auto level = [&](const uint32_t k, const uint32_t ak) {  // ak: the node's original value
             const uint32_t B1 = (1u << k) - 1u;
-            const uint32_t ak = anc_of(k, base);  // the node's original value
             const uint32_t comp = in ? (((c >> sb) << 7) | (forced ? 63u - i : 65u + i)) : IDENT;
             // exclusive prefix minimum inside the aligned block of 2^k lanes
             uint32_t x = wave_shr1(comp, IDENT);
@@ -359,11 +354,11 @@ struct FastHeap {
                 forced = true;
             }
         };
-        if (K >= 5) level(5, 34);
-        if (K >= 4) level(4, 31);
-        if (K >= 3) level(3, 26);
-        if (K >= 2) level(2, 17);
-        if (K >= 1) level(1, 0);
+        if (K >= 5) level(5, ak5);
+        if (K >= 4) level(4, ak4);
+        if (K >= 3) level(3, ak3);
+        if (K >= 2) level(2, ak2);
+        if (K >= 1) level(1, ak1);
         if (in) put(p1, c);
     }
     // pre_n / pre_anc: a wide load the caller already issued for the first run (pre_n = first_run(c)), or pre_n = 0
@@ -589,6 +584,23 @@ struct Visited {
                 }
             }
             len++;
+            return;
+        }
+        if (len < WAVE) {
+            // the whole list in one wave-wide read (the usual case: search_list_size + the rows not yet consumed stay below 64 for
+            // the operating points of small lists): lane i holds entry i, the entries from the insertion point on move one slot back —
+            // lane j writes slot j with the entry lane j - 1 read (a DPP shift), lane idx the new one.  One LDS read, one write, no loop.
+            const uint32_t x = head + (uint32_t)lane;
+            const uint32_t sl = x >= vcapv ? x - vcapv : x;  // (vcapv >= 64)
+            uint64_t e = ~0ull;
+            if ((uint32_t)lane < len) e = ring[sl];
+            const bool lt = (uint32_t)lane < len && ((uint32_t)(e >> 32) & VIS_HAM_MASK) < hd;
+            const uint32_t idx = (uint32_t)__popcll(__ballot(lt));
+            const uint32_t plo = wave_shr1((uint32_t)e, 0), phi = wave_shr1((uint32_t)(e >> 32), 0);
+            const uint64_t nw = ((uint64_t)(hd | (flags << 30)) << 32) | node;
+            if ((uint32_t)lane >= idx && (uint32_t)lane <= len) ring[sl] = (uint32_t)lane == idx ? nw : (((uint64_t)phi << 32) | plo);
+            len++;
+            wave_sync();
             return;
         }
         uint32_t idx = 0;
@@ -843,7 +855,10 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
     const uint32_t slot_limit = lhv - lhv / 8;  // stop at 87.5 % load: the scan is handed to the general kernel
     const uint32_t smask = (1u << s.sb) - 1u;
     uint32_t emitted = 0, status = wide_key ? (uint32_t)OVF_KEY : 0u, nins = 0, hmax = 0;
-    uint32_t st_visits = 0, st_cand = 0, st_dq = 0, st_reads = 0;
+    // (work counters kept in scalar registers: visits, candidates (= quantized distance computations in this kernel: every candidate is
+    // scored exactly once), and the pops of the visited list; SbqNode reads = pops + visits + ids that entered the dedup set, put
+    // together when the scan ends — round 6: each dropped counter is a register and an add per visit less)
+    uint32_t st_visits = 0, st_cand = 0, st_pops = 0;
     // optional phase clock (s_memtime): 0 pop, 1 row wait, 2 visited, 3 dedup, 4 gather, 5 push, 6 other
     uint64_t ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t tmark = TIMING ? __builtin_readcyclecounter() : 0;
@@ -1126,49 +1141,51 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
         if (!have_pre) {
             wave_sync();
             t = act ? b16_run(x) : 0u;
+            v = make_uint4(0, 0, 0, 0);
             if (t) v = b16_load(x);
         }
         const uint32_t hb = x >> s.qk, r = x & ((1u << s.qk) - 1u), pref = x & 7u;
-        bool fresh = false, pend = act;
-        if (act && t) {  // in the run of the snapshot, or new
-            const uint32_t rr = r | (r << 16);
-            const uint32_t dx = v.x ^ rr, dy = v.y ^ rr, dz = v.z ^ rr, dw = v.w ^ rr;
-            const uint32_t m = ((dx & 0xFFFFu) == 0 ? 1u : 0u) | ((dx >> 16) == 0 ? 2u : 0u) | ((dy & 0xFFFFu) == 0 ? 4u : 0u) |
-                               ((dy >> 16) == 0 ? 8u : 0u) | ((dz & 0xFFFFu) == 0 ? 16u : 0u) | ((dz >> 16) == 0 ? 32u : 0u) |
-                               ((dw & 0xFFFFu) == 0 ? 64u : 0u) | ((dw >> 16) == 0 ? 128u : 0u);
-            uint32_t rm = ((1u << t) - 1u) << pref;
-            rm = (rm | (rm >> 8)) & 0xFFu;
-            const uint32_t hit = m & rm;
-            if (hit) {
-                slot_out = lhv + (hb << 3) + (uint32_t)__builtin_ctz(hit);
-                pend = false;
-            }
-        }
-        bool ovf = false;
-        for (;;) {  // a new id takes the first free slot of its bucket, cyclic from its preferred one
+        // In the run of the snapshot, or new.  Straight-line for every lane (round 6; t == 0 is an empty run mask, a lane without a load
+        // compares zeros): which of the eight entries equal the remainder — per 16-bit half min(entry ^ r, 1) is 0 exactly where they do
+        // (v_pk_min_u16; the constant is kept opaque, or the compiler turns the minimum into eight compares and selects), the halves'
+        // bits are shifted into entry order (entry 2 i: bit 2 i, entry 2 i + 1: bit 16 + 2 i, folded down by 15)
+        const uint32_t rr = r | (r << 16);
+        uint32_t one = 0x00010001u;
+        asm volatile("" : "+v"(one));
+        const uint32_t z = pk_min_u16(v.x ^ rr, one) | (pk_min_u16(v.y ^ rr, one) << 2) | (pk_min_u16(v.z ^ rr, one) << 4) | (pk_min_u16(v.w ^ rr, one) << 6);
+        const uint32_t m = ~(z | (z >> 15)) & 0xFFu;
+        uint32_t rm = ((1u << t) - 1u) << pref;
+        rm = (rm | (rm >> 8)) & 0xFFu;
+        const uint32_t hit = act ? (m & rm) : 0u;
+        if (hit) slot_out = lhv + (hb << 3) + (uint32_t)__builtin_ctz(hit);
+        // A new id takes the first free slot of its bucket, cyclic from its preferred one.  Which lanes are still looking, which found a
+        // slot and which met a full bucket are wave-uniform lane masks kept by hand: as per-lane booleans carried through the loop each
+        // cost three scalar instructions per merge point
+        uint64_t pendm = __ballot(act && hit == 0), freshm = 0, ovfm = 0;
+        while (pendm) {
             wave_sync();
-            if (pend) {
-                const uint32_t occ = b16_occ(hb);
-                const uint32_t t2 = (uint32_t)__builtin_ctz(~(((occ | (occ << 8)) >> pref) & 0xFFu));
-                if (t2 >= 8u) {  // the bucket is full: the overflow table (where the id may also be already)
-                    ovf = true;
-                    pend = false;
-                } else {
-                    const uint32_t idx = (hb << 3) + ((pref + t2) & 7u);
-                    const uint32_t bit = 1u << (idx & 31u);
-                    if ((atomicOr(&vmap[idx >> 5], bit) & bit) == 0) {  // ds_or_rtn_b32: the lane that flips the bit owns the slot
-                        gstore16(reinterpret_cast<uint16_t*>(ghash) + idx, r);
-                        slot_out = lhv + idx;
-                        fresh = true;
-                        pend = false;
-                    }
-                }
+            const uint32_t occ = b16_occ(hb);
+            const uint32_t t2 = (uint32_t)__builtin_ctz(~(((occ | (occ << 8)) >> pref) & 0xFFu));  // (8: the bucket is full)
+            const uint32_t idx = (hb << 3) + ((pref + t2) & 7u);
+            const uint32_t bit = 1u << (idx & 31u);
+            const bool mine = lane_of(pendm);
+            uint32_t old = 0xFFFFFFFFu;
+            if (mine && t2 < 8u) old = atomicOr(&vmap[idx >> 5], bit);  // ds_or_rtn_b32: the lane that flips the bit owns the slot
+            const bool won = (old & bit) == 0;
+            if (won) {
+                gstore16(reinterpret_cast<uint16_t*>(ghash) + idx, r);
+                slot_out = lhv + idx;
             }
+            const uint64_t wonm = __ballot(won), fullm = __ballot(mine && t2 >= 8u);  // full: the overflow table (where the id may also be already)
+            freshm |= wonm;
+            ovfm |= fullm;
+            pendm &= ~(wonm | fullm);
             wave_sync();
-            if (!__ballot(pend)) break;
         }
-        if (__ballot(ovf)) fresh = ovf_insert(nid, ovf, slot_out) || fresh;
-        nins_g += (uint32_t)__popcll(__ballot(fresh));
+        bool fresh = lane_of(freshm);
+        const uint32_t ov0 = n_ovf;
+        if (ovfm) fresh = ovf_insert(nid, lane_of(ovfm), slot_out) || fresh;
+        nins_g += (uint32_t)__popcll(freshm) + (n_ovf - ov0);
         return fresh;
     };
     auto open_table = [&]() -> bool {  // first use: this wave claims and clears its own table
@@ -1245,10 +1262,8 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
             }
             if (!rfl(fr ? 1u : 0u)) continue;
             slot = rfl(slot);
-            st_reads++;
             const uint32_t d =
                 rfl(ham_row_reg<NCH, QL, XW>(a.codes + (size_t)sn * a.code_stride, qv, qc_l, l4, a.code_stride, lane < 4, stream_rows));
-            st_dq++;
             st_cand++;
             if (heap.len + 1 > s.hcap) { status |= OVF_HEAP; break; }
             heap.push((d << s.sb) | slot);
@@ -1302,7 +1317,7 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
             if (vis.len == 0) break;  // None: the stream has ended
             uint32_t fd, fnode, fflags;
             vis.pop_front(fd, fnode, fflags);
-            st_reads++;
+            st_pops++;
             if (VR > 0) {
                 const uint64_t tid = fnode == ft_node ? ft_val : load_stream64(a.tids + fnode);
                 fflags = (tid & 0xFFFFull) == 0 ? VIS_DEAD : 0u;
@@ -1382,9 +1397,8 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
             if (BUILD) vis.len = vis.capacity() - 1;  // build mode keeps the closest entries as prune candidates
             else { status |= OVF_VISITED; break; }
         }
-        st_visits++;
+        st_visits++;  // (also one SbqNode::read(visiting))
         // ---- visit_lsn_internal, Disk arm (AM/sbq/storage.rs:135-190) ----
-        st_reads++;  // SbqNode::read(visiting)
         uint32_t root_after = 0xFFFFFFFFu;
         uint32_t root_node_v = VS_INVALID_NODE;  // id of the new root (slot A of the row prefetch), resolved at gather time
         auto after_pop = [&]() {
@@ -1454,7 +1468,7 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
             } else {
                 fresh = finish_insert(nid, act, hslot, old, hslot);
             }
-            st_reads += (uint32_t)__popcll(__ballot(fresh));  // SbqNode::read(neighbor)
+            // (SbqNode::read(neighbor) for every fresh id: counted by the insert as nins / nins_g)
             // label filter: query.labels.overlaps(node.labels) (AM/labels/mod.rs:124-142)
             bool pass = fresh;
             if (has_label_filter && nbr_mask) {
@@ -1525,7 +1539,6 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
                 const uint32_t d = ham_row_reg<NCH, QL, XW>(crow, qv, qc_l, l4, a.code_stride, valid, stream_rows);
                 if (valid && l4 == 0) surv_d[j] = LEAN ? ((d << s.sb) | surv_slot[j]) : d;
             }
-            st_dq += c;
             st_cand += c;
             wave_sync();
             uint32_t entry = 0xFFFFFFFFu;
@@ -1598,8 +1611,8 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
             uint32_t* st = s.stats + (size_t)q * ST_N;
             st[ST_VISITS] = st_visits;
             st[ST_CAND] = st_cand;
-            st[ST_DQ] = st_dq;
-            st[ST_READS] = st_reads;
+            st[ST_DQ] = st_cand;
+            st[ST_READS] = st_pops + st_visits + nins + nins_g;
             st[ST_NEXT] = st_next;
             st[ST_GSPILL] = hmax;
             st[ST_INVIS] = st_invis;

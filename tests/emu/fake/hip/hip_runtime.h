@@ -89,6 +89,8 @@ static inline uint64_t emu_ballot(bool p, const char* f, int l) {
     return m;
 }
 #define __ballot(p) emu_ballot((p), __FILE__, __LINE__)
+// a wave-uniform lane mask back as a per-lane condition (s_and_saveexec on the mask itself: no vector instruction on the device)
+#define __builtin_amdgcn_inverse_ballot_w64(m) ((((uint64_t)(m) >> emu::lane_id()) & 1ull) != 0)
 
 static inline int emu_readfirstlane(int v, const char* f, int l) {
     const emu::Snap s = emu::wave_exchange((uint32_t)v, f, l);

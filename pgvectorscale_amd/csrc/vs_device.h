@@ -39,6 +39,15 @@ __device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {
     __builtin_memcpy(&r, &m, 4);
     return r;
 }
+// A wave-uniform value the compiler is told nothing about, held in a VECTOR register: scalar registers are what k_search_fast runs
+// out of (106 with 226 spilled in round 5), vector registers it has to spare, and a vector instruction takes its operand from
+// either file at the same cost — so the loop-invariant constants that only ever feed vector instructions (array base pointers, hash
+// masks) are parked there by hand instead of being re-read from the kernel arguments inside the loop (s_load + s_waitcnt).
+template <class T>
+__device__ __forceinline__ T in_vgpr(T x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
 // a wave-uniform 64-bit lane mask as a per-lane condition (no vector instruction: the mask goes straight into exec)
 __device__ __forceinline__ bool lane_of(uint64_t mask) { return __builtin_amdgcn_inverse_ballot_w64(mask); }
 

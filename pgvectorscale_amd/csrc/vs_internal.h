@@ -303,7 +303,16 @@ struct FastLaunch {
     uint64_t* phase = nullptr;  // optional [nq][8] per-phase shader-clock sums (VS_PHASE=1, diagnostics only)
     uint32_t* scan_counter = nullptr;  // persist: next scan to run (zero before the launch)
     uint64_t* timeline = nullptr;  // optional [nq][2] start / end of every scan in 100 MHz ticks (VS_TIMELINE=1, diagnostics only)
+    // resumable scans (the scan pools; as SearchLaunch::resume): resume[q * resume_stride ..] is scan q's saved state — header RSF_* + the
+    // LDS image; region q of heap_g / ghash lives on between launches; status[q] != 0 on entry marks the scans that run.  A launch
+    // continues a scan for M more rows (out_ids[q][0..M)); row_stats: [nq][M][ST_N] the work counters as each row was emitted.
+    uint32_t* resume = nullptr;
+    uint32_t resume_stride = 0;
+    uint32_t* row_stats = nullptr;
 };
+enum { RSF_INIT = 0, RSF_HLEN, RSF_VHEAD, RSF_VLEN, RSF_NINS_G, RSF_N_OVF, RSF_HMAX, RSF_VISITS, RSF_CAND, RSF_POPS, RSF_INVIS, RSF_STATUS,
+       RSF_NEXT, RSF_ENDED, RSF_HDR = 16 };
+size_t fast_resume_words(const FastLaunch& s);
 enum {
     // (1 was FAST_PLAIN_ROW_LOADS until round 5: code rows through the normal cache policy; the loads are non-temporal at compile time now)
     FAST_FULL_VARIANT = 8,     // run the instantiation that handles label keys and a visibility mask even when the batch has neither
@@ -330,6 +339,9 @@ int launch_resort(vs_index* idx, uint32_t nq, uint32_t M, uint32_t rescore, uint
 int launch_resort_cursor(vs_index* idx, uint32_t n, bool exhausted, uint32_t rescore, uint32_t k, const uint32_t* d_stream,
                          const float* d_dist, const uint32_t* d_keys, uint64_t* d_heap, uint32_t* d_cur, uint32_t* d_out_ids,
                          uint64_t* d_out_tids, float* d_out_dist);
+int launch_resort_cursor_batch(vs_index* idx, uint32_t n, const uint32_t* d_list, uint32_t rescore, uint32_t k, const uint32_t* d_stream,
+                               const float* d_dist, const uint32_t* d_keys, uint32_t row_stride, uint64_t* d_heap, uint32_t* d_cur,
+                               uint32_t* d_out_ids, uint64_t* d_out_tids, float* d_out_dist, uint32_t out_stride);
 int launch_row_norms(vs_index* idx);
 int launch_slice_norms(vs_index* idx, float* d_out);  // divisor of the first dim_index dims of every heap vector
 int launch_prepare_index_slice(vs_index* idx, const float* d_raw, uint32_t nq, float* d_q_index);

@@ -500,6 +500,122 @@ __global__ void k_resort_cursor(uint32_t n, uint32_t exhausted, uint32_t rescore
     cur[3] = produced;
 }
 
+// The resumable window for MANY scans in one launch (the scan pools' fetch, vs_scanpool.cpp): one wave per listed scan, scans side by
+// side on the chip instead of one single-thread launch per scan.  list[3 b ..] = (pool slot, stream rows the scan has emitted so
+// far, exhausted); the arrays of slot q are row q of the pool's 2-D arrays (strides below).  Inside a scan the heap mechanics are
+// serial — Rust's BinaryHeap<ResortData>, AM/scan.rs:111-117,244-305, replayed exactly as in k_resort_cursor — but they run on an LDS
+// copy of the heap (one coalesced load, one store) against keys the wave fetched ahead (total_cmp images of the distances the
+// refills will push), and the k result rows are gathered by k lanes at once afterwards (stream id, heap tid, distance: two
+// dependent round trips in all instead of three per row).  cur[] as in k_resort_cursor.
+__global__ __launch_bounds__(WAVE) void k_resort_cursor_batch(const uint32_t* __restrict__ list, uint32_t rescore, uint32_t k,
+                                                               const uint32_t* __restrict__ stream_base, const float* __restrict__ dist_base,
+                                                               const uint32_t* __restrict__ keys_base, uint32_t row_stride, uint32_t plain_keys,
+                                                               const uint64_t* __restrict__ tids, uint64_t* __restrict__ heap_base,
+                                                               uint32_t* __restrict__ cur_base, uint32_t* __restrict__ out_ids_base,
+                                                               uint64_t* __restrict__ out_tids_base, float* __restrict__ out_dist_base,
+                                                               uint32_t out_stride) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* hh = reinterpret_cast<uint64_t*>(smem);                 // rescore entries
+    uint32_t* kk = reinterpret_cast<uint32_t*>(hh + rescore);        // rescore + k keys of the rows the refills will push
+    uint32_t* sps = kk + rescore + k;                                // k stream positions of the rows produced
+    const uint32_t lane = threadIdx.x;
+    const uint32_t q = list[3 * blockIdx.x], n = list[3 * blockIdx.x + 1], exhausted = list[3 * blockIdx.x + 2];
+    const uint32_t* stream = stream_base + (size_t)q * row_stride;
+    const float* dist = dist_base + (size_t)q * row_stride;
+    const uint32_t* keys = keys_base + (size_t)q * row_stride;
+    uint64_t* h = heap_base + (size_t)q * rescore;
+    uint32_t* cur = cur_base + (size_t)q * 4;
+    uint32_t* out_ids = out_ids_base + (size_t)q * out_stride;
+    uint64_t* out_tids = out_tids_base + (size_t)q * out_stride;
+    float* out_dist = out_dist_base + (size_t)q * out_stride;
+    uint32_t len = cur[0], pos = cur[1];
+    uint32_t produced = 0;
+    if (rescore == 0) {  // resort_buffer.capacity() == 0 -> plain next(): rows pos .. pos + k - 1 as they are
+        produced = min(k, n > pos ? n - pos : 0u);
+        for (uint32_t j = lane; j < produced; j += WAVE) sps[j] = pos + j;
+        pos += produced;
+    } else {
+        const uint32_t pos0 = pos;
+        const uint32_t ahead = min(n > pos ? n - pos : 0u, rescore - len + k);  // (a call pushes at most that many rows)
+        for (uint32_t i = lane; i < len; i += WAVE) hh[i] = h[i];
+        for (uint32_t i = lane; i < ahead; i += WAVE) kk[i] = (uint32_t)total_key(dist[pos0 + i]);
+        __syncthreads();
+        if (lane == 0) {
+            auto kof = [](uint64_t e) { return (int32_t)(uint32_t)(e >> 32); };
+            auto sift_up = [&](uint32_t p, uint64_t elem) {
+                while (p > 0) {
+                    const uint32_t parent = (p - 1) >> 1;
+                    const uint64_t pe = hh[parent];
+                    if (kof(pe) <= kof(elem)) break;
+                    hh[p] = pe;
+                    p = parent;
+                }
+                hh[p] = elem;
+            };
+            while (produced < k) {
+                while (len < rescore && pos < n) {
+                    const uint64_t e = ((uint64_t)kk[pos - pos0] << 32) | pos;
+                    sift_up(len++, e);
+                    ++pos;
+                }
+                if (len < rescore && !exhausted) break;  // the window cannot be filled yet
+                if (len == 0) break;
+                const uint64_t item = hh[--len];
+                uint64_t top = item;
+                if (len > 0) {
+                    top = hh[0];
+                    const uint32_t end = len;
+                    uint32_t p = 0, child = 1;
+                    const uint32_t lim = end >= 2 ? end - 2 : 0;
+                    while (child <= lim) {
+                        const uint64_t le = hh[child], ri = hh[child + 1];
+                        const uint32_t pick = (kof(ri) <= kof(le)) ? 1u : 0u;
+                        child += pick;
+                        hh[p] = pick ? ri : le;
+                        p = child;
+                        child = 2 * p + 1;
+                    }
+                    if (child == end - 1) {
+                        hh[p] = hh[child];
+                        p = child;
+                    }
+                    sift_up(p, item);
+                }
+                sps[produced++] = (uint32_t)top;
+            }
+            sps[k] = produced;  // (one word past the k positions: the hand-over to the other lanes)
+            sps[k + 1] = len;
+            sps[k + 2] = pos;
+        }
+        __syncthreads();
+        produced = sps[k];
+        len = sps[k + 1];
+        pos = sps[k + 2];
+        for (uint32_t i = lane; i < len; i += WAVE) h[i] = hh[i];
+    }
+    __syncthreads();
+    for (uint32_t j = lane; j < produced; j += WAVE) {
+        const uint32_t sp = sps[j];
+        const uint32_t id = stream[sp];
+        out_ids[j] = id;
+        out_tids[j] = tids[id];
+        float d = __int_as_float(0x7fc00000);
+        if (rescore != 0) d = dist[sp];
+        else if (plain_keys) {
+            int32_t b = (int32_t)(keys[sp] ^ 0x80000000u);
+            b ^= (int32_t)(((uint32_t)(b >> 31)) >> 1);
+            d = __int_as_float(b);
+        }
+        out_dist[j] = d;
+    }
+    if (lane == 0) {
+        cur[0] = len;
+        cur[1] = pos;
+        cur[2] += produced;
+        cur[3] = produced;
+    }
+}
+
 // ===============================================================================================================
 // launch wrappers
 // ===============================================================================================================
@@ -580,6 +696,20 @@ int launch_resort_cursor(vs_index* idx, uint32_t n, bool exhausted, uint32_t res
     const uint32_t plain_keys = (idx->d.storage_type == VS_STORAGE_PLAIN && idx->d.dim_index == idx->d.dim_full) ? 1u : 0u;
     hipLaunchKernelGGL(k_resort_cursor, dim3(1), dim3(64), 0, idx->ctx->stream, n, exhausted ? 1u : 0u, rescore, k, d_stream, d_dist,
                        d_keys, plain_keys, idx->tids, d_heap, d_cur, d_out_ids, d_out_tids, d_out_dist);
+    VS_HIP(hipGetLastError());
+    return VS_OK;
+}
+
+// d_list: [n][3] (pool slot, rows emitted, exhausted) on the device; the per-scan arrays are rows of 2-D arrays (see the kernel)
+int launch_resort_cursor_batch(vs_index* idx, uint32_t n, const uint32_t* d_list, uint32_t rescore, uint32_t k, const uint32_t* d_stream,
+                               const float* d_dist, const uint32_t* d_keys, uint32_t row_stride, uint64_t* d_heap, uint32_t* d_cur,
+                               uint32_t* d_out_ids, uint64_t* d_out_tids, float* d_out_dist, uint32_t out_stride) {
+    if (n == 0) return VS_OK;
+    const uint32_t plain_keys = (idx->d.storage_type == VS_STORAGE_PLAIN && idx->d.dim_index == idx->d.dim_full) ? 1u : 0u;
+    const size_t lds = (size_t)rescore * 8 + ((size_t)rescore + k) * 4 + ((size_t)k + 4) * 4;
+    VS_REQUIRE(lds <= 64 * 1024, "resort window of %u rows / %u rows per fetch does not fit LDS", rescore, k);
+    hipLaunchKernelGGL(k_resort_cursor_batch, dim3(n), dim3(WAVE), lds, idx->ctx->stream, d_list, rescore, k, d_stream, d_dist, d_keys, row_stride,
+                       plain_keys, idx->tids, d_heap, d_cur, d_out_ids, d_out_tids, d_out_dist, out_stride);
     VS_HIP(hipGetLastError());
     return VS_OK;
 }

@@ -41,28 +41,23 @@ struct vs_scan_pool {
     vs_index* ix = nullptr;
     uint32_t cap = 0, L = 0, rescore = 0, S = 0, kmax = 0, rows_cap = 0, mmax = 0;
     uint32_t hl = 0, hcap = 0, vcap = 0, lh = 0, hashcap = 0, g0 = 0, rw = 0;
+    // round 6: the continuations run the RESUMABLE instantiation of the fast kernel (k_search_fast, OPT_RS: heap top, occupancy bits and
+    // visited ring on chip, 16-bit dedup tables) where the index and the capacities allow it — the general kernel otherwise (plain
+    // storage, codes wider than the register-resident widths, a state that does not fit LDS, VS_POOL_FAST=0).  `fl` holds the geometry.
+    bool fast = false;
+    FastLaunch fl{};
     std::vector<Slot> slots;
     bool csr_dirty = true;
     DevBuf raw_q, q_full, q_index, qcodes, qlabels, qlabel_off, heap_g, hash, state, cnt, stats, status, row_stats, stage, all, resort_heap,
-        cur, out_ids, out_tids, out_dist;
-    // the window kernel (k_resort_cursor) is one serial thread per scan: the launches of one fetch are dealt over a few streams so that
-    // they run side by side instead of one after the other
-    static constexpr int kAux = 8;
-    hipStream_t aux[kAux] = {nullptr};
-    hipEvent_t ev_main = nullptr, ev_aux[kAux] = {nullptr};
+        out_tids, list;
+    uint64_t* d_tids = nullptr;
+    uint32_t *d_cur = nullptr, *d_ids = nullptr;
+    float* d_dist = nullptr;
     uint64_t launches = 0, rounds = 0, fetches = 0, scans_served = 0;
     double t_search = 0, t_append = 0, t_resort = 0;  // (VS_POOL_DEBUG) host seconds: launch .. counters back / rerank + append / resort + rows back
     void free_all() {
-        for (int i = 0; i < kAux; ++i) {
-            if (aux[i]) (void)hipStreamDestroy(aux[i]);
-            if (ev_aux[i]) (void)hipEventDestroy(ev_aux[i]);
-            aux[i] = nullptr;
-            ev_aux[i] = nullptr;
-        }
-        if (ev_main) (void)hipEventDestroy(ev_main);
-        ev_main = nullptr;
         for (DevBuf* b : {&raw_q, &q_full, &q_index, &qcodes, &qlabels, &qlabel_off, &heap_g, &hash, &state, &cnt, &stats, &status, &row_stats,
-                          &stage, &all, &resort_heap, &cur, &out_ids, &out_tids, &out_dist}) {
+                          &stage, &all, &resort_heap, &out_tids, &list}) {
             if (b->p && !b->in_slab) (void)hipFree(b->p);
             b->p = nullptr;
             b->bytes = 0;
@@ -107,6 +102,34 @@ static int scanpool_create_impl(vs_index* ix, uint32_t capacity, uint32_t L, uin
     probe.lh = p->lh;
     probe.vcap = p->vcap;
     p->rw = (uint32_t)search_resume_words(probe);
+    if (ix->d.storage_type != VS_STORAGE_PLAIN && pool_env_u32("VS_POOL_FAST", 1) && ix->d.n > 0) {
+        FastLaunch f{};
+        f.hl = 511;
+        f.hcap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(pushes, f.hl), 1u << 22);
+        f.gstride = round_up_u32(f.hcap - f.hl + 2, 2);
+        f.vcap = round_up_u32(std::max<uint32_t>(2u * (uint32_t)std::min<uint64_t>((uint64_t)L + L / 2 + 32, 1u << 16), 64), 64);
+        f.minw = 1;
+        f.gcap = std::max<uint32_t>(next_pow2_u32(std::min<uint64_t>(pushes * 4 / 3 + 256, 1u << 22)), 1024);
+        f.ocap = std::max<uint32_t>(round_up_u32(f.gcap / 16, 32), 256);
+        f.vwords = (f.gcap + f.ocap) / 32;
+        f.vslot = 2;
+        while ((1ull << f.sb) < (uint64_t)f.gcap + f.ocap) f.sb++;
+        uint32_t qd = 1, lb = 0;
+        while ((1ull << qd) < (uint64_t)std::max<uint32_t>(ix->d.n, 2)) qd++;
+        while ((1u << lb) < (f.gcap >> 3)) lb++;
+        if (qd < lb + 3) qd = lb + 3;
+        f.qd = qd;
+        f.qk = qd - lb;
+        f.gregion = (f.gcap >> 1) + f.ocap;
+        f.glimit = (uint32_t)((uint64_t)f.gcap * 3 / 4) - 64u;
+        const uint64_t nbits = (uint64_t)ix->d.dim_index * ix->d.bits;
+        const uint32_t nch = (ix->code_stride + 7) / 8;
+        if (f.qk <= 16 && f.qd <= 32 && nbits < (1ull << (32 - f.sb)) && nch <= 6 && fast_lds_bytes(ix, f) <= 96 * 1024) {
+            p->fast = true;
+            p->fl = f;
+            p->rw = (uint32_t)fast_resume_words(f);
+        }
+    }
     p->slots.resize(capacity);
     const size_t G = capacity;
     auto all = [&]() -> int {
@@ -116,8 +139,13 @@ static int scanpool_create_impl(vs_index* ix, uint32_t capacity, uint32_t L, uin
         if (ix->d.storage_type == VS_STORAGE_PLAIN && ix->d.dim_index < ix->d.dim_full) VS_TRY(devbuf_reserve(c, p->q_index, G * ix->vec_stride * 4));
         VS_TRY(devbuf_reserve(c, p->qlabel_off, (G + 1) * 4));
         VS_TRY(devbuf_reserve(c, p->qlabels, 64));
-        VS_TRY(devbuf_reserve(c, p->heap_g, std::max<size_t>(G * (size_t)(p->hcap > p->hl ? p->hcap - p->hl : 0) * 8, 16)));
-        VS_TRY(devbuf_reserve(c, p->hash, G * (size_t)p->hashcap * 4));
+        if (p->fast) {
+            VS_TRY(devbuf_reserve(c, p->heap_g, std::max<size_t>(G * (size_t)p->fl.gstride * 4, 16)));
+            VS_TRY(devbuf_reserve(c, p->hash, G * (size_t)p->fl.gregion * 4));
+        } else {
+            VS_TRY(devbuf_reserve(c, p->heap_g, std::max<size_t>(G * (size_t)(p->hcap > p->hl ? p->hcap - p->hl : 0) * 8, 16)));
+            VS_TRY(devbuf_reserve(c, p->hash, G * (size_t)p->hashcap * 4));
+        }
         VS_TRY(devbuf_reserve(c, p->state, G * (size_t)p->rw * 4));
         VS_TRY(devbuf_reserve(c, p->cnt, G * 4));
         VS_TRY(devbuf_reserve(c, p->stats, G * ST_N * 4));
@@ -126,15 +154,13 @@ static int scanpool_create_impl(vs_index* ix, uint32_t capacity, uint32_t L, uin
         VS_TRY(devbuf_reserve(c, p->stage, 3 * G * (size_t)p->mmax * 4));     // [ids | ham | dist][slot][M of the round]
         VS_TRY(devbuf_reserve(c, p->all, 3 * G * (size_t)p->rows_cap * 4));   // [ids | ham | dist][slot][rows_cap]
         VS_TRY(devbuf_reserve(c, p->resort_heap, std::max<size_t>(G * (size_t)p->S * 8, 16)));
-        VS_TRY(devbuf_reserve(c, p->cur, G * 16));
-        VS_TRY(devbuf_reserve(c, p->out_ids, G * (size_t)kmax * 4));
-        VS_TRY(devbuf_reserve(c, p->out_tids, G * (size_t)kmax * 8));
-        VS_TRY(devbuf_reserve(c, p->out_dist, G * (size_t)kmax * 4));
-        VS_HIP(hipEventCreateWithFlags(&p->ev_main, hipEventDisableTiming));
-        for (int i = 0; i < vs_scan_pool::kAux; ++i) {
-            VS_HIP(hipStreamCreateWithFlags(&p->aux[i], hipStreamNonBlocking));
-            VS_HIP(hipEventCreateWithFlags(&p->ev_aux[i], hipEventDisableTiming));
-        }
+        // what a fetch brings back in ONE copy: [tids G x kmax u64 | cur G x 4 u32 | ids G x kmax u32 | dist G x kmax f32]
+        VS_TRY(devbuf_reserve(c, p->out_tids, G * (size_t)kmax * 16 + G * 16));
+        p->d_tids = (uint64_t*)p->out_tids.p;
+        p->d_cur = (uint32_t*)(p->d_tids + G * (size_t)kmax);
+        p->d_ids = p->d_cur + G * 4;
+        p->d_dist = (float*)(p->d_ids + G * (size_t)kmax);
+        VS_TRY(devbuf_reserve(c, p->list, G * 12));  // (slot, rows, exhausted) of the scans a fetch lists
         return VS_OK;
     };
     const int r = all();
@@ -153,8 +179,8 @@ extern "C" int vs_scanpool_create(vs_index* ix, uint32_t capacity, uint32_t L, u
 extern "C" void vs_scanpool_free(vs_scan_pool* p) {
     if (!p) return;
     if (pool_env_u32("VS_POOL_DEBUG", 0))
-        fprintf(stderr, "[VS_POOL_DEBUG] pool L=%u rescore=%u: %llu fetch calls serving %llu scan chunks in %llu rounds (%llu search launches); host ms: "
-                        "search %.1f, rerank+append %.1f, resort+rows %.1f\n", p->L, p->rescore, (unsigned long long)p->fetches,
+        fprintf(stderr, "[VS_POOL_DEBUG] pool L=%u rescore=%u (%s kernel): %llu fetch calls serving %llu scan chunks in %llu rounds (%llu search launches); host ms: "
+                        "search %.1f, rerank+append %.1f, resort+rows %.1f\n", p->L, p->rescore, p->fast ? "resumable fast" : "general", (unsigned long long)p->fetches,
                 (unsigned long long)p->scans_served, (unsigned long long)p->rounds, (unsigned long long)p->launches, p->t_search * 1e3, p->t_append * 1e3,
                 p->t_resort * 1e3);
     (void)hipSetDevice(p->ix->ctx->device);
@@ -190,7 +216,7 @@ static int scanpool_rescan_impl(vs_scan_pool* p, uint32_t slot, const float* que
     VS_TRY(launch_prepare_queries(ix, rq, 1, (float*)p->q_full.p + (size_t)slot * ix->vec_stride, (uint64_t*)p->qcodes.p + (size_t)slot * ix->code_stride));
     if (p->q_index.p) VS_TRY(launch_prepare_index_slice(ix, rq, 1, (float*)p->q_index.p + (size_t)slot * ix->vec_stride));
     VS_HIP(hipMemsetAsync((uint32_t*)p->state.p + (size_t)slot * p->rw, 0, RS_HDR * 4, c->stream));
-    VS_HIP(hipMemsetAsync((uint32_t*)p->cur.p + (size_t)slot * 4, 0, 16, c->stream));
+    VS_HIP(hipMemsetAsync(p->d_cur + (size_t)slot * 4, 0, 16, c->stream));
     return VS_OK;
 }
 extern "C" int vs_scanpool_rescan(vs_scan_pool* p, uint32_t slot, const float* query, const int16_t* labels, uint32_t n_labels, int has_label_key) {
@@ -249,6 +275,34 @@ static int pool_round(vs_scan_pool* p, const std::vector<uint32_t>& run, uint32_
         if (!any) continue;
         uint32_t* const d_status = (uint32_t*)p->status.p + (size_t)keyed * G;
         VS_HIP(hipMemcpyAsync(d_status, mask.data(), (size_t)nq * 4, hipMemcpyHostToDevice, c->stream));  // (pageable source: staged before the call returns)
+        if (p->fast) {
+            FastLaunch f = p->fl;
+            f.nq = nq;
+            f.L = p->L;
+            f.M = M;
+            f.qcodes = (const uint64_t*)p->qcodes.p;
+            f.qlabels = keyed ? (const int16_t*)p->qlabels.p : nullptr;
+            f.qlabel_off = keyed ? (const uint32_t*)p->qlabel_off.p : nullptr;
+            f.heap_g = (uint32_t*)p->heap_g.p;
+            f.ghash = (uint32_t*)p->hash.p;
+            f.pool_counter = nullptr;
+            f.pool_slots = G;
+            f.out_ids = stage_ids;  // [slot][M]
+            f.out_ham = stage_ham;
+            f.out_cnt = (uint32_t*)p->cnt.p;
+            f.stats = (uint32_t*)p->stats.p;
+            f.status = d_status;  // the run mask on entry, the scan's outcome on exit
+            f.visible = p->S > 0 ? ix->visible : nullptr;
+            f.resume = (uint32_t*)p->state.p;
+            f.resume_stride = p->rw;
+            f.row_stats = (uint32_t*)p->row_stats.p;
+            hipEvent_t ev = prof_begin(c);
+            const int lr = launch_search_fast(ix, f);
+            prof_end(c, PK_SEARCH, ev);
+            VS_TRY(lr);
+            p->launches++;
+            continue;
+        }
         SearchLaunch sl;
         sl.nq = nq;
         sl.L = p->L;
@@ -404,45 +458,39 @@ static int scanpool_fetch_impl(vs_scan_pool* p, const uint32_t* slots, uint32_t 
         VS_REQUIRE(M >= 1, "vs_scanpool_fetch: internal: empty round");
         VS_TRY(pool_round(p, run, M));
     }
-    // ---- next_with_resort x k per scan (AM/scan.rs:244-305): one k_resort_cursor launch per listed scan, all enqueued, one wait
+    // ---- next_with_resort x k per scan (AM/scan.rs:244-305): one k_resort_cursor_batch launch, a wave per listed scan
     const auto tr0 = std::chrono::steady_clock::now();
     p->fetches++;
     p->scans_served += n;
     uint32_t* const all_ids = (uint32_t*)p->all.p;
     uint32_t* const all_ham = all_ids + (size_t)G * p->rows_cap;
     float* const all_dist = (float*)(all_ham + (size_t)G * p->rows_cap);
-    const int naux = n >= 4 ? vs_scan_pool::kAux : 0;  // (a few scans: the context's own stream)
-    hipStream_t const main_stream = c->stream;
-    if (naux) {
-        VS_HIP(hipEventRecord(p->ev_main, main_stream));  // the rows appended above are in place
-        for (int a = 0; a < naux; ++a) VS_HIP(hipStreamWaitEvent(p->aux[a], p->ev_main, 0));
-    }
-    int lrc = VS_OK;
-    for (uint32_t i = 0; i < n && lrc == VS_OK; ++i) {
-        const uint32_t q = slots[i];
-        Slot& s = p->slots[q];
-        if (s.failed) continue;
-        if (naux) c->stream = p->aux[i % naux];  // (launch_resort_cursor launches on the context's stream; one dispatcher thread)
-        lrc = launch_resort_cursor(ix, s.rows, s.exhausted, S, k, all_ids + (size_t)q * p->rows_cap, all_dist + (size_t)q * p->rows_cap,
-                                   all_ham + (size_t)q * p->rows_cap, (uint64_t*)p->resort_heap.p + (size_t)q * S, (uint32_t*)p->cur.p + (size_t)q * 4,
-                                   (uint32_t*)p->out_ids.p + (size_t)q * p->kmax, (uint64_t*)p->out_tids.p + (size_t)q * p->kmax,
-                                   (float*)p->out_dist.p + (size_t)q * p->kmax);
-    }
-    c->stream = main_stream;
-    if (naux)
-        for (int a = 0; a < naux; ++a) {
-            VS_HIP(hipEventRecord(p->ev_aux[a], p->aux[a]));
-            VS_HIP(hipStreamWaitEvent(main_stream, p->ev_aux[a], 0));
+    // one wave per listed scan in ONE launch (round 6; until round 5: one single-thread k_resort_cursor launch per scan, dealt over eight
+    // streams — 64 launches per fetch of 64 scans)
+    {
+        std::vector<uint32_t> list;
+        list.reserve((size_t)n * 3);
+        for (uint32_t i = 0; i < n; ++i) {
+            const uint32_t q = slots[i];
+            const Slot& s = p->slots[q];
+            if (s.failed) continue;
+            list.push_back(q);
+            list.push_back(s.rows);
+            list.push_back(s.exhausted ? 1u : 0u);
         }
-    VS_TRY(lrc);
-    std::vector<uint32_t> cur((size_t)G * 4), ids((size_t)G * p->kmax);
-    std::vector<uint64_t> tids((size_t)G * p->kmax);
-    std::vector<float> dist((size_t)G * p->kmax);
-    VS_HIP(hipMemcpyAsync(cur.data(), p->cur.p, cur.size() * 4, hipMemcpyDeviceToHost, c->stream));
-    VS_HIP(hipMemcpyAsync(ids.data(), p->out_ids.p, ids.size() * 4, hipMemcpyDeviceToHost, c->stream));
-    VS_HIP(hipMemcpyAsync(tids.data(), p->out_tids.p, tids.size() * 8, hipMemcpyDeviceToHost, c->stream));
-    VS_HIP(hipMemcpyAsync(dist.data(), p->out_dist.p, dist.size() * 4, hipMemcpyDeviceToHost, c->stream));
+        if (!list.empty()) {
+            VS_HIP(hipMemcpyAsync(p->list.p, list.data(), list.size() * 4, hipMemcpyHostToDevice, c->stream));  // (pageable source: staged before the call returns)
+            VS_TRY(launch_resort_cursor_batch(ix, (uint32_t)(list.size() / 3), (const uint32_t*)p->list.p, S, k, all_ids, all_dist, all_ham, p->rows_cap,
+                                              (uint64_t*)p->resort_heap.p, p->d_cur, p->d_ids, p->d_tids, p->d_dist, p->kmax));
+        }
+    }
+    std::vector<uint64_t> pack((size_t)G * p->kmax * 2 + (size_t)G * 2);  // (u64 words of the layout above)
+    VS_HIP(hipMemcpyAsync(pack.data(), p->out_tids.p, pack.size() * 8, hipMemcpyDeviceToHost, c->stream));
     VS_HIP(hipStreamSynchronize(c->stream));
+    const uint64_t* const tids = pack.data();
+    const uint32_t* const cur = (const uint32_t*)(tids + (size_t)G * p->kmax);
+    const uint32_t* const ids = cur + (size_t)G * 4;
+    const float* const dist = (const float*)(ids + (size_t)G * p->kmax);
     p->t_resort += std::chrono::duration<double>(std::chrono::steady_clock::now() - tr0).count();
     for (uint32_t i = 0; i < n; ++i) {
         const uint32_t q = slots[i];

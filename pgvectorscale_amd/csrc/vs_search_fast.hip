@@ -243,11 +243,11 @@ struct FastHeap {
         const uint32_t IDENT = 0xFFFFFFFFu;
         const uint32_t p1f = len + 1;
         const uint32_t off = p1f & 31u;
-        // where ranks 0..5 of the run live: all in the spill array (the usual case of a deep heap), mixed, or all in LDS
-        const bool deep = (p1f >> 5) > hl;
-        auto put = [&](uint32_t idx, uint32_t v) {
-            if (deep) gstore32(g + (idx - 1 - hl), v);
-            else if (spill) set1(idx, v);
+        // Where rank k of the run lives: a run stays on one heap level and hl + 1 is a power of two, so the rank-k ancestors of its
+        // leaves are all on ONE level too — every one of them in LDS or every one in the spill array, a wave-uniform test per rank
+        // (round 6; the per-lane "LDS or spill array" of set1() cost two exec-mask regions per store)
+        auto put = [&](const uint32_t k, uint32_t idx, uint32_t v) {
+            if ((p1f >> k) > hl) gstore32(g + (idx - 1 - hl), v);
             else l[idx] = v;
         };
         const uint32_t i = (uint32_t)lane - off;            // this lane's element (leaf order); >= n: not a leaf of the run
@@ -347,7 +347,7 @@ struct FastHeap {
             const bool last = in && ((((uint32_t)lane & B1) == B1) || i + 1 == n);  // last push of the node: its final value
             if (last) {
                 const uint32_t fin = wins ? c : curv;
-                if (fin != ak) put(p1 >> k, fin);
+                if (fin != ak) put(k, p1 >> k, fin);
             }
             if (wins) {
                 c = curv;
@@ -359,7 +359,7 @@ struct FastHeap {
         if (K >= 3) level(3, ak3);
         if (K >= 2) level(2, ak2);
         if (K >= 1) level(1, ak1);
-        if (in) put(p1, c);
+        if (in) put(0, p1, c);
     }
     // pre_n / pre_anc: a wide load the caller already issued for the first run (pre_n = first_run(c)), or pre_n = 0
     __device__ __forceinline__ void push_run(uint32_t entry, uint32_t c, uint32_t pre_n, uint32_t pre_anc) {
@@ -736,25 +736,44 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 // workspace is a few hundred MB whatever the batch size, and no region is claimed with an atomic).
 // OPT: what the launch wrapper knows about the index and states at compile time (round 6: every one of these was a branch, a live
 // scalar register or an exec-mask region in a kernel that spilled 226 of them): OPT_XW = code rows are exactly 8 NCH words,
-// OPT_R1 = num_neighbors <= 64, i.e. a neighbor list is ONE wave-wide chunk.
+// OPT_R1 = num_neighbors <= 64, i.e. a neighbor list is ONE wave-wide chunk, OPT_NS64 = neighbor rows are 64 ids apart.
+// OPT_RS = RESUMABLE scans (the amgettuple continuations of the scan pools, AM/scan.rs:162-174,370-405): one workgroup per pool slot, the
+// slot's regions of the dedup tables / heap spill array live on between launches, and the on-chip state (heap top, occupancy bits,
+// visited ring, a header of counters) is restored from and saved to s.resume; a launch continues the scan for M more rows and records
+// the work counters per emitted row (s.row_stats).  status[q] is the run mask on entry (only the marked slots run).
 #define OPT_XW 1
 #define OPT_R1 2
+#define OPT_NS64 4
+#define OPT_RS 8
 template <int NCH, int VR, bool TIMING, int MINW, bool BUILD, bool FULL, int VG, int OPT>
 __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, const uint32_t slot) {
     constexpr bool XW = (OPT & OPT_XW) != 0 && NCH > 0;
     constexpr bool R1 = (OPT & OPT_R1) != 0;
+    constexpr bool RS = (OPT & OPT_RS) != 0;
+    static_assert(!RS || (VG == 3 && VR == 0 && !BUILD), "resumable scans: 16-bit tables, LDS-ring visited list");
+    // (vector-register copies of the array bases, see in_vgpr; the row stride is a compile-time constant where the launch says so)
+    // (the instantiation with label keys has the neighbors' masks in flight next to the rows: it keeps its vector registers for those)
+    const uint64_t* const codes_v = FULL ? a.codes : in_vgpr(a.codes);
+    const uint32_t* const nbrs_v = FULL ? a.nbrs : in_vgpr(a.nbrs);
+    const uint64_t* const tids_v = FULL ? a.tids : in_vgpr(a.tids);
+    const uint32_t cstride = XW ? 8u * (uint32_t)NCH : a.code_stride;
+    const uint32_t nstride = (OPT & OPT_NS64) ? 64u : a.nbr_stride;
+    const uint32_t R_v = in_vgpr(a.R);  // (only ever compared with lane indexes)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int lane_v = threadIdx.x;
     // (persistent grid: what a scan derives from its lane index is derived again by the next scan instead of being carried
     // across the whole kernel — the register allocation of one scan stays what it is with one workgroup per scan)
     asm volatile("" : "+v"(lane_v));
-    const int lane = lane_v;
+    int lane = lane_v;  // (re-read as an opaque value at the top of every iteration of the main loop, see there)
     const FastLaunch& s = a.s;
     // (the bitmap variants only exist for the table-less regime: the LDS-table code paths are not compiled into them)
     const uint32_t lhv = VG ? 0u : s.lh;
     const uint32_t onlyfv = VG ? 0u : s.only_failed;  // (second attempts run the instantiation that clears its tables)
     const uint32_t rcv = VG >= 2 ? 0u : s.rc;
     if (onlyfv && s.status[q] == 0) return;  // (wave-uniform) finished by the first launch
+    if (RS && s.status[q] == 0) return;      // (wave-uniform) not listed in this round
+    uint32_t* const rs = RS ? s.resume + (size_t)q * s.resume_stride : nullptr;
+    const bool resumed = RS && rfl(rs[RSF_INIT]) == 1u;
     if (s.timeline && lane == 0) s.timeline[2 * (size_t)q] = wall_clock64();
 
     // ---- LDS carve ----  Everything of a size known at compile time comes first, so its addresses are immediates of the ds
@@ -786,7 +805,7 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
     // the generic width's copy of the query code (code_stride words) is the one array of a size only the launch knows that wants 16 bytes
     uint64_t* qc_l = QL ? qc_fix : reinterpret_cast<uint64_t*>(smem + ((((vmap + s.vwords) - reinterpret_cast<uint32_t*>(smem)) * 4u + 15u) & ~15u));
 
-    const int l4 = lane & 3;
+    int l4 = lane & 3;
     // code rows are read once per scan: non-temporal loads, worth 10 % at 50M (profiles/r04/s5_ab_nt_rows_50m.txt).  A compile-time
     // constant since round 6: as a launch flag every row load was two instructions behind a branch.
     constexpr bool stream_rows = true;
@@ -797,25 +816,29 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
     if (QL) {
         qv[0] = make_ulonglong2(0, 0);
         for (uint32_t w = lane; w < 8u * (uint32_t)NCH; w += WAVE)
-            qc_l[w] = w < a.code_stride ? s.qcodes[(size_t)q * a.code_stride + w] : 0ull;
+            qc_l[w] = w < a.code_stride ? s.qcodes[(size_t)q * cstride + w] : 0ull;
     } else if (NCH > 0) {
 #pragma unroll
         for (int t = 0; t < NCH; ++t) {
             const uint32_t w = 2u * (uint32_t)l4 + 8u * (uint32_t)t;
             qv[t] = w < a.code_stride
-                        ? *reinterpret_cast<const ulonglong2*>(s.qcodes + (size_t)q * a.code_stride + w)
+                        ? *reinterpret_cast<const ulonglong2*>(s.qcodes + (size_t)q * cstride + w)
                         : make_ulonglong2(0, 0);
         }
     } else {
-        for (uint32_t w = lane; w < a.code_stride; w += WAVE) qc_l[w] = s.qcodes[(size_t)q * a.code_stride + w];
+        for (uint32_t w = lane; w < a.code_stride; w += WAVE) qc_l[w] = s.qcodes[(size_t)q * cstride + w];
     }
     for (uint32_t i = 4u * lane; i < lhv; i += 4u * WAVE)
         *reinterpret_cast<uint4*>(lhash + i) = make_uint4(VS_EMPTY, VS_EMPTY, VS_EMPTY, VS_EMPTY);
-    if (lane == 0) hp[0] = 0;  // heap sentinel
+    if (lane == 0 && !resumed) hp[0] = 0;  // heap sentinel
     for (uint32_t i = lane; i < ARB_N; i += WAVE) arb[i] = 0;
     for (uint32_t i = lane; i < rcv; i += WAVE) rc[i] = VS_EMPTY;
-    if (VG)
+    if (VG && !resumed)
         for (uint32_t i = lane; i < s.vwords; i += WAVE) vmap[i] = 0;
+    // (resumable scans) the image of a saved scan: everything from the heap top to the occupancy bits is one contiguous stretch of LDS
+    const uint32_t image_words = RS ? (uint32_t)((vmap + s.vwords) - hp) : 0u;
+    if (resumed)  // (16 bytes per lane: the image is padded to whole uint4, hp and the saved image are 16-byte aligned)
+        for (uint32_t i = 4u * lane; i < image_words; i += 4u * WAVE) *reinterpret_cast<uint4*>(hp + i) = *reinterpret_cast<const uint4*>(rs + RSF_HDR + i);
     const uint8_t* const visible = FULL ? s.visible : nullptr;
     const bool labels_some = FULL && s.qlabel_off != nullptr;  // LabeledVector.labels is Some (AM/labels/mod.rs:222-236)
     uint32_t nql = 0;
@@ -845,7 +868,7 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
     FastHeap<(MINW >= 7)> heap;
     heap.l = hp;
     // (second attempt with one workgroup per scan: set with the pool region)
-    heap.g = s.persist ? s.heap_g + (size_t)slot * s.gstride : (onlyfv ? s.heap_g : s.heap_g + (size_t)q * s.gstride);
+    heap.g = (s.persist || RS) ? s.heap_g + (size_t)slot * s.gstride : (onlyfv ? s.heap_g : s.heap_g + (size_t)q * s.gstride);
     heap.hl = s.hl;
     heap.sb = s.sb;
     heap.init(lane);
@@ -880,7 +903,7 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
     // global dedup overflow table: claimed from the pool on first need
     auto claim_region = [&]() -> bool {
         if (region) return true;
-        if (s.persist) {  // the workgroup's own region (the launch wrapper holds pool_slots >= the grid)
+        if (s.persist || RS) {  // the workgroup's own region (the launch wrapper holds pool_slots >= the grid) / the pool slot's
             region = true;
             ghash = s.ghash + (size_t)slot * (VG == 3 ? s.gregion : s.gcap);
             return true;
@@ -906,8 +929,10 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
     // ---- VG == 3: 16-bit entries.  The id is mapped by a bijection on qd bits (multiply, xor-shift, multiply, xor-shift: each step is
     // invertible mod 2^qd) to x; the bucket of eight slots is x >> qk, the entry the remainder x & (2^qk - 1), the preferred slot x & 7.
     // (bucket, entry) names the id: q_inv gives it back, so a heap entry's handle (the slot) still finds the node without a second array.
-    const uint32_t qdm = VG == 3 ? (s.qd >= 32 ? 0xFFFFFFFFu : (1u << s.qd) - 1u) : 0u;
-    const uint32_t qxs = (s.qd + 1u) >> 1;  // (2 qxs >= qd: x ^= x >> qxs is its own inverse)
+    const uint32_t qdm = in_vgpr(VG == 3 ? (s.qd >= 32 ? 0xFFFFFFFFu : (1u << s.qd) - 1u) : 0u);
+    const uint32_t qxs = in_vgpr((s.qd + 1u) >> 1);  // (2 qxs >= qd: x ^= x >> qxs is its own inverse)
+    const uint32_t qk_v = in_vgpr(s.qk), rmask_v = in_vgpr((1u << s.qk) - 1u);
+    const uint32_t ovf_lim_v = in_vgpr(s.ocap - s.ocap / 4);  // (the overflow table's load limit)
     // (the multipliers are compile-time constants — the kernel lives at its scalar-register limit; the launch wrapper checks that the
     // host's copies agree)
     auto q_fwd = [&](uint32_t id) -> uint32_t {
@@ -933,7 +958,7 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
     };
     // what node_load returned (made uniform by the caller) -> the node id
     auto node_of = [&](uint32_t handle, uint32_t raw) -> uint32_t {
-        if (VG == 3 && handle < s.gcap) return q_inv(((handle >> 3) << s.qk) | raw);
+        if (VG == 3 && handle < s.gcap) return rfl(q_inv(((handle >> 3) << qk_v) | raw));  // (vector instructions: the masks live in vector registers)
         return raw;
     };
     // true where the id was not present before; slot_out = its handle
@@ -1083,11 +1108,11 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
     // eight entries of the bucket are other ids.  Half the bytes per slot of the 4-byte table and never a second dependent load.
     auto b16_occ = [&](uint32_t hb) -> uint32_t { return (vmap[hb >> 2] >> ((hb & 3u) << 3)) & 0xFFu; };
     auto b16_run = [&](uint32_t x) -> uint32_t {  // occupied slots in a row, cyclic, from x's preferred slot (0: it is free, 8: full)
-        const uint32_t occ = b16_occ(x >> s.qk);
+        const uint32_t occ = b16_occ(x >> qk_v);
         const uint32_t rot = ((occ | (occ << 8)) >> (x & 7u)) & 0xFFu;
         return (uint32_t)__builtin_ctz(~rot);
     };
-    auto b16_load = [&](uint32_t x) -> uint4 { return *reinterpret_cast<const uint4*>(ghash + ((size_t)(x >> s.qk) << 2)); };
+    auto b16_load = [&](uint32_t x) -> uint4 { return *reinterpret_cast<const uint4*>(ghash + ((size_t)(x >> qk_v) << 2)); };
     uint32_t n_ovf = 0;
     auto ovf_insert = [&](uint32_t nid, bool act, uint32_t& slot_out) -> bool {  // (as slot_insert, on the overflow table)
         uint32_t* const ot = ghash + (s.gcap >> 1);
@@ -1144,7 +1169,7 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
             v = make_uint4(0, 0, 0, 0);
             if (t) v = b16_load(x);
         }
-        const uint32_t hb = x >> s.qk, r = x & ((1u << s.qk) - 1u), pref = x & 7u;
+        const uint32_t hb = x >> qk_v, r = x & rmask_v, pref = x & 7u;
         // In the run of the snapshot, or new.  Straight-line for every lane (round 6; t == 0 is an empty run mask, a lane without a load
         // compares zeros): which of the eight entries equal the remainder — per 16-bit half min(entry ^ r, 1) is 0 exactly where they do
         // (v_pk_min_u16; the constant is kept opaque, or the compiler turns the minimum into eight compares and selects), the halves'
@@ -1229,11 +1254,29 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
     if (status) { /* handed over (wide label key): no region is claimed */ }
     else if (gmode) open_table();  // claimed and cleared up front
     else if (onlyfv) claim_region();  // (the heap spill array of a second attempt comes with the region)
+    // (resumable scans) the scalars of a saved scan; `ended`: next() has returned None before (the stream is over for good)
+    uint32_t next_base = 0, invis_base = 0;
+    bool ended = false;
+    if (resumed) {
+        heap.len = rfl(rs[RSF_HLEN]);
+        vis.head = rfl(rs[RSF_VHEAD]);
+        vis.len = rfl(rs[RSF_VLEN]);
+        nins_g = rfl(rs[RSF_NINS_G]);
+        n_ovf = rfl(rs[RSF_N_OVF]);
+        hmax = rfl(rs[RSF_HMAX]);
+        st_visits = rfl(rs[RSF_VISITS]);
+        st_cand = rfl(rs[RSF_CAND]);
+        st_pops = rfl(rs[RSF_POPS]);
+        invis_base = rfl(rs[RSF_INVIS]);
+        status = rfl(rs[RSF_STATUS]);
+        next_base = rfl(rs[RSF_NEXT]);
+        ended = rfl(rs[RSF_ENDED]) != 0;
+    }
 
     // ---- ListSearchResult::new: start nodes (AM/graph/mod.rs:97-124, AM/graph/start_nodes.rs:39-48) ----
     {
         uint32_t nstarts = labels_some ? nql : 1u;
-        if (a.default_start == VS_INVALID_NODE || a.n == 0 || status) nstarts = 0;  // ListSearchResult::empty() (or a handed-over scan)
+        if (a.default_start == VS_INVALID_NODE || a.n == 0 || status || resumed) nstarts = 0;  // ListSearchResult::empty() (or a handed-over scan)
         for (uint32_t si = 0; si < nstarts; ++si) {
             uint32_t sn = VS_INVALID_NODE;
             if (!labels_some) {
@@ -1263,7 +1306,7 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
             if (!rfl(fr ? 1u : 0u)) continue;
             slot = rfl(slot);
             const uint32_t d =
-                rfl(ham_row_reg<NCH, QL, XW>(a.codes + (size_t)sn * a.code_stride, qv, qc_l, l4, a.code_stride, lane < 4, stream_rows));
+                rfl(ham_row_reg<NCH, QL, XW>(codes_v + (size_t)sn * cstride, qv, qc_l, l4, cstride, lane < 4, stream_rows));
             st_cand++;
             if (heap.len + 1 > s.hcap) { status |= OVF_HEAP; break; }
             heap.push((d << s.sb) | slot);
@@ -1284,13 +1327,21 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
     // either one visit_closest() expansion (greedy_search_iterate, AM/graph/mod.rs:357-385) or one consume() ----
     uint32_t ft_node = VS_INVALID_NODE;  // heap tid (and visibility) of the visited list's front entry, requested ahead of consume()
     uint64_t ft_val = 0;
-    uint32_t ft_vis = 1, st_invis = 0;
+    uint32_t ft_vis = 1, st_invis = invis_base;
     uint32_t hslot0 = 0;
     uint4 gbk0 = make_uint4(0, 0, 0, 0);
     bool rchit0 = false;  // this lane's id of the first chunk was found in the id cache
     bool virg0 = false;
     uint32_t pret0 = 0;  // (VG == 2) occupied run at the home slot of this lane's id of the first chunk when its group was requested
-    while (status == 0) {
+    while (status == 0 && !(RS && ended)) {
+        // What a lane derives from its index (lane < c, (lane & 15) == 0, lane == 0 ... as exec masks in scalar register pairs) is loop
+        // invariant, so the compiler computes some fifty of them ahead of the loop — and then has to park them in vector-register
+        // lanes, two v_readlane each to get one back (round 6: 226 scalar spills).  An opaque lane index per iteration makes each a
+        // one-instruction compare where it is used.
+        asm volatile("" : "+v"(lane));
+        heap.lane = lane;
+        vis.lane = lane;
+        l4 = lane & 3;
         hslot0 = 0;  // (these do not live across iterations)
         gbk0 = make_uint4(0, 0, 0, 0);
         rchit0 = false;
@@ -1300,7 +1351,7 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
             const uint32_t fn = readlane_u32(vis.n[0], 0);
             if (fn != ft_node) {
                 ft_node = fn;
-                ft_val = load_stream64(a.tids + fn);
+                ft_val = load_stream64(tids_v + fn);
                 if (visible) ft_vis = visible[fn];
             }
         }
@@ -1314,12 +1365,15 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
         if (!can_visit) {
             if (BUILD) break;  // greedy_search_for_build stops here: the visited list is the candidate set
             // ---- consume (AM/graph/mod.rs:174-184) + return_lsn (AM/sbq/storage.rs:404-414) ----
-            if (vis.len == 0) break;  // None: the stream has ended
+            if (vis.len == 0) {  // None: the stream has ended
+                ended = true;
+                break;
+            }
             uint32_t fd, fnode, fflags;
             vis.pop_front(fd, fnode, fflags);
             st_pops++;
             if (VR > 0) {
-                const uint64_t tid = fnode == ft_node ? ft_val : load_stream64(a.tids + fnode);
+                const uint64_t tid = fnode == ft_node ? ft_val : load_stream64(tids_v + fnode);
                 fflags = (tid & 0xFFFFull) == 0 ? VIS_DEAD : 0u;
                 if (visible) fflags |= rfl(fnode == ft_node ? ft_vis : (uint32_t)visible[fnode]) == 0 ? VIS_HIDDEN : 0u;
             }
@@ -1331,6 +1385,17 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
             if (lane == 0) {
                 s.out_ids[(size_t)q * s.M + emitted] = fnode;
                 s.out_ham[(size_t)q * s.M + emitted] = fd;
+                if (RS && s.row_stats) {  // the counters as the reference's stood when this row left next() (vs_search.hip has the same)
+                    uint32_t* r = s.row_stats + ((size_t)q * s.M + emitted) * ST_N;
+                    r[ST_VISITS] = st_visits;
+                    r[ST_CAND] = st_cand;
+                    r[ST_DQ] = st_cand;
+                    r[ST_READS] = st_pops + st_visits + nins + nins_g;
+                    r[ST_NEXT] = next_base + emitted + 1u + (st_invis - invis_base);
+                    r[ST_GSPILL] = hmax;
+                    r[ST_INVIS] = st_invis;
+                    r[7] = nins + nins_g;
+                }
             }
             emitted++;
             lap(6);
@@ -1356,7 +1421,7 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
         bool early = false;
         if (hit) {
             if (VR == 0 && !BUILD) {
-                vtid = load_stream64(a.tids + node_v);
+                vtid = load_stream64(tids_v + node_v);
                 if (visible) vvis = visible[node_v];
             }
             if (gmode && nins_g <= s.glimit) {
@@ -1384,13 +1449,13 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
         const uint32_t node = hit ? rfl(node_v) : node_of(th, rfl(node_v));
         // what consume() will need to know about this node: requested now, folded into the ring entry at the insert below
         if (!hit && VR == 0 && !BUILD) {
-            vtid = load_stream64(a.tids + node);
+            vtid = load_stream64(tids_v + node);
             if (visible) vvis = visible[node];
         }
-        const uint32_t* nrow = a.nbrs + (size_t)node * a.nbr_stride;
+        const uint32_t* nrow = nbrs_v + (size_t)node * nstride;
         if (!hit) {
-            row0 = ((uint32_t)lane < a.R) ? load_stream32(nrow + lane) : VS_INVALID_NODE;
-            if (nbr_mask) rowm = ((uint32_t)lane < a.R) ? load_stream64(nbr_mask + (size_t)node * a.nbr_stride + lane) : 0ull;
+            row0 = ((uint32_t)lane < R_v) ? load_stream32(nrow + lane) : VS_INVALID_NODE;
+            if (nbr_mask) rowm = ((uint32_t)lane < R_v) ? load_stream64(nbr_mask + (size_t)node * nstride + lane) : 0ull;
         }
         lap(0);
         if (vis.len + 1 > vis.capacity()) {
@@ -1412,7 +1477,7 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
         bool list_ended = false;
         for (uint32_t c0 = 0; c0 < (R1 ? 1u : a.R) && !list_ended; c0 += WAVE) {
             const uint32_t slotidx = c0 + lane;
-            const uint32_t nid = c0 == 0 ? row0 : ((slotidx < a.R) ? load_stream32(nrow + slotidx) : VS_INVALID_NODE);
+            const uint32_t nid = c0 == 0 ? row0 : ((slotidx < R_v) ? load_stream32(nrow + slotidx) : VS_INVALID_NODE);
             // list ends at the first InvalidBlockNumber (AM/sbq/node.rs:260-285)
             const uint64_t inval = __ballot(nid == VS_INVALID_NODE);
             const uint32_t nvalid = inval ? (uint32_t)__builtin_ctzll(inval) : WAVE;
@@ -1456,7 +1521,7 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
             bool fresh;
             if (gmode && VG == 3) {
                 fresh = b16_insert(nid, act, hslot, gbk, pret, true, hslot);
-                if (n_ovf + WAVE > s.ocap - s.ocap / 4) status |= OVF_HASH;  // (the overflow table at its load limit: the second attempt)
+                if (__ballot(n_ovf + WAVE > ovf_lim_v)) status |= OVF_HASH;  // (the overflow table at its load limit: the second attempt)
             } else if (gmode && VG == 2) {
                 fresh = slot_insert(nid, act, hslot, gbk, pret, hslot);
             } else if (gmode) {
@@ -1472,7 +1537,7 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
             // label filter: query.labels.overlaps(node.labels) (AM/labels/mod.rs:124-142)
             bool pass = fresh;
             if (has_label_filter && nbr_mask) {
-                const uint64_t nm = c0 == 0 ? rowm : ((slotidx < a.R) ? load_stream64(nbr_mask + (size_t)node * a.nbr_stride + slotidx) : 0ull);
+                const uint64_t nm = c0 == 0 ? rowm : ((slotidx < R_v) ? load_stream64(nbr_mask + (size_t)node * nstride + slotidx) : 0ull);
                 pass = fresh && (nm & qmask) != 0;
             } else if (has_label_filter && a.label_mask) {
                 if (fresh) pass = (a.label_mask[nid] & qmask) != 0;
@@ -1514,7 +1579,7 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
                 const uint32_t j = pass_i * 16u + (uint32_t)(lane >> 2);
                 const bool valid = j < c;
                 const uint32_t id = valid ? surv_id[j] : 0;
-                const uint64_t* crow = a.codes + (size_t)id * a.code_stride;
+                const uint64_t* crow = codes_v + (size_t)id * cstride;
                 if (pass_i == 0 && !pfa_issued) {
                     pfa_issued = true;
                     pfa_node = VS_INVALID_NODE;
@@ -1522,21 +1587,21 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
                     if (root_after != 0xFFFFFFFFu) {
                         pfa_node = node_of(root_after & smask, rfl(root_node_v));
                         pfa_h = root_after & smask;
-                        pfa_val = ((uint32_t)lane < a.R) ? load_stream32(a.nbrs + (size_t)pfa_node * a.nbr_stride + lane) : VS_INVALID_NODE;
-                        if (nbr_mask) pfa_m = ((uint32_t)lane < a.R) ? load_stream64(nbr_mask + (size_t)pfa_node * a.nbr_stride + lane) : 0ull;
+                        pfa_val = ((uint32_t)lane < R_v) ? load_stream32(nbrs_v + (size_t)pfa_node * nstride + lane) : VS_INVALID_NODE;
+                        if (nbr_mask) pfa_m = ((uint32_t)lane < R_v) ? load_stream64(nbr_mask + (size_t)pfa_node * nstride + lane) : 0ull;
                     }
                 }
                 if (G2) {
                     const uint32_t j2 = j + 16u;
                     const bool valid2 = j2 < c;
-                    const uint64_t* crow2 = a.codes + (size_t)(valid2 ? surv_id[j2] : 0u) * a.code_stride;
+                    const uint64_t* crow2 = codes_v + (size_t)(valid2 ? surv_id[j2] : 0u) * cstride;
                     uint32_t d, d2;
-                    ham_row_reg2<NCH>(crow, crow2, qv, l4, a.code_stride, valid, valid2, stream_rows, d, d2);
+                    ham_row_reg2<NCH>(crow, crow2, qv, l4, cstride, valid, valid2, stream_rows, d, d2);
                     if (valid && l4 == 0) surv_d[j] = LEAN ? ((d << s.sb) | surv_slot[j]) : d;
                     if (valid2 && l4 == 0) surv_d[j2] = LEAN ? ((d2 << s.sb) | surv_slot[j2]) : d2;
                     continue;
                 }
-                const uint32_t d = ham_row_reg<NCH, QL, XW>(crow, qv, qc_l, l4, a.code_stride, valid, stream_rows);
+                const uint32_t d = ham_row_reg<NCH, QL, XW>(crow, qv, qc_l, l4, cstride, valid, stream_rows);
                 if (valid && l4 == 0) surv_d[j] = LEAN ? ((d << s.sb) | surv_slot[j]) : d;
             }
             st_cand += c;
@@ -1562,8 +1627,8 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
                 if (best != 0xFFFFFFFFu && (best >> s.sb) < (root_after >> s.sb)) {
                     pfb_node = best_node;  // a candidate of this visit: its id is known without a table lookup
                     pfb_h = best & smask;
-                    pfb_val = ((uint32_t)lane < a.R) ? load_stream32(a.nbrs + (size_t)pfb_node * a.nbr_stride + lane) : VS_INVALID_NODE;
-                    if (nbr_mask) pfb_m = ((uint32_t)lane < a.R) ? load_stream64(nbr_mask + (size_t)pfb_node * a.nbr_stride + lane) : 0ull;
+                    pfb_val = ((uint32_t)lane < R_v) ? load_stream32(nbrs_v + (size_t)pfb_node * nstride + lane) : VS_INVALID_NODE;
+                    if (nbr_mask) pfb_m = ((uint32_t)lane < R_v) ? load_stream64(nbr_mask + (size_t)pfb_node * nstride + lane) : 0ull;
                 }
             }
             // insert_neighbor in list order (AM/graph/mod.rs:144-147)
@@ -1578,8 +1643,8 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
             if (root_after != 0xFFFFFFFFu) {
                 pfa_node = node_of(root_after & smask, rfl(root_node_v));
                 pfa_h = root_after & smask;
-                pfa_val = ((uint32_t)lane < a.R) ? load_stream32(a.nbrs + (size_t)pfa_node * a.nbr_stride + lane) : VS_INVALID_NODE;
-                if (nbr_mask) pfa_m = ((uint32_t)lane < a.R) ? load_stream64(nbr_mask + (size_t)pfa_node * a.nbr_stride + lane) : 0ull;
+                pfa_val = ((uint32_t)lane < R_v) ? load_stream32(nbrs_v + (size_t)pfa_node * nstride + lane) : VS_INVALID_NODE;
+                if (nbr_mask) pfa_m = ((uint32_t)lane < R_v) ? load_stream64(nbr_mask + (size_t)pfa_node * nstride + lane) : 0ull;
             }
         }
         if (!pfb_issued) {
@@ -1596,7 +1661,27 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
         }
     }
     // one `next` call per emitted row, plus the call that found the stream exhausted
-    const uint32_t st_next = emitted + st_invis + ((emitted < s.M && status == 0) ? 1u : 0u);
+    const uint32_t st_next = next_base + emitted + (st_invis - invis_base) + ((emitted < s.M && status == 0) ? 1u : 0u);
+    if (RS) {  // save the scan for the next launch (a failed scan keeps its flag: the pool hands it to a cursor of its own)
+        wave_sync();
+        for (uint32_t i = 4u * lane; i < image_words; i += 4u * WAVE) *reinterpret_cast<uint4*>(rs + RSF_HDR + i) = *reinterpret_cast<const uint4*>(hp + i);
+        if (lane == 0) {
+            rs[RSF_INIT] = 1u;
+            rs[RSF_HLEN] = heap.len;
+            rs[RSF_VHEAD] = vis.head;
+            rs[RSF_VLEN] = vis.len;
+            rs[RSF_NINS_G] = nins_g;
+            rs[RSF_N_OVF] = n_ovf;
+            rs[RSF_HMAX] = hmax;
+            rs[RSF_VISITS] = st_visits;
+            rs[RSF_CAND] = st_cand;
+            rs[RSF_POPS] = st_pops;
+            rs[RSF_INVIS] = st_invis;
+            rs[RSF_STATUS] = status;
+            rs[RSF_NEXT] = st_next;
+            rs[RSF_ENDED] = ended ? 1u : 0u;
+        }
+    }
     if (status == 0) {
         for (uint32_t i = emitted + lane; i < s.M; i += WAVE) {
             s.out_ids[(size_t)q * s.M + i] = VS_INVALID_NODE;
@@ -1644,6 +1729,9 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
     }
 }
 
+// u32 words of one saved scan at these capacities (header + the LDS image: heap top, visited ring, occupancy bits)
+size_t fast_resume_words(const FastLaunch& s) { return RSF_HDR + ((size_t)(s.hl + 1) + 2 * (size_t)s.vcap + s.vwords + 3) / 4 * 4; }
+
 size_t fast_lds_bytes(const vs_index* idx, const FastLaunch& s) {
     const size_t nch = (idx->code_stride + 7) / 8;
     // LDS copy of the query code: the generic variant (NCH == 0), and the register-capped variants (minw >= 6: 8 NCH words, zero padded)
@@ -1687,6 +1775,11 @@ static int launch_fast_t(vs_index* idx, const FastArgs& a, size_t lds, uint32_t*
         if (a.s.vr == 8) return launch_fast_tt<3, 8, true, 1, false>(idx, a, lds, res);
         return launch_fast_tt<3, 0, true, 1, false>(idx, a, lds, res);
     }
+    if (a.s.resume) {  // resumable scans (the scan pools): one workgroup per pool slot, registers unconstrained
+        VS_REQUIRE(a.s.vwords && a.s.vslot == 2 && !a.s.persist && a.s.vr == 0 && a.s.lh == 0 && a.s.rc == 0 && !a.s.only_failed && a.s.pool_slots >= a.s.nq,
+                   "fast search: resumable scans run the 16-bit tables with one region per slot");
+        return launch_fast_tt<NCH, 0, false, 1, false, true, 3, OPT_RS>(idx, a, lds, res);
+    }
     if (a.s.vwords && a.s.vslot == 2) {  // 16-bit entries in buckets of eight + overflow table, occupancy bits in LDS (see fast_scan)
         VS_REQUIRE(a.s.vr == 0 && a.s.lh == 0 && a.s.rc == 0 && a.s.gcap >= 256 && (a.s.gcap & (a.s.gcap - 1)) == 0 && a.s.ocap % 32 == 0 && a.s.ocap >= 64 &&
                        (uint64_t)a.s.vwords * 32 >= (uint64_t)a.s.gcap + a.s.ocap && a.s.qk >= 3 && a.s.qk <= 16 && a.s.qd <= 32 &&
@@ -1695,9 +1788,9 @@ static int launch_fast_t(vs_index* idx, const FastArgs& a, size_t lds, uint32_t*
                    "fast search: bad geometry of the 16-bit dedup table");
         const bool plain = !a.s.qlabel_off && !a.s.visible && !(a.s.flags & FAST_FULL_VARIANT);
         // (the usual index: 24-word code rows — 768 x 2 bit, 1536 x 1 bit — and num_neighbors <= 64)
-        const bool std_geom = a.code_stride == 24 && a.R <= WAVE;
-        if (NCH == 3 && a.s.minw == 6 && plain && std_geom) return launch_fast_tt<3, 0, false, 6, false, false, 3, OPT_XW | OPT_R1>(idx, a, lds, res);
-        if (NCH == 3 && a.s.minw == 6 && std_geom) return launch_fast_tt<3, 0, false, 6, false, true, 3, OPT_XW | OPT_R1>(idx, a, lds, res);
+        const bool std_geom = a.code_stride == 24 && a.R <= WAVE && a.nbr_stride == 64;
+        if (NCH == 3 && a.s.minw == 6 && plain && std_geom) return launch_fast_tt<3, 0, false, 6, false, false, 3, OPT_XW | OPT_R1 | OPT_NS64>(idx, a, lds, res);
+        if (NCH == 3 && a.s.minw == 6 && std_geom) return launch_fast_tt<3, 0, false, 6, false, true, 3, OPT_XW | OPT_R1 | OPT_NS64>(idx, a, lds, res);
         if (NCH == 3 && a.s.minw == 6 && plain) return launch_fast_tt<3, 0, false, 6, false, false, 3>(idx, a, lds, res);
         if (NCH == 3 && a.s.minw == 6) return launch_fast_tt<3, 0, false, 6, false, true, 3>(idx, a, lds, res);
         if (NCH == 3 && a.s.minw == 7 && plain) return launch_fast_tt<3, 0, false, 7, false, false, 3>(idx, a, lds, res);

@@ -11,6 +11,14 @@ from helpers import TestIndex
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True, params=["resumable_fast_kernel", "general_kernel"])
+def pool_kernel(request, monkeypatch):
+    """round 6: a pool continues its scans with the resumable instantiation of k_search_fast where the index allows it; VS_POOL_FAST=0 keeps
+    the general kernel's path (plain storage, wide codes) — every test holds both to the oracle"""
+    monkeypatch.setenv("VS_POOL_FAST", "1" if request.param == "resumable_fast_kernel" else "0")
+    return request.param
+
 STAT_KEYS = ("visited_nodes", "candidate_nodes", "quantized_distance_comparisons", "full_distance_comparisons", "node_reads",
              "node_heap_reads", "next_calls")
 

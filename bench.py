@@ -847,7 +847,10 @@ def main():
                 "alg_bytes_per_launch": int(per_launch), "avg_kernel_ms": round(avg_ms, 4), "launches": s_n,
                 "scans_per_launch": nq, "kernel_ms_per_131072_scans": round(avg_ms * 131072 / max(nq, 1), 4),
                 "alg_bytes_per_query": round(alg_bytes_search / max(ptot.get("queries", 1) - ptot.get("fallback_scans", 0), 1), 1),
-                "timed_over": "the timed steps" if args.pipeline == 1 else
+                "timed_over": ("the timed steps" + ("" if traffic is None else
+                               f"; `traffic` is NOT measured in this run (rocprofv3 cannot run inside it): it is read from {traffic_source['file']}, two "
+                               f"--pmc passes over this script at this operating point on kernel sources with "
+                               f"{'the same' if traffic_source['same_kernel_sources_as_this_build'] else 'ANOTHER'} hash as this build")) if args.pipeline == 1 else
                               f"{args.warmup} sequential warm-up steps (the timed steps overlap two batches: a kernel's duration there "
                               "includes the other stream's kernels)"}
     kernels = {name: {"ms_total": round(ms, 3), "launches": cnt} for name, (ms, cnt) in prof.items() if cnt}
@@ -1009,6 +1012,51 @@ def main():
         except Exception as e:  # noqa: BLE001 — an extra never costs the headline line
             cursor_pool = {"error": repr(e)}
 
+    # ---- extras (never the value): LATENCY of `LIMIT k` scans, the quantity the reference's own claims are about (p95 latency and
+    # throughput ratios, /root/reference/README.md:17-21; a scan = amrescan + k amgettuple calls, AM/scan.rs:335-436).  N backend PROCESSES —
+    # plain C clients of the shared-memory server (pgvectorscale_amd/vs_shm_lat: no HIP, no device context, as a PostgreSQL backend) — run
+    # scans in a closed loop at 1 / 8 / 64 / 512 backends: p50 / p95 / p99 per scan and scans/s, at the reference's default GUCs and at the
+    # operating point of the headline value, the same 4096 queries at every level; the oracle's single-thread latency on the same
+    # queries is added by the cpu_baseline leg below
+    latency = None
+    if extras_on and ix.desc.storage_type == _lib.VS_STORAGE_SBQ:
+        try:
+            import subprocess
+            import tempfile
+            lat_bin = os.path.join(ROOT, "pgvectorscale_amd", "vs_shm_lat")
+            total = 4096 if not EMU else 12
+            levels = (1, 8, 64, 512) if not EMU else (1, 3)
+            qh_l = ctx.download(qbuf[0], np.empty((nq, dim), np.float32))[:total]
+            total = len(qh_l)
+            qf = tempfile.NamedTemporaryFile(prefix="vs_lat_q_", suffix=".f32", dir="/dev/shm" if os.path.isdir("/dev/shm") else None, delete=False)
+            qf.write(np.ascontiguousarray(qh_l).tobytes())
+            qf.close()
+            shm_name = f"/vs_bench_lat_{os.getpid()}"
+            latency = {"k": k, "scans_per_level": total, "gather_window_us": 50,
+                       "transport": "vs_shm_* (POSIX shared memory + futex; the dispatcher groups the scans posted within the gather window into one "
+                                    "launch); backends are processes (vs_shm_lat), closed loop, two untimed warm-up scans each",
+                       "points": {}}
+            srv = P.ShmServer(ix, shm_name, nslots=max(levels), kmax=max(k, 16), max_batch=512, max_wait_us=50)
+            try:
+                for pname, Lp, Sp in (("default_gucs", 100, 50), ("operating_point_of_the_value", L, S)):
+                    rows_ = []
+                    for nb_ in levels:
+                        reps_ = max(total // nb_, 1)
+                        cp = subprocess.run([lat_bin, shm_name, qf.name, str(dim), str(total), str(nb_), str(reps_), str(Lp), str(Sp), str(k)],
+                                            capture_output=True, text=True, timeout=300)
+                        line = [ln for ln in cp.stdout.splitlines() if ln.startswith("{")]
+                        rows_.append(json.loads(line[-1]) if line else {"backends": nb_, "error": (cp.stderr or "no output")[-200:]})
+                    cs = {r_.get("ids_checksum") for r_ in rows_ if r_.get("scans_per_backend", 0) * r_.get("backends", 0) == total}
+                    latency["points"][pname] = {"search_list_size": Lp, "rescore": Sp, "levels": rows_, "same_rows_at_every_level": len(cs) <= 1}
+            finally:
+                srv.close()
+                os.unlink(qf.name)
+            p1 = latency["points"]["default_gucs"]["levels"]
+            log("latency of LIMIT %d scans at the default GUCs: " % k + ", ".join(
+                f"{r_.get('backends')} backends p50 {r_.get('p50_us', 0) / 1e3:.2f} / p95 {r_.get('p95_us', 0) / 1e3:.2f} ms ({r_.get('scans_per_s', 0):.0f}/s)" for r_ in p1))
+        except Exception as e:  # noqa: BLE001 — an extra never costs the headline line
+            latency = {"error": repr(e)}
+
     result = {
         "metric": f"QPS at recall@{k}>={args.recall_target:g}",
         "value": round(qps, 1),
@@ -1058,6 +1106,7 @@ def main():
         "setup_s": setup,
         "default_gucs": default_gucs,
         "cursor_pool": cursor_pool,
+        "latency": latency,
         "harder_corpus": None,
     }
 
@@ -1089,7 +1138,10 @@ def main():
 
             # single-thread latency first (the reference is one backend per query, AM/mod.rs:63), then a thread sweep: the
             # budget (--cpu-seconds) is split over the points, each point runs enough queries for about its share
-            one = min(nq, 48)
+            # (round 6: an untimed warm pass first, then 512 queries — the 48 cold queries of round 5 put the single-thread rate 30 % below
+            # the thread sweep's own one-thread point and `consistent` came out false)
+            cpu_run(min(nq, 64), 1)
+            one = min(nq, 512)
             t_one, _ = cpu_run(one, 1)
             cpu1 = t_one / one
             points = []
@@ -1137,6 +1189,16 @@ def main():
                 "gpu_rows_identical": bool((g_ids == o_ids).all()),
                 "gpu_dist_bit_identical_frac": float((g_dist.view(np.uint32) == o_dist.view(np.uint32)).mean()),
             }
+            if isinstance(result.get("latency"), dict) and "points" in result["latency"]:  # the oracle, one thread, the same queries
+                try:
+                    nlq = min(nq, 256)
+                    t1 = time.time()
+                    oidx.search_batch(qh[:nlq], L=100, rescore=50, k=k, threads=1, qlabels=hk and hk[:nlq])
+                    result["latency"]["cpu_oracle_single_thread_ms"] = {"default_gucs": round((time.time() - t1) / nlq * 1e3, 3),
+                                                                          "operating_point_of_the_value": round(cpu1 * 1e3, 3),
+                                                                          "note": "oracle (port of the reference path on flat arrays), one thread, no PostgreSQL buffer / heap cost"}
+                except Exception as e:  # noqa: BLE001
+                    result["latency"]["cpu_oracle_single_thread_ms"] = {"error": repr(e)}
             result["speedup_vs_cpu_baseline"] = round(qps / cpu_qps, 1)
             result["speedup_vs_one_cpu_thread"] = round(qps * cpu1, 1)
         except Exception as e:  # the GPU numbers stay valid without the baseline
@@ -1150,13 +1212,13 @@ def main():
         comm.close()
     ix.close()
     ctx.close()
-    # ---- extras: a harder corpus (never the value).  A child run of this script on 10M vectors of the `mid` corpus (64-dimensional latent
+    # ---- extras: a harder corpus (never the value).  A child run of this script on 20M vectors (10M until round 5) of the `mid` corpus (64-dimensional latent
     # space, wider clusters, 30 % isotropic noise), after this process has given its HBM back: own index build, own operating point,
     # own recall checks and CPU parity; its line is embedded here in short
     if extras_on and rank == 0:
         import subprocess
         t0 = time.time()
-        cmd = [sys.executable, os.path.abspath(__file__), "--n", "500" if EMU else "10000000", "--corpus-kind", "mid", "--extras", "off", "--steps", "3",
+        cmd = [sys.executable, os.path.abspath(__file__), "--n", "500" if EMU else "20000000", "--corpus-kind", "mid", "--extras", "off", "--steps", "3",
                "--warmup", "1", "--cpu-seconds", "4", "--pcie-steps", "0", "--scan-nq", "0", "--graph-cache", "none", "--distance", args.distance]
         if EMU:
             cmd += ["--nq", "16", "--dim", str(dim), "--recall-queries", "16", "--validate-queries", "16", "--heldout-queries", "16", "--build-l", "20"]
@@ -1183,7 +1245,7 @@ def main():
                 "gpu_rows_identical": (hj.get("cpu_baseline") or {}).get("gpu_rows_identical"),
                 "setup_s": hj.get("setup_s"),
                 "note": "a child run of this script after the headline index was freed; not the configuration the value is quoted on"}
-            log(f"harder corpus (10M mid, {result['harder_corpus']['seconds']} s): {hj['value']:.0f} QPS at L={hj['config']['search_list_size']} "
+            log(f"harder corpus (20M mid, {result['harder_corpus']['seconds']} s): {hj['value']:.0f} QPS at L={hj['config']['search_list_size']} "
                 f"rescore={hj['config']['rescore']}, met={hj['recall_target_met']}")
         except Exception as e:  # noqa: BLE001
             result["harder_corpus"] = {"error": repr(e), "seconds": round(time.time() - t0, 1)}

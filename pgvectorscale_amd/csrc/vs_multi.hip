@@ -21,6 +21,10 @@
 #include <mutex>
 #include <system_error>
 #include <thread>
+#include <condition_variable>
+#include <functional>
+#include <memory>
+#include <mutex>
 
 #include "vs_internal.h"
 
@@ -139,17 +143,69 @@ extern "C" int vs_index_replicate(vs_index* src, vs_ctx* c, vs_index** out) {
 // ---------------------------------------------------------------------------------------------------------------
 // vs_multi: one process, N devices
 // ---------------------------------------------------------------------------------------------------------------
+// One PERSISTENT worker thread per device after the first (round 6; a thread was spawned per device per batch until round 5): the
+// thread that runs a device's shard is the same from batch to batch — HIP keeps per-thread state (current device, the error slot),
+// thread creation costs tens of microseconds a batch, and a deployment wants to pin it.  A worker sleeps on its condition variable
+// between batches; a worker that could not be started leaves its shard to the caller's thread.
+struct MultiWorker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::function<void()> task;  // non-empty: posted, not yet finished
+    bool busy = false, stop = false, started = false;
+    void loop() {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv.wait(lk, [&] { return stop || (busy && task); });
+            if (stop) return;
+            std::function<void()> t = std::move(task);
+            task = nullptr;
+            lk.unlock();
+            t();
+            lk.lock();
+            busy = false;
+            cv.notify_all();
+        }
+    }
+    bool post(std::function<void()> t) {
+        if (!started) return false;
+        std::lock_guard<std::mutex> g(mu);
+        task = std::move(t);
+        busy = true;
+        cv.notify_all();
+        return true;
+    }
+    void wait() {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return !busy; });
+    }
+    void shutdown() {
+        if (!started) return;
+        {
+            std::lock_guard<std::mutex> g(mu);
+            stop = true;
+            cv.notify_all();
+        }
+        if (th.joinable()) th.join();
+        started = false;
+    }
+};
+
 struct vs_multi {
     struct Dev {
         vs_ctx* ctx = nullptr;
         vs_index* ix = nullptr;
         bool own_ix = true;
+        std::unique_ptr<MultiWorker> worker;  // (none for the first device: its shard runs on the caller's thread)
     };
     std::vector<Dev> devs;
+    std::mutex batch_mu;  // one batch at a time per vs_multi (the workers hold one task each)
 };
 
 extern "C" void vs_multi_destroy(vs_multi* m) {
     if (!m) return;
+    for (auto& d : m->devs)
+        if (d.worker) d.worker->shutdown();
     for (auto& d : m->devs) {
         if (d.ix && d.own_ix) vs_index_free(d.ix);
         if (d.ctx) vs_ctx_destroy(d.ctx);
@@ -182,6 +238,16 @@ static int vs_multi_create_impl(vs_index* src, const int* devices, uint32_t n, u
         }
         if (r != VS_OK) return fail(r);
     }
+    for (uint32_t i = 1; i < n; ++i) {
+        vs_multi::Dev& d = m->devs[i];
+        d.worker.reset(new MultiWorker());
+        try {
+            d.worker->th = std::thread([w = d.worker.get()] { w->loop(); });
+            d.worker->started = true;
+        } catch (const std::system_error&) {
+            d.worker.reset();  // (its shard runs on the caller's thread)
+        }
+    }
     *out = m;
     return VS_OK;
 }
@@ -210,6 +276,7 @@ static int vs_multi_search_impl(vs_multi* m, const float* queries, const int16_t
     std::vector<std::string> err(world);
     std::vector<vs_stats> st(world);
     auto work = [&](uint32_t g) {
+        try {
         uint32_t b, e;
         shard_of(nq, world, g, &b, &e);
         memset(&st[g], 0, sizeof(vs_stats));
@@ -233,21 +300,25 @@ static int vs_multi_search_impl(vs_multi* m, const float* queries, const int16_t
                                 out_dist ? out_dist + (size_t)b * k : nullptr, &st[g]);
         rc[g] = r;
         if (r != VS_OK) err[g] = vs_last_error();  // (thread-local: carried to the caller's thread below)
-    };
-    // (a thread that cannot be created — std::system_error — must not unwind past joinable threads: its shard runs inline)
-    std::vector<std::thread> th;
-    th.reserve(world);
-    std::vector<uint32_t> inline_shards;
-    for (uint32_t g = 1; g < world; ++g) {
-        try {
-            th.emplace_back(work, g);
-        } catch (const std::system_error&) {
-            inline_shards.push_back(g);
+        } catch (const std::exception& ex) {  // (nothing may leave a worker thread)
+            rc[g] = VS_ERR_OOM;
+            try {
+                err[g] = ex.what();
+            } catch (...) {
+            }
         }
+    };
+    // every shard but the first on its device's persistent worker; a device without one (thread creation failed) on this thread
+    std::lock_guard<std::mutex> batch(m->batch_mu);
+    std::vector<uint32_t> inline_shards, posted;
+    for (uint32_t g = 1; g < world; ++g) {
+        MultiWorker* w = m->devs[g].worker.get();
+        if (w && w->post([&work, g] { work(g); })) posted.push_back(g);
+        else inline_shards.push_back(g);
     }
     work(0);
     for (uint32_t g : inline_shards) work(g);
-    for (auto& t : th) t.join();
+    for (uint32_t g : posted) m->devs[g].worker->wait();
     for (uint32_t g = 0; g < world; ++g) {
         if (rc[g] != VS_OK) {
             vs_set_error("vs_multi_search_batch: device %d (shard %u of %u): %s", m->devs[g].ctx->device, g, world, err[g].c_str());

@@ -314,30 +314,31 @@ struct FastHeap {
         auto level = [&](const uint32_t k, const uint32_t ak) {  // ak: the node's original value
             const uint32_t B1 = (1u << k) - 1u;
             const uint32_t comp = in ? (((c >> sb) << 7) | (forced ? 63u - i : 65u + i)) : IDENT;
-            // exclusive prefix minimum inside the aligned block of 2^k lanes
+            // exclusive prefix minimum inside the aligned block of 2^k lanes: the values shifted by one lane (a block's first lane starts
+            // from the identity), then an inclusive scan whose steps cannot leave the block BY CONSTRUCTION (round 6; the row_shr steps
+            // of round 3 needed a compare + select per step to cut them at the block boundaries): inside a quad quad_perm moves, across
+            // the two quads of an 8-lane block the first quad's last lane broadcast into the second (bank mask 0b1010), whole 16-lane
+            // rows with row_shr (a row boundary ends a DPP move anyway), and row 1 / 3 of a 32-lane block take lane 15 of the row below
+            // (row_bcast:15, row mask 0b1010).  Every move is folded into its v_min_u32 (old = the identity).
+#define VS_DMIN(v, src, ctrl, rmask, bmask) min((v), (uint32_t)__builtin_amdgcn_update_dpp((int)IDENT, (int)(src), (ctrl), (rmask), (bmask), false))
             uint32_t x = wave_shr1(comp, IDENT);
             if (((uint32_t)lane & B1) == 0) x = IDENT;
-            if (k >= 2) {
-                uint32_t t1 = (uint32_t)__builtin_amdgcn_update_dpp((int)IDENT, (int)x, 0x111, 0xF, 0xF, false);
-                if (B1 < 15u && ((uint32_t)lane & B1) < 1u) t1 = IDENT;
-                x = min(x, t1);
-                uint32_t t2 = (uint32_t)__builtin_amdgcn_update_dpp((int)IDENT, (int)x, 0x112, 0xF, 0xF, false);
-                if (B1 < 15u && ((uint32_t)lane & B1) < 2u) t2 = IDENT;
-                x = min(x, t2);
+            if (k == 2 || k == 3) {
+                x = VS_DMIN(x, x, 0x90 /* quad_perm [0,0,1,2] */, 0xF, 0xF);
+                x = VS_DMIN(x, x, 0x44 /* quad_perm [0,1,0,1] */, 0xF, 0xF);
             }
-            if (k >= 3) {
-                uint32_t t4 = (uint32_t)__builtin_amdgcn_update_dpp((int)IDENT, (int)x, 0x114, 0xF, 0xF, false);
-                if (B1 < 15u && ((uint32_t)lane & B1) < 4u) t4 = IDENT;
-                x = min(x, t4);
+            if (k == 3) {
+                const uint32_t q3 = (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xFF /* quad_perm [3,3,3,3] */, 0xF, 0xF, true);
+                x = VS_DMIN(x, q3, 0x114 /* row_shr:4 */, 0xF, 0xA);
             }
             if (k >= 4) {
-                const uint32_t t8 = (uint32_t)__builtin_amdgcn_update_dpp((int)IDENT, (int)x, 0x118, 0xF, 0xF, false);
-                x = min(x, t8);
+                x = VS_DMIN(x, x, 0x111, 0xF, 0xF);
+                x = VS_DMIN(x, x, 0x112, 0xF, 0xF);
+                x = VS_DMIN(x, x, 0x114, 0xF, 0xF);
+                x = VS_DMIN(x, x, 0x118, 0xF, 0xF);
             }
-            if (k >= 5) {
-                const uint32_t t16 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((((uint32_t)lane & ~31u) + 15u) << 2), (int)x);
-                if ((uint32_t)lane & 16u) x = min(x, t16);
-            }
+            if (k >= 5) x = VS_DMIN(x, x, 0x142 /* row_bcast:15 */, 0xA, 0xF);
+#undef VS_DMIN
             const uint32_t cur = min(x, ((ak >> sb) << 7) | 64u);  // what the node holds when this push arrives
             const uint32_t tb = cur & 127u;
             const uint32_t src = (tb < 64u ? 63u - tb : tb - 65u) + off;  // lane of the push that brought it
@@ -1793,6 +1794,7 @@ static int launch_fast_t(vs_index* idx, const FastArgs& a, size_t lds, uint32_t*
         if (NCH == 3 && a.s.minw == 6 && std_geom) return launch_fast_tt<3, 0, false, 6, false, true, 3, OPT_XW | OPT_R1 | OPT_NS64>(idx, a, lds, res);
         if (NCH == 3 && a.s.minw == 6 && plain) return launch_fast_tt<3, 0, false, 6, false, false, 3>(idx, a, lds, res);
         if (NCH == 3 && a.s.minw == 6) return launch_fast_tt<3, 0, false, 6, false, true, 3>(idx, a, lds, res);
+        if (NCH == 3 && a.s.minw == 7 && plain && std_geom) return launch_fast_tt<3, 0, false, 7, false, false, 3, OPT_XW | OPT_R1 | OPT_NS64>(idx, a, lds, res);
         if (NCH == 3 && a.s.minw == 7 && plain) return launch_fast_tt<3, 0, false, 7, false, false, 3>(idx, a, lds, res);
         if (NCH == 3 && a.s.minw == 7) return launch_fast_tt<3, 0, false, 7, false, true, 3>(idx, a, lds, res);
         return launch_fast_tt<NCH, 0, false, 1, false, true, 3>(idx, a, lds, res);

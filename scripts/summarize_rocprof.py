@@ -28,7 +28,7 @@ def full_launches(trace_path, kernel="k_search_fast", min_ms=1.0):
     d = [dur(r) for r in full]
     # the timed region of bench.py is its last `steps` full launches (the earlier ones: warm-up, validation and held-out batches)
     r0 = max(full, key=dur)
-    return {"grid": int(r0["Grid_Size_X"]), "calls": len(d), "avg_ms": sum(d) / len(d), "min_ms": min(d), "max_ms": max(d),
+    return {"name": re.sub(r"^void\s+", "", r0["Kernel_Name"]), "grid": int(r0["Grid_Size_X"]), "calls": len(d), "avg_ms": sum(d) / len(d), "min_ms": min(d), "max_ms": max(d),
             "last20_avg_ms": sum(d[-20:]) / len(d[-20:]), "vgpr": r0["VGPR_Count"], "sgpr": r0["SGPR_Count"], "lds": r0["LDS_Block_Size"],
             "scratch": r0["Scratch_Size"]}
 
@@ -45,7 +45,22 @@ def main(src, dst, note=""):
             f.write(f"# k_search_fast, full launches only (grid {fl['grid']} threads = {fl['grid'] // 64} single-wave workgroups, within 2x of the longest; from the kernel "
                     f"trace of the same run): calls={fl['calls']} avg_ms={fl['avg_ms']:.3f} min_ms={fl['min_ms']:.3f} max_ms={fl['max_ms']:.3f} "
                     f"last_20_avg_ms={fl['last20_avg_ms']:.3f} "
-                    f"VGPRs={fl['vgpr']} SGPRs={fl['sgpr']} LDS={fl['lds']} B scratch={fl['scratch']} B\n")
+                    f"(rocprofv3's launch-time fields: VGPRs={fl['vgpr']} SGPRs={fl['sgpr']} LDS={fl['lds']} B scratch={fl['scratch']} B — allocation "
+                    f"granules, dynamic LDS not included; the code object's own numbers follow)\n")
+            # what the hardware runs: the AMDGPU metadata notes of the instantiation the trace names
+            try:
+                sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+                import codeobj_notes
+                root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+                want = re.sub(r"\s+", "", fl["name"].split("(")[0])
+                for d in codeobj_notes.kernels(os.path.join(root, "pgvectorscale_amd", "csrc", "vs_search_fast.o")):
+                    if re.sub(r"\s+", "", d["demangled"].split("(")[0].replace("void ", "")) == want:
+                        f.write(f"# code object (llvm-readelf --notes on csrc/vs_search_fast.o), {d['demangled'].split('(')[0]}: {codeobj_notes.line(d)}\n")
+                        break
+                else:
+                    f.write(f"# code object: no instantiation named {want} in csrc/vs_search_fast.o\n")
+            except Exception as e:  # noqa: BLE001
+                f.write(f"# code object notes unavailable: {e!r}\n")
         f.write("kernel,calls,total_ms,avg_us,min_us,max_us,pct\n")
         for r in rows:
             f.write(f"{short(r['Name'])},{r['Calls']},{float(r['TotalDurationNs'])/1e6:.3f},{float(r['AverageNs'])/1e3:.1f},"

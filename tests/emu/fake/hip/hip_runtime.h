@@ -105,7 +105,7 @@ static inline int emu_readlane(int v, int lane, const char* f, int l) {
 #define __builtin_amdgcn_readlane(v, lane) emu_readlane((v), (lane), __FILE__, __LINE__)
 
 // DPP controls used by this code base: quad_perm (0x00-0xFF), row_shl:n (0x101-0x10F), row_shr:n (0x111-0x11F),
-// row_ror:n (0x121-0x12F), wave_shl:1 (0x130),
+// row_ror:n (0x121-0x12F), row_bcast:15 / 31 (0x142, 0x143), wave_shl:1 (0x130),
 // wave_shr:1 (0x138).  A lane whose source is out of range or inactive keeps `old` (or gets 0 with bound_ctrl).
 static inline int emu_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl, const char* f, int l) {
     const emu::Snap s = emu::wave_exchange((uint32_t)src, f, l);
@@ -115,6 +115,8 @@ static inline int emu_dpp(int old, int src, int ctrl, int row_mask, int bank_mas
     else if (ctrl >= 0x101 && ctrl <= 0x10F) { const int n = ctrl & 0xF; from = (me & 15) + n < 16 ? me + n : -1; }      // row_shl:n
     else if (ctrl >= 0x111 && ctrl <= 0x11F) { const int n = ctrl & 0xF; from = (me & 15) >= n ? me - n : -1; }           // row_shr:n
     else if (ctrl >= 0x121 && ctrl <= 0x12F) { const int n = ctrl & 0xF; from = (me & ~15) | (((me & 15) - n) & 15); }    // row_ror:n
+    else if (ctrl == 0x142) from = me >= 16 ? ((me >> 4) - 1) * 16 + 15 : -1;  // row_bcast:15 (lane 15 of a row to every lane of the next row)
+    else if (ctrl == 0x143) from = me >= 32 ? 31 : -1;                         // row_bcast:31
     else if (ctrl == 0x130) from = me + 1 < 64 ? me + 1 : -1;
     else if (ctrl == 0x138) from = me >= 1 ? me - 1 : -1;
     else { fprintf(stderr, "emu: DPP control 0x%x not implemented (%s:%d)\n", ctrl, f, l); abort(); }

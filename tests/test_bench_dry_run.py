@@ -108,3 +108,38 @@ def test_bench_extras_small():
         assert cp[mode]["rows_identical_to_cursor_per_scan"] is True and cp[mode]["all_scans_ms"] > 0
     assert "error" not in hc, hc
     assert hc["gpu_rows_identical"] is True and isinstance(hc["recall_target_met"], bool) and "mid" in hc["corpus"]
+    # the latency leg (round 6): backend processes (pgvectorscale_amd/vs_shm_lat, plain C clients of the shared-memory server) at two
+    # concurrency levels, two operating points, the oracle's single-thread latency next to them
+    lt = j["latency"]
+    assert "error" not in lt, lt
+    for point in ("default_gucs", "operating_point_of_the_value"):
+        lv = lt["points"][point]["levels"]
+        assert [r_["backends"] for r_ in lv] == [1, 3] and all("error" not in r_ and r_["p50_us"] > 0 and r_["p95_us"] >= r_["p50_us"] and r_["p99_us"] >= r_["p95_us"]
+                                                                 for r_ in lv), lv
+        assert lt["points"][point]["same_rows_at_every_level"] is True
+    assert lt["cpu_oracle_single_thread_ms"]["default_gucs"] > 0 and lt["cpu_oracle_single_thread_ms"]["operating_point_of_the_value"] > 0
+    assert j["cpu_baseline"]["consistent"] in (True, False) and j["cpu_baseline"]["single_thread_qps"] > 0
+
+
+def test_bench_eight_emulated_devices():
+    """DEFAULT CPU tier: the driver's N = 8 launch line (torch.distributed.run, one rank per GPU) on the interpreter — eight processes,
+    rank 0 builds the graph and vs_comm_bcast hands it to the seven others over the stand-in RCCL, every rank searches its own block
+    (a query count that does not divide by eight on purpose: the pooled held-out rows are uneven), one vs_comm_gather_topk per step,
+    ONE JSON line from rank 0.  No 8-GPU node was available to any round: this is what `bench.py --gpus 8` has been through."""
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "emu"), "-j8", "-s"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    env = dict(os.environ, VS_EMU="1", VS_EMU_THREADS="1", VS_EMU_DEVICES="8", VS_F_LDS_MAX_INS="0", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", "29531", os.path.join(ROOT, "bench.py"), "--gpus", "8", "--corpus", "900", "--dim", "32", "--nq", "12",
+           "--steps", "2", "--warmup", "1", "--recall-queries", "6", "--validate-queries", "10", "--heldout-queries", "10",
+           "--scan-nq", "0", "--cpu-seconds", "1", "--graph-cache", "none", "--fixed", "20,10"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, cwd=ROOT, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line (rank 0)"
+    j = json.loads(lines[-1])
+    assert j["n_gpus"] == 8 and j["scaling"] == "weak" and "query-sharded x8" in j["config"]["parallelism"]
+    assert "vs_comm_gather_topk" in j["config"]["topk_gather"]
+    assert "graph_build_s" in j["setup_s"] and "graph_broadcast_s" in j["setup_s"]
+    assert j["recall_heldout_queries"] == 80  # 10 per rank, pooled
+    assert j["value"] > 0 and j["steps"] == 2

@@ -870,10 +870,10 @@ def main():
             if dt == P.VS_COSINE:
                 qh_s = qh_s / np.linalg.norm(qh_s, axis=1, keepdims=True)
             qcodes = ix.quantize(qh_s)
-            prev_q = os.environ.get("VS_SCAN_Q")
+            prev_q = P.get_option("VS_SCAN_Q")
             tiles_tried = []
             for qt in ((4, 8, 16) if prev_q is None else (int(prev_q),)):
-                os.environ["VS_SCAN_Q"] = str(qt)
+                P.set_option("VS_SCAN_Q", qt)  # (through the C ABI: vs_set_option)
                 ix.scan_topk(qcodes, k)  # warm-up
                 ctx.profile_enable(True)
                 ctx.profile_read(reset=True)
@@ -891,7 +891,7 @@ def main():
                                     "frac": round(sc_gbps / 8000.0, 4),
                                     "queries_per_s": round(args.scan_nq / (sc_ms * 1e-3), 1)})
             if prev_q is None:
-                os.environ.pop("VS_SCAN_Q", None)
+                P.set_option("VS_SCAN_Q", None)
             top = max(tiles_tried, key=lambda t: t["achieved"])
             fastest = min(tiles_tried, key=lambda t: t["avg_kernel_ms"])
             scan_roofline = {"bound": "hbm", "kernel": "k_scan_topk", "achieved": top["achieved"], "peak": 8000.0,

@@ -103,6 +103,15 @@ typedef struct vs_stats {
 } vs_stats;
 
 const char* vs_last_error(void);
+
+/* Tuning options (launch variants, capacities, slab placement, diagnostics), process wide.  `name` is one of the
+ * VS_* names listed there, `value` its text ("3", "0", a path ...; NULL unsets it again).  An option set here wins over the environment
+ * variable of the same name; the environment itself is only SNAPSHOT — at the first lookup and again when the process's VS_* variables
+ * change — never searched on the launch path.  No reference counterpart: these are the knobs of this implementation (the reference's
+ * own GUCs, diskann.query_search_list_size and diskann.query_rescore, are arguments of vs_rescan / vs_search_batch).  Thread safe.
+ * vs_get_option: 1 = set (copied to out, truncated to cap), 0 = set nowhere (out = ""). */
+int vs_set_option(const char* name, const char* value);
+int vs_get_option(const char* name, char* out, size_t cap);
 const char* vs_version(void);
 
 /* ---- context ------------------------------------------------------------------------------------------------- */

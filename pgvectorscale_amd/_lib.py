@@ -118,6 +118,8 @@ class DatagenParams(C.Structure):
 _vp, _u32, _u64, _i, _sz = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int, C.c_size_t
 SYMBOLS = {
     "vs_last_error": (C.c_char_p, []),
+    "vs_set_option": (_i, [C.c_char_p, C.c_char_p]),
+    "vs_get_option": (_i, [C.c_char_p, C.c_char_p, C.c_size_t]),
     "vs_version": (C.c_char_p, []),
     "vs_ctx_create": (_i, [_i, C.POINTER(_vp)]),
     "vs_ctx_create_staging": (_i, [_i, _sz, C.POINTER(_vp)]),

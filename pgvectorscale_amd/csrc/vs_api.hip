@@ -528,7 +528,7 @@ extern "C" int vs_dev_free(vs_ctx* c, void* p) {
 // 8 MiB and more are split over a few threads (VS_STAGE_THREADS, default 4; 1 = the plain memcpy).
 static unsigned stage_threads() {
     static const unsigned nt_cfg = [] {
-        const char* e = getenv("VS_STAGE_THREADS");
+        const char* e = vs_opt_get("VS_STAGE_THREADS");
         const unsigned v = e && *e ? (unsigned)strtoul(e, nullptr, 10) : 4u;
         return std::min(std::max(v, 1u), 16u);
     }();
@@ -1271,13 +1271,13 @@ struct Caps {
 };
 
 static uint32_t env_u32(const char* name, uint32_t dflt) {
-    const char* v = getenv(name);
+    const char* v = vs_opt_get(name);
     return v && *v ? (uint32_t)strtoul(v, nullptr, 10) : dflt;
 }
 
 // a launch knob: the environment variable when set, else the index's tuned variant (vs_index_autotune), else the default
 static uint32_t knob_u32(const char* name, int tuned, uint32_t dflt) {
-    const char* v = getenv(name);
+    const char* v = vs_opt_get(name);
     if (v && *v) return (uint32_t)strtoul(v, nullptr, 10);
     return tuned >= 0 ? (uint32_t)tuned : dflt;
 }
@@ -1316,7 +1316,7 @@ static Caps initial_caps(const vs_index* ix, uint32_t L, uint32_t M) {
     c.f_lh = env_u32("VS_F_LH", lds_table ? (uint32_t)round_up_u32((uint32_t)typ_ins, 64) : 0u);
     c.f_pool_frac = !lds_table ? 1.0
                     : (ix->obs.valid && ix->obs.L == L && ix->obs.M == M) ? std::min(1.0, 2.0 * ix->obs.ov_frac + 0.03) : 1.0;
-    if (const char* e = getenv("VS_F_POOL")) c.f_pool_frac = std::min(1.0, std::max(0.01, atof(e)));
+    if (const char* e = vs_opt_get("VS_F_POOL")) c.f_pool_frac = std::min(1.0, std::max(0.01, atof(e)));
     // LDS heap levels: spilling the bottom level to global memory costs every pop / push an L2 round trip, so the heap
     // gets LDS for about 3/4 of the ids a scan inserts (its typical final size) once that is known
     uint32_t hl_auto = 1023;
@@ -1368,7 +1368,7 @@ static Caps initial_caps(const vs_index* ix, uint32_t L, uint32_t M) {
 }
 
 static uint32_t fast_pool_slots(uint32_t nq, double frac) {
-    const uint64_t floor_slots = getenv("VS_F_POOL") ? 1 : 256;  // (the override exists to exercise pool exhaustion in tests)
+    const uint64_t floor_slots = vs_opt_get("VS_F_POOL") ? 1 : 256;  // (the override exists to exercise pool exhaustion in tests)
     return (uint32_t)std::min<uint64_t>(nq, std::max<uint64_t>(floor_slots, (uint64_t)(frac * nq) + 1));
 }
 static uint32_t general_pool_slots(uint32_t nq) { return std::max<uint32_t>(64, nq / 64); }
@@ -1648,8 +1648,10 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
             VS_HIP(hipMemsetAsync(w.phase.p, 0, (size_t)nq * 64, c->stream));
             f.phase = (uint64_t*)w.phase.p;
         }
-        const char* const tl_path = getenv("VS_TIMELINE");  // diagnostics: start / end of every scan of this launch, dumped to a file
-        if (tl_path && *tl_path) {
+        const char* const tl_opt = vs_opt_get("VS_TIMELINE");  // diagnostics: start / end of every scan of this launch, dumped to a file
+        const std::string tl_s = tl_opt ? tl_opt : "";  // (the option's pointer lives until this thread's next lookup)
+        const char* const tl_path = tl_s.c_str();
+        if (*tl_path) {
             VS_TRY(devbuf_reserve(c, w.timeline, (size_t)nq * 16));
             VS_HIP(hipMemsetAsync(w.timeline.p, 0, (size_t)nq * 16, c->stream));
             f.timeline = (uint64_t*)w.timeline.p;
@@ -2257,7 +2259,9 @@ static int vs_index_autotune_impl(vs_index* ix, const float* d_q, const int16_t*
     TuneRun base{};
     const bool w24 = (ix->code_stride + 7) / 8 == 3;
 #ifdef VS_TEST_HOOKS  // (the interpreter build of the test tier: the named variant's rows are damaged before the comparison)
-    const char* sabotage = getenv("VS_TUNE_SABOTAGE");
+    const char* const sabotage_opt = vs_opt_get("VS_TUNE_SABOTAGE");  // (the pointer lives until this thread's next lookup: copied)
+    const std::string sabotage_s = sabotage_opt ? sabotage_opt : "";
+    const char* sabotage = sabotage_opt ? sabotage_s.c_str() : nullptr;
 #else
     const char* sabotage = nullptr;
 #endif

@@ -33,6 +33,7 @@
 #include "../../include/vsgpu.h"
 
 void vs_set_error(const char* fmt, ...);
+const char* vs_opt_get(const char* name);  // vs_options.cpp: the option table (vs_set_option, snapshot of the VS_* environment)
 
 namespace {
 
@@ -295,7 +296,7 @@ int vs_broker_create(vs_index* idx, const vs_broker_config* cfg, vs_broker** out
     b->cfg.max_wait_us = cfg ? cfg->max_wait_us : 200;
     b->cfg.cursor_lanes = cfg ? std::min<uint32_t>(cfg->cursor_lanes, 64) : 0;
     if (!b->cfg.cursor_lanes)  // (VS_BROKER_LANES: the default for brokers created without a lane count — how the whole broker
-        if (const char* e = getenv("VS_BROKER_LANES")) b->cfg.cursor_lanes = std::min<uint32_t>((uint32_t)strtoul(e, nullptr, 10), 64);  // test tier runs on lanes)
+        if (const char* e = vs_opt_get("VS_BROKER_LANES")) b->cfg.cursor_lanes = std::min<uint32_t>((uint32_t)strtoul(e, nullptr, 10), 64);  // test tier runs on lanes)
     for (uint32_t i = 0; i < b->cfg.cursor_lanes; ++i) {
         std::unique_ptr<Lane> ln(new (std::nothrow) Lane());
         rc = ln ? vs_ctx_create_staging(vs_index_device(idx), (size_t)1 << 20, &ln->ctx) : VS_ERR_OOM;  // (a lane moves one query in and a few rows out)

@@ -577,7 +577,7 @@ static int build_graph_impl(vs_index* ix, uint32_t L, double max_alpha_d, uint32
     // re-runs the scans that outgrow it.  Same operating-point rule as for queries: dedup table in LDS for small graphs,
     // table-less (global table, high occupancy) once a search inserts more ids than an LDS table should hold.
     FastLaunch f{};
-    bool use_fast = getenv("VS_BUILD_FAST") ? atoi(getenv("VS_BUILD_FAST")) != 0 : true;
+    bool use_fast = vs_opt_get("VS_BUILD_FAST") ? atoi(vs_opt_get("VS_BUILD_FAST")) != 0 : true;
     {
         const uint64_t nbits = (uint64_t)ix->d.dim_index * ix->d.bits;
         const uint32_t typ_ins = (L + L / 4 + 16) * std::min<uint32_t>(R, 16);
@@ -723,7 +723,7 @@ static int build_graph_impl(vs_index* ix, uint32_t L, double max_alpha_d, uint32
 
     // repair pass (see k_reach_sweep): rounds of { reachable set, in-edges for the nodes outside it } until a sweep finds every
     // node (at most eight); what the last sweep still could not reach is reported by vs_index_build_unreachable()
-    const char* rep_env = getenv("VS_BUILD_REPAIR");
+    const char* rep_env = vs_opt_get("VS_BUILD_REPAIR");
     if (n > 2 && !(rep_env && *rep_env == '0')) {
         VS_HIP(hipMalloc(&B.mark, (size_t)n + 8));  // n flags, then (4-byte aligned) the `changed` word
         uint32_t* d_changed = reinterpret_cast<uint32_t*>(B.mark + (((size_t)n + 3) & ~(size_t)3));

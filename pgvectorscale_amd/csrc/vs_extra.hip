@@ -527,7 +527,7 @@ __global__ __launch_bounds__(256) void k_nbr_masks(const uint32_t* __restrict__ 
 extern "C" int vs_index_has_neighbor_masks(const vs_index* ix) { return ix && ix->nbr_mask_valid ? 1 : 0; }
 
 bool vs_neighbor_masks_wanted(const vs_index* ix) {
-    const char* e = getenv("VS_F_NBRMASK");
+    const char* e = vs_opt_get("VS_F_NBRMASK");
     if (e && *e == '0') return false;
     if (e && *e == '1') return true;
     return ix->d.n > (8u << 20);

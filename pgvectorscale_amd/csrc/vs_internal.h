@@ -15,6 +15,8 @@
 #define VS_EMPTY 0xFFFFFFFFu
 
 void vs_set_error(const char* fmt, ...);
+// vs_options.cpp: the option table (vs_set_option, else a snapshot of the VS_* environment refreshed only when it changes); nullptr = unset
+const char* vs_opt_get(const char* name);
 
 #define VS_HIP(expr)                                                                                   \
     do {                                                                                               \

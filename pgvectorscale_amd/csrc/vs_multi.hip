@@ -371,7 +371,7 @@ int rccl_load() {
     if (g_rccl.h) return VS_OK;
     // VS_RCCL_LIB names the library (the CPU test tier points it at tests/emu/libfakerccl.so); otherwise a librccl this process
     // has already mapped is reused (one RCCL per process), then the ROCm installation's
-    const char* env = getenv("VS_RCCL_LIB");
+    const char* env = vs_opt_get("VS_RCCL_LIB");
     void* h = nullptr;
     std::string tried;
     if (env && *env) {

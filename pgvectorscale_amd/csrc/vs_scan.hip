@@ -236,7 +236,7 @@ int launch_scan_topk(vs_index* idx, const uint64_t* d_qcodes, uint32_t nq, uint3
     // queries per tile: the codes are streamed once per tile, so wide tiles amortise HBM traffic until the xor/popcount
     // work per byte makes the kernel issue bound (about 8 queries at 24-word codes)
     uint32_t Q = nq <= 4 ? 4u : 8u;
-    if (const char* e = getenv("VS_SCAN_Q")) {
+    if (const char* e = vs_opt_get("VS_SCAN_Q")) {
         const uint32_t v = (uint32_t)strtoul(e, nullptr, 10);
         if (v == 4 || v == 8 || v == 16) Q = v;
     }

@@ -66,7 +66,7 @@ struct vs_scan_pool {
 };
 
 static uint32_t pool_env_u32(const char* name, uint32_t dflt) {
-    const char* v = getenv(name);
+    const char* v = vs_opt_get(name);
     return v && *v ? (uint32_t)strtoul(v, nullptr, 10) : dflt;
 }
 

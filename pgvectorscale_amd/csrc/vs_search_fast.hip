@@ -604,6 +604,36 @@ struct Visited {
             wave_sync();
             return;
         }
+        if (len < 4u * WAVE) {
+            // up to four chunks of 64 entries (the lists of the reference's default search_list_size 100 and its neighbourhood, round
+            // 6): every entry is read ONCE into registers, counted, and the entries from the insertion point on are written one slot
+            // further back by the lane that holds them — no chunk-by-chunk read / barrier / write loop
+            uint64_t e[4];
+            uint32_t idx = 0;
+#pragma unroll
+            for (uint32_t c = 0; c < 4; ++c) {
+                e[c] = ~0ull;
+                if (c * WAVE < len) {
+                    const uint32_t i = c * WAVE + (uint32_t)lane;
+                    const uint32_t x = head + i;
+                    if (i < len) e[c] = ring[x >= vcapv ? x - vcapv : x];
+                    idx += (uint32_t)__popcll(__ballot(i < len && ((uint32_t)(e[c] >> 32) & VIS_HAM_MASK) < hd));
+                }
+            }
+            wave_sync();
+#pragma unroll
+            for (uint32_t c = 0; c < 4; ++c) {
+                if (c * WAVE < len) {
+                    const uint32_t i = c * WAVE + (uint32_t)lane;
+                    const uint32_t x = head + i + 1u;  // (i + 1 <= len <= vcapv - 1: one wrap at most)
+                    if (i >= idx && i < len) ring[x >= vcapv ? x - vcapv : x] = e[c];
+                }
+            }
+            if (lane == 0) ring[slot(idx)] = ((uint64_t)(hd | (flags << 30)) << 32) | node;
+            len++;
+            wave_sync();
+            return;
+        }
         uint32_t idx = 0;
         for (uint32_t base = 0; base < len; base += WAVE) {
             const uint32_t i = base + lane;

@@ -56,6 +56,7 @@
 #include "../../include/vsgpu.h"
 
 void vs_set_error(const char* fmt, ...);
+const char* vs_opt_get(const char* name);  // vs_options.cpp: the option table (vs_set_option, snapshot of the VS_* environment)
 
 namespace {
 
@@ -977,9 +978,9 @@ int vs_shm_server_create(vs_index* idx, const char* name, uint32_t nslots, uint3
     s->cfg.cursor_lanes = cfg ? std::min<uint32_t>(cfg->cursor_lanes, 64) : 0;
     s->cfg.cursor_pool = cfg ? std::min<uint32_t>(cfg->cursor_pool, 1024) : 0;
     if (!s->cfg.cursor_pool)
-        if (const char* e = getenv("VS_SHM_CURSOR_POOL")) s->cfg.cursor_pool = std::min<uint32_t>((uint32_t)strtoul(e, nullptr, 10), 1024);
+        if (const char* e = vs_opt_get("VS_SHM_CURSOR_POOL")) s->cfg.cursor_pool = std::min<uint32_t>((uint32_t)strtoul(e, nullptr, 10), 1024);
     if (!s->cfg.cursor_lanes)
-        if (const char* e = getenv("VS_BROKER_LANES")) s->cfg.cursor_lanes = std::min<uint32_t>((uint32_t)strtoul(e, nullptr, 10), 64);
+        if (const char* e = vs_opt_get("VS_BROKER_LANES")) s->cfg.cursor_lanes = std::min<uint32_t>((uint32_t)strtoul(e, nullptr, 10), 64);
     s->main_tab.ix = idx;
     auto drop_lanes = [s] { free_lanes(s); };  // (no lane thread has been started yet)
     for (uint32_t i = 0; i < s->cfg.cursor_lanes; ++i) {

@@ -30,6 +30,18 @@ def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+def set_option(name, value):
+    """a tuning option of libvsgpu through the C ABI (vs_set_option); value None unsets it; wins over the environment"""
+    check(_lib.load().vs_set_option(name.encode(), None if value is None else str(value).encode()))
+
+
+def get_option(name):
+    """the option's value as the library sees it (vs_set_option, else the VS_* environment snapshot), or None"""
+    buf = C.create_string_buffer(256)
+    r = check(_lib.load().vs_get_option(name.encode(), buf, 256))
+    return buf.value.decode() if r == 1 else None
+
+
 class Context:
     """One MI355X + its streams and pinned staging buffers."""
 

@@ -3,6 +3,8 @@ import ctypes
 import os
 import re
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -81,3 +83,34 @@ int main(void) {
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "VS_ERR_HIP" in r.stdout or "device: ok" in r.stdout
+
+
+def test_options_go_through_the_abi_and_the_environment_is_a_snapshot(monkeypatch):
+    """vs_set_option / vs_get_option (round 6: the VS_* tuning switches of DESIGN.md section 10 are looked up in a table, not with getenv
+    on the launch path): an option set through the ABI wins over the environment variable of the same name; the environment is seen
+    through a snapshot that follows later changes of the process's VS_* variables; unsetting falls back; bad names are refused"""
+    import pgvectorscale_amd as P
+    monkeypatch.delenv("VS_TEST_OPTION_X", raising=False)
+    assert P.get_option("VS_TEST_OPTION_X") is None
+    monkeypatch.setenv("VS_TEST_OPTION_X", "7")
+    assert P.get_option("VS_TEST_OPTION_X") == "7"       # the snapshot follows the environment ...
+    monkeypatch.setenv("VS_TEST_OPTION_X", "8")
+    assert P.get_option("VS_TEST_OPTION_X") == "8"
+    P.set_option("VS_TEST_OPTION_X", 3)
+    assert P.get_option("VS_TEST_OPTION_X") == "3"       # ... and an option set through the ABI wins
+    monkeypatch.setenv("VS_TEST_OPTION_X", "9")
+    assert P.get_option("VS_TEST_OPTION_X") == "3"
+    P.set_option("VS_TEST_OPTION_X", None)
+    assert P.get_option("VS_TEST_OPTION_X") == "9"
+    monkeypatch.delenv("VS_TEST_OPTION_X")
+    assert P.get_option("VS_TEST_OPTION_X") is None
+    with pytest.raises(P.VsError):
+        P.set_option("PATH", "x")
+
+
+def test_no_getenv_on_the_launch_path():
+    """the product sources read their options through vs_opt_get (vs_options.cpp) only"""
+    csrc = os.path.join(ROOT, "pgvectorscale_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".cpp", ".h")) and f not in ("vs_options.cpp", "vs_shm_lat.cpp"):
+            assert "getenv(" not in open(os.path.join(csrc, f)).read(), f

@@ -43,7 +43,7 @@ PY
            head -8 $O/kernel_stats_50m.csv
            timeout 1500 bash scripts/pmc_traffic.sh 50000000 $NQ $L $S /tmp/g 2>&1 | tail -40 > $O/pmc_traffic.log
            cp gpurun_out/pmc_search_traffic.json $O/pmc_search_traffic_50m.json
-           mkdir -p profiles/r05 && cp $O/pmc_search_traffic_50m.json profiles/r05/pmc_search_traffic_50m.json
+           mkdir -p profiles/${PROFROUND:-r06} && cp $O/pmc_search_traffic_50m.json profiles/${PROFROUND:-r06}/pmc_search_traffic_50m.json
            timeout 900 python bench.py --steps 20 --warmup 5 --skip-cpu --extras off --graph-cache /tmp/g > $O/bench_50m_with_traffic.json 2> $O/bench_50m_with_traffic.err
            python - <<PY | tee $O/summary.txt
 import json

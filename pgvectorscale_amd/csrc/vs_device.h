@@ -18,14 +18,20 @@ __device__ __forceinline__ uint32_t quad_sum(uint32_t v) {
 
 // 16 bytes of a code row read once per scan: a non-temporal load (global_load_dwordx4 ... nt), so the stream of gathered
 // rows does not push the scans' own working sets (dedup tables, heap spill) out of L2
+// (the address space is spelled out: a pointer that went through in_vgpr() — or any other opaque step — is a generic one to the compiler,
+// and its load a FLAT load, which also counts against the LDS counter and waits for it: round 6 found every stream load of
+// k_search_fast compiled that way)
+typedef __attribute__((address_space(1))) __uint128_t vs_glb_u128;
+typedef __attribute__((address_space(1))) uint64_t vs_glb_u64;
+typedef __attribute__((address_space(1))) uint32_t vs_glb_u32;
 __device__ __forceinline__ ulonglong2 load_stream16(const uint64_t* p) {
-    const __uint128_t v = __builtin_nontemporal_load(reinterpret_cast<const __uint128_t*>(p));
+    const __uint128_t v = __builtin_nontemporal_load((const vs_glb_u128*)p);
     return make_ulonglong2((unsigned long long)v, (unsigned long long)(v >> 64));
 }
 
 // the same for data a scan reads once and never again: its visit's neighbor row (and the neighbors' label masks next to it), a heap tid
-__device__ __forceinline__ uint32_t load_stream32(const uint32_t* p) { return __builtin_nontemporal_load(p); }
-__device__ __forceinline__ uint64_t load_stream64(const uint64_t* p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ uint32_t load_stream32(const uint32_t* p) { return __builtin_nontemporal_load((const vs_glb_u32*)p); }
+__device__ __forceinline__ uint64_t load_stream64(const uint64_t* p) { return __builtin_nontemporal_load((const vs_glb_u64*)p); }
 
 // per 16-bit half: min(a, b) (v_pk_min_u16).  Written with the GCC vector extension so that the host build of the test interpreter
 // compiles it too.

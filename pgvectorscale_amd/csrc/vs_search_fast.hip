@@ -723,9 +723,9 @@ __device__ __forceinline__ uint32_t ham_row_reg(const uint64_t* __restrict__ row
 }
 
 // two rows at once (all loads issued before the first popcount)
-template <int NCH>
+template <int NCH, bool QL = false>
 __device__ __forceinline__ void ham_row_reg2(const uint64_t* __restrict__ row_a, const uint64_t* __restrict__ row_b,
-                                             const ulonglong2 (&qv)[NCH > 0 ? NCH : 1], int l4, uint32_t code_stride, bool act_a,
+                                             const ulonglong2 (&qv)[NCH > 0 ? NCH : 1], const uint64_t* qc_l, int l4, uint32_t code_stride, bool act_a,
                                              bool act_b, bool stream, uint32_t& da, uint32_t& db) {
     constexpr int N = NCH > 0 ? NCH : 1;
     ulonglong2 ra[N], rb[N];
@@ -739,8 +739,9 @@ __device__ __forceinline__ void ham_row_reg2(const uint64_t* __restrict__ row_a,
     uint32_t acc_a = 0, acc_b = 0;
 #pragma unroll
     for (int t = 0; t < N; ++t) {
-        acc_a += (uint32_t)__popcll(ra[t].x ^ qv[t].x) + (uint32_t)__popcll(ra[t].y ^ qv[t].y);
-        acc_b += (uint32_t)__popcll(rb[t].x ^ qv[t].x) + (uint32_t)__popcll(rb[t].y ^ qv[t].y);
+        const ulonglong2 qq = QL ? *reinterpret_cast<const ulonglong2*>(qc_l + 2u * (uint32_t)l4 + 8u * (uint32_t)t) : qv[t];
+        acc_a += (uint32_t)__popcll(ra[t].x ^ qq.x) + (uint32_t)__popcll(ra[t].y ^ qq.y);
+        acc_b += (uint32_t)__popcll(rb[t].x ^ qq.x) + (uint32_t)__popcll(rb[t].y ^ qq.y);
     }
     da = quad_sum(act_a ? acc_a : 0u);
     db = quad_sum(act_b ? acc_b : 0u);
@@ -776,6 +777,7 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 #define OPT_R1 2
 #define OPT_NS64 4
 #define OPT_RS 8
+#define OPT_G2 16
 template <int NCH, int VR, bool TIMING, int MINW, bool BUILD, bool FULL, int VG, int OPT>
 __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, const uint32_t slot) {
     constexpr bool XW = (OPT & OPT_XW) != 0 && NCH > 0;
@@ -842,7 +844,7 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
     constexpr bool stream_rows = true;
     // (neighbor rows, the neighbors' label masks and heap tids are read once per scan too and go through non-temporal loads as well:
     // measured neutral at 50M — 159.94 against 159.93 ms, profiles/r04/s5_ab_nt_rows_50m.txt — where the code rows' are worth 10 %)
-    constexpr bool G2 = NCH == 3 && VR == 0 && MINW == 5 && !BUILD && !TIMING;  // two code rows per 4-lane group in flight
+    constexpr bool G2 = NCH == 3 && VR == 0 && (MINW == 5 || (OPT & OPT_G2) != 0) && !BUILD && !TIMING;  // two code rows per 4-lane group in flight
     ulonglong2 qv[NCH > 0 ? NCH : 1];
     if (QL) {
         qv[0] = make_ulonglong2(0, 0);
@@ -1627,7 +1629,7 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
                     const bool valid2 = j2 < c;
                     const uint64_t* crow2 = codes_v + (size_t)(valid2 ? surv_id[j2] : 0u) * cstride;
                     uint32_t d, d2;
-                    ham_row_reg2<NCH>(crow, crow2, qv, l4, cstride, valid, valid2, stream_rows, d, d2);
+                    ham_row_reg2<NCH, QL>(crow, crow2, qv, qc_l, l4, cstride, valid, valid2, stream_rows, d, d2);
                     if (valid && l4 == 0) surv_d[j] = LEAN ? ((d << s.sb) | surv_slot[j]) : d;
                     if (valid2 && l4 == 0) surv_d[j2] = LEAN ? ((d2 << s.sb) | surv_slot[j2]) : d2;
                     continue;
@@ -1820,6 +1822,9 @@ static int launch_fast_t(vs_index* idx, const FastArgs& a, size_t lds, uint32_t*
         const bool plain = !a.s.qlabel_off && !a.s.visible && !(a.s.flags & FAST_FULL_VARIANT);
         // (the usual index: 24-word code rows — 768 x 2 bit, 1536 x 1 bit — and num_neighbors <= 64)
         const bool std_geom = a.code_stride == 24 && a.R <= WAVE && a.nbr_stride == 64;
+        // (OPT_G2 at six waves per SIMD — two code rows per 4-lane group in flight, 78 VGPRs, no spills — was timed at 50M in round 6:
+        // 134.6 ms against 130.3, profiles/r06/s4_ab_50m.txt.  More requests in flight per scan do not help a launch whose 6 144 scans
+        // already keep the memory system busy; the instantiation is not built.)
         if (NCH == 3 && a.s.minw == 6 && plain && std_geom) return launch_fast_tt<3, 0, false, 6, false, false, 3, OPT_XW | OPT_R1 | OPT_NS64>(idx, a, lds, res);
         if (NCH == 3 && a.s.minw == 6 && std_geom) return launch_fast_tt<3, 0, false, 6, false, true, 3, OPT_XW | OPT_R1 | OPT_NS64>(idx, a, lds, res);
         if (NCH == 3 && a.s.minw == 6 && plain) return launch_fast_tt<3, 0, false, 6, false, false, 3>(idx, a, lds, res);

@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvsgpu.so")
+LIB_PATH = os.environ.get("VS_LIB_PATH") or os.path.join(_HERE, "libvsgpu.so")  # (VS_LIB_PATH: A/B sessions time another build of the same ABI, scripts/ab_bench_libs.sh)
 
 VS_INVALID_NODE = 0xFFFFFFFF
 VS_COSINE, VS_L2, VS_IP = 0, 1, 2

@@ -344,6 +344,8 @@ int launch_resort_cursor(vs_index* idx, uint32_t n, bool exhausted, uint32_t res
 int launch_resort_cursor_batch(vs_index* idx, uint32_t n, const uint32_t* d_list, uint32_t rescore, uint32_t k, const uint32_t* d_stream,
                                const float* d_dist, const uint32_t* d_keys, uint32_t row_stride, uint64_t* d_heap, uint32_t* d_cur,
                                uint32_t* d_out_ids, uint64_t* d_out_tids, float* d_out_dist, uint32_t out_stride);
+int launch_pool_append(vs_index* idx, uint32_t nq, const uint32_t* d_cnt, const uint32_t* d_off, const uint32_t* d_stage, uint32_t stage_kind_stride, uint32_t M,
+                       uint32_t* d_all, uint32_t all_kind_stride, uint32_t rows_cap);
 int launch_row_norms(vs_index* idx);
 int launch_slice_norms(vs_index* idx, float* d_out);  // divisor of the first dim_index dims of every heap vector
 int launch_prepare_index_slice(vs_index* idx, const float* d_raw, uint32_t nq, float* d_q_index);

@@ -700,6 +700,31 @@ int launch_resort_cursor(vs_index* idx, uint32_t n, bool exhausted, uint32_t res
     return VS_OK;
 }
 
+// The new stream rows of one scan-pool round, moved from the round's staging rows to the slots' stream arrays: workgroup q copies
+// cnt[q] rows of each of the three kinds (ids, Hamming keys, distances) from stage[kind][q][0..] to all[kind][q][off[q]..].  The row
+// counts are read on the device, so the round needs no host round trip between its search launch and this one (round 6; until then:
+// one hipMemcpy2DAsync per slot after the counts had come back).  A slot that did not run, failed or ended at once has cnt 0.
+__global__ __launch_bounds__(WAVE) void k_pool_append(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off, const uint32_t* __restrict__ stage,
+                                                      uint32_t stage_kind_stride, uint32_t M, uint32_t* __restrict__ all, uint32_t all_kind_stride,
+                                                      uint32_t rows_cap) {
+    const uint32_t q = blockIdx.x;
+    const uint32_t n = min(cnt[q], M), o = off[q];
+    if (n == 0 || o >= rows_cap) return;
+    const uint32_t m = min(n, rows_cap - o);
+    for (uint32_t kind = 0; kind < 3; ++kind) {
+        const uint32_t* src = stage + (size_t)kind * stage_kind_stride + (size_t)q * M;
+        uint32_t* dst = all + (size_t)kind * all_kind_stride + (size_t)q * rows_cap + o;
+        for (uint32_t i = threadIdx.x; i < m; i += WAVE) dst[i] = src[i];
+    }
+}
+int launch_pool_append(vs_index* idx, uint32_t nq, const uint32_t* d_cnt, const uint32_t* d_off, const uint32_t* d_stage, uint32_t stage_kind_stride, uint32_t M,
+                       uint32_t* d_all, uint32_t all_kind_stride, uint32_t rows_cap) {
+    if (nq == 0) return VS_OK;
+    hipLaunchKernelGGL(k_pool_append, dim3(nq), dim3(WAVE), 0, idx->ctx->stream, d_cnt, d_off, d_stage, stage_kind_stride, M, d_all, all_kind_stride, rows_cap);
+    VS_HIP(hipGetLastError());
+    return VS_OK;
+}
+
 // d_list: [n][3] (pool slot, rows emitted, exhausted) on the device; the per-scan arrays are rows of 2-D arrays (see the kernel)
 int launch_resort_cursor_batch(vs_index* idx, uint32_t n, const uint32_t* d_list, uint32_t rescore, uint32_t k, const uint32_t* d_stream,
                                const float* d_dist, const uint32_t* d_keys, uint32_t row_stride, uint64_t* d_heap, uint32_t* d_cur,

@@ -49,7 +49,7 @@ struct vs_scan_pool {
     std::vector<Slot> slots;
     bool csr_dirty = true;
     DevBuf raw_q, q_full, q_index, qcodes, qlabels, qlabel_off, heap_g, hash, state, cnt, stats, status, row_stats, stage, all, resort_heap,
-        out_tids, list;
+        out_tids, list, roff;
     uint64_t* d_tids = nullptr;
     uint32_t *d_cur = nullptr, *d_ids = nullptr;
     float* d_dist = nullptr;
@@ -57,7 +57,7 @@ struct vs_scan_pool {
     double t_search = 0, t_append = 0, t_resort = 0;  // (VS_POOL_DEBUG) host seconds: launch .. counters back / rerank + append / resort + rows back
     void free_all() {
         for (DevBuf* b : {&raw_q, &q_full, &q_index, &qcodes, &qlabels, &qlabel_off, &heap_g, &hash, &state, &cnt, &stats, &status, &row_stats,
-                          &stage, &all, &resort_heap, &out_tids, &list}) {
+                          &stage, &all, &resort_heap, &out_tids, &list, &roff}) {
             if (b->p && !b->in_slab) (void)hipFree(b->p);
             b->p = nullptr;
             b->bytes = 0;
@@ -161,6 +161,7 @@ static int scanpool_create_impl(vs_index* ix, uint32_t capacity, uint32_t L, uin
         p->d_ids = p->d_cur + G * 4;
         p->d_dist = (float*)(p->d_ids + G * (size_t)kmax);
         VS_TRY(devbuf_reserve(c, p->list, G * 12));  // (slot, rows, exhausted) of the scans a fetch lists
+        VS_TRY(devbuf_reserve(c, p->roff, G * 4));   // where a round's new rows go in every slot's stream arrays
         return VS_OK;
     };
     const int r = all();
@@ -346,37 +347,31 @@ static int pool_round(vs_scan_pool* p, const std::vector<uint32_t>& run, uint32_
         p->launches++;
     }
     p->rounds++;
-    // outcome, counters and row counts of the slots that ran (what the kernel publishes per scan next to the saved state)
-    std::vector<uint32_t> kst((size_t)nq * ST_N), kstatus((size_t)2 * G), cnt(nq);
-    VS_HIP(hipMemcpyAsync(kst.data(), p->stats.p, (size_t)nq * ST_N * 4, hipMemcpyDeviceToHost, c->stream));
-    VS_HIP(hipMemcpyAsync(kstatus.data(), p->status.p, (size_t)2 * G * 4, hipMemcpyDeviceToHost, c->stream));
-    VS_HIP(hipMemcpyAsync(cnt.data(), p->cnt.p, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
-    VS_HIP(hipStreamSynchronize(c->stream));
-    const auto tp1 = std::chrono::steady_clock::now();
-    p->t_search += std::chrono::duration<double>(tp1 - tp0).count();
-    std::vector<uint32_t> rst((size_t)nq * M * ST_N);
-    VS_HIP(hipMemcpyAsync(rst.data(), p->row_stats.p, rst.size() * 4, hipMemcpyDeviceToHost, c->stream));
-    if (p->S > 0) {  // get_full_distance_for_resort of the new rows (AM/sbq/storage.rs:304-328): one launch for every slot
+    // get_full_distance_for_resort of the new rows (AM/sbq/storage.rs:304-328: one launch for every slot), then ids, Hamming keys and
+    // distances go from the round's staging rows to the slots' stream arrays — both take the row counts from the device, so the whole
+    // round is ONE trip to the host (round 6; until then: counts back, then a 2-D copy per slot, then a second synchronisation)
+    if (p->S > 0) {
         VS_REQUIRE(ix->vecs, "diskann.query_rescore > 0 needs the heap vector column on the device");
         hipEvent_t ev2 = prof_begin(c);
         VS_TRY(launch_rerank(ix, (const float*)p->q_full.p, stage_ids, nullptr, (const uint32_t*)p->cnt.p, M, nq, stage_dist));
         prof_end(c, PK_RERANK, ev2);
     }
-    uint32_t* const all_ids = (uint32_t*)p->all.p;
-    // ids, Hamming keys and distances of the new rows go from the round's staging rows to the slots' stream arrays.  Scans that are
-    // streamed side by side move in lockstep (same position, M new rows each): a contiguous run of such slots is ONE 2-D copy per kind
-    // of array; anything else one 2-D copy per slot (three "rows": the three kinds).
-    bool lockstep = run.size() > 1;
-    for (size_t i = 0; i < run.size() && lockstep; ++i)
-        lockstep = run[i] == run[0] + i && p->slots[run[i]].rows == p->slots[run[0]].rows && cnt[run[i]] == M &&
-                   kstatus[(size_t)(p->slots[run[i]].keys ? G : 0) + run[i]] == 0;
-    if (lockstep) {
-        const uint32_t q0 = run[0], r0 = p->slots[q0].rows;
-        for (int kind = 0; kind < 3; ++kind)
-            VS_HIP(hipMemcpy2DAsync(all_ids + (size_t)kind * G * p->rows_cap + (size_t)q0 * p->rows_cap + r0, (size_t)p->rows_cap * 4,
-                                    stage_ids + (size_t)kind * G * p->mmax + (size_t)q0 * M, (size_t)M * 4, (size_t)M * 4, run.size(),
-                                    hipMemcpyDeviceToDevice, c->stream));
+    {
+        std::vector<uint32_t> off(nq, p->rows_cap);  // (a slot that is not part of the round has no rows to move: its count is zero too)
+        for (uint32_t q : run) off[q] = p->slots[q].rows;
+        VS_HIP(hipMemcpyAsync(p->roff.p, off.data(), (size_t)nq * 4, hipMemcpyHostToDevice, c->stream));  // (pageable source: staged before the call returns)
+        VS_TRY(launch_pool_append(ix, nq, (const uint32_t*)p->cnt.p, (const uint32_t*)p->roff.p, stage_ids, (uint32_t)((size_t)G * p->mmax), M, (uint32_t*)p->all.p,
+                                  (uint32_t)((size_t)G * p->rows_cap), p->rows_cap));
     }
+    // outcome, counters and row counts of the slots that ran (what the kernel publishes per scan next to the saved state)
+    std::vector<uint32_t> kst((size_t)nq * ST_N), kstatus((size_t)2 * G), cnt(nq), rst((size_t)nq * M * ST_N);
+    VS_HIP(hipMemcpyAsync(kst.data(), p->stats.p, (size_t)nq * ST_N * 4, hipMemcpyDeviceToHost, c->stream));
+    VS_HIP(hipMemcpyAsync(kstatus.data(), p->status.p, (size_t)2 * G * 4, hipMemcpyDeviceToHost, c->stream));
+    VS_HIP(hipMemcpyAsync(cnt.data(), p->cnt.p, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
+    VS_HIP(hipMemcpyAsync(rst.data(), p->row_stats.p, rst.size() * 4, hipMemcpyDeviceToHost, c->stream));
+    VS_HIP(hipStreamSynchronize(c->stream));
+    const auto tp1 = std::chrono::steady_clock::now();
+    p->t_search += std::chrono::duration<double>(tp1 - tp0).count();
     for (uint32_t q : run) {
         Slot& s = p->slots[q];
         const uint32_t* h = kst.data() + (size_t)q * ST_N;
@@ -386,10 +381,8 @@ static int pool_round(vs_scan_pool* p, const std::vector<uint32_t>& run, uint32_
             s.failed = true;
             continue;
         }
-        const uint32_t n = cnt[q];
-        if (n && !lockstep)
-            VS_HIP(hipMemcpy2DAsync(all_ids + (size_t)q * p->rows_cap + s.rows, (size_t)G * p->rows_cap * 4, stage_ids + (size_t)q * M,
-                                    (size_t)G * p->mmax * 4, (size_t)n * 4, 3, hipMemcpyDeviceToDevice, c->stream));
+        const uint32_t n = std::min(cnt[q], M);
+        s.row_stats.insert(s.row_stats.end(), rst.begin() + (size_t)q * M * ST_N, rst.begin() + ((size_t)q * M + n) * ST_N);
         s.rows += n;
         if (n < M) {
             s.exhausted = true;
@@ -401,13 +394,6 @@ static int pool_round(vs_scan_pool* p, const std::vector<uint32_t>& run, uint32_
             s.final_counters[ST_NEXT] = h[ST_NEXT];
             s.final_counters[ST_INVIS] = h[ST_INVIS];
         }
-    }
-    VS_HIP(hipStreamSynchronize(c->stream));  // (row_stats: the per-row counters of this round)
-    for (uint32_t q : run) {
-        Slot& s = p->slots[q];
-        if (s.failed) continue;
-        const uint32_t n = cnt[q];
-        s.row_stats.insert(s.row_stats.end(), rst.begin() + (size_t)q * M * ST_N, rst.begin() + ((size_t)q * M + n) * ST_N);
     }
     p->t_append += std::chrono::duration<double>(std::chrono::steady_clock::now() - tp1).count();
     return VS_OK;
@@ -452,6 +438,25 @@ static int scanpool_fetch_impl(vs_scan_pool* p, const uint32_t* slots, uint32_t 
         for (uint32_t q : run) streaming = streaming && p->slots[q].launches >= 2;
         if (streaming) M = std::max(M, std::min<uint32_t>(4 * k, p->mmax));
         M = std::min(M, p->mmax);
+        // ... and the round carries the OTHER listed scans that are being streamed ahead as well (round 6).  A round costs the life of its
+        // longest scan whether it continues four scans or forty, and every backend of the fetch waits for it; when only the scans that
+        // had run out of rows took part, backends streaming side by side drifted into different phases and nearly every fetch paid for
+        // a round (64 backends x 1 000 rows: 99 rounds per 127 fetches where one scan alone needs 18).  Taking everybody along keeps
+        // them in phase: the rounds a group needs are the rounds its neediest scan needs.  Bounded: a scan is carried at most two
+        // rounds ahead of its executor, never past its row budget, and what the executor has not pulled shows in no counter.
+        if (streaming && pool_env_u32("VS_POOL_TOPUP", 1)) {
+            std::vector<uint8_t> in_run(G, 0);
+            for (uint32_t q : run) in_run[q] = 1;
+            for (uint32_t i = 0; i < n; ++i) {
+                const uint32_t q = slots[i];
+                const Slot& s = p->slots[q];
+                if (in_run[q] || s.failed || s.exhausted || s.launches < 2) continue;
+                const uint64_t need = S > 0 ? (uint64_t)S + s.handed + k - 1 : (uint64_t)s.handed + k;
+                if ((uint64_t)s.rows + M > p->rows_cap || s.rows >= need + M) continue;  // (no room / already a round ahead)
+                run.push_back(q);
+            }
+            std::sort(run.begin(), run.end());
+        }
         // (a scan that needs fewer rows than the round's M is simply further ahead afterwards — rows are handed out by the window
         // below and the counters are recorded per row — but no scan may pass its row budget)
         for (uint32_t q : run) M = std::min(M, p->rows_cap - p->slots[q].rows);

@@ -463,9 +463,13 @@ struct FastHeap {
             const uint32_t aidx = ((root + 1) << lvl()) + offm1();
             const uint32_t c = 2 * aidx + 1;
             const bool exists = aidx < end, have1 = c < end, have2 = c + 1 < end;
+            // (the subtree under the heap root — nodes 0..62, children up to 126 — lies in LDS whenever hl >= 127: the first round of
+            // every pop then takes the all-LDS path, a wave-uniform choice instead of a per-lane "LDS or spill array" around its load
+            // and its store; round 6)
+            const bool lo = all_lds || (root == 0 && hl >= 127u);
             uint32_t le = 0, ri = 0;
             if (have1) {
-                if (all_lds || c < hl) {
+                if (lo || c < hl) {
                     const uint2 p = *reinterpret_cast<const uint2*>(l + c + 1);
                     le = p.x;
                     ri = p.y;
@@ -483,7 +487,7 @@ struct FastHeap {
             const bool onpath = exists && (((uint32_t)B & amask) == dpat);
             const uint64_t pm = __ballot(onpath);
             if (onpath && have1) {
-                if (all_lds) l[aidx + 1] = cv;
+                if (lo) l[aidx + 1] = cv;
                 else set(aidx, cv);
             }
             wave_sync();
@@ -1220,10 +1224,11 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
         // slot and which met a full bucket are wave-uniform lane masks kept by hand: as per-lane booleans carried through the loop each
         // cost three scalar instructions per merge point
         uint64_t pendm = __ballot(act && hit == 0), freshm = 0, ovfm = 0;
+        // (the first attempt needs no second look at the occupancy bits: the occupied run found with the snapshot ends at the first free
+        // slot, and nothing has been inserted since; only a lane that lost its slot to another lane of the wave reads them again — round 6)
+        uint32_t t2 = t;
         while (pendm) {
             wave_sync();
-            const uint32_t occ = b16_occ(hb);
-            const uint32_t t2 = (uint32_t)__builtin_ctz(~(((occ | (occ << 8)) >> pref) & 0xFFu));  // (8: the bucket is full)
             const uint32_t idx = (hb << 3) + ((pref + t2) & 7u);
             const uint32_t bit = 1u << (idx & 31u);
             const bool mine = lane_of(pendm);
@@ -1239,6 +1244,9 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
             ovfm |= fullm;
             pendm &= ~(wonm | fullm);
             wave_sync();
+            if (!pendm) break;
+            const uint32_t occ = b16_occ(hb);
+            t2 = (uint32_t)__builtin_ctz(~(((occ | (occ << 8)) >> pref) & 0xFFu));  // (8: the bucket is full)
         }
         bool fresh = lane_of(freshm);
         const uint32_t ov0 = n_ovf;

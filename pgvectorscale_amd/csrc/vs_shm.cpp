@@ -833,6 +833,18 @@ void vs_shm_server::run() {
                         if (posted(i)) ready.push_back(i);
                     const auto now = std::chrono::steady_clock::now();
                     if (ready.size() >= cfg.max_batch || now >= deadline || stop.load()) break;
+                    // scans streamed out of the pools move in step: once every open cursor's backend has posted its next request (and no
+                    // new scan is waiting for company) the window has nobody left to wait for
+                    if (cfg.cursor_pool) {
+                        size_t nfetch = 0;
+                        bool search_posted = false;
+                        for (uint32_t i : ready) {
+                            const uint32_t op = m.slot(i)->op;
+                            nfetch += op == OP_FETCH;
+                            search_posted |= op == OP_SEARCH;
+                        }
+                        if (!search_posted && nfetch >= open_cursors.load()) break;
+                    }
                     const auto left = std::chrono::duration_cast<std::chrono::microseconds>(deadline - now).count();
                     futex_wait(&h->work_seq, seq2, (int)std::max<long long>(left, 1));
                 }

@@ -258,18 +258,25 @@ struct FastHeap {
         auto anc_of = [&](uint32_t rank, uint32_t base) -> uint32_t {
             return (uint32_t)__builtin_amdgcn_ds_bpermute((int)((base + (p1 >> rank) - (p1f >> rank)) << 2), (int)anc);
         };
-        // The leaf's original ancestors of ranks 1..6: six cross-lane reads issued back to back and kept in registers for the levels
-        // below (round 6; they used to be fetched once for the test here and again level by level — five more address computations,
-        // five more waits on the LDS crossbar per run).  Deepest rank (<= 5) any element can reach against the ORIGINAL ancestors
-        // (values only fall during the run), and the elements that can get above rank 5 (bit e <-> element e).
-        const uint32_t ak1 = anc_of(1, 0), ak2 = anc_of(2, 17), ak3 = anc_of(3, 26), ak4 = anc_of(4, 31), ak5 = anc_of(5, 34), ak6 = anc_of(6, 36);
+        // deepest rank (<= 5) any element can reach against the ORIGINAL ancestors (values only fall during the run), and the elements
+        // that can get above rank 5 (bit e <-> element e) — rank by rank, stopping at the first rank nothing reaches, and the ancestors
+        // are fetched AGAIN level by level below.  (Round 6 fetched all six ranks up front and kept them in registers — five address
+        // computations and five waits on the LDS crossbar less per run that climbs high, and 22 % more time per label-filtered scan,
+        // whose runs are short and mostly climb nowhere: 162.1 against 132.2 ms, profiles/r06/s8_ab_labels_10m.txt; rank 1 first and
+        // the rest together: 137.4, s9.  The unfiltered regimes cannot tell the three apart.)
         uint32_t K = 0, hm;
         {
-            const uint32_t kc = in ? c >> sb : IDENT;
-            const uint64_t b1 = __ballot(kc < (ak1 >> sb)), b2 = __ballot(kc < (ak2 >> sb)), b3 = __ballot(kc < (ak3 >> sb)),
-                           b4 = __ballot(kc < (ak4 >> sb)), b5 = __ballot(kc < (ak5 >> sb)), b6 = __ballot(kc < (ak6 >> sb));
-            K = !b1 ? 0u : !b2 ? 1u : !b3 ? 2u : !b4 ? 3u : !b5 ? 4u : 5u;
-            hm = K == 5 ? (uint32_t)(b6 >> off) : 0u;
+            const uint32_t kc = in ? c >> sb : IDENT;  // (every lane takes part in the fetches: they are cross-lane operations)
+            auto below = [&](uint32_t rank, uint32_t base) -> uint64_t {
+                const uint32_t ak = anc_of(rank, base);
+                return __ballot(kc < (ak >> sb));
+            };
+            if (below(1, 0)) K = 1;
+            if (K == 1 && below(2, 17)) K = 2;
+            if (K == 2 && below(3, 26)) K = 3;
+            if (K == 3 && below(4, 31)) K = 4;
+            if (K == 4 && below(5, 34)) K = 5;
+            hm = K == 5 ? (uint32_t)(below(6, 36) >> off) : 0u;
         }
         bool forced = false;
         // ---- above rank 5: the elements that can get there, one after another
@@ -311,7 +318,8 @@ struct FastHeap {
             if (__ballot(forced)) K = 5;
         }
         // ---- ranks 5..1, all leaves at once
-        auto level = [&](const uint32_t k, const uint32_t ak) {  // ak: the node's original value
+        auto level = [&](const uint32_t k, const uint32_t base) {
+            const uint32_t ak = anc_of(k, base);  // the node's original value
             const uint32_t B1 = (1u << k) - 1u;
             const uint32_t comp = in ? (((c >> sb) << 7) | (forced ? 63u - i : 65u + i)) : IDENT;
             // exclusive prefix minimum inside the aligned block of 2^k lanes: the values shifted by one lane (a block's first lane starts
@@ -355,11 +363,11 @@ struct FastHeap {
                 forced = true;
             }
         };
-        if (K >= 5) level(5, ak5);
-        if (K >= 4) level(4, ak4);
-        if (K >= 3) level(3, ak3);
-        if (K >= 2) level(2, ak2);
-        if (K >= 1) level(1, ak1);
+        if (K >= 5) level(5, 34);
+        if (K >= 4) level(4, 31);
+        if (K >= 3) level(3, 26);
+        if (K >= 2) level(2, 17);
+        if (K >= 1) level(1, 0);
         if (in) put(0, p1, c);
     }
     // pre_n / pre_anc: a wide load the caller already issued for the first run (pre_n = first_run(c)), or pre_n = 0
@@ -608,36 +616,10 @@ struct Visited {
             wave_sync();
             return;
         }
-        if (len < 4u * WAVE) {
-            // up to four chunks of 64 entries (the lists of the reference's default search_list_size 100 and its neighbourhood, round
-            // 6): every entry is read ONCE into registers, counted, and the entries from the insertion point on are written one slot
-            // further back by the lane that holds them — no chunk-by-chunk read / barrier / write loop
-            uint64_t e[4];
-            uint32_t idx = 0;
-#pragma unroll
-            for (uint32_t c = 0; c < 4; ++c) {
-                e[c] = ~0ull;
-                if (c * WAVE < len) {
-                    const uint32_t i = c * WAVE + (uint32_t)lane;
-                    const uint32_t x = head + i;
-                    if (i < len) e[c] = ring[x >= vcapv ? x - vcapv : x];
-                    idx += (uint32_t)__popcll(__ballot(i < len && ((uint32_t)(e[c] >> 32) & VIS_HAM_MASK) < hd));
-                }
-            }
-            wave_sync();
-#pragma unroll
-            for (uint32_t c = 0; c < 4; ++c) {
-                if (c * WAVE < len) {
-                    const uint32_t i = c * WAVE + (uint32_t)lane;
-                    const uint32_t x = head + i + 1u;  // (i + 1 <= len <= vcapv - 1: one wrap at most)
-                    if (i >= idx && i < len) ring[x >= vcapv ? x - vcapv : x] = e[c];
-                }
-            }
-            if (lane == 0) ring[slot(idx)] = ((uint64_t)(hd | (flags << 30)) << 32) | node;
-            len++;
-            wave_sync();
-            return;
-        }
+        // (a register-resident pass for lists of up to four chunks — every entry read once, the tail rewritten one slot further back — was
+        // built and measured in round 6: 190.3 against 162.6 ms per 262 144 label-filtered scans at search_list_size 100, 10M x 1536,
+        // profiles/r06/s7_ab_labels_10m.txt.  The loop below moves the SHORTER side of the insertion point, and a node that is visited
+        // late in a scan lands near the front of a long list.)
         uint32_t idx = 0;
         for (uint32_t base = 0; base < len; base += WAVE) {
             const uint32_t i = base + lane;

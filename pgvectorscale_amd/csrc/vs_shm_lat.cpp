@@ -6,6 +6,13 @@
 // oracle's single-thread latency on the same queries.
 //
 //   vs_shm_lat <segment> <queries.f32> <dim> <n_queries> <backends> <scans_per_backend> <search_list_size> <rescore> <k>
+//   vs_shm_lat <segment> <queries.f32> <dim> <n_queries> <backends> 1 <search_list_size> <rescore> <chunk> <rows_per_scan> [ids_out.u32]
+//
+// The second form STREAMS (round 6; the cursor measurements used Python backends until then, whose interpreter time per fetch was
+// of the order of the fetch itself): backend b runs ONE scan of query b and pulls rows_per_scan rows in chunks — the first chunk out of
+// a shared OP_SEARCH launch, every later one an OP_FETCH continuation, then OP_CLOSE — three times over, the third pass timed (the first
+// two pay the serving process's allocations).  wall_ms is the timed pass of all backends; ids_out receives [backends][rows_per_scan]
+// node ids (0xFFFFFFFF where a scan ended early).
 //
 // The parent forks the backends, releases them together once every one has mapped the segment and run two warm-up scans, and
 // aggregates: p50 / p95 / p99 / mean / max latency in microseconds over all timed scans, whole-run throughput, a checksum of the
@@ -60,6 +67,8 @@ int main(int argc, char** argv) {
     const char* qpath = argv[2];
     const uint32_t dim = (uint32_t)atoi(argv[3]), nqf = (uint32_t)atoi(argv[4]), nb = (uint32_t)atoi(argv[5]), reps = (uint32_t)atoi(argv[6]);
     const uint32_t L = (uint32_t)atoi(argv[7]), S = (uint32_t)atoi(argv[8]), k = (uint32_t)atoi(argv[9]);
+    const uint32_t stream_rows = argc > 10 ? (uint32_t)atoi(argv[10]) : 0u;
+    const char* rows_out = argc > 11 ? argv[11] : nullptr;
     if (!dim || !nqf || !nb || !reps || !k || nb > 4096) {
         fprintf(stderr, "vs_shm_lat: bad arguments\n");
         return 2;
@@ -83,6 +92,14 @@ int main(int argc, char** argv) {
         perror("vs_shm_lat: mmap");
         return 2;
     }
+    uint32_t* srows = nullptr;  // (stream mode) [backends][rows_per_scan] node ids
+    if (stream_rows) {
+        srows = (uint32_t*)mmap(nullptr, (size_t)nb * stream_rows * 4, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
+        if (srows == MAP_FAILED) {
+            perror("vs_shm_lat: mmap rows");
+            return 2;
+        }
+    }
     new (sh) Shared();
     std::vector<pid_t> kids;
     for (uint32_t b = 0; b < nb; ++b) {
@@ -98,12 +115,46 @@ int main(int argc, char** argv) {
             std::vector<uint64_t> tids(k);
             std::vector<float> dist(k);
             int rc = vs_shm_client_open(seg, &c);
-            for (int w = 0; w < 2 && rc == VS_OK; ++w)  // warm-up: the serving process's lazy allocations are not a backend's latency
+            for (int w = 0; w < 2 && rc == VS_OK && !stream_rows; ++w)  // warm-up: the serving process's lazy allocations are not a backend's latency
                 rc = vs_shm_client_search(c, queries + (size_t)((b * 7919u + w) % nqf) * dim, nullptr, 0, 0, L, S, k, ids.data(), tids.data(), dist.data());
             if (rc != VS_OK) {
                 if (!sh->failed.fetch_add(1)) snprintf(sh->err, sizeof(sh->err), "backend %u: %s", b, vs_last_error());
                 sh->ready.fetch_add(1);
                 _exit(1);
+            }
+            if (stream_rows) {  // ---- one streamed scan per backend, three passes, the third timed
+                const float* q = queries + (size_t)(b % nqf) * dim;
+                uint64_t sum = 0;
+                for (uint32_t pass = 0; pass < 3 && rc == VS_OK; ++pass) {
+                    const uint64_t sid = 1000ull * (pass + 1) + b;
+                    if (pass == 2) {
+                        sh->ready.fetch_add(1);
+                        while (!sh->go.load(std::memory_order_acquire)) usleep(50);
+                    }
+                    uint32_t have = 0;
+                    rc = vs_shm_client_search(c, q, nullptr, 0, 0, L, S, k, ids.data(), tids.data(), dist.data());
+                    if (rc != VS_OK) break;
+                    for (uint32_t j = 0; j < k && have < stream_rows; ++j) srows[(size_t)b * stream_rows + have++] = ids[j];
+                    while (have < stream_rows) {
+                        uint32_t n = 0;
+                        rc = vs_shm_client_fetch(c, sid, q, nullptr, 0, 0, L, S, 0, have, k, ids.data(), tids.data(), dist.data(), &n);
+                        if (rc != VS_OK) break;
+                        for (uint32_t j = 0; j < n && have < stream_rows; ++j) srows[(size_t)b * stream_rows + have++] = ids[j];
+                        if (n < k) break;
+                    }
+                    if (rc == VS_OK) rc = vs_shm_client_end_scan(c, sid);
+                    for (uint32_t j = have; j < stream_rows; ++j) srows[(size_t)b * stream_rows + j] = 0xFFFFFFFFu;
+                    if (pass == 2)
+                        for (uint32_t j = 0; j < have; ++j) sum += (uint64_t)srows[(size_t)b * stream_rows + j] * (uint64_t)(j + 1);
+                }
+                if (rc != VS_OK) {
+                    if (!sh->failed.fetch_add(1)) snprintf(sh->err, sizeof(sh->err), "backend %u (streamed scan): %s", b, vs_last_error());
+                    sh->ready.fetch_add(1);
+                    _exit(1);
+                }
+                sh->checksum.fetch_add(sum);
+                vs_shm_client_close(c);
+                _exit(0);
             }
             sh->ready.fetch_add(1);
             while (!sh->go.load(std::memory_order_acquire)) usleep(200);
@@ -137,6 +188,19 @@ int main(int argc, char** argv) {
     if (sh->failed.load() || kids.size() != nb) {
         printf("{\"error\": \"%s\"}\n", sh->err[0] ? sh->err : "a backend could not be started");
         return 1;
+    }
+    if (stream_rows) {
+        if (rows_out) {
+            FILE* f = fopen(rows_out, "wb");
+            if (!f || fwrite(srows, 4, (size_t)nb * stream_rows, f) != (size_t)nb * stream_rows) {
+                printf("{\"error\": \"cannot write %s\"}\n", rows_out);
+                return 1;
+            }
+            fclose(f);
+        }
+        printf("{\"backends\": %u, \"rows_per_scan\": %u, \"chunk\": %u, \"search_list_size\": %u, \"rescore\": %u, \"wall_ms\": %.3f, \"ids_checksum\": %llu}\n",
+               nb, stream_rows, k, L, S, wall_us * 1e-3, (unsigned long long)sh->checksum.load());
+        return 0;
     }
     std::vector<float> all(lat, lat + (size_t)nb * reps);
     std::sort(all.begin(), all.end());

@@ -38,8 +38,42 @@ def _backend(name, lib_path, t, query, L, rescore, rows_wanted, chunk, bar, outq
         outq.put(("error", t, repr(e)))
 
 
+def stream_many_c(name, queries, L, rescore, rows, chunk, timeout=600):
+    """the backends as plain C processes (pgvectorscale_amd/vs_shm_lat, stream mode: what a PostgreSQL backend is to the server — the Python
+    backends below spend about as long in the interpreter per fetch as the fetch takes) -> (wall ms of the timed pass, {backend: node ids})"""
+    import json
+    import subprocess
+    import tempfile
+
+    import numpy as np
+    q = np.ascontiguousarray(np.stack([np.asarray(x, np.float32) for x in queries]))
+    shm_dir = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    qf = tempfile.NamedTemporaryFile(prefix="vs_stream_q_", suffix=".f32", dir=shm_dir, delete=False)
+    qf.write(q.tobytes())
+    qf.close()
+    out_path = qf.name + ".ids"
+    try:
+        cp = subprocess.run([os.path.join(ROOT, "pgvectorscale_amd", "vs_shm_lat"), name, qf.name, str(q.shape[1]), str(len(q)), str(len(q)), "1",
+                             str(L), str(rescore), str(chunk), str(rows), out_path], capture_output=True, text=True, timeout=timeout)
+        line = [ln for ln in cp.stdout.splitlines() if ln.startswith("{")]
+        res = json.loads(line[-1]) if line else {"error": (cp.stderr or "no output")[-300:]}
+        if "error" in res:
+            raise RuntimeError(f"vs_shm_lat (stream mode) failed: {res['error']}")
+        ids = np.fromfile(out_path, np.uint32).reshape(len(q), rows)
+        return float(res["wall_ms"]), {b: [int(v) for v in ids[b] if v != 0xFFFFFFFF] for b in range(len(q))}
+    finally:
+        for f in (qf.name, out_path):
+            try:
+                os.unlink(f)
+            except OSError:
+                pass
+
+
 def stream_many(name, lib_path, queries, L, rescore, rows, chunk, timeout=600):
-    """len(queries) backend processes, one scan each, `rows` rows in chunks of `chunk` -> (wall ms of the timed pass, {backend: node ids})"""
+    """len(queries) backend processes, one scan each, `rows` rows in chunks of `chunk` -> (wall ms of the timed pass, {backend: node ids}).
+    C backends where the harness binary is built (VS_PY_BACKENDS=1 keeps the Python ones)"""
+    if os.path.exists(os.path.join(ROOT, "pgvectorscale_amd", "vs_shm_lat")) and not os.environ.get("VS_PY_BACKENDS"):
+        return stream_many_c(name, queries, L, rescore, rows, chunk, timeout)
     nt = len(queries)
     mpc = mp.get_context("spawn")
     bar = mpc.Barrier(nt + 1)

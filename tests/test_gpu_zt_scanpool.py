@@ -145,3 +145,47 @@ def test_a_pooled_scan_equals_the_single_cursor_and_ends_like_it(gpu_ctx, oracle
     finally:
         pool.close()
         ix.close()
+
+
+def test_a_round_carries_the_listed_scans_that_are_streamed_ahead(gpu_ctx, oracle):
+    """round 6: backends that stream side by side but out of phase (one scan started earlier, chunks of different sizes before they meet) —
+    a round continues every listed scan that is being streamed, not only the ones that ran out of rows, so the group needs the rounds of
+    its neediest scan instead of one round per fetch; the rows and the per-row counters are the same with and without (VS_POOL_TOPUP=0)"""
+    ti = TestIndex(n=4000, dim_full=64, bits=2, R=24, distance=oracle.L2, seed=17, kind="clustered")
+    ix = ti.upload(gpu_ctx)
+    G, k = 8, 8
+    q = ti.queries(G, seed=23, kind="clustered")
+    out, rounds = {}, {}
+    try:
+        for mode in ("1", "0"):
+            P.set_option("VS_POOL_TOPUP", mode)
+            pool = P.ScanPool(ix, G, search_list_size=20, rescore=10, kmax=k, rows_cap=1024)
+            try:
+                for i in range(G):
+                    pool.rescan(i, q[i])
+                got = [[] for _ in range(G)]
+                for i in range(G):  # out of phase: scan i has pulled i chunks of i + 1 rows before the others join
+                    for _ in range(i):
+                        rows, ids, tids, dist = pool.fetch([i], i + 1)
+                        got[i] += [(int(ids[0][j]), int(tids[0][j]), float(dist[0][j])) for j in range(int(rows[0]))]
+                w0 = pool.work()["rounds"]
+                for _ in range(24):  # ... then side by side
+                    rows, ids, tids, dist = pool.fetch(list(range(G)), k)
+                    for i in range(G):
+                        got[i] += [(int(ids[i][j]), int(tids[i][j]), float(dist[i][j])) for j in range(int(rows[i]))]
+                rounds[mode] = pool.work()["rounds"] - w0
+                out[mode] = (got, [pool.stats(i) for i in range(G)])
+            finally:
+                pool.close()
+        assert out["1"][0] == out["0"][0]
+        for a, b in zip(out["1"][1], out["0"][1]):
+            for key in STAT_KEYS:
+                assert a[key] == b[key], key
+        os0 = ti.oracle.scan(q[3], L=20, rescore=10)
+        for j, row in enumerate(out["1"][0][3]):
+            o = os0.gettuple()
+            assert o is not None and row[0] == o[0] and row[1] == o[1], j
+        assert rounds["1"] < rounds["0"], rounds  # (24 fetches of 8 scans out of phase on the interpreter: 12 rounds against 19)
+    finally:
+        P.set_option("VS_POOL_TOPUP", None)
+        ix.close()

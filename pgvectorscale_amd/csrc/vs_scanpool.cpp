@@ -53,9 +53,30 @@ struct vs_scan_pool {
     uint64_t* d_tids = nullptr;
     uint32_t *d_cur = nullptr, *d_ids = nullptr;
     float* d_dist = nullptr;
-    uint64_t launches = 0, rounds = 0, fetches = 0, scans_served = 0;
+    // round 6: a round that is PREFETCHED — launched on a stream of its own at the end of a fetch for the scans that are being streamed,
+    // not waited for — so that the search of the next rows runs while the backends consume the rows they have (see prefetch_round).
+    // One round is in flight at most; its results come back into pinned host memory and are booked when a later call finds it done
+    // (or needs its rows).  The staging arrays of a round (cnt, status, stats, row_stats, stage, roff) belong to the round in flight.
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_round = nullptr;
+    uint32_t* h_pin = nullptr;  // [kst G x ST_N | kstatus 2 G | cnt G | rst G x mmax x ST_N]
+    struct {
+        bool active = false, masked = false;
+        std::vector<uint32_t> run;
+        uint32_t M = 0, nq = 0;
+    } fly;
+    uint64_t launches = 0, rounds = 0, fetches = 0, scans_served = 0, prefetched = 0, prefetch_waits = 0;
     double t_search = 0, t_append = 0, t_resort = 0;  // (VS_POOL_DEBUG) host seconds: launch .. counters back / rerank + append / resort + rows back
     void free_all() {
+        if (stream2) {
+            (void)hipStreamSynchronize(stream2);
+            (void)hipStreamDestroy(stream2);
+            stream2 = nullptr;
+        }
+        if (ev_round) (void)hipEventDestroy(ev_round);
+        ev_round = nullptr;
+        if (h_pin) (void)hipHostFree(h_pin);
+        h_pin = nullptr;
         for (DevBuf* b : {&raw_q, &q_full, &q_index, &qcodes, &qlabels, &qlabel_off, &heap_g, &hash, &state, &cnt, &stats, &status, &row_stats,
                           &stage, &all, &resort_heap, &out_tids, &list, &roff}) {
             if (b->p && !b->in_slab) (void)hipFree(b->p);
@@ -64,6 +85,8 @@ struct vs_scan_pool {
         }
     }
 };
+
+static int settle_prefetch(vs_scan_pool* p, bool wait);
 
 static uint32_t pool_env_u32(const char* name, uint32_t dflt) {
     const char* v = vs_opt_get(name);
@@ -162,6 +185,9 @@ static int scanpool_create_impl(vs_index* ix, uint32_t capacity, uint32_t L, uin
         p->d_dist = (float*)(p->d_ids + G * (size_t)kmax);
         VS_TRY(devbuf_reserve(c, p->list, G * 12));  // (slot, rows, exhausted) of the scans a fetch lists
         VS_TRY(devbuf_reserve(c, p->roff, G * 4));   // where a round's new rows go in every slot's stream arrays
+        VS_HIP(hipStreamCreateWithFlags(&p->stream2, hipStreamNonBlocking));
+        VS_HIP(hipEventCreateWithFlags(&p->ev_round, hipEventDisableTiming));
+        VS_HIP(hipHostMalloc((void**)&p->h_pin, (G * ST_N + 2 * G + G + G * (size_t)p->mmax * ST_N) * 4, hipHostMallocDefault));
         return VS_OK;
     };
     const int r = all();
@@ -184,6 +210,9 @@ extern "C" void vs_scanpool_free(vs_scan_pool* p) {
                         "search %.1f, rerank+append %.1f, resort+rows %.1f\n", p->L, p->rescore, p->fast ? "resumable fast" : "general", (unsigned long long)p->fetches,
                 (unsigned long long)p->scans_served, (unsigned long long)p->rounds, (unsigned long long)p->launches, p->t_search * 1e3, p->t_append * 1e3,
                 p->t_resort * 1e3);
+    if (pool_env_u32("VS_POOL_DEBUG", 0))
+        fprintf(stderr, "[VS_POOL_DEBUG]   %llu of the rounds were prefetched, %llu of those were waited for\n", (unsigned long long)p->prefetched,
+                (unsigned long long)p->prefetch_waits);
     (void)hipSetDevice(p->ix->ctx->device);
     (void)hipStreamSynchronize(p->ix->ctx->stream);
     p->free_all();
@@ -196,6 +225,7 @@ static int scanpool_rescan_impl(vs_scan_pool* p, uint32_t slot, const float* que
     vs_index* ix = p->ix;
     vs_ctx* c = ix->ctx;
     VS_HIP(hipSetDevice(c->device));
+    VS_TRY(settle_prefetch(p, true));  // (a round in flight may be continuing this slot's former scan)
     Slot& s = p->slots[slot];
     const bool keys = has_label_key != 0 && query != nullptr;
     if (ix->d.storage_type == VS_STORAGE_PLAIN) VS_REQUIRE(!keys, "Plain storage does not support label filters");  // AM/plain/storage.rs:262
@@ -226,6 +256,10 @@ extern "C" int vs_scanpool_rescan(vs_scan_pool* p, uint32_t slot, const float* q
 
 extern "C" int vs_scanpool_endscan(vs_scan_pool* p, uint32_t slot) {
     VS_REQUIRE(p && slot < p->cap, "vs_scanpool_endscan: bad slot");
+    if (p->fly.active && std::find(p->fly.run.begin(), p->fly.run.end(), slot) != p->fly.run.end()) {
+        (void)hipSetDevice(p->ix->ctx->device);
+        VS_TRY(settle_prefetch(p, true));  // (its region of the pooled arrays is being written)
+    }
     p->slots[slot] = Slot{};
     p->csr_dirty = true;
     return VS_OK;
@@ -252,14 +286,15 @@ static int upload_csr(vs_scan_pool* p) {
 // One round: every slot of `run` is continued for M more stream rows by launches they share (keyed and unkeyed scans are two launches:
 // "labels is Some" is a property of a launch, AM/labels/mod.rs:222-236), their new rows are reranked together and appended to the
 // slots' stream arrays.
-static int pool_round(vs_scan_pool* p, const std::vector<uint32_t>& run, uint32_t M) {
+// round_launch puts the whole round on the context's current stream, the results' way back into the pinned block included, and does not
+// wait; round_finish books what came back.
+static int round_launch(vs_scan_pool* p, const std::vector<uint32_t>& run, uint32_t M) {
     vs_index* ix = p->ix;
     vs_ctx* c = ix->ctx;
     const uint32_t G = p->cap;
     const bool plain = ix->d.storage_type == VS_STORAGE_PLAIN;
     uint32_t nq = 0;
     for (uint32_t q : run) nq = std::max(nq, q + 1);
-    const auto tp0 = std::chrono::steady_clock::now();
     VS_TRY(upload_csr(p));
     VS_HIP(hipMemsetAsync(p->cnt.p, 0, (size_t)G * 4, c->stream));
     uint32_t* const stage_ids = (uint32_t*)p->stage.p;
@@ -364,25 +399,35 @@ static int pool_round(vs_scan_pool* p, const std::vector<uint32_t>& run, uint32_
                                   (uint32_t)((size_t)G * p->rows_cap), p->rows_cap));
     }
     // outcome, counters and row counts of the slots that ran (what the kernel publishes per scan next to the saved state)
-    std::vector<uint32_t> kst((size_t)nq * ST_N), kstatus((size_t)2 * G), cnt(nq), rst((size_t)nq * M * ST_N);
-    VS_HIP(hipMemcpyAsync(kst.data(), p->stats.p, (size_t)nq * ST_N * 4, hipMemcpyDeviceToHost, c->stream));
-    VS_HIP(hipMemcpyAsync(kstatus.data(), p->status.p, (size_t)2 * G * 4, hipMemcpyDeviceToHost, c->stream));
-    VS_HIP(hipMemcpyAsync(cnt.data(), p->cnt.p, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
-    VS_HIP(hipMemcpyAsync(rst.data(), p->row_stats.p, rst.size() * 4, hipMemcpyDeviceToHost, c->stream));
-    VS_HIP(hipStreamSynchronize(c->stream));
-    const auto tp1 = std::chrono::steady_clock::now();
-    p->t_search += std::chrono::duration<double>(tp1 - tp0).count();
+    uint32_t* const kst = p->h_pin;
+    uint32_t* const kstatus = kst + (size_t)G * ST_N;
+    uint32_t* const cnt = kstatus + 2 * (size_t)G;
+    uint32_t* const rst = cnt + G;
+    VS_HIP(hipMemcpyAsync(kst, p->stats.p, (size_t)nq * ST_N * 4, hipMemcpyDeviceToHost, c->stream));
+    VS_HIP(hipMemcpyAsync(kstatus, p->status.p, (size_t)2 * G * 4, hipMemcpyDeviceToHost, c->stream));
+    VS_HIP(hipMemcpyAsync(cnt, p->cnt.p, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
+    VS_HIP(hipMemcpyAsync(rst, p->row_stats.p, (size_t)nq * M * ST_N * 4, hipMemcpyDeviceToHost, c->stream));
+    return VS_OK;
+}
+
+static void round_finish(vs_scan_pool* p, const std::vector<uint32_t>& run, uint32_t M, bool masked) {
+    const uint32_t G = p->cap;
+    const uint32_t* const kst = p->h_pin;
+    const uint32_t* const kstatus = kst + (size_t)G * ST_N;
+    const uint32_t* const cnt = kstatus + 2 * (size_t)G;
+    const uint32_t* const rst = cnt + G;
     for (uint32_t q : run) {
         Slot& s = p->slots[q];
-        const uint32_t* h = kst.data() + (size_t)q * ST_N;
+        if (!s.active) continue;  // (ended while the round was in flight)
+        const uint32_t* h = kst + (size_t)q * ST_N;
         s.launches++;
-        s.masked = p->S > 0 && ix->visible != nullptr;
+        s.masked = masked;
         if (kstatus[(size_t)(s.keys ? G : 0) + q] != 0) {  // a structure outgrew the pool's capacities: the scan continues on a cursor of its own
             s.failed = true;
             continue;
         }
         const uint32_t n = std::min(cnt[q], M);
-        s.row_stats.insert(s.row_stats.end(), rst.begin() + (size_t)q * M * ST_N, rst.begin() + ((size_t)q * M + n) * ST_N);
+        s.row_stats.insert(s.row_stats.end(), rst + (size_t)q * M * ST_N, rst + ((size_t)q * M + n) * ST_N);
         s.rows += n;
         if (n < M) {
             s.exhausted = true;
@@ -395,7 +440,81 @@ static int pool_round(vs_scan_pool* p, const std::vector<uint32_t>& run, uint32_
             s.final_counters[ST_INVIS] = h[ST_INVIS];
         }
     }
+}
+
+// the round in flight, if any: booked when it has finished — or waited for when `wait` (a listed scan needs its rows, another round wants
+// the staging arrays, a slot is rescanned)
+static int settle_prefetch(vs_scan_pool* p, bool wait) {
+    if (!p->fly.active) return VS_OK;
+    if (!wait) {
+        const hipError_t e = hipEventQuery(p->ev_round);
+        if (e == hipErrorNotReady) return VS_OK;
+        VS_HIP(e);
+    } else {
+        const auto t0 = std::chrono::steady_clock::now();
+        VS_HIP(hipEventSynchronize(p->ev_round));
+        p->t_search += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        p->prefetch_waits++;
+    }
+    p->fly.active = false;
+    round_finish(p, p->fly.run, p->fly.M, p->fly.masked);
+    return VS_OK;
+}
+
+// a round the caller waits for (the first rows of a scan, scans that are not streamed ahead, whatever a prefetched round did not cover)
+static int pool_round(vs_scan_pool* p, const std::vector<uint32_t>& run, uint32_t M) {
+    vs_ctx* c = p->ix->ctx;
+    VS_TRY(settle_prefetch(p, true));  // (the staging arrays are one round's)
+    const auto tp0 = std::chrono::steady_clock::now();
+    VS_TRY(round_launch(p, run, M));
+    VS_HIP(hipStreamSynchronize(c->stream));
+    const auto tp1 = std::chrono::steady_clock::now();
+    p->t_search += std::chrono::duration<double>(tp1 - tp0).count();
+    round_finish(p, run, M, p->S > 0 && p->ix->visible != nullptr);
     p->t_append += std::chrono::duration<double>(std::chrono::steady_clock::now() - tp1).count();
+    return VS_OK;
+}
+
+// The next round of the scans that are being streamed, launched WITHOUT waiting at the end of a fetch (round 6).  A backend that pulls a
+// long scan chunk by chunk leaves the GPU idle between its fetches, and the round its fetch eventually needs costs the life of one wave
+// (0.6 ms for 64 rows at search_list_size 100) during which every backend of that fetch waits: with 64 backends streaming 1 000 rows each the
+// rounds were 15 of the 35 ms.  Launched one fetch early on a stream of its own, the round runs while the rows already there are
+// handed out.  What keeps it simple: ONE round in flight; only scans without label keys, only while no snapshot mask is in force
+// (a mask may be replaced while the round runs) and only on the resumable fast kernel — everything else takes the rounds it waits
+// for; a scan is carried at most two rounds ahead of its executor and never past its row budget; the per-row counters hide what the
+// executor has not pulled.
+static int prefetch_round(vs_scan_pool* p, const uint32_t* slots, uint32_t n, uint32_t k) {
+    vs_index* ix = p->ix;
+    vs_ctx* c = ix->ctx;
+    if (p->fly.active || !p->fast || ix->visible != nullptr || !pool_env_u32("VS_POOL_PREFETCH", 1)) return VS_OK;
+    const uint32_t S = p->S;
+    const uint32_t M = std::min<uint32_t>(4 * k, p->mmax);
+    std::vector<uint32_t> run;
+    for (uint32_t i = 0; i < n; ++i) {
+        const Slot& s = p->slots[slots[i]];
+        if (!s.active || s.failed || s.exhausted || s.keys || s.launches < 2) continue;
+        const uint64_t need = S > 0 ? (uint64_t)S + s.handed + k - 1 : (uint64_t)s.handed + k;  // what the NEXT fetch of k rows stands on
+        if ((uint64_t)s.rows + M > p->rows_cap || s.rows >= need + M) continue;  // (no room / a round ahead already)
+        run.push_back(slots[i]);
+    }
+    if (run.empty()) return VS_OK;
+    std::sort(run.begin(), run.end());
+    if (p->csr_dirty) {  // (the keys of the other slots changed: their upload goes over the context's own stream and is finished first)
+        VS_TRY(upload_csr(p));
+        VS_HIP(hipStreamSynchronize(c->stream));
+    }
+    hipStream_t const own = c->stream;
+    c->stream = p->stream2;  // (the launch wrappers take the stream from the context; the dispatcher thread is its only user)
+    const int r = round_launch(p, run, M);
+    const hipError_t e = r == VS_OK ? hipEventRecord(p->ev_round, p->stream2) : hipSuccess;
+    c->stream = own;
+    VS_TRY(r);
+    VS_HIP(e);
+    p->fly.active = true;
+    p->fly.masked = false;
+    p->fly.run.swap(run);
+    p->fly.M = M;
+    p->prefetched++;
     return VS_OK;
 }
 
@@ -414,6 +533,7 @@ static int scanpool_fetch_impl(vs_scan_pool* p, const uint32_t* slots, uint32_t 
         VS_REQUIRE(!listed[slots[i]], "vs_scanpool_fetch: slot %u listed twice", slots[i]);
         listed[slots[i]] = 1;
     }
+    VS_TRY(settle_prefetch(p, false));  // (a prefetched round that has finished meanwhile is booked; one that has not stays in flight)
     // ---- rounds of shared launches until every listed scan has the stream rows its k calls need (or has ended)
     for (;;) {
         std::vector<uint32_t> run;
@@ -431,6 +551,10 @@ static int scanpool_fetch_impl(vs_scan_pool* p, const uint32_t* slots, uint32_t 
             M = std::max<uint32_t>(M, (uint32_t)(need - s.rows));
         }
         if (run.empty()) break;
+        if (p->fly.active) {  // the rows may be on their way already (and the staging arrays are the round's in flight either way)
+            VS_TRY(settle_prefetch(p, true));
+            continue;
+        }
         // a scan that keeps being streamed is carried ahead of its executor: from its third continuation on a round produces up to
         // four chunks of rows (bounded by the round's staging rows), so most of its later fetches find their rows already there.  The
         // counters are recorded per row: what the executor has not pulled does not show in them.
@@ -515,7 +639,7 @@ static int scanpool_fetch_impl(vs_scan_pool* p, const uint32_t* slots, uint32_t 
         if (got < k) s.calls_after_end += 1;  // the call that found the scan at its end (the executor stops there)
         out_rows[i] = (int32_t)got;
     }
-    return VS_OK;
+    return prefetch_round(p, slots, n, k);  // the next rows of the scans that are being streamed: searched while these are consumed
 }
 extern "C" int vs_scanpool_fetch(vs_scan_pool* p, const uint32_t* slots, uint32_t n, uint32_t k, uint64_t* out_tids, uint32_t* out_ids,
                                  float* out_dist, int32_t* out_rows) {

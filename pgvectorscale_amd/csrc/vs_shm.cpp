@@ -258,6 +258,7 @@ const char* vs_shm_server::take(uint32_t slot) {
     if (r.op > OP_CLOSE) return "unknown request kind";
     if (r.op == OP_FETCH && (uint64_t)r.skip + r.k > (1u << 30)) return "row position out of range";
     memcpy(r.labels, s->labels, (size_t)r.n_labels * sizeof(int16_t));
+    r.query = std::move(reqs[slot].query);  // (the slot's buffer is kept from request to request: no allocation per cursor request)
     r.query.resize(d.dim_full);
     if (!r.null_query) memcpy(r.query.data(), Mapping::query(s), (size_t)d.dim_full * 4);
     reqs[slot] = std::move(r);
@@ -337,10 +338,19 @@ void vs_shm_server::reap_cursors(CursorTable& t) {
 // what identifies the scan a cursor belongs to besides (pid, scan_id): a client that reuses an id for another scan gets a new cursor
 template <class R>
 static uint64_t scan_signature(const R* s, const float* q, uint32_t dim) {
+    // (eight bytes per step: every cursor request carries its query and is hashed again — byte by byte that was 3 us per request, the
+    // largest single item of a dispatcher round with 64 backends streaming; the value only has to tell scans apart inside one server)
     uint64_t h = 1469598103934665603ull;
     auto mix = [&](const void* p, size_t n) {
         const unsigned char* b = static_cast<const unsigned char*>(p);
-        for (size_t i = 0; i < n; ++i) h = (h ^ b[i]) * 1099511628211ull;
+        size_t i = 0;
+        for (; i + 8 <= n; i += 8) {
+            uint64_t w;
+            memcpy(&w, b + i, 8);
+            h = (h ^ w) * 0x9E3779B97F4A7C15ull;
+            h ^= h >> 29;
+        }
+        for (; i < n; ++i) h = (h ^ b[i]) * 1099511628211ull;
     };
     const uint32_t g[6] = {s->L, s->rescore, s->has_label_key, s->null_query, s->snapshot, s->n_labels};
     mix(g, sizeof(g));

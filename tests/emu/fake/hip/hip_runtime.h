@@ -203,13 +203,13 @@ using std::min;
 
 // ---- runtime API (synchronous; "device" memory is host memory) -------------------------------------------------------
 typedef int hipError_t;
-enum { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorInvalidValue = 1, hipErrorPeerAccessAlreadyEnabled = 704 };
+enum { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorInvalidValue = 1, hipErrorNotReady = 600, hipErrorPeerAccessAlreadyEnabled = 704 };
 enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
 enum { hipStreamNonBlocking = 1, hipHostMallocDefault = 0, hipEventDisableTiming = 2, hipEventDefault = 0 };
 enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 struct emu_stream;
 typedef emu_stream* hipStream_t;
-struct emu_event { std::chrono::steady_clock::time_point t; };
+struct emu_event { std::chrono::steady_clock::time_point t; unsigned lag = 0; };
 typedef emu_event* hipEvent_t;
 struct hipDeviceProp_t {
     char name[256];
@@ -277,8 +277,22 @@ static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned = 
 static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = new emu_event(); return hipSuccess; }
 static inline hipError_t hipEventCreate(hipEvent_t* e) { return hipEventCreateWithFlags(e, 0); }
 static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
-static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = nullptr) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
-static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = nullptr) {
+    e->t = std::chrono::steady_clock::now();
+    // (work runs to completion inside the launch call here; VS_EMU_EVENT_LAG=n makes the first n queries of a recorded event answer "not
+    // ready", so that the callers' paths for work still in flight are walked too)
+    const char* lag = getenv("VS_EMU_EVENT_LAG");
+    e->lag = lag ? (unsigned)atoi(lag) : 0u;
+    return hipSuccess;
+}
+static inline hipError_t hipEventQuery(hipEvent_t e) {
+    if (e->lag) {
+        e->lag--;
+        return (hipError_t)hipErrorNotReady;
+    }
+    return hipSuccess;
+}
+static inline hipError_t hipEventSynchronize(hipEvent_t e) { e->lag = 0; return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
     *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();
     return hipSuccess;

@@ -157,8 +157,11 @@ def test_a_round_carries_the_listed_scans_that_are_streamed_ahead(gpu_ctx, oracl
     q = ti.queries(G, seed=23, kind="clustered")
     out, rounds = {}, {}
     try:
-        for mode in ("1", "0"):
-            P.set_option("VS_POOL_TOPUP", mode)
+        for mode in ("1", "0", "prefetch"):
+            # "1" / "0": rounds the caller waits for only, with / without carrying the other listed scans; "prefetch": the default — the next
+            # round of the streamed scans is launched at the end of a fetch and booked by a later call (VS_EMU_EVENT_LAG walks both ways)
+            P.set_option("VS_POOL_TOPUP", "0" if mode == "0" else "1")
+            P.set_option("VS_POOL_PREFETCH", "1" if mode == "prefetch" else "0")
             pool = P.ScanPool(ix, G, search_list_size=20, rescore=10, kmax=k, rows_cap=1024)
             try:
                 for i in range(G):
@@ -177,10 +180,11 @@ def test_a_round_carries_the_listed_scans_that_are_streamed_ahead(gpu_ctx, oracl
                 out[mode] = (got, [pool.stats(i) for i in range(G)])
             finally:
                 pool.close()
-        assert out["1"][0] == out["0"][0]
-        for a, b in zip(out["1"][1], out["0"][1]):
-            for key in STAT_KEYS:
-                assert a[key] == b[key], key
+        for other in ("0", "prefetch"):
+            assert out["1"][0] == out[other][0], other
+            for a, b in zip(out["1"][1], out[other][1]):
+                for key in STAT_KEYS:
+                    assert a[key] == b[key], (other, key)
         os0 = ti.oracle.scan(q[3], L=20, rescore=10)
         for j, row in enumerate(out["1"][0][3]):
             o = os0.gettuple()
@@ -188,4 +192,5 @@ def test_a_round_carries_the_listed_scans_that_are_streamed_ahead(gpu_ctx, oracl
         assert rounds["1"] < rounds["0"], rounds  # (24 fetches of 8 scans out of phase on the interpreter: 12 rounds against 19)
     finally:
         P.set_option("VS_POOL_TOPUP", None)
+        P.set_option("VS_POOL_PREFETCH", None)
         ix.close()

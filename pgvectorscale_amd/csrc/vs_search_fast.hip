@@ -1736,16 +1736,18 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
 
 template <int NCH, int VR, bool TIMING, int MINW, bool BUILD, bool FULL = true, int VG = 0, int OPT = 0>
 __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
-    if (!a.s.persist) {
-        if (blockIdx.x < a.s.nq) fast_scan<NCH, VR, TIMING, MINW, BUILD, FULL, VG, OPT>(a, blockIdx.x, blockIdx.x);
-        return;
-    }
-    // persistent grid: the launch has no tail of its own beyond the last scans' lives, and the hardware never has to place a
-    // new workgroup (LDS, registers, a wave slot) while the chip is full
-    for (;;) {
-        uint32_t q = 0;
-        if (threadIdx.x == 0) q = atomicAdd(a.s.scan_counter, 1u);
-        q = rfl(q);
+    // persistent grid (a.s.persist): the launch has no tail of its own beyond the last scans' lives, and the hardware never has to place a
+    // new workgroup (LDS, registers, a wave slot) while the chip is full; otherwise one workgroup per scan.  ONE inlined copy of the scan
+    // for both (round 6): as two copies the register allocator spilled differently in each, and a change that was neutral for the
+    // launches of one kind cost those of the other 35 % in scratch traffic (profiles/r06/s12, s13).
+    for (uint32_t it = 0;; ++it) {
+        uint32_t q = blockIdx.x;
+        if (a.s.persist) {
+            if (threadIdx.x == 0) q = atomicAdd(a.s.scan_counter, 1u);
+            q = rfl(q);
+        } else if (it) {
+            return;
+        }
         if (q >= a.s.nq) return;
         fast_scan<NCH, VR, TIMING, MINW, BUILD, FULL, VG, OPT>(a, q, blockIdx.x);
         wave_sync();  // the next scan re-initialises the LDS state: every lane is done with this one's

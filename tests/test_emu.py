@@ -31,7 +31,7 @@ SUBSET = ("test_hip_path_reproduces_golden or test_index_from_pages_searches_lik
           "test_small_scans_try_the_table_less_regime or test_set_variant_by_name or "
           "test_a_client_that_rewrites_its_request_after_posting_cannot_move_the_dispatcher or test_replica_on_a_second_context_outlives_its_source or (test_multi_search_batch_returns_the_single_device_rows and 33) or "
           "test_comm_world_of_one_gathers_and_replicates or test_entry_points_that_move_the_arrays_refuse_while_a_view_is_alive or "
-          "test_placement_never_changes_a_row or test_pooled_scans_hand_out_the_oracles_rows_and_stats or (test_every_regime_is_exact and tableless_q16_tight) or "
+          "test_placement_never_changes_a_row or test_pooled_scans_hand_out_the_oracles_rows_and_stats or test_a_round_carries_the_listed_scans_that_are_streamed_ahead or (test_every_regime_is_exact and tableless_q16_tight) or "
           "test_handles_return_their_device_memory or test_deep_scans_stream_on_lanes or test_shm_server_with_lanes_gives_its_memory_back or test_staging_ring_round_trip or test_row_wise_staging_pads_and_copies_every_row")
 
 

@@ -223,6 +223,19 @@ bool vs_neighbor_masks_wanted(const vs_index* ix);  // policy: > 8M nodes, or VS
 int vs_refresh_neighbor_masks(vs_index* ix);  // (re)derives nbr_mask when it is stale (no-op for a view or when it does not fit)
 int vs_refresh_label_masks(vs_index* ix);  // (re)derives label_mask / label_bit from the label CSR, or drops them when the index uses more than 64 distinct labels
 void devbuf_free(DevBuf& b);
+// ---- shared by the host-side translation units (vs_api / vs_slab / vs_batch / vs_tune / vs_cursor .hip) ----------
+// an option as a number (vs_options.cpp: vs_set_option, else the snapshot of the VS_* environment), else the default
+static inline uint32_t env_u32(const char* name, uint32_t dflt) {
+    const char* v = vs_opt_get(name);
+    return v && *v ? (uint32_t)strtoul(v, nullptr, 10) : dflt;
+}
+size_t slab_bytes_wanted(const vs_index* ix);                      // vs_slab.hip: 0 = this index gets no slab
+void slab_select(vs_index* ix, WsSlab* s, size_t slab_bytes);     // vs_slab.hip: probes the candidates (caller holds s->mu)
+hipEvent_t pool_event(vs_ctx* c);                                  // vs_api.hip: an event from the context's pool
+int download_async_rows(vs_ctx* c, void* dst, const void* src, size_t bytes);  // vs_api.hip: rows back through the pinned ring
+int vs_search_batch_dev_impl(vs_index* ix, const float* d_queries, const int16_t* d_qlabels, const uint32_t* d_qlabel_off, uint32_t nq,
+                             uint32_t L, uint32_t rescore, uint32_t k, uint32_t* d_out_ids, uint64_t* d_out_tids, float* d_out_dist);  // vs_batch.hip
+int vs_search_batch_dev_finish_impl(vs_index* ix, vs_stats* stats);  // vs_batch.hip
 
 // ---- kernel launch wrappers (defined in the .hip files) -------------------------------------------------------
 struct SearchLaunch {

@@ -33,6 +33,15 @@
 //
 // A scan whose state outgrows the LDS budget sets a status flag and is re-run by the general kernel
 // (vs_search.hip, unbounded global spill) in a follow-up launch that skips every scan that completed here.
+//
+// THREE translation units are compiled from this source (round 6; VS_FAST_TU, set by the two-line files vs_search_fast_plain6.hip and
+// vs_search_fast_keys6.hip that include it): 0 = the dispatcher and every instantiation but four; 1 = the two instantiations the
+// unfiltered scans of the usual index run at six waves per SIMD; 2 = their two label-key counterparts.  The split exists so that each
+// group can be built with the code-generation options measured best for IT: the compiler's scheduling strategy moves these kernels by
+// 1-10 % and in opposite directions (profiles/r06/s17, s18; csrc/Makefile has the options and the numbers).
+#ifndef VS_FAST_TU
+#define VS_FAST_TU 0
+#endif
 #include <cstdlib>
 
 #include "vs_device.h"
@@ -1754,6 +1763,7 @@ __global__ __launch_bounds__(WAVE, MINW) void k_search_fast(FastArgs a) {
     }
 }
 
+#if VS_FAST_TU == 0
 // u32 words of one saved scan at these capacities (header + the LDS image: heap top, visited ring, occupancy bits)
 size_t fast_resume_words(const FastLaunch& s) { return RSF_HDR + ((size_t)(s.hl + 1) + 2 * (size_t)s.vcap + s.vwords + 3) / 4 * 4; }
 
@@ -1767,6 +1777,8 @@ size_t fast_lds_bytes(const vs_index* idx, const FastLaunch& s) {
                (lean && plain ? 0 : MAX_QLABELS * 2) + qcopy + (size_t)s.rc * 4 + (size_t)s.vwords * 4 + (lean ? 16 : 32);
     return (b + 15) / 16 * 16;
 }
+
+#endif  // VS_FAST_TU == 0
 
 template <int NCH, int VR, bool TIMING, int MINW, bool BUILD, bool FULL = true, int VG = 0, int OPT = 0>
 static int launch_fast_tt(vs_index* idx, const FastArgs& a, size_t lds, uint32_t* resident) {
@@ -1789,6 +1801,21 @@ static int launch_fast_tt(vs_index* idx, const FastArgs& a, size_t lds, uint32_t
     return VS_OK;
 }
 
+// the four instantiations that live in translation units of their own (16-bit tables, 24-word code rows, six waves per SIMD; std_geom:
+// num_neighbors <= 64 at a row pitch of 64 ids, the compile-time geometry of OPT_XW | OPT_R1 | OPT_NS64)
+int launch_fast_plain6(vs_index* idx, const FastArgs& a, size_t lds, uint32_t* res, bool std_geom);  // no label keys, no visibility mask
+int launch_fast_keys6(vs_index* idx, const FastArgs& a, size_t lds, uint32_t* res, bool std_geom);   // with
+#if VS_FAST_TU == 1
+int launch_fast_plain6(vs_index* idx, const FastArgs& a, size_t lds, uint32_t* res, bool std_geom) {
+    if (std_geom) return launch_fast_tt<3, 0, false, 6, false, false, 3, OPT_XW | OPT_R1 | OPT_NS64>(idx, a, lds, res);
+    return launch_fast_tt<3, 0, false, 6, false, false, 3>(idx, a, lds, res);
+}
+#elif VS_FAST_TU == 2
+int launch_fast_keys6(vs_index* idx, const FastArgs& a, size_t lds, uint32_t* res, bool std_geom) {
+    if (std_geom) return launch_fast_tt<3, 0, false, 6, false, true, 3, OPT_XW | OPT_R1 | OPT_NS64>(idx, a, lds, res);
+    return launch_fast_tt<3, 0, false, 6, false, true, 3>(idx, a, lds, res);
+}
+#else
 template <int NCH>
 static int launch_fast_t(vs_index* idx, const FastArgs& a, size_t lds, uint32_t* res) {
     if (a.s.build) {
@@ -1817,10 +1844,8 @@ static int launch_fast_t(vs_index* idx, const FastArgs& a, size_t lds, uint32_t*
         // (OPT_G2 at six waves per SIMD — two code rows per 4-lane group in flight, 78 VGPRs, no spills — was timed at 50M in round 6:
         // 134.6 ms against 130.3, profiles/r06/s4_ab_50m.txt.  More requests in flight per scan do not help a launch whose 6 144 scans
         // already keep the memory system busy; the instantiation is not built.)
-        if (NCH == 3 && a.s.minw == 6 && plain && std_geom) return launch_fast_tt<3, 0, false, 6, false, false, 3, OPT_XW | OPT_R1 | OPT_NS64>(idx, a, lds, res);
-        if (NCH == 3 && a.s.minw == 6 && std_geom) return launch_fast_tt<3, 0, false, 6, false, true, 3, OPT_XW | OPT_R1 | OPT_NS64>(idx, a, lds, res);
-        if (NCH == 3 && a.s.minw == 6 && plain) return launch_fast_tt<3, 0, false, 6, false, false, 3>(idx, a, lds, res);
-        if (NCH == 3 && a.s.minw == 6) return launch_fast_tt<3, 0, false, 6, false, true, 3>(idx, a, lds, res);
+        if (NCH == 3 && a.s.minw == 6 && plain) return launch_fast_plain6(idx, a, lds, res, std_geom);
+        if (NCH == 3 && a.s.minw == 6) return launch_fast_keys6(idx, a, lds, res, std_geom);
         if (NCH == 3 && a.s.minw == 7 && plain && std_geom) return launch_fast_tt<3, 0, false, 7, false, false, 3, OPT_XW | OPT_R1 | OPT_NS64>(idx, a, lds, res);
         if (NCH == 3 && a.s.minw == 7 && plain) return launch_fast_tt<3, 0, false, 7, false, false, 3>(idx, a, lds, res);
         if (NCH == 3 && a.s.minw == 7) return launch_fast_tt<3, 0, false, 7, false, true, 3>(idx, a, lds, res);
@@ -1918,3 +1943,4 @@ int launch_search_fast(vs_index* idx, const FastLaunch& s) {
 
 // scans of the instantiation `s` selects that are resident on the device at once (the size of a persistent grid)
 int fast_resident_scans(vs_index* idx, const FastLaunch& s, uint32_t* out) { return fast_dispatch(idx, s, out); }
+#endif  // VS_FAST_TU

@@ -349,6 +349,11 @@ int devbuf_reserve_hot(vs_index* ix, DevBuf& b, size_t bytes, int which) {
                 s->used[which] += want;
                 return VS_OK;
             }
+            // chunks are bump-allocated and never returned (views that come and go, growth that cannot extend in place): a region
+            // that has run out sends the array to an allocation of its own — correct, but without the placement the slab exists for
+            if (env_u32("VS_WS_DEBUG", 0))
+                fprintf(stderr, "[VS_WS_DEBUG] workspace slab: region %d exhausted (%zu of %zu B used, %zu wanted): own allocation\n", which,
+                        s->used[which], s->bytes[which], want);
         }
     }
     return devbuf_reserve(ix->ctx, b, bytes);

@@ -3,7 +3,8 @@
 per kernel — from the AMDGPU metadata notes of the device ELF (llvm-readelf --notes), which is what the hardware runs.  rocprofv3's own
 VGPR / LDS columns are launch-time fields (allocation granules, dynamic LDS left out) and disagreed with these in round 5.
 
-  python scripts/codeobj_notes.py pgvectorscale_amd/csrc/vs_search_fast.o [name-filter]     (no GPU needed)
+  python scripts/codeobj_notes.py pgvectorscale_amd/csrc/vs_search_fast_plain6.o [name-filter]     (no GPU needed; k_search_fast lives in
+  vs_search_fast.o, vs_search_fast_plain6.o and vs_search_fast_keys6.o since round 6)
 """
 import os
 import re

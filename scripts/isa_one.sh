@@ -8,7 +8,7 @@ INST=${1:-"3, 0, false, 6, false, false, 3"}
 OUT=${2:-/tmp/isa/one.s}
 mkdir -p "$(dirname "$OUT")"
 TMP=$(mktemp /tmp/isa_one_XXXX.hip)
-awk '/^size_t fast_lds_bytes/ {exit} {print}' "$SRC" > "$TMP"
+awk '/^#if VS_FAST_TU == 0/ {exit} {print}' "$SRC" > "$TMP"   # (everything above the host side of translation unit 0)
 echo "template __global__ void k_search_fast<$INST>(FastArgs);" >> "$TMP"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math \
     -I"$ROOT/pgvectorscale_amd/csrc" --cuda-device-only -S -o "$OUT" "$TMP" 2>/dev/null

@@ -53,12 +53,20 @@ def main(src, dst, note=""):
                 import codeobj_notes
                 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
                 want = re.sub(r"\s+", "", fl["name"].split("(")[0])
-                for d in codeobj_notes.kernels(os.path.join(root, "pgvectorscale_amd", "csrc", "vs_search_fast.o")):
-                    if re.sub(r"\s+", "", d["demangled"].split("(")[0].replace("void ", "")) == want:
-                        f.write(f"# code object (llvm-readelf --notes on csrc/vs_search_fast.o), {d['demangled'].split('(')[0]}: {codeobj_notes.line(d)}\n")
+                # (k_search_fast is built as three translation units since round 6: look in each object)
+                objs = [o for o in ("vs_search_fast_plain6.o", "vs_search_fast_keys6.o", "vs_search_fast.o")
+                        if os.path.exists(os.path.join(root, "pgvectorscale_amd", "csrc", o))]
+                found = False
+                for o in objs:
+                    for d in codeobj_notes.kernels(os.path.join(root, "pgvectorscale_amd", "csrc", o)):
+                        if re.sub(r"\s+", "", d["demangled"].split("(")[0].replace("void ", "")) == want:
+                            f.write(f"# code object (llvm-readelf --notes on csrc/{o}), {d['demangled'].split('(')[0]}: {codeobj_notes.line(d)}\n")
+                            found = True
+                            break
+                    if found:
                         break
-                else:
-                    f.write(f"# code object: no instantiation named {want} in csrc/vs_search_fast.o\n")
+                if not found:
+                    f.write(f"# code object: no instantiation named {want} in {', '.join('csrc/' + o for o in objs)}\n")
             except Exception as e:  # noqa: BLE001
                 f.write(f"# code object notes unavailable: {e!r}\n")
         f.write("kernel,calls,total_ms,avg_us,min_us,max_us,pct\n")

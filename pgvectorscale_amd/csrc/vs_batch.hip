@@ -299,9 +299,11 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
         // Default since round 5: the 16-bit tables below (VS_F_VIRGIN=3) — 139.7 ms per 262 144 scans at 50M against 153.5 with the 4-byte
         // slot-bitmap tables, same session, same slab (profiles/r05/s10_ab_q16_50m.txt); 300 device fuzz runs, regimes green on hardware.
         const uint32_t vmode = knob_u32("VS_F_VIRGIN", ix->tune.virgin, 3);
+        bool slot_eligible = false;  // one occupancy bit per slot is possible for this table (whether or not the 4-byte slot bitmap is taken)
         if (caps.f_lh == 0 && !f.vr && vmode && !env_u32("VS_PHASE", 0) && f.gcap <= (1u << 16)) {
             f.vwords = (f.gcap + 127) / 128;
             if (vmode >= 2 && !f.rc && f.gcap % 32 == 0) {
+                slot_eligible = true;
                 FastLaunch g = f;
                 g.vwords = f.gcap / 32;
                 g.vslot = 1;
@@ -318,8 +320,18 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
         // hash of the node id given its bucket (quotienting), a small overflow table of whole ids behind the buckets.  Half the bytes
         // per slot: the tables of the scans in flight are the largest part of the kernel's hot private state (fast_scan, VG == 3).
         // Needs a power-of-two number of buckets and ceil(log2 n) - log2(buckets) <= 16 remainder bits.
+        // Round 6 (profiles/r06/s20-s22): the rule used to be "only while it costs no scans per CU", against the 4-byte slot bitmap, which
+        // itself had to cost none against the bucket bitmap — and at search_list_size 100 (a visited ring of 3 KB per scan) it does:
+        // 19 resident scans per CU against 23.  So the reference's default GUCs, the label-filtered configuration and every other long
+        // list ran round 3's bucket-bitmap tables and none of the round-5 / round-6 kernel work (rocprofv3 names the instantiation:
+        // k_search_fast<3,0,false,6,false,*,1,0>).  Measured at 10M, 100 / 50: 100.8 ms per 262 144 scans (bucket bitmap, 23 per CU)
+        // against 90.4 (16-bit tables, 19 per CU) and 86.2 (16-bit tables with the heap top below, 22 per CU); label keys at 100 / 90:
+        // 119.1 / 115.5 / 110.6.  The 16-bit tables are now taken while they keep at least four fifths of the resident scans of whatever
+        // the rules above chose — two thirds for label-filtered scans (s24, 10M x 1536, 100 / 90: 110.2 ms at 15 scans per CU against 119.0
+        // at 22).  Not below that for unfiltered scans: the `mid` corpus at 100 / 592 (tables of 32 Ki slots, 15 against 21 per CU, the
+        // heap spill arrays carrying most of the traffic) runs 436.6 ms with them against 382.2 without (s24).
         uint32_t gregion = f.gcap;
-        if (vmode == 3 && f.vslot == 1 && caps.f_lh == 0) {
+        if (vmode == 3 && f.vwords && slot_eligible && caps.f_lh == 0) {
             uint32_t qd = 1;
             while ((1ull << qd) < (uint64_t)std::max<uint32_t>(ix->d.n, 2)) qd++;
             const uint32_t gcap16 = std::max<uint32_t>(next_pow2_u32(f.gcap), 1024);
@@ -343,9 +355,34 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
                 g.glimit = (uint32_t)((uint64_t)g.gcap * gload_pct() / 100) - 64u;
                 VS_TRY(fast_resident_scans(ix, f, &res_s));
                 VS_TRY(fast_resident_scans(ix, g, &res_q));
-                if (res_q >= res_s || env_u32("VS_F_SLOTMAP_FORCE", 0)) {  // (taken only while it costs no scans per CU)
+                if (env_u32("VS_WS_DEBUG", 0))
+                    fprintf(stderr, "[VS_WS_DEBUG] resident scans: 4-byte tables %u, 16-bit tables %u; gcap %u -> %u\n", res_s, res_q, f.gcap, g.gcap);
+                // (label-filtered scans mark ~50 ids per ~9 scored rows, AM/sbq/storage.rs:148-172: the table is most of what they touch)
+                const bool keyed = f.qlabel_off != nullptr;
+                if ((keyed ? 3ull * res_q >= 2ull * res_s : 5ull * res_q >= 4ull * res_s) || env_u32("VS_F_SLOTMAP_FORCE", 0)) {
                     f = g;
                     gregion = g.gregion;
+                }
+            }
+        }
+        // LDS-bound launches: where the LDS per scan — not the register cap of the instantiation — limits the resident scans, a heap top
+        // of 255 entries instead of 511 (1 KB less) is taken when it buys at least a tenth more of them (s22: 90.4 -> 86.2 ms at 100 / 50,
+        // 115.5 -> 110.6 with label keys, 22 instead of 19 per CU; where the registers are the limit — search_list_size 3, 24 per CU —
+        // nothing changes: there a smaller heap top only costs).  An explicit VS_F_HL stands.
+        if (caps.f_lh == 0 && !f.vr && f.hl == 511 && f.hcap > 511 && !env_u32("VS_PHASE", 0)) {
+            const char* const hl_opt = vs_opt_get("VS_F_HL");
+            if (!(hl_opt && *hl_opt)) {
+                FastLaunch h = f;
+                h.hl = 255;
+                h.gstride = round_up_u32(h.hcap - h.hl + 2, 2);
+                uint32_t res_511 = 0, res_255 = 0;
+                VS_TRY(fast_resident_scans(ix, f, &res_511));
+                VS_TRY(fast_resident_scans(ix, h, &res_255));
+                if (env_u32("VS_WS_DEBUG", 0)) fprintf(stderr, "[VS_WS_DEBUG] resident scans: heap top 511 %u, 255 %u\n", res_511, res_255);
+                if (10ull * res_255 >= 11ull * res_511) {
+                    f = h;
+                    caps.f_hl = h.hl;
+                    caps.f_gstride = h.gstride;
                 }
             }
         }

@@ -92,17 +92,7 @@ __device__ __forceinline__ uint32_t gload32(const uint32_t* p) { return *(const 
 __device__ __forceinline__ void gstore32(uint32_t* p, uint32_t v) { *(glb_u32*)p = v; }
 __device__ __forceinline__ uint64_t gload64u(const uint64_t* p) { return *(const glb_u64*)p; }
 __device__ __forceinline__ uint32_t gload16(const uint16_t* p) { return (uint32_t)*(const glb_u16*)p; }
-// VS_TAB_NT (measurement builds only; 0 as shipped): bit 0 = the 16-bit table's stores, bit 1 = its bucket loads carry the non-temporal hint
-#ifndef VS_TAB_NT
-#define VS_TAB_NT 0
-#endif
-__device__ __forceinline__ void gstore16(uint16_t* p, uint32_t v) {
-#if VS_TAB_NT & 1
-    __builtin_nontemporal_store((uint16_t)v, (glb_u16*)p);
-#else
-    *(glb_u16*)p = (uint16_t)v;
-#endif
-}
+__device__ __forceinline__ void gstore16(uint16_t* p, uint32_t v) { *(glb_u16*)p = (uint16_t)v; }
 __device__ __forceinline__ uint32_t lload32(const uint32_t* p) { return *(const lds_u32*)p; }
 __device__ __forceinline__ void lstore32(uint32_t* p, uint32_t v) { *(lds_u32*)p = v; }
 __device__ __forceinline__ uint32_t readlane_u32(uint32_t v, uint32_t l) {
@@ -1150,13 +1140,7 @@ __device__ __forceinline__ void fast_scan(const FastArgs& a, const uint32_t q, c
         const uint32_t rot = ((occ | (occ << 8)) >> (x & 7u)) & 0xFFu;
         return (uint32_t)__builtin_ctz(~rot);
     };
-    auto b16_load = [&](uint32_t x) -> uint4 {
-        if (VS_TAB_NT & 2) {
-            const ulonglong2 v = load_stream16(reinterpret_cast<const uint64_t*>(ghash + ((size_t)(x >> qk_v) << 2)));
-            return make_uint4((uint32_t)v.x, (uint32_t)(v.x >> 32), (uint32_t)v.y, (uint32_t)(v.y >> 32));
-        }
-        return *reinterpret_cast<const uint4*>(ghash + ((size_t)(x >> qk_v) << 2));
-    };
+    auto b16_load = [&](uint32_t x) -> uint4 { return *reinterpret_cast<const uint4*>(ghash + ((size_t)(x >> qk_v) << 2)); };
     uint32_t n_ovf = 0;
     auto ovf_insert = [&](uint32_t nid, bool act, uint32_t& slot_out) -> bool {  // (as slot_insert, on the overflow table)
         uint32_t* const ot = ghash + (s.gcap >> 1);

@@ -24,7 +24,9 @@ VARIANTS = [{"VS_F_MINW": "5"}, {"VS_F_MINW": "5", "VS_F_VIRGIN": "1"}, {"VS_F_V
             # 16-bit entries in buckets of eight + overflow table (VS_F_VIRGIN=3): fitted, tight (full buckets, overflow inserts and
             # lookups), tight near the load limit (second attempts)
             {"VS_F_VIRGIN": "3", "VS_F_MINW": "7"}, {"VS_F_VIRGIN": "3", "VS_F_MINW": "7", "VS_F_GCAP": "2048"},  # ... the lean 7-wave layout
-            {"VS_F_VIRGIN": "3"}, {"VS_F_VIRGIN": "3", "VS_F_GCAP": "2048"}, {"VS_F_VIRGIN": "3", "VS_F_GCAP": "1024", "VS_F_GLOAD_PCT": "90"}]
+            {"VS_F_VIRGIN": "3"}, {"VS_F_VIRGIN": "3", "VS_F_GCAP": "2048"}, {"VS_F_VIRGIN": "3", "VS_F_GCAP": "1024", "VS_F_GLOAD_PCT": "90"},
+            # ... as long lists run them since round 6 (taken although they cost resident scans, heap top 255)
+            {"VS_F_VIRGIN": "3", "VS_F_SLOTMAP_FORCE": "1", "VS_F_HL": "255"}]
 KNOBS = sorted({k for v in VARIANTS for k in v})
 COUNTERS = ("visited_nodes", "candidate_nodes", "quantized_distance_comparisons", "node_reads", "next_calls")
 

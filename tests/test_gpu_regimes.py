@@ -37,6 +37,10 @@ REGIMES = {
     "tableless_q16_tight": {"VS_F_LDS_MAX_INS": "0", "VS_F_VIRGIN": "3", "VS_F_GCAP": "4096"},
     "tableless_q16_tighter": {"VS_F_LDS_MAX_INS": "0", "VS_F_VIRGIN": "3", "VS_F_GCAP": "2048", "VS_F_GLOAD_PCT": "90"},
     "tableless_q16_one_wg_per_scan": {"VS_F_LDS_MAX_INS": "0", "VS_F_VIRGIN": "3", "VS_F_PERSIST": "0"},
+    # ... as the long lists run them since round 6: LDS-ring visited list, taken even where they cost resident scans, heap top 255 / 63
+    "tableless_q16_ring_forced": {"VS_F_LDS_MAX_INS": "0", "VS_F_VIRGIN": "3", "VS_F_VR": "0", "VS_F_SLOTMAP_FORCE": "1"},
+    "tableless_q16_ring_heap_top_255": {"VS_F_LDS_MAX_INS": "0", "VS_F_VIRGIN": "3", "VS_F_VR": "0", "VS_F_HL": "255"},
+    "tableless_q16_ring_heap_spill": {"VS_F_LDS_MAX_INS": "0", "VS_F_VIRGIN": "3", "VS_F_VR": "0", "VS_F_HL": "63", "VS_F_SLOTMAP_FORCE": "1"},
     # ... at 7 waves per SIMD with the lean LDS layout (survivor distances merged into the slot words, visited ring in steps of 16)
     "tableless_q16_seven_waves": {"VS_F_LDS_MAX_INS": "0", "VS_F_VIRGIN": "3", "VS_F_MINW": "7"},
     "tableless_q16_seven_waves_tight": {"VS_F_LDS_MAX_INS": "0", "VS_F_VIRGIN": "3", "VS_F_MINW": "7", "VS_F_GCAP": "4096"},

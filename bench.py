@@ -90,6 +90,20 @@ def kernel_source_hash():
     return h.hexdigest()[:12]
 
 
+def library_info(path, rebuilt):
+    """which build of libvsgpu.so this process ran: its hash and age, the hash of the kernel sources beside it, and — with --rebuild —
+    the compile that produced it on this box"""
+    import hashlib
+    try:
+        st = os.stat(path)
+        digest = hashlib.sha256(open(path, "rb").read()).hexdigest()[:12]
+        return {"path": os.path.relpath(path, ROOT), "sha256_12": digest, "bytes": st.st_size,
+                "built_utc": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime(st.st_mtime)),
+                "kernel_source_hash": kernel_source_hash(), "rebuilt_on_this_box": rebuilt}
+    except OSError as e:
+        return {"path": path, "error": repr(e)}
+
+
 def usable_cores():
     """CPUs this process can really use: the affinity mask, capped by the cgroup CPU quota (a container on a 256-thread host
     is often limited to a few of them; os.cpu_count() reports the host)."""
@@ -302,7 +316,21 @@ def main():
     ap.add_argument("--tune-reps", type=int, default=3, help="timed steps per variant (after one warm-up step each)")
     ap.add_argument("--probe-n", type=int, default=100_000, help="nodes of the probe child's index")
     ap.add_argument("--probe-timeout", type=float, default=240.0)
+    ap.add_argument("--rebuild", action="store_true",
+                    help="compile libvsgpu.so from its sources on THIS box first (make -B: every translation unit through hipcc "
+                         "--offload-arch=gfx950), before anything is loaded; the line's `library` object says how long it took and "
+                         "with which hipcc.  Off by default: the library travels prebuilt and the full build takes minutes of host time")
     args = ap.parse_args()
+
+    rebuilt = None
+    if args.rebuild and int(os.environ.get("RANK", "0")) == 0 and not EMU:
+        import subprocess
+        t0 = time.time()
+        csrc = os.path.join(ROOT, "pgvectorscale_amd", "csrc")
+        subprocess.check_call(["make", "-C", csrc, "-B", "-s", f"-j{max(2, min(usable_cores(), 16))}"])
+        ver = subprocess.run(["/opt/rocm/bin/hipcc", "--version"], capture_output=True, text=True).stdout.splitlines()
+        rebuilt = {"seconds": round(time.time() - t0, 1), "hipcc": next((ln.strip() for ln in ver if "HIP version" in ln), None),
+                   "command": "make -B (every *.hip through hipcc --offload-arch=gfx950)"}
 
     import numpy as np
     import torch
@@ -1104,6 +1132,7 @@ def main():
         "autotune": tune,
         "work_per_query": {kk: round(vv / max(tot.get("queries", 1), 1), 2) for kk, vv in tot.items() if kk != "queries"},
         "setup_s": setup,
+        "library": library_info(_lib.LIB_PATH, rebuilt),
         "default_gucs": default_gucs,
         "cursor_pool": cursor_pool,
         "latency": latency,

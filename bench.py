@@ -278,6 +278,8 @@ def main():
                          "'auto' (default): $TMPDIR/vs_graph_cache_<hash of the kernel sources> for n >= 10M when the "
                          "disk has room; 'none': always rebuild")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--parity-seconds", type=float, default=45.0,
+                    help="the oracle re-runs a WHOLE step for the row-identity check when that takes at most this long at its measured rate")
     ap.add_argument("--heldout-queries", type=int, default=8192,
                     help="queries of the LAST TIMED batch whose exact top-k is computed (outside the timed region) so that the recall "
                          "of the timed results themselves is reported (recall_heldout); when it is below the target the rescore window "
@@ -1192,8 +1194,11 @@ def main():
                     best = (rows / dt_, tc, rows, r_)
             cpu_qps, cpu_threads, sample, (o_ids, o_dist, o_st) = best
             cpu1 = min(cpu1, 1.0 / max(sweep[0]["qps"], 1e-9))  # (the first probe runs on cold caches: the sweep's one-thread point counts too)
-            # the final sample for the parity check: at least 2048 rows (or the step), at the best thread count
+            # the final sample for the parity check, at the best thread count: the WHOLE step when the oracle gets through it within
+            # --parity-seconds at the rate just measured (50M x 768: 262 144 scans in about 20 s on 16 cores), else at least 2048 rows
             sample = int(min(nq, max(sample, 2048)))
+            if nq / max(cpu_qps, 1e-9) <= args.parity_seconds:
+                sample = nq
             cpu_t, (o_ids, o_dist, o_st) = cpu_run(sample, cpu_threads)
             cpu_qps = max(cpu_qps, sample / cpu_t)
             # and the same sample through the GPU path: identical rows expected
@@ -1215,6 +1220,7 @@ def main():
                 "parallel_efficiency": round(cpu_qps * cpu1 / cpu_threads, 3),  # value / (threads x single-thread rate)
                 "consistent": bool(cpu_qps <= cpu_threads / cpu1 * 1.1),
                 "micro_ns_per_call": O.micro_bench(),  # the reference's criterion bench shapes (benches/distance.rs), one thread
+                "parity_rows": sample, "parity_covers_the_whole_step": bool(sample == nq),
                 "gpu_rows_identical": bool((g_ids == o_ids).all()),
                 "gpu_dist_bit_identical_frac": float((g_dist.view(np.uint32) == o_dist.view(np.uint32)).mean()),
             }

@@ -31,6 +31,7 @@ def test_bench_dry_run_on_the_interpreter():
     assert j["cpu_baseline"]["gpu_rows_identical"] is True and j["cpu_baseline"]["gpu_dist_bit_identical_frac"] == 1.0
     # (16 tuning queries: the 0.99 target is a matter of luck here; what is checked is that all three recalls are reported)
     assert isinstance(j["recall_target_met"], bool) and 0.9 < j["recall_heldout"] <= 1.0 and 0.9 < j["recall_validate"] <= 1.0
+    assert j["cpu_baseline"]["parity_covers_the_whole_step"] is True and j["cpu_baseline"]["parity_rows"] == 128
     assert j["library"]["sha256_12"] and j["library"]["kernel_source_hash"] and j["library"]["rebuilt_on_this_box"] is None
     cb = j["cpu_baseline"]
     # (a 128-query sample takes milliseconds here: the consistency flag is only checked for being reported)

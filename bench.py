@@ -329,7 +329,8 @@ def main():
         import subprocess
         t0 = time.time()
         csrc = os.path.join(ROOT, "pgvectorscale_amd", "csrc")
-        subprocess.check_call(["make", "-C", csrc, "-B", "-s", f"-j{max(2, min(usable_cores(), 16))}"])
+        jobs = max(2, min(usable_cores()["usable"], 16))
+        subprocess.check_call(["make", "-C", csrc, "-B", "-s", f"-j{jobs}"])
         ver = subprocess.run(["/opt/rocm/bin/hipcc", "--version"], capture_output=True, text=True).stdout.splitlines()
         rebuilt = {"seconds": round(time.time() - t0, 1), "hipcc": next((ln.strip() for ln in ver if "HIP version" in ln), None),
                    "command": "make -B (every *.hip through hipcc --offload-arch=gfx950)"}

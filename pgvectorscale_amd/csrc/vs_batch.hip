@@ -386,6 +386,26 @@ static int run_search_chunk(vs_index* ix, const BatchPlan& bp, const float* d_ra
                 }
             }
         }
+        // ... and likewise the visited ring: room for 1.4 instead of 2 times the list's expected length (1 KB less at search_list_size 100)
+        // where that buys at least a tenth more resident scans.  The scans that outgrow the smaller ring are finished by the second
+        // attempt below, a few milliseconds on the critical path — worth it for label-filtered scans (s21 / s22, 10M x 1536, 100 / 90: 98 of
+        // 262 144 scans, 3.5 ms, for a first attempt of 101.5 instead of 110.6 ms: 17 -> 19 scans per CU), a wash for unfiltered ones at
+        // 100 / 50 (83.5 + 1.8 against 86.2 ms; 22 -> 24 per CU is under the threshold).  An explicit VS_F_VCAP stands.
+        if (caps.f_lh == 0 && !f.vr && f.minw != 7 && !env_u32("VS_PHASE", 0)) {
+            const char* const vc_opt = vs_opt_get("VS_F_VCAP");
+            const uint32_t want_v = (uint32_t)std::min<uint64_t>((uint64_t)bp.L + bp.L / 2 + 32, 1u << 20);
+            const uint32_t lean_v = round_up_u32(std::max<uint32_t>(want_v + 2 * want_v / 5, 64), 64);
+            if (!(vc_opt && *vc_opt) && lean_v < f.vcap) {
+                FastLaunch v = f;
+                v.vcap = lean_v;
+                uint32_t res_wide = 0, res_lean = 0;
+                VS_TRY(fast_resident_scans(ix, f, &res_wide));
+                VS_TRY(fast_resident_scans(ix, v, &res_lean));
+                if (env_u32("VS_WS_DEBUG", 0))
+                    fprintf(stderr, "[VS_WS_DEBUG] resident scans: visited ring %u entries %u, %u entries %u\n", f.vcap, res_wide, v.vcap, res_lean);
+                if (10ull * res_lean >= 11ull * res_wide) f = v;
+            }
+        }
         // (VS_F_MINW=7 with the 16-bit tables: 28 scans per CU when a scan's LDS fits 5 632 B — the visited ring is then sized in steps
         // of 16 entries instead of 64)
         if (f.minw == 7 && f.vslot == 2 && !f.vr && !env_u32("VS_F_VCAP", 0)) {

@@ -29,7 +29,7 @@ for step in "$@"; do
     fuzzv) timeout $(( ${arg:-40} * 8 + 120 )) python scripts/fuzz_variants.py --gpu --cases ${arg:-40} --seed $RANDOM 2>&1 | tail -4 | tee $O/fuzz_variants_gpu.txt ;;
     final) # the evidence set of the frozen tree: the driver's bench command (builds, writes the graph cache), the same under rocprofv3
            # --kernel-trace --stats, two --pmc passes at the bench's operating point, the bench once more WITH roofline.traffic
-           timeout 2400 python bench.py --steps 20 --warmup 5 --graph-cache /tmp/g > $O/bench_50m.json 2> $O/bench_50m.err; tail -3 $O/bench_50m.err
+           timeout 2400 python bench.py --steps 20 --warmup 5 --graph-cache /tmp/g $FINAL_BENCH_ARGS > $O/bench_50m.json 2> $O/bench_50m.err; tail -3 $O/bench_50m.err
            LS=$(python - <<PY
 import json
 j = json.loads(open("$O/bench_50m.json").read().strip().splitlines()[-1])

@@ -1030,14 +1030,21 @@ def main():
                 shm_name = f"/vs_bench_cp_{os.getpid()}_{mode}"
                 srv = P.ShmServer(ix, shm_name, nslots=nb, kmax=chunk, max_batch=256, max_wait_us=100, **kw)
                 try:
-                    wall1, out1 = stream_many(shm_name, _lib.LIB_PATH, [qh_c[0]], 100, 50, rows_each, chunk, timeout=240)
-                    walln, outn = stream_many(shm_name, _lib.LIB_PATH, [qh_c[t] for t in range(nb)], 100, 50, rows_each, chunk, timeout=240)
+                    # (three passes each, the fastest counts: one pass is 32 processes woken 20 times each on 16 host cores, and a single
+                    # late wake-up costs a whole dispatcher round — s29 measured 18.7 ms where four other sessions measured 11.0-11.1)
+                    ones = [stream_many(shm_name, _lib.LIB_PATH, [qh_c[0]], 100, 50, rows_each, chunk, timeout=240) for _ in range(3)]
+                    alls = [stream_many(shm_name, _lib.LIB_PATH, [qh_c[t] for t in range(nb)], 100, 50, rows_each, chunk, timeout=240)
+                            for _ in range(3)]
                 finally:
                     srv.close()
+                wall1, out1 = min(ones, key=lambda r_: r_[0])
+                walln, outn = min(alls, key=lambda r_: r_[0])
                 if ref_rows is None:
                     ref_rows = outn
                 cursor_pool[mode] = {"one_scan_ms": round(wall1, 2), "all_scans_ms": round(walln, 2), "ratio": round(walln / max(wall1, 1e-9), 2),
-                                     "rows_identical_to_cursor_per_scan": bool(outn == ref_rows and out1[0] == ref_rows[0])}
+                                     "passes_ms": {"one_scan": [round(r_[0], 2) for r_ in ones], "all_scans": [round(r_[0], 2) for r_ in alls]},
+                                     "rows_identical_to_cursor_per_scan": bool(all(r_[1] == ref_rows for r_ in alls) and
+                                                                               all(r_[1][0] == ref_rows[0] for r_ in ones))}
             log(f"cursor continuations of {nb} backends: {cursor_pool['cursor_per_scan']['all_scans_ms']} ms with a cursor per scan, "
                 f"{cursor_pool['scan_pools']['all_scans_ms']} ms out of scan pools (one scan: {cursor_pool['scan_pools']['one_scan_ms']} ms)")
         except Exception as e:  # noqa: BLE001 — an extra never costs the headline line
